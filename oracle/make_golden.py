@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures under tests/golden/ from the reference's saved
+MATLAB workspaces (run ONCE in the build container where /root/reference exists).
+
+TEST INFRASTRUCTURE ONLY.  The fixtures are *data* (inputs and recorded MATLAB/quadprog
+outputs of the hot path), derived from GPL-3 data files of carlosluis/multiagent_planning:
+
+  data/failure_rate/failure_rate2.mat   written by test/failure_rate.m:205 (`save`), solver
+                                         solveSoftDMPCbound (test/failure_rate.m:110), N=200
+  data/comp_kctr/comp_kctr_3.mat        written by test/comp_kctr.m, last run = solveSoftDMPCbound2
+                                         (test/comp_kctr.m:248), N=100
+
+What is usable in each workspace: the trial aborted at MPC step k=14
+while solving agent n (1-based), so
+  * pk/vk/ak(:,1:13,:)  complete, un-rescaled closed-loop history of all N agents
+  * l                   prediction table after MPC step 13 (input of step 14)
+  * new_l(:,:,1:n-1)    outputs (3xK predicted positions) of step 14 for agents 1..n-1
+  * pk/vk/ak(:,14,1:n-1) first-column outputs of step 14
+Layout conversion: MATLAB l(3,K,N) column-major == row-major [N][3K] with the stacked
+[x1 y1 z1 x2 ...] order of the QP vector, so `l.transpose(2,1,0).reshape(N,45)`.
+"""
+import os
+import sys
+import numpy as np
+import scipy.io as sio
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+
+def table(l):  # (3,K,N) -> (N,3K) row-major, [x1 y1 z1 x2 ...]
+    return np.ascontiguousarray(l.transpose(2, 1, 0).reshape(l.shape[2], -1))
+
+
+def hist(x):  # (3,T,N) -> (N,T,3)
+    return np.ascontiguousarray(x.transpose(2, 1, 0))
+
+
+def convert(path, name, variant):
+    m = sio.loadmat(os.path.join(REF, path))
+    N = int(m["N"][0, 0])
+    n_fail = int(m["n"][0, 0])  # 1-based agent at which the trial aborted
+    k = int(m["k"][0, 0])
+    assert k == 14
+    out = dict(
+        variant=variant,
+        N=N,
+        n_done=n_fail - 1,  # agents [0, n_done) have recorded step-14 outputs
+        k_step=k,
+        h=float(m["h"][0, 0]),
+        k_hor=int(m["k_hor"][0, 0]),
+        rmin=float(m["rmin"][0, 0]),
+        c=float(m["c"][0, 0]),
+        alim=float(m["alim"][0, 0]),
+        Q=float(m["Q"][0, 0]),
+        S=float(m["S"][0, 0]),
+        term=float(m["term"][0, 0]),
+        order=int(m["order"][0, 0]),
+        pmin=m["pmin"].astype(np.float64).ravel(),
+        pmax=m["pmax"].astype(np.float64).ravel(),
+        po=np.ascontiguousarray(m["po"].reshape(3, N).T),
+        pf=np.ascontiguousarray(m["pf"].reshape(3, N).T),
+        pk=hist(m["pk"]),
+        vk=hist(m["vk"]),
+        ak=hist(m["ak"]),
+        l=table(m["l"]),
+        new_l=table(m["new_l"]),
+        # model-matrix goldens (a1-a3)
+        A=m["A"],
+        A_initp=m["A_initp"],
+        Delta=m["Delta"],
+        A_p=m["A_p_dmpc"],
+        A_v=m["A_v_dmpc"],
+    )
+    # sanity: MATLAB reshape(po,1,3,N) keeps column n = agent n
+    assert np.allclose(out["pk"][:, 0, :], out["po"])
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print("wrote", name, "N=%d n_done=%d" % (N, n_fail - 1))
+
+
+if __name__ == "__main__":
+    if not os.path.isdir(REF):
+        sys.exit("reference not present; fixtures are already committed")
+    convert("data/failure_rate/failure_rate2.mat", "failure_rate2_bound", "bound")
+    convert("data/comp_kctr/comp_kctr_3.mat", "comp_kctr_3_bound2", "bound2")
