@@ -15,6 +15,7 @@
 #include <string.h>
 
 #define MAXK 32
+#define GIVENS_TINY 1e-200
 
 /* ------------------------------------------------------------------------------------------ */
 /* a1-a3 model matrices                                                                       */
@@ -120,7 +121,7 @@ static void gi_drop(gi_t *g, int l)
     g->q--;
     for (int j = l; j < g->q; ++j) {
         double a = g->R[j + (size_t)n * j], b = g->R[j + 1 + (size_t)n * j];
-        if (b == 0.0) continue;
+        if (fabs(b) < GIVENS_TINY) { g->R[j + 1 + (size_t)n * j] = 0.0; continue; } /* denormal guard */
         double rr = hypot(a, b), c = a / rr, s = b / rr;
         g->R[j + (size_t)n * j] = rr;
         g->R[j + 1 + (size_t)n * j] = 0.0;
@@ -144,7 +145,7 @@ static void gi_add(gi_t *g, int p, double up)
     double *dv = g->dv;
     for (int j = n - 1; j > q; --j) {
         double a = dv[j - 1], b = dv[j];
-        if (b == 0.0) continue;
+        if (fabs(b) < GIVENS_TINY) { dv[j] = 0.0; continue; } /* denormal guard: c,s from denormals are garbage */
         double rr = hypot(a, b), c = a / rr, s = b / rr;
         dv[j - 1] = rr;
         dv[j] = 0.0;

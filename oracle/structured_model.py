@@ -1,0 +1,381 @@
+"""Numpy model of the DEVICE algorithm (design validation) -- TEST INFRASTRUCTURE ONLY.
+
+This is a slow, scalar Python model of what multiagent_planning_amd/csrc/dmpc_kernels.hip does per
+agent: structured (never-dense) Schur-complement Goldfarb-Idnani with an explicitly maintained
+inverse of the active-set Schur matrix and lazily instantiated slack constraints.  It exists so the
+algorithm could be validated against the literal dense oracle on the CPU before the HIP kernel was
+written; tests use it to cross-check design invariants.  It is never imported by the product.
+
+Notation:
+  L      15x15 lower-triangular per-axis position matrix (Lambda = L (x) I3)
+  Hinv1  inverse of the per-axis Hessian H1 = 2(q L_K' L_K + s D1'D1 + I)
+  M1     Hinv1 L'          P1 = L Hinv1 L'
+  every constraint c:  n_c = alpha_c (a-space, <=1 block) + Lambda' y_c (position space, <=1 block)
+                       + sigma_c e_{slack(si_c)}
+"""
+import numpy as np
+
+BOXHI, BOXLO, POSHI, POSLO, COLL, SLKU, SLKL = range(7)
+DEBUG = False
+
+
+class Tables:
+    def __init__(self, h, K, q, s):
+        L = np.zeros((K, K))
+        for i in range(K):
+            for j in range(i + 1):
+                L[i, j] = h * h / 2 + (i - j) * h * h
+        D = np.eye(K) - np.eye(K, k=-1)
+        H1 = 2.0 * (q * np.outer(L[K - 1], L[K - 1]) + s * D.T @ D + np.eye(K))
+        self.L = L
+        self.Hinv1 = np.linalg.inv(H1)
+        self.Hinv1 = 0.5 * (self.Hinv1 + self.Hinv1.T)
+        self.M1 = self.Hinv1 @ L.T
+        self.P1 = L @ self.Hinv1 @ L.T
+        self.q, self.s = q, s
+
+
+class Cons:
+    __slots__ = ("typ", "idx", "ka", "av", "ky", "yv", "si", "ss", "d")
+
+    def __init__(self, typ, idx, ka=0, av=(0, 0, 0), ky=0, yv=(0, 0, 0), si=-1, ss=0.0, d=0.0):
+        self.typ, self.idx = typ, idx
+        self.ka, self.av = ka, np.asarray(av, float)
+        self.ky, self.yv = ky, np.asarray(yv, float)
+        self.si, self.ss, self.d = si, ss, d
+
+
+def sdot(T, c1, c2):
+    v = T.Hinv1[c1.ka, c2.ka] * (c1.av @ c2.av) + T.M1[c1.ka, c2.ky] * (c1.av @ c2.yv) \
+        + T.M1[c2.ka, c1.ky] * (c2.av @ c1.yv) + T.P1[c1.ky, c2.ky] * (c1.yv @ c2.yv)
+    if c1.si >= 0 and c1.si == c2.si:
+        v += 0.5 * c1.ss * c2.ss
+    return v
+
+
+def solve_structured(Tbl, K, h, po, vo, ao, pf, alim, pmin, pmax, rows, stats=None, tol=1e-10):
+    """rows: list of dict(xi(3), kc(0-based), b, sd, st, slb). Returns (rc, a(3K), eps(nr)).
+    rc: 0 ok, 1 infeasible."""
+    n3 = 3 * K
+    nr = len(rows)
+    q, s = Tbl.q, Tbl.s
+    LK = Tbl.L[K - 1]
+    e3 = np.eye(3)
+    # f and unconstrained minimiser (per axis)
+    f = np.zeros((K, 3))
+    for ax in range(3):
+        f[:, ax] = -2.0 * q * LK * (pf[ax] - (po[ax] + K * h * vo[ax]))
+        f[0, ax] += -2.0 * s * ao[ax]
+    a_unc = -Tbl.Hinv1 @ f  # (K,3)
+    whi = np.array([[pmax[ax] - (po[ax] + (k + 1) * h * vo[ax]) for ax in range(3)] for k in range(K)])
+    wlo = np.array([[pmin[ax] - (po[ax] + (k + 1) * h * vo[ax]) for ax in range(3)] for k in range(K)])
+
+    def mk(typ, idx):
+        if typ == BOXHI:
+            return Cons(typ, idx, ka=idx // 3, av=e3[idx % 3], d=alim)
+        if typ == BOXLO:
+            return Cons(typ, idx, ka=idx // 3, av=-e3[idx % 3], d=alim)
+        if typ == POSHI:
+            return Cons(typ, idx, ky=idx // 3, yv=e3[idx % 3], d=whi[idx // 3, idx % 3])
+        if typ == POSLO:
+            return Cons(typ, idx, ky=idx // 3, yv=-e3[idx % 3], d=-wlo[idx // 3, idx % 3])
+        r = rows[idx]
+        if typ == COLL:
+            return Cons(typ, idx, ky=r["kc"], yv=-np.asarray(r["xi"]), si=idx if r["sd"] > 0 else -1, ss=r["sd"], d=r["b"])
+        if typ == SLKU:
+            return Cons(typ, idx, si=idx, ss=1.0, d=0.0)
+        return Cons(typ, idx, si=idx, ss=-1.0, d=-r["slb"])
+
+    W = []        # active constraints
+    lam = []      # multipliers
+    T = np.zeros((0, 0))   # upper-triangular inverse Cholesky factor: T T' = (N' H^-1 N)^-1 over W
+    live = [False] * nr
+    inW = {}
+    Tm = Tbl
+
+    def primal():
+        U = np.zeros((K, 3))
+        Y = np.zeros((K, 3))
+        es = np.zeros(nr)
+        for c, lm in zip(W, lam):
+            U[c.ka] += lm * c.av
+            Y[c.ky] += lm * c.yv
+            if c.si >= 0:
+                es[c.si] += lm * c.ss
+        a = a_unc - Tm.Hinv1 @ U - Tm.M1 @ Y
+        w = Tm.L @ a
+        eps = np.array([(-0.5 * (rows[i]["st"] + es[i])) if live[i] else 0.0 for i in range(nr)])
+        return a, w, eps
+
+    def value(c, a, w, eps):
+        v = c.av @ a[c.ka] + c.yv @ w[c.ky] - c.d
+        if c.si >= 0 and live[c.si]:
+            v += c.ss * eps[c.si]
+        return v
+
+    def append_slot(c, lm, col):
+        nonlocal T
+        k = len(W)
+        T2 = np.zeros((k + 1, k + 1))
+        T2[:k, :k] = T
+        T2[:, k] = col
+        T = T2
+        W.append(c)
+        lam.append(lm)
+        inW[(c.typ, c.idx)] = True
+
+    def remove_slot(l):
+        """Delete constraint l: Givens rotations on adjacent COLUMNS of T that zero row l
+        left-to-right, then delete row l and the last column (stable inverse-factor downdate)."""
+        nonlocal T
+        k = len(W)
+        for j in range(l, k - 1):
+            a_, b_ = T[l, j], T[l, j + 1]
+            rr = np.hypot(a_, b_)
+            if rr == 0.0:
+                continue
+            cc, ss_ = b_ / rr, a_ / rr
+            cj, cj1 = T[:, j].copy(), T[:, j + 1].copy()
+            T[:, j] = cc * cj - ss_ * cj1
+            T[:, j + 1] = ss_ * cj + cc * cj1
+        keep = [i for i in range(k) if i != l]
+        T = T[np.ix_(keep, list(range(k - 1)))]
+        c = W.pop(l)
+        lam.pop(l)
+        del inW[(c.typ, c.idx)]
+
+    def cleanup(protect=-1):
+        # de-instantiate slack of rows whose collision row left W while its eps<=0 pin is active
+        # (never the row whose collision constraint is currently being added)
+        for i in range(nr):
+            if i != protect and live[i] and (COLL, i) not in inW and (SLKL, i) not in inW and (SLKU, i) in inW:
+                l = next(k for k, c in enumerate(W) if c.typ == SLKU and c.idx == i)
+                remove_slot(l)
+                live[i] = False
+
+    iters = 0
+    maxq = 0
+    nrefine = 0
+
+    def check(tag):
+        if not DEBUG or not W:
+            return
+        S = np.array([[sdot(Tm, c1, c2) for c2 in W] for c1 in W])
+        err = np.abs(T @ T.T @ S - np.eye(len(W))).max()
+        if err > 1e-6:
+            print("  [model] factor inconsistent after", tag, "err", err, "cond", np.linalg.cond(S), [(c.typ, c.idx) for c in W])
+
+    while True:
+        check("loop")
+        a, w, eps = primal()
+        # refinement of the active set residual (keeps factor round-off out of x)
+        if W:
+            for _ in range(3):
+                rho = np.array([value(c, a, w, eps) for c in W])
+                if np.abs(rho).max() <= 1e-13:
+                    break
+                lam_new = np.array(lam) + T @ (T.T @ rho)
+                for k in range(len(lam)):
+                    lam[k] = lam_new[k]
+                a, w, eps = primal()
+                nrefine += 1
+        # most violated candidate
+        best, bestv = None, tol
+        for j in range(n3):
+            for typ in (BOXHI, BOXLO, POSHI, POSLO):
+                if (typ, j) in inW:
+                    continue
+                c = mk(typ, j)
+                v = value(c, a, w, eps)
+                if v > bestv:
+                    best, bestv = c, v
+        for i in range(nr):
+            cands = [COLL]
+            if live[i]:
+                cands.append(SLKU)
+                if np.isfinite(rows[i]["slb"]):
+                    cands.append(SLKL)
+            for typ in cands:
+                if (typ, i) in inW:
+                    continue
+                c = mk(typ, i)
+                v = value(c, a, w, eps)
+                if v > bestv:
+                    best, bestv = c, v
+        if best is None:
+            break
+        p = best
+        if p.typ == COLL and p.si >= 0 and not live[p.idx]:
+            k = len(W)
+            col = np.zeros(k + 1)
+            col[k] = np.sqrt(2.0)     # S(u,u) = 1/2, decoupled from everything in W
+            append_slot(mk(SLKU, p.idx), -rows[p.idx]["st"], col)
+            live[p.idx] = True
+        vp = bestv
+        lam_p = 0.0
+        spp = sdot(Tm, p, p)
+        while True:
+            iters += 1
+            if iters > 2000:
+                return 2, None, None
+            k = len(W)
+            sv = np.array([sdot(Tm, c, p) for c in W]) if k else np.zeros(0)
+            dv = T.T @ sv if k else np.zeros(0)
+            r = T @ dv if k else np.zeros(0)
+            # step direction z = H^-1 (n_p - N_W r) and delta = z'Hz from the explicit residual
+            # (squares the round-off of r instead of cancelling spp - |d|^2: robust dependence test)
+            Ur = np.zeros((K, 3)); Yr = np.zeros((K, 3)); Er = np.zeros(nr)
+            Ur[p.ka] += p.av; Yr[p.ky] += p.yv
+            if p.si >= 0:
+                Er[p.si] += p.ss
+            for c, rj in zip(W, r):
+                Ur[c.ka] -= rj * c.av
+                Yr[c.ky] -= rj * c.yv
+                if c.si >= 0:
+                    Er[c.si] -= rj * c.ss
+            za = Tm.Hinv1 @ Ur + Tm.M1 @ Yr
+            zw = Tm.L @ za
+            delta = (Ur * za).sum() + (Yr * zw).sum() + 0.5 * (Er * Er).sum()
+            dependent = not (delta > 1e-13 * spp)
+            t2 = np.inf if dependent else vp / delta
+            t1, l = np.inf, -1
+            for j in range(k):
+                if r[j] > 0:
+                    t = lam[j] / r[j]
+                    if t < t1:
+                        t1, l = t, j
+            t = min(t1, t2)
+            if not np.isfinite(t):
+                if stats is not None:
+                    stats.append(dict(iters=iters, maxq=maxq, nref=nrefine, infeasible=True))
+                return 1, None, None
+            for j in range(k):
+                lam[j] -= t * r[j]
+            lam_p += t
+            if not dependent:
+                vp -= t * delta
+            if t2 <= t1:  # full step: add p
+                rho_ = np.sqrt(delta)
+                append_slot(p, lam_p, np.r_[-r / rho_, 1.0 / rho_])
+                maxq = max(maxq, len(W))
+                check("add %s delta=%g spp=%g" % ((p.typ, p.idx), delta, spp))
+                cleanup()
+                break
+            # partial step: drop l
+            lam[l] = 0.0
+            dropped = (W[l].typ, W[l].idx)
+            remove_slot(l)
+            check("drop %s" % (dropped,))
+            cleanup(p.idx if p.typ == COLL else -1)
+    a, w, eps = primal()
+    if stats is not None:
+        stats.append(dict(iters=iters, maxq=maxq, nref=nrefine, infeasible=False, nact=len(W)))
+    return 0, a.reshape(-1), eps
+
+
+# ----------------------------------------------------------------------------------------------
+# scan + structured rows per variant (mirrors oracle/dmpc_oracle.c scan_and_rows, in row form)
+# ----------------------------------------------------------------------------------------------
+
+def scan_rows(variant, K, h, l, n, po, vo, rmin, c, term):
+    """Returns (status, viol_k, rows, rows_exist, violation)."""
+    N = l.shape[0]
+    own = l[n].reshape(K, 3)
+    E1 = np.array([1, 1, 1 / c])
+    E2 = np.array([1, 1, 1 / (c * c)])
+    x0 = np.r_[po, vo]
+
+    def row(j, ke, kc, sd_mode, st, slb):
+        p = own[ke]
+        pj = l[j].reshape(K, 3)[ke]
+        dist = np.linalg.norm(E1 * (p - pj))
+        xi = E2 * (p - pj)
+        a0x0 = po + (kc + 1) * h * vo
+        r = dist * (rmin - dist + (xi @ p) / dist) - xi @ a0x0
+        sd = dist if sd_mode == "dist" else (1.0 if sd_mode == "one" else 0.0)
+        stv = st / dist if sd_mode == "dist_over" else st
+        if sd_mode == "dist_over":
+            sd = dist
+        return dict(xi=xi, kc=kc, b=-r, sd=sd, st=stv, slb=slb, j=j)
+
+    others = [j for j in range(N) if j != n]
+    if variant == "hard":
+        rows = []
+        for k in range(K):
+            for j in others:
+                d = np.linalg.norm(E1 * (own[k] - l[j].reshape(K, 3)[k]))
+                if d < 1:
+                    rows.append(row(j, k, k, "none", 0.0, 0.0))
+        return 0, 0, rows, N > 1, False
+    soft_near = variant in ("bound", "bound2", "all3", "ondemand")
+    coll_check = variant in ("bound", "bound2", "all3", "repair")
+    skip_k1 = variant in ("bound2", "all3", "repair")
+    cfg = dict(bound=("dist", term, -0.05), bound2=("dist", term, -0.01), all3=("dist", term, -0.01),
+               ondemand=("none", 0.0, 0.0), ellip=("none", 0.0, 0.0), softall=("one", -1e5, -np.inf),
+               repair=("dist_over", term, -np.inf))[variant]
+    some_violation = False
+    for k in range(K):
+        d = np.array([np.linalg.norm(E1 * (own[k] - l[j].reshape(K, 3)[k])) for j in others])
+        if not (d < rmin).any():
+            continue
+        if variant == "all3":
+            some_violation = True
+        if coll_check and k == 0 and d.min() < rmin - 0.05:
+            return 4, 1, [], False, some_violation
+        if skip_k1 and k == 0:
+            continue
+        sel = [j for j, dj in zip(others, d) if (dj < 3 * rmin if soft_near else True)]
+        if variant == "all3":
+            ks = [k, k + 1] if k == 1 else ([k - 1, k] if k == K - 1 else [k - 1, k, k + 1])
+            rows = [row(j, kk, kk, *cfg) for kk in ks for j in sel]
+        else:
+            kc = k - 1 if variant == "bound2" else k
+            rows = [row(j, k, kc, *cfg) for j in sel]
+        return 0, k + 1, rows, True, True
+    return 0, 0, [], False, some_violation
+
+
+_TABLE_CACHE = {}
+
+
+def solve_agent_model(variant, K, h, rmin, c, alim, Q1, S1, term, pmin, pmax, l, n, po, vo, ao, pf, stats=None):
+    """Full per-agent step in the structured formulation. Returns dict(status, p, v, a, tries)."""
+    po, vo, ao, pf = (np.asarray(x, float) for x in (po, vo, ao, pf))
+    st, viol_k, rows, rows_exist, violation = scan_rows(variant, K, h, l, n, po, vo, rmin, c, term)
+    if st == 4:
+        return dict(status=4, viol_k=viol_k)
+    dn = np.linalg.norm(po - pf)
+    far = dn > 1 if variant == "ellip" else dn >= 1
+    if not rows_exist and far:
+        qs = (1000.0, 10.0)
+    elif not rows_exist and dn < 1:
+        qs = (10000.0, 10.0)
+    else:
+        qs = (Q1, 10.0 if variant == "all3" else S1)
+    key = (h, K) + qs
+    if key not in _TABLE_CACHE:
+        _TABLE_CACHE[key] = Tables(h, K, *qs)
+    T = _TABLE_CACHE[key]
+    ladder = variant in ("bound", "bound2", "all3")
+    tries = 0
+    while tries < 30:
+        rc, a, eps = solve_structured(T, K, h, po, vo, ao, pf, alim, pmin, pmax, rows, stats)
+        tries += 1
+        if rc == 0:
+            a3 = a.reshape(K, 3)
+            w = T.L @ a3
+            p = w + np.array([po + (k + 1) * h * vo for k in range(K)])
+            v = h * np.cumsum(a3, axis=0) + vo
+            status = 1
+            tolb = 50e-3
+            if variant not in ("ellip", "softall"):
+                if not ((p[0] < np.asarray(pmax) + tolb).all() and (p[0] > np.asarray(pmin) - tolb).all()):
+                    status |= 2
+            return dict(status=status, p=p.reshape(-1), v=v.reshape(-1), a=a, tries=tries, viol_k=viol_k, eps=eps)
+        if ladder and violation:
+            for r in rows:
+                r["slb"] *= 2
+                r["st"] *= 2
+            continue
+        break
+    return dict(status=8, tries=tries, viol_k=viol_k)
