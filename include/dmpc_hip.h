@@ -1,0 +1,167 @@
+/*
+ * dmpc_hip.h -- C ABI of libdmpc_hip.so: the MI355X (gfx950) implementation of the DMPC
+ * per-agent horizon-QP hot path of carlosluis/multiagent_planning.
+ *
+ * Every entry point names the reference interface it replaces (paths relative to the
+ * reference repository root).  Plain C, plain pointers and sizes: this is what a MEX gateway,
+ * a cgo/ctypes stub or the C++ DMPC class would bind.
+ *
+ * Conventions
+ *   - all real data is IEEE fp64 (MATLAB double / C++ double), K = k_hor = 15
+ *   - "table" l: the previous MPC step's predicted position horizons of all agents.
+ *     Host layout == MATLAB l(3,K,N) column-major == row-major [N][3K] with the stacked
+ *     [x1 y1 z1 x2 ...] order (dmpc/matlab/dmpc_soft_bound.m:131,146).
+ *   - S independent scenes ("trials", test/failure_rate.m:65) may be batched: arrays are
+ *     [S][N][...]; agents only see neighbours of their own scene.  S = 1 is the reference case.
+ *   - return value: 0 = ok, <0 = API/runtime error (text via dmpc_last_error); numerical
+ *     outcomes are reported per agent in status[] (DMPC_ST_* bits) and info[] (DMPC_I_*).
+ *   - entry points are synchronous unless noted; one HIP stream per context; a context may be
+ *     used from one host thread at a time, distinct contexts are independent
+ *     (dmpc/cpp/cluster_test.cpp:40 runs up to 10 solver threads).
+ */
+#ifndef DMPC_HIP_H
+#define DMPC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* solver variants == reference functions under dmpc/matlab/ */
+enum {
+    DMPC_VAR_BOUND = 0,    /* solveSoftDMPCbound.m:1        (primary; test/failure_rate.m:110)  */
+    DMPC_VAR_BOUND2 = 1,   /* solveSoftDMPCbound2.m:1       (test/comp_kctr.m:248)              */
+    DMPC_VAR_ALL3 = 2,     /* solveSoftDMPCall.m:1                                              */
+    DMPC_VAR_HARD = 3,     /* solveHardDMPC.m:1             (test/comp_hardsoft2.m)             */
+    DMPC_VAR_ONDEMAND = 4, /* solveHardDMPCOnDemand.m:1                                         */
+    DMPC_VAR_ELLIP = 5,    /* solveEllipDMPC.m:1                                                */
+    DMPC_VAR_SOFTALL = 6,  /* solveSoftDMPC.m:1             (test/success_test_softdmpc.m:90)   */
+    DMPC_VAR_REPAIR = 7    /* solveSoftDMPCrepair.m:1       (test/comp_repair.m:93)             */
+};
+
+/* per-agent status bits (the reference's feasible/success, outbound, coll flags) */
+enum {
+    DMPC_ST_SOLVED = 1,    /* p,v,a valid                                                        */
+    DMPC_ST_OUTBOUND = 2,  /* is_inbounds.m:2-5 failed for the first predicted position          */
+    DMPC_ST_COLL = 4,      /* already collided at horizon step 1 (solveSoftDMPCbound.m:25-31)    */
+    DMPC_ST_INFEAS = 8,    /* QP infeasible after the retry ladder (solveSoftDMPCbound.m:102-155) */
+    DMPC_ST_CAPACITY = 16, /* internal capacity exceeded (rows / active set): result NOT valid   */
+    DMPC_ST_ITERCAP = 32   /* iteration cap hit: result NOT valid                                */
+};
+
+/* info[] : 8 int32 per agent */
+enum {
+    DMPC_I_VIOLK = 0,   /* 1-based first violating horizon step handled (0 = none)              */
+    DMPC_I_NROWS = 1,   /* number of collision rows built (Nv)                                  */
+    DMPC_I_TRIES = 2,   /* QP attempts (retry ladder)                                           */
+    DMPC_I_CASE = 3,    /* cost case 0 far / 1 near / 2 collision (solveSoftDMPCbound.m:43-58)  */
+    DMPC_I_ITERS = 4,   /* active-set iterations (all tries)                                    */
+    DMPC_I_NSLACK = 5,  /* slack variables < 0 at the solution                                  */
+    DMPC_I_NACTIVE = 6, /* active constraints at the solution                                   */
+    DMPC_I_MAXQ = 7,    /* peak working-set size                                                */
+    DMPC_INFO_LEN = 8
+};
+
+/* mirrors the reference's constants block (dmpc/matlab/dmpc_soft_bound.m:7-78;
+ * dmpc/cpp/dmpc.h:50-63 `struct Params`) */
+typedef struct {
+    int32_t K;         /* horizon length k_hor; must be 15                                   */
+    int32_t variant;   /* DMPC_VAR_*                                                         */
+    int32_t order;     /* ellipsoid order; must be 2 (the only value the reference uses)     */
+    int32_t max_tries; /* <=0: reference default (30)                                        */
+    double h;          /* time step                                                          */
+    double rmin;       /* collision radius                                                   */
+    double c;          /* E = diag(1,1,c)                                                    */
+    double alim;       /* |a| limit                                                          */
+    double Q1, S1;     /* collision-case weights                                             */
+    double term;       /* linear slack penalty (negative)                                    */
+    double pmin[3], pmax[3];
+} dmpc_params;
+
+typedef struct dmpc_ctx dmpc_ctx;
+
+/* Create a solver context on HIP device `device` (>= 0).  Replaces the constants/precompute
+ * preamble of dmpc/matlab/dmpc_soft_bound.m:80-108 and the DMPC ctor dmpc/cpp/dmpc.cpp:19-75.
+ * Returns NULL on failure (no device, bad parameters); dmpc_last_error(NULL) has the text. */
+dmpc_ctx *dmpc_create(const dmpc_params *prm, int device);
+void dmpc_destroy(dmpc_ctx *ctx);
+const char *dmpc_last_error(const dmpc_ctx *ctx);
+
+/* Change parameters (variant, weights, bounds ...) of an existing context. */
+int dmpc_set_params(dmpc_ctx *ctx, const dmpc_params *prm);
+
+/* a1-a3: getPosMat.m:1 (Lambda = A = A_p), A_v / A_initp loop dmpc_soft_bound.m:92-108,
+ * getDeltaMat.m:1.  Host computation, row-major; any pointer may be NULL.
+ * Lambda, Av, Delta: 3K x 3K; A0: 3K x 6. */
+int dmpc_model_matrices(const dmpc_params *prm, double *Lambda, double *Av, double *A0, double *Delta);
+
+/* getPosVelMat.m:1 (dec-iSCP/cup-SCP helper kept for signature parity): Aaug (12 x 3K). */
+int dmpc_posvel_matrix(double h, int K, double *Aaug);
+
+/* a4: initDMPC.m:1 for S*N agents (MPC step k = 1).  Host pointers.
+ * po, pf: [S][N][3]; l_out, v_out, a_out: [S][N][3K]. */
+int dmpc_init_batch(dmpc_ctx *ctx, int S, int N, const double *po, const double *pf, double *l_out,
+                    double *v_out, double *a_out);
+
+/* a11: ONE MPC step for all agents of S scenes == the body of `for n = 1:N`
+ * (dmpc_soft_bound.m:116-135 / cluster_solvev2 dmpc/cpp/dmpc.cpp:1792-1841) with the solver
+ * selected by prm.variant.  Host pointers; copies in, launches, copies out, synchronises.
+ * l: [S][N][3K]; x_p,x_v,x_a (= pk,vk,ak(:,k-1,n)), pf: [S][N][3];
+ * p_out,v_out,a_out: [S][N][3K] (rows of agents without DMPC_ST_SOLVED are zero);
+ * status: [S][N]; info: [S][N][8] (may be NULL). */
+int dmpc_step_batch(dmpc_ctx *ctx, int S, int N, const double *l, const double *x_p, const double *x_v,
+                    const double *x_a, const double *pf, double *p_out, double *v_out, double *a_out,
+                    int32_t *status, int32_t *info);
+
+/* a7/a8: one agent (0-based n) of one scene: the per-call entry the signature-preserving MATLAB
+ * wrappers use ([p,v,a,feasible,outbound,coll] = solveSoftDMPCbound(...), solveSoftDMPCbound.m:1).
+ * Host pointers.  l: [N][3K]; po,vo,ao,pf: [3]; p,v,a: [3K]; info: [8] or NULL. */
+int dmpc_solve_one(dmpc_ctx *ctx, int N, int n, const double *l, const double *po, const double *vo,
+                   const double *ao, const double *pf, double *p, double *v, double *a, int32_t *status,
+                   int32_t *info);
+
+/* Device-resident form of a11 for callers that keep state in HBM (bench, multi-GPU driver).
+ * The table is in the chunked transposed layout lT[G][S][3K][C]: G chunks (= ranks) of C agents
+ * each, N = G*C agents per scene; this call solves the C agents of chunk g_local of every scene
+ * against the whole table (the per-step all-gather concatenates the ranks' lT_next chunks).
+ * All pointers are DEVICE pointers; `stream` is a hipStream_t (NULL = the context's stream);
+ * asynchronous: returns after enqueueing.
+ *   x_p,x_v,x_a,pf : [S][C][3]          p_out,v_out,a_out : [S][C][3K]
+ *   lT_next        : [S][3K][C] (this chunk, may be NULL)   status [S][C], info [S][C][8] */
+int dmpc_step_device(dmpc_ctx *ctx, int S, int G, int C, int g_local, const double *lT, const double *x_p,
+                     const double *x_v, const double *x_a, const double *pf, double *p_out, double *v_out,
+                     double *a_out, double *lT_next, int32_t *status, int32_t *info, void *stream);
+
+/* layout helpers (device pointers, asynchronous on `stream`):
+ * rows [S][N][3K] -> lT [G][S][3K][C] with N = G*C, and first columns x_next = out(:,1). */
+int dmpc_table_from_rows_device(dmpc_ctx *ctx, int S, int G, int C, const double *rows, double *lT, void *stream);
+
+/* Fused state advance on device: x_p,x_v,x_a <- first horizon column of p_out,v_out,a_out for
+ * SOLVED agents (dmpc_soft_bound.m:132-134).  [S][C] agents. */
+int dmpc_advance_device(dmpc_ctx *ctx, int count, const double *p_out, const double *v_out, const double *a_out,
+                        const int32_t *status, double *x_p, double *x_v, double *x_a, void *stream);
+
+/* Whole transition on one device: the `for k = 1:K_T` loop of dmpc_soft_bound.m:115-148 /
+ * DMPC::solveParallelDMPCv2 (dmpc/cpp/dmpc.cpp:1656-1686) incl. initDMPC at k = 1, the table
+ * swap l = new_l and the ReachedGoal.m test.  Host pointers.
+ * po,pf: [S][N][3]; pk,vk,ak: [S][N][K_T_max][3] (written up to K_T_used[s]);
+ * K_T_used[S]: number of MPC steps taken per scene; scene_status[S]: OR of agent status bits at
+ * the step where the scene stopped (DMPC_ST_SOLVED only = ran to goal / K_T_max). */
+int dmpc_transition(dmpc_ctx *ctx, int S, int N, const double *po, const double *pf, int K_T_max,
+                    double error_tol, double *pk, double *vk, double *ak, int32_t *K_T_used,
+                    int32_t *scene_status);
+
+/* number of agent-QP solves launched by this context so far (for throughput accounting) */
+int64_t dmpc_solve_count(const dmpc_ctx *ctx);
+
+/* Roofline instrumentation: with dmpc_profile(ctx,1) every step-kernel launch is bracketed by HIP
+ * events on the stream it is launched on; dmpc_profile_read drains them and returns the average
+ * kernel duration (ms) and launch count since the previous read. */
+int dmpc_profile(dmpc_ctx *ctx, int enable);
+int dmpc_profile_read(dmpc_ctx *ctx, double *avg_ms, int64_t *n_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DMPC_HIP_H */

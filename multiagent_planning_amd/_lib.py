@@ -1,0 +1,219 @@
+"""ctypes binding of libdmpc_hip.so (the C ABI in include/dmpc_hip.h).
+
+The shared library is built in-tree (multiagent_planning_amd/libdmpc_hip.so) by
+`__graft_entry__.build()` / `make -C multiagent_planning_amd/csrc`.  There is no fallback of any
+kind: if the library is missing, or no HIP device is present, the calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdmpc_hip.so")
+
+VARIANTS = dict(bound=0, bound2=1, all3=2, hard=3, ondemand=4, ellip=5, softall=6, repair=7)
+ST_SOLVED, ST_OUTBOUND, ST_COLL, ST_INFEAS, ST_CAPACITY, ST_ITERCAP = 1, 2, 4, 8, 16, 32
+INFO_LEN = 8
+I_VIOLK, I_NROWS, I_TRIES, I_CASE, I_ITERS, I_NSLACK, I_NACTIVE, I_MAXQ = range(8)
+K_HOR = 15
+
+# every symbol include/dmpc_hip.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "dmpc_create", "dmpc_destroy", "dmpc_last_error", "dmpc_set_params", "dmpc_model_matrices",
+    "dmpc_posvel_matrix", "dmpc_init_batch", "dmpc_step_batch", "dmpc_solve_one", "dmpc_step_device",
+    "dmpc_table_from_rows_device", "dmpc_advance_device", "dmpc_transition", "dmpc_solve_count",
+    "dmpc_profile", "dmpc_profile_read",
+]
+
+
+class DmpcParams(C.Structure):
+    _fields_ = [
+        ("K", C.c_int32), ("variant", C.c_int32), ("order", C.c_int32), ("max_tries", C.c_int32),
+        ("h", C.c_double), ("rmin", C.c_double), ("c", C.c_double), ("alim", C.c_double),
+        ("Q1", C.c_double), ("S1", C.c_double), ("term", C.c_double),
+        ("pmin", C.c_double * 3), ("pmax", C.c_double * 3),
+    ]
+
+
+class DmpcError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load libdmpc_hip.so; raises DmpcError (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DmpcError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C multiagent_planning_amd/csrc` (hipcc, gfx950). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    dp, ip, vp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_void_p
+    pp = C.POINTER(DmpcParams)
+    L.dmpc_create.restype = vp
+    L.dmpc_create.argtypes = [pp, C.c_int]
+    L.dmpc_destroy.restype = None
+    L.dmpc_destroy.argtypes = [vp]
+    L.dmpc_last_error.restype = C.c_char_p
+    L.dmpc_last_error.argtypes = [vp]
+    L.dmpc_set_params.argtypes = [vp, pp]
+    L.dmpc_model_matrices.argtypes = [pp, dp, dp, dp, dp]
+    L.dmpc_posvel_matrix.argtypes = [C.c_double, C.c_int, dp]
+    L.dmpc_init_batch.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp, dp, dp]
+    L.dmpc_step_batch.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, dp, dp, ip, ip]
+    L.dmpc_solve_one.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, dp, dp, ip, ip]
+    L.dmpc_step_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int] + [vp] * 12
+    L.dmpc_table_from_rows_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]
+    L.dmpc_advance_device.argtypes = [vp, C.c_int] + [vp] * 8
+    L.dmpc_transition.argtypes = [vp, C.c_int, C.c_int, dp, dp, C.c_int, C.c_double, dp, dp, dp, ip, ip]
+    L.dmpc_solve_count.restype = C.c_int64
+    L.dmpc_solve_count.argtypes = [vp]
+    L.dmpc_profile.argtypes = [vp, C.c_int]
+    L.dmpc_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    _lib = L
+    return L
+
+
+def make_params(variant="bound", K=K_HOR, h=0.2, rmin=0.35, c=2.0, alim=1.0, Q1=1000.0, S1=100.0, term=-5e4,
+                pmin=(-2.5, -2.5, 0.2), pmax=(2.5, 2.5, 2.2), order=2, max_tries=0):
+    p = DmpcParams()
+    p.K, p.order, p.max_tries = int(K), int(order), int(max_tries)
+    p.variant = VARIANTS[variant] if isinstance(variant, str) else int(variant)
+    p.h, p.rmin, p.c, p.alim, p.Q1, p.S1, p.term = float(h), float(rmin), float(c), float(alim), float(Q1), float(S1), float(term)
+    for i in range(3):
+        p.pmin[i] = float(pmin[i])
+        p.pmax[i] = float(pmax[i])
+    return p
+
+
+def _f(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def model_matrices(h, K=K_HOR):
+    """(Lambda, A_v, A_initp, Delta) -- getPosMat.m / dmpc_soft_bound.m:92-108 / getDeltaMat.m (host, no GPU needed)."""
+    L = load()
+    prm = make_params(K=K, h=h)
+    n = 3 * K
+    Lam, Av, A0, Dl = np.zeros((n, n)), np.zeros((n, n)), np.zeros((n, 6)), np.zeros((n, n))
+    if L.dmpc_model_matrices(C.byref(prm), _dp(Lam), _dp(Av), _dp(A0), _dp(Dl)) != 0:
+        raise DmpcError(L.dmpc_last_error(None).decode())
+    return Lam, Av, A0, Dl
+
+
+def posvel_matrix(h, K):
+    L = load()
+    A = np.zeros((12, 3 * K))
+    if L.dmpc_posvel_matrix(float(h), int(K), _dp(A)) != 0:
+        raise DmpcError(L.dmpc_last_error(None).decode())
+    return A
+
+
+class Dmpc:
+    """One solver context on one HIP device (wraps dmpc_create/dmpc_destroy)."""
+
+    def __init__(self, variant="bound", device=0, **kw):
+        self._L = load()
+        self.prm = make_params(variant, **kw)
+        self._ctx = self._L.dmpc_create(C.byref(self.prm), int(device))
+        if not self._ctx:
+            raise DmpcError(self._L.dmpc_last_error(None).decode())
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._L.dmpc_destroy(self._ctx)
+            self._ctx = None
+
+    __del__ = close
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise DmpcError(self._L.dmpc_last_error(self._ctx).decode())
+
+    def set_params(self, variant=None, **kw):
+        base = {f: getattr(self.prm, f) for f in ("h", "rmin", "c", "alim", "Q1", "S1", "term", "max_tries")}
+        base["pmin"], base["pmax"] = tuple(self.prm.pmin), tuple(self.prm.pmax)
+        base.update(kw)
+        self.prm = make_params(self.prm.variant if variant is None else variant, **base)
+        self._chk(self._L.dmpc_set_params(self._ctx, C.byref(self.prm)))
+
+    # ---- host-array entry points -------------------------------------------------------------
+    def init_batch(self, po, pf):
+        po, pf = _f(po), _f(pf)
+        shp = po.shape[:-1]
+        S, N = (1, shp[0]) if len(shp) == 1 else shp
+        l = np.zeros(shp + (45,))
+        v = np.zeros_like(l)
+        a = np.zeros_like(l)
+        self._chk(self._L.dmpc_init_batch(self._ctx, S, N, _dp(po), _dp(pf), _dp(l), _dp(v), _dp(a)))
+        return l, v, a
+
+    def step_batch(self, l, x_p, x_v, x_a, pf):
+        """l: [N,45] or [S,N,45]; states/goals [..,3]. Returns dict(p,v,a,status,info)."""
+        l, x_p, x_v, x_a, pf = _f(l), _f(x_p), _f(x_v), _f(x_a), _f(pf)
+        lead = l.shape[:-1]
+        S, N = (1, lead[0]) if len(lead) == 1 else lead
+        p, v, a = np.zeros(lead + (45,)), np.zeros(lead + (45,)), np.zeros(lead + (45,))
+        status = np.zeros(lead, dtype=np.int32)
+        info = np.zeros(lead + (INFO_LEN,), dtype=np.int32)
+        self._chk(self._L.dmpc_step_batch(self._ctx, S, N, _dp(l), _dp(x_p), _dp(x_v), _dp(x_a), _dp(pf), _dp(p), _dp(v),
+                                          _dp(a), _ip(status), _ip(info)))
+        return dict(p=p, v=v, a=a, status=status, info=info)
+
+    def solve_one(self, l, n, po, vo, ao, pf):
+        l, po, vo, ao, pf = _f(l), _f(po), _f(vo), _f(ao), _f(pf)
+        p, v, a = np.zeros(45), np.zeros(45), np.zeros(45)
+        status = np.zeros(1, dtype=np.int32)
+        info = np.zeros(INFO_LEN, dtype=np.int32)
+        self._chk(self._L.dmpc_solve_one(self._ctx, l.shape[0], int(n), _dp(l), _dp(po), _dp(vo), _dp(ao), _dp(pf), _dp(p),
+                                         _dp(v), _dp(a), _ip(status), _ip(info)))
+        return dict(p=p, v=v, a=a, status=int(status[0]), info=info)
+
+    def transition(self, po, pf, K_T_max, error_tol=0.01):
+        po, pf = _f(po), _f(pf)
+        shp = po.shape[:-1]
+        S, N = (1, shp[0]) if len(shp) == 1 else shp
+        pk = np.zeros(shp + (K_T_max, 3))
+        vk, ak = np.zeros_like(pk), np.zeros_like(pk)
+        used = np.zeros(S, dtype=np.int32)
+        sst = np.zeros(S, dtype=np.int32)
+        self._chk(self._L.dmpc_transition(self._ctx, S, N, _dp(po), _dp(pf), int(K_T_max), float(error_tol), _dp(pk), _dp(vk),
+                                          _dp(ak), _ip(used), _ip(sst)))
+        return dict(pk=pk, vk=vk, ak=ak, K_T_used=used, scene_status=sst)
+
+    # ---- device-pointer entry points (torch tensors: pass t.data_ptr()) ------------------------
+    def step_device(self, S, G, Cn, g_local, lT, x_p, x_v, x_a, pf, p_out, v_out, a_out, lT_next, status, info, stream=0):
+        self._chk(self._L.dmpc_step_device(self._ctx, S, G, Cn, g_local, lT, x_p, x_v, x_a, pf, p_out, v_out, a_out,
+                                           lT_next or None, status, info or None, stream or None))
+
+    def table_from_rows_device(self, S, G, Cn, rows, lT, stream=0):
+        self._chk(self._L.dmpc_table_from_rows_device(self._ctx, S, G, Cn, rows, lT, stream or None))
+
+    def advance_device(self, count, p_out, v_out, a_out, status, x_p, x_v, x_a, stream=0):
+        self._chk(self._L.dmpc_advance_device(self._ctx, count, p_out, v_out, a_out, status, x_p, x_v, x_a, stream or None))
+
+    def profile(self, enable=True):
+        self._chk(self._L.dmpc_profile(self._ctx, 1 if enable else 0))
+
+    def profile_read(self):
+        ms, n = C.c_double(0.0), C.c_int64(0)
+        self._chk(self._L.dmpc_profile_read(self._ctx, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    @property
+    def solve_count(self):
+        return int(self._L.dmpc_solve_count(self._ctx))

@@ -1,0 +1,596 @@
+// dmpc_api.hip -- host side of libdmpc_hip.so: the C ABI declared in include/dmpc_hip.h.
+//
+// Owns the HIP context state (stream, precomputed per-case tables, scratch buffers) and launches
+// the kernels of dmpc_kernels.hip.  There is deliberately NO CPU fallback anywhere in this file:
+// without a HIP device every compute entry point fails with an error.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/dmpc_hip.h"
+#include "dmpc_device.h"
+
+#include "dmpc_kernels.hip"   // single translation unit: kernels + host ABI
+
+using namespace dmpc;
+
+static thread_local std::string g_err;
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes)
+    {
+        if (bytes <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        if (hipMalloc(&p, bytes) != hipSuccess) return -1;
+        cap = bytes;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() { return (T *)p; }
+};
+
+struct dmpc_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    dmpc_params prm{};
+    double *d_tables = nullptr;   // [3][3][225]
+    std::string err;
+    int64_t solves = 0;
+    int max_lds_set = 0;
+    // scratch for the host-pointer entry points
+    DevBuf rows, lT, lT2, xp, xv, xa, pf, po, pout, vout, aout, status, info, hist_p, hist_v, hist_a, flags;
+    // profiling
+    int profile = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    double prof_ms_sum = 0.0;
+    int64_t prof_n = 0;
+};
+
+#define FAIL(ctx, msg)                                   \
+    do {                                                 \
+        std::string m_ = (msg);                          \
+        if (ctx) (ctx)->err = m_;                        \
+        g_err = m_;                                      \
+        return -1;                                       \
+    } while (0)
+#define HIPCHK(ctx, call)                                                                         \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess) FAIL(ctx, std::string(#call) + ": " + hipGetErrorString(e_));       \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// host math: model matrices (a1-a3) and the per-case tables
+// ---------------------------------------------------------------------------------------------
+
+static int check_params(const dmpc_params *p, std::string &why)
+{
+    if (!p) { why = "params is NULL"; return -1; }
+    if (p->K != K) { why = "only K = k_hor = 15 is supported (the value every reference script uses)"; return -1; }
+    if (p->order != 2) { why = "only ellipsoid order 2 is supported (the value every reference script uses)"; return -1; }
+    if (p->variant < 0 || p->variant > DMPC_VAR_REPAIR) { why = "unknown variant"; return -1; }
+    if (!(p->h > 0) || !(p->rmin > 0) || !(p->c > 0) || !(p->alim > 0)) { why = "h, rmin, c, alim must be positive"; return -1; }
+    for (int d = 0; d < 3; ++d)
+        if (!(p->pmax[d] > p->pmin[d])) { why = "pmax must exceed pmin"; return -1; }
+    return 0;
+}
+
+extern "C" int dmpc_model_matrices(const dmpc_params *prm, double *Lambda, double *Av, double *A0, double *Delta)
+{
+    if (!prm || prm->K < 1 || prm->K > 64) { g_err = "dmpc_model_matrices: bad params"; return -1; }
+    const int Kh = prm->K, n = 3 * Kh;
+    const double h = prm->h;
+    // Same floating-point recurrences as the reference so the matrices agree bit for bit:
+    //   row_k = Aux*row_{k-1} + [0 .. b .. 0]  (getPosMat.m:18-23, dmpc_soft_bound.m:100-105)
+    //   A_init = Aux*A_init                     (dmpc_soft_bound.m:106-107)
+    // with Aux = [I3 h*I3; 0 I3], b = [h^2/2*I3; h*I3].  Per axis the state is (pos,vel) so only the
+    // two scalar sequences pr[j], vr[j] (coefficients of a_j) are needed.
+    std::vector<double> pr(Kh, 0.0), vr(Kh, 0.0);
+    double a0p = 1.0, a0v = 0.0;   // A_init(1,1), A_init(1,4) of the current power of Aux
+    if (Lambda) memset(Lambda, 0, sizeof(double) * n * n);
+    if (Av) memset(Av, 0, sizeof(double) * n * n);
+    if (A0) memset(A0, 0, sizeof(double) * n * 6);
+    for (int k = 0; k < Kh; ++k) {
+        for (int j = 0; j < Kh; ++j) {
+            const double np_ = 1.0 * pr[j] + h * vr[j];   // Aux rows 1:3
+            const double nv_ = 1.0 * vr[j];               // Aux rows 4:6
+            pr[j] = np_; vr[j] = nv_;
+        }
+        pr[k] += h * h / 2; vr[k] += h;
+        a0v = 1.0 * a0v + h * 1.0;   // (Aux*A_init)(1,4) = A_init(1,4) + h*A_init(4,4)
+        for (int j = 0; j < Kh; ++j)
+            for (int a = 0; a < 3; ++a) {
+                if (Lambda) Lambda[(size_t)(3 * k + a) * n + 3 * j + a] = pr[j];
+                if (Av) Av[(size_t)(3 * k + a) * n + 3 * j + a] = vr[j];
+            }
+        if (A0)
+            for (int a = 0; a < 3; ++a) { A0[(size_t)(3 * k + a) * 6 + a] = a0p; A0[(size_t)(3 * k + a) * 6 + 3 + a] = a0v; }
+    }
+    if (Delta) {   // getDeltaMat.m:2-8: [I 0 ..; -I I 0 ..; ...]
+        memset(Delta, 0, sizeof(double) * n * n);
+        for (int k = 0; k < Kh; ++k)
+            for (int a = 0; a < 3; ++a) {
+                Delta[(size_t)(3 * k + a) * n + 3 * k + a] = 1.0;
+                if (k > 0) Delta[(size_t)(3 * k + a) * n + 3 * (k - 1) + a] = -1.0;
+            }
+    }
+    return 0;
+}
+
+extern "C" int dmpc_posvel_matrix(double h, int Kh, double *Aaug)
+{
+    // getPosVelMat.m:24: Aaug = [new_row(K); [0 .. I3]; [I3 0 ..]]  (12 x 3K): final position and
+    // velocity rows, then the selectors of the last and first acceleration
+    if (!Aaug || Kh < 1) { g_err = "dmpc_posvel_matrix: bad arguments"; return -1; }
+    const int n = 3 * Kh;
+    memset(Aaug, 0, sizeof(double) * 12 * n);
+    for (int j = 0; j < Kh; ++j)
+        for (int a = 0; a < 3; ++a) {
+            Aaug[(size_t)a * n + 3 * j + a] = h * h / 2 + (double)(Kh - 1 - j) * h * h;
+            Aaug[(size_t)(3 + a) * n + 3 * j + a] = h;
+        }
+    for (int a = 0; a < 3; ++a) {
+        Aaug[(size_t)(6 + a) * n + 3 * (Kh - 1) + a] = 1.0;
+        Aaug[(size_t)(9 + a) * n + a] = 1.0;
+    }
+    return 0;
+}
+
+// H1 = 2(q l_K l_K' + s D1'D1 + I)  (per-axis block of solveSoftDMPCbound.m:98); returns
+// H1^-1, M1 = H1^-1 L', P1 = L H1^-1 L' (row-major 15x15 each)
+static void build_case_tables(double h, double q, double s, double *out /*675*/)
+{
+    long double L[K][K], H[K][K], Hi[K][K], C[K][K];
+    for (int i = 0; i < K; ++i)
+        for (int j = 0; j < K; ++j) L[i][j] = (j <= i) ? ((long double)h * h / 2 + (long double)(i - j) * h * h) : 0.0L;
+    for (int i = 0; i < K; ++i)
+        for (int j = 0; j < K; ++j) {
+            long double dd = 0.0L;   // (D1'D1)_{ij}: tridiagonal [.. -1 2 -1 ..], last diagonal entry 1
+            if (i == j) dd = (i == K - 1) ? 1.0L : 2.0L;
+            else if (i == j + 1 || j == i + 1) dd = -1.0L;
+            H[i][j] = 2.0L * ((long double)q * L[K - 1][i] * L[K - 1][j] + (long double)s * dd + (i == j ? 1.0L : 0.0L));
+        }
+    // Cholesky H = C C'
+    memset(C, 0, sizeof(C));
+    for (int j = 0; j < K; ++j) {
+        long double d = H[j][j];
+        for (int k = 0; k < j; ++k) d -= C[j][k] * C[j][k];
+        C[j][j] = sqrtl(d);
+        for (int i = j + 1; i < K; ++i) {
+            long double t = H[i][j];
+            for (int k = 0; k < j; ++k) t -= C[i][k] * C[j][k];
+            C[i][j] = t / C[j][j];
+        }
+    }
+    // Hi = H^-1 column by column
+    for (int c = 0; c < K; ++c) {
+        long double y[K], x[K];
+        for (int i = 0; i < K; ++i) {
+            long double t = (i == c) ? 1.0L : 0.0L;
+            for (int k = 0; k < i; ++k) t -= C[i][k] * y[k];
+            y[i] = t / C[i][i];
+        }
+        for (int i = K - 1; i >= 0; --i) {
+            long double t = y[i];
+            for (int k = i + 1; k < K; ++k) t -= C[k][i] * x[k];
+            x[i] = t / C[i][i];
+        }
+        for (int i = 0; i < K; ++i) Hi[i][c] = x[i];
+    }
+    for (int i = 0; i < K; ++i)
+        for (int j = 0; j < K; ++j) {
+            long double sym = 0.5L * (Hi[i][j] + Hi[j][i]);
+            out[i * K + j] = (double)sym;
+        }
+    long double M[K][K];
+    for (int i = 0; i < K; ++i)
+        for (int j = 0; j < K; ++j) {
+            long double t = 0.0L;
+            for (int k = 0; k < K; ++k) t += 0.5L * (Hi[i][k] + Hi[k][i]) * L[j][k];
+            M[i][j] = t;
+            out[225 + i * K + j] = (double)t;
+        }
+    for (int i = 0; i < K; ++i)
+        for (int j = 0; j < K; ++j) {
+            long double t = 0.0L;
+            for (int k = 0; k < K; ++k) t += L[i][k] * M[k][j];
+            out[450 + i * K + j] = (double)t;
+        }
+    // P1 is symmetric in exact arithmetic: symmetrise the rounded table
+    for (int i = 0; i < K; ++i)
+        for (int j = i + 1; j < K; ++j) {
+            double m = 0.5 * (out[450 + i * K + j] + out[450 + j * K + i]);
+            out[450 + i * K + j] = out[450 + j * K + i] = m;
+        }
+}
+
+static int upload_tables(dmpc_ctx *ctx)
+{
+    std::vector<double> t(3 * 675);
+    const dmpc_params &p = ctx->prm;
+    build_case_tables(p.h, 1000.0, 10.0, &t[0]);                                         // far   (:44-47)
+    build_case_tables(p.h, 10000.0, 10.0, &t[675]);                                      // near  (:49-52)
+    build_case_tables(p.h, p.Q1, (p.variant == DMPC_VAR_ALL3) ? 10.0 : p.S1, &t[1350]);  // coll  (:54-57; all:71)
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_tables, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------
+
+extern "C" const char *dmpc_last_error(const dmpc_ctx *ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+extern "C" dmpc_ctx *dmpc_create(const dmpc_params *prm, int device)
+{
+    std::string why;
+    if (check_params(prm, why)) { g_err = "dmpc_create: " + why; return nullptr; }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        g_err = std::string("dmpc_create: no HIP device available (") + hipGetErrorString(e) +
+                "); this library has no CPU fallback";
+        return nullptr;
+    }
+    if (device < 0 || device >= ndev) { g_err = "dmpc_create: device index out of range"; return nullptr; }
+    if (hipSetDevice(device) != hipSuccess) { g_err = "dmpc_create: hipSetDevice failed"; return nullptr; }
+    dmpc_ctx *ctx = new dmpc_ctx();
+    ctx->device = device;
+    ctx->prm = *prm;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc((void **)&ctx->d_tables, sizeof(double) * 3 * 675) != hipSuccess || upload_tables(ctx) != 0) {
+        g_err = "dmpc_create: device initialisation failed: " + ctx->err;
+        dmpc_destroy(ctx);
+        return nullptr;
+    }
+    return ctx;
+}
+
+extern "C" void dmpc_destroy(dmpc_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (auto &ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    DevBuf *bufs[] = {&ctx->rows, &ctx->lT, &ctx->lT2, &ctx->xp, &ctx->xv, &ctx->xa, &ctx->pf, &ctx->po, &ctx->pout,
+                      &ctx->vout, &ctx->aout, &ctx->status, &ctx->info, &ctx->hist_p, &ctx->hist_v, &ctx->hist_a, &ctx->flags};
+    for (DevBuf *b : bufs) b->release();
+    if (ctx->d_tables) (void)hipFree(ctx->d_tables);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int dmpc_set_params(dmpc_ctx *ctx, const dmpc_params *prm)
+{
+    if (!ctx) { g_err = "dmpc_set_params: ctx is NULL"; return -1; }
+    std::string why;
+    if (check_params(prm, why)) FAIL(ctx, "dmpc_set_params: " + why);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ctx->prm = *prm;
+    return upload_tables(ctx);
+}
+
+extern "C" int64_t dmpc_solve_count(const dmpc_ctx *ctx) { return ctx ? ctx->solves : 0; }
+
+extern "C" int dmpc_profile(dmpc_ctx *ctx, int enable)
+{
+    if (!ctx) return -1;
+    ctx->profile = enable;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// launches
+// ---------------------------------------------------------------------------------------------
+
+static bool variant_soft(int v)
+{
+    return v == DMPC_VAR_BOUND || v == DMPC_VAR_BOUND2 || v == DMPC_VAR_ALL3 || v == DMPC_VAR_SOFTALL || v == DMPC_VAR_REPAIR;
+}
+
+// row capacity per agent: the exact worst case where it is affordable, else the LDS budget
+static int row_capacity(int variant, int N)
+{
+    const long nb = N > 1 ? N - 1 : 1;
+    long want;
+    switch (variant) {
+    case DMPC_VAR_HARD: want = (long)K * nb; break;   // every k, every neighbour (CollConstrHardDMPC.m:3)
+    case DMPC_VAR_ALL3: want = 3 * nb; break;
+    default: want = nb; break;
+    }
+    const bool soft = variant_soft(variant);
+    const long budget = 150 * 1024;   // leave headroom below the 160 KiB/CU LDS
+    const long fixed = (long)step_lds_bytes(0, soft);
+    const long per_row = (long)(step_lds_bytes(1, soft) - step_lds_bytes(0, soft));
+    long cap = (budget - fixed) / per_row;
+    // soft near-neighbour variants only ever select d < 3 rmin: 128 rows is generous and keeps
+    // several workgroups resident per CU; the kernel flags DMPC_ST_CAPACITY if it is ever exceeded
+    if (variant == DMPC_VAR_BOUND || variant == DMPC_VAR_BOUND2 || variant == DMPC_VAR_ONDEMAND) cap = cap < 128 ? cap : 128;
+    if (variant == DMPC_VAR_ALL3) cap = cap < 384 ? cap : 384;
+    if (variant == DMPC_VAR_HARD) cap = cap < 768 ? cap : 768;
+    long r = want < cap ? want : cap;
+    if (r < 8) r = 8;
+    return (int)((r + 1) & ~1L);
+}
+
+static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_first, int c_count, const double *lT,
+                       const double *x_p, const double *x_v, const double *x_a, const double *pf, double *p_out,
+                       double *v_out, double *a_out, double *lT_next, int32_t *status, int32_t *info, hipStream_t st)
+{
+    const dmpc_params &p = ctx->prm;
+    StepParams P;
+    memset(&P, 0, sizeof(P));
+    P.variant = p.variant; P.S = S; P.G = G; P.C = C; P.g_local = g_local;
+    P.c_first = c_first; P.c_count = c_count;
+    P.nrmax = row_capacity(p.variant, G * C);
+    P.max_tries = p.max_tries;
+    P.h = p.h; P.rmin = p.rmin; P.e1z = 1.0 / p.c; P.e2z = 1.0 / (p.c * p.c);
+    P.alim = p.alim; P.Q1 = p.Q1; P.S1 = p.S1; P.term = p.term;
+    for (int d = 0; d < 3; ++d) { P.pmin[d] = p.pmin[d]; P.pmax[d] = p.pmax[d]; }
+    P.tables = ctx->d_tables;
+    P.lT = lT; P.x_p = x_p; P.x_v = x_v; P.x_a = x_a; P.pf = pf;
+    P.p_out = p_out; P.v_out = v_out; P.a_out = a_out; P.lT_next = lT_next;
+    P.status = status; P.info = info;
+    const size_t lds = step_lds_bytes(P.nrmax, variant_soft(p.variant));
+    if ((int)lds > ctx->max_lds_set) {
+        HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        ctx->max_lds_set = (int)lds;
+    }
+    std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+    if (ctx->profile) {
+        HIPCHK(ctx, hipEventCreate(&ev.first));
+        HIPCHK(ctx, hipEventCreate(&ev.second));
+        HIPCHK(ctx, hipEventRecord(ev.first, st));
+    }
+    hipLaunchKernelGGL(dmpc_step_kernel, dim3((unsigned)(S * c_count)), dim3(64), lds, st, P);
+    HIPCHK(ctx, hipGetLastError());
+    if (ctx->profile) {
+        HIPCHK(ctx, hipEventRecord(ev.second, st));
+        ctx->events.push_back(ev);
+    }
+    ctx->solves += (int64_t)S * c_count;
+    return 0;
+}
+
+extern "C" int dmpc_profile_read(dmpc_ctx *ctx, double *avg_ms, int64_t *n_launches)
+{
+    if (!ctx) return -1;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    for (auto &ev : ctx->events) {
+        HIPCHK(ctx, hipEventSynchronize(ev.second));
+        float ms = 0.f;
+        HIPCHK(ctx, hipEventElapsedTime(&ms, ev.first, ev.second));
+        ctx->prof_ms_sum += ms;
+        ctx->prof_n += 1;
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
+    }
+    ctx->events.clear();
+    if (avg_ms) *avg_ms = ctx->prof_n ? ctx->prof_ms_sum / (double)ctx->prof_n : 0.0;
+    if (n_launches) *n_launches = ctx->prof_n;
+    ctx->prof_ms_sum = 0.0;
+    ctx->prof_n = 0;
+    return 0;
+}
+
+extern "C" int dmpc_step_device(dmpc_ctx *ctx, int S, int G, int C, int g_local, const double *lT, const double *x_p,
+                                const double *x_v, const double *x_a, const double *pf, double *p_out, double *v_out,
+                                double *a_out, double *lT_next, int32_t *status, int32_t *info, void *stream)
+{
+    if (!ctx) { g_err = "dmpc_step_device: ctx is NULL"; return -1; }
+    if (S < 1 || G < 1 || C < 1 || g_local < 0 || g_local >= G) FAIL(ctx, "dmpc_step_device: bad S/G/C/g_local");
+    if (!lT || !x_p || !x_v || !x_a || !pf || !p_out || !v_out || !a_out || !status) FAIL(ctx, "dmpc_step_device: NULL pointer");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    return launch_step(ctx, S, G, C, g_local, 0, C, lT, x_p, x_v, x_a, pf, p_out, v_out, a_out, lT_next, status, info,
+                       stream ? (hipStream_t)stream : ctx->stream);
+}
+
+extern "C" int dmpc_table_from_rows_device(dmpc_ctx *ctx, int S, int G, int C, const double *rows, double *lT, void *stream)
+{
+    if (!ctx) { g_err = "dmpc_table_from_rows_device: ctx is NULL"; return -1; }
+    if (S < 1 || G < 1 || C < 1 || !rows || !lT) FAIL(ctx, "dmpc_table_from_rows_device: bad arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t total = (size_t)S * G * C * N3;
+    const unsigned blocks = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(table_from_rows_kernel, dim3(blocks), dim3(256), 0, stream ? (hipStream_t)stream : ctx->stream, S, G, C, rows, lT);
+    HIPCHK(ctx, hipGetLastError());
+    return 0;
+}
+
+extern "C" int dmpc_advance_device(dmpc_ctx *ctx, int count, const double *p_out, const double *v_out, const double *a_out,
+                                   const int32_t *status, double *x_p, double *x_v, double *x_a, void *stream)
+{
+    if (!ctx) { g_err = "dmpc_advance_device: ctx is NULL"; return -1; }
+    if (count < 1 || !p_out || !v_out || !a_out || !status || !x_p || !x_v || !x_a) FAIL(ctx, "dmpc_advance_device: bad arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(advance_kernel, dim3((unsigned)((count * 3 + 255) / 256)), dim3(256), 0,
+                       stream ? (hipStream_t)stream : ctx->stream, count, p_out, v_out, a_out, (const int *)status, x_p, x_v, x_a);
+    HIPCHK(ctx, hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-pointer entry points
+// ---------------------------------------------------------------------------------------------
+
+static int ensure_step_scratch(dmpc_ctx *ctx, size_t agents_table, size_t agents_solved)
+{
+    int rc = 0;
+    rc |= ctx->rows.ensure(agents_table * N3 * 8);
+    rc |= ctx->lT.ensure(agents_table * N3 * 8);
+    rc |= ctx->xp.ensure(agents_solved * 24);
+    rc |= ctx->xv.ensure(agents_solved * 24);
+    rc |= ctx->xa.ensure(agents_solved * 24);
+    rc |= ctx->pf.ensure(agents_solved * 24);
+    rc |= ctx->pout.ensure(agents_solved * N3 * 8);
+    rc |= ctx->vout.ensure(agents_solved * N3 * 8);
+    rc |= ctx->aout.ensure(agents_solved * N3 * 8);
+    rc |= ctx->status.ensure(agents_solved * 4);
+    rc |= ctx->info.ensure(agents_solved * 32);
+    if (rc) FAIL(ctx, "device allocation failed");
+    return 0;
+}
+
+extern "C" int dmpc_step_batch(dmpc_ctx *ctx, int S, int N, const double *l, const double *x_p, const double *x_v,
+                               const double *x_a, const double *pf, double *p_out, double *v_out, double *a_out,
+                               int32_t *status, int32_t *info)
+{
+    if (!ctx) { g_err = "dmpc_step_batch: ctx is NULL"; return -1; }
+    if (S < 1 || N < 1) FAIL(ctx, "dmpc_step_batch: S and N must be >= 1");
+    if (!l || !x_p || !x_v || !x_a || !pf || !p_out || !v_out || !a_out || !status) FAIL(ctx, "dmpc_step_batch: NULL pointer");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t A = (size_t)S * N;
+    if (ensure_step_scratch(ctx, A, A)) return -1;
+    hipStream_t st = ctx->stream;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->rows.p, l, A * N3 * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->xp.p, x_p, A * 24, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->xv.p, x_v, A * 24, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->xa.p, x_a, A * 24, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->pf.p, pf, A * 24, hipMemcpyHostToDevice, st));
+    if (dmpc_table_from_rows_device(ctx, S, 1, N, ctx->rows.as<double>(), ctx->lT.as<double>(), st)) return -1;
+    if (launch_step(ctx, S, 1, N, 0, 0, N, ctx->lT.as<double>(), ctx->xp.as<double>(), ctx->xv.as<double>(),
+                    ctx->xa.as<double>(), ctx->pf.as<double>(), ctx->pout.as<double>(), ctx->vout.as<double>(),
+                    ctx->aout.as<double>(), nullptr, ctx->status.as<int32_t>(), ctx->info.as<int32_t>(), st))
+        return -1;
+    HIPCHK(ctx, hipMemcpyAsync(p_out, ctx->pout.p, A * N3 * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(v_out, ctx->vout.p, A * N3 * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(a_out, ctx->aout.p, A * N3 * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(status, ctx->status.p, A * 4, hipMemcpyDeviceToHost, st));
+    if (info) HIPCHK(ctx, hipMemcpyAsync(info, ctx->info.p, A * 32, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    return 0;
+}
+
+extern "C" int dmpc_solve_one(dmpc_ctx *ctx, int N, int n, const double *l, const double *po, const double *vo,
+                              const double *ao, const double *pf, double *p, double *v, double *a, int32_t *status,
+                              int32_t *info)
+{
+    if (!ctx) { g_err = "dmpc_solve_one: ctx is NULL"; return -1; }
+    if (N < 1 || n < 0 || n >= N) FAIL(ctx, "dmpc_solve_one: agent index out of range");
+    if (!l || !po || !vo || !ao || !pf || !p || !v || !a || !status) FAIL(ctx, "dmpc_solve_one: NULL pointer");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (ensure_step_scratch(ctx, (size_t)N, 1)) return -1;
+    hipStream_t st = ctx->stream;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->rows.p, l, (size_t)N * N3 * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->xp.p, po, 24, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->xv.p, vo, 24, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->xa.p, ao, 24, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->pf.p, pf, 24, hipMemcpyHostToDevice, st));
+    if (dmpc_table_from_rows_device(ctx, 1, 1, N, ctx->rows.as<double>(), ctx->lT.as<double>(), st)) return -1;
+    if (launch_step(ctx, 1, 1, N, 0, n, 1, ctx->lT.as<double>(), ctx->xp.as<double>(), ctx->xv.as<double>(),
+                    ctx->xa.as<double>(), ctx->pf.as<double>(), ctx->pout.as<double>(), ctx->vout.as<double>(),
+                    ctx->aout.as<double>(), nullptr, ctx->status.as<int32_t>(), ctx->info.as<int32_t>(), st))
+        return -1;
+    HIPCHK(ctx, hipMemcpyAsync(p, ctx->pout.p, N3 * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(v, ctx->vout.p, N3 * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(a, ctx->aout.p, N3 * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(status, ctx->status.p, 4, hipMemcpyDeviceToHost, st));
+    if (info) HIPCHK(ctx, hipMemcpyAsync(info, ctx->info.p, 32, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    return 0;
+}
+
+extern "C" int dmpc_init_batch(dmpc_ctx *ctx, int S, int N, const double *po, const double *pf, double *l_out,
+                               double *v_out, double *a_out)
+{
+    if (!ctx) { g_err = "dmpc_init_batch: ctx is NULL"; return -1; }
+    if (S < 1 || N < 1 || !po || !pf || !l_out) FAIL(ctx, "dmpc_init_batch: bad arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t A = (size_t)S * N;
+    if (ctx->po.ensure(A * 24) || ctx->pf.ensure(A * 24) || ctx->rows.ensure(A * N3 * 8)) FAIL(ctx, "device allocation failed");
+    hipStream_t st = ctx->stream;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->po.p, po, A * 24, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->pf.p, pf, A * 24, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(init_rows_kernel, dim3((unsigned)((A * N3 + 255) / 256)), dim3(256), 0, st, (int)A, ctx->prm.h,
+                       ctx->po.as<double>(), ctx->pf.as<double>(), ctx->rows.as<double>());
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(l_out, ctx->rows.p, A * N3 * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    if (v_out) memset(v_out, 0, A * N3 * 8);   // initDMPC.m:11-12: v = a = zeros(3,k_hor)
+    if (a_out) memset(a_out, 0, A * N3 * 8);
+    return 0;
+}
+
+// the whole `for k = 1:K_T` loop on the device (dmpc_soft_bound.m:115-148, failure_rate.m:99-127)
+extern "C" int dmpc_transition(dmpc_ctx *ctx, int S, int N, const double *po, const double *pf, int K_T_max,
+                               double error_tol, double *pk, double *vk, double *ak, int32_t *K_T_used,
+                               int32_t *scene_status)
+{
+    if (!ctx) { g_err = "dmpc_transition: ctx is NULL"; return -1; }
+    if (S < 1 || N < 1 || K_T_max < 2 || !po || !pf || !pk || !vk || !ak || !K_T_used || !scene_status)
+        FAIL(ctx, "dmpc_transition: bad arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t A = (size_t)S * N;
+    if (ensure_step_scratch(ctx, A, A)) return -1;
+    const size_t hist = A * (size_t)K_T_max * 24;
+    if (ctx->lT2.ensure(A * N3 * 8) || ctx->po.ensure(A * 24) || ctx->hist_p.ensure(hist) || ctx->hist_v.ensure(hist) ||
+        ctx->hist_a.ensure(hist) || ctx->flags.ensure((size_t)K_T_max * S * 8))
+        FAIL(ctx, "device allocation failed");
+    hipStream_t st = ctx->stream;
+    double *xp = ctx->xp.as<double>(), *xv = ctx->xv.as<double>(), *xa = ctx->xa.as<double>();
+    HIPCHK(ctx, hipMemcpyAsync(ctx->po.p, po, A * 24, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->pf.p, pf, A * 24, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemsetAsync(ctx->flags.p, 0, (size_t)K_T_max * S * 8, st));
+    HIPCHK(ctx, hipMemsetAsync(ctx->hist_p.p, 0, hist, st));
+    HIPCHK(ctx, hipMemsetAsync(ctx->hist_v.p, 0, hist, st));
+    HIPCHK(ctx, hipMemsetAsync(ctx->hist_a.p, 0, hist, st));
+    // k = 1: initDMPC (dmpc_soft_bound.m:117-121): state = (po, 0, 0), table = straight lines
+    HIPCHK(ctx, hipMemcpyAsync(xp, ctx->po.p, A * 24, hipMemcpyDeviceToDevice, st));
+    HIPCHK(ctx, hipMemsetAsync(xv, 0, A * 24, st));
+    HIPCHK(ctx, hipMemsetAsync(xa, 0, A * 24, st));
+    hipLaunchKernelGGL(init_rows_kernel, dim3((unsigned)((A * N3 + 255) / 256)), dim3(256), 0, st, (int)A, ctx->prm.h,
+                       ctx->po.as<double>(), ctx->pf.as<double>(), ctx->rows.as<double>());
+    if (dmpc_table_from_rows_device(ctx, S, 1, N, ctx->rows.as<double>(), ctx->lT.as<double>(), st)) return -1;
+    const unsigned rb = (unsigned)((A * 3 + 255) / 256);
+    hipLaunchKernelGGL(record_kernel, dim3(rb), dim3(256), 0, st, S, N, K_T_max, 0, xp, xv, xa, ctx->hist_p.as<double>(),
+                       ctx->hist_v.as<double>(), ctx->hist_a.as<double>());
+    double *cur = ctx->lT.as<double>(), *nxt = ctx->lT2.as<double>();
+    std::vector<int32_t> flags((size_t)K_T_max * S * 2, 0);
+    std::vector<int> done(S, 0);
+    for (int s = 0; s < S; ++s) { K_T_used[s] = K_T_max; scene_status[s] = DMPC_ST_SOLVED; }
+    int ndone = 0;
+    const int chunk = 8;   // host looks at the per-step flags every `chunk` MPC steps
+    for (int k = 1; k < K_T_max && ndone < S; ++k) {
+        if (launch_step(ctx, S, 1, N, 0, 0, N, cur, xp, xv, xa, ctx->pf.as<double>(), ctx->pout.as<double>(),
+                        ctx->vout.as<double>(), ctx->aout.as<double>(), nxt, ctx->status.as<int32_t>(), nullptr, st))
+            return -1;
+        hipLaunchKernelGGL(advance_kernel, dim3(rb), dim3(256), 0, st, (int)A, ctx->pout.as<double>(), ctx->vout.as<double>(),
+                           ctx->aout.as<double>(), (const int *)ctx->status.as<int32_t>(), xp, xv, xa);
+        hipLaunchKernelGGL(record_kernel, dim3(rb), dim3(256), 0, st, S, N, K_T_max, k, xp, xv, xa, ctx->hist_p.as<double>(),
+                           ctx->hist_v.as<double>(), ctx->hist_a.as<double>());
+        hipLaunchKernelGGL(scene_reduce_kernel, dim3((unsigned)S), dim3(256), 0, st, N, error_tol, xp, ctx->pf.as<double>(),
+                           (const int *)ctx->status.as<int32_t>(), ctx->flags.as<int>() + (size_t)k * S * 2);
+        HIPCHK(ctx, hipGetLastError());
+        std::swap(cur, nxt);   // l = new_l (dmpc_soft_bound.m:146)
+        if (k % chunk == 0 || k == K_T_max - 1) {
+            const int k0 = ((k - 1) / chunk) * chunk + 1;
+            HIPCHK(ctx, hipMemcpyAsync(&flags[(size_t)k0 * S * 2], ctx->flags.as<int>() + (size_t)k0 * S * 2,
+                                       (size_t)(k - k0 + 1) * S * 8, hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipStreamSynchronize(st));
+            for (int kk = k0; kk <= k; ++kk)
+                for (int s = 0; s < S; ++s) {
+                    if (done[s]) continue;
+                    const int32_t reached = flags[((size_t)kk * S + s) * 2], stbits = flags[((size_t)kk * S + s) * 2 + 1];
+                    if (stbits & ~DMPC_ST_SOLVED) {   // some agent failed: the reference aborts the trial
+                        done[s] = 1; ndone++; K_T_used[s] = kk + 1; scene_status[s] = stbits;
+                    } else if (reached) {             // ReachedGoal.m (failure_rate.m:125)
+                        done[s] = 1; ndone++; K_T_used[s] = kk + 1; scene_status[s] = DMPC_ST_SOLVED;
+                    }
+                }
+        }
+    }
+    HIPCHK(ctx, hipMemcpyAsync(pk, ctx->hist_p.p, hist, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(vk, ctx->hist_v.p, hist, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(ak, ctx->hist_a.p, hist, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    return 0;
+}

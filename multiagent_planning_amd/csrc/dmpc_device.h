@@ -1,0 +1,36 @@
+// dmpc_device.h -- constants and the kernel parameter block shared by dmpc_kernels.hip and dmpc_api.hip
+#pragma once
+#include <stdint.h>
+
+namespace dmpc {
+
+constexpr int K = 15;         // horizon k_hor (dmpc_soft_bound.m:13)
+constexpr int N3 = 3 * K;     // stacked acceleration / position vector length
+constexpr int QMAX = 48;      // working-set capacity (slots of the inverse factor T)
+constexpr int LD = QMAX + 1;  // odd leading dimension: conflict-free ds_read_b64 along rows and columns
+constexpr int ITER_CAP = 4000;
+
+enum { VAR_BOUND = 0, VAR_BOUND2 = 1, VAR_ALL3 = 2, VAR_HARD = 3, VAR_ONDEMAND = 4, VAR_ELLIP = 5, VAR_SOFTALL = 6, VAR_REPAIR = 7 };
+enum { ST_SOLVED = 1, ST_OUTBOUND = 2, ST_COLL = 4, ST_INFEAS = 8, ST_CAPACITY = 16, ST_ITERCAP = 32 };
+
+struct StepParams {
+    int variant, S, G, C, g_local, nrmax, max_tries, c_first, c_count, pad_;
+    double h, rmin, e1z, e2z, alim, Q1, S1, term;
+    double pmin[3], pmax[3];
+    const double *tables;   // [3 cost cases][H1^-1 | H1^-1 L' | L H1^-1 L'][15*15]
+    const double *lT;       // [G][S][3K][C]
+    const double *x_p, *x_v, *x_a, *pf;   // [S][c_count][3]  (agents c_first .. c_first+c_count-1 of chunk g_local)
+    double *p_out, *v_out, *a_out;        // [S][c_count][3K]
+    double *lT_next;                      // [S][3K][C] or null
+    int *status, *info;
+};
+
+// bytes of dynamic LDS the step kernel carves for a given row capacity
+inline size_t step_lds_bytes(int nrmax, bool soft)
+{
+    size_t dbl = (size_t)QMAX * LD + 675 + 5 * 48 + 3 * QMAX + 3 * QMAX + (size_t)nrmax * (4 + (soft ? 5 : 0));
+    size_t ints = 3 * QMAX + 2 * (size_t)nrmax;
+    return dbl * 8 + ints * 4;
+}
+
+}  // namespace dmpc

@@ -1,0 +1,751 @@
+// dmpc_kernels.hip -- gfx950 (MI355X, CDNA4) device code of the DMPC per-agent horizon-QP hot path.
+//
+// One 64-lane wavefront (= one workgroup) owns one agent for one MPC step:
+//   scan   (a5)  CheckCollSoftDMPC.m:7-15 / CheckCollEllipDMPC.m:4-11 : coalesced reads of the
+//                transposed prediction table lT[G][S][3K][C], lane = neighbour
+//   rows   (a6)  CollConstrSoftDMPC.m:16-28 (+2/Hard/OnDemand/Ellip variants): compacted into LDS in
+//                structured form (xi, kc, rhs, slack descriptor) -- 5..9 numbers per row, never dense
+//   solve  (a7)  the QP of solveSoftDMPCbound.m:43-103 (and variants) by a dual active-set
+//                (Goldfarb-Idnani) method in Schur-complement form: the Hessian is input-independent
+//                and per-axis (H = H1 (x) I3), so H1^-1, H1^-1 L', L H1^-1 L' (15x15 each) are
+//                precomputed per cost case and staged in LDS; the only per-agent matrix is the
+//                upper-triangular inverse Cholesky factor T of the active-set Schur matrix
+//                (T T' = (N' H^-1 N)^-1), kept in LDS and updated by column append / Givens deletes.
+//                Slack variables (solveSoftDMPCbound.m:60-88) are explicit but their eps<=0 pins are
+//                instantiated lazily, so the working set only holds what is really active.
+//   prop   (a9)  propStatedmpc.m:3-4, is_inbounds.m:2-5 (a10), outputs + next table chunk.
+//
+// All arithmetic is fp64 (the reference is MATLAB double).  No atomics: every reduction is a fixed
+// butterfly, so results are bit-reproducible and independent of how agents are sharded.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "dmpc_device.h"
+
+namespace dmpc {
+
+// --------------------------------------------------------------------------------------------
+// wave64 helpers
+// --------------------------------------------------------------------------------------------
+#define LSYNC() __syncthreads() /* block == one wave: orders LDS traffic, no cross-wave wait */
+
+__device__ __forceinline__ double readlane_d(double v, int l /*uniform*/)
+{
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int readlane_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+
+__device__ __forceinline__ double wave_max(double v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m));
+    return v;
+}
+__device__ __forceinline__ double wave_min(double v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmin(v, __shfl_xor(v, m));
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+__device__ __forceinline__ int lanes_below(unsigned long long mask, int lane)
+{
+    return __popcll(mask & ((1ull << lane) - 1ull));
+}
+
+__device__ __forceinline__ double sel3(const double *v, int ax) { return ax == 0 ? v[0] : (ax == 1 ? v[1] : v[2]); }
+
+// constraint types
+enum { TY_BOXHI = 0, TY_BOXLO = 1, TY_POSHI = 2, TY_POSLO = 3, TY_COLL = 4, TY_SLKU = 5, TY_SLKL = 6 };
+// row flags
+enum { RF_COLL = 1, RF_SLKU = 2, RF_SLKL = 4, RF_LIVE = 8 };
+
+struct Lds {
+    double *T;      // QMAX x LD inverse Cholesky factor
+    double *tabH, *tabM, *tabP;  // 15x15: H1^-1, H1^-1 L', L H1^-1 L'
+    double *a_s, *w_s, *za_s, *zw_s, *own_s;   // 48 each
+    double *s_vec;  // QMAX x 3
+    double *s_ss, *s_d, *s_lam;
+    double *r_xi;   // nrmax x 3
+    double *r_b;
+    double *r_sd, *r_st, *r_slb, *r_eps, *r_ze;  // soft variants only
+    int *s_kb, *s_ty, *s_idx;
+    int *r_kc, *r_fl;
+};
+
+// uniform description of one constraint
+struct Cdesc {
+    int ty, idx, kb, isA, si;
+    double v0, v1, v2, ss, d;
+};
+
+struct Agent {   // wave-uniform agent data
+    double po[3], vo[3], ao[3], pf[3];
+    double whi0[3], wlo0[3];   // pmax - po, pmin - po (w bounds at k: whi0 - (k+1) h vo)
+};
+
+__device__ __forceinline__ Cdesc make_desc(int ty, int idx, const Lds &L, const Agent &A, const StepParams &P, bool soft)
+{
+    Cdesc c;
+    c.ty = ty; c.idx = idx; c.kb = 0; c.isA = 0; c.si = -1;
+    c.v0 = c.v1 = c.v2 = 0.0; c.ss = 0.0; c.d = 0.0;
+    if (ty < TY_COLL) {
+        const int k = idx / 3, ax = idx - 3 * k;
+        const double sgn = (ty == TY_BOXHI || ty == TY_POSHI) ? 1.0 : -1.0;
+        c.kb = k; c.isA = (ty < TY_POSHI);
+        c.v0 = ax == 0 ? sgn : 0.0; c.v1 = ax == 1 ? sgn : 0.0; c.v2 = ax == 2 ? sgn : 0.0;
+        if (c.isA) c.d = P.alim;
+        else {
+            const double sh = (double)(k + 1) * P.h * sel3(A.vo, ax);
+            c.d = (ty == TY_POSHI) ? (sel3(A.whi0, ax) - sh) : -(sel3(A.wlo0, ax) - sh);
+        }
+    } else if (ty == TY_COLL) {
+        c.kb = L.r_kc[idx];
+        c.v0 = -L.r_xi[3 * idx]; c.v1 = -L.r_xi[3 * idx + 1]; c.v2 = -L.r_xi[3 * idx + 2];
+        c.d = L.r_b[idx];
+        if (soft) { c.si = idx; c.ss = L.r_sd[idx]; }
+    } else if (ty == TY_SLKU) {
+        c.si = idx; c.ss = 1.0; c.d = 0.0;
+    } else {
+        c.si = idx; c.ss = -1.0; c.d = -L.r_slb[idx];
+    }
+    return c;
+}
+
+// n_j' H^-1 n_p for the slot held by this lane (j) against the uniform constraint p
+__device__ __forceinline__ double sdot_slot(const Lds &L, int j, const Cdesc &p)
+{
+    const int kb = L.s_kb[j], ty = L.s_ty[j];
+    const int isA = ty < TY_POSHI;
+    const double dot3 = L.s_vec[3 * j] * p.v0 + L.s_vec[3 * j + 1] * p.v1 + L.s_vec[3 * j + 2] * p.v2;
+    double tab;
+    if (isA && p.isA) tab = L.tabH[kb * 15 + p.kb];
+    else if (isA) tab = L.tabM[kb * 15 + p.kb];
+    else if (p.isA) tab = L.tabM[p.kb * 15 + kb];
+    else tab = L.tabP[kb * 15 + p.kb];
+    double v = tab * dot3;
+    if (ty >= TY_COLL && p.si >= 0 && L.s_idx[j] == p.si && L.s_ss[j] != 0.0) v += 0.5 * L.s_ss[j] * p.ss;
+    return v;
+}
+
+__device__ __forceinline__ double sdot_self(const Lds &L, const Cdesc &p)
+{
+    const double dot3 = p.v0 * p.v0 + p.v1 * p.v1 + p.v2 * p.v2;
+    const double tab = p.isA ? L.tabH[p.kb * 15 + p.kb] : L.tabP[p.kb * 15 + p.kb];
+    double v = tab * dot3;
+    if (p.si >= 0) v += 0.5 * p.ss * p.ss;
+    return v;
+}
+
+// x(lambda): a = a_unc - H^-1 N lam, w = Lambda a ; written to a_s / w_s.  eps for live slack rows.
+__device__ __forceinline__ void primal(const Lds &L, int lane, int q, int nr, bool soft, double a_unc, double w_unc,
+                                       double &a, double &w)
+{
+    const int k = lane / 3, ax = lane - 3 * k;
+    a = a_unc; w = w_unc;
+    if (lane < 45) {
+        for (int j = 0; j < q; ++j) {
+            const int ty = L.s_ty[j];
+            if (ty > TY_COLL) continue;   // slack-only constraints do not touch a
+            const int kb = L.s_kb[j];
+            const double coef = L.s_lam[j] * L.s_vec[3 * j + ax];
+            if (ty < TY_POSHI) { a -= coef * L.tabH[k * 15 + kb]; w -= coef * L.tabM[kb * 15 + k]; }
+            else { a -= coef * L.tabM[k * 15 + kb]; w -= coef * L.tabP[k * 15 + kb]; }
+        }
+        L.a_s[lane] = a; L.w_s[lane] = w;
+    }
+    if (soft) {
+        for (int i = lane; i < nr; i += 64) {
+            double e = 0.0;
+            if (L.r_fl[i] & RF_LIVE) {
+                double acc = L.r_st[i];
+                for (int j = 0; j < q; ++j)
+                    if (L.s_ty[j] >= TY_COLL && L.s_idx[j] == i) acc += L.s_lam[j] * L.s_ss[j];
+                e = -0.5 * acc;
+            }
+            L.r_eps[i] = e;
+        }
+    }
+    LSYNC();
+}
+
+// value n_j'x - d_j of the slot owned by this lane
+__device__ __forceinline__ double slot_value(const Lds &L, int j, const double *av, const double *wv, const double *ev)
+{
+    const int kb = L.s_kb[j], ty = L.s_ty[j];
+    const double *base = (ty < TY_POSHI) ? av : wv;
+    double v = L.s_vec[3 * j] * base[3 * kb] + L.s_vec[3 * j + 1] * base[3 * kb + 1] + L.s_vec[3 * j + 2] * base[3 * kb + 2];
+    if (ty >= TY_COLL && L.s_ss[j] != 0.0) v += L.s_ss[j] * ev[L.s_idx[j]];
+    return v;
+}
+
+// delete slot l from the working set: Givens rotations on adjacent columns zero row l of T
+// left-to-right, then row l and the last column are removed (stable inverse-factor downdate).
+__device__ __forceinline__ void remove_slot(const Lds &L, int lane, int &q, int l)
+{
+    for (int j = l; j < q - 1; ++j) {
+        const double a_ = L.T[l * LD + j], b_ = L.T[l * LD + j + 1];
+        const double rr = sqrt(a_ * a_ + b_ * b_);
+        if (rr > 1e-150) {
+            const double cc = b_ / rr, ss = a_ / rr;
+            if (lane < q) {
+                const double cj = L.T[lane * LD + j], cj1 = L.T[lane * LD + j + 1];
+                L.T[lane * LD + j] = cc * cj - ss * cj1;
+                L.T[lane * LD + j + 1] = ss * cj + cc * cj1;
+            }
+        }
+        LSYNC();
+    }
+    for (int i = l + 1; i < q; ++i)
+        if (lane < q) L.T[(i - 1) * LD + lane] = L.T[i * LD + lane];
+    // shift slot records
+    const bool mv = lane > l && lane < q;
+    double v0 = 0, v1 = 0, v2 = 0, ss = 0, d = 0, lam = 0; int kb = 0, ty = 0, idx = 0;
+    if (mv) {
+        v0 = L.s_vec[3 * lane]; v1 = L.s_vec[3 * lane + 1]; v2 = L.s_vec[3 * lane + 2];
+        ss = L.s_ss[lane]; d = L.s_d[lane]; lam = L.s_lam[lane];
+        kb = L.s_kb[lane]; ty = L.s_ty[lane]; idx = L.s_idx[lane];
+    }
+    LSYNC();
+    if (mv) {
+        const int t = lane - 1;
+        L.s_vec[3 * t] = v0; L.s_vec[3 * t + 1] = v1; L.s_vec[3 * t + 2] = v2;
+        L.s_ss[t] = ss; L.s_d[t] = d; L.s_lam[t] = lam;
+        L.s_kb[t] = kb; L.s_ty[t] = ty; L.s_idx[t] = idx;
+    }
+    q -= 1;
+    LSYNC();
+}
+
+__device__ __forceinline__ void write_slot(const Lds &L, int lane, int q, const Cdesc &p, double lam)
+{
+    if (lane == 0) {
+        L.s_vec[3 * q] = p.v0; L.s_vec[3 * q + 1] = p.v1; L.s_vec[3 * q + 2] = p.v2;
+        L.s_ss[q] = p.ss; L.s_d[q] = p.d; L.s_lam[q] = lam;
+        L.s_kb[q] = p.kb; L.s_ty[q] = p.ty; L.s_idx[q] = p.idx;
+    }
+}
+
+// mark / unmark a constraint as member of the working set
+__device__ __forceinline__ void set_member(const Lds &L, int lane, int ty, int idx, bool on, unsigned &cmask)
+{
+    if (ty < TY_COLL) {
+        if (lane == idx) cmask = on ? (cmask | (1u << ty)) : (cmask & ~(1u << ty));
+    } else if (lane == 0) {
+        const int bit = (ty == TY_COLL) ? RF_COLL : (ty == TY_SLKU ? RF_SLKU : RF_SLKL);
+        L.r_fl[idx] = on ? (L.r_fl[idx] | bit) : (L.r_fl[idx] & ~bit);
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// the step kernel: grid = S * C workgroups of 64 threads
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void dmpc_step_kernel(StepParams P)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const int S = P.S, G = P.G, C = P.C, nrmax = P.nrmax;
+    const int scene = blockIdx.x / P.c_count, ci = blockIdx.x - scene * P.c_count;
+    const int cl = P.c_first + ci;                                     // agent inside chunk g_local
+    const int gid = scene * P.c_count + ci;                            // index into the launch's arrays
+    const int var = P.variant;
+    const bool soft = (var == VAR_BOUND || var == VAR_BOUND2 || var == VAR_ALL3 || var == VAR_SOFTALL || var == VAR_REPAIR);
+
+    Lds L;
+    {
+        double *p = (double *)smem;
+        L.T = p; p += QMAX * LD;
+        L.tabH = p; p += 225; L.tabM = p; p += 225; L.tabP = p; p += 225;
+        L.a_s = p; p += 48; L.w_s = p; p += 48; L.za_s = p; p += 48; L.zw_s = p; p += 48; L.own_s = p; p += 48;
+        L.s_vec = p; p += 3 * QMAX;
+        L.s_ss = p; p += QMAX; L.s_d = p; p += QMAX; L.s_lam = p; p += QMAX;
+        L.r_xi = p; p += 3 * nrmax;
+        L.r_b = p; p += nrmax;
+        if (soft) { L.r_sd = p; p += nrmax; L.r_st = p; p += nrmax; L.r_slb = p; p += nrmax; L.r_eps = p; p += nrmax; L.r_ze = p; p += nrmax; }
+        else { L.r_sd = L.r_st = L.r_slb = L.r_eps = L.r_ze = nullptr; }
+        int *ip = (int *)p;
+        L.s_kb = ip; ip += QMAX; L.s_ty = ip; ip += QMAX; L.s_idx = ip; ip += QMAX;
+        L.r_kc = ip; ip += nrmax; L.r_fl = ip; ip += nrmax;
+    }
+
+    // ---------------------------------------------------------------- agent state (uniform)
+    Agent A;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        A.po[d] = P.x_p[3 * gid + d]; A.vo[d] = P.x_v[3 * gid + d];
+        A.ao[d] = P.x_a[3 * gid + d]; A.pf[d] = P.pf[3 * gid + d];
+        A.whi0[d] = P.pmax[d] - A.po[d];
+        A.wlo0[d] = P.pmin[d] - A.po[d];
+    }
+    // own previous prediction: prev_p = l(:,:,n)  (solveSoftDMPCbound.m:6)
+    const double *lT_own = P.lT + ((size_t)(P.g_local * S + scene) * N3) * C + cl;
+    double own = 0.0;
+    if (lane < N3) { own = lT_own[(size_t)lane * C]; L.own_s[lane] = own; }
+    LSYNC();
+
+    // ---------------------------------------------------------------- a5/a6: scan + rows
+    int nr = 0, viol_k = 0, status = 0;
+    bool rows_exist = false, violation = false;
+    const double rmin = P.rmin;
+    const bool near_sel = (var == VAR_BOUND || var == VAR_BOUND2 || var == VAR_ALL3 || var == VAR_ONDEMAND);
+    const bool coll_check = (var == VAR_BOUND || var == VAR_BOUND2 || var == VAR_ALL3 || var == VAR_REPAIR);
+    const bool skip_k1 = (var == VAR_BOUND2 || var == VAR_ALL3 || var == VAR_REPAIR);
+
+    // appends the rows of horizon step ke (evaluated positions) constraining step kc for every
+    // neighbour with dist < sel_r (or all), in increasing neighbour index (CollConstrSoftDMPC.m:11-31)
+    auto build_rows = [&](int ksel, int ke, int kc, double sel_r, bool sel_all) {
+        // selection distance is taken at step ksel (viol_constr of CheckCollSoftDMPC.m:12), the row
+        // itself is evaluated at step ke and constrains step kc
+        const double qx = L.own_s[3 * ksel], qy = L.own_s[3 * ksel + 1], qz = L.own_s[3 * ksel + 2];
+        const double px = L.own_s[3 * ke], py = L.own_s[3 * ke + 1], pz = L.own_s[3 * ke + 2];
+        const double sh = (double)(kc + 1) * P.h;
+        const double a0x = A.po[0] + sh * A.vo[0], a0y = A.po[1] + sh * A.vo[1], a0z = A.po[2] + sh * A.vo[2];
+        for (int r = 0; r < G; ++r) {
+            const double *bsel = P.lT + ((size_t)(r * S + scene) * N3 + 3 * ksel) * C;
+            const double *base = P.lT + ((size_t)(r * S + scene) * N3 + 3 * ke) * C;
+            for (int j0 = 0; j0 < C; j0 += 64) {
+                const int jj = j0 + lane;
+                const bool valid = jj < C && !(r == P.g_local && jj == cl);
+                double dx = 0, dy = 0, dz = 0, dist = 1e300, dsel = 1e300;
+                if (valid) {
+                    dx = px - base[jj]; dy = py - base[(size_t)C + jj]; dz = pz - base[2 * (size_t)C + jj];
+                    const double ez = dz * P.e1z;
+                    dist = sqrt(dx * dx + dy * dy + ez * ez);
+                    if (ksel == ke) dsel = dist;
+                    else if (!sel_all) {
+                        const double sx = qx - bsel[jj], sy = qy - bsel[(size_t)C + jj];
+                        const double sz = (qz - bsel[2 * (size_t)C + jj]) * P.e1z;
+                        dsel = sqrt(sx * sx + sy * sy + sz * sz);
+                    }
+                }
+                const bool sel = valid && (sel_all || dsel < sel_r);
+                const unsigned long long m = __ballot(sel);
+                const int pos = nr + lanes_below(m, lane);
+                if (sel && pos < nrmax) {
+                    const double x0 = dx, x1 = dy, x2 = dz * P.e2z;   // diff = E2*(p - pj)
+                    // r = dist*(rmin - dist + diff*p/dist) - diff*A_initp(kc)*[po;vo]   (:21)
+                    const double rr = dist * (rmin - dist + (x0 * px + x1 * py + x2 * pz) / dist) - (x0 * a0x + x1 * a0y + x2 * a0z);
+                    L.r_xi[3 * pos] = x0; L.r_xi[3 * pos + 1] = x1; L.r_xi[3 * pos + 2] = x2;
+                    L.r_b[pos] = -rr;
+                    L.r_kc[pos] = kc;
+                    L.r_fl[pos] = 0;
+                    if (soft) {
+                        double sd = dist, st = P.term, slb = -0.05;
+                        if (var == VAR_BOUND2 || var == VAR_ALL3) slb = -0.01;           // bound2:77, all:92
+                        else if (var == VAR_SOFTALL) { sd = 1.0; st = -1e5; slb = -INFINITY; }  // solveSoftDMPC.m:21,65
+                        else if (var == VAR_REPAIR) { st = P.term / dist; slb = -INFINITY; }    // repair:77,81
+                        L.r_sd[pos] = sd; L.r_st[pos] = st; L.r_slb[pos] = slb; L.r_eps[pos] = 0.0;
+                    }
+                }
+                nr += __popcll(m);
+            }
+        }
+    };
+
+    if (var == VAR_HARD) {
+        // solveHardDMPC.m:18-22 + CollConstrHardDMPC.m:19: every k, neighbours with dist < 1
+        for (int k = 0; k < K; ++k) build_rows(k, k, k, 1.0, false);
+        rows_exist = (G * C > 1);   // preallocated zero rows make Ain_coll non-empty
+    } else {
+        for (int k = 0; k < K; ++k) {
+            const double px = L.own_s[3 * k], py = L.own_s[3 * k + 1], pz = L.own_s[3 * k + 2];
+            bool any = false;
+            double mind = 1e300;
+            for (int r = 0; r < G; ++r) {
+                const double *base = P.lT + ((size_t)(r * S + scene) * N3 + 3 * k) * C;
+                for (int j0 = 0; j0 < C; j0 += 64) {
+                    const int jj = j0 + lane;
+                    const bool valid = jj < C && !(r == P.g_local && jj == cl);
+                    if (valid) {
+                        const double dx = px - base[jj], dy = py - base[(size_t)C + jj];
+                        const double ez = (pz - base[2 * (size_t)C + jj]) * P.e1z;
+                        const double dist = sqrt(dx * dx + dy * dy + ez * ez);
+                        any = any || (dist < rmin);            // CheckCollSoftDMPC.m:11
+                        mind = fmin(mind, dist);
+                    }
+                }
+            }
+            if (!__any(any)) continue;
+            if (var == VAR_ALL3) violation = true;   // solveSoftDMPCall.m:22 (some_violation)
+            if (coll_check && k == 0) {
+                mind = wave_min(mind);
+                if (mind < rmin - 0.05) { status = ST_COLL; viol_k = 1; break; }   // :25-31
+            }
+            if (skip_k1 && k == 0) continue;          // solveSoftDMPCbound2.m:29-31
+            viol_k = k + 1; violation = true; rows_exist = true;
+            if (var == VAR_ALL3) {                     // solveSoftDMPCall.m:34-48: steps k-1,k,k+1
+                const int k0 = (k == 1) ? k : k - 1, k1 = (k == K - 1) ? k : k + 1;
+                for (int kk = k0; kk <= k1; ++kk) build_rows(k, kk, kk, 3.0 * rmin, false);
+            } else {
+                const int kc = (var == VAR_BOUND2) ? k - 1 : k;   // CollConstrSoftDMPC2.m:8
+                build_rows(k, k, kc, 3.0 * rmin, !near_sel);
+            }
+            break;
+        }
+    }
+    LSYNC();
+    const int nrows_built = nr;
+    if (nr > nrmax) { status |= ST_CAPACITY; nr = nrmax; }
+
+    // ---------------------------------------------------------------- cost case + tables (a7, :43-58)
+    int ccase = 2;
+    {
+        const double dn = sqrt((A.po[0] - A.pf[0]) * (A.po[0] - A.pf[0]) + (A.po[1] - A.pf[1]) * (A.po[1] - A.pf[1]) +
+                               (A.po[2] - A.pf[2]) * (A.po[2] - A.pf[2]));
+        const bool far = (var == VAR_ELLIP) ? (dn > 1.0) : (dn >= 1.0);
+        if (!rows_exist && far) ccase = 0;
+        else if (!rows_exist && dn < 1.0) ccase = 1;
+    }
+    const double qw = ccase == 0 ? 1000.0 : (ccase == 1 ? 10000.0 : P.Q1);
+    const double sw = ccase == 2 ? ((var == VAR_ALL3) ? 10.0 : P.S1) : 10.0;
+    {
+        const double *src = P.tables + (size_t)ccase * 675;
+        for (int i = lane; i < 675; i += 64) L.tabH[i] = src[i];   // tabH, tabM, tabP are contiguous
+    }
+    LSYNC();
+
+    const int k_l = lane / 3, ax_l = lane - 3 * k_l;
+    // unconstrained minimiser per axis: a_unc = -H1^-1 f,  f = -2(q L_K'(pf - A0_K x0) + s [ao;0..])
+    //   => a_unc(k) = 2 q g M1[k][K-1] + 2 s ao H1inv[k][0],  g = pf - (po + K h vo)      (:88/:93)
+    double a_unc = 0.0, w_unc = 0.0;
+    if (lane < N3) {
+        const double gax = sel3(A.pf, ax_l) - (sel3(A.po, ax_l) + (double)K * P.h * sel3(A.vo, ax_l));
+        a_unc = 2.0 * qw * gax * L.tabM[k_l * 15 + (K - 1)] + 2.0 * sw * sel3(A.ao, ax_l) * L.tabH[k_l * 15];
+        L.a_s[lane] = a_unc;
+    }
+    LSYNC();
+    if (lane < N3) {
+        const double h2 = P.h * P.h;
+        for (int kk = 0; kk <= k_l; ++kk) w_unc += (0.5 * h2 + (double)(k_l - kk) * h2) * L.a_s[3 * kk + ax_l];   // getPosMat.m
+    }
+    LSYNC();
+
+    // ---------------------------------------------------------------- a7: dual active-set solve
+    const bool ladder = (var == VAR_BOUND || var == VAR_BOUND2 || var == VAR_ALL3);
+    const int max_tries = P.max_tries > 0 ? P.max_tries : 30;
+    int tries = 0, iters_total = 0, maxq = 0, q = 0;
+    bool solved = false;
+    double a = 0.0, w = 0.0;
+    const double tol = 1e-10;
+
+    if (!(status & (ST_COLL | ST_CAPACITY))) {
+        while (tries < max_tries) {
+            tries++;
+            // reset working set
+            q = 0;
+            unsigned cmask = 0;
+            for (int i = lane; i < nr; i += 64) L.r_fl[i] = 0;
+            LSYNC();
+            int rc = 0;   // 0 running/ok, 1 infeasible, 2 capacity, 3 itercap
+            int iters = 0;
+            for (;;) {
+                primal(L, lane, q, nr, soft, a_unc, w_unc, a, w);
+                // refinement of the active-set residual: lam += T T' rho
+                if (q > 0) {
+                    for (int pass = 0; pass < 3; ++pass) {
+                        double rho = (lane < q) ? (slot_value(L, lane, L.a_s, L.w_s, L.r_eps) - L.s_d[lane]) : 0.0;
+                        const double mx = wave_max(fabs(rho));
+                        if (!(mx > 1e-13)) break;
+                        double dvj = 0.0;
+                        for (int i = 0; i < q; ++i) dvj += L.T[i * LD + (lane < q ? lane : 0)] * readlane_d(rho, i);
+                        if (lane >= q) dvj = 0.0;
+                        double ri = 0.0;
+                        for (int j = 0; j < q; ++j) ri += L.T[(lane < q ? lane : 0) * LD + j] * readlane_d(dvj, j);
+                        if (lane < q) L.s_lam[lane] += ri;
+                        LSYNC();
+                        primal(L, lane, q, nr, soft, a_unc, w_unc, a, w);
+                    }
+                }
+                // ---- most violated constraint not in the working set
+                double bestv = tol; int bestc = -1;
+                if (lane < N3) {
+                    const double sh = (double)(k_l + 1) * P.h * sel3(A.vo, ax_l);
+                    const double c0 = a - P.alim, c1 = -a - P.alim;
+                    const double c2 = w - (sel3(A.whi0, ax_l) - sh), c3 = (sel3(A.wlo0, ax_l) - sh) - w;
+                    if (!(cmask & 1u) && c0 > bestv) { bestv = c0; bestc = (TY_BOXHI << 16) | lane; }
+                    if (!(cmask & 2u) && c1 > bestv) { bestv = c1; bestc = (TY_BOXLO << 16) | lane; }
+                    if (!(cmask & 4u) && c2 > bestv) { bestv = c2; bestc = (TY_POSHI << 16) | lane; }
+                    if (!(cmask & 8u) && c3 > bestv) { bestv = c3; bestc = (TY_POSLO << 16) | lane; }
+                }
+                for (int i = lane; i < nr; i += 64) {
+                    const int fl = L.r_fl[i], kc = L.r_kc[i];
+                    double v = -(L.r_xi[3 * i] * L.w_s[3 * kc] + L.r_xi[3 * i + 1] * L.w_s[3 * kc + 1] + L.r_xi[3 * i + 2] * L.w_s[3 * kc + 2]) - L.r_b[i];
+                    if (soft && (fl & RF_LIVE)) {
+                        const double e = L.r_eps[i];
+                        v += L.r_sd[i] * e;
+                        if (!(fl & RF_SLKU) && e > bestv) { bestv = e; bestc = (TY_SLKU << 16) | i; }
+                        const double lo = L.r_slb[i] - e;   // -eps <= -slb
+                        if (!(fl & RF_SLKL) && lo > bestv) { bestv = lo; bestc = (TY_SLKL << 16) | i; }
+                    }
+                    if (!(fl & RF_COLL) && v > bestv) { bestv = v; bestc = (TY_COLL << 16) | i; }
+                }
+                const double vmax = wave_max(bestv);
+                const unsigned long long wm = __ballot(bestc >= 0 && bestv == vmax);
+                if (wm == 0ull) break;   // optimal
+                const int src = __ffsll((long long)wm) - 1;
+                const int pcode = readlane_i(bestc, src);
+                double vp = readlane_d(bestv, src);
+                Cdesc p = make_desc(pcode >> 16, pcode & 0xffff, L, A, P, soft);
+                // lazily instantiate the eps<=0 pin of a soft row that becomes active (S(u,u) = 1/2)
+                if (p.ty == TY_COLL && p.si >= 0 && !(L.r_fl[p.idx] & RF_LIVE)) {
+                    if (q >= QMAX - 1) { rc = 2; break; }
+                    Cdesc u = make_desc(TY_SLKU, p.idx, L, A, P, soft);
+                    if (lane < q) { L.T[lane * LD + q] = 0.0; L.T[q * LD + lane] = 0.0; }
+                    if (lane == 0) { L.T[q * LD + q] = 1.4142135623730951; L.r_fl[p.idx] |= (RF_LIVE | RF_SLKU); }
+                    write_slot(L, lane, q, u, -L.r_st[p.idx]);
+                    q++;
+                    LSYNC();
+                }
+                double lam_p = 0.0;
+                const double spp = sdot_self(L, p);
+                // ---- inner loop: partial steps until p can be added
+                for (;;) {
+                    if (++iters > ITER_CAP) { rc = 3; break; }
+                    const int ls = lane < q ? lane : 0;
+                    double sv = (lane < q) ? sdot_slot(L, lane, p) : 0.0;
+                    double dvj = 0.0;
+                    for (int i = 0; i < q; ++i) dvj += L.T[i * LD + ls] * readlane_d(sv, i);
+                    if (lane >= q) dvj = 0.0;
+                    double ri = 0.0;
+                    for (int j = 0; j < q; ++j) ri += L.T[ls * LD + j] * readlane_d(dvj, j);
+                    if (lane >= q) ri = 0.0;
+                    // step direction z = H^-1 (n_p - N r) in a- and position space
+                    double za = 0.0, zw = 0.0;
+                    if (lane < N3) {
+                        const double vpax = ax_l == 0 ? p.v0 : (ax_l == 1 ? p.v1 : p.v2);
+                        if (p.ty <= TY_COLL) {
+                            if (p.isA) { za += vpax * L.tabH[k_l * 15 + p.kb]; zw += vpax * L.tabM[p.kb * 15 + k_l]; }
+                            else { za += vpax * L.tabM[k_l * 15 + p.kb]; zw += vpax * L.tabP[k_l * 15 + p.kb]; }
+                        }
+                        for (int j = 0; j < q; ++j) {
+                            const int ty = L.s_ty[j];
+                            if (ty > TY_COLL) continue;
+                            const int kb = L.s_kb[j];
+                            const double coef = -readlane_d(ri, j) * L.s_vec[3 * j + ax_l];
+                            if (ty < TY_POSHI) { za += coef * L.tabH[k_l * 15 + kb]; zw += coef * L.tabM[kb * 15 + k_l]; }
+                            else { za += coef * L.tabM[k_l * 15 + kb]; zw += coef * L.tabP[k_l * 15 + kb]; }
+                        }
+                        L.za_s[lane] = za; L.zw_s[lane] = zw;
+                    }
+                    if (soft) {   // slack part of z: z_eps(i) = 1/2 (sigma_p[si_p==i] - sum_j r_j sigma_j[si_j==i])
+                        for (int i = lane; i < nr; i += 64) {
+                            double e = 0.0;
+                            if (L.r_fl[i] & RF_LIVE) {
+                                if (p.si == i) e += p.ss;
+                                for (int j = 0; j < q; ++j)
+                                    if (L.s_ty[j] >= TY_COLL && L.s_idx[j] == i) e -= readlane_d(ri, j) * L.s_ss[j];
+                                e *= 0.5;
+                            }
+                            L.r_ze[i] = e;
+                        }
+                    }
+                    LSYNC();
+                    // delta = z'Hz = n_p'z - sum_j r_j n_j'z   (robust against round-off in r)
+                    double part = (lane < q) ? (-ri * slot_value(L, lane, L.za_s, L.zw_s, L.r_ze)) : 0.0;
+                    if (lane == 63) {
+                        const double *base = p.isA ? L.za_s : L.zw_s;
+                        double v = p.v0 * base[3 * p.kb] + p.v1 * base[3 * p.kb + 1] + p.v2 * base[3 * p.kb + 2];
+                        if (p.si >= 0) v += p.ss * L.r_ze[p.si];
+                        part += v;
+                    }
+                    const double delta = wave_sum(part);
+                    const bool dependent = !(delta > 1e-13 * spp);
+                    const double t2 = dependent ? INFINITY : vp / delta;
+                    // ratio test on the multipliers
+                    const double ratio = (lane < q && ri > 0.0) ? (L.s_lam[lane] / ri) : INFINITY;
+                    const double t1 = wave_min(ratio);
+                    const double t = fmin(t1, t2);
+                    if (!(t < INFINITY)) { rc = 1; break; }
+                    if (lane < q) L.s_lam[lane] -= t * ri;
+                    lam_p += t;
+                    if (!dependent) vp -= t * delta;
+                    if (t2 <= t1) {
+                        // full step: append p (new column of T = [-r/rho ; 1/rho])
+                        if (q >= QMAX) { rc = 2; break; }
+                        const double rho = sqrt(delta);
+                        if (lane < q) { L.T[lane * LD + q] = -ri / rho; L.T[q * LD + lane] = 0.0; }
+                        if (lane == 0) L.T[q * LD + q] = 1.0 / rho;
+                        write_slot(L, lane, q, p, lam_p);
+                        set_member(L, lane, p.ty, p.idx, true, cmask);
+                        q++;
+                        if (q > maxq) maxq = q;
+                        LSYNC();
+                        break;
+                    }
+                    // partial step: drop the blocking constraint
+                    const unsigned long long bm = __ballot(lane < q && ri > 0.0 && ratio == t1);
+                    const int l = __ffsll((long long)bm) - 1;
+                    const int dty = L.s_ty[l], didx = L.s_idx[l];
+                    LSYNC();
+                    set_member(L, lane, dty, didx, false, cmask);
+                    remove_slot(L, lane, q, l);
+                    // de-instantiate the pin of a soft row whose collision row just left the set
+                    if (soft && dty == TY_COLL && didx != ((p.ty == TY_COLL) ? p.idx : -1)) {
+                        const int fl = L.r_fl[didx];
+                        if ((fl & RF_LIVE) && (fl & RF_SLKU) && !(fl & RF_SLKL)) {
+                            const unsigned long long um = __ballot(lane < q && L.s_ty[lane] == TY_SLKU && L.s_idx[lane] == didx);
+                            const int ul = __ffsll((long long)um) - 1;
+                            LSYNC();
+                            if (lane == 0) L.r_fl[didx] = 0;
+                            remove_slot(L, lane, q, ul);
+                        }
+                    }
+                }
+                if (rc) break;
+                // pin added while its collision row is not active: decoupled again -> drop both
+                if (soft && p.ty == TY_SLKU && !(L.r_fl[p.idx] & (RF_COLL | RF_SLKL))) {
+                    const unsigned long long um = __ballot(lane < q && L.s_ty[lane] == TY_SLKU && L.s_idx[lane] == p.idx);
+                    const int ul = __ffsll((long long)um) - 1;
+                    LSYNC();
+                    if (lane == 0) L.r_fl[p.idx] = 0;
+                    remove_slot(L, lane, q, ul);
+                }
+            }
+            iters_total += iters;
+            if (rc == 0) { solved = true; break; }
+            if (rc == 2) { status |= ST_CAPACITY; break; }
+            if (rc == 3) { status |= ST_ITERCAP; break; }
+            // infeasible: retry ladder (solveSoftDMPCbound.m:147-153): lb_eps *= 2, term *= 2
+            if (ladder && violation) {
+                for (int i = lane; i < nr; i += 64) { L.r_slb[i] *= 2.0; L.r_st[i] *= 2.0; }
+                LSYNC();
+                continue;
+            }
+            if (ladder || var == VAR_REPAIR) tries = (var == VAR_REPAIR && P.max_tries <= 0) ? 10 : max_tries;
+            break;
+        }
+        if (!solved && !(status & (ST_CAPACITY | ST_ITERCAP))) status |= ST_INFEAS;
+    }
+
+    // ---------------------------------------------------------------- a9/a10: propagate, outputs
+    int nslack = 0;
+    if (solved) {
+        status |= ST_SOLVED;
+        if (soft) {
+            int cnt = 0;
+            for (int i = lane; i < nr; i += 64) cnt += (L.r_eps[i] < -1e-12) ? 1 : 0;
+            nslack = (int)wave_sum((double)cnt);
+        }
+    }
+    double p_out = 0.0, v_out = 0.0, a_out = 0.0;
+    if (solved && lane < N3) {
+        // p = A_p a + A_initp [po;vo] ; v = A_v a + vo   (propStatedmpc.m:3-4)
+        p_out = w + (sel3(A.po, ax_l) + (double)(k_l + 1) * P.h * sel3(A.vo, ax_l));
+        double sv = 0.0;
+        for (int kk = 0; kk <= k_l; ++kk) sv += L.a_s[3 * kk + ax_l];
+        v_out = P.h * sv + sel3(A.vo, ax_l);
+        a_out = a;
+    }
+    if (solved) {
+        const bool ob_check = !(var == VAR_ELLIP || var == VAR_SOFTALL);
+        if (ob_check) {   // is_inbounds.m:2-5 on p(:,1)
+            const double tolb = 50e-3;
+            bool bad = false;
+            if (lane < 3) bad = !(p_out < sel3(P.pmax, lane) + tolb) || !(p_out > sel3(P.pmin, lane) - tolb);
+            if (__any(bad)) status |= ST_OUTBOUND;
+        }
+    }
+    if (lane < N3) {
+        P.p_out[(size_t)gid * N3 + lane] = p_out;
+        P.v_out[(size_t)gid * N3 + lane] = v_out;
+        P.a_out[(size_t)gid * N3 + lane] = a_out;
+        if (P.lT_next) P.lT_next[((size_t)scene * N3 + lane) * C + cl] = solved ? p_out : own;
+    }
+    if (lane == 0) {
+        P.status[gid] = status;
+        if (P.info) {
+            int *inf = P.info + (size_t)gid * 8;
+            inf[0] = viol_k; inf[1] = nrows_built; inf[2] = tries; inf[3] = ccase;
+            inf[4] = iters_total; inf[5] = nslack; inf[6] = solved ? q : 0; inf[7] = maxq;
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// small layout / bookkeeping kernels
+// --------------------------------------------------------------------------------------------
+
+// rows[S][N][3K] -> lT[G][S][3K][C], N = G*C
+__global__ void table_from_rows_kernel(int S, int G, int C, const double *__restrict__ rows, double *__restrict__ lT)
+{
+    const size_t total = (size_t)S * G * C * N3;
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        // t enumerates the destination (coalesced writes): [g][s][j][c]
+        const int c = (int)(t % C);
+        size_t u = t / C;
+        const int j = (int)(u % N3); u /= N3;
+        const int s = (int)(u % S);
+        const int g = (int)(u / S);
+        lT[t] = rows[((size_t)s * (G * C) + (size_t)g * C + c) * N3 + j];
+    }
+}
+
+// x <- first horizon column for solved agents (dmpc_soft_bound.m:132-134)
+__global__ void advance_kernel(int count, const double *__restrict__ p, const double *__restrict__ v,
+                               const double *__restrict__ a, const int *__restrict__ status, double *x_p, double *x_v, double *x_a)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count * 3) return;
+    const int ag = i / 3, d = i - 3 * ag;
+    if (status[ag] & ST_SOLVED) {
+        x_p[i] = p[(size_t)ag * N3 + d];
+        x_v[i] = v[(size_t)ag * N3 + d];
+        x_a[i] = a[(size_t)ag * N3 + d];
+    }
+}
+
+// initDMPC.m:6-12: p(:,i) = po + t_i (pf - po)/10, v = a = 0 ; writes rows [count][3K]
+__global__ void init_rows_kernel(int count, double h, const double *__restrict__ po, const double *__restrict__ pf,
+                                 double *__restrict__ l_rows)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count * N3) return;
+    const int ag = i / N3, j = i - ag * N3;
+    const int k = j / 3, d = j - 3 * k;
+    const double t = (double)k * h;
+    const double diff = pf[3 * ag + d] - po[3 * ag + d];
+    l_rows[i] = po[3 * ag + d] + 1 * t * diff / 10;
+}
+
+// pk/vk/ak(:,k,n) = state after MPC step k   (dmpc_soft_bound.m:132-134); hist: [S][N][KT][3]
+__global__ void record_kernel(int S, int N, int KT, int k, const double *__restrict__ x_p, const double *__restrict__ x_v,
+                              const double *__restrict__ x_a, double *pk, double *vk, double *ak)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S * N * 3) return;
+    const int ag = i / 3, d = i - 3 * ag;
+    const size_t o = ((size_t)ag * KT + k) * 3 + d;
+    pk[o] = x_p[i]; vk[o] = x_v[i]; ak[o] = x_a[i];
+}
+
+// one block per scene: flags[0] = ReachedGoal.m:3-11 (max_i ||p_i - pf_i|| < tol), flags[1] = OR of status bits
+__global__ void scene_reduce_kernel(int N, double tol, const double *__restrict__ x_p, const double *__restrict__ pf,
+                                    const int *__restrict__ status, int *flags)
+{
+    __shared__ double smax[256];
+    __shared__ int sor[256];
+    const int s = blockIdx.x;
+    double m = 0.0; int o = 0;
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+        const size_t b = ((size_t)s * N + i) * 3;
+        const double dx = x_p[b] - pf[b], dy = x_p[b + 1] - pf[b + 1], dz = x_p[b + 2] - pf[b + 2];
+        m = fmax(m, sqrt(dx * dx + dy * dy + dz * dz));
+        o |= status[(size_t)s * N + i];
+    }
+    smax[threadIdx.x] = m; sor[threadIdx.x] = o;
+    __syncthreads();
+    for (int w = blockDim.x / 2; w >= 1; w >>= 1) {
+        if ((int)threadIdx.x < w) { smax[threadIdx.x] = fmax(smax[threadIdx.x], smax[threadIdx.x + w]); sor[threadIdx.x] |= sor[threadIdx.x + w]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { flags[(size_t)s * 2] = smax[0] < tol ? 1 : 0; flags[(size_t)s * 2 + 1] = sor[0]; }
+}
+
+}  // namespace dmpc

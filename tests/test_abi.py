@@ -1,0 +1,56 @@
+"""CPU: the C-ABI library loads and exports every symbol include/dmpc_hip.h declares; host-only
+entry points work; compute entry points fail loudly without a GPU (no silent fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import multiagent_planning_amd as mp
+from multiagent_planning_amd import _lib
+from helpers import ROOT, load_golden
+
+
+def _header_symbols():
+    txt = open(os.path.join(ROOT, "include", "dmpc_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(dmpc_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    syms = _header_symbols()
+    assert len(syms) >= 14
+    for s in syms:
+        assert hasattr(lib, s), f"libdmpc_hip.so does not export {s}"
+    assert sorted(_lib.ABI_SYMBOLS) == syms
+
+
+def test_model_matrices_match_goldens_bitwise():
+    g, kw = load_golden("failure_rate2_bound")
+    Lam, Av, A0, Dl = mp.model_matrices(kw["h"])
+    assert np.array_equal(Lam, g["A"]) and np.array_equal(Av, g["A_v"])
+    assert np.array_equal(A0, g["A_initp"]) and np.array_equal(Dl, g["Delta"])
+
+
+def test_posvel_matrix():
+    A = mp.posvel_matrix(0.2, 15)
+    Lam, Av, _, _ = mp.model_matrices(0.2)
+    assert np.allclose(A[0:3], Lam[42:45]) and np.allclose(A[3:6], Av[42:45])
+    assert np.array_equal(A[6:9, 42:45], np.eye(3)) and np.array_equal(A[9:12, 0:3], np.eye(3))
+
+
+def test_bad_params_rejected():
+    L = _lib.load()
+    p = _lib.make_params("bound", K=10)
+    assert not L.dmpc_create(ctypes.byref(p), 0)
+    assert b"K" in L.dmpc_last_error(None)
+
+
+def test_no_silent_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(mp.DmpcError):
+        mp.Dmpc("bound")

@@ -1,0 +1,86 @@
+"""GPU: parity of the HIP path (through the C ABI) against the CPU oracle and the MATLAB goldens.
+
+Protocol (SURVEY.md Appendix C "Parity protocol"): teacher-forced single MPC steps -- identical
+(state, table) inputs on both sides; bar: identical branch records (status, first violating step,
+row count, cost case, retry count) and trajectory l_inf(p,v,a) <= 1e-9 (fp64) against the oracle;
+two-tier tolerance against the quadprog records.
+"""
+import numpy as np
+import pytest
+
+import multiagent_planning_amd as mp
+from oracle import oracle as orc
+from helpers import ALL_VARIANTS, load_golden, oracle_params, init_table, step14_inputs, compare_to_oracle
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"softall": 2e-8, "repair": 2e-8}   # |term| = 1e5-scale multipliers: see DESIGN.md section 6
+
+
+@pytest.mark.parametrize("name,variant", [("failure_rate2_bound", "bound"), ("comp_kctr_3_bound2", "bound2")])
+def test_golden_step14(name, variant):
+    g, kw = load_golden(name)
+    l, xp, xv, xa, pf = step14_inputs(g)
+    nd = int(g["n_done"])
+    with_gpu = mp.Dmpc(variant, **kw)
+    out = with_gpu.step_batch(l, xp, xv, xa, pf)
+    ref = orc.step(oracle_params(variant, kw), l, xp, xv, xa, pf)
+    compare_to_oracle(out, ref, 1e-9, name)
+    err = np.abs(out["p"][:nd] - g["new_l"][:nd]).max(axis=1)
+    assert (err <= 2e-6).sum() >= int(0.75 * nd)
+    assert np.median(err) < 1e-8
+    assert out["status"][nd] == mp.ST_COLL
+
+
+@pytest.mark.parametrize("variant", ALL_VARIANTS)
+@pytest.mark.parametrize("name", ["failure_rate2_bound", "comp_kctr_3_bound2"])
+def test_all_variants_vs_oracle_on_recorded_scenes(name, variant):
+    g, kw = load_golden(name)
+    l, xp, xv, xa, pf = step14_inputs(g)
+    out = mp.Dmpc(variant, **kw).step_batch(l, xp, xv, xa, pf)
+    ref = orc.step(oracle_params(variant, kw), l, xp, xv, xa, pf)
+    assert not np.any(out["status"] & (mp.ST_CAPACITY | mp.ST_ITERCAP))
+    compare_to_oracle(out, ref, TOL.get(variant, 1e-9), f"{name}/{variant}")
+
+
+@pytest.mark.parametrize("name,variant", [("failure_rate2_bound", "bound"), ("comp_kctr_3_bound2", "bound2")])
+def test_step2_from_init(name, variant):
+    g, kw = load_golden(name)
+    N = int(g["N"])
+    d = mp.Dmpc(variant, **kw)
+    l0, v0, a0 = d.init_batch(g["po"], g["pf"])
+    assert np.array_equal(l0, init_table(g["po"], g["pf"]))
+    z = np.zeros((N, 3))
+    out = d.step_batch(l0, g["po"], z, z, g["pf"])
+    ref = orc.step(oracle_params(variant, kw), l0, g["po"], z, z, g["pf"])
+    compare_to_oracle(out, ref, 1e-9, name + "/step2")
+    ea = np.abs(out["a"][:, :3] - g["ak"][:, 1]).max(axis=1)
+    assert (ea <= 1e-5).sum() >= N - 2
+
+
+def test_solve_one_matches_batch():
+    g, kw = load_golden("failure_rate2_bound")
+    l, xp, xv, xa, pf = step14_inputs(g)
+    d = mp.Dmpc("bound", **kw)
+    out = d.step_batch(l, xp, xv, xa, pf)
+    for n in (0, 1, 3, 10, 157, 169):
+        r = d.solve_one(l, n, xp[n], xv[n], xa[n], pf[n])
+        assert r["status"] == out["status"][n]
+        assert np.array_equal(r["p"], out["p"][n]) and np.array_equal(r["a"], out["a"][n])
+
+
+def test_scene_batching_is_independent():
+    """S scenes in one launch == S separate launches, bit for bit."""
+    g1, kw = load_golden("comp_kctr_3_bound2")
+    l, xp, xv, xa, pf = step14_inputs(g1)
+    rng = np.random.default_rng(3)
+    perm = rng.permutation(l.shape[0])
+    L2 = np.stack([l, l[perm]]); XP = np.stack([xp, xp[perm]]); XV = np.stack([xv, xv[perm]])
+    XA = np.stack([xa, xa[perm]]); PF = np.stack([pf, pf[perm]])
+    d = mp.Dmpc("bound2", **kw)
+    both = d.step_batch(L2, XP, XV, XA, PF)
+    one = d.step_batch(l, xp, xv, xa, pf)
+    assert np.array_equal(both["p"][0], one["p"]) and np.array_equal(both["status"][0], one["status"])
+    # permuting the agents of a scene permutes the answers (neighbour order only affects tie breaks)
+    assert np.array_equal(both["status"][1], one["status"][perm])
+    assert np.abs(both["p"][1] - one["p"][perm]).max() < 1e-9
