@@ -49,6 +49,7 @@ struct dmpc_ctx {
     DevBuf rows, lT, lT2, xp, xv, xa, pf, po, pout, vout, aout, status, info, hist_p, hist_v, hist_a, flags;
     // profiling
     int profile = 0;
+    double *dbg = nullptr; int dbg_agent = -1, dbg_cap = 0;   // development trace (dmpc_debug_trace)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     double prof_ms_sum = 0.0;
     int64_t prof_n = 0;
@@ -340,6 +341,7 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     P.lT = lT; P.x_p = x_p; P.x_v = x_v; P.x_a = x_a; P.pf = pf;
     P.p_out = p_out; P.v_out = v_out; P.a_out = a_out; P.lT_next = lT_next;
     P.status = status; P.info = info;
+    P.dbg = ctx->dbg; P.dbg_agent = ctx->dbg_agent; P.dbg_cap = ctx->dbg_cap;
     const size_t lds = step_lds_bytes(P.nrmax, variant_soft(p.variant));
     if ((int)lds > ctx->max_lds_set) {
         HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -358,6 +360,25 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
         ctx->events.push_back(ev);
     }
     ctx->solves += (int64_t)S * c_count;
+    return 0;
+}
+
+// development aid (not part of the public header): trace the active-set iterations of one agent
+extern "C" int dmpc_debug_trace(dmpc_ctx *ctx, int agent, int cap, double *host_out)
+{
+    if (!ctx) return -1;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (host_out && ctx->dbg) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, hipMemcpy(host_out, ctx->dbg, sizeof(double) * 8 * ctx->dbg_cap, hipMemcpyDeviceToHost));
+        return 0;
+    }
+    if (ctx->dbg) { (void)hipFree(ctx->dbg); ctx->dbg = nullptr; }
+    ctx->dbg_agent = agent; ctx->dbg_cap = cap;
+    if (agent >= 0 && cap > 0) {
+        HIPCHK(ctx, hipMalloc((void **)&ctx->dbg, sizeof(double) * 8 * cap));
+        HIPCHK(ctx, hipMemset(ctx->dbg, 0, sizeof(double) * 8 * cap));
+    }
     return 0;
 }
 

@@ -6,8 +6,8 @@ namespace dmpc {
 
 constexpr int K = 15;         // horizon k_hor (dmpc_soft_bound.m:13)
 constexpr int N3 = 3 * K;     // stacked acceleration / position vector length
-constexpr int QMAX = 48;      // working-set capacity (slots of the inverse factor T)
-constexpr int LD = QMAX + 1;  // odd leading dimension: conflict-free ds_read_b64 along rows and columns
+constexpr int QMAX = 64;      // working-set capacity (slots of the inverse factor T) == wave size
+constexpr int TPACK = QMAX * (QMAX + 1) / 2;   // packed upper-triangular storage of T
 constexpr int ITER_CAP = 4000;
 
 enum { VAR_BOUND = 0, VAR_BOUND2 = 1, VAR_ALL3 = 2, VAR_HARD = 3, VAR_ONDEMAND = 4, VAR_ELLIP = 5, VAR_SOFTALL = 6, VAR_REPAIR = 7 };
@@ -23,12 +23,14 @@ struct StepParams {
     double *p_out, *v_out, *a_out;        // [S][c_count][3K]
     double *lT_next;                      // [S][3K][C] or null
     int *status, *info;
+    double *dbg;            // optional per-iteration trace of agent dbg_agent (development aid)
+    int dbg_agent, dbg_cap;
 };
 
 // bytes of dynamic LDS the step kernel carves for a given row capacity
 inline size_t step_lds_bytes(int nrmax, bool soft)
 {
-    size_t dbl = (size_t)QMAX * LD + 675 + 5 * 48 + 3 * QMAX + 3 * QMAX + (size_t)nrmax * (4 + (soft ? 5 : 0));
+    size_t dbl = (size_t)TPACK + 675 + 5 * 48 + 3 * QMAX + 3 * QMAX + (size_t)nrmax * (4 + (soft ? 4 : 0));
     size_t ints = 3 * QMAX + 2 * (size_t)nrmax;
     return dbl * 8 + ints * 4;
 }

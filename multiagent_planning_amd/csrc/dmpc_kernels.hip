@@ -68,14 +68,14 @@ enum { TY_BOXHI = 0, TY_BOXLO = 1, TY_POSHI = 2, TY_POSLO = 3, TY_COLL = 4, TY_S
 enum { RF_COLL = 1, RF_SLKU = 2, RF_SLKL = 4, RF_LIVE = 8 };
 
 struct Lds {
-    double *T;      // QMAX x LD inverse Cholesky factor
+    double *T;      // packed upper-triangular inverse Cholesky factor (TPACK doubles)
     double *tabH, *tabM, *tabP;  // 15x15: H1^-1, H1^-1 L', L H1^-1 L'
-    double *a_s, *w_s, *za_s, *zw_s, *own_s;   // 48 each
+    double *a_s, *w_s, *own_s, *nu_s, *yt_s;   // 48 each
     double *s_vec;  // QMAX x 3
     double *s_ss, *s_d, *s_lam;
     double *r_xi;   // nrmax x 3
     double *r_b;
-    double *r_sd, *r_st, *r_slb, *r_eps, *r_ze;  // soft variants only
+    double *r_sd, *r_st, *r_slb, *r_eps;  // soft variants only
     int *s_kb, *s_ty, *s_idx;
     int *r_kc, *r_fl;
 };
@@ -176,6 +176,33 @@ __device__ __forceinline__ void primal(const Lds &L, int lane, int q, int nr, bo
     LSYNC();
 }
 
+// ---- packed upper-triangular inverse factor: T[i][j] (i <= j) at Tp[j(j+1)/2 + i] (column-major packed).
+// Triangular numbers mod 32 are a permutation, so "lane j reads column j" is conflict-free for
+// ds_read_b64, and "lane i reads row i of one column" is a contiguous read.
+__device__ __forceinline__ int tcol(int j) { return (j * (j + 1)) >> 1; }
+
+// y = T' x  (lane j gets y_j; x_i lives in lane i)
+__device__ __forceinline__ double t_tmul(const double *Tp, int lane, int q, double x)
+{
+    double acc = 0.0;
+    const int cj = tcol(lane < q ? lane : 0);
+    for (int i = 0; i < q; ++i) {
+        const double xi = readlane_d(x, i);
+        if (i <= lane && lane < q) acc += Tp[cj + i] * xi;
+    }
+    return acc;
+}
+// y = T x  (lane i gets y_i; x_j lives in lane j)
+__device__ __forceinline__ double t_mul(const double *Tp, int lane, int q, double x)
+{
+    double acc = 0.0;
+    for (int j = 0; j < q; ++j) {
+        const double xj = readlane_d(x, j);
+        if (j >= lane && lane < q) acc += Tp[tcol(j) + lane] * xj;
+    }
+    return acc;
+}
+
 // value n_j'x - d_j of the slot owned by this lane
 __device__ __forceinline__ double slot_value(const Lds &L, int j, const double *av, const double *wv, const double *ev)
 {
@@ -187,24 +214,23 @@ __device__ __forceinline__ double slot_value(const Lds &L, int j, const double *
 }
 
 // delete slot l from the working set: Givens rotations on adjacent columns zero row l of T
-// left-to-right, then row l and the last column are removed (stable inverse-factor downdate).
+// left-to-right; row l and the last column then drop out (stable inverse-factor downdate).  Fused
+// with the row deletion so that the packed storage never needs the transient fill-in: each lane
+// carries its row of the "current right column" in a register.
 __device__ __forceinline__ void remove_slot(const Lds &L, int lane, int &q, int l)
 {
+    double carry = (lane <= l) ? L.T[tcol(l) + lane] : 0.0;
     for (int j = l; j < q - 1; ++j) {
-        const double a_ = L.T[l * LD + j], b_ = L.T[l * LD + j + 1];
+        const double right = (lane <= j + 1) ? L.T[tcol(j + 1) + lane] : 0.0;
+        const double a_ = readlane_d(carry, l), b_ = readlane_d(right, l);
         const double rr = sqrt(a_ * a_ + b_ * b_);
-        if (rr > 1e-150) {
-            const double cc = b_ / rr, ss = a_ / rr;
-            if (lane < q) {
-                const double cj = L.T[lane * LD + j], cj1 = L.T[lane * LD + j + 1];
-                L.T[lane * LD + j] = cc * cj - ss * cj1;
-                L.T[lane * LD + j + 1] = ss * cj + cc * cj1;
-            }
-        }
-        LSYNC();
+        double cc = 1.0, ss = 0.0;
+        if (rr > 1e-150) { cc = b_ / rr; ss = a_ / rr; }
+        const double nl = cc * carry - ss * right;
+        const double nr_ = ss * carry + cc * right;
+        if (lane <= j + 1 && lane != l) L.T[tcol(j) + (lane < l ? lane : lane - 1)] = nl;
+        carry = nr_;
     }
-    for (int i = l + 1; i < q; ++i)
-        if (lane < q) L.T[(i - 1) * LD + lane] = L.T[i * LD + lane];
     // shift slot records
     const bool mv = lane > l && lane < q;
     double v0 = 0, v1 = 0, v2 = 0, ss = 0, d = 0, lam = 0; int kb = 0, ty = 0, idx = 0;
@@ -261,15 +287,15 @@ __global__ __launch_bounds__(64) void dmpc_step_kernel(StepParams P)
     Lds L;
     {
         double *p = (double *)smem;
-        L.T = p; p += QMAX * LD;
+        L.T = p; p += TPACK;
         L.tabH = p; p += 225; L.tabM = p; p += 225; L.tabP = p; p += 225;
-        L.a_s = p; p += 48; L.w_s = p; p += 48; L.za_s = p; p += 48; L.zw_s = p; p += 48; L.own_s = p; p += 48;
+        L.a_s = p; p += 48; L.w_s = p; p += 48; L.own_s = p; p += 48; L.nu_s = p; p += 48; L.yt_s = p; p += 48;
         L.s_vec = p; p += 3 * QMAX;
         L.s_ss = p; p += QMAX; L.s_d = p; p += QMAX; L.s_lam = p; p += QMAX;
         L.r_xi = p; p += 3 * nrmax;
         L.r_b = p; p += nrmax;
-        if (soft) { L.r_sd = p; p += nrmax; L.r_st = p; p += nrmax; L.r_slb = p; p += nrmax; L.r_eps = p; p += nrmax; L.r_ze = p; p += nrmax; }
-        else { L.r_sd = L.r_st = L.r_slb = L.r_eps = L.r_ze = nullptr; }
+        if (soft) { L.r_sd = p; p += nrmax; L.r_st = p; p += nrmax; L.r_slb = p; p += nrmax; L.r_eps = p; p += nrmax; }
+        else { L.r_sd = L.r_st = L.r_slb = L.r_eps = nullptr; }
         int *ip = (int *)p;
         L.s_kb = ip; ip += QMAX; L.s_ty = ip; ip += QMAX; L.s_idx = ip; ip += QMAX;
         L.r_kc = ip; ip += nrmax; L.r_fl = ip; ip += nrmax;
@@ -453,11 +479,8 @@ __global__ __launch_bounds__(64) void dmpc_step_kernel(StepParams P)
                         double rho = (lane < q) ? (slot_value(L, lane, L.a_s, L.w_s, L.r_eps) - L.s_d[lane]) : 0.0;
                         const double mx = wave_max(fabs(rho));
                         if (!(mx > 1e-13)) break;
-                        double dvj = 0.0;
-                        for (int i = 0; i < q; ++i) dvj += L.T[i * LD + (lane < q ? lane : 0)] * readlane_d(rho, i);
-                        if (lane >= q) dvj = 0.0;
-                        double ri = 0.0;
-                        for (int j = 0; j < q; ++j) ri += L.T[(lane < q ? lane : 0) * LD + j] * readlane_d(dvj, j);
+                        const double dvj = t_tmul(L.T, lane, q, rho);
+                        const double ri = t_mul(L.T, lane, q, dvj);
                         if (lane < q) L.s_lam[lane] += ri;
                         LSYNC();
                         primal(L, lane, q, nr, soft, a_unc, w_unc, a, w);
@@ -497,8 +520,8 @@ __global__ __launch_bounds__(64) void dmpc_step_kernel(StepParams P)
                 if (p.ty == TY_COLL && p.si >= 0 && !(L.r_fl[p.idx] & RF_LIVE)) {
                     if (q >= QMAX - 1) { rc = 2; break; }
                     Cdesc u = make_desc(TY_SLKU, p.idx, L, A, P, soft);
-                    if (lane < q) { L.T[lane * LD + q] = 0.0; L.T[q * LD + lane] = 0.0; }
-                    if (lane == 0) { L.T[q * LD + q] = 1.4142135623730951; L.r_fl[p.idx] |= (RF_LIVE | RF_SLKU); }
+                    if (lane < q) L.T[tcol(q) + lane] = 0.0;
+                    if (lane == 0) { L.T[tcol(q) + q] = 1.4142135623730951; L.r_fl[p.idx] |= (RF_LIVE | RF_SLKU); }
                     write_slot(L, lane, q, u, -L.r_st[p.idx]);
                     q++;
                     LSYNC();
@@ -508,52 +531,50 @@ __global__ __launch_bounds__(64) void dmpc_step_kernel(StepParams P)
                 // ---- inner loop: partial steps until p can be added
                 for (;;) {
                     if (++iters > ITER_CAP) { rc = 3; break; }
-                    const int ls = lane < q ? lane : 0;
-                    double sv = (lane < q) ? sdot_slot(L, lane, p) : 0.0;
-                    double dvj = 0.0;
-                    for (int i = 0; i < q; ++i) dvj += L.T[i * LD + ls] * readlane_d(sv, i);
-                    if (lane >= q) dvj = 0.0;
-                    double ri = 0.0;
-                    for (int j = 0; j < q; ++j) ri += L.T[ls * LD + j] * readlane_d(dvj, j);
-                    if (lane >= q) ri = 0.0;
-                    // step direction z = H^-1 (n_p - N r) in a- and position space
-                    double za = 0.0, zw = 0.0;
+                    const double sv = (lane < q) ? sdot_slot(L, lane, p) : 0.0;
+                    const double dvj = t_tmul(L.T, lane, q, sv);
+                    const double ri = t_mul(L.T, lane, q, dvj);
+                    // residual nu = n_p - N_W r, assembled EXPLICITLY as one vector in a-space
+                    //   nu_a = U + Lambda' Y   (U: box part, Y: position/collision part),  nu_eps per live slack
+                    // and delta = nu' H^-1 nu = z'Hz.  When p is (nearly) dependent on W, nu is small and the
+                    // round-off of r enters delta squared -- this makes the dependence / infeasibility test
+                    // reliable (a cancelling form such as spp - s'r is not).
+                    double Uacc = 0.0, Yacc = 0.0;
                     if (lane < N3) {
                         const double vpax = ax_l == 0 ? p.v0 : (ax_l == 1 ? p.v1 : p.v2);
-                        if (p.ty <= TY_COLL) {
-                            if (p.isA) { za += vpax * L.tabH[k_l * 15 + p.kb]; zw += vpax * L.tabM[p.kb * 15 + k_l]; }
-                            else { za += vpax * L.tabM[k_l * 15 + p.kb]; zw += vpax * L.tabP[k_l * 15 + p.kb]; }
-                        }
+                        if (p.ty <= TY_COLL && p.kb == k_l) { if (p.isA) Uacc += vpax; else Yacc += vpax; }
                         for (int j = 0; j < q; ++j) {
                             const int ty = L.s_ty[j];
-                            if (ty > TY_COLL) continue;
-                            const int kb = L.s_kb[j];
+                            if (ty > TY_COLL || L.s_kb[j] != k_l) continue;
                             const double coef = -readlane_d(ri, j) * L.s_vec[3 * j + ax_l];
-                            if (ty < TY_POSHI) { za += coef * L.tabH[k_l * 15 + kb]; zw += coef * L.tabM[kb * 15 + k_l]; }
-                            else { za += coef * L.tabM[k_l * 15 + kb]; zw += coef * L.tabP[k_l * 15 + kb]; }
+                            if (ty < TY_POSHI) Uacc += coef; else Yacc += coef;
                         }
-                        L.za_s[lane] = za; L.zw_s[lane] = zw;
-                    }
-                    if (soft) {   // slack part of z: z_eps(i) = 1/2 (sigma_p[si_p==i] - sum_j r_j sigma_j[si_j==i])
-                        for (int i = lane; i < nr; i += 64) {
-                            double e = 0.0;
-                            if (L.r_fl[i] & RF_LIVE) {
-                                if (p.si == i) e += p.ss;
-                                for (int j = 0; j < q; ++j)
-                                    if (L.s_ty[j] >= TY_COLL && L.s_idx[j] == i) e -= readlane_d(ri, j) * L.s_ss[j];
-                                e *= 0.5;
-                            }
-                            L.r_ze[i] = e;
-                        }
+                        L.yt_s[lane] = Yacc;
                     }
                     LSYNC();
-                    // delta = z'Hz = n_p'z - sum_j r_j n_j'z   (robust against round-off in r)
-                    double part = (lane < q) ? (-ri * slot_value(L, lane, L.za_s, L.zw_s, L.r_ze)) : 0.0;
-                    if (lane == 63) {
-                        const double *base = p.isA ? L.za_s : L.zw_s;
-                        double v = p.v0 * base[3 * p.kb] + p.v1 * base[3 * p.kb + 1] + p.v2 * base[3 * p.kb + 2];
-                        if (p.si >= 0) v += p.ss * L.r_ze[p.si];
-                        part += v;
+                    double nu = 0.0;
+                    if (lane < N3) {
+                        const double h2 = P.h * P.h;
+                        nu = Uacc;
+                        for (int kk = k_l; kk < K; ++kk) nu += (0.5 * h2 + (double)(kk - k_l) * h2) * L.yt_s[3 * kk + ax_l];
+                        L.nu_s[lane] = nu;
+                    }
+                    LSYNC();
+                    double part = 0.0;
+                    if (lane < N3) {
+                        double za = 0.0;
+                        for (int kk = 0; kk < K; ++kk) za += L.tabH[k_l * 15 + kk] * L.nu_s[3 * kk + ax_l];
+                        part = nu * za;
+                    }
+                    if (soft) {   // slack part: nu_eps(i) = sigma_p[si_p==i] - sum_j r_j sigma_j[si_j==i]; H_eps^-1 = 1/2
+                        for (int i = lane; i < nr; i += 64) {
+                            if (L.r_fl[i] & RF_LIVE) {
+                                double e = (p.si == i) ? p.ss : 0.0;
+                                for (int j = 0; j < q; ++j)
+                                    if (L.s_ty[j] >= TY_COLL && L.s_idx[j] == i) e -= readlane_d(ri, j) * L.s_ss[j];
+                                part += 0.5 * e * e;
+                            }
+                        }
                     }
                     const double delta = wave_sum(part);
                     const bool dependent = !(delta > 1e-13 * spp);
@@ -562,6 +583,10 @@ __global__ __launch_bounds__(64) void dmpc_step_kernel(StepParams P)
                     const double ratio = (lane < q && ri > 0.0) ? (L.s_lam[lane] / ri) : INFINITY;
                     const double t1 = wave_min(ratio);
                     const double t = fmin(t1, t2);
+                    if (P.dbg && gid == P.dbg_agent && lane == 0 && iters <= P.dbg_cap) {
+                        double *d = P.dbg + (size_t)(iters - 1) * 8;
+                        d[0] = (double)pcode; d[1] = (double)q; d[2] = delta; d[3] = spp; d[4] = t1; d[5] = t2; d[6] = vp; d[7] = lam_p;
+                    }
                     if (!(t < INFINITY)) { rc = 1; break; }
                     if (lane < q) L.s_lam[lane] -= t * ri;
                     lam_p += t;
@@ -570,8 +595,8 @@ __global__ __launch_bounds__(64) void dmpc_step_kernel(StepParams P)
                         // full step: append p (new column of T = [-r/rho ; 1/rho])
                         if (q >= QMAX) { rc = 2; break; }
                         const double rho = sqrt(delta);
-                        if (lane < q) { L.T[lane * LD + q] = -ri / rho; L.T[q * LD + lane] = 0.0; }
-                        if (lane == 0) L.T[q * LD + q] = 1.0 / rho;
+                        if (lane < q) L.T[tcol(q) + lane] = -ri / rho;
+                        if (lane == 0) L.T[tcol(q) + q] = 1.0 / rho;
                         write_slot(L, lane, q, p, lam_p);
                         set_member(L, lane, p.ty, p.idx, true, cmask);
                         q++;

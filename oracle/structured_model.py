@@ -17,6 +17,7 @@ import numpy as np
 
 BOXHI, BOXLO, POSHI, POSLO, COLL, SLKU, SLKL = range(7)
 DEBUG = False
+TRACE = None   # list collecting per-iteration records when set
 
 
 class Tables:
@@ -244,6 +245,8 @@ def solve_structured(Tbl, K, h, po, vo, ao, pf, alim, pmin, pmax, rows, stats=No
                     t = lam[j] / r[j]
                     if t < t1:
                         t1, l = t, j
+            if TRACE is not None:
+                TRACE.append((p.typ, p.idx, k, delta / spp, t1, t2, vp, lam_p))
             t = min(t1, t2)
             if not np.isfinite(t):
                 if stats is not None:
