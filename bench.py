@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py -- agent-QP solves/sec of the DMPC per-agent horizon QP (K = 15) on MI355X.
+
+Contract (one JSON line on rank 0):  python bench.py --gpus N --steps K --warmup W
+  * a "step" = ONE MPC step of the hot path (scan + rows + QP + propagate for every agent) over a
+    batch of S independent scenes ("trials", test/comp_hardsoft2.m:12) whose tables and states are
+    already resident in HBM; steady-state replay of a captured congested MPC step
+  * workload at 1 GPU = BASELINE.json configs[1]: 100 agents/scene, hard ellipsoidal constraints
+    (solveHardDMPC, constants of test/comp_hardsoft2.m), S scenes batched
+  * N > 1 GPUs: one process per GPU (torch.distributed / RCCL); every scene has 100*N agents in a
+    density-scaled box, rank r owns agents [100r, 100r+100) of every scene (contiguous clusters as
+    dmpc/cpp/dmpc.cpp:1600-1625) and each step ends with ONE all-gather of the new predictions
+    (the `l = new_l` / `prev_obs = obs` exchange).  Per-GPU work is fixed -> "scaling": "weak".
+  * value = solves of all ranks / max-over-ranks wall time between barriers.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def capture_state(dmpc, cfg, S, N, k_cap, seed):
+    """Closed-loop run of S scenes up to MPC step k_cap on the GPU (host-array API); returns the
+    table and states that are the INPUT of step k_cap+1.  Scenes that abort earlier (an agent
+    infeasible / collided, the reference `break`s the trial) keep the last valid state."""
+    from multiagent_planning_amd import workload as wl
+    po, pf = wl.make_scenes(cfg, S, N, seed)
+    l, _, _ = dmpc.init_batch(po, pf)
+    xp, xv, xa = po.copy(), np.zeros_like(po), np.zeros_like(po)
+    alive = np.ones(S, bool)
+    for k in range(1, k_cap):
+        out = dmpc.step_batch(l, xp, xv, xa, pf)
+        ok = (out["status"] == 1)
+        alive &= ok.all(axis=1)
+        upd = alive[:, None] & ok
+        l = np.where(upd[..., None], out["p"], l)
+        xp = np.where(upd[..., None], out["p"][..., :3], xp)
+        xv = np.where(upd[..., None], out["v"][..., :3], xv)
+        xa = np.where(upd[..., None], out["a"][..., :3], xa)
+    return l, xp, xv, xa, pf, alive
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--scenes", type=int, default=64, help="independent scenes batched per step")
+    ap.add_argument("--agents-per-gpu", type=int, default=100)
+    ap.add_argument("--config", default="C2")
+    ap.add_argument("--capture-step", type=int, default=12)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import multiagent_planning_amd as mp
+    from multiagent_planning_amd import workload as wl
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    G = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if G > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=G)
+
+    cfg = wl.CONFIGS[args.config]
+    C = args.agents_per_gpu
+    N = C * G
+    S = args.scenes
+    kw = wl.solver_kwargs(cfg, N)
+    dmpc = mp.Dmpc(cfg["variant"], device=local_rank, **kw)
+
+    # ---- synthetic inputs: captured congested step (identical on every rank: deterministic) ----
+    l, xp, xv, xa, pf, alive = capture_state(dmpc, cfg, S, N, args.capture_step, wl.SEED0 + 2)
+    # device-resident buffers in the kernel's layouts
+    def dev_t(a, dtype=torch.float64):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(dev, dtype)
+    rows = dev_t(l)                                                     # [S][N][45]
+    lT = torch.empty((G, S, 45, C), dtype=torch.float64, device=dev)    # chunked transposed table
+    stream = torch.cuda.current_stream().cuda_stream
+    dmpc.table_from_rows_device(S, G, C, rows.data_ptr(), lT.data_ptr(), stream)
+    lo = rank * C
+    x_p, x_v, x_a, p_f = (dev_t(a[:, lo:lo + C]) for a in (xp, xv, xa, pf))
+    p_out = torch.empty((S, C, 45), dtype=torch.float64, device=dev)
+    v_out, a_out = torch.empty_like(p_out), torch.empty_like(p_out)
+    lT_next = torch.empty((S, 45, C), dtype=torch.float64, device=dev)
+    lT_gath = torch.empty((G, S, 45, C), dtype=torch.float64, device=dev)
+    status = torch.zeros((S, C), dtype=torch.int32, device=dev)
+    info = torch.zeros((S, C, 8), dtype=torch.int32, device=dev)
+
+    def one_step():
+        dmpc.step_device(S, G, C, rank, lT.data_ptr(), x_p.data_ptr(), x_v.data_ptr(), x_a.data_ptr(), p_f.data_ptr(),
+                         p_out.data_ptr(), v_out.data_ptr(), a_out.data_ptr(), lT_next.data_ptr(), status.data_ptr(),
+                         info.data_ptr(), stream)
+        if G > 1:   # the per-step exchange: every rank publishes its agents' new predictions
+            dist.all_gather_into_tensor(lT_gath, lT_next)
+
+    def barrier():
+        if G > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    dmpc.profile(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    barrier()
+    t1 = time.perf_counter()
+    kern_ms, n_launch = dmpc.profile_read()
+    dmpc.profile(False)
+    elapsed = t1 - t0
+    if G > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    solves_per_step = S * N
+    value = solves_per_step * args.steps / elapsed
+    st = status.cpu().numpy()
+    inf = info.cpu().numpy()
+
+    if rank == 0:
+        # algorithmic HBM bytes per solve (SURVEY.md 8d / BASELINE.md 3): table read once per step by the
+        # GPU (360 B per agent of the scene), state+goal 96 B, p/v/a horizons 1080 B, status 20 B
+        b_alg = 360.0 * N / C + 1196.0
+        achieved = (S * C) * b_alg / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+        traffic = None
+        tj = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(tj) and G == 1:
+            try:
+                traffic = json.load(open(tj)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "agent-QP solves/sec (K=15 horizon)",
+            "value": value, "unit": "solves/s", "n_gpus": G, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.config}: {C} agents/GPU x {G} GPU(s) per scene, variant {cfg['variant']} "
+                                   f"(solve{'Hard' if cfg['variant']=='hard' else ''}DMPC), K=15, {S} scenes batched, "
+                                   f"steady-state replay of MPC step {args.capture_step}",
+                       "agents_per_scene": N, "scenes": S, "solves_per_step": solves_per_step,
+                       "parallelism": f"agents sharded x{G}, all-gather per step" if G > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "dmpc_step_kernel", "kernel_ms_avg": kern_ms, "launches": n_launch,
+                         "alg_bytes_per_solve": b_alg,
+                         "note": "on-chip bound (LDS latency + fp64 issue); compulsory HBM traffic is ~1.5 KB/solve"},
+            "workload_stats": {"solved_frac": float((st & 1).mean()), "infeasible_frac": float(((st & 8) != 0).mean()),
+                               "invalid": int(((st & 48) != 0).sum()), "mean_iters": float(inf[..., 4].mean()),
+                               "max_iters": int(inf[..., 4].max()), "mean_rows": float(inf[..., 1].mean()),
+                               "max_rows": int(inf[..., 1].max()), "max_working_set": int(inf[..., 7].max()),
+                               "scenes_alive_at_capture": int(alive.sum())},
+        }
+        if not args.no_cpu_baseline and G == 1:
+            from oracle import oracle as orc
+            prm = orc.make_params(cfg["variant"], **kw)
+            ncpu = os.cpu_count() or 1
+            # bounded sample: whole scenes of the same captured step until ~10 s of single-thread work
+            t_cpu, n_cpu, s_i = 0.0, 0, 0
+            while t_cpu < 10.0 and s_i < S:
+                tt = time.perf_counter()
+                orc.step(prm, l[s_i], xp[s_i], xv[s_i], xa[s_i], pf[s_i], nthreads=1)
+                t_cpu += time.perf_counter() - tt
+                n_cpu += N
+                s_i += 1
+            one = n_cpu / t_cpu
+            # all host cores with the reference's contiguous-cluster partition (dmpc.cpp:1600-1625)
+            tt = time.perf_counter()
+            reps = 0
+            while time.perf_counter() - tt < 5.0:
+                orc.step(prm, l[reps % S], xp[reps % S], xv[reps % S], xa[reps % S], pf[reps % S], nthreads=min(ncpu, N))
+                reps += 1
+            allc = reps * N / (time.perf_counter() - tt)
+            line["cpu_baseline"] = {"value": one, "unit": "solves/s", "cores": 1, "kind": "port",
+                                    "sample": f"{s_i} scene(s) x {N} agents of the same captured step, oracle/dmpc_oracle.c (dense Goldfarb-Idnani), 1 thread",
+                                    "all_cores": {"value": allc, "threads": min(ncpu, N), "host_cpus": ncpu}}
+        print(json.dumps(line))
+    if G > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
