@@ -108,7 +108,7 @@ def main():
                          p_out.data_ptr(), v_out.data_ptr(), a_out.data_ptr(), lT_next.data_ptr(), status.data_ptr(),
                          info.data_ptr(), stream)
         if G > 1:   # the per-step exchange: every rank publishes its agents' new predictions
-            dist.all_gather_into_tensor(lT_gath, lT_next)
+            dist.all_gather_into_tensor(lT_gath.view(-1), lT_next.view(-1))
 
     def barrier():
         if G > 1:

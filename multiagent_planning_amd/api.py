@@ -1,0 +1,181 @@
+"""Host-side mirror of the reference's MATLAB interface for the DMPC hot path.
+
+Same function names, positional argument lists, return tuples and failure conventions as the
+`.m` files under dmpc/matlab/ (SURVEY.md section 8b), so code (and tests) written against the reference
+reads the same.  Every solver call goes through the C ABI of libdmpc_hip.so to the HIP kernel; there
+is no CPU path here -- without the library or a GPU the calls raise DmpcError.
+
+Array conventions are MATLAB's: `l` is 3 x K x N, states are length-3 vectors, `n` is 1-based,
+outputs p, v, a are 3 x K; on failure p = v = a = empty (0 x 0) exactly as the reference returns `[]`.
+"""
+import numpy as np
+
+from . import _lib
+from ._lib import Dmpc, ST_COLL, ST_INFEAS, ST_OUTBOUND, ST_SOLVED, ST_CAPACITY, ST_ITERCAP
+
+_EMPTY = np.zeros((0, 0))
+_ctx_cache = {}
+
+
+def _table(l):
+    """MATLAB l(3,K,N) -> rows [N, 3K] (same memory order as column-major MATLAB storage)."""
+    l = np.asarray(l, dtype=np.float64)
+    if l.ndim != 3 or l.shape[0] != 3:
+        raise ValueError("l must be 3 x K x N")
+    return np.ascontiguousarray(l.transpose(2, 1, 0).reshape(l.shape[2], -1))
+
+
+def _ctx(variant, h, K, rmin, pmin, pmax, alim, Q1, S1, E1, order, term, device=0):
+    if int(K) != _lib.K_HOR:
+        raise ValueError("K (k_hor) must be 15")
+    c = 1.0 / float(np.asarray(E1)[2, 2])
+    key = (variant, float(h), float(rmin), tuple(map(float, np.ravel(pmin))), tuple(map(float, np.ravel(pmax))),
+           float(alim), float(Q1), float(S1), c, int(order), float(term), device)
+    d = _ctx_cache.get(key)
+    if d is None:
+        d = Dmpc(variant, device=device, h=h, rmin=rmin, c=c, alim=alim, Q1=Q1, S1=S1, term=term,
+                 pmin=tuple(np.ravel(pmin)), pmax=tuple(np.ravel(pmax)), order=order)
+        _ctx_cache[key] = d
+    return d
+
+
+def _solve(variant, po, pf, vo, ao, n, h, l, K, rmin, pmin, pmax, alim, Q1, S1, E1, order, term):
+    d = _ctx(variant, h, K, rmin, pmin, pmax, alim, Q1, S1, E1, order, term)
+    r = d.solve_one(_table(l), int(n) - 1, np.ravel(po), np.ravel(vo), np.ravel(ao), np.ravel(pf))
+    st = r["status"]
+    if st & (ST_CAPACITY | ST_ITERCAP):
+        raise _lib.DmpcError(f"internal capacity/iteration limit hit (status {st}); result not valid")
+    if st & ST_SOLVED:
+        p, v, a = (r[k].reshape(K, 3).T.copy() for k in ("p", "v", "a"))   # vec2mat(.,3)'
+    else:
+        p = v = a = _EMPTY
+    return p, v, a, st
+
+
+# ---- solver entry points (signatures of the .m files) ------------------------------------------
+
+def solveSoftDMPCbound(po, pf, vo, ao, n, h, l, K, rmin, pmin, pmax, alim, A, A_initp, A_p, A_v, Delta, Q1, S1, E1, E2, order, term):
+    """[p,v,a,feasible,outbound,coll] = solveSoftDMPCbound(...)  (solveSoftDMPCbound.m:1).
+    coll -> feasible = 1 with empty outputs (:25-31); outbound keeps feasible = 1 (:125-128)."""
+    p, v, a, st = _solve("bound", po, pf, vo, ao, n, h, l, K, rmin, pmin, pmax, alim, Q1, S1, E1, order, term)
+    coll = int(bool(st & ST_COLL))
+    feasible = int(bool(st & (ST_SOLVED | ST_COLL)))
+    return p, v, a, feasible, int(bool(st & ST_OUTBOUND)), coll
+
+
+def _success6(variant, args, term):
+    (po, pf, vo, ao, n, h, l, K, rmin, pmin, pmax, alim, A, A_initp, A_p, A_v, Delta, Q1, S1, E1, E2, order) = args
+    p, v, a, st = _solve(variant, po, pf, vo, ao, n, h, l, K, rmin, pmin, pmax, alim, Q1, S1, E1, order, term)
+    outbound = int(bool(st & ST_OUTBOUND))
+    success = int(bool(st & ST_SOLVED) and not outbound)   # solveSoftDMPCbound2.m:123-126: outbound -> success = 0
+    return p, v, a, success, outbound, int(bool(st & ST_COLL))
+
+
+def solveSoftDMPCbound2(*args):
+    """[p,v,a,success,outbound,coll] = solveSoftDMPCbound2(...23 args...)  (solveSoftDMPCbound2.m:1)."""
+    return _success6("bound2", args[:22], args[22])
+
+
+def solveSoftDMPCall(*args):
+    """[p,v,a,success,outbound,coll] = solveSoftDMPCall(...23 args...)  (solveSoftDMPCall.m:1)."""
+    return _success6("all3", args[:22], args[22])
+
+
+def solveHardDMPC(*args):
+    """[p,v,a,success,outbound,coll] = solveHardDMPC(...22 args, no term...)  (solveHardDMPC.m:1)."""
+    return _success6("hard", args[:22], -5e4)
+
+
+def solveHardDMPCOnDemand(*args):
+    """[p,v,a,success,outbound,coll] = solveHardDMPCOnDemand(...22 args...)  (solveHardDMPCOnDemand.m:1)."""
+    return _success6("ondemand", args[:22], -5e4)
+
+
+def solveSoftDMPCrepair(po, pf, vo, ao, n, h, l, K, rmin, pmin, pmax, alim, A, A_initp, Delta, Q1, S1, E1, E2, order, term):
+    """[p,v,a,success,outbound,coll] = solveSoftDMPCrepair(...)  (solveSoftDMPCrepair.m:1)."""
+    p, v, a, st = _solve("repair", po, pf, vo, ao, n, h, l, K, rmin, pmin, pmax, alim, Q1, S1, E1, order, term)
+    outbound = int(bool(st & ST_OUTBOUND))
+    return p, v, a, int(bool(st & ST_SOLVED) and not outbound), outbound, int(bool(st & ST_COLL))
+
+
+def solveSoftDMPC(po, pf, vo, ao, n, h, l, K, rmin, pmin, pmax, alim, A, A_initp, Delta, Q1, S1, E1, E2, order):
+    """[p,v,a,success,outbound] = solveSoftDMPC(...)  (solveSoftDMPC.m:1; failure without a
+    violation is reported as outbound, :88-96)."""
+    d = _ctx("softall", h, K, rmin, pmin, pmax, alim, Q1, S1, E1, order, -1e5)
+    r = d.solve_one(_table(l), int(n) - 1, np.ravel(po), np.ravel(vo), np.ravel(ao), np.ravel(pf))
+    st = r["status"]
+    if st & ST_SOLVED:
+        return tuple(r[k].reshape(K, 3).T.copy() for k in ("p", "v", "a")) + (1, 0)
+    return _EMPTY, _EMPTY, _EMPTY, 0, int(r["info"][_lib.I_VIOLK] == 0)
+
+
+def solveEllipDMPC(po, pf, vo, ao, n, h, l, K, rmin, pmin, pmax, alim, A, A_initp, Delta, Q1, S1, E1, E2, order):
+    """[p,v,a,success,outbound] = solveEllipDMPC(...)  (solveEllipDMPC.m:1)."""
+    p, v, a, st = _solve("ellip", po, pf, vo, ao, n, h, l, K, rmin, pmin, pmax, alim, Q1, S1, E1, order, -5e4)
+    return p, v, a, int(bool(st & ST_SOLVED)), 0
+
+
+# ---- model / helper functions -------------------------------------------------------------------
+
+def getPosMat(h, K):
+    """Apos = getPosMat(h,K)  (getPosMat.m:1): acceleration -> position matrix, 3K x 3K."""
+    return _lib.model_matrices(h, K)[0]
+
+
+def getPosVelMat(h, K):
+    """Aaug = getPosVelMat(h,K)  (getPosVelMat.m:1): [x_K (6 rows); a_K (3); a_1 (3)] selectors, 12 x 3K."""
+    return _lib.posvel_matrix(h, K)
+
+
+def getDeltaMat(k_hor):
+    """Delta = getDeltaMat(k_hor)  (getDeltaMat.m:1)."""
+    return _lib.model_matrices(0.2, k_hor)[3]
+
+
+def getModelMats(h, k_hor):
+    """(A_p, A_v, A_initp) of the precompute loop dmpc_soft_bound.m:92-108."""
+    Lam, Av, A0, _ = _lib.model_matrices(h, k_hor)
+    return Lam, Av, A0
+
+
+def propStatedmpc(po, vo, a, A_initp, A_p, A_v):
+    """[p,v] = propStatedmpc(po,vo,a,A_initp,A_p,A_v)  (propStatedmpc.m:1-8); stacked 3K vectors.
+    (Inside the solvers this step is fused into the HIP kernel; this standalone form is plain host
+    linear algebra on caller-supplied matrices, exactly the two products of the .m file.)"""
+    a = np.ravel(a)
+    x0 = np.r_[np.ravel(po), np.ravel(vo)]
+    return A_p @ a + A_initp @ x0, A_v @ a + np.tile(np.ravel(vo), a.size // 3)
+
+
+def propState(po, a, A_p, A_v, K):
+    """[p,v] = propState(po,a,A_p,A_v,K)  (dec-iSCP/propState.m:1-10): zero initial velocity, the
+    initial state prepended."""
+    a = np.ravel(a)
+    po = np.ravel(po)
+    new_p, new_v = A_p @ a, A_v @ a
+    return np.r_[po, new_p + np.tile(po, K - 1)], np.r_[np.zeros(3), new_v]
+
+
+def initDMPC(po, pf, h, k_hor, K):
+    """[p,v,a] = initDMPC(po,pf,h,k_hor,K)  (initDMPC.m:1-13), 3 x k_hor each."""
+    po, pf = np.ravel(po).astype(float), np.ravel(pf).astype(float)
+    t = np.arange(k_hor) * h
+    p = po[:, None] + 1 * t[None, :] * (pf - po)[:, None] / 10
+    return p, np.zeros((3, k_hor)), np.zeros((3, k_hor))
+
+
+def is_inbounds(p, pmin, pmax):
+    """inbounds = is_inbounds(p,pmin,pmax)  (is_inbounds.m:1-6)."""
+    p = np.asarray(p, float).reshape(3, -1)
+    tol = 50e-3
+    return bool(np.all(p.max(axis=1) < np.ravel(pmax) + tol) and np.all(p.min(axis=1) > np.ravel(pmin) - tol))
+
+
+def ReachedGoal(p, pf, length_t, error_tol, N):
+    """pass = ReachedGoal(p,pf,length_t,error_tol,N)  (ReachedGoal.m:1-11); p is 3 x T x N, pf 1 x 3 x N."""
+    p = np.asarray(p, float)
+    if N > 1:
+        differ = p[:, length_t - 1, :] - np.asarray(pf, float).reshape(3, N)
+    else:
+        differ = p[:, length_t - 1].reshape(3, 1) - np.ravel(pf).reshape(3, 1)
+    return bool(np.sqrt((differ ** 2).sum(axis=0)).max() < error_tol)

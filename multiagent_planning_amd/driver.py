@@ -1,0 +1,102 @@
+"""Transition drivers: the MPC outer loop around the batched step (a11).
+
+  run_transition      -- the loop of dmpc/matlab/dmpc_soft_bound.m:115-148 / test/failure_rate.m:99-127
+                         for S scenes on ONE device (thin wrapper of dmpc_transition in the C ABI).
+  ShardedStepper      -- agents of every scene sharded across the ranks of a torch.distributed
+                         group exactly like the reference's thread clusters (contiguous ranges,
+                         dmpc/cpp/dmpc.cpp:1600-1625); per MPC step each rank solves its chunk against the
+                         full table and ONE all-gather publishes the new predictions
+                         (`l = new_l`, dmpc_soft_bound.m:146; `prev_obs = obs`, dmpc.cpp:1681).
+
+The table layout lT[G][S][3K][C] is rank-major, so the all-gather output IS the next table: no
+repacking, no other collective on the data path.  The goal / abort test is a tiny all-reduce(max).
+"""
+import numpy as np
+
+K3 = 45
+
+
+def partition(N, G):
+    """Contiguous clusters: N//G each, the first N % G get one more (dmpc.cpp:1600-1625).
+    Returns list of (lo, hi)."""
+    base, rem = divmod(N, G)
+    out, lo = [], 0
+    for r in range(G):
+        cnt = base + (1 if r < rem else 0)
+        out.append((lo, lo + cnt))
+        lo += cnt
+    return out
+
+
+def rows_to_chunked(rows, G):
+    """[S,N,45] rows -> lT[G,S,45,C] (N = G*C)."""
+    S, N, _ = rows.shape
+    C = N // G
+    assert C * G == N, "equal chunks required (pad the scene to a multiple of the rank count)"
+    return np.ascontiguousarray(rows.reshape(S, G, C, K3).transpose(1, 0, 3, 2))
+
+
+def chunked_to_rows(lT):
+    G, S, _, C = lT.shape
+    return np.ascontiguousarray(lT.transpose(1, 0, 3, 2).reshape(S, G * C, K3))
+
+
+def run_transition(dmpc, po, pf, K_T_max, error_tol=0.01):
+    """Whole transitions of S scenes on one device. Returns dict(pk,vk,ak,K_T_used,scene_status)."""
+    return dmpc.transition(po, pf, K_T_max, error_tol)
+
+
+class ShardedStepper:
+    """One rank's view of the sharded MPC step.
+
+    local_step(lT_full, x_p, x_v, x_a, pf, g_local) -> dict(p, v, a, status) for this rank's C agents of
+    every scene; arrays are numpy on the CPU path used by the gloo tests and torch CUDA tensors on the
+    GPU path (see GpuLocalStep).  all_gather is torch.distributed's; with world size 1 it is skipped.
+    """
+
+    def __init__(self, local_step, rank, world, group=None):
+        self.local_step, self.rank, self.world, self.group = local_step, rank, world, group
+
+    def step(self, lT_full, x_p, x_v, x_a, pf):
+        import torch
+        import torch.distributed as dist
+        out = self.local_step(lT_full, x_p, x_v, x_a, pf, self.rank)
+        ok = (out["status"] & 1) == 1
+        own = lT_full[self.rank]                                        # [S,45,C]
+        newp = out["p"].transpose(-1, -2) if isinstance(out["p"], torch.Tensor) else np.swapaxes(out["p"], -1, -2)
+        if isinstance(newp, torch.Tensor):
+            chunk = torch.where(ok[:, None, :], newp, own).contiguous()
+        else:
+            chunk = torch.from_numpy(np.ascontiguousarray(np.where(ok[:, None, :], newp, own)))
+        if self.world > 1:
+            nxt = torch.empty((self.world,) + tuple(chunk.shape), dtype=chunk.dtype, device=chunk.device)
+            dist.all_gather_into_tensor(nxt.view(-1), chunk.view(-1), group=self.group)   # rank-major == table layout
+            flag = torch.tensor([int((~ok).any())], dtype=torch.int32, device=chunk.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)   # abort test (failure_rate.m:112-123)
+            failed = bool(flag.item())
+        else:
+            nxt, failed = chunk[None], bool((~ok).any())
+        if not isinstance(lT_full, torch.Tensor):
+            nxt = nxt.numpy()
+        return nxt, out, failed
+
+
+class GpuLocalStep:
+    """local_step for ShardedStepper on a GPU: torch CUDA tensors in, HIP kernel through the C ABI."""
+
+    def __init__(self, dmpc, S, G, C, device):
+        import torch
+        self.d, self.S, self.G, self.C = dmpc, S, G, C
+        f = dict(dtype=torch.float64, device=device)
+        self.p = torch.empty((S, C, K3), **f)
+        self.v, self.a = torch.empty_like(self.p), torch.empty_like(self.p)
+        self.status = torch.zeros((S, C), dtype=torch.int32, device=device)
+        self.info = torch.zeros((S, C, 8), dtype=torch.int32, device=device)
+
+    def __call__(self, lT_full, x_p, x_v, x_a, pf, g_local):
+        import torch
+        st = torch.cuda.current_stream().cuda_stream
+        self.d.step_device(self.S, self.G, self.C, g_local, lT_full.data_ptr(), x_p.data_ptr(), x_v.data_ptr(), x_a.data_ptr(),
+                           pf.data_ptr(), self.p.data_ptr(), self.v.data_ptr(), self.a.data_ptr(), 0, self.status.data_ptr(),
+                           self.info.data_ptr(), st)
+        return dict(p=self.p, v=self.v, a=self.a, status=self.status, info=self.info)

@@ -1,0 +1,113 @@
+// dmpc_mex.cpp -- MEX gateway binding libdmpc_hip.so (include/dmpc_hip.h) into MATLAB.
+//
+// Build on a MATLAB host (mex.h is NOT available in the build container, so this file is compiled
+// there, not here):   mex -I../../include dmpc_mex.cpp -L.. -ldmpc_hip
+//
+// One gateway, dispatched on a command string, keeps ONE persistent context per parameter set:
+//   [p,v,a,status,info] = dmpc_mex('solve_one', params, l, n, po, vo, ao, pf)
+//   [P,V,A,status,info] = dmpc_mex('step_batch', params, l, x_p, x_v, x_a, pf)
+//   [Lambda,Av,A0,Delta] = dmpc_mex('model_matrices', params)
+// `params` is a struct with the fields of dmpc_params (variant as the DMPC_VAR_* integer).
+// The signature-preserving wrappers (solveSoftDMPCbound.m, ...) in this directory call 'solve_one'
+// and convert status bits into the reference's [] + flag conventions.
+#include "mex.h"
+
+#include <cstring>
+#include <string>
+
+#include "dmpc_hip.h"
+
+static dmpc_ctx *g_ctx = nullptr;
+static dmpc_params g_prm;
+
+static void cleanup() { if (g_ctx) { dmpc_destroy(g_ctx); g_ctx = nullptr; } }
+
+static double field(const mxArray *s, const char *name)
+{
+    const mxArray *f = mxGetField(s, 0, name);
+    if (!f) mexErrMsgIdAndTxt("dmpc:params", "missing field %s", name);
+    return mxGetScalar(f);
+}
+
+static dmpc_params read_params(const mxArray *s)
+{
+    if (!mxIsStruct(s)) mexErrMsgIdAndTxt("dmpc:params", "params must be a struct");
+    dmpc_params p;
+    p.K = (int32_t)field(s, "K"); p.variant = (int32_t)field(s, "variant");
+    p.order = (int32_t)field(s, "order"); p.max_tries = 0;
+    p.h = field(s, "h"); p.rmin = field(s, "rmin"); p.c = field(s, "c"); p.alim = field(s, "alim");
+    p.Q1 = field(s, "Q1"); p.S1 = field(s, "S1"); p.term = field(s, "term");
+    const double *pmin = mxGetPr(mxGetField(s, 0, "pmin")), *pmax = mxGetPr(mxGetField(s, 0, "pmax"));
+    for (int d = 0; d < 3; ++d) { p.pmin[d] = pmin[d]; p.pmax[d] = pmax[d]; }
+    return p;
+}
+
+static dmpc_ctx *context(const dmpc_params &p)
+{
+    if (!g_ctx) {
+        g_ctx = dmpc_create(&p, 0);
+        if (!g_ctx) mexErrMsgIdAndTxt("dmpc:create", "%s", dmpc_last_error(nullptr));
+        g_prm = p;
+        mexAtExit(cleanup);
+        mexLock();
+    } else if (std::memcmp(&p, &g_prm, sizeof(p)) != 0) {
+        if (dmpc_set_params(g_ctx, &p)) mexErrMsgIdAndTxt("dmpc:params", "%s", dmpc_last_error(g_ctx));
+        g_prm = p;
+    }
+    return g_ctx;
+}
+
+static void need(bool ok, const char *what) { if (!ok) mexErrMsgIdAndTxt("dmpc:shape", "%s", what); }
+
+void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
+{
+    need(nrhs >= 2 && mxIsChar(prhs[0]), "usage: dmpc_mex(cmd, params, ...)");
+    char cmd[32];
+    mxGetString(prhs[0], cmd, sizeof(cmd));
+    dmpc_params p = read_params(prhs[1]);
+    const int n3 = 3 * p.K;
+    if (!std::strcmp(cmd, "model_matrices")) {
+        plhs[0] = mxCreateDoubleMatrix(n3, n3, mxREAL);
+        mxArray *Av = mxCreateDoubleMatrix(n3, n3, mxREAL), *A0 = mxCreateDoubleMatrix(6, n3, mxREAL),
+                *Dl = mxCreateDoubleMatrix(n3, n3, mxREAL);
+        // the C ABI is row-major: the returned column-major MATLAB arrays hold the TRANSPOSES, which the
+        // .m wrappers undo (Lambda, A_v, Delta) / A0 is created 6 x 3K and transposed there
+        dmpc_model_matrices(&p, mxGetPr(plhs[0]), mxGetPr(Av), mxGetPr(A0), mxGetPr(Dl));
+        if (nlhs > 1) plhs[1] = Av; if (nlhs > 2) plhs[2] = A0; if (nlhs > 3) plhs[3] = Dl;
+        return;
+    }
+    dmpc_ctx *ctx = context(p);
+    if (!std::strcmp(cmd, "solve_one")) {
+        need(nrhs == 8, "solve_one: (cmd, params, l, n, po, vo, ao, pf)");
+        const mwSize *dl = mxGetDimensions(prhs[2]);
+        need(mxGetNumberOfDimensions(prhs[2]) == 3 && dl[0] == 3 && (int)dl[1] == p.K, "l must be 3 x K x N");
+        const int N = (int)dl[2], n = (int)mxGetScalar(prhs[3]);
+        for (int i = 4; i < 8; ++i) need(mxGetNumberOfElements(prhs[i]) == 3, "po, vo, ao, pf must have 3 elements");
+        plhs[0] = mxCreateDoubleMatrix(3, p.K, mxREAL);   // column-major 3 x K == stacked [x1 y1 z1 x2 ...]
+        mxArray *v = mxCreateDoubleMatrix(3, p.K, mxREAL), *a = mxCreateDoubleMatrix(3, p.K, mxREAL);
+        mxArray *st = mxCreateNumericMatrix(1, 1, mxINT32_CLASS, mxREAL), *inf = mxCreateNumericMatrix(1, 8, mxINT32_CLASS, mxREAL);
+        // MATLAB l(3,K,N) column-major IS the [N][3K] row-major table: passed without copying
+        if (dmpc_solve_one(ctx, N, n - 1, mxGetPr(prhs[2]), mxGetPr(prhs[4]), mxGetPr(prhs[5]), mxGetPr(prhs[6]), mxGetPr(prhs[7]),
+                           mxGetPr(plhs[0]), mxGetPr(v), mxGetPr(a), (int32_t *)mxGetData(st), (int32_t *)mxGetData(inf)))
+            mexErrMsgIdAndTxt("dmpc:solve", "%s", dmpc_last_error(ctx));
+        if (nlhs > 1) plhs[1] = v; if (nlhs > 2) plhs[2] = a; if (nlhs > 3) plhs[3] = st; if (nlhs > 4) plhs[4] = inf;
+        return;
+    }
+    if (!std::strcmp(cmd, "step_batch")) {
+        need(nrhs == 7, "step_batch: (cmd, params, l, x_p, x_v, x_a, pf)");
+        const mwSize *dl = mxGetDimensions(prhs[2]);
+        need(mxGetNumberOfDimensions(prhs[2]) == 3 && dl[0] == 3 && (int)dl[1] == p.K, "l must be 3 x K x N");
+        const int N = (int)dl[2];
+        for (int i = 3; i < 7; ++i) need(mxGetNumberOfElements(prhs[i]) == (size_t)3 * N, "states must be 3 x N");
+        const mwSize d3[3] = {3, (mwSize)p.K, (mwSize)N};
+        plhs[0] = mxCreateNumericArray(3, d3, mxDOUBLE_CLASS, mxREAL);
+        mxArray *v = mxCreateNumericArray(3, d3, mxDOUBLE_CLASS, mxREAL), *a = mxCreateNumericArray(3, d3, mxDOUBLE_CLASS, mxREAL);
+        mxArray *st = mxCreateNumericMatrix(1, N, mxINT32_CLASS, mxREAL), *inf = mxCreateNumericMatrix(8, N, mxINT32_CLASS, mxREAL);
+        if (dmpc_step_batch(ctx, 1, N, mxGetPr(prhs[2]), mxGetPr(prhs[3]), mxGetPr(prhs[4]), mxGetPr(prhs[5]), mxGetPr(prhs[6]),
+                            mxGetPr(plhs[0]), mxGetPr(v), mxGetPr(a), (int32_t *)mxGetData(st), (int32_t *)mxGetData(inf)))
+            mexErrMsgIdAndTxt("dmpc:step", "%s", dmpc_last_error(ctx));
+        if (nlhs > 1) plhs[1] = v; if (nlhs > 2) plhs[2] = a; if (nlhs > 3) plhs[3] = st; if (nlhs > 4) plhs[4] = inf;
+        return;
+    }
+    mexErrMsgIdAndTxt("dmpc:cmd", "unknown command %s", cmd);
+}
