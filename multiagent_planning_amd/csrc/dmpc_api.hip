@@ -317,7 +317,7 @@ static int row_capacity(int variant, int N)
     // several workgroups resident per CU; the kernel flags DMPC_ST_CAPACITY if it is ever exceeded
     if (variant == DMPC_VAR_BOUND || variant == DMPC_VAR_BOUND2 || variant == DMPC_VAR_ONDEMAND) cap = cap < 128 ? cap : 128;
     if (variant == DMPC_VAR_ALL3) cap = cap < 384 ? cap : 384;
-    if (variant == DMPC_VAR_HARD) cap = cap < 768 ? cap : 768;
+    if (variant == DMPC_VAR_HARD) cap = cap < 320 ? cap : 320;   // after exact pruning; beyond: DMPC_ST_CAPACITY
     long r = want < cap ? want : cap;
     if (r < 8) r = 8;
     return (int)((r + 1) & ~1L);
@@ -333,6 +333,8 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     P.variant = p.variant; P.S = S; P.G = G; P.C = C; P.g_local = g_local;
     P.c_first = c_first; P.c_count = c_count;
     P.nrmax = row_capacity(p.variant, G * C);
+    // hard-constraint variants have 45 variables => at most 45 independent active constraints
+    P.qcap = variant_soft(p.variant) ? QMAX : 46;
     P.max_tries = p.max_tries;
     P.h = p.h; P.rmin = p.rmin; P.e1z = 1.0 / p.c; P.e2z = 1.0 / (p.c * p.c);
     P.alim = p.alim; P.Q1 = p.Q1; P.S1 = p.S1; P.term = p.term;
@@ -342,7 +344,7 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     P.p_out = p_out; P.v_out = v_out; P.a_out = a_out; P.lT_next = lT_next;
     P.status = status; P.info = info;
     P.dbg = ctx->dbg; P.dbg_agent = ctx->dbg_agent; P.dbg_cap = ctx->dbg_cap;
-    const size_t lds = step_lds_bytes(P.nrmax, variant_soft(p.variant));
+    const size_t lds = step_lds_bytes(P.nrmax, variant_soft(p.variant), P.qcap);
     if ((int)lds > ctx->max_lds_set) {
         HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         ctx->max_lds_set = (int)lds;

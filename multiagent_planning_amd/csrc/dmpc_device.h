@@ -14,7 +14,7 @@ enum { VAR_BOUND = 0, VAR_BOUND2 = 1, VAR_ALL3 = 2, VAR_HARD = 3, VAR_ONDEMAND =
 enum { ST_SOLVED = 1, ST_OUTBOUND = 2, ST_COLL = 4, ST_INFEAS = 8, ST_CAPACITY = 16, ST_ITERCAP = 32 };
 
 struct StepParams {
-    int variant, S, G, C, g_local, nrmax, max_tries, c_first, c_count, pad_;
+    int variant, S, G, C, g_local, nrmax, max_tries, c_first, c_count, qcap;
     double h, rmin, e1z, e2z, alim, Q1, S1, term;
     double pmin[3], pmax[3];
     const double *tables;   // [3 cost cases][H1^-1 | H1^-1 L' | L H1^-1 L'][15*15]
@@ -28,9 +28,9 @@ struct StepParams {
 };
 
 // bytes of dynamic LDS the step kernel carves for a given row capacity
-inline size_t step_lds_bytes(int nrmax, bool soft)
+inline size_t step_lds_bytes(int nrmax, bool soft, int qcap = QMAX)
 {
-    size_t dbl = (size_t)TPACK + 675 + 5 * 48 + 3 * QMAX + 3 * QMAX + (size_t)nrmax * (4 + (soft ? 4 : 0));
+    size_t dbl = (size_t)(qcap * (qcap + 1)) / 2 + 675 + 5 * 48 + 3 * QMAX + 4 * QMAX + (size_t)nrmax * (4 + (soft ? 4 : 0));
     size_t ints = 3 * QMAX + 2 * (size_t)nrmax;
     return dbl * 8 + ints * 4;
 }

@@ -37,24 +37,45 @@ __device__ __forceinline__ double readlane_d(double v, int l /*uniform*/)
 }
 __device__ __forceinline__ int readlane_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 
-__device__ __forceinline__ double wave_max(double v)
+// Wave-wide reductions on the VALU with DPP row shifts / row broadcasts (gfx9 scan idiom): six
+// steps, no LDS crossbar traffic (a ds_bpermute butterfly costs ~10x more here).  Lane 63 ends up
+// with the total, which is then broadcast through an SGPR.  Fixed order => bit-reproducible.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_d(double ident, double v)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m));
-    return v;
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(ident), __double2loint(v), CTRL, ROWMASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(ident), __double2hiint(v), CTRL, ROWMASK, 0xf, false);
+    return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double wave_min(double v)
+#define DMPC_WAVE_REDUCE(NAME, IDENT, OP)                                     \
+    __device__ __forceinline__ double NAME(double v)                          \
+    {                                                                         \
+        const double id = IDENT;                                              \
+        v = OP(v, dpp_d<0x111, 0xf>(id, v)); /* row_shr:1 */                  \
+        v = OP(v, dpp_d<0x112, 0xf>(id, v)); /* row_shr:2 */                  \
+        v = OP(v, dpp_d<0x114, 0xf>(id, v)); /* row_shr:4 */                  \
+        v = OP(v, dpp_d<0x118, 0xf>(id, v)); /* row_shr:8 */                  \
+        v = OP(v, dpp_d<0x142, 0xa>(id, v)); /* row_bcast:15 -> rows 1,3 */   \
+        v = OP(v, dpp_d<0x143, 0xc>(id, v)); /* row_bcast:31 -> rows 2,3 */   \
+        return readlane_d(v, 63);                                             \
+    }
+__device__ __forceinline__ double op_max(double a, double b) { return fmax(a, b); }
+__device__ __forceinline__ double op_min(double a, double b) { return fmin(a, b); }
+__device__ __forceinline__ double op_add(double a, double b) { return a + b; }
+DMPC_WAVE_REDUCE(wave_max, -INFINITY, op_max)
+DMPC_WAVE_REDUCE(wave_min, INFINITY, op_min)
+DMPC_WAVE_REDUCE(wave_sum, 0.0, op_add)
+__device__ __forceinline__ unsigned wave_or(unsigned v)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = fmin(v, __shfl_xor(v, m));
-    return v;
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-    return v;
-}
+
 __device__ __forceinline__ int lanes_below(unsigned long long mask, int lane)
 {
     return __popcll(mask & ((1ull << lane) - 1ull));
@@ -72,7 +93,7 @@ struct Lds {
     double *tabH, *tabM, *tabP;  // 15x15: H1^-1, H1^-1 L', L H1^-1 L'
     double *a_s, *w_s, *own_s, *nu_s, *yt_s;   // 48 each
     double *s_vec;  // QMAX x 3
-    double *s_ss, *s_d, *s_lam;
+    double *s_ss, *s_d, *s_lam, *rr_s;
     double *r_xi;   // nrmax x 3
     double *r_b;
     double *r_sd, *r_st, *r_slb, *r_eps;  // soft variants only
@@ -181,26 +202,36 @@ __device__ __forceinline__ void primal(const Lds &L, int lane, int q, int nr, bo
 // ds_read_b64, and "lane i reads row i of one column" is a contiguous read.
 __device__ __forceinline__ int tcol(int j) { return (j * (j + 1)) >> 1; }
 
-// y = T' x  (lane j gets y_j; x_i lives in lane i)
+// y = T' x  (lane j gets y_j; x_i lives in lane i).  Branch-free: addresses are clamped into the
+// lane's own column and the value is masked afterwards, so the four LDS reads of an unrolled group are
+// issued back to back (a predicated load would serialise on exec-mask branches).
 __device__ __forceinline__ double t_tmul(const double *Tp, int lane, int q, double x)
 {
     double acc = 0.0;
-    const int cj = tcol(lane < q ? lane : 0);
-    for (int i = 0; i < q; ++i) {
-        const double xi = readlane_d(x, i);
-        if (i <= lane && lane < q) acc += Tp[cj + i] * xi;
+    const int jl = lane < q ? lane : 0;
+    const int cj = tcol(jl);
+    for (int i0 = 0; i0 < q; i0 += 16) {
+        double t[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int i = i0 + u; t[u] = Tp[cj + (i < jl ? i : jl)]; }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int i = i0 + u; acc = fma((i <= jl) ? t[u] : 0.0, readlane_d(x, i & 63), acc); }
     }
-    return acc;
+    return lane < q ? acc : 0.0;
 }
 // y = T x  (lane i gets y_i; x_j lives in lane j)
 __device__ __forceinline__ double t_mul(const double *Tp, int lane, int q, double x)
 {
     double acc = 0.0;
-    for (int j = 0; j < q; ++j) {
-        const double xj = readlane_d(x, j);
-        if (j >= lane && lane < q) acc += Tp[tcol(j) + lane] * xj;
+    const int il = lane < q ? lane : 0;
+    for (int j0 = 0; j0 < q; j0 += 16) {
+        double t[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int j = j0 + u; const int jc = j < q ? j : q - 1; t[u] = Tp[tcol(jc) + (il < jc ? il : jc)]; }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int j = j0 + u; acc = fma((j >= il && j < q) ? t[u] : 0.0, readlane_d(x, j & 63), acc); }
     }
-    return acc;
+    return lane < q ? acc : 0.0;
 }
 
 // value n_j'x - d_j of the slot owned by this lane
@@ -217,8 +248,17 @@ __device__ __forceinline__ double slot_value(const Lds &L, int j, const double *
 // left-to-right; row l and the last column then drop out (stable inverse-factor downdate).  Fused
 // with the row deletion so that the packed storage never needs the transient fill-in: each lane
 // carries its row of the "current right column" in a register.
-__device__ __forceinline__ void remove_slot(const Lds &L, int lane, int &q, int l)
+__device__ __forceinline__ void remove_slot(const Lds &L, int lane, int &q, int l, unsigned &cslot)
 {
+    // per-component slot indices: the removed slot disappears, higher slots move down by one
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const unsigned v = (cslot >> (8 * b)) & 0xffu;
+        if (v != 0xffu) {
+            const unsigned nv = (v == (unsigned)l) ? 0xffu : (v > (unsigned)l ? v - 1 : v);
+            cslot = (cslot & ~(0xffu << (8 * b))) | (nv << (8 * b));
+        }
+    }
     double carry = (lane <= l) ? L.T[tcol(l) + lane] : 0.0;
     for (int j = l; j < q - 1; ++j) {
         const double right = (lane <= j + 1) ? L.T[tcol(j + 1) + lane] : 0.0;
@@ -273,7 +313,7 @@ __device__ __forceinline__ void set_member(const Lds &L, int lane, int ty, int i
 // --------------------------------------------------------------------------------------------
 // the step kernel: grid = S * C workgroups of 64 threads
 // --------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void dmpc_step_kernel(StepParams P)
+__global__ __launch_bounds__(64, 2) void dmpc_step_kernel(StepParams P)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
@@ -287,11 +327,11 @@ __global__ __launch_bounds__(64) void dmpc_step_kernel(StepParams P)
     Lds L;
     {
         double *p = (double *)smem;
-        L.T = p; p += TPACK;
+        L.T = p; p += (P.qcap * (P.qcap + 1)) / 2;
         L.tabH = p; p += 225; L.tabM = p; p += 225; L.tabP = p; p += 225;
         L.a_s = p; p += 48; L.w_s = p; p += 48; L.own_s = p; p += 48; L.nu_s = p; p += 48; L.yt_s = p; p += 48;
         L.s_vec = p; p += 3 * QMAX;
-        L.s_ss = p; p += QMAX; L.s_d = p; p += QMAX; L.s_lam = p; p += QMAX;
+        L.s_ss = p; p += QMAX; L.s_d = p; p += QMAX; L.s_lam = p; p += QMAX; L.rr_s = p; p += QMAX;
         L.r_xi = p; p += 3 * nrmax;
         L.r_b = p; p += nrmax;
         if (soft) { L.r_sd = p; p += nrmax; L.r_st = p; p += nrmax; L.r_slb = p; p += nrmax; L.r_eps = p; p += nrmax; }
@@ -316,8 +356,9 @@ __global__ __launch_bounds__(64) void dmpc_step_kernel(StepParams P)
     if (lane < N3) { own = lT_own[(size_t)lane * C]; L.own_s[lane] = own; }
     LSYNC();
 
+    const long long tk0 = clock64();
     // ---------------------------------------------------------------- a5/a6: scan + rows
-    int nr = 0, viol_k = 0, status = 0;
+    int nr = 0, nrows_ref = 0, viol_k = 0, status = 0;
     bool rows_exist = false, violation = false;
     const double rmin = P.rmin;
     const bool near_sel = (var == VAR_BOUND || var == VAR_BOUND2 || var == VAR_ALL3 || var == VAR_ONDEMAND);
@@ -326,83 +367,120 @@ __global__ __launch_bounds__(64) void dmpc_step_kernel(StepParams P)
 
     // appends the rows of horizon step ke (evaluated positions) constraining step kc for every
     // neighbour with dist < sel_r (or all), in increasing neighbour index (CollConstrSoftDMPC.m:11-31)
-    auto build_rows = [&](int ksel, int ke, int kc, double sel_r, bool sel_all) {
-        // selection distance is taken at step ksel (viol_constr of CheckCollSoftDMPC.m:12), the row
-        // itself is evaluated at step ke and constrains step kc
-        const double qx = L.own_s[3 * ksel], qy = L.own_s[3 * ksel + 1], qz = L.own_s[3 * ksel + 2];
-        const double px = L.own_s[3 * ke], py = L.own_s[3 * ke + 1], pz = L.own_s[3 * ke + 2];
+    // one collision row, CollConstrSoftDMPC.m:16-28: neighbour offset (dx,dy,dz) and ellipsoidal distance at
+    // the evaluation step (own position px,py,pz), constraining horizon step kc; compacted by ballot
+    auto emit_row = [&](bool sel, int kc, double dx, double dy, double dz, double dist, double px, double py, double pz) {
         const double sh = (double)(kc + 1) * P.h;
         const double a0x = A.po[0] + sh * A.vo[0], a0y = A.po[1] + sh * A.vo[1], a0z = A.po[2] + sh * A.vo[2];
+        const double x0 = dx, x1 = dy, x2 = dz * P.e2z;   // diff = E2*(p - pj)
+        nrows_ref += __popcll(__ballot(sel));               // the reference's row count (branch record)
+        // Exact pruning: with |a| <= alim the position at step kc stays in the box
+        // A0_kc x0 +- alim (kc h)^2/2, so a row whose linearised distance cannot drop below rmin anywhere in
+        // that box can never become active; dropping it (and its slack, which stays 0) leaves the minimiser
+        // unchanged.  Margin 1e-9 keeps borderline rows.
+        {
+            const double hw = 0.5 * P.alim * sh * sh;
+            const double lin_min = x0 * (a0x - (px - dx)) + x1 * (a0y - (py - dy)) + x2 * (a0z - (pz - dz)) - (fabs(x0) + fabs(x1) + fabs(x2)) * hw;
+            if (lin_min >= dist * rmin + 1e-9) sel = false;
+        }
+        const unsigned long long m = __ballot(sel);
+        const int pos = nr + lanes_below(m, lane);
+        if (sel && pos < nrmax) {
+            // r = dist*(rmin - dist + diff*p/dist) - diff*A_initp(kc)*[po;vo]   (:21)
+            const double rr = dist * (rmin - dist + (x0 * px + x1 * py + x2 * pz) / dist) - (x0 * a0x + x1 * a0y + x2 * a0z);
+            L.r_xi[3 * pos] = x0; L.r_xi[3 * pos + 1] = x1; L.r_xi[3 * pos + 2] = x2;
+            L.r_b[pos] = -rr;
+            L.r_kc[pos] = kc;
+            L.r_fl[pos] = 0;
+            if (soft) {
+                double sd = dist, st = P.term, slb = -0.05;
+                if (var == VAR_BOUND2 || var == VAR_ALL3) slb = -0.01;           // bound2:77, all:92
+                else if (var == VAR_SOFTALL) { sd = 1.0; st = -1e5; slb = -INFINITY; }  // solveSoftDMPC.m:21,65
+                else if (var == VAR_REPAIR) { st = P.term / dist; slb = -INFINITY; }    // repair:77,81
+                L.r_sd[pos] = sd; L.r_st[pos] = st; L.r_slb[pos] = slb; L.r_eps[pos] = 0.0;
+            }
+        }
+        nr += __popcll(m);
+    };
+
+    // rows of horizon step ke (positions evaluated there) constraining step kc for every neighbour whose
+    // distance AT STEP ksel is < sel_r (viol_constr of CheckCollSoftDMPC.m:12) or for all neighbours,
+    // in increasing neighbour index (CollConstrSoftDMPC.m:11-31)
+    auto build_rows = [&](int ksel, int ke, int kc, double sel_r, bool sel_all) {
+        const double qx = L.own_s[3 * ksel], qy = L.own_s[3 * ksel + 1], qz = L.own_s[3 * ksel + 2];
+        const double px = L.own_s[3 * ke], py = L.own_s[3 * ke + 1], pz = L.own_s[3 * ke + 2];
         for (int r = 0; r < G; ++r) {
             const double *bsel = P.lT + ((size_t)(r * S + scene) * N3 + 3 * ksel) * C;
             const double *base = P.lT + ((size_t)(r * S + scene) * N3 + 3 * ke) * C;
             for (int j0 = 0; j0 < C; j0 += 64) {
                 const int jj = j0 + lane;
                 const bool valid = jj < C && !(r == P.g_local && jj == cl);
-                double dx = 0, dy = 0, dz = 0, dist = 1e300, dsel = 1e300;
-                if (valid) {
-                    dx = px - base[jj]; dy = py - base[(size_t)C + jj]; dz = pz - base[2 * (size_t)C + jj];
-                    const double ez = dz * P.e1z;
-                    dist = sqrt(dx * dx + dy * dy + ez * ez);
-                    if (ksel == ke) dsel = dist;
-                    else if (!sel_all) {
-                        const double sx = qx - bsel[jj], sy = qy - bsel[(size_t)C + jj];
-                        const double sz = (qz - bsel[2 * (size_t)C + jj]) * P.e1z;
-                        dsel = sqrt(sx * sx + sy * sy + sz * sz);
-                    }
+                const int jc = jj < C ? jj : C - 1;   // clamped: loads are unconditional, results masked
+                const double dx = px - base[jc], dy = py - base[(size_t)C + jc], dz = pz - base[2 * (size_t)C + jc];
+                const double ez = dz * P.e1z;
+                const double dist = sqrt(dx * dx + dy * dy + ez * ez);
+                double dsel = dist;
+                if (ksel != ke && !sel_all) {
+                    const double sx = qx - bsel[jc], sy = qy - bsel[(size_t)C + jc];
+                    const double sz = (qz - bsel[2 * (size_t)C + jc]) * P.e1z;
+                    dsel = sqrt(sx * sx + sy * sy + sz * sz);
                 }
-                const bool sel = valid && (sel_all || dsel < sel_r);
-                const unsigned long long m = __ballot(sel);
-                const int pos = nr + lanes_below(m, lane);
-                if (sel && pos < nrmax) {
-                    const double x0 = dx, x1 = dy, x2 = dz * P.e2z;   // diff = E2*(p - pj)
-                    // r = dist*(rmin - dist + diff*p/dist) - diff*A_initp(kc)*[po;vo]   (:21)
-                    const double rr = dist * (rmin - dist + (x0 * px + x1 * py + x2 * pz) / dist) - (x0 * a0x + x1 * a0y + x2 * a0z);
-                    L.r_xi[3 * pos] = x0; L.r_xi[3 * pos + 1] = x1; L.r_xi[3 * pos + 2] = x2;
-                    L.r_b[pos] = -rr;
-                    L.r_kc[pos] = kc;
-                    L.r_fl[pos] = 0;
-                    if (soft) {
-                        double sd = dist, st = P.term, slb = -0.05;
-                        if (var == VAR_BOUND2 || var == VAR_ALL3) slb = -0.01;           // bound2:77, all:92
-                        else if (var == VAR_SOFTALL) { sd = 1.0; st = -1e5; slb = -INFINITY; }  // solveSoftDMPC.m:21,65
-                        else if (var == VAR_REPAIR) { st = P.term / dist; slb = -INFINITY; }    // repair:77,81
-                        L.r_sd[pos] = sd; L.r_st[pos] = st; L.r_slb[pos] = slb; L.r_eps[pos] = 0.0;
-                    }
-                }
-                nr += __popcll(m);
+                emit_row(valid && (sel_all || dsel < sel_r), kc, dx, dy, dz, dist, px, py, pz);
             }
         }
     };
 
-    if (var == VAR_HARD) {
-        // solveHardDMPC.m:18-22 + CollConstrHardDMPC.m:19: every k, neighbours with dist < 1
-        for (int k = 0; k < K; ++k) build_rows(k, k, k, 1.0, false);
-        rows_exist = (G * C > 1);   // preallocated zero rows make Ain_coll non-empty
-    } else {
-        for (int k = 0; k < K; ++k) {
-            const double px = L.own_s[3 * k], py = L.own_s[3 * k + 1], pz = L.own_s[3 * k + 2];
-            bool any = false;
-            double mind = 1e300;
-            for (int r = 0; r < G; ++r) {
-                const double *base = P.lT + ((size_t)(r * S + scene) * N3 + 3 * k) * C;
-                for (int j0 = 0; j0 < C; j0 += 64) {
-                    const int jj = j0 + lane;
-                    const bool valid = jj < C && !(r == P.g_local && jj == cl);
-                    if (valid) {
-                        const double dx = px - base[jj], dy = py - base[(size_t)C + jj];
-                        const double ez = (pz - base[2 * (size_t)C + jj]) * P.e1z;
-                        const double dist = sqrt(dx * dx + dy * dy + ez * ez);
-                        any = any || (dist < rmin);            // CheckCollSoftDMPC.m:11
-                        mind = fmin(mind, dist);
+    // Scan (CheckCollSoftDMPC.m:7-15): all K distances of a neighbour are computed from loads issued
+    // together (5 horizon steps = 15 coalesced wave loads per batch) instead of one dependent round per
+    // step; per-step "any neighbour inside rmin" bits are OR-reduced across the wave afterwards.
+    unsigned anyb = 0;
+    double mind0 = 1e300;
+    for (int r = 0; r < G; ++r) {
+        const double *base = P.lT + ((size_t)(r * S + scene) * N3) * C;
+        for (int j0 = 0; j0 < C; j0 += 64) {
+            const int jj = j0 + lane;
+            const bool valid = jj < C && !(r == P.g_local && jj == cl);
+            const int jc = jj < C ? jj : C - 1;
+#pragma unroll
+            for (int kg = 0; kg < 3; ++kg) {
+                double nx[5], ny[5], nz[5];
+#pragma unroll
+                for (int u = 0; u < 5; ++u) {
+                    const int k = 5 * kg + u;
+                    nx[u] = base[(size_t)(3 * k) * C + jc];
+                    ny[u] = base[(size_t)(3 * k + 1) * C + jc];
+                    nz[u] = base[(size_t)(3 * k + 2) * C + jc];
+                }
+#pragma unroll
+                for (int u = 0; u < 5; ++u) {
+                    const int k = 5 * kg + u;
+                    const double px = L.own_s[3 * k], py = L.own_s[3 * k + 1], pz = L.own_s[3 * k + 2];
+                    const double dx = px - nx[u], dy = py - ny[u], dz = pz - nz[u];
+                    const double ez = dz * P.e1z;
+                    const double dist = sqrt(dx * dx + dy * dy + ez * ez);
+                    if (var == VAR_HARD) {
+                        // solveHardDMPC.m:18-22 + CollConstrHardDMPC.m:19: every k, neighbours with dist < 1.
+                        // (rows are emitted neighbour-chunk-major here; the reference's k-major order only
+                        //  changes tie breaks of the active-set path, not the unique minimiser)
+                        emit_row(valid && dist < 1.0, k, dx, dy, dz, dist, px, py, pz);
+                    } else {
+                        if (valid && dist < rmin) anyb |= (1u << k);           // CheckCollSoftDMPC.m:11
+                        if (k == 0 && valid) mind0 = fmin(mind0, dist);
                     }
                 }
             }
-            if (!__any(any)) continue;
+        }
+    }
+    if (var == VAR_HARD) {
+        rows_exist = (G * C > 1);   // preallocated zero rows make Ain_coll non-empty (CollConstrHardDMPC.m:3-4)
+    } else {
+        anyb = wave_or(anyb);
+        for (int k = 0; k < K; ++k) {
+            if (!((anyb >> k) & 1u)) continue;
             if (var == VAR_ALL3) violation = true;   // solveSoftDMPCall.m:22 (some_violation)
             if (coll_check && k == 0) {
-                mind = wave_min(mind);
-                if (mind < rmin - 0.05) { status = ST_COLL; viol_k = 1; break; }   // :25-31
+                mind0 = wave_min(mind0);
+                if (mind0 < rmin - 0.05) { status = ST_COLL; viol_k = 1; break; }   // :25-31
             }
             if (skip_k1 && k == 0) continue;          // solveSoftDMPCbound2.m:29-31
             viol_k = k + 1; violation = true; rows_exist = true;
@@ -417,9 +495,10 @@ __global__ __launch_bounds__(64) void dmpc_step_kernel(StepParams P)
         }
     }
     LSYNC();
-    const int nrows_built = nr;
+    const int nrows_built = nrows_ref;
     if (nr > nrmax) { status |= ST_CAPACITY; nr = nrmax; }
 
+    const long long tk1 = clock64();
     // ---------------------------------------------------------------- cost case + tables (a7, :43-58)
     int ccase = 2;
     {
@@ -453,6 +532,8 @@ __global__ __launch_bounds__(64) void dmpc_step_kernel(StepParams P)
     }
     LSYNC();
 
+    const long long tk2 = clock64();
+    long long tkA = 0, tkB = 0, tkC = 0, tkD = 0;
     // ---------------------------------------------------------------- a7: dual active-set solve
     const bool ladder = (var == VAR_BOUND || var == VAR_BOUND2 || var == VAR_ALL3);
     const int max_tries = P.max_tries > 0 ? P.max_tries : 30;
@@ -471,21 +552,19 @@ __global__ __launch_bounds__(64) void dmpc_step_kernel(StepParams P)
             LSYNC();
             int rc = 0;   // 0 running/ok, 1 infeasible, 2 capacity, 3 itercap
             int iters = 0;
+            // x(lambda = 0): the unconstrained minimiser.  From here on the primal (a, w in registers,
+            // w_s / r_eps in LDS) is updated INCREMENTALLY with the step direction z = H^-1 nu that the
+            // dependence test needs anyway; it is re-derived from the multipliers (and the active-set
+            // residual refined) before the solution is accepted and every 32 changes of the working set.
+            a = a_unc; w = w_unc;
+            if (lane < N3) { L.a_s[lane] = a; L.w_s[lane] = w; }
+            if (soft) for (int i = lane; i < nr; i += 64) L.r_eps[i] = 0.0;
+            unsigned cslot = 0xffffffffu;   // component lane: slots of its BOXHI | BOXLO | POSHI | POSLO (0xff = none)
+            LSYNC();
+            bool fresh = true;              // primal == x(lambda) with refined lambda
+            int since_sync = 0;
             for (;;) {
-                primal(L, lane, q, nr, soft, a_unc, w_unc, a, w);
-                // refinement of the active-set residual: lam += T T' rho
-                if (q > 0) {
-                    for (int pass = 0; pass < 3; ++pass) {
-                        double rho = (lane < q) ? (slot_value(L, lane, L.a_s, L.w_s, L.r_eps) - L.s_d[lane]) : 0.0;
-                        const double mx = wave_max(fabs(rho));
-                        if (!(mx > 1e-13)) break;
-                        const double dvj = t_tmul(L.T, lane, q, rho);
-                        const double ri = t_mul(L.T, lane, q, dvj);
-                        if (lane < q) L.s_lam[lane] += ri;
-                        LSYNC();
-                        primal(L, lane, q, nr, soft, a_unc, w_unc, a, w);
-                    }
-                }
+                const long long tq0 = clock64();
                 // ---- most violated constraint not in the working set
                 double bestv = tol; int bestc = -1;
                 if (lane < N3) {
@@ -511,14 +590,32 @@ __global__ __launch_bounds__(64) void dmpc_step_kernel(StepParams P)
                 }
                 const double vmax = wave_max(bestv);
                 const unsigned long long wm = __ballot(bestc >= 0 && bestv == vmax);
-                if (wm == 0ull) break;   // optimal
+                if (wm == 0ull) {
+                    if (q == 0 || fresh) break;   // optimal
+                    // verification: primal from the multipliers, refine the active-set residual, re-check
+                    primal(L, lane, q, nr, soft, a_unc, w_unc, a, w);
+                    for (int pass = 0; pass < 3; ++pass) {
+                        double rho = (lane < q) ? (slot_value(L, lane, L.a_s, L.w_s, L.r_eps) - L.s_d[lane]) : 0.0;
+                        const double mx = wave_max(fabs(rho));
+                        if (!(mx > 1e-13)) break;
+                        const double dvj = t_tmul(L.T, lane, q, rho);
+                        const double ri = t_mul(L.T, lane, q, dvj);
+                        if (lane < q) L.s_lam[lane] += ri;
+                        LSYNC();
+                        primal(L, lane, q, nr, soft, a_unc, w_unc, a, w);
+                    }
+                    fresh = true;
+                    continue;
+                }
+                fresh = false;
+                tkA += clock64() - tq0;
                 const int src = __ffsll((long long)wm) - 1;
                 const int pcode = readlane_i(bestc, src);
                 double vp = readlane_d(bestv, src);
                 Cdesc p = make_desc(pcode >> 16, pcode & 0xffff, L, A, P, soft);
                 // lazily instantiate the eps<=0 pin of a soft row that becomes active (S(u,u) = 1/2)
                 if (p.ty == TY_COLL && p.si >= 0 && !(L.r_fl[p.idx] & RF_LIVE)) {
-                    if (q >= QMAX - 1) { rc = 2; break; }
+                    if (q >= P.qcap - 1) { rc = 2; break; }
                     Cdesc u = make_desc(TY_SLKU, p.idx, L, A, P, soft);
                     if (lane < q) L.T[tcol(q) + lane] = 0.0;
                     if (lane == 0) { L.T[tcol(q) + q] = 1.4142135623730951; L.r_fl[p.idx] |= (RF_LIVE | RF_SLKU); }
@@ -531,9 +628,18 @@ __global__ __launch_bounds__(64) void dmpc_step_kernel(StepParams P)
                 // ---- inner loop: partial steps until p can be added
                 for (;;) {
                     if (++iters > ITER_CAP) { rc = 3; break; }
+                    const long long tq1 = clock64();
                     const double sv = (lane < q) ? sdot_slot(L, lane, p) : 0.0;
                     const double dvj = t_tmul(L.T, lane, q, sv);
                     const double ri = t_mul(L.T, lane, q, dvj);
+                    if (lane < q) L.rr_s[lane] = ri;
+                    const long long tq2 = clock64(); tkB += tq2 - tq1;
+                    // masks of the slots that need a loop: collision rows (position-space normals that are not
+                    // unit vectors) and slack-coupled constraints; boxes / position bounds are O(1) per lane
+                    const int myty = (lane < q) ? L.s_ty[lane] : -1;
+                    const unsigned long long cmk = __ballot(myty == TY_COLL);
+                    const unsigned long long smk = soft ? __ballot(myty >= TY_COLL && L.s_ss[lane < q ? lane : 0] != 0.0) : 0ull;
+                    LSYNC();
                     // residual nu = n_p - N_W r, assembled EXPLICITLY as one vector in a-space
                     //   nu_a = U + Lambda' Y   (U: box part, Y: position/collision part),  nu_eps per live slack
                     // and delta = nu' H^-1 nu = z'Hz.  When p is (nearly) dependent on W, nu is small and the
@@ -543,11 +649,14 @@ __global__ __launch_bounds__(64) void dmpc_step_kernel(StepParams P)
                     if (lane < N3) {
                         const double vpax = ax_l == 0 ? p.v0 : (ax_l == 1 ? p.v1 : p.v2);
                         if (p.ty <= TY_COLL && p.kb == k_l) { if (p.isA) Uacc += vpax; else Yacc += vpax; }
-                        for (int j = 0; j < q; ++j) {
-                            const int ty = L.s_ty[j];
-                            if (ty > TY_COLL || L.s_kb[j] != k_l) continue;
-                            const double coef = -readlane_d(ri, j) * L.s_vec[3 * j + ax_l];
-                            if (ty < TY_POSHI) Uacc += coef; else Yacc += coef;
+                        const unsigned s0 = cslot & 0xffu, s1 = (cslot >> 8) & 0xffu, s2 = (cslot >> 16) & 0xffu, s3 = cslot >> 24;
+                        if (s0 != 0xffu) Uacc -= L.rr_s[s0];   // BOXHI: vec = +e
+                        if (s1 != 0xffu) Uacc += L.rr_s[s1];   // BOXLO: vec = -e
+                        if (s2 != 0xffu) Yacc -= L.rr_s[s2];   // POSHI
+                        if (s3 != 0xffu) Yacc += L.rr_s[s3];   // POSLO
+                        for (unsigned long long m = cmk; m; m &= m - 1) {
+                            const int j = __ffsll((long long)m) - 1;
+                            if (L.s_kb[j] == k_l) Yacc -= L.rr_s[j] * L.s_vec[3 * j + ax_l];
                         }
                         L.yt_s[lane] = Yacc;
                     }
@@ -556,27 +665,43 @@ __global__ __launch_bounds__(64) void dmpc_step_kernel(StepParams P)
                     if (lane < N3) {
                         const double h2 = P.h * P.h;
                         nu = Uacc;
-                        for (int kk = k_l; kk < K; ++kk) nu += (0.5 * h2 + (double)(kk - k_l) * h2) * L.yt_s[3 * kk + ax_l];
+#pragma unroll
+                        for (int kk = 0; kk < K; ++kk)
+                            if (kk >= k_l) nu += (0.5 * h2 + (double)(kk - k_l) * h2) * L.yt_s[3 * kk + ax_l];
                         L.nu_s[lane] = nu;
                     }
                     LSYNC();
-                    double part = 0.0;
+                    double part = 0.0, za = 0.0, zw = 0.0;
                     if (lane < N3) {
-                        double za = 0.0;
-                        for (int kk = 0; kk < K; ++kk) za += L.tabH[k_l * 15 + kk] * L.nu_s[3 * kk + ax_l];
+#pragma unroll
+                        for (int kk = 0; kk < K; ++kk) {
+                            const double nk = L.nu_s[3 * kk + ax_l];
+                            za += L.tabH[k_l * 15 + kk] * nk;
+                            zw += L.tabM[kk * 15 + k_l] * nk;
+                        }
                         part = nu * za;
                     }
-                    if (soft) {   // slack part: nu_eps(i) = sigma_p[si_p==i] - sum_j r_j sigma_j[si_j==i]; H_eps^-1 = 1/2
-                        for (int i = lane; i < nr; i += 64) {
-                            if (L.r_fl[i] & RF_LIVE) {
-                                double e = (p.si == i) ? p.ss : 0.0;
-                                for (int j = 0; j < q; ++j)
-                                    if (L.s_ty[j] >= TY_COLL && L.s_idx[j] == i) e -= readlane_d(ri, j) * L.s_ss[j];
-                                part += 0.5 * e * e;
-                            }
+                    // slack part: nu_eps(row) = sigma_p[si_p==row] - sum_j r_j sigma_j[si_j==row]; H_eps^-1 = 1/2.
+                    // Each slack-coupled slot lane gathers its row's value; the lowest such slot of a row
+                    // accounts for it (and for the eps update below).
+                    double nue = 0.0; bool owner = false;
+                    bool p_row_has_slot = false;
+                    if (soft) {
+                        const bool mine = (smk >> lane) & 1ull;
+                        const int myrow = mine ? L.s_idx[lane] : -1;
+                        owner = mine;
+                        if (mine && p.si == myrow) nue += p.ss;
+                        for (unsigned long long m = smk; m; m &= m - 1) {
+                            const int j = __ffsll((long long)m) - 1;
+                            const int rj = L.s_idx[j];
+                            if (rj == myrow) { nue -= L.rr_s[j] * L.s_ss[j]; if (j < lane) owner = false; }
+                            if (rj == p.si) p_row_has_slot = true;
                         }
+                        if (owner) part += 0.5 * nue * nue;
+                        if (p.si >= 0 && !p_row_has_slot && lane == 63) part += 0.5 * p.ss * p.ss;
                     }
                     const double delta = wave_sum(part);
+                    const long long tq3 = clock64(); tkC += tq3 - tq2;
                     const bool dependent = !(delta > 1e-13 * spp);
                     const double t2 = dependent ? INFINITY : vp / delta;
                     // ratio test on the multipliers
@@ -590,15 +715,25 @@ __global__ __launch_bounds__(64) void dmpc_step_kernel(StepParams P)
                     if (!(t < INFINITY)) { rc = 1; break; }
                     if (lane < q) L.s_lam[lane] -= t * ri;
                     lam_p += t;
-                    if (!dependent) vp -= t * delta;
+                    if (!dependent) {
+                        vp -= t * delta;
+                        // primal step x -= t z
+                        a -= t * za; w -= t * zw;
+                        if (lane < N3) { L.a_s[lane] = a; L.w_s[lane] = w; }
+                        if (soft) {
+                            if (owner) L.r_eps[L.s_idx[lane]] -= t * 0.5 * nue;
+                            if (p.si >= 0 && !p_row_has_slot && lane == 63) L.r_eps[p.si] -= t * 0.5 * p.ss;
+                        }
+                    }
                     if (t2 <= t1) {
                         // full step: append p (new column of T = [-r/rho ; 1/rho])
-                        if (q >= QMAX) { rc = 2; break; }
+                        if (q >= P.qcap) { rc = 2; break; }
                         const double rho = sqrt(delta);
                         if (lane < q) L.T[tcol(q) + lane] = -ri / rho;
                         if (lane == 0) L.T[tcol(q) + q] = 1.0 / rho;
                         write_slot(L, lane, q, p, lam_p);
                         set_member(L, lane, p.ty, p.idx, true, cmask);
+                        if (p.ty < TY_COLL && lane == p.idx) cslot = (cslot & ~(0xffu << (8 * p.ty))) | ((unsigned)q << (8 * p.ty));
                         q++;
                         if (q > maxq) maxq = q;
                         LSYNC();
@@ -610,7 +745,7 @@ __global__ __launch_bounds__(64) void dmpc_step_kernel(StepParams P)
                     const int dty = L.s_ty[l], didx = L.s_idx[l];
                     LSYNC();
                     set_member(L, lane, dty, didx, false, cmask);
-                    remove_slot(L, lane, q, l);
+                    remove_slot(L, lane, q, l, cslot);
                     // de-instantiate the pin of a soft row whose collision row just left the set
                     if (soft && dty == TY_COLL && didx != ((p.ty == TY_COLL) ? p.idx : -1)) {
                         const int fl = L.r_fl[didx];
@@ -618,8 +753,8 @@ __global__ __launch_bounds__(64) void dmpc_step_kernel(StepParams P)
                             const unsigned long long um = __ballot(lane < q && L.s_ty[lane] == TY_SLKU && L.s_idx[lane] == didx);
                             const int ul = __ffsll((long long)um) - 1;
                             LSYNC();
-                            if (lane == 0) L.r_fl[didx] = 0;
-                            remove_slot(L, lane, q, ul);
+                            if (lane == 0) { L.r_fl[didx] = 0; L.r_eps[didx] = 0.0; }
+                            remove_slot(L, lane, q, ul, cslot);
                         }
                     }
                 }
@@ -629,9 +764,10 @@ __global__ __launch_bounds__(64) void dmpc_step_kernel(StepParams P)
                     const unsigned long long um = __ballot(lane < q && L.s_ty[lane] == TY_SLKU && L.s_idx[lane] == p.idx);
                     const int ul = __ffsll((long long)um) - 1;
                     LSYNC();
-                    if (lane == 0) L.r_fl[p.idx] = 0;
-                    remove_slot(L, lane, q, ul);
+                    if (lane == 0) { L.r_fl[p.idx] = 0; L.r_eps[p.idx] = 0.0; }
+                    remove_slot(L, lane, q, ul, cslot);
                 }
+                if (((++since_sync) & 31) == 0) primal(L, lane, q, nr, soft, a_unc, w_unc, a, w);   // periodic re-sync with x(lambda)
             }
             iters_total += iters;
             if (rc == 0) { solved = true; break; }
@@ -649,6 +785,7 @@ __global__ __launch_bounds__(64) void dmpc_step_kernel(StepParams P)
         if (!solved && !(status & (ST_CAPACITY | ST_ITERCAP))) status |= ST_INFEAS;
     }
 
+    const long long tk3 = clock64();
     // ---------------------------------------------------------------- a9/a10: propagate, outputs
     int nslack = 0;
     if (solved) {
@@ -682,6 +819,11 @@ __global__ __launch_bounds__(64) void dmpc_step_kernel(StepParams P)
         P.v_out[(size_t)gid * N3 + lane] = v_out;
         P.a_out[(size_t)gid * N3 + lane] = a_out;
         if (P.lT_next) P.lT_next[((size_t)scene * N3 + lane) * C + cl] = solved ? p_out : own;
+    }
+    if (P.dbg && gid == P.dbg_agent && lane == 0) {
+        double *d = P.dbg + (size_t)P.dbg_cap * 8 - 8;
+        d[0] = (double)(tk1 - tk0); d[1] = (double)(tk2 - tk1); d[2] = (double)(tk3 - tk2); d[3] = (double)(clock64() - tk3);
+        d[4] = (double)tkA; d[5] = (double)tkB; d[6] = (double)tkC; d[7] = (double)iters_total;
     }
     if (lane == 0) {
         P.status[gid] = status;

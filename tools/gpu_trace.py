@@ -18,7 +18,11 @@ buf = np.zeros((cap, 8))
 L.dmpc_debug_trace(d._ctx, agent, cap, buf.ctypes.data_as(C.c_void_p))
 print("status", out["status"][agent], "info", out["info"][agent])
 names = ["BH", "BL", "PH", "PL", "CO", "SU", "SL"]
-for i, r in enumerate(buf):
-    if r[3] == 0: break
+for i, r in enumerate(buf[:-1]):
+    if r[3] == 0 or i >= 6: break
     code = int(r[0])
     print(f"{i+1:4d} p={names[code>>16]}{code&0xffff:<4d} q={int(r[1]):2d} delta/spp={r[2]/r[3]:.3e} t1={r[4]:.4e} t2={r[5]:.4e} vp={r[6]:.3e} lam_p={r[7]:.3e}")
+
+ph = buf[cap - 1]
+print("phase cycles: scan+rows=%d setup=%d solve=%d out=%d | in solve: violation-scan=%d sdot+matvec=%d nu/delta=%d iters=%d" % tuple(int(x) for x in ph))
+if ph[7] > 0: print("per iteration: solve=%.0f viol=%.0f matvec=%.0f nu=%.0f cycles" % (ph[2]/ph[7], ph[4]/ph[7], ph[5]/ph[7], ph[6]/ph[7]))
