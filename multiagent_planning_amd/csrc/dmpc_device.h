@@ -7,7 +7,9 @@ namespace dmpc {
 constexpr int K = 15;         // horizon k_hor (dmpc_soft_bound.m:13)
 constexpr int N3 = 3 * K;     // stacked acceleration / position vector length
 constexpr int QMAX = 64;      // working-set capacity (slots of the inverse factor T) == wave size
-constexpr int TPACK = QMAX * (QMAX + 1) / 2;   // packed upper-triangular storage of T
+// doubles of the zero-padded column-major upper-triangular factor for a given working-set capacity
+// (columns up to the next multiple of 8, plus slack for unconditional wave reads past the last column)
+__host__ __device__ inline int t_doubles(int qcap) { const int c = (qcap + 7) & ~7; const int g = c >> 3; return 8 * (g + 1) * (c - 4 * g) + 64; }
 constexpr int ITER_CAP = 4000;
 
 enum { VAR_BOUND = 0, VAR_BOUND2 = 1, VAR_ALL3 = 2, VAR_HARD = 3, VAR_ONDEMAND = 4, VAR_ELLIP = 5, VAR_SOFTALL = 6, VAR_REPAIR = 7 };
@@ -30,7 +32,7 @@ struct StepParams {
 // bytes of dynamic LDS the step kernel carves for a given row capacity
 inline size_t step_lds_bytes(int nrmax, bool soft, int qcap = QMAX)
 {
-    size_t dbl = (size_t)(qcap * (qcap + 1)) / 2 + 675 + 5 * 48 + 3 * QMAX + 4 * QMAX + (size_t)nrmax * (4 + (soft ? 4 : 0));
+    size_t dbl = (size_t)t_doubles(qcap) + 675 + 5 * 48 + 3 * QMAX + 5 * QMAX + (size_t)nrmax * (4 + (soft ? 4 : 0));
     size_t ints = 3 * QMAX + 2 * (size_t)nrmax;
     return dbl * 8 + ints * 4;
 }

@@ -89,11 +89,11 @@ enum { TY_BOXHI = 0, TY_BOXLO = 1, TY_POSHI = 2, TY_POSLO = 3, TY_COLL = 4, TY_S
 enum { RF_COLL = 1, RF_SLKU = 2, RF_SLKL = 4, RF_LIVE = 8 };
 
 struct Lds {
-    double *T;      // packed upper-triangular inverse Cholesky factor (TPACK doubles)
+    double *T;      // zero-padded column-major upper-triangular inverse Cholesky factor (t_doubles(qcap))
     double *tabH, *tabM, *tabP;  // 15x15: H1^-1, H1^-1 L', L H1^-1 L'
     double *a_s, *w_s, *own_s, *nu_s, *yt_s;   // 48 each
     double *s_vec;  // QMAX x 3
-    double *s_ss, *s_d, *s_lam, *rr_s;
+    double *s_ss, *s_d, *s_lam, *rr_s, *xs_s;
     double *r_xi;   // nrmax x 3
     double *r_b;
     double *r_sd, *r_st, *r_slb, *r_eps;  // soft variants only
@@ -197,41 +197,43 @@ __device__ __forceinline__ void primal(const Lds &L, int lane, int q, int nr, bo
     LSYNC();
 }
 
-// ---- packed upper-triangular inverse factor: T[i][j] (i <= j) at Tp[j(j+1)/2 + i] (column-major packed).
-// Triangular numbers mod 32 are a permutation, so "lane j reads column j" is conflict-free for
-// ds_read_b64, and "lane i reads row i of one column" is a contiguous read.
-__device__ __forceinline__ int tcol(int j) { return (j * (j + 1)) >> 1; }
+// ---- inverse factor storage: upper-triangular T, column-major, column j zero-padded to a multiple of 8 rows:
+//   T[i][j] (i <= j) at Tp[tcol(j) + i],  tcol(j) = 8 (g+1)(j - 4g), g = j/8;  rows j+1 .. 8*ceil((j+1)/8)-1 are ZERO.
+// The padding lets the column dot products run in unmasked groups of 8 (a lane either owns the whole group
+// or skips it), and "lane i reads row i of column j" is a contiguous wave read.
+__device__ __forceinline__ int tcol(int j) { const int g = j >> 3; return 8 * (g + 1) * (j - 4 * g); }
 
-// y = T' x  (lane j gets y_j; x_i lives in lane i).  Branch-free: addresses are clamped into the
-// lane's own column and the value is masked afterwards, so the four LDS reads of an unrolled group are
-// issued back to back (a predicated load would serialise on exec-mask branches).
-__device__ __forceinline__ double t_tmul(const double *Tp, int lane, int q, double x)
+// y = T' x  (lane j gets y_j).  x is in the LDS staging vector xs[0..63] (zero beyond q).  Per group of 8:
+// 16 unconditional LDS reads with immediate offsets, one wait, 8 FMAs, one lane mask for the whole group.
+__device__ __forceinline__ double t_tmul(const double *Tp, const double *xs, int lane, int q, int qcap)
 {
     double acc = 0.0;
-    const int jl = lane < q ? lane : 0;
-    const int cj = tcol(jl);
-    for (int i0 = 0; i0 < q; i0 += 16) {
-        double t[16];
+    const double *col = Tp + tcol(lane < qcap ? lane : qcap - 1);
+    for (int i0 = 0; i0 < q; i0 += 8) {
+        double t[8], x[8];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) { const int i = i0 + u; t[u] = Tp[cj + (i < jl ? i : jl)]; }
+        for (int u = 0; u < 8; ++u) { t[u] = col[i0 + u]; x[u] = xs[i0 + u]; }
+        double g = 0.0;
 #pragma unroll
-        for (int u = 0; u < 16; ++u) { const int i = i0 + u; acc = fma((i <= jl) ? t[u] : 0.0, readlane_d(x, i & 63), acc); }
+        for (int u = 0; u < 8; ++u) g = fma(t[u], x[u], g);
+        acc += (i0 <= lane && lane < q) ? g : 0.0;
     }
-    return lane < q ? acc : 0.0;
+    return acc;
 }
-// y = T x  (lane i gets y_i; x_j lives in lane j)
-__device__ __forceinline__ double t_mul(const double *Tp, int lane, int q, double x)
+// y = T x  (lane i gets y_i): column-oriented accumulation, lane mask i <= j per element
+__device__ __forceinline__ double t_mul(const double *Tp, const double *xs, int lane, int q, int qcap)
 {
     double acc = 0.0;
-    const int il = lane < q ? lane : 0;
-    for (int j0 = 0; j0 < q; j0 += 16) {
-        double t[16];
+    const double *row = Tp + lane;
+    for (int j0 = 0; j0 < q; j0 += 8) {
+        double t[8], x[8];
+        const int c0 = tcol(j0), len = j0 + 8;   // the 8 columns of this group all have padded length j0 + 8
 #pragma unroll
-        for (int u = 0; u < 16; ++u) { const int j = j0 + u; const int jc = j < q ? j : q - 1; t[u] = Tp[tcol(jc) + (il < jc ? il : jc)]; }
+        for (int u = 0; u < 8; ++u) { t[u] = row[c0 + u * len]; x[u] = xs[j0 + u]; }
 #pragma unroll
-        for (int u = 0; u < 16; ++u) { const int j = j0 + u; acc = fma((j >= il && j < q) ? t[u] : 0.0, readlane_d(x, j & 63), acc); }
+        for (int u = 0; u < 8; ++u) acc = fma((lane <= j0 + u && j0 + u < q) ? t[u] : 0.0, x[u], acc);   // columns >= q are uninitialised
     }
-    return lane < q ? acc : 0.0;
+    return (lane < q) ? acc : 0.0;
 }
 
 // value n_j'x - d_j of the slot owned by this lane
@@ -318,7 +320,17 @@ __global__ __launch_bounds__(64, 2) void dmpc_step_kernel(StepParams P)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
     const int S = P.S, G = P.G, C = P.C, nrmax = P.nrmax;
-    const int scene = blockIdx.x / P.c_count, ci = blockIdx.x - scene * P.c_count;
+    // XCD-aware mapping: workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8, private L2
+    // each), so renumber them such that every XCD works on whole scenes: a scene's prediction table is then
+    // fetched into ONE L2 instead of eight.  Pure performance remap (a bijection on [0, gridDim)).
+    int vb;
+    {
+        const int nb = gridDim.x, x = blockIdx.x & 7, y = blockIdx.x >> 3;
+        int off = 0;
+        for (int xx = 0; xx < x; ++xx) off += (nb - xx + 7) >> 3;
+        vb = off + y;
+    }
+    const int scene = vb / P.c_count, ci = vb - scene * P.c_count;
     const int cl = P.c_first + ci;                                     // agent inside chunk g_local
     const int gid = scene * P.c_count + ci;                            // index into the launch's arrays
     const int var = P.variant;
@@ -327,11 +339,11 @@ __global__ __launch_bounds__(64, 2) void dmpc_step_kernel(StepParams P)
     Lds L;
     {
         double *p = (double *)smem;
-        L.T = p; p += (P.qcap * (P.qcap + 1)) / 2;
+        L.T = p; p += t_doubles(P.qcap);
         L.tabH = p; p += 225; L.tabM = p; p += 225; L.tabP = p; p += 225;
         L.a_s = p; p += 48; L.w_s = p; p += 48; L.own_s = p; p += 48; L.nu_s = p; p += 48; L.yt_s = p; p += 48;
         L.s_vec = p; p += 3 * QMAX;
-        L.s_ss = p; p += QMAX; L.s_d = p; p += QMAX; L.s_lam = p; p += QMAX; L.rr_s = p; p += QMAX;
+        L.s_ss = p; p += QMAX; L.s_d = p; p += QMAX; L.s_lam = p; p += QMAX; L.rr_s = p; p += QMAX; L.xs_s = p; p += QMAX;
         L.r_xi = p; p += 3 * nrmax;
         L.r_b = p; p += nrmax;
         if (soft) { L.r_sd = p; p += nrmax; L.r_st = p; p += nrmax; L.r_slb = p; p += nrmax; L.r_eps = p; p += nrmax; }
@@ -598,8 +610,10 @@ __global__ __launch_bounds__(64, 2) void dmpc_step_kernel(StepParams P)
                         double rho = (lane < q) ? (slot_value(L, lane, L.a_s, L.w_s, L.r_eps) - L.s_d[lane]) : 0.0;
                         const double mx = wave_max(fabs(rho));
                         if (!(mx > 1e-13)) break;
-                        const double dvj = t_tmul(L.T, lane, q, rho);
-                        const double ri = t_mul(L.T, lane, q, dvj);
+                        L.xs_s[lane] = rho; LSYNC();
+                        const double dvj = t_tmul(L.T, L.xs_s, lane, q, P.qcap);
+                        L.rr_s[lane] = dvj; LSYNC();
+                        const double ri = t_mul(L.T, L.rr_s, lane, q, P.qcap);
                         if (lane < q) L.s_lam[lane] += ri;
                         LSYNC();
                         primal(L, lane, q, nr, soft, a_unc, w_unc, a, w);
@@ -617,8 +631,8 @@ __global__ __launch_bounds__(64, 2) void dmpc_step_kernel(StepParams P)
                 if (p.ty == TY_COLL && p.si >= 0 && !(L.r_fl[p.idx] & RF_LIVE)) {
                     if (q >= P.qcap - 1) { rc = 2; break; }
                     Cdesc u = make_desc(TY_SLKU, p.idx, L, A, P, soft);
-                    if (lane < q) L.T[tcol(q) + lane] = 0.0;
-                    if (lane == 0) { L.T[tcol(q) + q] = 1.4142135623730951; L.r_fl[p.idx] |= (RF_LIVE | RF_SLKU); }
+                    if (lane < ((q + 8) & ~7)) L.T[tcol(q) + lane] = (lane == q) ? 1.4142135623730951 : 0.0;   // column + zero padding
+                    if (lane == 0) L.r_fl[p.idx] |= (RF_LIVE | RF_SLKU);
                     write_slot(L, lane, q, u, -L.r_st[p.idx]);
                     q++;
                     LSYNC();
@@ -630,9 +644,12 @@ __global__ __launch_bounds__(64, 2) void dmpc_step_kernel(StepParams P)
                     if (++iters > ITER_CAP) { rc = 3; break; }
                     const long long tq1 = clock64();
                     const double sv = (lane < q) ? sdot_slot(L, lane, p) : 0.0;
-                    const double dvj = t_tmul(L.T, lane, q, sv);
-                    const double ri = t_mul(L.T, lane, q, dvj);
-                    if (lane < q) L.rr_s[lane] = ri;
+                    L.xs_s[lane] = sv; LSYNC();
+                    const double dvj = t_tmul(L.T, L.xs_s, lane, q, P.qcap);
+                    L.rr_s[lane] = dvj; LSYNC();
+                    const double ri = t_mul(L.T, L.rr_s, lane, q, P.qcap);
+                    LSYNC();
+                    L.rr_s[lane] = ri;
                     const long long tq2 = clock64(); tkB += tq2 - tq1;
                     // masks of the slots that need a loop: collision rows (position-space normals that are not
                     // unit vectors) and slack-coupled constraints; boxes / position bounds are O(1) per lane
@@ -729,8 +746,7 @@ __global__ __launch_bounds__(64, 2) void dmpc_step_kernel(StepParams P)
                         // full step: append p (new column of T = [-r/rho ; 1/rho])
                         if (q >= P.qcap) { rc = 2; break; }
                         const double rho = sqrt(delta);
-                        if (lane < q) L.T[tcol(q) + lane] = -ri / rho;
-                        if (lane == 0) L.T[tcol(q) + q] = 1.0 / rho;
+                        if (lane < ((q + 8) & ~7)) L.T[tcol(q) + lane] = (lane < q) ? (-ri / rho) : ((lane == q) ? 1.0 / rho : 0.0);
                         write_slot(L, lane, q, p, lam_p);
                         set_member(L, lane, p.ty, p.idx, true, cmask);
                         if (p.ty < TY_COLL && lane == p.idx) cslot = (cslot & ~(0xffu << (8 * p.ty))) | ((unsigned)q << (8 * p.ty));
