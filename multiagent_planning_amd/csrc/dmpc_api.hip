@@ -46,6 +46,7 @@ struct dmpc_ctx {
     int64_t solves = 0;
     int max_lds_set = 0;
     // scratch for the host-pointer entry points
+    DevBuf rowbuf, rowkc;   // collision-row scratch of the step kernel
     DevBuf rows, lT, lT2, xp, xv, xa, pf, po, pout, vout, aout, status, info, hist_p, hist_v, hist_a, flags;
     // profiling
     int profile = 0;
@@ -262,7 +263,7 @@ extern "C" void dmpc_destroy(dmpc_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (auto &ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
-    DevBuf *bufs[] = {&ctx->rows, &ctx->lT, &ctx->lT2, &ctx->xp, &ctx->xv, &ctx->xa, &ctx->pf, &ctx->po, &ctx->pout,
+    DevBuf *bufs[] = {&ctx->rowbuf, &ctx->rowkc, &ctx->rows, &ctx->lT, &ctx->lT2, &ctx->xp, &ctx->xv, &ctx->xa, &ctx->pf, &ctx->po, &ctx->pout,
                       &ctx->vout, &ctx->aout, &ctx->status, &ctx->info, &ctx->hist_p, &ctx->hist_v, &ctx->hist_a, &ctx->flags};
     for (DevBuf *b : bufs) b->release();
     if (ctx->d_tables) (void)hipFree(ctx->d_tables);
@@ -298,26 +299,19 @@ static bool variant_soft(int v)
     return v == DMPC_VAR_BOUND || v == DMPC_VAR_BOUND2 || v == DMPC_VAR_ALL3 || v == DMPC_VAR_SOFTALL || v == DMPC_VAR_REPAIR;
 }
 
-// row capacity per agent: the exact worst case where it is affordable, else the LDS budget
+// row capacity per agent.  Rows live in global scratch (40-64 B each); LDS only holds 4-12 B per row
+// (working-set flags, slack value), so the exact worst case is affordable up to a few thousand rows.
+// The kernel flags DMPC_ST_CAPACITY if a cap is ever exceeded (never silently truncated).
 static int row_capacity(int variant, int N)
 {
     const long nb = N > 1 ? N - 1 : 1;
-    long want;
+    long want, cap;
     switch (variant) {
-    case DMPC_VAR_HARD: want = (long)K * nb; break;   // every k, every neighbour (CollConstrHardDMPC.m:3)
-    case DMPC_VAR_ALL3: want = 3 * nb; break;
-    default: want = nb; break;
+    case DMPC_VAR_HARD: want = (long)K * nb; cap = 640; break;     // every k, neighbours with d < 1 (CollConstrHardDMPC.m:19), after exact pruning
+    case DMPC_VAR_ALL3: want = 3 * nb; cap = 384; break;           // three steps x neighbours with d < 3 rmin
+    case DMPC_VAR_BOUND: case DMPC_VAR_BOUND2: case DMPC_VAR_ONDEMAND: want = nb; cap = 128; break;   // d < 3 rmin only
+    default: want = nb; cap = 4096; break;                         // ellip / softall / repair: all N-1 neighbours
     }
-    const bool soft = variant_soft(variant);
-    const long budget = 150 * 1024;   // leave headroom below the 160 KiB/CU LDS
-    const long fixed = (long)step_lds_bytes(0, soft);
-    const long per_row = (long)(step_lds_bytes(1, soft) - step_lds_bytes(0, soft));
-    long cap = (budget - fixed) / per_row;
-    // soft near-neighbour variants only ever select d < 3 rmin: 128 rows is generous and keeps
-    // several workgroups resident per CU; the kernel flags DMPC_ST_CAPACITY if it is ever exceeded
-    if (variant == DMPC_VAR_BOUND || variant == DMPC_VAR_BOUND2 || variant == DMPC_VAR_ONDEMAND) cap = cap < 128 ? cap : 128;
-    if (variant == DMPC_VAR_ALL3) cap = cap < 384 ? cap : 384;
-    if (variant == DMPC_VAR_HARD) cap = cap < 320 ? cap : 320;   // after exact pruning; beyond: DMPC_ST_CAPACITY
     long r = want < cap ? want : cap;
     if (r < 8) r = 8;
     return (int)((r + 1) & ~1L);
@@ -343,6 +337,12 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     P.lT = lT; P.x_p = x_p; P.x_v = x_v; P.x_a = x_a; P.pf = pf;
     P.p_out = p_out; P.v_out = v_out; P.a_out = a_out; P.lT_next = lT_next;
     P.status = status; P.info = info;
+    {
+        const size_t agents = (size_t)S * c_count;
+        if (ctx->rowbuf.ensure(agents * P.nrmax * (variant_soft(p.variant) ? 7 : 4) * 8) || ctx->rowkc.ensure(agents * P.nrmax * 4))
+            FAIL(ctx, "device allocation failed (row scratch)");
+        P.rowbuf = ctx->rowbuf.as<double>(); P.rowkc = ctx->rowkc.as<int>();
+    }
     P.dbg = ctx->dbg; P.dbg_agent = ctx->dbg_agent; P.dbg_cap = ctx->dbg_cap;
     const size_t lds = step_lds_bytes(P.nrmax, variant_soft(p.variant), P.qcap);
     if ((int)lds > ctx->max_lds_set) {

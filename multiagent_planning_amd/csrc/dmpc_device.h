@@ -25,6 +25,8 @@ struct StepParams {
     double *p_out, *v_out, *a_out;        // [S][c_count][3K]
     double *lT_next;                      // [S][3K][C] or null
     int *status, *info;
+    double *rowbuf;         // per-agent collision-row scratch [S*c_count][nrmax*(soft?7:4)] doubles (global, L2-resident)
+    int *rowkc;             // [S*c_count][nrmax] constrained horizon step of each row
     double *dbg;            // optional per-iteration trace of agent dbg_agent (development aid)
     int dbg_agent, dbg_cap;
 };
@@ -32,8 +34,8 @@ struct StepParams {
 // bytes of dynamic LDS the step kernel carves for a given row capacity
 inline size_t step_lds_bytes(int nrmax, bool soft, int qcap = QMAX)
 {
-    size_t dbl = (size_t)t_doubles(qcap) + 675 + 5 * 48 + 3 * QMAX + 5 * QMAX + (size_t)nrmax * (4 + (soft ? 4 : 0));
-    size_t ints = 3 * QMAX + 2 * (size_t)nrmax;
+    size_t dbl = (size_t)t_doubles(qcap) + 675 + 5 * 48 + 3 * QMAX + 5 * QMAX + (size_t)nrmax * (soft ? 1 : 0);   // r_eps only (rows themselves are in global memory)
+    size_t ints = 3 * QMAX + (size_t)nrmax;                                // r_fl
     return dbl * 8 + ints * 4;
 }
 

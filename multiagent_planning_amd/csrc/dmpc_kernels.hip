@@ -27,7 +27,10 @@ namespace dmpc {
 // --------------------------------------------------------------------------------------------
 // wave64 helpers
 // --------------------------------------------------------------------------------------------
-#define LSYNC() __syncthreads() /* block == one wave: orders LDS traffic, no cross-wave wait */
+// The workgroup is ONE wavefront and the LDS executes a wave's DS instructions in issue order, so lanes
+// exchanging data through LDS need no hardware barrier or counter wait -- only the compiler must not
+// reorder the accesses.  (A __syncthreads() here would also drain outstanding global loads.)
+#define LSYNC() asm volatile("" ::: "memory")
 
 __device__ __forceinline__ double readlane_d(double v, int l /*uniform*/)
 {
@@ -344,13 +347,21 @@ __global__ __launch_bounds__(64, 2) void dmpc_step_kernel(StepParams P)
         L.a_s = p; p += 48; L.w_s = p; p += 48; L.own_s = p; p += 48; L.nu_s = p; p += 48; L.yt_s = p; p += 48;
         L.s_vec = p; p += 3 * QMAX;
         L.s_ss = p; p += QMAX; L.s_d = p; p += QMAX; L.s_lam = p; p += QMAX; L.rr_s = p; p += QMAX; L.xs_s = p; p += QMAX;
-        L.r_xi = p; p += 3 * nrmax;
-        L.r_b = p; p += nrmax;
-        if (soft) { L.r_sd = p; p += nrmax; L.r_st = p; p += nrmax; L.r_slb = p; p += nrmax; L.r_eps = p; p += nrmax; }
-        else { L.r_sd = L.r_st = L.r_slb = L.r_eps = nullptr; }
+        // Collision rows live in a per-agent slice of a GLOBAL scratch buffer (L2-resident; lane = row, so
+        // every access is a coalesced wave load): keeping them out of LDS is what lets ~2x more agents be
+        // resident per CU.  Only the per-row working-set flags and the slack values stay in LDS.
+        {
+            const size_t per = (size_t)nrmax * (soft ? 7 : 4);
+            double *g = P.rowbuf + (size_t)gid * per;
+            L.r_xi = g; g += 3 * nrmax;
+            L.r_b = g; g += nrmax;
+            if (soft) { L.r_sd = g; g += nrmax; L.r_st = g; g += nrmax; L.r_slb = g; g += nrmax; }
+            else { L.r_sd = L.r_st = L.r_slb = nullptr; }
+        }
+        if (soft) { L.r_eps = p; p += nrmax; } else L.r_eps = nullptr;
         int *ip = (int *)p;
         L.s_kb = ip; ip += QMAX; L.s_ty = ip; ip += QMAX; L.s_idx = ip; ip += QMAX;
-        L.r_kc = ip; ip += nrmax; L.r_fl = ip; ip += nrmax;
+        L.r_kc = P.rowkc + (size_t)gid * nrmax; L.r_fl = ip; ip += nrmax;
     }
 
     // ---------------------------------------------------------------- agent state (uniform)
@@ -507,6 +518,9 @@ __global__ __launch_bounds__(64, 2) void dmpc_step_kernel(StepParams P)
         }
     }
     LSYNC();
+    // rows were written to global memory by this wave and are re-read by it: make the stores visible
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     const int nrows_built = nrows_ref;
     if (nr > nrmax) { status |= ST_CAPACITY; nr = nrmax; }
 
@@ -682,19 +696,29 @@ __global__ __launch_bounds__(64, 2) void dmpc_step_kernel(StepParams P)
                     if (lane < N3) {
                         const double h2 = P.h * P.h;
                         nu = Uacc;
+                        double yv[K];
 #pragma unroll
-                        for (int kk = 0; kk < K; ++kk)
-                            if (kk >= k_l) nu += (0.5 * h2 + (double)(kk - k_l) * h2) * L.yt_s[3 * kk + ax_l];
+                        for (int kk = 0; kk < K; ++kk) yv[kk] = L.yt_s[3 * kk + ax_l];
+#pragma unroll
+                        for (int kk = 0; kk < K; ++kk) {
+                            const double cf = (kk >= k_l) ? (0.5 * h2 + (double)(kk - k_l) * h2) : 0.0;   // Lambda(kk,k)
+                            nu = fma(cf, yv[kk], nu);
+                        }
                         L.nu_s[lane] = nu;
                     }
                     LSYNC();
                     double part = 0.0, za = 0.0, zw = 0.0;
                     if (lane < N3) {
 #pragma unroll
-                        for (int kk = 0; kk < K; ++kk) {
-                            const double nk = L.nu_s[3 * kk + ax_l];
-                            za += L.tabH[k_l * 15 + kk] * nk;
-                            zw += L.tabM[kk * 15 + k_l] * nk;
+                        for (int kg = 0; kg < 3; ++kg) {   // 15 loads in flight per group
+                            double nk[5], th[5], tm[5];
+#pragma unroll
+                            for (int u = 0; u < 5; ++u) {
+                                const int kk = 5 * kg + u;
+                                nk[u] = L.nu_s[3 * kk + ax_l]; th[u] = L.tabH[k_l * 15 + kk]; tm[u] = L.tabM[kk * 15 + k_l];
+                            }
+#pragma unroll
+                            for (int u = 0; u < 5; ++u) { za = fma(th[u], nk[u], za); zw = fma(tm[u], nk[u], zw); }
                         }
                         part = nu * za;
                     }
@@ -792,6 +816,8 @@ __global__ __launch_bounds__(64, 2) void dmpc_step_kernel(StepParams P)
             // infeasible: retry ladder (solveSoftDMPCbound.m:147-153): lb_eps *= 2, term *= 2
             if (ladder && violation) {
                 for (int i = lane; i < nr; i += 64) { L.r_slb[i] *= 2.0; L.r_st[i] *= 2.0; }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 LSYNC();
                 continue;
             }

@@ -84,3 +84,16 @@ def test_scene_batching_is_independent():
     # permuting the agents of a scene permutes the answers (neighbour order only affects tie breaks)
     assert np.array_equal(both["status"][1], one["status"][perm])
     assert np.abs(both["p"][1] - one["p"][perm]).max() < 1e-9
+
+
+@pytest.mark.parametrize("variant", ["bound", "hard", "all3"])
+def test_replicated_scenes_are_bitwise_identical(variant):
+    """The same scene 24x in one launch: every copy must give identical bits (catches any dependence on
+    uninitialised LDS / scheduling; LDS contents differ between first and later workgroups of a CU)."""
+    g, kw = load_golden("failure_rate2_bound")
+    l, xp, xv, xa, pf = step14_inputs(g)
+    S = 24
+    rep = lambda a: np.ascontiguousarray(np.broadcast_to(a, (S,) + a.shape))
+    out = mp.Dmpc(variant, **kw).step_batch(rep(l), rep(xp), rep(xv), rep(xa), rep(pf))
+    for k in ("p", "v", "a", "status", "info"):
+        assert np.array_equal(out[k], np.broadcast_to(out[k][0], out[k].shape)), k
