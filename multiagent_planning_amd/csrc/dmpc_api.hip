@@ -46,7 +46,9 @@ struct dmpc_ctx {
     int64_t solves = 0;
     int max_lds_set = 0;
     // scratch for the host-pointer entry points
-    DevBuf rowbuf, rowkc;   // collision-row scratch of the step kernel
+    DevBuf rowbuf, rowkc, hdr, order;   // collision-row scratch + scan->solve header of the step kernels
+    int no_lpt = getenv("DMPC_NO_LPT") ? 1 : 0;   // tuning: disable the heaviest-first solve order
+    int single_tier = 0;         // 1: solve with the full working-set capacity in one launch
     DevBuf rows, lT, lT2, xp, xv, xa, pf, po, pout, vout, aout, status, info, hist_p, hist_v, hist_a, flags;
     // profiling
     int profile = 0;
@@ -263,7 +265,7 @@ extern "C" void dmpc_destroy(dmpc_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (auto &ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
-    DevBuf *bufs[] = {&ctx->rowbuf, &ctx->rowkc, &ctx->rows, &ctx->lT, &ctx->lT2, &ctx->xp, &ctx->xv, &ctx->xa, &ctx->pf, &ctx->po, &ctx->pout,
+    DevBuf *bufs[] = {&ctx->rowbuf, &ctx->rowkc, &ctx->hdr, &ctx->order, &ctx->rows, &ctx->lT, &ctx->lT2, &ctx->xp, &ctx->xv, &ctx->xa, &ctx->pf, &ctx->po, &ctx->pout,
                       &ctx->vout, &ctx->aout, &ctx->status, &ctx->info, &ctx->hist_p, &ctx->hist_v, &ctx->hist_a, &ctx->flags};
     for (DevBuf *b : bufs) b->release();
     if (ctx->d_tables) (void)hipFree(ctx->d_tables);
@@ -317,18 +319,29 @@ static int row_capacity(int variant, int N)
     return (int)((r + 1) & ~1L);
 }
 
+// tier-1 working-set capacity of the solve kernel: small enough for high occupancy; the (few) agents
+// whose working set outgrows it are flagged and re-solved by a tier-2 launch with the full capacity
+static int tier1_qcap(int variant)
+{
+    static const int env = getenv("DMPC_TIER1_QCAP") ? atoi(getenv("DMPC_TIER1_QCAP")) : 0;   // tuning override
+    if (env >= 8) return env < 64 ? (env & ~7) : 64;
+    // solveHardDMPC builds rows for every horizon step: working sets routinely approach the 45-variable
+    // limit, so a small first tier would only add a second pass; every other variant stays far below 32
+    return variant == DMPC_VAR_HARD ? 46 : 32;
+}
+static int full_qcap(int variant) { return variant_soft(variant) ? QMAX : 46; }   // hard: 45 variables => <= 45 independent rows
+
 static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_first, int c_count, const double *lT,
                        const double *x_p, const double *x_v, const double *x_a, const double *pf, double *p_out,
                        double *v_out, double *a_out, double *lT_next, int32_t *status, int32_t *info, hipStream_t st)
 {
     const dmpc_params &p = ctx->prm;
+    const bool soft = variant_soft(p.variant);
     StepParams P;
     memset(&P, 0, sizeof(P));
     P.variant = p.variant; P.S = S; P.G = G; P.C = C; P.g_local = g_local;
     P.c_first = c_first; P.c_count = c_count;
     P.nrmax = row_capacity(p.variant, G * C);
-    // hard-constraint variants have 45 variables => at most 45 independent active constraints
-    P.qcap = variant_soft(p.variant) ? QMAX : 46;
     P.max_tries = p.max_tries;
     P.h = p.h; P.rmin = p.rmin; P.e1z = 1.0 / p.c; P.e2z = 1.0 / (p.c * p.c);
     P.alim = p.alim; P.Q1 = p.Q1; P.S1 = p.S1; P.term = p.term;
@@ -339,15 +352,20 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     P.status = status; P.info = info;
     {
         const size_t agents = (size_t)S * c_count;
-        if (ctx->rowbuf.ensure(agents * P.nrmax * (variant_soft(p.variant) ? 7 : 4) * 8) || ctx->rowkc.ensure(agents * P.nrmax * 4))
+        if (ctx->rowbuf.ensure(agents * P.nrmax * (soft ? 7 : 4) * 8) || ctx->rowkc.ensure(agents * P.nrmax * 4) ||
+            ctx->hdr.ensure(agents * 8 * 4) || ctx->order.ensure(agents * 4))
             FAIL(ctx, "device allocation failed (row scratch)");
-        P.rowbuf = ctx->rowbuf.as<double>(); P.rowkc = ctx->rowkc.as<int>();
+        P.rowbuf = ctx->rowbuf.as<double>(); P.rowkc = ctx->rowkc.as<int>(); P.hdr = ctx->hdr.as<int>();
     }
     P.dbg = ctx->dbg; P.dbg_agent = ctx->dbg_agent; P.dbg_cap = ctx->dbg_cap;
-    const size_t lds = step_lds_bytes(P.nrmax, variant_soft(p.variant), P.qcap);
-    if ((int)lds > ctx->max_lds_set) {
-        HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        ctx->max_lds_set = (int)lds;
+    const int q1 = ctx->single_tier ? full_qcap(p.variant) : tier1_qcap(p.variant), q2 = full_qcap(p.variant);
+    const bool two_tier = q1 < q2;
+    const size_t lds0 = step_lds_bytes(P.nrmax, soft, q1, 0);
+    const size_t lds1 = step_lds_bytes(P.nrmax, soft, q1, 1), lds2 = step_lds_bytes(P.nrmax, soft, q2, 1);
+    const size_t ldsmax = lds2 > lds1 ? lds2 : lds1;
+    if ((int)ldsmax > ctx->max_lds_set) {
+        HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_step_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsmax));
+        ctx->max_lds_set = (int)ldsmax;
     }
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
     if (ctx->profile) {
@@ -355,7 +373,21 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
         HIPCHK(ctx, hipEventCreate(&ev.second));
         HIPCHK(ctx, hipEventRecord(ev.first, st));
     }
-    hipLaunchKernelGGL(dmpc_step_kernel, dim3((unsigned)(S * c_count)), dim3(64), lds, st, P);
+    const dim3 grid((unsigned)(S * c_count)), block(64);
+    // phase 0: scan + rows
+    P.qcap = q1; P.only_flagged = 0; P.qover_bit = two_tier ? ST_QOVER : ST_CAPACITY;
+    hipLaunchKernelGGL(dmpc_step_kernel<0>, grid, block, lds0, st, P);
+    // heaviest-first launch order for the solve phase (skipped for tiny launches)
+    if (S * c_count >= 512 && !ctx->no_lpt) {
+        hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, st, S * c_count, (const int *)P.hdr, ctx->order.as<int>());
+        P.order = ctx->order.as<int>();
+    }
+    // phase 1, tier 1
+    hipLaunchKernelGGL(dmpc_step_kernel<1>, grid, block, lds1, st, P);
+    if (two_tier) {   // phase 1, tier 2: only agents flagged ST_QOVER do any work
+        P.qcap = q2; P.only_flagged = 1; P.qover_bit = ST_CAPACITY;
+        hipLaunchKernelGGL(dmpc_step_kernel<1>, grid, block, lds2, st, P);
+    }
     HIPCHK(ctx, hipGetLastError());
     if (ctx->profile) {
         HIPCHK(ctx, hipEventRecord(ev.second, st));

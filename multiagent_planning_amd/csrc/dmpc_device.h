@@ -13,7 +13,8 @@ __host__ __device__ inline int t_doubles(int qcap) { const int c = (qcap + 7) & 
 constexpr int ITER_CAP = 4000;
 
 enum { VAR_BOUND = 0, VAR_BOUND2 = 1, VAR_ALL3 = 2, VAR_HARD = 3, VAR_ONDEMAND = 4, VAR_ELLIP = 5, VAR_SOFTALL = 6, VAR_REPAIR = 7 };
-enum { ST_SOLVED = 1, ST_OUTBOUND = 2, ST_COLL = 4, ST_INFEAS = 8, ST_CAPACITY = 16, ST_ITERCAP = 32 };
+enum { ST_SOLVED = 1, ST_OUTBOUND = 2, ST_COLL = 4, ST_INFEAS = 8, ST_CAPACITY = 16, ST_ITERCAP = 32,
+       ST_QOVER = 64 /* internal: tier-1 working set overflowed, tier 2 re-solves */ };
 
 struct StepParams {
     int variant, S, G, C, g_local, nrmax, max_tries, c_first, c_count, qcap;
@@ -27,16 +28,20 @@ struct StepParams {
     int *status, *info;
     double *rowbuf;         // per-agent collision-row scratch [S*c_count][nrmax*(soft?7:4)] doubles (global, L2-resident)
     int *rowkc;             // [S*c_count][nrmax] constrained horizon step of each row
+    int *hdr;               // [S*c_count][8] scan -> solve hand-off (row count, branch record)
+    int only_flagged, qover_bit;
+    const int *order;       // solve-phase launch order (agent ids, heaviest first) or null
     double *dbg;            // optional per-iteration trace of agent dbg_agent (development aid)
     int dbg_agent, dbg_cap;
 };
 
 // bytes of dynamic LDS the step kernel carves for a given row capacity
-inline size_t step_lds_bytes(int nrmax, bool soft, int qcap = QMAX)
+inline size_t step_lds_bytes(int nrmax, bool soft, int qcap, int phase)
 {
-    size_t dbl = (size_t)t_doubles(qcap) + 675 + 5 * 48 + 3 * QMAX + 5 * QMAX + (size_t)nrmax * (soft ? 1 : 0);   // r_eps only (rows themselves are in global memory)
-    size_t ints = 3 * QMAX + (size_t)nrmax;                                // r_fl
-    return dbl * 8 + ints * 4;
+    if (phase == 0) return 48 * 8;
+    size_t dbl = (size_t)t_doubles(qcap) + 675 + 4 * 48 + 2 * 64 + 6 * (size_t)qcap + (soft ? (size_t)nrmax : 0);
+    size_t bytes = dbl * 8 + 3 * (size_t)qcap * 4 + (size_t)nrmax;   // + slot ints + row flags (bytes)
+    return (bytes + 15) & ~(size_t)15;
 }
 
 }  // namespace dmpc

@@ -101,7 +101,8 @@ struct Lds {
     double *r_b;
     double *r_sd, *r_st, *r_slb, *r_eps;  // soft variants only
     int *s_kb, *s_ty, *s_idx;
-    int *r_kc, *r_fl;
+    int *r_kc;
+    unsigned char *r_fl;
 };
 
 // uniform description of one constraint
@@ -318,6 +319,12 @@ __device__ __forceinline__ void set_member(const Lds &L, int lane, int ty, int i
 // --------------------------------------------------------------------------------------------
 // the step kernel: grid = S * C workgroups of 64 threads
 // --------------------------------------------------------------------------------------------
+// PHASE 0: scan + collision rows (a5/a6) -> global row scratch + 8-int header per agent
+// PHASE 1: QP solve + propagate + outputs (a7-a10), reading the header and the rows
+// Splitting the step keeps the solver's register and LDS footprint free of the scan's needs (more
+// resident agents per CU) and lets the solver be re-launched for the few agents that overflow the
+// tier-1 working-set capacity.
+template <int PHASE>
 __global__ __launch_bounds__(64, 2) void dmpc_step_kernel(StepParams P)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -333,36 +340,47 @@ __global__ __launch_bounds__(64, 2) void dmpc_step_kernel(StepParams P)
         for (int xx = 0; xx < x; ++xx) off += (nb - xx + 7) >> 3;
         vb = off + y;
     }
+    if (PHASE == 1 && P.order) vb = P.order[blockIdx.x];   // heaviest agents first (order_kernel)
     const int scene = vb / P.c_count, ci = vb - scene * P.c_count;
     const int cl = P.c_first + ci;                                     // agent inside chunk g_local
     const int gid = scene * P.c_count + ci;                            // index into the launch's arrays
     const int var = P.variant;
     const bool soft = (var == VAR_BOUND || var == VAR_BOUND2 || var == VAR_ALL3 || var == VAR_SOFTALL || var == VAR_REPAIR);
 
+    const int qcap = P.qcap;
     Lds L;
     {
         double *p = (double *)smem;
-        L.T = p; p += t_doubles(P.qcap);
-        L.tabH = p; p += 225; L.tabM = p; p += 225; L.tabP = p; p += 225;
-        L.a_s = p; p += 48; L.w_s = p; p += 48; L.own_s = p; p += 48; L.nu_s = p; p += 48; L.yt_s = p; p += 48;
-        L.s_vec = p; p += 3 * QMAX;
-        L.s_ss = p; p += QMAX; L.s_d = p; p += QMAX; L.s_lam = p; p += QMAX; L.rr_s = p; p += QMAX; L.xs_s = p; p += QMAX;
-        // Collision rows live in a per-agent slice of a GLOBAL scratch buffer (L2-resident; lane = row, so
-        // every access is a coalesced wave load): keeping them out of LDS is what lets ~2x more agents be
-        // resident per CU.  Only the per-row working-set flags and the slack values stay in LDS.
-        {
-            const size_t per = (size_t)nrmax * (soft ? 7 : 4);
-            double *g = P.rowbuf + (size_t)gid * per;
-            L.r_xi = g; g += 3 * nrmax;
-            L.r_b = g; g += nrmax;
-            if (soft) { L.r_sd = g; g += nrmax; L.r_st = g; g += nrmax; L.r_slb = g; g += nrmax; }
-            else { L.r_sd = L.r_st = L.r_slb = nullptr; }
+        if (PHASE == 0) {
+            L.own_s = p; p += 48;
+            L.T = L.tabH = L.tabM = L.tabP = L.a_s = L.w_s = L.nu_s = L.yt_s = nullptr;
+            L.s_vec = L.s_ss = L.s_d = L.s_lam = L.rr_s = L.xs_s = L.r_eps = nullptr;
+            L.s_kb = L.s_ty = L.s_idx = nullptr; L.r_fl = nullptr;
+        } else {
+            L.T = p; p += t_doubles(qcap);
+            L.tabH = p; p += 225; L.tabM = p; p += 225; L.tabP = p; p += 225;
+            L.a_s = p; p += 48; L.w_s = p; p += 48; L.nu_s = p; p += 48; L.yt_s = p; p += 48; L.own_s = nullptr;
+            L.rr_s = p; p += 64; L.xs_s = p; p += 64;
+            L.s_vec = p; p += 3 * qcap;
+            L.s_ss = p; p += qcap; L.s_d = p; p += qcap; L.s_lam = p; p += qcap;
+            if (soft) { L.r_eps = p; p += nrmax; } else L.r_eps = nullptr;
+            int *ip = (int *)p;
+            L.s_kb = ip; ip += qcap; L.s_ty = ip; ip += qcap; L.s_idx = ip; ip += qcap;
+            L.r_fl = (unsigned char *)ip;   // nrmax bytes
         }
-        if (soft) { L.r_eps = p; p += nrmax; } else L.r_eps = nullptr;
-        int *ip = (int *)p;
-        L.s_kb = ip; ip += QMAX; L.s_ty = ip; ip += QMAX; L.s_idx = ip; ip += QMAX;
-        L.r_kc = P.rowkc + (size_t)gid * nrmax; L.r_fl = ip; ip += nrmax;
+        // Collision rows live in a per-agent slice of a GLOBAL scratch buffer (L2-resident; lane = row, so
+        // every access is a coalesced wave load): keeping them out of LDS is what lets several times more
+        // agents be resident per CU.  Only the per-row working-set flags and the slack values stay in LDS.
+        const size_t per = (size_t)nrmax * (soft ? 7 : 4);
+        double *g = P.rowbuf + (size_t)gid * per;
+        L.r_xi = g; g += 3 * nrmax;
+        L.r_b = g; g += nrmax;
+        if (soft) { L.r_sd = g; g += nrmax; L.r_st = g; g += nrmax; L.r_slb = g; g += nrmax; }
+        else { L.r_sd = L.r_st = L.r_slb = nullptr; }
+        L.r_kc = P.rowkc + (size_t)gid * nrmax;
     }
+    int *hdr = P.hdr + (size_t)gid * 8;
+    if (PHASE == 1 && P.only_flagged && !(P.status[gid] & ST_QOVER)) return;   // tier 2: only agents that overflowed tier 1
 
     // ---------------------------------------------------------------- agent state (uniform)
     Agent A;
@@ -375,9 +393,10 @@ __global__ __launch_bounds__(64, 2) void dmpc_step_kernel(StepParams P)
     }
     // own previous prediction: prev_p = l(:,:,n)  (solveSoftDMPCbound.m:6)
     const double *lT_own = P.lT + ((size_t)(P.g_local * S + scene) * N3) * C + cl;
-    double own = 0.0;
-    if (lane < N3) { own = lT_own[(size_t)lane * C]; L.own_s[lane] = own; }
-    LSYNC();
+    if (PHASE == 0) {
+        if (lane < N3) L.own_s[lane] = lT_own[(size_t)lane * C];
+        LSYNC();
+    }
 
     const long long tk0 = clock64();
     // ---------------------------------------------------------------- a5/a6: scan + rows
@@ -388,141 +407,147 @@ __global__ __launch_bounds__(64, 2) void dmpc_step_kernel(StepParams P)
     const bool coll_check = (var == VAR_BOUND || var == VAR_BOUND2 || var == VAR_ALL3 || var == VAR_REPAIR);
     const bool skip_k1 = (var == VAR_BOUND2 || var == VAR_ALL3 || var == VAR_REPAIR);
 
-    // appends the rows of horizon step ke (evaluated positions) constraining step kc for every
-    // neighbour with dist < sel_r (or all), in increasing neighbour index (CollConstrSoftDMPC.m:11-31)
-    // one collision row, CollConstrSoftDMPC.m:16-28: neighbour offset (dx,dy,dz) and ellipsoidal distance at
-    // the evaluation step (own position px,py,pz), constraining horizon step kc; compacted by ballot
-    auto emit_row = [&](bool sel, int kc, double dx, double dy, double dz, double dist, double px, double py, double pz) {
-        const double sh = (double)(kc + 1) * P.h;
-        const double a0x = A.po[0] + sh * A.vo[0], a0y = A.po[1] + sh * A.vo[1], a0z = A.po[2] + sh * A.vo[2];
-        const double x0 = dx, x1 = dy, x2 = dz * P.e2z;   // diff = E2*(p - pj)
-        nrows_ref += __popcll(__ballot(sel));               // the reference's row count (branch record)
-        // Exact pruning: with |a| <= alim the position at step kc stays in the box
-        // A0_kc x0 +- alim (kc h)^2/2, so a row whose linearised distance cannot drop below rmin anywhere in
-        // that box can never become active; dropping it (and its slack, which stays 0) leaves the minimiser
-        // unchanged.  Margin 1e-9 keeps borderline rows.
-        {
-            const double hw = 0.5 * P.alim * sh * sh;
-            const double lin_min = x0 * (a0x - (px - dx)) + x1 * (a0y - (py - dy)) + x2 * (a0z - (pz - dz)) - (fabs(x0) + fabs(x1) + fabs(x2)) * hw;
-            if (lin_min >= dist * rmin + 1e-9) sel = false;
-        }
-        const unsigned long long m = __ballot(sel);
-        const int pos = nr + lanes_below(m, lane);
-        if (sel && pos < nrmax) {
-            // r = dist*(rmin - dist + diff*p/dist) - diff*A_initp(kc)*[po;vo]   (:21)
-            const double rr = dist * (rmin - dist + (x0 * px + x1 * py + x2 * pz) / dist) - (x0 * a0x + x1 * a0y + x2 * a0z);
-            L.r_xi[3 * pos] = x0; L.r_xi[3 * pos + 1] = x1; L.r_xi[3 * pos + 2] = x2;
-            L.r_b[pos] = -rr;
-            L.r_kc[pos] = kc;
-            L.r_fl[pos] = 0;
-            if (soft) {
-                double sd = dist, st = P.term, slb = -0.05;
-                if (var == VAR_BOUND2 || var == VAR_ALL3) slb = -0.01;           // bound2:77, all:92
-                else if (var == VAR_SOFTALL) { sd = 1.0; st = -1e5; slb = -INFINITY; }  // solveSoftDMPC.m:21,65
-                else if (var == VAR_REPAIR) { st = P.term / dist; slb = -INFINITY; }    // repair:77,81
-                L.r_sd[pos] = sd; L.r_st[pos] = st; L.r_slb[pos] = slb; L.r_eps[pos] = 0.0;
+    if (PHASE == 0) {
+        // appends the rows of horizon step ke (evaluated positions) constraining step kc for every
+        // neighbour with dist < sel_r (or all), in increasing neighbour index (CollConstrSoftDMPC.m:11-31)
+        // one collision row, CollConstrSoftDMPC.m:16-28: neighbour offset (dx,dy,dz) and ellipsoidal distance at
+        // the evaluation step (own position px,py,pz), constraining horizon step kc; compacted by ballot
+        auto emit_row = [&](bool sel, int kc, double dx, double dy, double dz, double dist, double px, double py, double pz) {
+            const double sh = (double)(kc + 1) * P.h;
+            const double a0x = A.po[0] + sh * A.vo[0], a0y = A.po[1] + sh * A.vo[1], a0z = A.po[2] + sh * A.vo[2];
+            const double x0 = dx, x1 = dy, x2 = dz * P.e2z;   // diff = E2*(p - pj)
+            nrows_ref += __popcll(__ballot(sel));               // the reference's row count (branch record)
+            // Exact pruning: with |a| <= alim the position at step kc stays in the box
+            // A0_kc x0 +- alim (kc h)^2/2, so a row whose linearised distance cannot drop below rmin anywhere in
+            // that box can never become active; dropping it (and its slack, which stays 0) leaves the minimiser
+            // unchanged.  Margin 1e-9 keeps borderline rows.
+            {
+                const double hw = 0.5 * P.alim * sh * sh;
+                const double lin_min = x0 * (a0x - (px - dx)) + x1 * (a0y - (py - dy)) + x2 * (a0z - (pz - dz)) - (fabs(x0) + fabs(x1) + fabs(x2)) * hw;
+                if (lin_min >= dist * rmin + 1e-9) sel = false;
             }
-        }
-        nr += __popcll(m);
-    };
+            const unsigned long long m = __ballot(sel);
+            const int pos = nr + lanes_below(m, lane);
+            if (sel && pos < nrmax) {
+                // r = dist*(rmin - dist + diff*p/dist) - diff*A_initp(kc)*[po;vo]   (:21)
+                const double rr = dist * (rmin - dist + (x0 * px + x1 * py + x2 * pz) / dist) - (x0 * a0x + x1 * a0y + x2 * a0z);
+                L.r_xi[3 * pos] = x0; L.r_xi[3 * pos + 1] = x1; L.r_xi[3 * pos + 2] = x2;
+                L.r_b[pos] = -rr;
+                L.r_kc[pos] = kc;
+                    if (soft) {
+                    double sd = dist, st = P.term, slb = -0.05;
+                    if (var == VAR_BOUND2 || var == VAR_ALL3) slb = -0.01;           // bound2:77, all:92
+                    else if (var == VAR_SOFTALL) { sd = 1.0; st = -1e5; slb = -INFINITY; }  // solveSoftDMPC.m:21,65
+                    else if (var == VAR_REPAIR) { st = P.term / dist; slb = -INFINITY; }    // repair:77,81
+                    L.r_sd[pos] = sd; L.r_st[pos] = st; L.r_slb[pos] = slb;
+                }
+            }
+            nr += __popcll(m);
+        };
 
-    // rows of horizon step ke (positions evaluated there) constraining step kc for every neighbour whose
-    // distance AT STEP ksel is < sel_r (viol_constr of CheckCollSoftDMPC.m:12) or for all neighbours,
-    // in increasing neighbour index (CollConstrSoftDMPC.m:11-31)
-    auto build_rows = [&](int ksel, int ke, int kc, double sel_r, bool sel_all) {
-        const double qx = L.own_s[3 * ksel], qy = L.own_s[3 * ksel + 1], qz = L.own_s[3 * ksel + 2];
-        const double px = L.own_s[3 * ke], py = L.own_s[3 * ke + 1], pz = L.own_s[3 * ke + 2];
+        // rows of horizon step ke (positions evaluated there) constraining step kc for every neighbour whose
+        // distance AT STEP ksel is < sel_r (viol_constr of CheckCollSoftDMPC.m:12) or for all neighbours,
+        // in increasing neighbour index (CollConstrSoftDMPC.m:11-31)
+        auto build_rows = [&](int ksel, int ke, int kc, double sel_r, bool sel_all) {
+            const double qx = L.own_s[3 * ksel], qy = L.own_s[3 * ksel + 1], qz = L.own_s[3 * ksel + 2];
+            const double px = L.own_s[3 * ke], py = L.own_s[3 * ke + 1], pz = L.own_s[3 * ke + 2];
+            for (int r = 0; r < G; ++r) {
+                const double *bsel = P.lT + ((size_t)(r * S + scene) * N3 + 3 * ksel) * C;
+                const double *base = P.lT + ((size_t)(r * S + scene) * N3 + 3 * ke) * C;
+                for (int j0 = 0; j0 < C; j0 += 64) {
+                    const int jj = j0 + lane;
+                    const bool valid = jj < C && !(r == P.g_local && jj == cl);
+                    const int jc = jj < C ? jj : C - 1;   // clamped: loads are unconditional, results masked
+                    const double dx = px - base[jc], dy = py - base[(size_t)C + jc], dz = pz - base[2 * (size_t)C + jc];
+                    const double ez = dz * P.e1z;
+                    const double dist = sqrt(dx * dx + dy * dy + ez * ez);
+                    double dsel = dist;
+                    if (ksel != ke && !sel_all) {
+                        const double sx = qx - bsel[jc], sy = qy - bsel[(size_t)C + jc];
+                        const double sz = (qz - bsel[2 * (size_t)C + jc]) * P.e1z;
+                        dsel = sqrt(sx * sx + sy * sy + sz * sz);
+                    }
+                    emit_row(valid && (sel_all || dsel < sel_r), kc, dx, dy, dz, dist, px, py, pz);
+                }
+            }
+        };
+
+        // Scan (CheckCollSoftDMPC.m:7-15): all K distances of a neighbour are computed from loads issued
+        // together (5 horizon steps = 15 coalesced wave loads per batch) instead of one dependent round per
+        // step; per-step "any neighbour inside rmin" bits are OR-reduced across the wave afterwards.
+        unsigned anyb = 0;
+        double mind0 = 1e300;
         for (int r = 0; r < G; ++r) {
-            const double *bsel = P.lT + ((size_t)(r * S + scene) * N3 + 3 * ksel) * C;
-            const double *base = P.lT + ((size_t)(r * S + scene) * N3 + 3 * ke) * C;
+            const double *base = P.lT + ((size_t)(r * S + scene) * N3) * C;
             for (int j0 = 0; j0 < C; j0 += 64) {
                 const int jj = j0 + lane;
                 const bool valid = jj < C && !(r == P.g_local && jj == cl);
-                const int jc = jj < C ? jj : C - 1;   // clamped: loads are unconditional, results masked
-                const double dx = px - base[jc], dy = py - base[(size_t)C + jc], dz = pz - base[2 * (size_t)C + jc];
-                const double ez = dz * P.e1z;
-                const double dist = sqrt(dx * dx + dy * dy + ez * ez);
-                double dsel = dist;
-                if (ksel != ke && !sel_all) {
-                    const double sx = qx - bsel[jc], sy = qy - bsel[(size_t)C + jc];
-                    const double sz = (qz - bsel[2 * (size_t)C + jc]) * P.e1z;
-                    dsel = sqrt(sx * sx + sy * sy + sz * sz);
-                }
-                emit_row(valid && (sel_all || dsel < sel_r), kc, dx, dy, dz, dist, px, py, pz);
-            }
-        }
-    };
-
-    // Scan (CheckCollSoftDMPC.m:7-15): all K distances of a neighbour are computed from loads issued
-    // together (5 horizon steps = 15 coalesced wave loads per batch) instead of one dependent round per
-    // step; per-step "any neighbour inside rmin" bits are OR-reduced across the wave afterwards.
-    unsigned anyb = 0;
-    double mind0 = 1e300;
-    for (int r = 0; r < G; ++r) {
-        const double *base = P.lT + ((size_t)(r * S + scene) * N3) * C;
-        for (int j0 = 0; j0 < C; j0 += 64) {
-            const int jj = j0 + lane;
-            const bool valid = jj < C && !(r == P.g_local && jj == cl);
-            const int jc = jj < C ? jj : C - 1;
-#pragma unroll
-            for (int kg = 0; kg < 3; ++kg) {
-                double nx[5], ny[5], nz[5];
-#pragma unroll
-                for (int u = 0; u < 5; ++u) {
-                    const int k = 5 * kg + u;
-                    nx[u] = base[(size_t)(3 * k) * C + jc];
-                    ny[u] = base[(size_t)(3 * k + 1) * C + jc];
-                    nz[u] = base[(size_t)(3 * k + 2) * C + jc];
-                }
-#pragma unroll
-                for (int u = 0; u < 5; ++u) {
-                    const int k = 5 * kg + u;
-                    const double px = L.own_s[3 * k], py = L.own_s[3 * k + 1], pz = L.own_s[3 * k + 2];
-                    const double dx = px - nx[u], dy = py - ny[u], dz = pz - nz[u];
-                    const double ez = dz * P.e1z;
-                    const double dist = sqrt(dx * dx + dy * dy + ez * ez);
-                    if (var == VAR_HARD) {
-                        // solveHardDMPC.m:18-22 + CollConstrHardDMPC.m:19: every k, neighbours with dist < 1.
-                        // (rows are emitted neighbour-chunk-major here; the reference's k-major order only
-                        //  changes tie breaks of the active-set path, not the unique minimiser)
-                        emit_row(valid && dist < 1.0, k, dx, dy, dz, dist, px, py, pz);
-                    } else {
-                        if (valid && dist < rmin) anyb |= (1u << k);           // CheckCollSoftDMPC.m:11
-                        if (k == 0 && valid) mind0 = fmin(mind0, dist);
+                const int jc = jj < C ? jj : C - 1;
+    #pragma unroll
+                for (int kg = 0; kg < 3; ++kg) {
+                    double nx[5], ny[5], nz[5];
+    #pragma unroll
+                    for (int u = 0; u < 5; ++u) {
+                        const int k = 5 * kg + u;
+                        nx[u] = base[(size_t)(3 * k) * C + jc];
+                        ny[u] = base[(size_t)(3 * k + 1) * C + jc];
+                        nz[u] = base[(size_t)(3 * k + 2) * C + jc];
+                    }
+    #pragma unroll
+                    for (int u = 0; u < 5; ++u) {
+                        const int k = 5 * kg + u;
+                        const double px = L.own_s[3 * k], py = L.own_s[3 * k + 1], pz = L.own_s[3 * k + 2];
+                        const double dx = px - nx[u], dy = py - ny[u], dz = pz - nz[u];
+                        const double ez = dz * P.e1z;
+                        const double dist = sqrt(dx * dx + dy * dy + ez * ez);
+                        if (var == VAR_HARD) {
+                            // solveHardDMPC.m:18-22 + CollConstrHardDMPC.m:19: every k, neighbours with dist < 1.
+                            // (rows are emitted neighbour-chunk-major here; the reference's k-major order only
+                            //  changes tie breaks of the active-set path, not the unique minimiser)
+                            emit_row(valid && dist < 1.0, k, dx, dy, dz, dist, px, py, pz);
+                        } else {
+                            if (valid && dist < rmin) anyb |= (1u << k);           // CheckCollSoftDMPC.m:11
+                            if (k == 0 && valid) mind0 = fmin(mind0, dist);
+                        }
                     }
                 }
             }
         }
-    }
-    if (var == VAR_HARD) {
-        rows_exist = (G * C > 1);   // preallocated zero rows make Ain_coll non-empty (CollConstrHardDMPC.m:3-4)
-    } else {
-        anyb = wave_or(anyb);
-        for (int k = 0; k < K; ++k) {
-            if (!((anyb >> k) & 1u)) continue;
-            if (var == VAR_ALL3) violation = true;   // solveSoftDMPCall.m:22 (some_violation)
-            if (coll_check && k == 0) {
-                mind0 = wave_min(mind0);
-                if (mind0 < rmin - 0.05) { status = ST_COLL; viol_k = 1; break; }   // :25-31
+        if (var == VAR_HARD) {
+            rows_exist = (G * C > 1);   // preallocated zero rows make Ain_coll non-empty (CollConstrHardDMPC.m:3-4)
+        } else {
+            anyb = wave_or(anyb);
+            for (int k = 0; k < K; ++k) {
+                if (!((anyb >> k) & 1u)) continue;
+                if (var == VAR_ALL3) violation = true;   // solveSoftDMPCall.m:22 (some_violation)
+                if (coll_check && k == 0) {
+                    mind0 = wave_min(mind0);
+                    if (mind0 < rmin - 0.05) { status = ST_COLL; viol_k = 1; break; }   // :25-31
+                }
+                if (skip_k1 && k == 0) continue;          // solveSoftDMPCbound2.m:29-31
+                viol_k = k + 1; violation = true; rows_exist = true;
+                if (var == VAR_ALL3) {                     // solveSoftDMPCall.m:34-48: steps k-1,k,k+1
+                    const int k0 = (k == 1) ? k : k - 1, k1 = (k == K - 1) ? k : k + 1;
+                    for (int kk = k0; kk <= k1; ++kk) build_rows(k, kk, kk, 3.0 * rmin, false);
+                } else {
+                    const int kc = (var == VAR_BOUND2) ? k - 1 : k;   // CollConstrSoftDMPC2.m:8
+                    build_rows(k, k, kc, 3.0 * rmin, !near_sel);
+                }
+                break;
             }
-            if (skip_k1 && k == 0) continue;          // solveSoftDMPCbound2.m:29-31
-            viol_k = k + 1; violation = true; rows_exist = true;
-            if (var == VAR_ALL3) {                     // solveSoftDMPCall.m:34-48: steps k-1,k,k+1
-                const int k0 = (k == 1) ? k : k - 1, k1 = (k == K - 1) ? k : k + 1;
-                for (int kk = k0; kk <= k1; ++kk) build_rows(k, kk, kk, 3.0 * rmin, false);
-            } else {
-                const int kc = (var == VAR_BOUND2) ? k - 1 : k;   // CollConstrSoftDMPC2.m:8
-                build_rows(k, k, kc, 3.0 * rmin, !near_sel);
-            }
-            break;
         }
+        // header for the solve phase
+        if (nr > nrmax) { status |= ST_CAPACITY; nr = nrmax; }
+        if (lane == 0) {
+            hdr[0] = nr; hdr[1] = nrows_ref; hdr[2] = viol_k; hdr[3] = status;
+            hdr[4] = violation ? 1 : 0; hdr[5] = rows_exist ? 1 : 0; hdr[6] = 0; hdr[7] = 0;
+        }
+        return;
     }
-    LSYNC();
-    // rows were written to global memory by this wave and are re-read by it: make the stores visible
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // PHASE 1: pick up the scan's branch record
+    nr = hdr[0]; nrows_ref = hdr[1]; viol_k = hdr[2]; status = hdr[3];
+    violation = hdr[4] != 0; rows_exist = hdr[5] != 0;
     const int nrows_built = nrows_ref;
-    if (nr > nrmax) { status |= ST_CAPACITY; nr = nrmax; }
 
     const long long tk1 = clock64();
     // ---------------------------------------------------------------- cost case + tables (a7, :43-58)
@@ -563,7 +588,9 @@ __global__ __launch_bounds__(64, 2) void dmpc_step_kernel(StepParams P)
     // ---------------------------------------------------------------- a7: dual active-set solve
     const bool ladder = (var == VAR_BOUND || var == VAR_BOUND2 || var == VAR_ALL3);
     const int max_tries = P.max_tries > 0 ? P.max_tries : 30;
-    int tries = 0, iters_total = 0, maxq = 0, q = 0;
+    // a tier-2 relaunch resumes the retry ladder where tier 1 left it (the row data in global memory already
+    // carries the doublings of the tries that were proven infeasible)
+    int tries = (P.only_flagged ? hdr[6] : 0), iters_total = (P.only_flagged ? hdr[7] : 0), maxq = 0, q = 0;
     bool solved = false;
     double a = 0.0, w = 0.0;
     const double tol = 1e-10;
@@ -625,9 +652,9 @@ __global__ __launch_bounds__(64, 2) void dmpc_step_kernel(StepParams P)
                         const double mx = wave_max(fabs(rho));
                         if (!(mx > 1e-13)) break;
                         L.xs_s[lane] = rho; LSYNC();
-                        const double dvj = t_tmul(L.T, L.xs_s, lane, q, P.qcap);
+                        const double dvj = t_tmul(L.T, L.xs_s, lane, q, qcap);
                         L.rr_s[lane] = dvj; LSYNC();
-                        const double ri = t_mul(L.T, L.rr_s, lane, q, P.qcap);
+                        const double ri = t_mul(L.T, L.rr_s, lane, q, qcap);
                         if (lane < q) L.s_lam[lane] += ri;
                         LSYNC();
                         primal(L, lane, q, nr, soft, a_unc, w_unc, a, w);
@@ -643,7 +670,7 @@ __global__ __launch_bounds__(64, 2) void dmpc_step_kernel(StepParams P)
                 Cdesc p = make_desc(pcode >> 16, pcode & 0xffff, L, A, P, soft);
                 // lazily instantiate the eps<=0 pin of a soft row that becomes active (S(u,u) = 1/2)
                 if (p.ty == TY_COLL && p.si >= 0 && !(L.r_fl[p.idx] & RF_LIVE)) {
-                    if (q >= P.qcap - 1) { rc = 2; break; }
+                    if (q >= qcap - 1) { rc = 2; break; }
                     Cdesc u = make_desc(TY_SLKU, p.idx, L, A, P, soft);
                     if (lane < ((q + 8) & ~7)) L.T[tcol(q) + lane] = (lane == q) ? 1.4142135623730951 : 0.0;   // column + zero padding
                     if (lane == 0) L.r_fl[p.idx] |= (RF_LIVE | RF_SLKU);
@@ -659,9 +686,9 @@ __global__ __launch_bounds__(64, 2) void dmpc_step_kernel(StepParams P)
                     const long long tq1 = clock64();
                     const double sv = (lane < q) ? sdot_slot(L, lane, p) : 0.0;
                     L.xs_s[lane] = sv; LSYNC();
-                    const double dvj = t_tmul(L.T, L.xs_s, lane, q, P.qcap);
+                    const double dvj = t_tmul(L.T, L.xs_s, lane, q, qcap);
                     L.rr_s[lane] = dvj; LSYNC();
-                    const double ri = t_mul(L.T, L.rr_s, lane, q, P.qcap);
+                    const double ri = t_mul(L.T, L.rr_s, lane, q, qcap);
                     LSYNC();
                     L.rr_s[lane] = ri;
                     const long long tq2 = clock64(); tkB += tq2 - tq1;
@@ -768,7 +795,7 @@ __global__ __launch_bounds__(64, 2) void dmpc_step_kernel(StepParams P)
                     }
                     if (t2 <= t1) {
                         // full step: append p (new column of T = [-r/rho ; 1/rho])
-                        if (q >= P.qcap) { rc = 2; break; }
+                        if (q >= qcap) { rc = 2; break; }
                         const double rho = sqrt(delta);
                         if (lane < ((q + 8) & ~7)) L.T[tcol(q) + lane] = (lane < q) ? (-ri / rho) : ((lane == q) ? 1.0 / rho : 0.0);
                         write_slot(L, lane, q, p, lam_p);
@@ -811,7 +838,11 @@ __global__ __launch_bounds__(64, 2) void dmpc_step_kernel(StepParams P)
             }
             iters_total += iters;
             if (rc == 0) { solved = true; break; }
-            if (rc == 2) { status |= ST_CAPACITY; break; }
+            if (rc == 2) {   // tier 1: flag for the tier-2 relaunch (and record the ladder position); last tier: capacity error
+                status |= P.qover_bit;
+                if (lane == 0) { hdr[6] = tries - 1; hdr[7] = iters_total; }
+                break;
+            }
             if (rc == 3) { status |= ST_ITERCAP; break; }
             // infeasible: retry ladder (solveSoftDMPCbound.m:147-153): lb_eps *= 2, term *= 2
             if (ladder && violation) {
@@ -824,7 +855,7 @@ __global__ __launch_bounds__(64, 2) void dmpc_step_kernel(StepParams P)
             if (ladder || var == VAR_REPAIR) tries = (var == VAR_REPAIR && P.max_tries <= 0) ? 10 : max_tries;
             break;
         }
-        if (!solved && !(status & (ST_CAPACITY | ST_ITERCAP))) status |= ST_INFEAS;
+        if (!solved && !(status & (ST_CAPACITY | ST_ITERCAP | ST_QOVER))) status |= ST_INFEAS;
     }
 
     const long long tk3 = clock64();
@@ -860,7 +891,7 @@ __global__ __launch_bounds__(64, 2) void dmpc_step_kernel(StepParams P)
         P.p_out[(size_t)gid * N3 + lane] = p_out;
         P.v_out[(size_t)gid * N3 + lane] = v_out;
         P.a_out[(size_t)gid * N3 + lane] = a_out;
-        if (P.lT_next) P.lT_next[((size_t)scene * N3 + lane) * C + cl] = solved ? p_out : own;
+        if (P.lT_next) P.lT_next[((size_t)scene * N3 + lane) * C + cl] = solved ? p_out : lT_own[(size_t)lane * C];
     }
     if (P.dbg && gid == P.dbg_agent && lane == 0) {
         double *d = P.dbg + (size_t)P.dbg_cap * 8 - 8;
@@ -880,6 +911,29 @@ __global__ __launch_bounds__(64, 2) void dmpc_step_kernel(StepParams P)
 // --------------------------------------------------------------------------------------------
 // small layout / bookkeeping kernels
 // --------------------------------------------------------------------------------------------
+
+// Longest-processing-time-first launch order for the solve phase: agents are bucketed by the number of
+// collision rows the scan produced (a good proxy for active-set iterations) and the solve kernel takes
+// them heaviest first, so the long solves do not end up alone at the tail of the launch.  Pure scheduling:
+// results do not depend on the order.  One workgroup.
+__global__ void order_kernel(int count, const int *__restrict__ hdr, int *__restrict__ order)
+{
+    __shared__ int hist[256];
+    __shared__ int offs[256];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < count; i += blockDim.x) {
+        int key = hdr[(size_t)i * 8] >> 2; key = key > 255 ? 255 : key;
+        atomicAdd(&hist[key], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { int acc = 0; for (int b = 255; b >= 0; --b) { offs[b] = acc; acc += hist[b]; } }
+    __syncthreads();
+    for (int i = threadIdx.x; i < count; i += blockDim.x) {
+        int key = hdr[(size_t)i * 8] >> 2; key = key > 255 ? 255 : key;
+        order[atomicAdd(&offs[key], 1)] = i;
+    }
+}
 
 // rows[S][N][3K] -> lT[G][S][3K][C], N = G*C
 __global__ void table_from_rows_kernel(int S, int G, int C, const double *__restrict__ rows, double *__restrict__ lT)
