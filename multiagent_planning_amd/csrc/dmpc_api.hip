@@ -364,7 +364,7 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     const size_t lds1 = step_lds_bytes(P.nrmax, soft, q1, 1), lds2 = step_lds_bytes(P.nrmax, soft, q2, 1);
     const size_t ldsmax = lds2 > lds1 ? lds2 : lds1;
     if ((int)ldsmax > ctx->max_lds_set) {
-        HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_step_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsmax));
+        HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsmax));
         ctx->max_lds_set = (int)ldsmax;
     }
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
@@ -376,17 +376,17 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     const dim3 grid((unsigned)(S * c_count)), block(64);
     // phase 0: scan + rows
     P.qcap = q1; P.only_flagged = 0; P.qover_bit = two_tier ? ST_QOVER : ST_CAPACITY;
-    hipLaunchKernelGGL(dmpc_step_kernel<0>, grid, block, lds0, st, P);
+    hipLaunchKernelGGL(dmpc_scan_kernel, grid, block, lds0, st, P);
     // heaviest-first launch order for the solve phase (skipped for tiny launches)
     if (S * c_count >= 512 && !ctx->no_lpt) {
         hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, st, S * c_count, (const int *)P.hdr, ctx->order.as<int>());
         P.order = ctx->order.as<int>();
     }
     // phase 1, tier 1
-    hipLaunchKernelGGL(dmpc_step_kernel<1>, grid, block, lds1, st, P);
+    hipLaunchKernelGGL(dmpc_solve_kernel, grid, block, lds1, st, P);
     if (two_tier) {   // phase 1, tier 2: only agents flagged ST_QOVER do any work
         P.qcap = q2; P.only_flagged = 1; P.qover_bit = ST_CAPACITY;
-        hipLaunchKernelGGL(dmpc_step_kernel<1>, grid, block, lds2, st, P);
+        hipLaunchKernelGGL(dmpc_solve_kernel, grid, block, lds2, st, P);
     }
     HIPCHK(ctx, hipGetLastError());
     if (ctx->profile) {

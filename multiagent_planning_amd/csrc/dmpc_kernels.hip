@@ -87,6 +87,9 @@ __device__ __forceinline__ int lanes_below(unsigned long long mask, int lane)
 __device__ __forceinline__ double sel3(const double *v, int ax) { return ax == 0 ? v[0] : (ax == 1 ? v[1] : v[2]); }
 
 // constraint types
+#ifndef SOLVE_WAVES_PER_SIMD
+#define SOLVE_WAVES_PER_SIMD 2
+#endif
 enum { TY_BOXHI = 0, TY_BOXLO = 1, TY_POSHI = 2, TY_POSLO = 3, TY_COLL = 4, TY_SLKU = 5, TY_SLKL = 6 };
 // row flags
 enum { RF_COLL = 1, RF_SLKU = 2, RF_SLKL = 4, RF_LIVE = 8 };
@@ -116,7 +119,7 @@ struct Agent {   // wave-uniform agent data
     double whi0[3], wlo0[3];   // pmax - po, pmin - po (w bounds at k: whi0 - (k+1) h vo)
 };
 
-__device__ __forceinline__ Cdesc make_desc(int ty, int idx, const Lds &L, const Agent &A, const StepParams &P, bool soft)
+__device__ __forceinline__ Cdesc make_desc(int ty, int idx, const Lds &L, double whi_l, double wlo_l, const StepParams &P, bool soft)
 {
     Cdesc c;
     c.ty = ty; c.idx = idx; c.kb = 0; c.isA = 0; c.si = -1;
@@ -128,8 +131,9 @@ __device__ __forceinline__ Cdesc make_desc(int ty, int idx, const Lds &L, const 
         c.v0 = ax == 0 ? sgn : 0.0; c.v1 = ax == 1 ? sgn : 0.0; c.v2 = ax == 2 ? sgn : 0.0;
         if (c.isA) c.d = P.alim;
         else {
-            const double sh = (double)(k + 1) * P.h * sel3(A.vo, ax);
-            c.d = (ty == TY_POSHI) ? (sel3(A.whi0, ax) - sh) : -(sel3(A.wlo0, ax) - sh);
+            // bounds of w = Lambda a for component idx are held by lane idx (whi_l / wlo_l)
+            c.d = (ty == TY_POSHI) ? readlane_d(whi_l, idx) : -readlane_d(wlo_l, idx);
+            (void)ax;
         }
     } else if (ty == TY_COLL) {
         c.kb = L.r_kc[idx];
@@ -266,16 +270,19 @@ __device__ __forceinline__ void remove_slot(const Lds &L, int lane, int &q, int 
         }
     }
     double carry = (lane <= l) ? L.T[tcol(l) + lane] : 0.0;
+    double right = (q - 1 > l && lane <= l + 1) ? L.T[tcol(l + 1) + lane] : 0.0;
     for (int j = l; j < q - 1; ++j) {
-        const double right = (lane <= j + 1) ? L.T[tcol(j + 1) + lane] : 0.0;
+        // prefetch the next column while this rotation is computed (the chain through lane l is the latency)
+        const double next = (j + 2 < q && lane <= j + 2) ? L.T[tcol(j + 2) + lane] : 0.0;
         const double a_ = readlane_d(carry, l), b_ = readlane_d(right, l);
-        const double rr = sqrt(a_ * a_ + b_ * b_);
+        const double n2 = a_ * a_ + b_ * b_;
         double cc = 1.0, ss = 0.0;
-        if (rr > 1e-150) { cc = b_ / rr; ss = a_ / rr; }
+        if (n2 > 1e-300) { const double inv = rsqrt(n2); cc = b_ * inv; ss = a_ * inv; }
         const double nl = cc * carry - ss * right;
         const double nr_ = ss * carry + cc * right;
         if (lane <= j + 1 && lane != l) L.T[tcol(j) + (lane < l ? lane : lane - 1)] = nl;
         carry = nr_;
+        right = next;
     }
     // shift slot records
     const bool mv = lane > l && lane < q;
@@ -325,7 +332,7 @@ __device__ __forceinline__ void set_member(const Lds &L, int lane, int ty, int i
 // resident agents per CU) and lets the solver be re-launched for the few agents that overflow the
 // tier-1 working-set capacity.
 template <int PHASE>
-__global__ __launch_bounds__(64, 2) void dmpc_step_kernel(StepParams P)
+__device__ __forceinline__ void step_body(const StepParams &P)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
@@ -401,6 +408,7 @@ __global__ __launch_bounds__(64, 2) void dmpc_step_kernel(StepParams P)
     const long long tk0 = clock64();
     // ---------------------------------------------------------------- a5/a6: scan + rows
     int nr = 0, nrows_ref = 0, viol_k = 0, status = 0;
+    bool cert_infeasible = false;
     bool rows_exist = false, violation = false;
     const double rmin = P.rmin;
     const bool near_sel = (var == VAR_BOUND || var == VAR_BOUND2 || var == VAR_ALL3 || var == VAR_ONDEMAND);
@@ -425,6 +433,13 @@ __global__ __launch_bounds__(64, 2) void dmpc_step_kernel(StepParams P)
                 const double hw = 0.5 * P.alim * sh * sh;
                 const double lin_min = x0 * (a0x - (px - dx)) + x1 * (a0y - (py - dy)) + x2 * (a0z - (pz - dz)) - (fabs(x0) + fabs(x1) + fabs(x2)) * hw;
                 if (lin_min >= dist * rmin + 1e-9) sel = false;
+                // Exact infeasibility certificate for rows without slack: if even the BEST point of the
+                // reachable box violates the row (max of the linearised distance < dist*rmin), no acceleration
+                // within |a| <= alim satisfies it -> the QP is infeasible; the long active-set proof is skipped.
+                if (!soft && sel) {
+                    const double lin_max = lin_min + 2.0 * (fabs(x0) + fabs(x1) + fabs(x2)) * hw;
+                    if (lin_max < dist * rmin - 1e-9) cert_infeasible = true;
+                }
             }
             const unsigned long long m = __ballot(sel);
             const int pos = nr + lanes_below(m, lane);
@@ -538,6 +553,7 @@ __global__ __launch_bounds__(64, 2) void dmpc_step_kernel(StepParams P)
         }
         // header for the solve phase
         if (nr > nrmax) { status |= ST_CAPACITY; nr = nrmax; }
+        if (__any(cert_infeasible)) status |= ST_INFEAS;
         if (lane == 0) {
             hdr[0] = nr; hdr[1] = nrows_ref; hdr[2] = viol_k; hdr[3] = status;
             hdr[4] = violation ? 1 : 0; hdr[5] = rows_exist ? 1 : 0; hdr[6] = 0; hdr[7] = 0;
@@ -583,8 +599,31 @@ __global__ __launch_bounds__(64, 2) void dmpc_step_kernel(StepParams P)
     }
     LSYNC();
 
+    // per-lane constants of component (k_l, ax_l): offset A0 x0, bounds of w = Lambda a, initial velocity.
+    // (the uniform agent state is not needed inside the solver loop any more -> fewer live registers)
+    double p0_l = 0.0, whi_l = 0.0, wlo_l = 0.0, vo_l = 0.0;
+    if (lane < N3) {
+        vo_l = sel3(A.vo, ax_l);
+        p0_l = sel3(A.po, ax_l) + (double)(k_l + 1) * P.h * vo_l;               // A_initp(k,:) [po;vo]
+        whi_l = sel3(A.whi0, ax_l) - (double)(k_l + 1) * P.h * vo_l;           // pmax - A0 x0  (:72)
+        wlo_l = sel3(A.wlo0, ax_l) - (double)(k_l + 1) * P.h * vo_l;
+    }
+    // Register cache of the first 128 collision rows (2 per lane): the row data is constant during the solve
+    // and most agents have fewer rows than that, so the per-iteration violation scan and the descriptor of a
+    // newly picked row need no global-memory round trip.  Rows 128+ are streamed from the L2-resident scratch.
+    double rcx0[2], rcx1[2], rcx2[2], rcb[2], rcsd[2], rcslb[2];
+    int rckc[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int i = lane + 64 * c;
+        const bool in = i < nr;
+        const int ii = in ? i : 0;
+        rcx0[c] = L.r_xi[3 * ii]; rcx1[c] = L.r_xi[3 * ii + 1]; rcx2[c] = L.r_xi[3 * ii + 2];
+        rcb[c] = L.r_b[ii]; rckc[c] = L.r_kc[ii];
+        rcsd[c] = soft ? L.r_sd[ii] : 0.0; rcslb[c] = soft ? L.r_slb[ii] : 0.0;
+    }
     const long long tk2 = clock64();
-    long long tkA = 0, tkB = 0, tkC = 0, tkD = 0;
+    long long tkA = 0, tkB = 0, tkC = 0, tkD = 0, tkE = 0, tkF = 0, tkG = 0, tkH = 0;
     // ---------------------------------------------------------------- a7: dual active-set solve
     const bool ladder = (var == VAR_BOUND || var == VAR_BOUND2 || var == VAR_ALL3);
     const int max_tries = P.max_tries > 0 ? P.max_tries : 30;
@@ -595,7 +634,8 @@ __global__ __launch_bounds__(64, 2) void dmpc_step_kernel(StepParams P)
     double a = 0.0, w = 0.0;
     const double tol = 1e-10;
 
-    if (!(status & (ST_COLL | ST_CAPACITY))) {
+    if (status & ST_INFEAS) tries = 1;   // certified infeasible by the scan (single attempt, no ladder: hard rows only)
+    if (!(status & (ST_COLL | ST_CAPACITY | ST_INFEAS))) {
         while (tries < max_tries) {
             tries++;
             // reset working set
@@ -614,6 +654,75 @@ __global__ __launch_bounds__(64, 2) void dmpc_step_kernel(StepParams P)
             if (soft) for (int i = lane; i < nr; i += 64) L.r_eps[i] = 0.0;
             unsigned cslot = 0xffffffffu;   // component lane: slots of its BOXHI | BOXLO | POSHI | POSLO (0xff = none)
             LSYNC();
+            // x(lambda) re-derived from the multipliers with the same O(1)-per-lane assembly the step direction
+            // uses: nu = -N_W lambda (boxes / position bounds through the per-component slot indices, collision
+            // rows through a short mask loop), then a = a_unc + H^-1 nu, w = w_unc + Lambda H^-1 nu, and
+            // eps = -(st + sum lambda sigma)/2 for live slack rows.
+            auto primal_fast = [&]() {
+                L.rr_s[lane] = (lane < q) ? L.s_lam[lane] : 0.0;
+                const int myty = (lane < q) ? L.s_ty[lane] : -1;
+                const unsigned long long cmk = __ballot(myty == TY_COLL);
+                const unsigned long long smk = soft ? __ballot(myty >= TY_COLL && L.s_ss[lane < q ? lane : 0] != 0.0) : 0ull;
+                LSYNC();
+                double Uacc = 0.0, Yacc = 0.0;
+                if (lane < N3) {
+                    const unsigned s0 = cslot & 0xffu, s1 = (cslot >> 8) & 0xffu, s2 = (cslot >> 16) & 0xffu, s3 = cslot >> 24;
+                    if (s0 != 0xffu) Uacc -= L.rr_s[s0];
+                    if (s1 != 0xffu) Uacc += L.rr_s[s1];
+                    if (s2 != 0xffu) Yacc -= L.rr_s[s2];
+                    if (s3 != 0xffu) Yacc += L.rr_s[s3];
+                    for (unsigned long long m = cmk; m; m &= m - 1) {
+                        const int j = __ffsll((long long)m) - 1;
+                        if (L.s_kb[j] == k_l) Yacc -= L.rr_s[j] * L.s_vec[3 * j + ax_l];
+                    }
+                    L.yt_s[lane] = Yacc;
+                }
+                LSYNC();
+                if (lane < N3) {
+                    const double h2 = P.h * P.h;
+                    double nu = Uacc, yv[K];
+#pragma unroll
+                    for (int kk = 0; kk < K; ++kk) yv[kk] = L.yt_s[3 * kk + ax_l];
+#pragma unroll
+                    for (int kk = 0; kk < K; ++kk) nu = fma((kk >= k_l) ? (0.5 * h2 + (double)(kk - k_l) * h2) : 0.0, yv[kk], nu);
+                    L.nu_s[lane] = nu;
+                }
+                LSYNC();
+                if (lane < N3) {
+                    double za = 0.0, zw = 0.0;
+#pragma unroll
+                    for (int kg = 0; kg < 3; ++kg) {
+                        double nk[5], th[5], tm[5];
+#pragma unroll
+                        for (int u = 0; u < 5; ++u) {
+                            const int kk = 5 * kg + u;
+                            nk[u] = L.nu_s[3 * kk + ax_l]; th[u] = L.tabH[k_l * 15 + kk]; tm[u] = L.tabM[kk * 15 + k_l];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 5; ++u) { za = fma(th[u], nk[u], za); zw = fma(tm[u], nk[u], zw); }
+                    }
+                    a = a_unc + za; w = w_unc + zw;
+                    L.a_s[lane] = a; L.w_s[lane] = w;
+                }
+                if (soft) {
+                    // live rows without any slot in W: unconstrained slack -st/2; rows that are not live: 0
+                    for (int i = lane; i < nr; i += 64) {
+                        const int fl = L.r_fl[i];
+                        if (!(fl & RF_LIVE)) L.r_eps[i] = 0.0;
+                        else if (!(fl & (RF_COLL | RF_SLKU | RF_SLKL))) L.r_eps[i] = -0.5 * L.r_st[i];
+                    }
+                    const bool mine = (smk >> lane) & 1ull;
+                    const int myrow = mine ? L.s_idx[lane] : -1;
+                    bool owner = mine;
+                    double acc = 0.0;
+                    for (unsigned long long m = smk; m; m &= m - 1) {
+                        const int j = __ffsll((long long)m) - 1;
+                        if (L.s_idx[j] == myrow) { acc += L.rr_s[j] * L.s_ss[j]; if (j < lane) owner = false; }
+                    }
+                    if (owner) L.r_eps[myrow] = -0.5 * (L.r_st[myrow] + acc);
+                }
+                LSYNC();
+            };
             bool fresh = true;              // primal == x(lambda) with refined lambda
             int since_sync = 0;
             for (;;) {
@@ -621,15 +730,30 @@ __global__ __launch_bounds__(64, 2) void dmpc_step_kernel(StepParams P)
                 // ---- most violated constraint not in the working set
                 double bestv = tol; int bestc = -1;
                 if (lane < N3) {
-                    const double sh = (double)(k_l + 1) * P.h * sel3(A.vo, ax_l);
                     const double c0 = a - P.alim, c1 = -a - P.alim;
-                    const double c2 = w - (sel3(A.whi0, ax_l) - sh), c3 = (sel3(A.wlo0, ax_l) - sh) - w;
+                    const double c2 = w - whi_l, c3 = wlo_l - w;
                     if (!(cmask & 1u) && c0 > bestv) { bestv = c0; bestc = (TY_BOXHI << 16) | lane; }
                     if (!(cmask & 2u) && c1 > bestv) { bestv = c1; bestc = (TY_BOXLO << 16) | lane; }
                     if (!(cmask & 4u) && c2 > bestv) { bestv = c2; bestc = (TY_POSHI << 16) | lane; }
                     if (!(cmask & 8u) && c3 > bestv) { bestv = c3; bestc = (TY_POSLO << 16) | lane; }
                 }
-                for (int i = lane; i < nr; i += 64) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {   // rows held in registers
+                    const int i = lane + 64 * c;
+                    if (i < nr) {
+                        const int fl = L.r_fl[i], kc = rckc[c];
+                        double v = -(rcx0[c] * L.w_s[3 * kc] + rcx1[c] * L.w_s[3 * kc + 1] + rcx2[c] * L.w_s[3 * kc + 2]) - rcb[c];
+                        if (soft && (fl & RF_LIVE)) {
+                            const double e = L.r_eps[i];
+                            v += rcsd[c] * e;
+                            if (!(fl & RF_SLKU) && e > bestv) { bestv = e; bestc = (TY_SLKU << 16) | i; }
+                            const double lo = rcslb[c] - e;   // -eps <= -slb
+                            if (!(fl & RF_SLKL) && lo > bestv) { bestv = lo; bestc = (TY_SLKL << 16) | i; }
+                        }
+                        if (!(fl & RF_COLL) && v > bestv) { bestv = v; bestc = (TY_COLL << 16) | i; }
+                    }
+                }
+                for (int i = lane + 128; i < nr; i += 64) {   // the rest streams from the global scratch
                     const int fl = L.r_fl[i], kc = L.r_kc[i];
                     double v = -(L.r_xi[3 * i] * L.w_s[3 * kc] + L.r_xi[3 * i + 1] * L.w_s[3 * kc + 1] + L.r_xi[3 * i + 2] * L.w_s[3 * kc + 2]) - L.r_b[i];
                     if (soft && (fl & RF_LIVE)) {
@@ -646,7 +770,7 @@ __global__ __launch_bounds__(64, 2) void dmpc_step_kernel(StepParams P)
                 if (wm == 0ull) {
                     if (q == 0 || fresh) break;   // optimal
                     // verification: primal from the multipliers, refine the active-set residual, re-check
-                    primal(L, lane, q, nr, soft, a_unc, w_unc, a, w);
+                    primal_fast();
                     for (int pass = 0; pass < 3; ++pass) {
                         double rho = (lane < q) ? (slot_value(L, lane, L.a_s, L.w_s, L.r_eps) - L.s_d[lane]) : 0.0;
                         const double mx = wave_max(fabs(rho));
@@ -657,21 +781,36 @@ __global__ __launch_bounds__(64, 2) void dmpc_step_kernel(StepParams P)
                         const double ri = t_mul(L.T, L.rr_s, lane, q, qcap);
                         if (lane < q) L.s_lam[lane] += ri;
                         LSYNC();
-                        primal(L, lane, q, nr, soft, a_unc, w_unc, a, w);
+                        primal_fast();
                     }
                     fresh = true;
                     continue;
                 }
                 fresh = false;
-                tkA += clock64() - tq0;
+                const long long tqa = clock64(); tkA += tqa - tq0;
                 const int src = __ffsll((long long)wm) - 1;
                 const int pcode = readlane_i(bestc, src);
                 double vp = readlane_d(bestv, src);
-                Cdesc p = make_desc(pcode >> 16, pcode & 0xffff, L, A, P, soft);
+                Cdesc p;
+                {
+                    const int pty = pcode >> 16, pidx = pcode & 0xffff;
+                    if (pty >= TY_COLL && pidx < 128) {   // row data from the owning lane's registers
+                        const int ol = pidx & 63;
+                        const bool hi = pidx >= 64;
+                        p.ty = pty; p.idx = pidx; p.kb = 0; p.isA = 0; p.si = -1; p.v0 = p.v1 = p.v2 = 0.0; p.ss = 0.0; p.d = 0.0;
+                        if (pty == TY_COLL) {
+                            p.kb = readlane_i(hi ? rckc[1] : rckc[0], ol);
+                            p.v0 = -readlane_d(hi ? rcx0[1] : rcx0[0], ol); p.v1 = -readlane_d(hi ? rcx1[1] : rcx1[0], ol);
+                            p.v2 = -readlane_d(hi ? rcx2[1] : rcx2[0], ol); p.d = readlane_d(hi ? rcb[1] : rcb[0], ol);
+                            if (soft) { p.si = pidx; p.ss = readlane_d(hi ? rcsd[1] : rcsd[0], ol); }
+                        } else if (pty == TY_SLKU) { p.si = pidx; p.ss = 1.0; }
+                        else { p.si = pidx; p.ss = -1.0; p.d = -readlane_d(hi ? rcslb[1] : rcslb[0], ol); }
+                    } else p = make_desc(pty, pidx, L, whi_l, wlo_l, P, soft);
+                }
                 // lazily instantiate the eps<=0 pin of a soft row that becomes active (S(u,u) = 1/2)
                 if (p.ty == TY_COLL && p.si >= 0 && !(L.r_fl[p.idx] & RF_LIVE)) {
                     if (q >= qcap - 1) { rc = 2; break; }
-                    Cdesc u = make_desc(TY_SLKU, p.idx, L, A, P, soft);
+                    Cdesc u = make_desc(TY_SLKU, p.idx, L, whi_l, wlo_l, P, soft);
                     if (lane < ((q + 8) & ~7)) L.T[tcol(q) + lane] = (lane == q) ? 1.4142135623730951 : 0.0;   // column + zero padding
                     if (lane == 0) L.r_fl[p.idx] |= (RF_LIVE | RF_SLKU);
                     write_slot(L, lane, q, u, -L.r_st[p.idx]);
@@ -680,6 +819,7 @@ __global__ __launch_bounds__(64, 2) void dmpc_step_kernel(StepParams P)
                 }
                 double lam_p = 0.0;
                 const double spp = sdot_self(L, p);
+                tkF += clock64() - tqa;
                 // ---- inner loop: partial steps until p can be added
                 for (;;) {
                     if (++iters > ITER_CAP) { rc = 3; break; }
@@ -782,6 +922,7 @@ __global__ __launch_bounds__(64, 2) void dmpc_step_kernel(StepParams P)
                     }
                     if (!(t < INFINITY)) { rc = 1; break; }
                     if (lane < q) L.s_lam[lane] -= t * ri;
+                    const long long tq4 = clock64(); tkD += tq4 - tq3;
                     lam_p += t;
                     if (!dependent) {
                         vp -= t * delta;
@@ -796,14 +937,15 @@ __global__ __launch_bounds__(64, 2) void dmpc_step_kernel(StepParams P)
                     if (t2 <= t1) {
                         // full step: append p (new column of T = [-r/rho ; 1/rho])
                         if (q >= qcap) { rc = 2; break; }
-                        const double rho = sqrt(delta);
-                        if (lane < ((q + 8) & ~7)) L.T[tcol(q) + lane] = (lane < q) ? (-ri / rho) : ((lane == q) ? 1.0 / rho : 0.0);
+                        const double irho = 1.0 / sqrt(delta);
+                        if (lane < ((q + 8) & ~7)) L.T[tcol(q) + lane] = (lane < q) ? (-ri * irho) : ((lane == q) ? irho : 0.0);
                         write_slot(L, lane, q, p, lam_p);
                         set_member(L, lane, p.ty, p.idx, true, cmask);
                         if (p.ty < TY_COLL && lane == p.idx) cslot = (cslot & ~(0xffu << (8 * p.ty))) | ((unsigned)q << (8 * p.ty));
                         q++;
                         if (q > maxq) maxq = q;
                         LSYNC();
+                        tkE += clock64() - tq4;
                         break;
                     }
                     // partial step: drop the blocking constraint
@@ -824,6 +966,7 @@ __global__ __launch_bounds__(64, 2) void dmpc_step_kernel(StepParams P)
                             remove_slot(L, lane, q, ul, cslot);
                         }
                     }
+                    tkG += clock64() - tq4;
                 }
                 if (rc) break;
                 // pin added while its collision row is not active: decoupled again -> drop both
@@ -834,7 +977,7 @@ __global__ __launch_bounds__(64, 2) void dmpc_step_kernel(StepParams P)
                     if (lane == 0) { L.r_fl[p.idx] = 0; L.r_eps[p.idx] = 0.0; }
                     remove_slot(L, lane, q, ul, cslot);
                 }
-                if (((++since_sync) & 31) == 0) primal(L, lane, q, nr, soft, a_unc, w_unc, a, w);   // periodic re-sync with x(lambda)
+                if (((++since_sync) & 31) == 0) primal_fast();   // periodic re-sync with x(lambda)
             }
             iters_total += iters;
             if (rc == 0) { solved = true; break; }
@@ -847,6 +990,7 @@ __global__ __launch_bounds__(64, 2) void dmpc_step_kernel(StepParams P)
             // infeasible: retry ladder (solveSoftDMPCbound.m:147-153): lb_eps *= 2, term *= 2
             if (ladder && violation) {
                 for (int i = lane; i < nr; i += 64) { L.r_slb[i] *= 2.0; L.r_st[i] *= 2.0; }
+                rcslb[0] *= 2.0; rcslb[1] *= 2.0;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 LSYNC();
@@ -872,10 +1016,10 @@ __global__ __launch_bounds__(64, 2) void dmpc_step_kernel(StepParams P)
     double p_out = 0.0, v_out = 0.0, a_out = 0.0;
     if (solved && lane < N3) {
         // p = A_p a + A_initp [po;vo] ; v = A_v a + vo   (propStatedmpc.m:3-4)
-        p_out = w + (sel3(A.po, ax_l) + (double)(k_l + 1) * P.h * sel3(A.vo, ax_l));
+        p_out = w + p0_l;
         double sv = 0.0;
         for (int kk = 0; kk <= k_l; ++kk) sv += L.a_s[3 * kk + ax_l];
-        v_out = P.h * sv + sel3(A.vo, ax_l);
+        v_out = P.h * sv + vo_l;
         a_out = a;
     }
     if (solved) {
@@ -897,6 +1041,7 @@ __global__ __launch_bounds__(64, 2) void dmpc_step_kernel(StepParams P)
         double *d = P.dbg + (size_t)P.dbg_cap * 8 - 8;
         d[0] = (double)(tk1 - tk0); d[1] = (double)(tk2 - tk1); d[2] = (double)(tk3 - tk2); d[3] = (double)(clock64() - tk3);
         d[4] = (double)tkA; d[5] = (double)tkB; d[6] = (double)tkC; d[7] = (double)iters_total;
+        d[-8] = (double)tkD; d[-7] = (double)tkE; d[-6] = (double)tkF; d[-5] = (double)tkG;
     }
     if (lane == 0) {
         P.status[gid] = status;
@@ -907,6 +1052,9 @@ __global__ __launch_bounds__(64, 2) void dmpc_step_kernel(StepParams P)
         }
     }
 }
+
+__global__ __launch_bounds__(64, 2) void dmpc_scan_kernel(StepParams P) { step_body<0>(P); }
+__global__ __launch_bounds__(64, SOLVE_WAVES_PER_SIMD) void dmpc_solve_kernel(StepParams P) { step_body<1>(P); }
 
 // --------------------------------------------------------------------------------------------
 // small layout / bookkeeping kernels

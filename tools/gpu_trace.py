@@ -25,4 +25,5 @@ for i, r in enumerate(buf[:-1]):
 
 ph = buf[cap - 1]
 print("phase cycles: scan+rows=%d setup=%d solve=%d out=%d | in solve: violation-scan=%d sdot+matvec=%d nu/delta=%d iters=%d" % tuple(int(x) for x in ph))
+print("ratio/lambda=%d  step+append=%d  desc=%d  drop-path=%d" % tuple(buf[cap-2][:4]))
 if ph[7] > 0: print("per iteration: solve=%.0f viol=%.0f matvec=%.0f nu=%.0f cycles" % (ph[2]/ph[7], ph[4]/ph[7], ph[5]/ph[7], ph[6]/ph[7]))
