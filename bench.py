@@ -56,7 +56,10 @@ def main():
     ap.add_argument("--scenes", type=int, default=64, help="independent scenes batched per step")
     ap.add_argument("--agents-per-gpu", type=int, default=100)
     ap.add_argument("--config", default="C2")
-    ap.add_argument("--capture-step", type=int, default=12)
+    ap.add_argument("--capture-step", type=int, default=12,
+                    help="MPC step whose inputs are replayed; scenes that abort earlier keep their last valid state "
+                         "(solveHardDMPC on C2 aborts every scene at its first solve, so the replayed state is step 2)")
+    ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -124,7 +127,7 @@ def main():
         one_step()
     barrier()
     t1 = time.perf_counter()
-    kern_ms, n_launch = dmpc.profile_read()
+    kern_ms, scan_ms, n_launch = dmpc.profile_read2()
     dmpc.profile(False)
     elapsed = t1 - t0
     if G > 1:
@@ -134,6 +137,40 @@ def main():
 
     solves_per_step = S * N
     value = solves_per_step * args.steps / elapsed
+
+    # secondary workload (reported, not the headline): the reference's primary variant solveSoftDMPCbound
+    # (test/failure_rate.m) on the same start/goal sets, MPC step 12 of the live transitions
+    secondary = None
+    if not args.no_secondary and G == 1 and rank == 0:
+        cfg2 = dict(cfg, variant="bound")
+        d2 = mp.Dmpc("bound", device=local_rank, **kw)
+        l2, xp2, xv2, xa2, pf2, alive2 = capture_state(d2, cfg2, S, N, 12, wl.SEED0 + 2)
+        rows2 = dev_t(l2)
+        lT2 = torch.empty((1, S, 45, C), dtype=torch.float64, device=dev)
+        d2.table_from_rows_device(S, 1, C, rows2.data_ptr(), lT2.data_ptr(), stream)
+        t2 = [dev_t(a_) for a_ in (xp2, xv2, xa2, pf2)]
+        def step2():
+            d2.step_device(S, 1, C, 0, lT2.data_ptr(), t2[0].data_ptr(), t2[1].data_ptr(), t2[2].data_ptr(), t2[3].data_ptr(),
+                           p_out.data_ptr(), v_out.data_ptr(), a_out.data_ptr(), lT_next.data_ptr(), status.data_ptr(),
+                           info.data_ptr(), stream)
+        for _ in range(3):
+            step2()
+        torch.cuda.synchronize()
+        tt = time.perf_counter()
+        for _ in range(args.steps):
+            step2()
+        torch.cuda.synchronize()
+        el2 = time.perf_counter() - tt
+        st2 = status.cpu().numpy(); inf2 = info.cpu().numpy()
+        secondary = [{"workload": f"{C} agents/scene, variant bound (solveSoftDMPCbound, failure_rate.m constants), {S} scenes, "
+                                  f"replay of MPC step 12 ({int(alive2.sum())}/{S} scenes alive)",
+                      "value": S * N * args.steps / el2, "unit": "solves/s", "ms_per_step": el2 / args.steps * 1e3,
+                      "solved_frac": float((st2 & 1).mean()), "mean_iters": float(inf2[..., 4].mean()),
+                      "max_iters": int(inf2[..., 4].max()), "max_tries": int(inf2[..., 2].max()), "invalid": int(((st2 & 48) != 0).sum()),
+                      "mean_rows": float(inf2[..., 1].mean())}]
+        # restore the headline workload's last outputs for the statistics below
+        one_step()
+        torch.cuda.synchronize()
     st = status.cpu().numpy()
     inf = info.cpu().numpy()
 
@@ -156,20 +193,25 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.config}: {C} agents/GPU x {G} GPU(s) per scene, variant {cfg['variant']} "
                                    f"(solve{'Hard' if cfg['variant']=='hard' else ''}DMPC), K=15, {S} scenes batched, "
-                                   f"steady-state replay of MPC step {args.capture_step}",
+                                   f"steady-state replay of the captured MPC step (requested {args.capture_step}; "
+                                   f"{int(alive.sum())}/{S} scenes still alive there)",
                        "agents_per_scene": N, "scenes": S, "solves_per_step": solves_per_step,
                        "parallelism": f"agents sharded x{G}, all-gather per step" if G > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "dmpc_step_kernel", "kernel_ms_avg": kern_ms, "launches": n_launch,
-                         "alg_bytes_per_solve": b_alg,
-                         "note": "on-chip bound (LDS latency + fp64 issue); compulsory HBM traffic is ~1.5 KB/solve"},
+                         "kernel": "dmpc_solve_kernel", "kernel_ms_avg": kern_ms, "launches": n_launch,
+                         "other_kernels_ms_avg": {"dmpc_scan_kernel+order_kernel": scan_ms},
+                         "alg_bytes_per_solve": b_alg, "solves_per_launch": S * C,
+                         "note": "on-chip bound (dependent LDS/VALU chains of the active-set iterations); compulsory HBM "
+                                 "traffic is ~1.5 KB/solve, so the HBM fraction is small by construction"},
             "workload_stats": {"solved_frac": float((st & 1).mean()), "infeasible_frac": float(((st & 8) != 0).mean()),
                                "invalid": int(((st & 48) != 0).sum()), "mean_iters": float(inf[..., 4].mean()),
                                "max_iters": int(inf[..., 4].max()), "mean_rows": float(inf[..., 1].mean()),
                                "max_rows": int(inf[..., 1].max()), "max_working_set": int(inf[..., 7].max()),
                                "scenes_alive_at_capture": int(alive.sum())},
         }
+        if not args.no_secondary and G == 1:
+            line["secondary"] = secondary
         if not args.no_cpu_baseline and G == 1:
             from oracle import oracle as orc
             prm = orc.make_params(cfg["variant"], **kw)

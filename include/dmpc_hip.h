@@ -157,9 +157,11 @@ int64_t dmpc_solve_count(const dmpc_ctx *ctx);
 
 /* Roofline instrumentation: with dmpc_profile(ctx,1) every step-kernel launch is bracketed by HIP
  * events on the stream it is launched on; dmpc_profile_read drains them and returns the average
- * kernel duration (ms) and launch count since the previous read. */
+ * duration (ms) of the step's kernels and the step count since the previous read. */
 int dmpc_profile(dmpc_ctx *ctx, int enable);
 int dmpc_profile_read(dmpc_ctx *ctx, double *avg_ms, int64_t *n_launches);
+/* same, split into the solve kernel(s) (dmpc_solve_kernel, the dominant kernel) and scan + ordering */
+int dmpc_profile_read2(dmpc_ctx *ctx, double *solve_avg_ms, double *scan_avg_ms, int64_t *n_steps);
 
 #ifdef __cplusplus
 }

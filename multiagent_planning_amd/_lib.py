@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "dmpc_create", "dmpc_destroy", "dmpc_last_error", "dmpc_set_params", "dmpc_model_matrices",
     "dmpc_posvel_matrix", "dmpc_init_batch", "dmpc_step_batch", "dmpc_solve_one", "dmpc_step_device",
     "dmpc_table_from_rows_device", "dmpc_advance_device", "dmpc_transition", "dmpc_solve_count",
-    "dmpc_profile", "dmpc_profile_read",
+    "dmpc_profile", "dmpc_profile_read", "dmpc_profile_read2",
 ]
 
 
@@ -75,6 +75,7 @@ def load():
     L.dmpc_solve_count.argtypes = [vp]
     L.dmpc_profile.argtypes = [vp, C.c_int]
     L.dmpc_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    L.dmpc_profile_read2.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     _lib = L
     return L
 
@@ -213,6 +214,12 @@ class Dmpc:
         ms, n = C.c_double(0.0), C.c_int64(0)
         self._chk(self._L.dmpc_profile_read(self._ctx, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def profile_read2(self):
+        """(solve-kernel avg ms, scan+order avg ms, steps) since the previous read."""
+        a, b, n = C.c_double(0.0), C.c_double(0.0), C.c_int64(0)
+        self._chk(self._L.dmpc_profile_read2(self._ctx, C.byref(a), C.byref(b), C.byref(n)))
+        return a.value, b.value, n.value
 
     @property
     def solve_count(self):

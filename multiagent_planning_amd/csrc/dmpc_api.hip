@@ -53,7 +53,9 @@ struct dmpc_ctx {
     // profiling
     int profile = 0;
     double *dbg = nullptr; int dbg_agent = -1, dbg_cap = 0;   // development trace (dmpc_debug_trace)
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    struct Ev { hipEvent_t t0, t1, t2; };   // step start | scan+order done | solve tiers done
+    std::vector<Ev> events;
+    double prof_scan_ms_sum = 0.0;
     double prof_ms_sum = 0.0;
     int64_t prof_n = 0;
 };
@@ -264,7 +266,7 @@ extern "C" void dmpc_destroy(dmpc_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    for (auto &ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    for (auto &ev : ctx->events) { (void)hipEventDestroy(ev.t0); (void)hipEventDestroy(ev.t1); (void)hipEventDestroy(ev.t2); }
     DevBuf *bufs[] = {&ctx->rowbuf, &ctx->rowkc, &ctx->hdr, &ctx->order, &ctx->rows, &ctx->lT, &ctx->lT2, &ctx->xp, &ctx->xv, &ctx->xa, &ctx->pf, &ctx->po, &ctx->pout,
                       &ctx->vout, &ctx->aout, &ctx->status, &ctx->info, &ctx->hist_p, &ctx->hist_v, &ctx->hist_a, &ctx->flags};
     for (DevBuf *b : bufs) b->release();
@@ -367,11 +369,12 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
         HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsmax));
         ctx->max_lds_set = (int)ldsmax;
     }
-    std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+    dmpc_ctx::Ev ev{nullptr, nullptr, nullptr};
     if (ctx->profile) {
-        HIPCHK(ctx, hipEventCreate(&ev.first));
-        HIPCHK(ctx, hipEventCreate(&ev.second));
-        HIPCHK(ctx, hipEventRecord(ev.first, st));
+        HIPCHK(ctx, hipEventCreate(&ev.t0));
+        HIPCHK(ctx, hipEventCreate(&ev.t1));
+        HIPCHK(ctx, hipEventCreate(&ev.t2));
+        HIPCHK(ctx, hipEventRecord(ev.t0, st));
     }
     const dim3 grid((unsigned)(S * c_count)), block(64);
     // phase 0: scan + rows
@@ -382,6 +385,7 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
         hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, st, S * c_count, (const int *)P.hdr, ctx->order.as<int>());
         P.order = ctx->order.as<int>();
     }
+    if (ctx->profile) HIPCHK(ctx, hipEventRecord(ev.t1, st));
     // phase 1, tier 1
     hipLaunchKernelGGL(dmpc_solve_kernel, grid, block, lds1, st, P);
     if (two_tier) {   // phase 1, tier 2: only agents flagged ST_QOVER do any work
@@ -390,7 +394,7 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     }
     HIPCHK(ctx, hipGetLastError());
     if (ctx->profile) {
-        HIPCHK(ctx, hipEventRecord(ev.second, st));
+        HIPCHK(ctx, hipEventRecord(ev.t2, st));
         ctx->events.push_back(ev);
     }
     ctx->solves += (int64_t)S * c_count;
@@ -416,25 +420,36 @@ extern "C" int dmpc_debug_trace(dmpc_ctx *ctx, int agent, int cap, double *host_
     return 0;
 }
 
-extern "C" int dmpc_profile_read(dmpc_ctx *ctx, double *avg_ms, int64_t *n_launches)
+extern "C" int dmpc_profile_read2(dmpc_ctx *ctx, double *solve_avg_ms, double *scan_avg_ms, int64_t *n_steps)
 {
     if (!ctx) return -1;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     for (auto &ev : ctx->events) {
-        HIPCHK(ctx, hipEventSynchronize(ev.second));
-        float ms = 0.f;
-        HIPCHK(ctx, hipEventElapsedTime(&ms, ev.first, ev.second));
-        ctx->prof_ms_sum += ms;
+        HIPCHK(ctx, hipEventSynchronize(ev.t2));
+        float ms_scan = 0.f, ms_solve = 0.f;
+        HIPCHK(ctx, hipEventElapsedTime(&ms_scan, ev.t0, ev.t1));
+        HIPCHK(ctx, hipEventElapsedTime(&ms_solve, ev.t1, ev.t2));
+        ctx->prof_scan_ms_sum += ms_scan;
+        ctx->prof_ms_sum += ms_solve;
         ctx->prof_n += 1;
-        (void)hipEventDestroy(ev.first);
-        (void)hipEventDestroy(ev.second);
+        (void)hipEventDestroy(ev.t0); (void)hipEventDestroy(ev.t1); (void)hipEventDestroy(ev.t2);
     }
     ctx->events.clear();
-    if (avg_ms) *avg_ms = ctx->prof_n ? ctx->prof_ms_sum / (double)ctx->prof_n : 0.0;
-    if (n_launches) *n_launches = ctx->prof_n;
-    ctx->prof_ms_sum = 0.0;
+    if (solve_avg_ms) *solve_avg_ms = ctx->prof_n ? ctx->prof_ms_sum / (double)ctx->prof_n : 0.0;
+    if (scan_avg_ms) *scan_avg_ms = ctx->prof_n ? ctx->prof_scan_ms_sum / (double)ctx->prof_n : 0.0;
+    if (n_steps) *n_steps = ctx->prof_n;
+    ctx->prof_ms_sum = ctx->prof_scan_ms_sum = 0.0;
     ctx->prof_n = 0;
     return 0;
+}
+
+// average duration (ms) of the step's kernels (scan + order + solve tiers) since the previous read
+extern "C" int dmpc_profile_read(dmpc_ctx *ctx, double *avg_ms, int64_t *n_launches)
+{
+    double a = 0.0, b = 0.0;
+    const int rc = dmpc_profile_read2(ctx, &a, &b, n_launches);
+    if (avg_ms) *avg_ms = a + b;
+    return rc;
 }
 
 extern "C" int dmpc_step_device(dmpc_ctx *ctx, int S, int G, int C, int g_local, const double *lT, const double *x_p,

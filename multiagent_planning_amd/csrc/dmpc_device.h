@@ -39,7 +39,7 @@ struct StepParams {
 inline size_t step_lds_bytes(int nrmax, bool soft, int qcap, int phase)
 {
     if (phase == 0) return 48 * 8;
-    size_t dbl = (size_t)t_doubles(qcap) + 675 + 4 * 48 + 2 * 64 + 6 * (size_t)qcap + (soft ? (size_t)nrmax : 0);
+    size_t dbl = (size_t)t_doubles(qcap) + 676 + 4 * 48 + 2 * 64 + 6 * (size_t)qcap + (soft ? (size_t)nrmax : 0);
     size_t bytes = dbl * 8 + 3 * (size_t)qcap * 4 + (size_t)nrmax;   // + slot ints + row flags (bytes)
     return (bytes + 15) & ~(size_t)15;
 }

@@ -365,7 +365,7 @@ __device__ __forceinline__ void step_body(const StepParams &P)
             L.s_kb = L.s_ty = L.s_idx = nullptr; L.r_fl = nullptr;
         } else {
             L.T = p; p += t_doubles(qcap);
-            L.tabH = p; p += 225; L.tabM = p; p += 225; L.tabP = p; p += 225;
+            L.tabH = p; p += 225; L.tabM = p; p += 225; L.tabP = p; p += 226;   // 676: keep 16-B alignment of what follows
             L.a_s = p; p += 48; L.w_s = p; p += 48; L.nu_s = p; p += 48; L.yt_s = p; p += 48; L.own_s = nullptr;
             L.rr_s = p; p += 64; L.xs_s = p; p += 64;
             L.s_vec = p; p += 3 * qcap;
@@ -409,6 +409,7 @@ __device__ __forceinline__ void step_body(const StepParams &P)
     // ---------------------------------------------------------------- a5/a6: scan + rows
     int nr = 0, nrows_ref = 0, viol_k = 0, status = 0;
     bool cert_infeasible = false;
+    int ladder_start = 0;   // first retry-ladder level that is not certainly infeasible (soft ladder variants)
     bool rows_exist = false, violation = false;
     const double rmin = P.rmin;
     const bool near_sel = (var == VAR_BOUND || var == VAR_BOUND2 || var == VAR_ALL3 || var == VAR_ONDEMAND);
@@ -436,9 +437,20 @@ __device__ __forceinline__ void step_body(const StepParams &P)
                 // Exact infeasibility certificate for rows without slack: if even the BEST point of the
                 // reachable box violates the row (max of the linearised distance < dist*rmin), no acceleration
                 // within |a| <= alim satisfies it -> the QP is infeasible; the long active-set proof is skipped.
-                if (!soft && sel) {
+                if (sel) {
                     const double lin_max = lin_min + 2.0 * (fabs(x0) + fabs(x1) + fabs(x2)) * hw;
-                    if (lin_max < dist * rmin - 1e-9) cert_infeasible = true;
+                    if (!soft) {
+                        if (lin_max < dist * rmin - 1e-9) cert_infeasible = true;
+                    } else if (var == VAR_BOUND || var == VAR_BOUND2 || var == VAR_ALL3) {
+                        // Soft rows with a bounded slack (coefficient dist): the row needs
+                        //   lin >= dist*(rmin + eps),  eps >= slb * 2^t at ladder level t (solveSoftDMPCbound.m:147-153),
+                        // so every level with lin_max < dist*(rmin + slb 2^t) is certainly infeasible and the
+                        // retry ladder can start at the first level that passes this necessary test.
+                        double slb_t = (var == VAR_BOUND) ? -0.05 : -0.01;
+                        int t = 0;
+                        while (t < 40 && lin_max < dist * (rmin + slb_t) - 1e-9) { slb_t *= 2.0; ++t; }
+                        if (t > ladder_start) ladder_start = t;
+                    }
                 }
             }
             const unsigned long long m = __ballot(sel);
@@ -558,11 +570,15 @@ __device__ __forceinline__ void step_body(const StepParams &P)
             hdr[0] = nr; hdr[1] = nrows_ref; hdr[2] = viol_k; hdr[3] = status;
             hdr[4] = violation ? 1 : 0; hdr[5] = rows_exist ? 1 : 0; hdr[6] = 0; hdr[7] = 0;
         }
+        {
+            const int ls = (int)wave_max((double)ladder_start);
+            if (lane == 0) hdr[6] = ls;
+        }
         return;
     }
     // PHASE 1: pick up the scan's branch record
     nr = hdr[0]; nrows_ref = hdr[1]; viol_k = hdr[2]; status = hdr[3];
-    violation = hdr[4] != 0; rows_exist = hdr[5] != 0;
+    violation = (hdr[4] & 1) != 0; rows_exist = hdr[5] != 0;
     const int nrows_built = nrows_ref;
 
     const long long tk1 = clock64();
@@ -629,12 +645,26 @@ __device__ __forceinline__ void step_body(const StepParams &P)
     const int max_tries = P.max_tries > 0 ? P.max_tries : 30;
     // a tier-2 relaunch resumes the retry ladder where tier 1 left it (the row data in global memory already
     // carries the doublings of the tries that were proven infeasible)
-    int tries = (P.only_flagged ? hdr[6] : 0), iters_total = (P.only_flagged ? hdr[7] : 0), maxq = 0, q = 0;
+    // hdr[6] = retry-ladder levels already known to be infeasible (certified by the scan, or proven by a
+    // tier-1 launch that then overflowed); hdr[4] bit 1 = the row data in global memory is already scaled
+    int tries = hdr[6], iters_total = (P.only_flagged ? hdr[7] : 0), maxq = 0, q = 0;
+    const bool rows_scaled = (hdr[4] & 2) != 0;
     bool solved = false;
     double a = 0.0, w = 0.0;
     const double tol = 1e-10;
 
     if (status & ST_INFEAS) tries = 1;   // certified infeasible by the scan (single attempt, no ladder: hard rows only)
+    if (tries > 0 && !rows_scaled && !(status & ST_INFEAS)) {
+        // skip the ladder levels the scan certified infeasible: lb_eps *= 2, term *= 2 per level (:147-153)
+        if (tries >= max_tries) { status |= ST_INFEAS; tries = max_tries; }
+        else {
+            const double f = ldexp(1.0, tries);
+            for (int i = lane; i < nr; i += 64) { L.r_slb[i] *= f; L.r_st[i] *= f; }
+            rcslb[0] *= f; rcslb[1] *= f;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+    }
     if (!(status & (ST_COLL | ST_CAPACITY | ST_INFEAS))) {
         while (tries < max_tries) {
             tries++;
@@ -983,7 +1013,7 @@ __device__ __forceinline__ void step_body(const StepParams &P)
             if (rc == 0) { solved = true; break; }
             if (rc == 2) {   // tier 1: flag for the tier-2 relaunch (and record the ladder position); last tier: capacity error
                 status |= P.qover_bit;
-                if (lane == 0) { hdr[6] = tries - 1; hdr[7] = iters_total; }
+                if (lane == 0) { hdr[6] = tries - 1; hdr[7] = iters_total; hdr[4] |= 2; }
                 break;
             }
             if (rc == 3) { status |= ST_ITERCAP; break; }
