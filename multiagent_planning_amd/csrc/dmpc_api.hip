@@ -46,7 +46,11 @@ struct dmpc_ctx {
     int64_t solves = 0;
     int max_lds_set = 0;
     // scratch for the host-pointer entry points
-    DevBuf rowbuf, rowkc, hdr, order;   // collision-row scratch + scan->solve header of the step kernels
+    DevBuf rowbuf, rowkc, hdr, order, bbox;
+    // chunk-level bounding-box neighbour culling in the scan: measured SLOWER on C4 at MPC steps 2-4 (3 s horizon
+    // boxes of fast agents overlap almost every 64-neighbour chunk), so it is opt-in (DMPC_CULL=1) until the scan
+    // compacts survivors per neighbour
+    int no_cull = getenv("DMPC_CULL") ? 0 : 1;   // collision-row scratch + scan->solve header of the step kernels
     int no_lpt = getenv("DMPC_NO_LPT") ? 1 : 0;   // tuning: disable the heaviest-first solve order
     int single_tier = 0;         // 1: solve with the full working-set capacity in one launch
     DevBuf rows, lT, lT2, xp, xv, xa, pf, po, pout, vout, aout, status, info, hist_p, hist_v, hist_a, flags;
@@ -267,7 +271,7 @@ extern "C" void dmpc_destroy(dmpc_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (auto &ev : ctx->events) { (void)hipEventDestroy(ev.t0); (void)hipEventDestroy(ev.t1); (void)hipEventDestroy(ev.t2); }
-    DevBuf *bufs[] = {&ctx->rowbuf, &ctx->rowkc, &ctx->hdr, &ctx->order, &ctx->rows, &ctx->lT, &ctx->lT2, &ctx->xp, &ctx->xv, &ctx->xa, &ctx->pf, &ctx->po, &ctx->pout,
+    DevBuf *bufs[] = {&ctx->rowbuf, &ctx->rowkc, &ctx->hdr, &ctx->order, &ctx->bbox, &ctx->rows, &ctx->lT, &ctx->lT2, &ctx->xp, &ctx->xv, &ctx->xa, &ctx->pf, &ctx->po, &ctx->pout,
                       &ctx->vout, &ctx->aout, &ctx->status, &ctx->info, &ctx->hist_p, &ctx->hist_v, &ctx->hist_a, &ctx->flags};
     for (DevBuf *b : bufs) b->release();
     if (ctx->d_tables) (void)hipFree(ctx->d_tables);
@@ -377,6 +381,13 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
         HIPCHK(ctx, hipEventRecord(ev.t0, st));
     }
     const dim3 grid((unsigned)(S * c_count)), block(64);
+    // neighbour culling boxes (worth it once a scene has more than a few chunks of neighbours)
+    if (G * C >= 256 && !ctx->no_cull) {
+        const int total = G * S * C;
+        if (ctx->bbox.ensure((size_t)total * 6 * 8)) FAIL(ctx, "device allocation failed (bbox)");
+        hipLaunchKernelGGL(bbox_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, C, lT, ctx->bbox.as<double>());
+        P.bbox = ctx->bbox.as<double>();
+    }
     // phase 0: scan + rows
     P.qcap = q1; P.only_flagged = 0; P.qover_bit = two_tier ? ST_QOVER : ST_CAPACITY;
     hipLaunchKernelGGL(dmpc_scan_kernel, grid, block, lds0, st, P);

@@ -415,6 +415,24 @@ __device__ __forceinline__ void step_body(const StepParams &P)
     const bool near_sel = (var == VAR_BOUND || var == VAR_BOUND2 || var == VAR_ALL3 || var == VAR_ONDEMAND);
     const bool coll_check = (var == VAR_BOUND || var == VAR_BOUND2 || var == VAR_ALL3 || var == VAR_REPAIR);
     const bool skip_k1 = (var == VAR_BOUND2 || var == VAR_ALL3 || var == VAR_REPAIR);
+    // own horizon box (uniform) for the neighbour culling, PHASE 0 only
+    double obx0 = 0, obx1 = 0, oby0 = 0, oby1 = 0, obz0 = 0, obz1 = 0;
+    if (PHASE == 0) {
+        const double v = (lane < N3) ? L.own_s[lane] : 0.0;
+        const int ax = lane % 3;
+        obx0 = wave_min((lane < N3 && ax == 0) ? v : INFINITY); obx1 = wave_max((lane < N3 && ax == 0) ? v : -INFINITY);
+        oby0 = wave_min((lane < N3 && ax == 1) ? v : INFINITY); oby1 = wave_max((lane < N3 && ax == 1) ? v : -INFINITY);
+        obz0 = wave_min((lane < N3 && ax == 2) ? v : INFINITY); obz1 = wave_max((lane < N3 && ax == 2) ? v : -INFINITY);
+    }
+    // true if some neighbour of this 64-wide chunk can come within ellipsoidal distance R of the agent
+    auto chunk_may_hit = [&](int r, int jc, bool valid, double R) -> bool {
+        if (!P.bbox) return true;
+        const double *bb = P.bbox + ((size_t)(r * S + scene) * 6) * C + jc;
+        const double Rz = R / P.e1z;   // |dz|/c < R
+        const bool hit = valid && bb[0] <= obx1 + R && bb[(size_t)C] >= obx0 - R && bb[2 * (size_t)C] <= oby1 + R &&
+                         bb[3 * (size_t)C] >= oby0 - R && bb[4 * (size_t)C] <= obz1 + Rz && bb[5 * (size_t)C] >= obz0 - Rz;
+        return __any(hit);
+    };
 
     if (PHASE == 0) {
         // appends the rows of horizon step ke (evaluated positions) constraining step kc for every
@@ -485,6 +503,7 @@ __device__ __forceinline__ void step_body(const StepParams &P)
                     const int jj = j0 + lane;
                     const bool valid = jj < C && !(r == P.g_local && jj == cl);
                     const int jc = jj < C ? jj : C - 1;   // clamped: loads are unconditional, results masked
+                    if (!sel_all && !chunk_may_hit(r, jc, valid, sel_r)) continue;
                     const double dx = px - base[jc], dy = py - base[(size_t)C + jc], dz = pz - base[2 * (size_t)C + jc];
                     const double ez = dz * P.e1z;
                     const double dist = sqrt(dx * dx + dy * dy + ez * ez);
@@ -510,6 +529,8 @@ __device__ __forceinline__ void step_body(const StepParams &P)
                 const int jj = j0 + lane;
                 const bool valid = jj < C && !(r == P.g_local && jj == cl);
                 const int jc = jj < C ? jj : C - 1;
+                // hard rows need d < 1; every other variant only needs to know about neighbours inside rmin here
+                if (!chunk_may_hit(r, jc, valid, var == VAR_HARD ? 1.0 : rmin)) continue;
     #pragma unroll
                 for (int kg = 0; kg < 3; ++kg) {
                     double nx[5], ny[5], nz[5];
@@ -1089,6 +1110,29 @@ __global__ __launch_bounds__(64, SOLVE_WAVES_PER_SIMD) void dmpc_solve_kernel(St
 // --------------------------------------------------------------------------------------------
 // small layout / bookkeeping kernels
 // --------------------------------------------------------------------------------------------
+
+// Axis-aligned bounding box of every agent's predicted horizon: bbox[G][S][6][C] = xmin,xmax,ymin,ymax,zmin,zmax.
+// The scan culls whole neighbour chunks with it (a neighbour can come within R of the agent at some step
+// only if the boxes are within R per axis), which turns the O(K N) table reads per agent into O(N) 48-B
+// box reads plus the few chunks that really contain near neighbours.  Conservative => results unchanged.
+__global__ void bbox_kernel(int total, int C, const double *__restrict__ lT, double *__restrict__ bbox)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // enumerates (g*S + s)*C + c
+    if (i >= total) return;
+    const int c = i % C;
+    const size_t gs = (size_t)(i / C);
+    const double *src = lT + gs * N3 * C + c;
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double v = src[(size_t)(3 * k + a) * C];
+            lo[a] = fmin(lo[a], v); hi[a] = fmax(hi[a], v);
+        }
+    double *dst = bbox + gs * 6 * C + c;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { dst[(size_t)(2 * a) * C] = lo[a]; dst[(size_t)(2 * a + 1) * C] = hi[a]; }
+}
 
 // Longest-processing-time-first launch order for the solve phase: agents are bucketed by the number of
 // collision rows the scan produced (a good proxy for active-set iterations) and the solve kernel takes
