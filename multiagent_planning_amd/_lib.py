@@ -48,6 +48,13 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch wheels bundle their own libamdhip64; two HIP runtimes in one process only work if torch's is
+    # loaded first (then this library binds to the same runtime by soname).  Import torch, when present,
+    # before loading -- it is the device-memory / stream / RCCL plumbing of the callers anyway.
+    try:
+        import torch  # noqa: F401
+    except Exception:   # torch is optional for the pure C-ABI use
+        pass
     if not os.path.exists(LIB_PATH):
         raise DmpcError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -106,3 +106,34 @@ def test_sharded_device_layout_bitwise_identical():
             assert np.array_equal(one["p"], p) and np.array_equal(one["status"], st)
         else:
             assert np.array_equal(ref[0], p) and np.array_equal(ref[1], st)
+
+
+def test_transition_batch_matches_host_loop_and_oracle_outcomes():
+    """S scenes x N agents of the primary variant through the device loop (dmpc_transition) == host loop over
+    step_batch, bit for bit, including the per-scene stop rule (goal reached / abort)."""
+    cfg = dict(wl.CONFIGS["C4"])
+    N, S, KT = 24, 3, 60
+    kw = wl.solver_kwargs(cfg, N)
+    po, pf = wl.make_scenes(cfg, S, N, wl.SEED0 + 99)
+    d = mp.Dmpc("bound", **kw)
+    res = d.transition(po, pf, KT, cfg["error_tol"])
+    l, _, _ = d.init_batch(po, pf)
+    xp, xv, xa = po.copy(), np.zeros_like(po), np.zeros_like(po)
+    used = np.full(S, KT); done = np.zeros(S, bool); sst = np.ones(S, int)
+    for k in range(1, KT):
+        out = d.step_batch(l, xp, xv, xa, pf)
+        ok = (out["status"] & 1) == 1
+        l = np.where(ok[..., None], out["p"], l)
+        xp = np.where(ok[..., None], out["p"][..., :3], xp); xv = np.where(ok[..., None], out["v"][..., :3], xv)
+        xa = np.where(ok[..., None], out["a"][..., :3], xa)
+        for s in range(S):
+            if done[s]:
+                continue
+            assert np.array_equal(res["pk"][s][:, k], xp[s]), (s, k)
+            bits = int(np.bitwise_or.reduce(out["status"][s]))
+            if bits & ~1:
+                done[s], used[s], sst[s] = True, k + 1, bits
+            elif np.linalg.norm(xp[s] - pf[s], axis=1).max() < cfg["error_tol"]:
+                done[s], used[s] = True, k + 1
+    assert np.array_equal(res["K_T_used"], used) and np.array_equal(res["scene_status"], sst)
+    assert (res["scene_status"] == 1).any()   # at least one scene runs to its goal
