@@ -121,6 +121,18 @@ int dmpc_solve_one(dmpc_ctx *ctx, int N, int n, const double *l, const double *p
                    const double *ao, const double *pf, double *p, double *v, double *a, int32_t *status,
                    int32_t *info);
 
+/* a5/a6 standalone: the scan and the collision rows of ONE agent (0-based n) exactly as the selected
+ * solver variant builds them -- [violation,min_dist,viol_constr] = CheckCollSoftDMPC(...) (CheckCollSoftDMPC.m:1)
+ * followed by [Ain,bin,prev_dist] = CollConstrSoftDMPC(...) (CollConstrSoftDMPC.m:1; ...2 / Hard / HardOnDemand /
+ * Ellip variants) -- in structured form, reference row order, no pruning.  Host pointers.
+ *   row i:  -xi_i' * Lambda(3kc_i-2:3kc_i, :) * a  [+ slack_coef_i * eps_i]  <=  rhs_i
+ *   xi: [max_rows][3] = E2*(p - p_j); kc: 1-based constrained horizon step; rhs = bin; slack_coef = prev_dist
+ *   (1 for solveSoftDMPC, 0 for the hard variants); nrows = number of rows built (may exceed max_rows);
+ *   viol_k = 1-based first violating horizon step (0 none); status = DMPC_ST_COLL or 0. */
+int dmpc_rows_one(dmpc_ctx *ctx, int N, int n, const double *l, const double *po, const double *vo, int max_rows,
+                  double *xi, double *rhs, double *slack_coef, int32_t *kc, int32_t *nrows, int32_t *viol_k,
+                  int32_t *status);
+
 /* Device-resident form of a11 for callers that keep state in HBM (bench, multi-GPU driver).
  * The table is in the chunked transposed layout lT[G][S][3K][C]: G chunks (= ranks) of C agents
  * each, N = G*C agents per scene; this call solves the C agents of chunk g_local of every scene

@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "dmpc_create", "dmpc_destroy", "dmpc_last_error", "dmpc_set_params", "dmpc_model_matrices",
     "dmpc_posvel_matrix", "dmpc_init_batch", "dmpc_step_batch", "dmpc_solve_one", "dmpc_step_device",
     "dmpc_table_from_rows_device", "dmpc_advance_device", "dmpc_transition", "dmpc_solve_count",
-    "dmpc_profile", "dmpc_profile_read", "dmpc_profile_read2",
+    "dmpc_profile", "dmpc_profile_read", "dmpc_profile_read2", "dmpc_rows_one",
 ]
 
 
@@ -74,6 +74,7 @@ def load():
     L.dmpc_init_batch.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp, dp, dp]
     L.dmpc_step_batch.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, dp, dp, ip, ip]
     L.dmpc_solve_one.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, dp, dp, ip, ip]
+    L.dmpc_rows_one.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp, C.c_int, dp, dp, dp, ip, ip, ip, ip]
     L.dmpc_step_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int] + [vp] * 12
     L.dmpc_table_from_rows_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]
     L.dmpc_advance_device.argtypes = [vp, C.c_int] + [vp] * 8
@@ -190,6 +191,17 @@ class Dmpc:
         self._chk(self._L.dmpc_solve_one(self._ctx, l.shape[0], int(n), _dp(l), _dp(po), _dp(vo), _dp(ao), _dp(pf), _dp(p),
                                          _dp(v), _dp(a), _ip(status), _ip(info)))
         return dict(p=p, v=v, a=a, status=int(status[0]), info=info)
+
+    def rows_one(self, l, n, po, vo, max_rows=4096):
+        """a5/a6 standalone: structured collision rows of agent n (reference order, unpruned)."""
+        l, po, vo = _f(l), _f(po), _f(vo)
+        xi, rhs, sc = np.zeros((max_rows, 3)), np.zeros(max_rows), np.zeros(max_rows)
+        kc = np.zeros(max_rows, dtype=np.int32)
+        nr, vk, st = (np.zeros(1, dtype=np.int32) for _ in range(3))
+        self._chk(self._L.dmpc_rows_one(self._ctx, l.shape[0], int(n), _dp(l), _dp(po), _dp(vo), max_rows, _dp(xi), _dp(rhs),
+                                        _dp(sc), _ip(kc), _ip(nr), _ip(vk), _ip(st)))
+        k = min(int(nr[0]), max_rows)
+        return dict(xi=xi[:k], rhs=rhs[:k], slack_coef=sc[:k], kc=kc[:k], nrows=int(nr[0]), viol_k=int(vk[0]), status=int(st[0]))
 
     def transition(self, po, pf, K_T_max, error_tol=0.01):
         po, pf = _f(po), _f(pf)

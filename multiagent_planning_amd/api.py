@@ -179,3 +179,34 @@ def ReachedGoal(p, pf, length_t, error_tol, N):
     else:
         differ = p[:, length_t - 1].reshape(3, 1) - np.ravel(pf).reshape(3, 1)
     return bool(np.sqrt((differ ** 2).sum(axis=0)).max() < error_tol)
+
+
+# ---- a5/a6 helpers -------------------------------------------------------------------------------
+
+def CheckCollSoftDMPC(p, l, n, k, E1, rmin, order):
+    """[violation,min_dist,viol_constr] = CheckCollSoftDMPC(p,l,n,k,E1,rmin,order)  (CheckCollSoftDMPC.m:1-17).
+    Host mirror of one scan step (inside the solvers the whole scan runs fused on the GPU)."""
+    l = np.asarray(l, float)
+    N = l.shape[2]
+    d = np.linalg.norm(np.asarray(E1) @ (np.ravel(p)[:, None] - l[:, k - 1, :]), ord=order, axis=0)
+    mask = np.arange(N) != (n - 1)
+    violation = np.where(mask, d < rmin, False).astype(float)
+    viol_constr = np.where(mask, d < rmin * 3, False).astype(float)
+    return violation, float(d[mask].min()) if mask.any() else np.inf, viol_constr
+
+
+def collision_rows(variant, po, vo, n, h, l, K, rmin, pmin, pmax, alim, Q1, S1, E1, order, term=-5e4):
+    """Scan + collision rows of agent n exactly as solver `variant` builds them, computed by the GPU scan
+    kernel (dmpc_rows_one) and expanded to the reference's dense form:
+    returns (Ain [Nv x 3K], bin [Nv], prev_dist [Nv], k_viol, coll) -- cf. CollConstrSoftDMPC.m:1 and variants."""
+    d = _ctx(variant, h, K, rmin, pmin, pmax, alim, Q1, S1, E1, order, term)
+    r = d.rows_one(_table(l), int(n) - 1, np.ravel(po), np.ravel(vo))
+    Lam = _lib.model_matrices(h, K)[0]
+    nr = len(r["kc"])
+    Ain = np.zeros((nr, 3 * K))
+    for i in range(nr):
+        kc = int(r["kc"][i])
+        Ain[i] = -(r["xi"][i] @ Lam[3 * kc - 3:3 * kc, :])   # -diff_mat*Ain  (CollConstrSoftDMPC.m:27)
+    c = 1.0 / float(np.asarray(E1)[2, 2])
+    dist = np.sqrt(r["xi"][:, 0] ** 2 + r["xi"][:, 1] ** 2 + (r["xi"][:, 2] * c) ** 2)
+    return Ain, r["rhs"].copy(), dist, r["viol_k"], int(bool(r["status"] & ST_COLL))

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -577,6 +578,71 @@ extern "C" int dmpc_solve_one(dmpc_ctx *ctx, int N, int n, const double *l, cons
     HIPCHK(ctx, hipMemcpyAsync(status, ctx->status.p, 4, hipMemcpyDeviceToHost, st));
     if (info) HIPCHK(ctx, hipMemcpyAsync(info, ctx->info.p, 32, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
+    return 0;
+}
+
+// a5/a6 standalone: scan + collision rows of ONE agent in the reference's row order
+// (CheckCollSoftDMPC.m + CollConstrSoftDMPC.m and variants), without pruning.  Host pointers.
+extern "C" int dmpc_rows_one(dmpc_ctx *ctx, int N, int n, const double *l, const double *po, const double *vo,
+                             int max_rows, double *xi, double *rhs, double *slack_coef, int32_t *kc, int32_t *nrows,
+                             int32_t *viol_k, int32_t *status)
+{
+    if (!ctx) { g_err = "dmpc_rows_one: ctx is NULL"; return -1; }
+    if (N < 1 || n < 0 || n >= N || max_rows < 0) FAIL(ctx, "dmpc_rows_one: bad arguments");
+    if (!l || !po || !vo || !nrows || !viol_k || !status) FAIL(ctx, "dmpc_rows_one: NULL pointer");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (ensure_step_scratch(ctx, (size_t)N, 1)) return -1;
+    hipStream_t st = ctx->stream;
+    const dmpc_params &p = ctx->prm;
+    const bool soft = variant_soft(p.variant);
+    double zero3[3] = {0, 0, 0};
+    HIPCHK(ctx, hipMemcpyAsync(ctx->rows.p, l, (size_t)N * N3 * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->xp.p, po, 24, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->xv.p, vo, 24, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->xa.p, zero3, 24, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->pf.p, zero3, 24, hipMemcpyHostToDevice, st));
+    if (dmpc_table_from_rows_device(ctx, 1, 1, N, ctx->rows.as<double>(), ctx->lT.as<double>(), st)) return -1;
+    StepParams P;
+    memset(&P, 0, sizeof(P));
+    P.variant = p.variant; P.S = 1; P.G = 1; P.C = N; P.g_local = 0; P.c_first = n; P.c_count = 1;
+    const long want = (p.variant == DMPC_VAR_HARD ? (long)K : (p.variant == DMPC_VAR_ALL3 ? 3L : 1L)) * (N > 1 ? N - 1 : 1);
+    P.nrmax = (int)((want + 1) & ~1L);   // the exact worst case: nothing is pruned or truncated here
+    P.h = p.h; P.rmin = p.rmin; P.e1z = 1.0 / p.c; P.e2z = 1.0 / (p.c * p.c);
+    P.alim = p.alim; P.Q1 = p.Q1; P.S1 = p.S1; P.term = p.term;
+    for (int d = 0; d < 3; ++d) { P.pmin[d] = p.pmin[d]; P.pmax[d] = p.pmax[d]; }
+    P.tables = ctx->d_tables; P.lT = ctx->lT.as<double>();
+    P.x_p = ctx->xp.as<double>(); P.x_v = ctx->xv.as<double>(); P.x_a = ctx->xa.as<double>(); P.pf = ctx->pf.as<double>();
+    P.status = ctx->status.as<int32_t>(); P.no_prune = 1; P.qcap = QMAX; P.qover_bit = ST_CAPACITY;
+    const size_t per = (size_t)P.nrmax * (soft ? 7 : 4);
+    if (ctx->rowbuf.ensure(per * 8) || ctx->rowkc.ensure((size_t)P.nrmax * 4) || ctx->hdr.ensure(32)) FAIL(ctx, "device allocation failed");
+    P.rowbuf = ctx->rowbuf.as<double>(); P.rowkc = ctx->rowkc.as<int>(); P.hdr = ctx->hdr.as<int>();
+    hipLaunchKernelGGL(dmpc_scan_kernel, dim3(1), dim3(64), step_lds_bytes(P.nrmax, soft, QMAX, 0), st, P);
+    HIPCHK(ctx, hipGetLastError());
+    int hdr[8];
+    HIPCHK(ctx, hipMemcpyAsync(hdr, ctx->hdr.p, 32, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    const int nr = hdr[0];
+    *nrows = hdr[1]; *viol_k = hdr[2]; *status = hdr[3] & (DMPC_ST_COLL | DMPC_ST_CAPACITY);
+    const int cnt = nr < max_rows ? nr : max_rows;
+    if (cnt > 0 && xi && rhs && kc) {
+        std::vector<double> buf(per);
+        std::vector<int> kbuf(P.nrmax);
+        HIPCHK(ctx, hipMemcpy(buf.data(), ctx->rowbuf.p, per * 8, hipMemcpyDeviceToHost));
+        HIPCHK(ctx, hipMemcpy(kbuf.data(), ctx->rowkc.p, (size_t)P.nrmax * 4, hipMemcpyDeviceToHost));
+        // reference order: horizon step major, neighbour index minor (the hard variant's rows are emitted
+        // neighbour-chunk major on the device): stable sort by constrained step
+        std::vector<int> idx(nr);
+        for (int i = 0; i < nr; ++i) idx[i] = i;
+        if (p.variant == DMPC_VAR_HARD || p.variant == DMPC_VAR_ALL3)
+            std::stable_sort(idx.begin(), idx.end(), [&](int a_, int b_) { return kbuf[a_] < kbuf[b_]; });
+        for (int i = 0; i < cnt; ++i) {
+            const int j = idx[i];
+            xi[3 * i] = buf[3 * j]; xi[3 * i + 1] = buf[3 * j + 1]; xi[3 * i + 2] = buf[3 * j + 2];
+            rhs[i] = buf[(size_t)3 * P.nrmax + j];
+            if (slack_coef) slack_coef[i] = soft ? buf[(size_t)4 * P.nrmax + j] : 0.0;
+            kc[i] = kbuf[j] + 1;   // 1-based like the reference's k_ctr
+        }
+    }
     return 0;
 }
 

@@ -30,6 +30,7 @@ struct StepParams {
     int *rowkc;             // [S*c_count][nrmax] constrained horizon step of each row
     int *hdr;               // [S*c_count][8] scan -> solve hand-off (row count, branch record)
     int only_flagged, qover_bit;
+    int no_prune;           // 1: keep every row the reference builds (dmpc_rows_one); 0: exact pruning
     const double *bbox;     // [G][S][6][C] horizon bounding boxes (bbox_kernel) or null: neighbour culling in the scan
     const int *order;       // solve-phase launch order (agent ids, heaviest first) or null
     double *dbg;            // optional per-iteration trace of agent dbg_agent (development aid)

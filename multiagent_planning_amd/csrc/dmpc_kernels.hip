@@ -451,7 +451,7 @@ __device__ __forceinline__ void step_body(const StepParams &P)
             {
                 const double hw = 0.5 * P.alim * sh * sh;
                 const double lin_min = x0 * (a0x - (px - dx)) + x1 * (a0y - (py - dy)) + x2 * (a0z - (pz - dz)) - (fabs(x0) + fabs(x1) + fabs(x2)) * hw;
-                if (lin_min >= dist * rmin + 1e-9) sel = false;
+                if (lin_min >= dist * rmin + 1e-9 && !P.no_prune) sel = false;
                 // Exact infeasibility certificate for rows without slack: if even the BEST point of the
                 // reachable box violates the row (max of the linearised distance < dist*rmin), no acceleration
                 // within |a| <= alim satisfies it -> the QP is infeasible; the long active-set proof is skipped.

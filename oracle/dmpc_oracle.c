@@ -861,3 +861,25 @@ out:
     ctx_free(c);
     return rc;
 }
+
+/* a5/a6 standalone: the rows scan_and_rows builds for agent n, dense (G: nrows x 3K, b, dist) */
+int orc_rows_one(const orc_params *prm, int N, int n, const double *l, const double po[3], const double vo[3],
+                 int max_rows, double *G, double *b, double *dist, int *nrows, int *viol_k, int *status)
+{
+    if (prm->order != 2 || prm->K < 1 || prm->K > MAXK) return -1;
+    ctx_t *c = ctx_new(prm->h, prm->K);
+    double x0[6] = {po[0], po[1], po[2], vo[0], vo[1], vo[2]};
+    rows_t R;
+    memset(&R, 0, sizeof(R));
+    scan_t sc = scan_and_rows(c, prm, N, n, l, x0, &R);
+    *nrows = R.nrows; *viol_k = sc.viol_k; *status = sc.status;
+    int cnt = R.nrows < max_rows ? R.nrows : max_rows;
+    if (cnt > 0) {
+        memcpy(G, R.G, sizeof(double) * (size_t)cnt * c->n3);
+        memcpy(b, R.b, sizeof(double) * cnt);
+        memcpy(dist, R.dist, sizeof(double) * cnt);
+    }
+    free(R.G); free(R.b); free(R.dist);
+    ctx_free(c);
+    return 0;
+}

@@ -87,6 +87,10 @@ int orc_eval_one(const orc_params *prm, int N, int n, const double *l, const dou
                  const double vo[3], const double ao[3], const double pf[3], const double *acc,
                  double *obj, double *maxviol);
 
+/* a5/a6 standalone: collision rows of agent n exactly as the solver variant builds them (dense) */
+int orc_rows_one(const orc_params *prm, int N, int n, const double *l, const double po[3], const double vo[3],
+                 int max_rows, double *G, double *b, double *dist, int *nrows, int *viol_k, int *status);
+
 /* generic dense strictly-convex QP: min 1/2 x'Gx + g'x  s.t. C x <= d (m rows), used by tests.
  * lam: m multipliers. returns 0 ok, 1 infeasible, <0 error */
 int orc_qp_dense(int n, int m, const double *G, const double *g, const double *C, const double *d,

@@ -54,6 +54,7 @@ def lib(path=None):
         L.orc_solve_one.argtypes = [C.POINTER(Params), C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, dp, dp, ip, dp]
         L.orc_step.argtypes = [C.POINTER(Params), C.c_int, dp, dp, dp, dp, dp, dp, dp, dp, ip, ip, dp, C.c_int]
         L.orc_eval_one.argtypes = [C.POINTER(Params), C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, dp, dp]
+        L.orc_rows_one.argtypes = [C.POINTER(Params), C.c_int, C.c_int, dp, dp, dp, C.c_int, dp, dp, dp, ip, ip, ip]
         L.orc_qp_dense.argtypes = [C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, ip]
         if path is not None:
             return L
@@ -142,3 +143,16 @@ def qp_dense(G, g, Cm, d):
     it = C.c_int(0)
     rc = lib().orc_qp_dense(n, m, _dp(G), _dp(g), _dp(Cm), _dp(d), _dp(x), _dp(lam), C.byref(it))
     return rc, x, lam[:m], it.value
+
+
+def rows_one(prm, l, n, po, vo, max_rows=4096):
+    """collision rows of agent n (dense): dict(G [nr,3K], b, dist, nrows, viol_k, status)."""
+    l, po, vo = _f(l), _f(po), _f(vo)
+    n3 = 3 * prm.K
+    G, b, dist = np.zeros((max_rows, n3)), np.zeros(max_rows), np.zeros(max_rows)
+    nr, vk, st = C.c_int(0), C.c_int(0), C.c_int(0)
+    rc = lib().orc_rows_one(C.byref(prm), l.shape[0], n, _dp(l), _dp(po), _dp(vo), max_rows, _dp(G), _dp(b), _dp(dist),
+                            C.byref(nr), C.byref(vk), C.byref(st))
+    assert rc == 0
+    k = min(nr.value, max_rows)
+    return dict(G=G[:k], b=b[:k], dist=dist[:k], nrows=nr.value, viol_k=vk.value, status=st.value)
