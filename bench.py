@@ -60,6 +60,9 @@ def main():
                     help="MPC step whose inputs are replayed; scenes that abort earlier keep their last valid state "
                          "(solveHardDMPC on C2 aborts every scene at its first solve, so the replayed state is step 2)")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--emulate-gpus", type=int, default=0,
+                    help="tuning aid: on ONE GPU run rank 0's share of a G-GPU job (table of 100*G agents per scene, "
+                         "no collective) to see the per-rank step time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -75,9 +78,12 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     G = world
+    emu = args.emulate_gpus if (world == 1 and args.emulate_gpus > 1) else 0
+    if emu:
+        G = emu
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if G > 1:
+    if G > 1 and not emu:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=G)
 
@@ -110,11 +116,11 @@ def main():
         dmpc.step_device(S, G, C, rank, lT.data_ptr(), x_p.data_ptr(), x_v.data_ptr(), x_a.data_ptr(), p_f.data_ptr(),
                          p_out.data_ptr(), v_out.data_ptr(), a_out.data_ptr(), lT_next.data_ptr(), status.data_ptr(),
                          info.data_ptr(), stream)
-        if G > 1:   # the per-step exchange: every rank publishes its agents' new predictions
+        if G > 1 and not emu:   # the per-step exchange: every rank publishes its agents' new predictions
             dist.all_gather_into_tensor(lT_gath.view(-1), lT_next.view(-1))
 
     def barrier():
-        if G > 1:
+        if G > 1 and not emu:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -130,12 +136,12 @@ def main():
     kern_ms, scan_ms, n_launch = dmpc.profile_read2()
     dmpc.profile(False)
     elapsed = t1 - t0
-    if G > 1:
+    if G > 1 and not emu:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    solves_per_step = S * N
+    solves_per_step = S * N if not emu else S * C
     value = solves_per_step * args.steps / elapsed
 
     # secondary workload (reported, not the headline): the reference's primary variant solveSoftDMPCbound
@@ -188,7 +194,7 @@ def main():
                 traffic = None
         line = {
             "metric": "agent-QP solves/sec (K=15 horizon)",
-            "value": value, "unit": "solves/s", "n_gpus": G, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "solves/s", "n_gpus": (1 if emu else G), "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.config}: {C} agents/GPU x {G} GPU(s) per scene, variant {cfg['variant']} "
@@ -236,7 +242,7 @@ def main():
                                     "sample": f"{s_i} scene(s) x {N} agents of the same captured step, oracle/dmpc_oracle.c (dense Goldfarb-Idnani), 1 thread",
                                     "all_cores": {"value": allc, "threads": min(ncpu, N), "host_cpus": ncpu}}
         print(json.dumps(line))
-    if G > 1:
+    if G > 1 and not emu:
         dist.destroy_process_group()
 
 

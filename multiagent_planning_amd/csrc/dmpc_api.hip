@@ -334,9 +334,10 @@ static int tier1_qcap(int variant)
     if (env >= 8) return env < 64 ? (env & ~7) : 64;
     // solveHardDMPC builds rows for every horizon step: working sets routinely approach the 45-variable
     // limit, so a small first tier would only add a second pass; every other variant stays far below 32
-    return variant == DMPC_VAR_HARD ? 46 : 32;
+    return variant == DMPC_VAR_HARD ? 48 : 32;
 }
-static int full_qcap(int variant) { return variant_soft(variant) ? QMAX : 46; }   // hard: 45 variables => <= 45 independent rows
+// hard: 45 variables => at most 45 independent active rows; 48 leaves room for a numerically near-dependent addition
+static int full_qcap(int variant) { return variant_soft(variant) ? QMAX : 48; }
 
 static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_first, int c_count, const double *lT,
                        const double *x_p, const double *x_v, const double *x_a, const double *pf, double *p_out,

@@ -87,6 +87,9 @@ __device__ __forceinline__ int lanes_below(unsigned long long mask, int lane)
 __device__ __forceinline__ double sel3(const double *v, int ax) { return ax == 0 ? v[0] : (ax == 1 ? v[1] : v[2]); }
 
 // constraint types
+#ifndef SCAN_WAVES_PER_SIMD
+#define SCAN_WAVES_PER_SIMD 4
+#endif
 #ifndef SOLVE_WAVES_PER_SIMD
 #define SOLVE_WAVES_PER_SIMD 2
 #endif
@@ -531,8 +534,8 @@ __device__ __forceinline__ void step_body(const StepParams &P)
                 const int jc = jj < C ? jj : C - 1;
                 // hard rows need d < 1; every other variant only needs to know about neighbours inside rmin here
                 if (!chunk_may_hit(r, jc, valid, var == VAR_HARD ? 1.0 : rmin)) continue;
-    #pragma unroll
-                for (int kg = 0; kg < 3; ++kg) {
+    #pragma unroll 1
+                for (int kg = 0; kg < 3; ++kg) {   // not unrolled: keeps the scan's register footprint small
                     double nx[5], ny[5], nz[5];
     #pragma unroll
                     for (int u = 0; u < 5; ++u) {
@@ -774,6 +777,7 @@ __device__ __forceinline__ void step_body(const StepParams &P)
                 }
                 LSYNC();
             };
+            int nlive = 0;                  // live slack variables (instantiated eps): the problem has 45 + nlive variables
             bool fresh = true;              // primal == x(lambda) with refined lambda
             int since_sync = 0;
             for (;;) {
@@ -864,6 +868,7 @@ __device__ __forceinline__ void step_body(const StepParams &P)
                     Cdesc u = make_desc(TY_SLKU, p.idx, L, whi_l, wlo_l, P, soft);
                     if (lane < ((q + 8) & ~7)) L.T[tcol(q) + lane] = (lane == q) ? 1.4142135623730951 : 0.0;   // column + zero padding
                     if (lane == 0) L.r_fl[p.idx] |= (RF_LIVE | RF_SLKU);
+                    nlive++;
                     write_slot(L, lane, q, u, -L.r_st[p.idx]);
                     q++;
                     LSYNC();
@@ -961,7 +966,9 @@ __device__ __forceinline__ void step_body(const StepParams &P)
                     }
                     const double delta = wave_sum(part);
                     const long long tq3 = clock64(); tkC += tq3 - tq2;
-                    const bool dependent = !(delta > 1e-13 * spp);
+                    // more active constraints than variables is impossible: whatever round-off says, a constraint
+                    // picked when the working set already spans all 45 + nlive variables is dependent
+                    const bool dependent = !(delta > 1e-13 * spp) || q >= N3 + nlive;
                     const double t2 = dependent ? INFINITY : vp / delta;
                     // ratio test on the multipliers
                     const double ratio = (lane < q && ri > 0.0) ? (L.s_lam[lane] / ri) : INFINITY;
@@ -1015,6 +1022,7 @@ __device__ __forceinline__ void step_body(const StepParams &P)
                             LSYNC();
                             if (lane == 0) { L.r_fl[didx] = 0; L.r_eps[didx] = 0.0; }
                             remove_slot(L, lane, q, ul, cslot);
+                            nlive--;
                         }
                     }
                     tkG += clock64() - tq4;
@@ -1027,6 +1035,7 @@ __device__ __forceinline__ void step_body(const StepParams &P)
                     LSYNC();
                     if (lane == 0) { L.r_fl[p.idx] = 0; L.r_eps[p.idx] = 0.0; }
                     remove_slot(L, lane, q, ul, cslot);
+                    nlive--;
                 }
                 if (((++since_sync) & 31) == 0) primal_fast();   // periodic re-sync with x(lambda)
             }
@@ -1104,7 +1113,7 @@ __device__ __forceinline__ void step_body(const StepParams &P)
     }
 }
 
-__global__ __launch_bounds__(64, 2) void dmpc_scan_kernel(StepParams P) { step_body<0>(P); }
+__global__ __launch_bounds__(64, SCAN_WAVES_PER_SIMD) void dmpc_scan_kernel(StepParams P) { step_body<0>(P); }
 __global__ __launch_bounds__(64, SOLVE_WAVES_PER_SIMD) void dmpc_solve_kernel(StepParams P) { step_body<1>(P); }
 
 // --------------------------------------------------------------------------------------------

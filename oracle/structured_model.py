@@ -272,7 +272,7 @@ def solve_structured(Tbl, K, h, po, vo, ao, pf, alim, pmin, pmax, rows, stats=No
             cleanup(p.idx if p.typ == COLL else -1)
     a, w, eps = primal()
     if stats is not None:
-        stats.append(dict(iters=iters, maxq=maxq, nref=nrefine, infeasible=False, nact=len(W)))
+        stats.append(dict(iters=iters, maxq=maxq, nref=nrefine, infeasible=False, nact=len(W), Wfinal=[(c.typ, c.idx) for c in W], a_unc=a_unc.reshape(-1).copy()))
     return 0, a.reshape(-1), eps
 
 
