@@ -137,3 +137,28 @@ def test_transition_batch_matches_host_loop_and_oracle_outcomes():
                 done[s], used[s] = True, k + 1
     assert np.array_equal(res["K_T_used"], used) and np.array_equal(res["scene_status"], sst)
     assert (res["scene_status"] == 1).any()   # at least one scene runs to its goal
+
+
+def test_transition_outcomes_n20():
+    """Outcome equivalence (SURVEY.md App. C parity protocol item 4): on sparse 20-agent scenes every transition
+    reaches its goals within error_tol, never leaves the workspace, and keeps the ellipsoidal separation
+    >= rmin - 0.05 at every MPC knot (the reference's acceptance tests, failure_rate.m:125,170-181)."""
+    cfg = dict(wl.CONFIGS["C4"])
+    N, S = 20, 6
+    kw = wl.solver_kwargs(cfg, N)
+    po, pf = wl.make_scenes(cfg, S, N, wl.SEED0 + 20)
+    res = mp.Dmpc("bound", **kw).transition(po, pf, 151, cfg["error_tol"])
+    e1 = np.array([1, 1, 1 / cfg["c"]])
+    assert np.all(res["scene_status"] == 1)
+    for s in range(S):
+        KT = int(res["K_T_used"][s])
+        pk = res["pk"][s][:, :KT]
+        assert 30 < KT < 151
+        assert np.linalg.norm(pk[:, -1] - pf[s], axis=1).max() < cfg["error_tol"]
+        assert np.all(pk >= np.array(kw["pmin"]) - 0.05) and np.all(pk <= np.array(kw["pmax"]) + 0.05)
+        assert np.abs(res["ak"][s][:, :KT]).max() <= cfg["alim"] + 1e-9
+        d = np.sqrt((((pk[:, None] - pk[None]) * e1) ** 2).sum(-1)) + 10 * np.eye(N)[:, :, None]
+        assert d.min() > cfg["rmin"] - 0.05
+        # recorded states obey the reference's dynamics identity p_{k+1} = p_k + h v_k + h^2/2 a_{k+1}
+        vk, ak, h = res["vk"][s][:, :KT], res["ak"][s][:, :KT], cfg["h"]
+        assert np.abs(pk[:, 1:] - (pk[:, :-1] + h * vk[:, :-1] + h * h / 2 * ak[:, 1:])).max() < 1e-12
