@@ -372,7 +372,8 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     const size_t lds1 = step_lds_bytes(P.nrmax, soft, q1, 1), lds2 = step_lds_bytes(P.nrmax, soft, q2, 1);
     const size_t ldsmax = lds2 > lds1 ? lds2 : lds1;
     if ((int)ldsmax > ctx->max_lds_set) {
-        HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsmax));
+        HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsmax));
+        HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsmax));
         ctx->max_lds_set = (int)ldsmax;
     }
     dmpc_ctx::Ev ev{nullptr, nullptr, nullptr};
@@ -392,7 +393,8 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     }
     // phase 0: scan + rows
     P.qcap = q1; P.only_flagged = 0; P.qover_bit = two_tier ? ST_QOVER : ST_CAPACITY;
-    hipLaunchKernelGGL(dmpc_scan_kernel, grid, block, lds0, st, P);
+    if (soft) hipLaunchKernelGGL(dmpc_scan_kernel<true>, grid, block, lds0, st, P);
+    else hipLaunchKernelGGL(dmpc_scan_kernel<false>, grid, block, lds0, st, P);
     // heaviest-first launch order for the solve phase (skipped for tiny launches)
     if (S * c_count >= 512 && !ctx->no_lpt) {
         hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, st, S * c_count, (const int *)P.hdr, ctx->order.as<int>());
@@ -400,10 +402,12 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     }
     if (ctx->profile) HIPCHK(ctx, hipEventRecord(ev.t1, st));
     // phase 1, tier 1
-    hipLaunchKernelGGL(dmpc_solve_kernel, grid, block, lds1, st, P);
+    if (soft) hipLaunchKernelGGL(dmpc_solve_kernel<true>, grid, block, lds1, st, P);
+    else hipLaunchKernelGGL(dmpc_solve_kernel<false>, grid, block, lds1, st, P);
     if (two_tier) {   // phase 1, tier 2: only agents flagged ST_QOVER do any work
         P.qcap = q2; P.only_flagged = 1; P.qover_bit = ST_CAPACITY;
-        hipLaunchKernelGGL(dmpc_solve_kernel, grid, block, lds2, st, P);
+        if (soft) hipLaunchKernelGGL(dmpc_solve_kernel<true>, grid, block, lds2, st, P);
+        else hipLaunchKernelGGL(dmpc_solve_kernel<false>, grid, block, lds2, st, P);
     }
     HIPCHK(ctx, hipGetLastError());
     if (ctx->profile) {
@@ -617,7 +621,8 @@ extern "C" int dmpc_rows_one(dmpc_ctx *ctx, int N, int n, const double *l, const
     const size_t per = (size_t)P.nrmax * (soft ? 7 : 4);
     if (ctx->rowbuf.ensure(per * 8) || ctx->rowkc.ensure((size_t)P.nrmax * 4) || ctx->hdr.ensure(32)) FAIL(ctx, "device allocation failed");
     P.rowbuf = ctx->rowbuf.as<double>(); P.rowkc = ctx->rowkc.as<int>(); P.hdr = ctx->hdr.as<int>();
-    hipLaunchKernelGGL(dmpc_scan_kernel, dim3(1), dim3(64), step_lds_bytes(P.nrmax, soft, QMAX, 0), st, P);
+    if (soft) hipLaunchKernelGGL(dmpc_scan_kernel<true>, dim3(1), dim3(64), step_lds_bytes(P.nrmax, soft, QMAX, 0), st, P);
+    else hipLaunchKernelGGL(dmpc_scan_kernel<false>, dim3(1), dim3(64), step_lds_bytes(P.nrmax, soft, QMAX, 0), st, P);
     HIPCHK(ctx, hipGetLastError());
     int hdr[8];
     HIPCHK(ctx, hipMemcpyAsync(hdr, ctx->hdr.p, 32, hipMemcpyDeviceToHost, st));

@@ -334,7 +334,7 @@ __device__ __forceinline__ void set_member(const Lds &L, int lane, int ty, int i
 // Splitting the step keeps the solver's register and LDS footprint free of the scan's needs (more
 // resident agents per CU) and lets the solver be re-launched for the few agents that overflow the
 // tier-1 working-set capacity.
-template <int PHASE>
+template <int PHASE, bool SOFT>
 __device__ __forceinline__ void step_body(const StepParams &P)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -355,7 +355,7 @@ __device__ __forceinline__ void step_body(const StepParams &P)
     const int cl = P.c_first + ci;                                     // agent inside chunk g_local
     const int gid = scene * P.c_count + ci;                            // index into the launch's arrays
     const int var = P.variant;
-    const bool soft = (var == VAR_BOUND || var == VAR_BOUND2 || var == VAR_ALL3 || var == VAR_SOFTALL || var == VAR_REPAIR);
+    constexpr bool soft = SOFT;   // slack-carrying variants (bound, bound2, all3, softall, repair) vs hard rows (hard, ondemand, ellip)
 
     const int qcap = P.qcap;
     Lds L;
@@ -1113,8 +1113,10 @@ __device__ __forceinline__ void step_body(const StepParams &P)
     }
 }
 
-__global__ __launch_bounds__(64, SCAN_WAVES_PER_SIMD) void dmpc_scan_kernel(StepParams P) { step_body<0>(P); }
-__global__ __launch_bounds__(64, SOLVE_WAVES_PER_SIMD) void dmpc_solve_kernel(StepParams P) { step_body<1>(P); }
+template <bool SOFT>
+__global__ __launch_bounds__(64, SCAN_WAVES_PER_SIMD) void dmpc_scan_kernel(StepParams P) { step_body<0, SOFT>(P); }
+template <bool SOFT>
+__global__ __launch_bounds__(64, SOLVE_WAVES_PER_SIMD) void dmpc_solve_kernel(StepParams P) { step_body<1, SOFT>(P); }
 
 // --------------------------------------------------------------------------------------------
 // small layout / bookkeeping kernels
