@@ -164,6 +164,26 @@ int dmpc_transition(dmpc_ctx *ctx, int S, int N, const double *po, const double 
                     double error_tol, double *pk, double *vk, double *ak, int32_t *K_T_used,
                     int32_t *scene_status);
 
+/* f-1: the post-checks the reference runs after every transition -- test/failure_rate.m:136-195 (identical
+ * blocks: test/comp_kctr.m:141-205, test/comp_hardsoft2.m:140-204, dmpc/matlab/dmpc_soft_bound.m:152-190):
+ *   r_factor = min_{i,k} min(amax/|a_k|, vmax/|v_k|), h_scaled = h/sqrt(r_factor)       (:138-146)
+ *   rescale  a_k *= r_factor; v,p re-integrated with h_scaled                           (:156-162)
+ *   p(t) = spline(tk, pk, 0:Ts:T) (MATLAB not-a-knot cubic), T = (K_T_used-1) h_scaled  (:149-167)
+ *   violation = any pair with |E1 (p_i - p_j)| < rmin - 0.05 at any sample              (:170-181)
+ *   totdist = sum of sample-to-sample path lengths over all agents                      (:183)
+ *   traj_time = Ts * max_i (1 + last sample index with |p_i - pf_i| >= 0.05)            (:186-194)
+ * pk, vk, ak: [S][N][KT_alloc][3] un-rescaled histories exactly as dmpc_transition returns them, K_T_used[S]
+ * valid columns per scene; pass pk = vk = ak = NULL to use the histories the last dmpc_transition of this
+ * context left resident on the device.  Inputs are not modified.  Any output pointer may be NULL.
+ * scene_mask (optional, [S]): 0 skips a scene (the reference only post-checks trials that stayed feasible and
+ * reached their goals, failure_rate.m:136); skipped scenes report NaN / 0.  A checked scene whose histories are
+ * all zero is an error (MATLAB: h_scaled = 0 makes tk empty and spline() fails).
+ * p_interp (optional): [S][N][ns_alloc][3] interpolated positions (samples >= n_samples[s] are zero). */
+int dmpc_postcheck(dmpc_ctx *ctx, int S, int N, int KT_alloc, const int32_t *K_T_used, const int32_t *scene_mask,
+                   const double *pk, const double *vk, const double *ak, const double *pf, double vmax, double amax, double Ts,
+                   double *r_factor, double *h_scaled, int32_t *n_samples, double *min_dist, int32_t *violation,
+                   double *totdist, double *traj_time, double *p_interp, int ns_alloc);
+
 /* number of agent-QP solves launched by this context so far (for throughput accounting) */
 int64_t dmpc_solve_count(const dmpc_ctx *ctx);
 

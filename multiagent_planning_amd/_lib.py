@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "dmpc_create", "dmpc_destroy", "dmpc_last_error", "dmpc_set_params", "dmpc_model_matrices",
     "dmpc_posvel_matrix", "dmpc_init_batch", "dmpc_step_batch", "dmpc_solve_one", "dmpc_step_device",
     "dmpc_table_from_rows_device", "dmpc_advance_device", "dmpc_transition", "dmpc_solve_count",
-    "dmpc_profile", "dmpc_profile_read", "dmpc_profile_read2", "dmpc_rows_one",
+    "dmpc_profile", "dmpc_profile_read", "dmpc_profile_read2", "dmpc_rows_one", "dmpc_postcheck",
 ]
 
 
@@ -79,6 +79,8 @@ def load():
     L.dmpc_table_from_rows_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]
     L.dmpc_advance_device.argtypes = [vp, C.c_int] + [vp] * 8
     L.dmpc_transition.argtypes = [vp, C.c_int, C.c_int, dp, dp, C.c_int, C.c_double, dp, dp, dp, ip, ip]
+    L.dmpc_postcheck.argtypes = [vp, C.c_int, C.c_int, C.c_int, ip, ip, dp, dp, dp, dp, C.c_double, C.c_double, C.c_double,
+                                 dp, dp, ip, dp, ip, dp, dp, dp, C.c_int]
     L.dmpc_solve_count.restype = C.c_int64
     L.dmpc_solve_count.argtypes = [vp]
     L.dmpc_profile.argtypes = [vp, C.c_int]
@@ -214,6 +216,37 @@ class Dmpc:
         self._chk(self._L.dmpc_transition(self._ctx, S, N, _dp(po), _dp(pf), int(K_T_max), float(error_tol), _dp(pk), _dp(vk),
                                           _dp(ak), _ip(used), _ip(sst)))
         return dict(pk=pk, vk=vk, ak=ak, K_T_used=used, scene_status=sst)
+
+    def postcheck(self, K_T_used, pf, pk=None, vk=None, ak=None, KT_alloc=None, vmax=2.0, amax=1.0, Ts=0.01, interp=False,
+                  mask=None):
+        """failure_rate.m:136-195 for S scenes.  pk/vk/ak [S,N,KT_alloc,3] (or [N,KT,3]); None: use the histories the
+        last transition() left on the device (then KT_alloc = its K_T_max)."""
+        pf = _f(pf)
+        shp = pf.shape[:-1]
+        S, N = (1, shp[0]) if len(shp) == 1 else shp
+        used = np.ascontiguousarray(np.atleast_1d(K_T_used), dtype=np.int32)
+        if pk is not None:
+            pk, vk, ak = _f(pk), _f(vk), _f(ak)
+            KT_alloc = pk.shape[-2]
+        assert KT_alloc is not None
+        out = dict(r_factor=np.zeros(S), h_scaled=np.zeros(S), n_samples=np.zeros(S, dtype=np.int32), min_dist=np.zeros(S),
+                   violation=np.zeros(S, dtype=np.int32), totdist=np.zeros(S), traj_time=np.zeros(S))
+        ns_alloc, p_i = 0, None
+        if interp:   # upper bound of the sample count: r_factor is not known yet, so run once without and size from it
+            pre = self.postcheck(K_T_used, pf, pk, vk, ak, KT_alloc, vmax, amax, Ts, False, mask)
+            ns_alloc = max(int(pre["n_samples"].max()), 1)
+            p_i = np.zeros((S, N, ns_alloc, 3))
+        nul = C.POINTER(C.c_double)()
+        msk = None if mask is None else np.ascontiguousarray(np.atleast_1d(mask), dtype=np.int32)
+        self._chk(self._L.dmpc_postcheck(self._ctx, S, N, int(KT_alloc), _ip(used),
+                                         _ip(msk) if msk is not None else C.POINTER(C.c_int32)(), _dp(pk) if pk is not None else nul,
+                                         _dp(vk) if pk is not None else nul, _dp(ak) if pk is not None else nul, _dp(pf),
+                                         float(vmax), float(amax), float(Ts), _dp(out["r_factor"]), _dp(out["h_scaled"]),
+                                         _ip(out["n_samples"]), _dp(out["min_dist"]), _ip(out["violation"]), _dp(out["totdist"]),
+                                         _dp(out["traj_time"]), _dp(p_i) if p_i is not None else nul, ns_alloc))
+        if p_i is not None:
+            out["p"] = p_i
+        return out
 
     # ---- device-pointer entry points (torch tensors: pass t.data_ptr()) ------------------------
     def step_device(self, S, G, Cn, g_local, lT, x_p, x_v, x_a, pf, p_out, v_out, a_out, lT_next, status, info, stream=0):

@@ -16,7 +16,8 @@
 #include "../../include/dmpc_hip.h"
 #include "dmpc_device.h"
 
-#include "dmpc_kernels.hip"   // single translation unit: kernels + host ABI
+#include "dmpc_kernels.hip"
+#include "dmpc_postcheck.hip"   // single translation unit: kernels + host ABI
 
 using namespace dmpc;
 
@@ -55,6 +56,8 @@ struct dmpc_ctx {
     int no_lpt = getenv("DMPC_NO_LPT") ? 1 : 0;   // tuning: disable the heaviest-first solve order
     int single_tier = 0;         // 1: solve with the full working-set capacity in one launch
     DevBuf rows, lT, lT2, xp, xv, xa, pf, po, pout, vout, aout, status, info, hist_p, hist_v, hist_a, flags;
+    int hist_S = 0, hist_N = 0, hist_KT = 0;   // shape of the histories left resident by the last dmpc_transition
+    DevBuf pc_p, pc_v, pc_a, pc_M, pc_w, pc_scene, pc_agent, pc_interp;   // post-check work buffers
     // profiling
     int profile = 0;
     double *dbg = nullptr; int dbg_agent = -1, dbg_cap = 0;   // development trace (dmpc_debug_trace)
@@ -745,5 +748,124 @@ extern "C" int dmpc_transition(dmpc_ctx *ctx, int S, int N, const double *po, co
     HIPCHK(ctx, hipMemcpyAsync(vk, ctx->hist_v.p, hist, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipMemcpyAsync(ak, ctx->hist_a.p, hist, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
+    ctx->hist_S = S; ctx->hist_N = N; ctx->hist_KT = K_T_max;
+    return 0;
+}
+
+// post-checks of S finished transitions (failure_rate.m:136-195): rescale, 100 Hz not-a-knot spline, pairwise
+// ellipsoidal collision check, path length, trajectory time.  pk == NULL: use the histories dmpc_transition left
+// resident on the device (no PCIe round trip).
+extern "C" int dmpc_postcheck(dmpc_ctx *ctx, int S, int N, int KT_alloc, const int32_t *K_T_used, const int32_t *scene_mask,
+                              const double *pk, const double *vk, const double *ak, const double *pf, double vmax, double amax, double Ts,
+                              double *r_factor, double *h_scaled, int32_t *n_samples, double *min_dist,
+                              int32_t *violation, double *totdist, double *traj_time, double *p_interp, int ns_alloc)
+{
+    if (!ctx) { g_err = "dmpc_postcheck: ctx is NULL"; return -1; }
+    if (S < 1 || N < 1 || KT_alloc < 2 || !K_T_used || !pf || !(vmax > 0) || !(amax > 0) || !(Ts > 0))
+        FAIL(ctx, "dmpc_postcheck: bad arguments");
+    if (N > 2048) FAIL(ctx, "dmpc_postcheck: at most 2048 agents per scene");
+    std::vector<int32_t> kt(S);
+    for (int s = 0; s < S; ++s) {
+        const bool on = !scene_mask || scene_mask[s];
+        if (on && (K_T_used[s] < 2 || K_T_used[s] > KT_alloc)) FAIL(ctx, "dmpc_postcheck: K_T_used out of range");
+        kt[s] = on ? K_T_used[s] : 0;   // masked scenes (aborted trials, failure_rate.m:136) are skipped by every kernel
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const size_t A = (size_t)S * N, hist = A * (size_t)KT_alloc * 24;
+    if (ctx->pc_p.ensure(hist) || ctx->pc_v.ensure(hist) || ctx->pc_a.ensure(hist) || ctx->pc_M.ensure(hist) ||
+        ctx->pc_w.ensure(hist) || ctx->pc_scene.ensure((size_t)S * 64) || ctx->pc_agent.ensure(A * 16) || ctx->pf.ensure(A * 24))
+        FAIL(ctx, "device allocation failed");
+    if (pk) {
+        if (!vk || !ak) FAIL(ctx, "dmpc_postcheck: vk/ak missing");
+        HIPCHK(ctx, hipMemcpyAsync(ctx->pc_p.p, pk, hist, hipMemcpyHostToDevice, st));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->pc_v.p, vk, hist, hipMemcpyHostToDevice, st));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->pc_a.p, ak, hist, hipMemcpyHostToDevice, st));
+    } else {
+        if (ctx->hist_S != S || ctx->hist_N != N || ctx->hist_KT != KT_alloc)
+            FAIL(ctx, "dmpc_postcheck: no resident histories of this shape (run dmpc_transition first or pass pk/vk/ak)");
+        HIPCHK(ctx, hipMemcpyAsync(ctx->pc_p.p, ctx->hist_p.p, hist, hipMemcpyDeviceToDevice, st));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->pc_v.p, ctx->hist_v.p, hist, hipMemcpyDeviceToDevice, st));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->pc_a.p, ctx->hist_a.p, hist, hipMemcpyDeviceToDevice, st));
+    }
+    HIPCHK(ctx, hipMemcpyAsync(ctx->pf.p, pf, A * 24, hipMemcpyHostToDevice, st));
+    // per-scene scalars: [0] kt_used(int) [1] rf [2] hs [3] ns(int) [4] mind2(u64) [5] totdist [6] traj_time
+    char *sc = ctx->pc_scene.as<char>();
+    int *d_kt = (int *)sc;
+    double *d_rf = (double *)(sc + (size_t)S * 8), *d_hs = (double *)(sc + (size_t)S * 16);
+    int *d_ns = (int *)(sc + (size_t)S * 24);
+    unsigned long long *d_min = (unsigned long long *)(sc + (size_t)S * 32);
+    double *d_tot = (double *)(sc + (size_t)S * 40), *d_tt = (double *)(sc + (size_t)S * 48);
+    HIPCHK(ctx, hipMemcpyAsync(d_kt, kt.data(), (size_t)S * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemsetAsync(d_min, 0x7f, (size_t)S * 8, st));   // 0x7f7f... = a huge finite double
+    double *dp = ctx->pc_p.as<double>(), *dv = ctx->pc_v.as<double>(), *da = ctx->pc_a.as<double>();
+    hipLaunchKernelGGL(pc::rfactor_kernel, dim3((unsigned)S), dim3(256), 0, st, N, KT_alloc, (const int *)d_kt, (const double *)dv,
+                       (const double *)da, vmax, amax, d_rf);
+    std::vector<double> rf(S), hs(S), md(S), tot(S), tt(S);
+    std::vector<int32_t> ns(S);
+    HIPCHK(ctx, hipMemcpyAsync(rf.data(), d_rf, (size_t)S * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    int ns_max = 0;
+    for (int s = 0; s < S; ++s) {
+        if (!kt[s]) { rf[s] = hs[s] = NAN; ns[s] = 0; continue; }
+        if (!(std::isfinite(rf[s]) && rf[s] > 0))   // MATLAB: h_scaled = 0, tk = 0:0:T is empty and spline() errors
+            FAIL(ctx, "dmpc_postcheck: degenerate r_factor (all-zero or non-finite histories)");
+        hs[s] = ctx->prm.h / std::sqrt(rf[s]);                                   // failure_rate.m:146
+        const double T = (kt[s] - 1) * hs[s];                              // :149
+        ns[s] = (std::isfinite(T) && T / Ts < 5e7) ? (int)std::floor(T / Ts + 1e-10) + 1 : -1;   // :152
+        if (ns[s] < 1) FAIL(ctx, "dmpc_postcheck: degenerate r_factor (all-zero or non-finite histories)");
+        ns_max = std::max(ns_max, (int)ns[s]);
+    }
+    HIPCHK(ctx, hipMemcpyAsync(d_hs, hs.data(), (size_t)S * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(d_ns, ns.data(), (size_t)S * 4, hipMemcpyHostToDevice, st));
+    const unsigned b3 = (unsigned)((A * 3 + 255) / 256);
+    hipLaunchKernelGGL(pc::rescale_kernel, dim3(b3), dim3(256), 0, st, S, N, KT_alloc, (const int *)d_kt, (const double *)d_rf,
+                       (const double *)d_hs, dp, dv, da);
+    hipLaunchKernelGGL(pc::spline_kernel, dim3(b3), dim3(256), 0, st, S, N, KT_alloc, (const int *)d_kt, (const double *)d_hs,
+                       (const double *)dp, ctx->pc_M.as<double>(), ctx->pc_w.as<double>());
+    double *d_interp = nullptr;
+    if (p_interp) {
+        if (ns_alloc < 1) FAIL(ctx, "dmpc_postcheck: ns_alloc must be positive with p_interp");
+        if (ctx->pc_interp.ensure(A * (size_t)ns_alloc * 24)) FAIL(ctx, "device allocation failed");
+        d_interp = ctx->pc_interp.as<double>();
+        HIPCHK(ctx, hipMemsetAsync(d_interp, 0, A * (size_t)ns_alloc * 24, st));
+    }
+    if (ns_max > 0)
+    hipLaunchKernelGGL(pc::pairdist_kernel, dim3((unsigned)((ns_max + PC_SAMPLES_PER_BLOCK - 1) / PC_SAMPLES_PER_BLOCK), (unsigned)S),
+                       dim3(256), (size_t)N * 24, st, N, KT_alloc, (const int *)d_kt, (const double *)d_hs, (const int *)d_ns, Ts,
+                       1.0 / ctx->prm.c, (const double *)dp, (const double *)ctx->pc_M.as<double>(), d_min, d_interp, ns_alloc);
+    double *d_dist = ctx->pc_agent.as<double>();
+    int *d_tidx = (int *)(ctx->pc_agent.as<char>() + A * 8);
+    hipLaunchKernelGGL(pc::path_kernel, dim3((unsigned)((A + 63) / 64)), dim3(64), 0, st, S, N, KT_alloc, (const int *)d_kt,
+                       (const double *)d_hs, (const int *)d_ns, Ts, (const double *)dp, (const double *)ctx->pc_M.as<double>(),
+                       (const double *)ctx->pf.as<double>(), d_dist, d_tidx);
+    hipLaunchKernelGGL(pc::finish_kernel, dim3((unsigned)S), dim3(256), 0, st, N, (const double *)d_dist, (const int *)d_tidx, Ts,
+                       d_tot, d_tt);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(md.data(), d_min, (size_t)S * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(tot.data(), d_tot, (size_t)S * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(tt.data(), d_tt, (size_t)S * 8, hipMemcpyDeviceToHost, st));
+    if (p_interp) HIPCHK(ctx, hipMemcpyAsync(p_interp, d_interp, A * (size_t)ns_alloc * 24, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    for (int s = 0; s < S; ++s) {
+        if (!kt[s]) {
+            if (r_factor) r_factor[s] = NAN;
+            if (h_scaled) h_scaled[s] = NAN;
+            if (n_samples) n_samples[s] = 0;
+            if (min_dist) min_dist[s] = NAN;
+            if (violation) violation[s] = 0;
+            if (totdist) totdist[s] = NAN;
+            if (traj_time) traj_time[s] = NAN;
+            continue;
+        }
+        const double d = (N > 1) ? std::sqrt(md[s]) : INFINITY;
+        if (r_factor) r_factor[s] = rf[s];
+        if (h_scaled) h_scaled[s] = hs[s];
+        if (n_samples) n_samples[s] = ns[s];
+        if (min_dist) min_dist[s] = d;
+        if (violation) violation[s] = d < ctx->prm.rmin - 0.05;                  // failure_rate.m:175
+        if (totdist) totdist[s] = tot[s];
+        if (traj_time) traj_time[s] = tt[s];
+    }
     return 0;
 }

@@ -46,6 +46,26 @@ def run_transition(dmpc, po, pf, K_T_max, error_tol=0.01):
     return dmpc.transition(po, pf, K_T_max, error_tol)
 
 
+def run_trial(dmpc, po, pf, K_T_max, error_tol=0.01, vmax=2.0, amax=1.0, Ts=0.01):
+    """One trial of the reference's test scripts for S scenes (test/failure_rate.m:99-197): the transition loop,
+    then -- for scenes that stayed feasible and reached their goals -- the post-checks, which read the histories
+    the transition left on the device.  `success` is failure_rate.m:196
+    (`feasible && ~failed_goal && ~violation`); t/totdist/traj_time are NaN for failed scenes (:197-201)."""
+    tr = dmpc.transition(po, pf, K_T_max, error_tol)
+    S = tr["K_T_used"].shape[0]
+    feasible = tr["scene_status"] == 1
+    reached = feasible & (np.linalg.norm(tr["pk"][np.arange(S), :, tr["K_T_used"] - 1] - np.asarray(pf).reshape(S, -1, 3),
+                                         axis=-1) < error_tol).all(-1)                     # ReachedGoal.m
+    out = dict(tr, feasible=feasible, failed_goal=feasible & ~reached, violation=np.zeros(S, dtype=np.int32),
+               totdist=np.full(S, np.nan), traj_time=np.full(S, np.nan), r_factor=np.full(S, np.nan))
+    if reached.any():
+        pc = dmpc.postcheck(tr["K_T_used"], pf, KT_alloc=K_T_max, vmax=vmax, amax=amax, Ts=Ts, mask=reached)
+        for k in ("violation", "totdist", "traj_time", "r_factor"):
+            out[k] = pc[k]
+    out["success"] = feasible & reached & (out["violation"] == 0)
+    return out
+
+
 class ShardedStepper:
     """One rank's view of the sharded MPC step.
 

@@ -6,6 +6,7 @@
 // One gateway, dispatched on a command string, keeps ONE persistent context per parameter set:
 //   [p,v,a,status,info] = dmpc_mex('solve_one', params, l, n, po, vo, ao, pf)
 //   [P,V,A,status,info] = dmpc_mex('step_batch', params, l, x_p, x_v, x_a, pf)
+//   [r_factor,h_scaled,violation,totdist,traj_time,p] = dmpc_mex('postcheck', params, pk, vk, ak, pf, vmax, amax, Ts)
 //   [Lambda,Av,A0,Delta] = dmpc_mex('model_matrices', params)
 // `params` is a struct with the fields of dmpc_params (variant as the DMPC_VAR_* integer).
 // The signature-preserving wrappers (solveSoftDMPCbound.m, ...) in this directory call 'solve_one'
@@ -107,6 +108,34 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
                             mxGetPr(plhs[0]), mxGetPr(v), mxGetPr(a), (int32_t *)mxGetData(st), (int32_t *)mxGetData(inf)))
             mexErrMsgIdAndTxt("dmpc:step", "%s", dmpc_last_error(ctx));
         if (nlhs > 1) plhs[1] = v; if (nlhs > 2) plhs[2] = a; if (nlhs > 3) plhs[3] = st; if (nlhs > 4) plhs[4] = inf;
+        return;
+    }
+    if (!std::strcmp(cmd, "postcheck")) {   // failure_rate.m:136-195 for one trial
+        need(nrhs == 9, "postcheck: (cmd, params, pk, vk, ak, pf, vmax, amax, Ts)");
+        const mwSize *dh = mxGetDimensions(prhs[2]);
+        need(mxGetNumberOfDimensions(prhs[2]) == 3 && dh[0] == 3, "pk must be 3 x KT x N");
+        const int KT = (int)dh[1], N = (int)dh[2];
+        for (int i = 3; i < 5; ++i) need(mxGetNumberOfElements(prhs[i]) == (size_t)3 * KT * N, "vk, ak must match pk");
+        need(mxGetNumberOfElements(prhs[5]) == (size_t)3 * N, "pf must be 1 x 3 x N");
+        const double vmax = mxGetScalar(prhs[6]), amax = mxGetScalar(prhs[7]), Ts = mxGetScalar(prhs[8]);
+        double rf = 0, hs = 0, tot = 0, tt = 0;
+        int32_t ns = 0, viol = 0, kt = KT;
+        // MATLAB pk(3,KT,N) column-major IS the [N][KT][3] history layout
+        if (dmpc_postcheck(ctx, 1, N, KT, &kt, nullptr, mxGetPr(prhs[2]), mxGetPr(prhs[3]), mxGetPr(prhs[4]), mxGetPr(prhs[5]), vmax,
+                           amax, Ts, &rf, &hs, &ns, nullptr, &viol, &tot, &tt, nullptr, 0))
+            mexErrMsgIdAndTxt("dmpc:postcheck", "%s", dmpc_last_error(ctx));
+        plhs[0] = mxCreateDoubleScalar(rf);
+        if (nlhs > 1) plhs[1] = mxCreateDoubleScalar(hs);
+        if (nlhs > 2) plhs[2] = mxCreateDoubleScalar((double)viol);
+        if (nlhs > 3) plhs[3] = mxCreateDoubleScalar(tot);
+        if (nlhs > 4) plhs[4] = mxCreateDoubleScalar(tt);
+        if (nlhs > 5) {   // the interpolated positions p(3, length(t), N), second pass now that length(t) is known
+            const mwSize d3[3] = {3, (mwSize)ns, (mwSize)N};
+            plhs[5] = mxCreateNumericArray(3, d3, mxDOUBLE_CLASS, mxREAL);
+            if (dmpc_postcheck(ctx, 1, N, KT, &kt, nullptr, mxGetPr(prhs[2]), mxGetPr(prhs[3]), mxGetPr(prhs[4]), mxGetPr(prhs[5]),
+                               vmax, amax, Ts, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, mxGetPr(plhs[5]), ns))
+                mexErrMsgIdAndTxt("dmpc:postcheck", "%s", dmpc_last_error(ctx));
+        }
         return;
     }
     mexErrMsgIdAndTxt("dmpc:cmd", "unknown command %s", cmd);

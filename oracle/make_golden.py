@@ -79,8 +79,36 @@ def convert(path, name, variant):
     print("wrote", name, "N=%d n_done=%d" % (N, n_fail - 1))
 
 
+def convert_postcheck(path, name, idx, stride=4):
+    """A workspace that ends with a SUCCESSFUL trial still holds that trial's post-check block
+    (comp_kctr.m:274-335): rescaled pk/vk/ak, tk, t, p = spline(tk, pk, t), ak_mod/vk_mod (from the un-rescaled
+    histories), r_factor, h_scaled, time_index, and the trial's totdist / traj_time / violation entries."""
+    m = sio.loadmat(os.path.join(REF, path))
+    N = int(m["N"][0, 0])
+    q, r = int(m["q"][0, 0]) - 1, int(m["r"][0, 0]) - 1
+    p = hist(m["p"])
+    keep = np.unique(np.concatenate([np.arange(0, p.shape[1], stride), [p.shape[1] - 1]]))
+    out = dict(
+        N=N, h=float(m["h"][0, 0]), rmin=float(m["rmin"][0, 0]), c=float(m["c"][0, 0]), Ts=float(m["Ts"][0, 0]),
+        vmax=float(m["vmax"][0, 0]), amax=float(m["amax"][0, 0]),
+        pf=np.ascontiguousarray(m["pf"].reshape(3, N).T),
+        pk=hist(m["pk"]), vk=hist(m["vk"]), ak=hist(m["ak"]),      # rescaled in place by the script
+        tk=m["tk"].ravel(), n_samples=m["t"].size, t_last=float(m["t"].ravel()[-1]),
+        ak_mod=m["ak_mod"], vk_mod=m["vk_mod"], r_factor=float(m["r_factor"][0, 0]), h_scaled=float(m["h_scaled"][0, 0]),
+        p_idx=keep, p=np.ascontiguousarray(p[:, keep]),
+        time_index=m["time_index"].ravel().astype(np.int64),
+        totdist=float(m["totdist_dmpc" + idx][q, r]), traj_time=float(m["traj_time" + idx][q, r]),
+        violation=int(m["violation" + idx][q, r]),
+    )
+    # consistency of the record itself: the saved p reproduces the saved totdist entry
+    assert abs(np.sqrt((np.diff(p, axis=1) ** 2).sum(-1)).sum() - out["totdist"]) < 1e-9
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print("wrote", name, "N=%d KT=%d ns=%d" % (N, out["pk"].shape[1], out["n_samples"]))
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("reference not present; fixtures are already committed")
     convert("data/failure_rate/failure_rate2.mat", "failure_rate2_bound", "bound")
     convert("data/comp_kctr/comp_kctr_3.mat", "comp_kctr_3_bound2", "bound2")
+    convert_postcheck("data/comp_kctr/comp_kctr_2.mat", "postcheck_comp_kctr_2", "2")

@@ -50,3 +50,18 @@ def compare_to_oracle(out, ref, tol=1e-9, what=""):
         assert e <= tol, f"{what}: l_inf({key}) = {e:.3e} > {tol:.1e}"
         assert np.all(o[~solved] == 0.0), f"{what}: outputs of unsolved agents must be zero"
     return errs
+
+
+def unrescale(g):
+    """Recover the un-rescaled MPC histories behind a recorded post-check block: a_k = recorded/r_factor (the last
+    column is never rescaled, failure_rate.m:156), and v, p follow the MPC model x_k = A x_{k-1} + b a_k the
+    histories were produced with (the rescale loop only needs a_k, p_1, v_1; v_k enters r_factor)."""
+    rf, h = float(g["r_factor"]), float(g["h"])
+    a = g["ak"] / rf
+    a[:, -1] = g["ak"][:, -1]
+    p, v = np.zeros_like(a), np.zeros_like(a)
+    p[:, 0], v[:, 0] = g["pk"][:, 0], g["vk"][:, 0]
+    for k in range(1, a.shape[1]):
+        v[:, k] = v[:, k - 1] + h * a[:, k]
+        p[:, k] = p[:, k - 1] + h * v[:, k - 1] + h * h / 2 * a[:, k]
+    return p, v, a

@@ -4,11 +4,13 @@ Two-tier tolerance: Tier A (no slack active) l_inf(p) <= 
 slack active: quadprog itself is only accurate to ~1e-2 there) = our point is feasible and its
 objective is <= the recorded one.
 """
+import os
+
 import numpy as np
 import pytest
 
 from oracle import oracle as orc
-from helpers import load_golden, oracle_params, init_table, step14_inputs
+from helpers import GOLD, unrescale, load_golden, oracle_params, init_table, step14_inputs
 
 CASES = [("failure_rate2_bound", "bound"), ("comp_kctr_3_bound2", "bound2")]
 
@@ -94,3 +96,28 @@ def test_dense_qp_kkt_random():
         assert np.abs(H @ x + f + Cm.T @ lam).max() < 1e-7
         assert (Cm @ x - d).max() < 1e-8 and lam.min() >= 0
         assert np.abs(lam * (Cm @ x - d)).max() < 1e-7
+
+
+def test_postcheck_oracle_pinned_to_matlab_record():
+    """oracle/postcheck.py against a complete recorded post-check block (comp_kctr.m:274-335 in comp_kctr_2.mat):
+    MATLAB's own spline output p, sample count, per-agent time_index, totdist, traj_time, violation."""
+    from oracle import postcheck as PC
+    g = np.load(os.path.join(GOLD, "postcheck_comp_kctr_2.npz"))
+    hs = float(g["h_scaled"])
+    assert abs(hs - float(g["h"]) / np.sqrt(float(g["r_factor"]))) < 1e-15
+    tk, t = PC.sample_times(g["pk"].shape[1], hs, float(g["Ts"]))
+    assert len(t) == int(g["n_samples"]) and abs(t[-1] - float(g["t_last"])) < 1e-12 and np.abs(tk - g["tk"]).max() < 1e-12
+    r = PC.interp_check(g["pk"], hs, g["pf"], float(g["rmin"]), float(g["c"]), float(g["Ts"]))
+    assert np.abs(r["p"][:, g["p_idx"]] - g["p"]).max() < 1e-13          # MATLAB spline() == not-a-knot CubicSpline
+    assert np.array_equal(r["time_index"], g["time_index"])
+    assert abs(r["totdist"] - float(g["totdist"])) < 1e-10 and r["traj_time"] == float(g["traj_time"])
+    assert r["violation"] == int(g["violation"]) == 0
+    # whole pipeline from the un-rescaled histories: scale factor (against the recorded ak_mod / vk_mod), rescale
+    p, v, a = unrescale(g)
+    rf, am, vm = PC.scale_factor(v, a, float(g["vmax"]), float(g["amax"]))
+    assert abs(rf - float(g["r_factor"])) < 1e-14
+    fin = np.isfinite(g["ak_mod"]) & np.isfinite(g["vk_mod"])
+    assert np.abs(am[fin] / g["ak_mod"][fin] - 1).max() < 1e-12 and np.abs(vm[fin] / g["vk_mod"][fin] - 1).max() < 1e-9
+    full = PC.postcheck(p, v, a, g["pf"], float(g["h"]), float(g["rmin"]), float(g["c"]))
+    assert np.abs(full["pk"] - g["pk"]).max() < 1e-12 and np.abs(full["vk"] - g["vk"]).max() < 1e-12
+    assert np.abs(full["p"][:, g["p_idx"]] - g["p"]).max() < 1e-11 and full["n_samples"] == int(g["n_samples"])
