@@ -21,6 +21,8 @@ import time
 
 import numpy as np
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: required by RCCL on this driver
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -81,11 +83,16 @@ def main():
     emu = args.emulate_gpus if (world == 1 and args.emulate_gpus > 1) else 0
     if emu:
         G = emu
+    # functional check of the multi-rank path on a box with ONE GPU (tests only, never a reported number): all ranks
+    # share cuda:0 and the exchange is staged through gloo
+    share = bool(os.environ.get("DMPC_BENCH_SHARE_GPU")) and world > 1
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if G > 1 and not emu:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=G)
+        dist.init_process_group("gloo" if share else "nccl", rank=rank, world_size=G)
 
     cfg = wl.CONFIGS[args.config]
     C = args.agents_per_gpu
@@ -117,7 +124,13 @@ def main():
                          p_out.data_ptr(), v_out.data_ptr(), a_out.data_ptr(), lT_next.data_ptr(), status.data_ptr(),
                          info.data_ptr(), stream)
         if G > 1 and not emu:   # the per-step exchange: every rank publishes its agents' new predictions
-            dist.all_gather_into_tensor(lT_gath.view(-1), lT_next.view(-1))
+            if share:
+                h_in = lT_next.cpu()
+                h_out = torch.empty((G,) + tuple(h_in.shape), dtype=h_in.dtype)
+                dist.all_gather_into_tensor(h_out.view(-1), h_in.view(-1))
+                lT_gath.copy_(h_out)
+            else:
+                dist.all_gather_into_tensor(lT_gath.view(-1), lT_next.view(-1))
 
     def barrier():
         if G > 1 and not emu:
@@ -137,9 +150,17 @@ def main():
     dmpc.profile(False)
     elapsed = t1 - t0
     if G > 1 and not emu:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # outside the timed region: the gathered table is the same on every rank and holds this rank's chunk in its slot
+    exchange_ok = None
+    if G > 1 and not emu:
+        ck = lT_gath.view(torch.int64).sum(dtype=torch.int64)    # bit-pattern checksum
+        ck = torch.stack([ck, -ck]).to("cpu" if share else dev)
+        dist.all_reduce(ck, op=dist.ReduceOp.MAX)
+        exchange_ok = bool(torch.equal(lT_gath[rank], lT_next)) and int(ck[0].item()) == -int(ck[1].item())
 
     solves_per_step = S * N if not emu else S * C
     value = solves_per_step * args.steps / elapsed
@@ -213,13 +234,14 @@ def main():
             "metric": "agent-QP solves/sec (K=15 horizon)",
             "value": value, "unit": "solves/s", "n_gpus": (1 if emu else G), "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic" + (" [SHARED-GPU FUNCTIONAL CHECK, not a measurement]" if share else ""),
             "config": {"workload": f"{args.config}: {C} agents/GPU x {G} GPU(s) per scene, variant {cfg['variant']} "
                                    f"(solve{'Hard' if cfg['variant']=='hard' else ''}DMPC), K=15, {S} scenes batched, "
                                    f"steady-state replay of the captured MPC step (requested {args.capture_step}; "
                                    f"{int(alive.sum())}/{S} scenes still alive there)",
                        "agents_per_scene": N, "scenes": S, "solves_per_step": solves_per_step,
-                       "parallelism": f"agents sharded x{G}, all-gather per step" if G > 1 else "single GPU"},
+                       "parallelism": f"agents sharded x{G}, all-gather per step" if G > 1 else "single GPU",
+                       "exchange_verified": exchange_ok},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "dmpc_solve_kernel", "kernel_ms_avg": kern_ms, "launches": n_launch,

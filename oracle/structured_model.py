@@ -18,6 +18,7 @@ import numpy as np
 BOXHI, BOXLO, POSHI, POSLO, COLL, SLKU, SLKL = range(7)
 DEBUG = False
 TRACE = None   # list collecting per-iteration records when set
+ITER_HOOK = None   # callable(a[K,3], f[K,3], W, iters) after every primal update (experiments)
 
 
 class Tables:
@@ -180,6 +181,8 @@ def solve_structured(Tbl, K, h, po, vo, ao, pf, alim, pmin, pmax, rows, stats=No
                     lam[k] = lam_new[k]
                 a, w, eps = primal()
                 nrefine += 1
+        if ITER_HOOK is not None:
+            ITER_HOOK(a, f, W, iters)
         # most violated candidate
         best, bestv = None, tol
         for j in range(n3):
