@@ -137,8 +137,9 @@ int dmpc_rows_one(dmpc_ctx *ctx, int N, int n, const double *l, const double *po
  * The table is in the chunked transposed layout lT[G][S][3K][C]: G chunks (= ranks) of C agents
  * each, N = G*C agents per scene; this call solves the C agents of chunk g_local of every scene
  * against the whole table (the per-step all-gather concatenates the ranks' lT_next chunks).
- * All pointers are DEVICE pointers; `stream` is a hipStream_t (NULL = the context's stream);
- * asynchronous: returns after enqueueing.
+ * All pointers are DEVICE pointers; `stream` is the caller's hipStream_t and is used as given (NULL = HIP's
+ * default stream, which is also PyTorch's default current stream), so the launches are ordered with the caller's
+ * other work on that stream (e.g. the RCCL all-gather of lT_next); asynchronous: returns after enqueueing.
  *   x_p,x_v,x_a,pf : [S][C][3]          p_out,v_out,a_out : [S][C][3K]
  *   lT_next        : [S][3K][C] (this chunk, may be NULL)   status [S][C], info [S][C][8] */
 int dmpc_step_device(dmpc_ctx *ctx, int S, int G, int C, int g_local, const double *lT, const double *x_p,
@@ -183,6 +184,38 @@ int dmpc_postcheck(dmpc_ctx *ctx, int S, int N, int KT_alloc, const int32_t *K_T
                    const double *pk, const double *vk, const double *ak, const double *pf, double vmax, double amax, double Ts,
                    double *r_factor, double *h_scaled, int32_t *n_samples, double *min_dist, int32_t *violation,
                    double *totdist, double *traj_time, double *p_interp, int ns_alloc);
+
+/* f-3: dense collision rows behind the CollConstr / AddCollConstr helpers named in the north star.  All of them
+ * compute, per neighbour j (order = 2, E1 = diag(1,1,1/c), E2 = E1^2):
+ *     dist = |E1 (p - p_j)|,  diff = E2 (p - p_j),  r = dist (rmin - dist + diff.p/dist) - diff.a0,
+ *     Ain(row,:) = -diff_mat * A = -(diff . A(3 k_blk + 1..3, :)),  bin(row) = -r
+ * replacing (file:line)
+ *     dec-iSCP/CollConstr.m:1-24                (k_cmp = k-1, k_blk = k-2, a0 = po; all obstacles of `l`)
+ *     dmpc/matlab/CollConstrSoftDMPC.m:1-32     (k_cmp = k_blk = k-1, a0 = A_initp(3k-2:3k,:)[po;vo]; `violation` mask)
+ *     dmpc/matlab/CollConstrSoftDMPC2.m:8       (k_blk = k-2)     CollConstrHardDMPC.m:19 (all j != n, dist < 1)
+ *     CollConstrHardDMPCOnDemand.m, CollConstrEllipDMPC.m, CollConstrSoftDMPCall.m
+ * l: [N_obs][K][3] (== MATLAB l(3,K,N_obs)); sel: the n_sel 0-based obstacle indices to build rows for, in output
+ * order; k_cmp / k_blk: 0-based horizon column compared / 3-row block of A used; A: a_rows x ncols with element
+ * (i,j) at A[i*a_rs + j*a_cs] (MATLAB column-major: a_rs = 1, a_cs = a_rows); Ain: n_sel x ncols with strides
+ * o_rs / o_cs; bin, dist (optional): [n_sel].  The *_device form takes device pointers and a HIP stream. */
+int dmpc_coll_rows(dmpc_ctx *ctx, int K, int N_obs, int n_sel, const int32_t *sel, const double *l, int k_cmp, int k_blk,
+                   const double *p, const double *a0, double rmin, double c, const double *A, int a_rows, int ncols,
+                   int64_t a_rs, int64_t a_cs, double *Ain, int64_t o_rs, int64_t o_cs, double *bin, double *dist);
+int dmpc_coll_rows_device(dmpc_ctx *ctx, int K, int n_sel, const int32_t *d_sel, const double *d_l, int k_cmp, int k_blk,
+                          const double *p, const double *a0, double rmin, double c, const double *d_A, int64_t a_rs,
+                          int64_t a_cs, int ncols, double *d_Ain, int64_t o_rs, int64_t o_cs, double *d_bin, double *d_dist,
+                          void *stream);
+
+/* cup-SCP/AddCollConstr.m:1-31: the K N(N-1)/2 pairwise rows (pairs i<j in order, k fastest) of the coupled QP
+ *     r = dist (rmin - dist) + diff.(p_i,k - p_j,k) - diff.(po_i - po_j)
+ *     Ain(row,:) = -(diff . A(blk(i,k),:) - diff . A(blk(j,k),:)),  blk(i,k) = rows 3K(i-1)+3(k-1)+1..3;  bin = -r
+ * p: [N][K][3] (== MATLAB p(3,K,N)); po: [N][3]; A: 3KN x ncols (strided as above); Ain: K N(N-1)/2 x ncols. */
+int dmpc_add_coll_constr(dmpc_ctx *ctx, int K, int N, const double *p, const double *po, double rmin, double c,
+                         const double *A, int ncols, int64_t a_rs, int64_t a_cs, double *Ain, int64_t o_rs, int64_t o_cs,
+                         double *bin);
+int dmpc_add_coll_constr_device(dmpc_ctx *ctx, int K, int N, const double *d_p, const double *d_po, double rmin, double c,
+                                const double *d_A, int64_t a_rs, int64_t a_cs, int ncols, double *d_Ain, int64_t o_rs,
+                                int64_t o_cs, double *d_bin, void *stream);
 
 /* number of agent-QP solves launched by this context so far (for throughput accounting) */
 int64_t dmpc_solve_count(const dmpc_ctx *ctx);

@@ -24,6 +24,7 @@ ABI_SYMBOLS = [
     "dmpc_posvel_matrix", "dmpc_init_batch", "dmpc_step_batch", "dmpc_solve_one", "dmpc_step_device",
     "dmpc_table_from_rows_device", "dmpc_advance_device", "dmpc_transition", "dmpc_solve_count",
     "dmpc_profile", "dmpc_profile_read", "dmpc_profile_read2", "dmpc_rows_one", "dmpc_postcheck",
+    "dmpc_coll_rows", "dmpc_coll_rows_device", "dmpc_add_coll_constr", "dmpc_add_coll_constr_device",
 ]
 
 
@@ -79,6 +80,14 @@ def load():
     L.dmpc_table_from_rows_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]
     L.dmpc_advance_device.argtypes = [vp, C.c_int] + [vp] * 8
     L.dmpc_transition.argtypes = [vp, C.c_int, C.c_int, dp, dp, C.c_int, C.c_double, dp, dp, dp, ip, ip]
+    i64 = C.c_int64
+    L.dmpc_coll_rows.argtypes = [vp, C.c_int, C.c_int, C.c_int, ip, dp, C.c_int, C.c_int, dp, dp, C.c_double, C.c_double, dp,
+                                 C.c_int, C.c_int, i64, i64, dp, i64, i64, dp, dp]
+    L.dmpc_coll_rows_device.argtypes = [vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, dp, dp, C.c_double, C.c_double, vp, i64, i64,
+                                        C.c_int, vp, i64, i64, vp, vp, vp]
+    L.dmpc_add_coll_constr.argtypes = [vp, C.c_int, C.c_int, dp, dp, C.c_double, C.c_double, dp, C.c_int, i64, i64, dp, i64, i64, dp]
+    L.dmpc_add_coll_constr_device.argtypes = [vp, C.c_int, C.c_int, vp, vp, C.c_double, C.c_double, vp, i64, i64, C.c_int, vp, i64,
+                                              i64, vp, vp]
     L.dmpc_postcheck.argtypes = [vp, C.c_int, C.c_int, C.c_int, ip, ip, dp, dp, dp, dp, C.c_double, C.c_double, C.c_double,
                                  dp, dp, ip, dp, ip, dp, dp, dp, C.c_int]
     L.dmpc_solve_count.restype = C.c_int64
@@ -108,6 +117,12 @@ def _f(a):
 
 def _dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _strided_base(A):
+    """(pointer, row stride, column stride) in elements of a 2-D float64 array with positive strides (C or Fortran order,
+    or a view): the ABI's A[i*rs + j*cs] addressing covers MATLAB's column-major arrays without a copy."""
+    return A.ctypes.data_as(C.POINTER(C.c_double)), A.strides[0] // 8, A.strides[1] // 8
 
 
 def _ip(a):
@@ -247,6 +262,41 @@ class Dmpc:
         if p_i is not None:
             out["p"] = p_i
         return out
+
+    # ---- dense collision rows (CollConstr* / AddCollConstr helpers) --------------------------
+    def coll_rows(self, l, sel, k_cmp, k_blk, p, a0, rmin, c, A):
+        """rows for the obstacles `sel` (0-based) of l [N_obs,K,3] at horizon column k_cmp against block k_blk of A
+        [a_rows, ncols] (any strides).  Returns (Ain [n_sel, ncols], bin [n_sel], dist [n_sel])."""
+        l = _f(l); A = np.asarray(A, dtype=np.float64)
+        N_obs, K = l.shape[0], l.shape[1]
+        sel = np.ascontiguousarray(sel, dtype=np.int32)
+        n_sel, (a_rows, ncols) = len(sel), A.shape
+        if A.strides[0] % 8 or A.strides[1] % 8 or min(A.strides) <= 0:
+            A = np.ascontiguousarray(A)
+        base, rs, cs = _strided_base(A)
+        Ain = np.zeros((n_sel, ncols)); b = np.zeros(n_sel); d = np.zeros(n_sel)
+        self._chk(self._L.dmpc_coll_rows(self._ctx, K, N_obs, n_sel, _ip(sel), _dp(l), int(k_cmp), int(k_blk), _dp(_f(p)), _dp(_f(a0)),
+                                         float(rmin), float(c), base, a_rows, ncols, rs, cs, _dp(Ain), ncols, 1, _dp(b), _dp(d)))
+        return Ain, b, d
+
+    def add_coll_constr(self, p, po, rmin, c, A, out_order="C"):
+        """cup-SCP pairwise rows: p [N,K,3], po [N,3], A [3KN, ncols] -> (Ain [K N(N-1)/2, ncols], bin).
+        out_order: "C" row-major, "F" column-major (MATLAB), "S" generic strides (a padded row-major buffer)."""
+        p, po = _f(p), _f(po); A = np.asarray(A, dtype=np.float64)
+        N, K = p.shape[0], p.shape[1]
+        assert A.shape[0] == 3 * K * N
+        if A.strides[0] % 8 or A.strides[1] % 8 or min(A.strides) <= 0:
+            A = np.ascontiguousarray(A)
+        base, rs, cs = _strided_base(A)
+        nrows, ncols = K * N * (N - 1) // 2, A.shape[1]
+        if out_order == "S":
+            buf = np.zeros((nrows, 2 * ncols + 3)); Ain = buf[:, 1:2 * ncols + 1:2]
+        else:
+            Ain = np.zeros((nrows, ncols), order=out_order)
+        b = np.zeros(nrows)
+        self._chk(self._L.dmpc_add_coll_constr(self._ctx, K, N, _dp(p), _dp(po), float(rmin), float(c), base, ncols, rs, cs,
+                                               Ain.ctypes.data_as(C.POINTER(C.c_double)), Ain.strides[0] // 8, Ain.strides[1] // 8, _dp(b)))
+        return Ain, b
 
     # ---- device-pointer entry points (torch tensors: pass t.data_ptr()) ------------------------
     def step_device(self, S, G, Cn, g_local, lT, x_p, x_v, x_a, pf, p_out, v_out, a_out, lT_next, status, info, stream=0):

@@ -210,3 +210,119 @@ def collision_rows(variant, po, vo, n, h, l, K, rmin, pmin, pmax, alim, Q1, S1, 
     c = 1.0 / float(np.asarray(E1)[2, 2])
     dist = np.sqrt(r["xi"][:, 0] ** 2 + r["xi"][:, 1] ** 2 + (r["xi"][:, 2] * c) ** 2)
     return Ain, r["rhs"].copy(), dist, r["viol_k"], int(bool(r["status"] & ST_COLL))
+
+
+# ---------------------------------------------------------------------------------------------
+# CollConstr* / AddCollConstr: the dense collision rows the reference's helpers return, built on the GPU
+# ---------------------------------------------------------------------------------------------
+def _c_of(E1, E2, order):
+    E1, E2 = np.asarray(E1, float), np.asarray(E2, float)
+    if int(order) != 2:
+        raise NotImplementedError("only order = 2 ellipsoids are supported (the only value the reference's scripts use)")
+    if not (np.allclose(E1, np.diag(np.diag(E1))) and abs(E1[0, 0] - 1) < 1e-15 and abs(E1[1, 1] - 1) < 1e-15
+            and np.allclose(E2, E1 @ E1, rtol=0, atol=1e-15)):
+        raise NotImplementedError("E1 must be diag(1,1,1/c) and E2 = E1^2")
+    return 1.0 / E1[2, 2]
+
+
+def _obst(l):
+    """MATLAB l(3,K,N_obs) -> [N_obs,K,3]."""
+    l = np.asarray(l, float)
+    return np.ascontiguousarray(l.transpose(2, 1, 0)) if l.size else np.zeros((0, 1, 3))
+
+
+_ROWCTX = {}
+
+
+def _rowctx(device=0):
+    if device not in _ROWCTX:
+        _ROWCTX[device] = _lib.Dmpc("bound", device=device)
+    return _ROWCTX[device]
+
+
+def CollConstr(p, po, k, l, Ain, rmin, E1, E2, order):
+    """[Ain_total, bin_total] = CollConstr(p,po,k,l,Ain,rmin,E1,E2,order)   (dec-iSCP/CollConstr.m:1-24):
+    rows of time step k (1-based, >= 2) against every obstacle in l(3,K,N_obs); the non-zero block of diff_mat is
+    block k-1 (`zeros(1,3*(k-2))`, :17) and the rhs uses the agent's own start po (:14)."""
+    lo = _obst(l)
+    N_obs = lo.shape[0] if np.asarray(l).size else 0
+    Ain = np.asarray(Ain, float)
+    if N_obs == 0:
+        return np.zeros((0, Ain.shape[1])), np.zeros((0, 1))
+    c = _c_of(E1, E2, order)
+    A, b, _ = _rowctx().coll_rows(lo, np.arange(N_obs), k - 1, k - 2, np.ravel(p), np.ravel(po), rmin, c, Ain)
+    return A, b[:, None]
+
+
+def _dmpc_rows(p, po, vo, n, k, l, rmin, Ain, A_initp, E1, E2, order, sel, k_ctr):
+    lo = _obst(l)
+    c = _c_of(E1, E2, order)
+    a0 = np.asarray(A_initp, float)[3 * (k_ctr - 1):3 * k_ctr, :] @ np.r_[np.ravel(po), np.ravel(vo)]
+    return _rowctx().coll_rows(lo, sel, k - 1, k_ctr - 1, np.ravel(p), a0, rmin, c, np.asarray(Ain, float))
+
+
+def CollConstrSoftDMPC(p, po, vo, n, k, l, rmin, Ain, A_initp, E1, E2, order, violation):
+    """[Ain_total,bin_total,prev_dist] = CollConstrSoftDMPC(...)   (dmpc/matlab/CollConstrSoftDMPC.m:1-32)."""
+    v = np.ravel(violation).astype(bool)
+    sel = [i for i in range(v.size) if i != n - 1 and v[i]]
+    A, b, d = _dmpc_rows(p, po, vo, n, k, l, rmin, Ain, A_initp, E1, E2, order, sel, k)
+    return _pad(A, b, d, int(v.sum()))
+
+
+def CollConstrSoftDMPC2(p, po, vo, n, k, l, rmin, Ain, A_initp, E1, E2, order, violation):
+    """same with the constraint enforced one step earlier, k_ctr = k-1   (CollConstrSoftDMPC2.m:8)."""
+    v = np.ravel(violation).astype(bool)
+    sel = [i for i in range(v.size) if i != n - 1 and v[i]]
+    A, b, d = _dmpc_rows(p, po, vo, n, k, l, rmin, Ain, A_initp, E1, E2, order, sel, k - 1)
+    return _pad(A, b, d, int(v.sum()))
+
+
+def CollConstrHardDMPCOnDemand(p, po, vo, n, k, l, rmin, Ain, A_initp, E1, E2, order, violation):
+    """[Ain_total,bin_total] = CollConstrHardDMPCOnDemand(...)   (CollConstrHardDMPCOnDemand.m)."""
+    v = np.ravel(violation).astype(bool)
+    sel = [i for i in range(v.size) if i != n - 1 and v[i]]
+    A, b, d = _dmpc_rows(p, po, vo, n, k, l, rmin, Ain, A_initp, E1, E2, order, sel, k)
+    return _pad(A, b, d, int(v.sum()))[:2]
+
+
+def CollConstrHardDMPC(p, po, vo, n, k, l, rmin, Ain, A_initp, E1, E2, order):
+    """[Ain_total,bin_total] = CollConstrHardDMPC(...)   (CollConstrHardDMPC.m:1-36): every j != n closer than 1 (:19);
+    the preallocated N_obs-1 rows that stay unused remain zero, as in the reference."""
+    N_obs = np.asarray(l).shape[2]
+    sel = [i for i in range(N_obs) if i != n - 1]
+    A, b, d = _dmpc_rows(p, po, vo, n, k, l, rmin, Ain, A_initp, E1, E2, order, sel, k)
+    keep = d < 1
+    return _pad(A[keep], b[keep], d[keep], N_obs - 1)[:2]
+
+
+def CollConstrEllipDMPC(p, po, vo, n, k, l, rmin, Ain, A_initp, E1, E2, order):
+    """[Ain_total,bin_total,prev_dist] = CollConstrEllipDMPC(...)   (CollConstrEllipDMPC.m): all j != n."""
+    N_obs = np.asarray(l).shape[2]
+    sel = [i for i in range(N_obs) if i != n - 1]
+    A, b, d = _dmpc_rows(p, po, vo, n, k, l, rmin, Ain, A_initp, E1, E2, order, sel, k)
+    return A, b[:, None], d[:, None]
+
+
+def _pad(A, b, d, nrows):
+    """the reference preallocates `N_violation` rows (zeros) and fills the first idx-1 of them."""
+    Ao, bo, do = np.zeros((nrows, A.shape[1])), np.zeros((nrows, 1)), np.zeros((nrows, 1))
+    m = min(nrows, A.shape[0])
+    Ao[:m], bo[:m, 0], do[:m, 0] = A[:m], b[:m], d[:m]
+    if A.shape[0] > nrows:   # MATLAB grows the arrays when more rows are written than preallocated
+        Ao, bo, do = A, b[:, None], d[:, None]
+    return Ao, bo, do
+
+
+def AddCollConstr(p, po, K, rmin, A, E1, E2, order):
+    """[Ain_total, bin_total] = AddCollConstr(p,po,K,rmin,A,E1,E2,order)   (cup-SCP/AddCollConstr.m:1-31):
+    p(3,K,N) previous trajectories, po(1,3,N); K N(N-1)/2 pairwise rows of the coupled QP over [a_1; ...; a_N]."""
+    p = np.asarray(p, float)
+    N = p.shape[2]
+    c = _c_of(E1, E2, order)
+    A = np.asarray(A, float)
+    if N < 2:
+        return np.zeros((0, A.shape[1])), np.zeros((0, 1))
+    po = np.asarray(po, float)
+    po = np.ascontiguousarray(po[0].T) if po.ndim == 3 else po.reshape(N, 3)      # MATLAB po(1,3,N) or [N,3]
+    Ain, b = _rowctx().add_coll_constr(np.ascontiguousarray(p.transpose(2, 1, 0)), po, rmin, c, A)
+    return Ain, b[:, None]

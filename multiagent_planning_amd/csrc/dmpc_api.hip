@@ -17,7 +17,8 @@
 #include "dmpc_device.h"
 
 #include "dmpc_kernels.hip"
-#include "dmpc_postcheck.hip"   // single translation unit: kernels + host ABI
+#include "dmpc_postcheck.hip"
+#include "dmpc_rowbuild.hip"   // single translation unit: kernels + host ABI
 
 using namespace dmpc;
 
@@ -58,6 +59,7 @@ struct dmpc_ctx {
     DevBuf rows, lT, lT2, xp, xv, xa, pf, po, pout, vout, aout, status, info, hist_p, hist_v, hist_a, flags;
     int hist_S = 0, hist_N = 0, hist_KT = 0;   // shape of the histories left resident by the last dmpc_transition
     DevBuf pc_p, pc_v, pc_a, pc_M, pc_w, pc_scene, pc_agent, pc_interp;   // post-check work buffers
+    DevBuf rb_A, rb_l, rb_sel, rb_out, rb_bin, rb_po;                     // dense row builders (host-pointer entries)
     // profiling
     int profile = 0;
     double *dbg = nullptr; int dbg_agent = -1, dbg_cap = 0;   // development trace (dmpc_debug_trace)
@@ -481,7 +483,7 @@ extern "C" int dmpc_step_device(dmpc_ctx *ctx, int S, int G, int C, int g_local,
     if (!lT || !x_p || !x_v || !x_a || !pf || !p_out || !v_out || !a_out || !status) FAIL(ctx, "dmpc_step_device: NULL pointer");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     return launch_step(ctx, S, G, C, g_local, 0, C, lT, x_p, x_v, x_a, pf, p_out, v_out, a_out, lT_next, status, info,
-                       stream ? (hipStream_t)stream : ctx->stream);
+                       (hipStream_t)stream);
 }
 
 extern "C" int dmpc_table_from_rows_device(dmpc_ctx *ctx, int S, int G, int C, const double *rows, double *lT, void *stream)
@@ -491,7 +493,7 @@ extern "C" int dmpc_table_from_rows_device(dmpc_ctx *ctx, int S, int G, int C, c
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const size_t total = (size_t)S * G * C * N3;
     const unsigned blocks = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-    hipLaunchKernelGGL(table_from_rows_kernel, dim3(blocks), dim3(256), 0, stream ? (hipStream_t)stream : ctx->stream, S, G, C, rows, lT);
+    hipLaunchKernelGGL(table_from_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, S, G, C, rows, lT);
     HIPCHK(ctx, hipGetLastError());
     return 0;
 }
@@ -503,7 +505,7 @@ extern "C" int dmpc_advance_device(dmpc_ctx *ctx, int count, const double *p_out
     if (count < 1 || !p_out || !v_out || !a_out || !status || !x_p || !x_v || !x_a) FAIL(ctx, "dmpc_advance_device: bad arguments");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipLaunchKernelGGL(advance_kernel, dim3((unsigned)((count * 3 + 255) / 256)), dim3(256), 0,
-                       stream ? (hipStream_t)stream : ctx->stream, count, p_out, v_out, a_out, (const int *)status, x_p, x_v, x_a);
+                       (hipStream_t)stream, count, p_out, v_out, a_out, (const int *)status, x_p, x_v, x_a);
     HIPCHK(ctx, hipGetLastError());
     return 0;
 }
@@ -867,5 +869,122 @@ extern "C" int dmpc_postcheck(dmpc_ctx *ctx, int S, int N, int KT_alloc, const i
         if (totdist) totdist[s] = tot[s];
         if (traj_time) traj_time[s] = tt[s];
     }
+    return 0;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// dense collision-row builders (dec-iSCP/CollConstr.m, dmpc/matlab/CollConstr*DMPC.m, cup-SCP/AddCollConstr.m)
+// ---------------------------------------------------------------------------------------------
+static size_t strided_extent(int rows, int cols, int64_t rs, int64_t cs)
+{
+    return (size_t)((rows - 1) * rs + (cols - 1) * cs + 1);
+}
+
+extern "C" int dmpc_coll_rows_device(dmpc_ctx *ctx, int K, int n_sel, const int32_t *d_sel, const double *d_l, int k_cmp, int k_blk,
+                                     const double *p, const double *a0, double rmin, double c, const double *d_A, int64_t a_rs,
+                                     int64_t a_cs, int ncols, double *d_Ain, int64_t o_rs, int64_t o_cs, double *d_bin,
+                                     double *d_dist, void *stream)
+{
+    if (!ctx) { g_err = "dmpc_coll_rows_device: ctx is NULL"; return -1; }
+    if (K < 1 || n_sel < 0 || !p || !a0 || k_cmp < 0 || k_cmp >= K || k_blk < 0 || ncols < 1 || !(c > 0) || !d_A || !d_Ain || !d_bin)
+        FAIL(ctx, "dmpc_coll_rows_device: bad arguments");
+    if (n_sel == 0) return 0;
+    if (!d_sel || !d_l) FAIL(ctx, "dmpc_coll_rows_device: bad arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t tot = (size_t)n_sel * ncols;
+    hipLaunchKernelGGL(rb::coll_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       n_sel, (const int *)d_sel, K, d_l, k_cmp, k_blk, p[0], p[1], p[2], a0[0], a0[1], a0[2], rmin, 1.0 / c, d_A,
+                       (long)a_rs, (long)a_cs, ncols, d_Ain, (long)o_rs, (long)o_cs, d_bin, d_dist);
+    HIPCHK(ctx, hipGetLastError());
+    return 0;
+}
+
+extern "C" int dmpc_coll_rows(dmpc_ctx *ctx, int K, int N_obs, int n_sel, const int32_t *sel, const double *l, int k_cmp, int k_blk,
+                              const double *p, const double *a0, double rmin, double c, const double *A, int a_rows, int ncols,
+                              int64_t a_rs, int64_t a_cs, double *Ain, int64_t o_rs, int64_t o_cs, double *bin, double *dist)
+{
+    if (!ctx) { g_err = "dmpc_coll_rows: ctx is NULL"; return -1; }
+    if (K < 1 || N_obs < 0 || n_sel < 0 || n_sel > N_obs || a_rows < 3 || ncols < 1 || a_rs < 1 || a_cs < 1 || o_rs < 1 || o_cs < 1 ||
+        !A || !Ain || !bin || !p || !a0)
+        FAIL(ctx, "dmpc_coll_rows: bad arguments");
+    if (3 * k_blk + 2 >= a_rows || k_blk < 0) FAIL(ctx, "dmpc_coll_rows: constraint block outside A");
+    if (n_sel == 0) return 0;
+    if (!sel || !l) FAIL(ctx, "dmpc_coll_rows: bad arguments");
+    for (int i = 0; i < n_sel; ++i)
+        if (sel[i] < 0 || sel[i] >= N_obs) FAIL(ctx, "dmpc_coll_rows: obstacle index out of range");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const size_t a_ext = strided_extent(a_rows, ncols, a_rs, a_cs), o_ext = strided_extent(n_sel, ncols, o_rs, o_cs);
+    if (ctx->rb_A.ensure(a_ext * 8) || ctx->rb_l.ensure((size_t)N_obs * K * 24) || ctx->rb_sel.ensure((size_t)n_sel * 4) ||
+        ctx->rb_out.ensure(o_ext * 8) || ctx->rb_bin.ensure((size_t)n_sel * 16))
+        FAIL(ctx, "device allocation failed");
+    HIPCHK(ctx, hipMemcpyAsync(ctx->rb_A.p, A, a_ext * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->rb_l.p, l, (size_t)N_obs * K * 24, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->rb_sel.p, sel, (size_t)n_sel * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemsetAsync(ctx->rb_out.p, 0, o_ext * 8, st));
+    double *d_bin = ctx->rb_bin.as<double>(), *d_dist = d_bin + n_sel;
+    if (dmpc_coll_rows_device(ctx, K, n_sel, ctx->rb_sel.as<int32_t>(), ctx->rb_l.as<double>(), k_cmp, k_blk, p, a0, rmin, c,
+                              ctx->rb_A.as<double>(), a_rs, a_cs, ncols, ctx->rb_out.as<double>(), o_rs, o_cs, d_bin, d_dist, st))
+        return -1;
+    HIPCHK(ctx, hipMemcpyAsync(Ain, ctx->rb_out.p, o_ext * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(bin, d_bin, (size_t)n_sel * 8, hipMemcpyDeviceToHost, st));
+    if (dist) HIPCHK(ctx, hipMemcpyAsync(dist, d_dist, (size_t)n_sel * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    return 0;
+}
+
+extern "C" int dmpc_add_coll_constr_device(dmpc_ctx *ctx, int K, int N, const double *d_p, const double *d_po, double rmin, double c,
+                                           const double *d_A, int64_t a_rs, int64_t a_cs, int ncols, double *d_Ain, int64_t o_rs,
+                                           int64_t o_cs, double *d_bin, void *stream)
+{
+    if (!ctx) { g_err = "dmpc_add_coll_constr_device: ctx is NULL"; return -1; }
+    if (K < 1 || N < 2 || ncols < 1 || !(c > 0) || !d_p || !d_po || !d_A || !d_Ain || !d_bin)
+        FAIL(ctx, "dmpc_add_coll_constr_device: bad arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t nrows = (size_t)K * N * (N - 1) / 2, tot = nrows * (size_t)ncols;
+    if ((tot + 255) / 256 > 0x7fffffffull) FAIL(ctx, "dmpc_add_coll_constr_device: problem too large for one launch");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t pch = ((size_t)N * (N - 1) / 2 + RB_PCH - 1) / RB_PCH;
+    if (o_cs == 1 && K <= 65535 && pch <= 65535) {   // row-major output: (column tile, k, pair chunk) blocks
+        hipLaunchKernelGGL(rb::add_coll_rows_rm_kernel, dim3((unsigned)((ncols + 255) / 256), (unsigned)K, (unsigned)pch), dim3(256), 0, st,
+                           N, K, d_p, d_po, rmin, 1.0 / c, d_A, (long)a_rs, (long)a_cs, ncols, d_Ain, (long)o_rs, d_bin);
+    } else if (o_rs == 1 && (ncols + RB_CCH - 1) / RB_CCH <= 65535) {   // column-major output (MATLAB): row-per-thread
+        hipLaunchKernelGGL(rb::add_coll_rows_cm_kernel, dim3((unsigned)((nrows + 255) / 256), (unsigned)((ncols + RB_CCH - 1) / RB_CCH)),
+                           dim3(256), 0, st, N, K, d_p, d_po, rmin, 1.0 / c, d_A, (long)a_rs, (long)a_cs, ncols, d_Ain, (long)o_cs,
+                           d_bin, nrows);
+    } else {                                // arbitrary strides: one element per thread
+        hipLaunchKernelGGL(rb::add_coll_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, N, K, d_p, d_po, rmin,
+                           1.0 / c, d_A, (long)a_rs, (long)a_cs, ncols, d_Ain, (long)o_rs, (long)o_cs, d_bin, nrows);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return 0;
+}
+
+extern "C" int dmpc_add_coll_constr(dmpc_ctx *ctx, int K, int N, const double *p, const double *po, double rmin, double c,
+                                    const double *A, int ncols, int64_t a_rs, int64_t a_cs, double *Ain, int64_t o_rs, int64_t o_cs,
+                                    double *bin)
+{
+    if (!ctx) { g_err = "dmpc_add_coll_constr: ctx is NULL"; return -1; }
+    if (K < 1 || N < 2 || ncols < 1 || a_rs < 1 || a_cs < 1 || o_rs < 1 || o_cs < 1 || !p || !po || !A || !Ain || !bin)
+        FAIL(ctx, "dmpc_add_coll_constr: bad arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int a_rows = 3 * K * N;
+    const size_t nrows = (size_t)K * N * (N - 1) / 2;
+    const size_t a_ext = strided_extent(a_rows, ncols, a_rs, a_cs);
+    const size_t o_ext = (size_t)((nrows - 1) * o_rs + (size_t)(ncols - 1) * o_cs + 1);
+    if (ctx->rb_A.ensure(a_ext * 8) || ctx->rb_l.ensure((size_t)N * K * 24) || ctx->rb_po.ensure((size_t)N * 24) ||
+        ctx->rb_out.ensure(o_ext * 8) || ctx->rb_bin.ensure(nrows * 8))
+        FAIL(ctx, "device allocation failed");
+    HIPCHK(ctx, hipMemcpyAsync(ctx->rb_A.p, A, a_ext * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->rb_l.p, p, (size_t)N * K * 24, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->rb_po.p, po, (size_t)N * 24, hipMemcpyHostToDevice, st));
+    if (dmpc_add_coll_constr_device(ctx, K, N, ctx->rb_l.as<double>(), ctx->rb_po.as<double>(), rmin, c, ctx->rb_A.as<double>(), a_rs,
+                                    a_cs, ncols, ctx->rb_out.as<double>(), o_rs, o_cs, ctx->rb_bin.as<double>(), st))
+        return -1;
+    HIPCHK(ctx, hipMemcpyAsync(Ain, ctx->rb_out.p, o_ext * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(bin, ctx->rb_bin.p, nrows * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
     return 0;
 }

@@ -1,0 +1,126 @@
+"""GPU: the dense collision-row helpers (CollConstr*, AddCollConstr) through the C ABI against the literal numpy
+restatements of the .m files (oracle/sibling_rows.py)."""
+import numpy as np
+import pytest
+
+import multiagent_planning_amd as mp
+from multiagent_planning_amd import api
+from oracle import sibling_rows as SR
+from oracle import oracle as orc
+from helpers import load_golden
+
+pytestmark = pytest.mark.gpu
+
+C_ = 2.0
+E1 = np.diag([1, 1, 1 / C_]); E2 = np.diag([1, 1, 1 / C_ ** 2])
+
+
+def _scene(rng, N, K):
+    base = rng.uniform(-2, 2, (3, 1, N))
+    return base + np.cumsum(rng.normal(0, 0.08, (3, K, N)), axis=1)
+
+
+def _close(a, b, tol=1e-12):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert np.abs(a - b).max(initial=0.0) <= tol * max(1.0, np.abs(b).max(initial=0.0))
+
+
+def test_CollConstr_dec_iSCP():
+    rng = np.random.default_rng(1)
+    K, N_obs = 20, 9
+    l = _scene(rng, N_obs, K)
+    A = mp.model_matrices(0.2, K)[0]          # getPosMat(h, K)
+    for k in (2, 3, 11, 20):
+        p, po = rng.uniform(-2, 2, 3), rng.uniform(-2, 2, 3)
+        got = api.CollConstr(p, po, k, l, A, 0.5, E1, E2, 2)
+        ref = SR.CollConstr(p, po, k, l, A, 0.5, E1, E2, 2)
+        _close(got[0], ref[0]); _close(got[1], ref[1])
+        # MATLAB-layout operand: a column-major (Fortran-order) A binds through the strides without a copy
+        got_f = api.CollConstr(p, po, k, l, np.asfortranarray(A), 0.5, E1, E2, 2)
+        assert np.array_equal(got_f[0], got[0])
+    e = api.CollConstr(np.zeros(3), np.zeros(3), 2, np.zeros((3, K, 0)), A, 0.5, E1, E2, 2)
+    assert e[0].shape == (0, 3 * K) and e[1].shape == (0, 1)
+    with pytest.raises(NotImplementedError):
+        api.CollConstr(np.zeros(3), np.zeros(3), 2, l, A, 0.5, E1, E2, 4)
+
+
+def test_CollConstr_dmpc_family():
+    rng = np.random.default_rng(2)
+    K, N = 15, 12
+    l = _scene(rng, N, K)
+    Lam, Av, A0, Dl = mp.model_matrices(0.2, K)
+    for n, k in ((1, 1), (5, 4), (12, 15), (3, 2)):
+        p = l[:, k - 1, n - 1].copy()
+        po, vo = rng.uniform(-2, 2, 3), rng.uniform(-1, 1, 3)
+        viol = (rng.random(N) < 0.5).astype(float); viol[n - 1] = 0
+        if viol.sum() == 0:
+            viol[n % N] = 1
+        for name in ("CollConstrSoftDMPC", "CollConstrHardDMPCOnDemand") + (("CollConstrSoftDMPC2",) if k > 1 else ()):
+            got = getattr(api, name)(p, po, vo, n, k, l, 0.35, Lam, A0, E1, E2, 2, viol)
+            ref = getattr(SR, name)(p, po, vo, n, k, l, 0.35, Lam, A0, E1, E2, 2, viol)
+            assert len(got) == len(ref)
+            for g, r in zip(got, ref):
+                _close(g, r)
+        for name in ("CollConstrHardDMPC", "CollConstrEllipDMPC"):
+            got = getattr(api, name)(p, po, vo, n, k, l, 0.35, Lam, A0, E1, E2, 2)
+            ref = getattr(SR, name)(p, po, vo, n, k, l, 0.35, Lam, A0, E1, E2, 2)
+            assert len(got) == len(ref)
+            for g, r in zip(got, ref):
+                _close(g, r)
+
+
+def test_CollConstrSoftDMPC_agrees_with_pinned_solver_rows():
+    """the helper's dense rows equal the rows the (golden-pinned) solver oracle assembles for the same agent."""
+    g, kw = load_golden("failure_rate2_bound")
+    prm = orc.make_params("bound", **kw)
+    Lam, Av, A0, Dl = mp.model_matrices(kw["h"], 15)
+    l3 = g["l"].reshape(-1, 15, 3).transpose(2, 1, 0)
+    E1g = np.diag([1, 1, 1 / kw["c"]]); E2g = E1g @ E1g
+    checked = 0
+    for n in range(1, 60):
+        po, vo = g["pk"][n - 1, 12], g["vk"][n - 1, 12]
+        r = orc.rows_one(prm, g["l"], n - 1, po, vo)
+        if r["nrows"] == 0 or r["status"] & orc.ST_COLL:
+            continue
+        k = int(r["viol_k"])
+        viol, _, near = api.CheckCollSoftDMPC(l3[:, k - 1, n - 1], l3, n, k, E1g, kw["rmin"], 2)
+        A, b, d = api.CollConstrSoftDMPC(l3[:, k - 1, n - 1], po, vo, n, k, l3, kw["rmin"], Lam, A0, E1g, E2g, 2, near)
+        assert A.shape[0] == r["nrows"]
+        assert np.abs(A - r["G"][:r["nrows"], :45]).max() < 1e-12 and np.abs(b[:, 0] - r["b"][:r["nrows"]]).max() < 1e-12
+        checked += 1
+    assert checked >= 3
+
+
+def test_AddCollConstr_cup_SCP():
+    rng = np.random.default_rng(3)
+    for N, K in ((2, 5), (5, 12), (9, 15)):
+        p = _scene(rng, N, K)
+        po = p[:, 0, :].reshape(1, 3, N)                               # MATLAB po(1,3,N)
+        A = np.kron(np.eye(N), mp.model_matrices(0.2, K)[0])          # Atot = kron(eye(N), getPosMat(h,K))
+        got = api.AddCollConstr(p, po, K, 0.5, A, E1, E2, 2)
+        ref = SR.AddCollConstr(p, po[0].T, K, 0.5, A, E1, E2, 2)
+        assert got[0].shape == (K * N * (N - 1) // 2, 3 * K * N)
+        _close(got[0], ref[0]); _close(got[1], ref[1])
+    # a generic (dense, non block-diagonal) A and a column-major operand
+    N, K = 4, 6
+    p = _scene(rng, N, K); po = rng.uniform(-2, 2, (N, 3))
+    A = rng.normal(size=(3 * K * N, 3 * K * N + 7))
+    got = api.AddCollConstr(p, po.T.reshape(1, 3, N), K, 0.4, np.asfortranarray(A), E1, E2, 2)
+    ref = SR.AddCollConstr(p, po, K, 0.4, A, E1, E2, 2)
+    _close(got[0], ref[0]); _close(got[1], ref[1])
+    # the three output layouts (row-major tiles, MATLAB column-major, arbitrary strides) run different kernels
+    d = mp.Dmpc("bound")
+    for N, K in ((4, 6), (23, 17)):
+        p = _scene(rng, N, K); po = rng.uniform(-2, 2, (N, 3))
+        A = rng.normal(size=(3 * K * N, 3 * K * N + 5))
+        ref = SR.AddCollConstr(p, po, K, 0.4, A, E1, E2, 2)
+        for Aop in (A, np.asfortranarray(A)):
+            for layout in "CFS":
+                Ain, b = d.add_coll_constr(np.ascontiguousarray(p.transpose(2, 1, 0)), po, 0.4, C_, Aop, out_order=layout)
+                _close(Ain, ref[0]); _close(b[:, None], ref[1])
+    N, K = 4, 6
+    p = _scene(rng, N, K); po = rng.uniform(-2, 2, (N, 3))
+    A = rng.normal(size=(3 * K * N, 3 * K * N + 7))
+    one = api.AddCollConstr(p[:, :, :1], po[:1].T.reshape(1, 3, 1), K, 0.4, A[:3 * K], E1, E2, 2)
+    assert one[0].shape == (0, A.shape[1])

@@ -121,3 +121,30 @@ def test_postcheck_oracle_pinned_to_matlab_record():
     full = PC.postcheck(p, v, a, g["pf"], float(g["h"]), float(g["rmin"]), float(g["c"]))
     assert np.abs(full["pk"] - g["pk"]).max() < 1e-12 and np.abs(full["vk"] - g["vk"]).max() < 1e-12
     assert np.abs(full["p"][:, g["p_idx"]] - g["p"]).max() < 1e-11 and full["n_samples"] == int(g["n_samples"])
+
+
+def test_collconstr_restatement_agrees_with_pinned_solver_rows():
+    """oracle/sibling_rows.py (literal CollConstrSoftDMPC.m) builds the same dense rows as the golden-pinned solver
+    oracle (orc_rows_one) for the recorded N=200 scene."""
+    from oracle import sibling_rows as SR
+    g, kw = load_golden("failure_rate2_bound")
+    prm = oracle_params("bound", kw)
+    Lam, Av, A0, Dl = orc.model_matrices(kw["h"], 15)
+    l3 = g["l"].reshape(-1, 15, 3).transpose(2, 1, 0)
+    E1 = np.diag([1, 1, 1 / kw["c"]]); E2 = E1 @ E1
+    checked = 0
+    for n in range(1, 80):
+        po, vo = g["pk"][n - 1, 12], g["vk"][n - 1, 12]
+        r = orc.rows_one(prm, g["l"], n - 1, po, vo)
+        if r["nrows"] == 0 or r["status"] & orc.ST_COLL:
+            continue
+        k = int(r["viol_k"])
+        p = l3[:, k - 1, n - 1]
+        d = np.linalg.norm(E1 @ (p[:, None] - l3[:, k - 1, :]), axis=0)
+        near = (d < 3 * kw["rmin"]); near[n - 1] = False           # CheckCollSoftDMPC.m:12
+        A, b, pd = SR.CollConstrSoftDMPC(p, po, vo, n, k, l3, kw["rmin"], Lam, A0, E1, E2, 2, near)
+        assert A.shape[0] == r["nrows"]
+        assert np.abs(A - r["G"][:, :45]).max() < 1e-12 and np.abs(b[:, 0] - r["b"]).max() < 1e-12
+        assert np.abs(pd[:, 0] - r["dist"]).max() < 1e-13
+        checked += 1
+    assert checked >= 3
