@@ -8,6 +8,8 @@
 //   [P,V,A,status,info] = dmpc_mex('step_batch', params, l, x_p, x_v, x_a, pf)
 //   [r_factor,h_scaled,violation,totdist,traj_time,p] = dmpc_mex('postcheck', params, pk, vk, ak, pf, vmax, amax, Ts)
 //   [Lambda,Av,A0,Delta] = dmpc_mex('model_matrices', params)
+//   [Ain,bin,dist] = dmpc_mex('coll_rows', params, l, sel0, k_cmp0, k_blk0, p, a0, rmin, c, A)     (0-based indices)
+//   [Ain,bin]      = dmpc_mex('add_coll_constr', params, p, po, rmin, c, A)
 // `params` is a struct with the fields of dmpc_params (variant as the DMPC_VAR_* integer).
 // The signature-preserving wrappers (solveSoftDMPCbound.m, ...) in this directory call 'solve_one'
 // and convert status bits into the reference's [] + flag conventions.
@@ -136,6 +138,44 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
                                vmax, amax, Ts, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, mxGetPr(plhs[5]), ns))
                 mexErrMsgIdAndTxt("dmpc:postcheck", "%s", dmpc_last_error(ctx));
         }
+        return;
+    }
+    if (!std::strcmp(cmd, "coll_rows")) {   // dec-iSCP/CollConstr.m, dmpc/matlab/CollConstr*DMPC.m
+        need(nrhs == 11, "coll_rows: (cmd, params, l, sel0, k_cmp0, k_blk0, p, a0, rmin, c, A)");
+        const mwSize *dl = mxGetDimensions(prhs[2]);
+        need(mxGetNumberOfDimensions(prhs[2]) >= 2 && dl[0] == 3, "l must be 3 x K x N_obs");
+        const int K = (int)dl[1], N_obs = mxGetNumberOfDimensions(prhs[2]) == 3 ? (int)dl[2] : 1;
+        const int n_sel = (int)mxGetNumberOfElements(prhs[3]);
+        std::string selbuf((size_t)n_sel * sizeof(int32_t) + 1, '\0');
+        int32_t *sel = (int32_t *)&selbuf[0];
+        for (int i = 0; i < n_sel; ++i) sel[i] = (int32_t)mxGetPr(prhs[3])[i];
+        need(mxGetNumberOfElements(prhs[6]) == 3 && mxGetNumberOfElements(prhs[7]) == 3, "p, a0 must have 3 elements");
+        const int a_rows = (int)mxGetM(prhs[10]), ncols = (int)mxGetN(prhs[10]);
+        plhs[0] = mxCreateDoubleMatrix(n_sel, ncols, mxREAL);
+        mxArray *b = mxCreateDoubleMatrix(n_sel, 1, mxREAL), *d = mxCreateDoubleMatrix(n_sel, 1, mxREAL);
+        // column-major operands bind through the strides: A(i,j) at i + j*a_rows, Ain(r,c) at r + c*n_sel
+        if (dmpc_coll_rows(ctx, K, N_obs, n_sel, sel, mxGetPr(prhs[2]), (int)mxGetScalar(prhs[4]), (int)mxGetScalar(prhs[5]),
+                           mxGetPr(prhs[6]), mxGetPr(prhs[7]), mxGetScalar(prhs[8]), mxGetScalar(prhs[9]), mxGetPr(prhs[10]), a_rows,
+                           ncols, 1, a_rows, mxGetPr(plhs[0]), 1, n_sel > 0 ? n_sel : 1, mxGetPr(b), mxGetPr(d)))
+            mexErrMsgIdAndTxt("dmpc:coll_rows", "%s", dmpc_last_error(ctx));
+        if (nlhs > 1) plhs[1] = b; if (nlhs > 2) plhs[2] = d;
+        return;
+    }
+    if (!std::strcmp(cmd, "add_coll_constr")) {   // cup-SCP/AddCollConstr.m
+        need(nrhs == 7, "add_coll_constr: (cmd, params, p, po, rmin, c, A)");
+        const mwSize *dp_ = mxGetDimensions(prhs[2]);
+        need(mxGetNumberOfDimensions(prhs[2]) == 3 && dp_[0] == 3, "p must be 3 x K x N");
+        const int K = (int)dp_[1], N = (int)dp_[2];
+        need(mxGetNumberOfElements(prhs[3]) == (size_t)3 * N, "po must be 1 x 3 x N");
+        need((int)mxGetM(prhs[6]) == 3 * K * N, "A must have 3*K*N rows");
+        const int ncols = (int)mxGetN(prhs[6]);
+        const mwSize nrows = (mwSize)K * N * (N - 1) / 2;
+        plhs[0] = mxCreateDoubleMatrix(nrows, ncols, mxREAL);
+        mxArray *b = mxCreateDoubleMatrix(nrows, 1, mxREAL);
+        if (dmpc_add_coll_constr(ctx, K, N, mxGetPr(prhs[2]), mxGetPr(prhs[3]), mxGetScalar(prhs[4]), mxGetScalar(prhs[5]),
+                                 mxGetPr(prhs[6]), ncols, 1, 3 * K * N, mxGetPr(plhs[0]), 1, (int64_t)nrows, mxGetPr(b)))
+            mexErrMsgIdAndTxt("dmpc:add_coll_constr", "%s", dmpc_last_error(ctx));
+        if (nlhs > 1) plhs[1] = b;
         return;
     }
     mexErrMsgIdAndTxt("dmpc:cmd", "unknown command %s", cmd);
