@@ -4,6 +4,6 @@ assert(order == 2, 'only order = 2 is supported');
 if isempty(l)
     Ain_total = zeros(0,size(Ain,1)); bin_total = zeros(0,1); return
 end
-prm = dmpc_params_struct(0, 0.2, size(l,2), rmin, [0 0 0], [0 0 0], 1, 1000, 100, E1, order, -5e4);   % context only
+prm = dmpc_params_struct(0, 0.2, 15, rmin, [0 0 0], [0 0 0], 1, 1000, 100, E1, order, -5e4);   % context only
 [Ain_total, bin_total] = dmpc_mex('coll_rows', prm, l, 0:size(l,3)-1, k-1, k-2, p(:), po(:), rmin, 1/E1(3,3), Ain);
 end
