@@ -217,6 +217,21 @@ int dmpc_add_coll_constr_device(dmpc_ctx *ctx, int K, int N, const double *d_p, 
                                 const double *d_A, int64_t a_rs, int64_t a_cs, int ncols, double *d_Ain, int64_t o_rs,
                                 int64_t o_cs, double *d_bin, void *stream);
 
+/* f-2: the reference's on-disk result formats (host code, no context needed; return 0 / -1 + dmpc_last_error(NULL)).
+ * dmpc_trajectories2file == DMPC::trajectories2file (dmpc/cpp/dmpc.cpp:2088-2126), the text file
+ * dmpc/cpp_results/read_result.m:4-44 reads: header `N N_cmd h_scaled pmin' pmax'`, then po (3 x N), pf (3 x N_cmd),
+ * then the 3 x T position block of every trajectory, then the velocity blocks, then the acceleration blocks -- each
+ * matrix in Eigen's default stream format (6 significant digits, columns aligned per matrix), byte for byte.
+ * po [N][3], pf [N_cmd][3], pos/vel/acc [N_cmd][T][3] (== MATLAB pk(3,T,N_cmd)). */
+int dmpc_trajectories2file(const char *path, int N, int N_cmd, int T, double h_scaled, const double *pmin,
+                           const double *pmax, const double *po, const double *pf, const double *pos,
+                           const double *vel, const double *acc);
+/* test2file (dmpc/cpp/cluster_test.cpp:9-33; read by dmpc/cpp_results/cluster_test.m): header
+ * `n_cluster n_vehicles n_trials`, the cluster sizes and vehicle counts, then one n_vehicles x n_trials block of
+ * wall times per cluster size.  times [n_cluster][n_vehicles][n_trials]. */
+int dmpc_test2file(const char *path, int n_cluster, int n_vehicles, int n_trials, const double *cluster_size,
+                   const double *num_vehicles, const double *times);
+
 /* number of agent-QP solves launched by this context so far (for throughput accounting) */
 int64_t dmpc_solve_count(const dmpc_ctx *ctx);
 

@@ -25,6 +25,7 @@ ABI_SYMBOLS = [
     "dmpc_table_from_rows_device", "dmpc_advance_device", "dmpc_transition", "dmpc_solve_count",
     "dmpc_profile", "dmpc_profile_read", "dmpc_profile_read2", "dmpc_rows_one", "dmpc_postcheck",
     "dmpc_coll_rows", "dmpc_coll_rows_device", "dmpc_add_coll_constr", "dmpc_add_coll_constr_device",
+    "dmpc_trajectories2file", "dmpc_test2file",
 ]
 
 
@@ -88,6 +89,8 @@ def load():
     L.dmpc_add_coll_constr.argtypes = [vp, C.c_int, C.c_int, dp, dp, C.c_double, C.c_double, dp, C.c_int, i64, i64, dp, i64, i64, dp]
     L.dmpc_add_coll_constr_device.argtypes = [vp, C.c_int, C.c_int, vp, vp, C.c_double, C.c_double, vp, i64, i64, C.c_int, vp, i64,
                                               i64, vp, vp]
+    L.dmpc_trajectories2file.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_double, dp, dp, dp, dp, dp, dp, dp]
+    L.dmpc_test2file.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, dp, dp, dp]
     L.dmpc_postcheck.argtypes = [vp, C.c_int, C.c_int, C.c_int, ip, ip, dp, dp, dp, dp, C.c_double, C.c_double, C.c_double,
                                  dp, dp, ip, dp, ip, dp, dp, dp, C.c_int]
     L.dmpc_solve_count.restype = C.c_int64

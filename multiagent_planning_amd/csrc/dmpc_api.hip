@@ -988,3 +988,5 @@ extern "C" int dmpc_add_coll_constr(dmpc_ctx *ctx, int K, int N, const double *p
     HIPCHK(ctx, hipStreamSynchronize(st));
     return 0;
 }
+
+#include "dmpc_fileio.hip"
