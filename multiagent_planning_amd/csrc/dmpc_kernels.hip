@@ -648,10 +648,20 @@ __device__ __forceinline__ void step_body(const StepParams &P)
         whi_l = sel3(A.whi0, ax_l) - (double)(k_l + 1) * P.h * vo_l;           // pmax - A0 x0  (:72)
         wlo_l = sel3(A.wlo0, ax_l) - (double)(k_l + 1) * P.h * vo_l;
     }
+    // Pivot weights.  The entering constraint is the one farthest from feasibility in the metric of the problem,
+    // violation / |n|_{H^-1} (the H-norm distance to its hyperplane), not the largest raw violation: rows in position
+    // space and unit box rows live on very different scales, and the raw rule keeps adding (and later dropping) box
+    // rows one by one.  Measured on the C2 scenes (numpy model of this solver): 42 % fewer active-set iterations in
+    // total, the longest infeasibility proof 107 -> 67.  The minimiser does not depend on the pivot order.
+    double wbox_l = 0.0, wpos_l = 0.0;
+    if (lane < N3) { wbox_l = rsqrt(L.tabH[k_l * 16]); wpos_l = rsqrt(L.tabP[k_l * 16]); }
+    auto row_weight = [&](double x0, double x1, double x2, int kc, double sd) {
+        return rsqrt(L.tabP[kc * 16] * (x0 * x0 + x1 * x1 + x2 * x2) + (soft ? 0.5 * sd * sd : 0.0));
+    };
     // Register cache of the first 128 collision rows (2 per lane): the row data is constant during the solve
     // and most agents have fewer rows than that, so the per-iteration violation scan and the descriptor of a
     // newly picked row need no global-memory round trip.  Rows 128+ are streamed from the L2-resident scratch.
-    double rcx0[2], rcx1[2], rcx2[2], rcb[2], rcsd[2], rcslb[2];
+    double rcx0[2], rcx1[2], rcx2[2], rcb[2], rcsd[2], rcslb[2], rcw[2];
     int rckc[2];
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -661,6 +671,7 @@ __device__ __forceinline__ void step_body(const StepParams &P)
         rcx0[c] = L.r_xi[3 * ii]; rcx1[c] = L.r_xi[3 * ii + 1]; rcx2[c] = L.r_xi[3 * ii + 2];
         rcb[c] = L.r_b[ii]; rckc[c] = L.r_kc[ii];
         rcsd[c] = soft ? L.r_sd[ii] : 0.0; rcslb[c] = soft ? L.r_slb[ii] : 0.0;
+        rcw[c] = row_weight(rcx0[c], rcx1[c], rcx2[c], rckc[c], rcsd[c]);
     }
     const long long tk2 = clock64();
     long long tkA = 0, tkB = 0, tkC = 0, tkD = 0, tkE = 0, tkF = 0, tkG = 0, tkH = 0;
@@ -783,14 +794,17 @@ __device__ __forceinline__ void step_body(const StepParams &P)
             for (;;) {
                 const long long tq0 = clock64();
                 // ---- most violated constraint not in the working set
-                double bestv = tol; int bestc = -1;
+                double bestv = tol, bests = 0.0; int bestc = -1;   // raw violation, weighted score, constraint code
+                // candidate: violated by more than tol and with a larger weighted violation than the lane's best so far
+#define CAND(v_, w_, code_) do { const double v__ = (v_); const double s__ = v__ * (w_); \
+                                 if (v__ > tol && s__ > bests) { bests = s__; bestv = v__; bestc = (code_); } } while (0)
                 if (lane < N3) {
                     const double c0 = a - P.alim, c1 = -a - P.alim;
                     const double c2 = w - whi_l, c3 = wlo_l - w;
-                    if (!(cmask & 1u) && c0 > bestv) { bestv = c0; bestc = (TY_BOXHI << 16) | lane; }
-                    if (!(cmask & 2u) && c1 > bestv) { bestv = c1; bestc = (TY_BOXLO << 16) | lane; }
-                    if (!(cmask & 4u) && c2 > bestv) { bestv = c2; bestc = (TY_POSHI << 16) | lane; }
-                    if (!(cmask & 8u) && c3 > bestv) { bestv = c3; bestc = (TY_POSLO << 16) | lane; }
+                    if (!(cmask & 1u)) CAND(c0, wbox_l, (TY_BOXHI << 16) | lane);
+                    if (!(cmask & 2u)) CAND(c1, wbox_l, (TY_BOXLO << 16) | lane);
+                    if (!(cmask & 4u)) CAND(c2, wpos_l, (TY_POSHI << 16) | lane);
+                    if (!(cmask & 8u)) CAND(c3, wpos_l, (TY_POSLO << 16) | lane);
                 }
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {   // rows held in registers
@@ -801,27 +815,29 @@ __device__ __forceinline__ void step_body(const StepParams &P)
                         if (soft && (fl & RF_LIVE)) {
                             const double e = L.r_eps[i];
                             v += rcsd[c] * e;
-                            if (!(fl & RF_SLKU) && e > bestv) { bestv = e; bestc = (TY_SLKU << 16) | i; }
+                            if (!(fl & RF_SLKU)) CAND(e, 1.4142135623730951, (TY_SLKU << 16) | i);   // |n|^2 = 1/2
                             const double lo = rcslb[c] - e;   // -eps <= -slb
-                            if (!(fl & RF_SLKL) && lo > bestv) { bestv = lo; bestc = (TY_SLKL << 16) | i; }
+                            if (!(fl & RF_SLKL)) CAND(lo, 1.4142135623730951, (TY_SLKL << 16) | i);
                         }
-                        if (!(fl & RF_COLL) && v > bestv) { bestv = v; bestc = (TY_COLL << 16) | i; }
+                        if (!(fl & RF_COLL)) CAND(v, rcw[c], (TY_COLL << 16) | i);
                     }
                 }
                 for (int i = lane + 128; i < nr; i += 64) {   // the rest streams from the global scratch
                     const int fl = L.r_fl[i], kc = L.r_kc[i];
-                    double v = -(L.r_xi[3 * i] * L.w_s[3 * kc] + L.r_xi[3 * i + 1] * L.w_s[3 * kc + 1] + L.r_xi[3 * i + 2] * L.w_s[3 * kc + 2]) - L.r_b[i];
+                    const double x0 = L.r_xi[3 * i], x1 = L.r_xi[3 * i + 1], x2 = L.r_xi[3 * i + 2];
+                    double v = -(x0 * L.w_s[3 * kc] + x1 * L.w_s[3 * kc + 1] + x2 * L.w_s[3 * kc + 2]) - L.r_b[i];
                     if (soft && (fl & RF_LIVE)) {
                         const double e = L.r_eps[i];
                         v += L.r_sd[i] * e;
-                        if (!(fl & RF_SLKU) && e > bestv) { bestv = e; bestc = (TY_SLKU << 16) | i; }
+                        if (!(fl & RF_SLKU)) CAND(e, 1.4142135623730951, (TY_SLKU << 16) | i);
                         const double lo = L.r_slb[i] - e;   // -eps <= -slb
-                        if (!(fl & RF_SLKL) && lo > bestv) { bestv = lo; bestc = (TY_SLKL << 16) | i; }
+                        if (!(fl & RF_SLKL)) CAND(lo, 1.4142135623730951, (TY_SLKL << 16) | i);
                     }
-                    if (!(fl & RF_COLL) && v > bestv) { bestv = v; bestc = (TY_COLL << 16) | i; }
+                    if (!(fl & RF_COLL) && v > tol) CAND(v, row_weight(x0, x1, x2, kc, soft ? L.r_sd[i] : 0.0), (TY_COLL << 16) | i);
                 }
-                const double vmax = wave_max(bestv);
-                const unsigned long long wm = __ballot(bestc >= 0 && bestv == vmax);
+#undef CAND
+                const double smax = wave_max(bests);
+                const unsigned long long wm = __ballot(bestc >= 0 && bests == smax);
                 if (wm == 0ull) {
                     if (q == 0 || fresh) break;   // optimal
                     // verification: primal from the multipliers, refine the active-set residual, re-check

@@ -19,6 +19,7 @@ BOXHI, BOXLO, POSHI, POSLO, COLL, SLKU, SLKL = range(7)
 DEBUG = False
 TRACE = None   # list collecting per-iteration records when set
 ITER_HOOK = None   # callable(a[K,3], f[K,3], W, iters) after every primal update (experiments)
+PIVOT = None       # experiments: callable(c, v, Tm) -> score replacing the raw violation in the pivot choice
 
 
 class Tables:
@@ -184,15 +185,16 @@ def solve_structured(Tbl, K, h, po, vo, ao, pf, alim, pmin, pmax, rows, stats=No
         if ITER_HOOK is not None:
             ITER_HOOK(a, f, W, iters)
         # most violated candidate
-        best, bestv = None, tol
+        best, bestv, bests = None, tol, -np.inf
         for j in range(n3):
             for typ in (BOXHI, BOXLO, POSHI, POSLO):
                 if (typ, j) in inW:
                     continue
                 c = mk(typ, j)
                 v = value(c, a, w, eps)
-                if v > bestv:
-                    best, bestv = c, v
+                sc = v if (PIVOT is None or not v > tol) else PIVOT(c, v, Tm)
+                if v > tol and sc > bests:
+                    best, bestv, bests = c, v, sc
         for i in range(nr):
             cands = [COLL]
             if live[i]:
@@ -204,8 +206,9 @@ def solve_structured(Tbl, K, h, po, vo, ao, pf, alim, pmin, pmax, rows, stats=No
                     continue
                 c = mk(typ, i)
                 v = value(c, a, w, eps)
-                if v > bestv:
-                    best, bestv = c, v
+                sc = v if (PIVOT is None or not v > tol) else PIVOT(c, v, Tm)
+                if v > tol and sc > bests:
+                    best, bestv, bests = c, v, sc
         if best is None:
             break
         p = best
