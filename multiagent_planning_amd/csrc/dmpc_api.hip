@@ -49,7 +49,11 @@ struct dmpc_ctx {
     int64_t solves = 0;
     int max_lds_set = 0;
     // scratch for the host-pointer entry points
-    DevBuf rowbuf, rowkc, hdr, order, bbox;
+    DevBuf rowbuf, rowkc, hdr, order, bbox, counter;
+    int num_cu = 0;
+    int no_persist = getenv("DMPC_NO_PERSIST") ? 1 : 0;   // tuning: one-agent-per-workgroup solve launches
+    int max_lds_persist = 0;
+    int force_persist = getenv("DMPC_FORCE_PERSIST") ? 1 : 0;   // tests: exercise the persistent kernel on small launches
     // chunk-level bounding-box neighbour culling in the scan: measured SLOWER on C4 at MPC steps 2-4 (3 s horizon
     // boxes of fast agents overlap almost every 64-neighbour chunk), so it is opt-in (DMPC_CULL=1) until the scan
     // compacts survivors per neighbour
@@ -268,6 +272,7 @@ extern "C" dmpc_ctx *dmpc_create(const dmpc_params *prm, int device)
         dmpc_destroy(ctx);
         return nullptr;
     }
+    if (hipDeviceGetAttribute(&ctx->num_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) ctx->num_cu = 0;
     return ctx;
 }
 
@@ -366,7 +371,7 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     {
         const size_t agents = (size_t)S * c_count;
         if (ctx->rowbuf.ensure(agents * P.nrmax * (soft ? 7 : 4) * 8) || ctx->rowkc.ensure(agents * P.nrmax * 4) ||
-            ctx->hdr.ensure(agents * 8 * 4) || ctx->order.ensure(agents * 4))
+            ctx->hdr.ensure(agents * 8 * 4) || ctx->order.ensure(agents * 4) || ctx->counter.ensure(16))
             FAIL(ctx, "device allocation failed (row scratch)");
         P.rowbuf = ctx->rowbuf.as<double>(); P.rowkc = ctx->rowkc.as<int>(); P.hdr = ctx->hdr.as<int>();
     }
@@ -396,6 +401,7 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
         hipLaunchKernelGGL(bbox_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, C, lT, ctx->bbox.as<double>());
         P.bbox = ctx->bbox.as<double>();
     }
+    HIPCHK(ctx, hipMemsetAsync(ctx->counter.p, 0, 16, st));   // queue heads of the persistent solve launches
     // phase 0: scan + rows
     P.qcap = q1; P.only_flagged = 0; P.qover_bit = two_tier ? ST_QOVER : ST_CAPACITY;
     if (soft) hipLaunchKernelGGL(dmpc_scan_kernel<true>, grid, block, lds0, st, P);
@@ -406,13 +412,41 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
         P.order = ctx->order.as<int>();
     }
     if (ctx->profile) HIPCHK(ctx, hipEventRecord(ev.t1, st));
-    // phase 1, tier 1
-    if (soft) hipLaunchKernelGGL(dmpc_solve_kernel<true>, grid, block, lds1, st, P);
-    else hipLaunchKernelGGL(dmpc_solve_kernel<false>, grid, block, lds1, st, P);
-    if (two_tier) {   // phase 1, tier 2: only agents flagged ST_QOVER do any work
+    // phase 1: persistent waves (one workgroup per CU, shared tables, agents claimed from a queue) when at least two
+    // waves fit next to the shared tables; otherwise one agent per workgroup
+    const size_t LDS_CU = 160 * 1024;
+    auto solve_launch = [&](int qcap, size_t lds_plain, int tier) -> int {
+        const size_t per = (persist_wave_bytes(P.nrmax, soft, qcap) + 15) & ~(size_t)15;
+        int pw = (int)((LDS_CU - PERSIST_TABLE_BYTES) / per);
+        if (pw > 8) pw = 8;
+        const int total = S * c_count;
+        // Measured on C2 (hard, 100 agents/scene): persistent waves win once the launch is deep enough to be
+        // throughput-bound (+6 % at 102 400 agents: 8 instead of 7 resident agents per CU), while short launches are
+        // bound by their single slowest agent, which runs ~4 % faster in the leaner one-agent-per-workgroup kernel.
+        const bool deep = (long)total >= 16L * ctx->num_cu * pw;
+        if (ctx->no_persist || pw < 2 || ctx->num_cu < 1 || (!deep && !ctx->force_persist)) {
+            if (soft) hipLaunchKernelGGL(dmpc_solve_kernel<true>, grid, block, lds_plain, st, P);
+            else hipLaunchKernelGGL(dmpc_solve_kernel<false>, grid, block, lds_plain, st, P);
+            return 0;
+        }
+        const size_t lds = PERSIST_TABLE_BYTES + (size_t)pw * per;
+        if ((int)lds > ctx->max_lds_persist) {
+            HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_persist_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_persist_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            ctx->max_lds_persist = (int)lds;
+        }
+        P.counter = ctx->counter.as<int>() + tier;
+        P.lds_per_wave = (int)per;
+        int wgs = (total + pw - 1) / pw;
+        if (wgs > ctx->num_cu) wgs = ctx->num_cu;
+        if (soft) hipLaunchKernelGGL(dmpc_solve_persist_kernel<true>, dim3((unsigned)wgs), dim3((unsigned)(64 * pw)), lds, st, P);
+        else hipLaunchKernelGGL(dmpc_solve_persist_kernel<false>, dim3((unsigned)wgs), dim3((unsigned)(64 * pw)), lds, st, P);
+        return 0;
+    };
+    if (solve_launch(q1, lds1, 0)) return -1;
+    if (two_tier) {   // tier 2: only agents flagged ST_QOVER do any work
         P.qcap = q2; P.only_flagged = 1; P.qover_bit = ST_CAPACITY;
-        if (soft) hipLaunchKernelGGL(dmpc_solve_kernel<true>, grid, block, lds2, st, P);
-        else hipLaunchKernelGGL(dmpc_solve_kernel<false>, grid, block, lds2, st, P);
+        if (solve_launch(q2, lds2, 1)) return -1;
     }
     HIPCHK(ctx, hipGetLastError());
     if (ctx->profile) {

@@ -33,6 +33,8 @@ struct StepParams {
     int no_prune;           // 1: keep every row the reference builds (dmpc_rows_one); 0: exact pruning
     const double *bbox;     // [G][S][6][C] horizon bounding boxes (bbox_kernel) or null: neighbour culling in the scan
     const int *order;       // solve-phase launch order (agent ids, heaviest first) or null
+    int *counter;           // persistent solve kernel: queue head (zeroed before the launch)
+    int lds_per_wave;       // persistent solve kernel: bytes of LDS per wave (after the shared tables)
     double *dbg;            // optional per-iteration trace of agent dbg_agent (development aid)
     int dbg_agent, dbg_cap;
 };
@@ -45,5 +47,8 @@ inline size_t step_lds_bytes(int nrmax, bool soft, int qcap, int phase)
     size_t bytes = dbl * 8 + 3 * (size_t)qcap * 4 + (size_t)nrmax;   // + slot ints + row flags (bytes)
     return (bytes + 15) & ~(size_t)15;
 }
+// persistent solve kernel: the tables are shared by the workgroup (3 cost cases x 676 doubles at the front)
+constexpr size_t PERSIST_TABLE_BYTES = 3 * 676 * 8;
+inline size_t persist_wave_bytes(int nrmax, bool soft, int qcap) { return step_lds_bytes(nrmax, soft, qcap, 1) - 676 * 8; }
 
 }  // namespace dmpc

@@ -334,23 +334,25 @@ __device__ __forceinline__ void set_member(const Lds &L, int lane, int ty, int i
 // Splitting the step keeps the solver's register and LDS footprint free of the scan's needs (more
 // resident agents per CU) and lets the solver be re-launched for the few agents that overflow the
 // tier-1 working-set capacity.
+// `bidx` of `nblocks`: the workgroup's index (one-agent-per-workgroup launches) or the queue position a persistent
+// wave just claimed; `smem`: this wave's LDS; `shtab`: the workgroup-shared copy of the three cost-case tables
+// (persistent solve kernel) or null (tables are copied into the wave's own LDS).
 template <int PHASE, bool SOFT>
-__device__ __forceinline__ void step_body(const StepParams &P)
+__device__ __forceinline__ void step_body(const StepParams &P, const int lane, const int bidx, const int nblocks,
+                                          unsigned char *smem, const double *shtab)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x;
     const int S = P.S, G = P.G, C = P.C, nrmax = P.nrmax;
     // XCD-aware mapping: workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8, private L2
     // each), so renumber them such that every XCD works on whole scenes: a scene's prediction table is then
     // fetched into ONE L2 instead of eight.  Pure performance remap (a bijection on [0, gridDim)).
-    int vb;
-    {
-        const int nb = gridDim.x, x = blockIdx.x & 7, y = blockIdx.x >> 3;
+    int vb = bidx;
+    if (!shtab) {
+        const int nb = nblocks, x = bidx & 7, y = bidx >> 3;
         int off = 0;
         for (int xx = 0; xx < x; ++xx) off += (nb - xx + 7) >> 3;
         vb = off + y;
     }
-    if (PHASE == 1 && P.order) vb = P.order[blockIdx.x];   // heaviest agents first (order_kernel)
+    if (PHASE == 1 && P.order) vb = P.order[bidx];   // heaviest agents first (order_kernel)
     const int scene = vb / P.c_count, ci = vb - scene * P.c_count;
     const int cl = P.c_first + ci;                                     // agent inside chunk g_local
     const int gid = scene * P.c_count + ci;                            // index into the launch's arrays
@@ -368,7 +370,8 @@ __device__ __forceinline__ void step_body(const StepParams &P)
             L.s_kb = L.s_ty = L.s_idx = nullptr; L.r_fl = nullptr;
         } else {
             L.T = p; p += t_doubles(qcap);
-            L.tabH = p; p += 225; L.tabM = p; p += 225; L.tabP = p; p += 226;   // 676: keep 16-B alignment of what follows
+            if (!shtab) { L.tabH = p; p += 225; L.tabM = p; p += 225; L.tabP = p; p += 226; }   // 676: keep 16-B alignment of what follows
+            else L.tabH = L.tabM = L.tabP = nullptr;   // set once the cost case is known
             L.a_s = p; p += 48; L.w_s = p; p += 48; L.nu_s = p; p += 48; L.yt_s = p; p += 48; L.own_s = nullptr;
             L.rr_s = p; p += 64; L.xs_s = p; p += 64;
             L.s_vec = p; p += 3 * qcap;
@@ -617,9 +620,11 @@ __device__ __forceinline__ void step_body(const StepParams &P)
     }
     const double qw = ccase == 0 ? 1000.0 : (ccase == 1 ? 10000.0 : P.Q1);
     const double sw = ccase == 2 ? ((var == VAR_ALL3) ? 10.0 : P.S1) : 10.0;
-    {
+    if (!shtab) {
         const double *src = P.tables + (size_t)ccase * 675;
         for (int i = lane; i < 675; i += 64) L.tabH[i] = src[i];   // tabH, tabM, tabP are contiguous
+    } else {
+        L.tabH = const_cast<double *>(shtab) + (size_t)ccase * 676; L.tabM = L.tabH + 225; L.tabP = L.tabH + 450;
     }
     LSYNC();
 
@@ -1129,10 +1134,56 @@ __device__ __forceinline__ void step_body(const StepParams &P)
     }
 }
 
+extern __shared__ __attribute__((aligned(16))) unsigned char dmpc_smem[];
+
 template <bool SOFT>
-__global__ __launch_bounds__(64, SCAN_WAVES_PER_SIMD) void dmpc_scan_kernel(StepParams P) { step_body<0, SOFT>(P); }
+__global__ __launch_bounds__(64, SCAN_WAVES_PER_SIMD) void dmpc_scan_kernel(StepParams P)
+{
+    step_body<0, SOFT>(P, threadIdx.x, blockIdx.x, gridDim.x, dmpc_smem, nullptr);
+}
 template <bool SOFT>
-__global__ __launch_bounds__(64, SOLVE_WAVES_PER_SIMD) void dmpc_solve_kernel(StepParams P) { step_body<1, SOFT>(P); }
+__global__ __launch_bounds__(64, SOLVE_WAVES_PER_SIMD) void dmpc_solve_kernel(StepParams P)
+{
+    step_body<1, SOFT>(P, threadIdx.x, blockIdx.x, gridDim.x, dmpc_smem, nullptr);
+}
+
+// Persistent form of the solve phase: one workgroup of up to 8 independent waves per CU.  The three cost-case
+// table sets (16 KB) are staged in LDS ONCE per workgroup and shared by its waves instead of being copied into
+// every agent's own LDS (5.4 KB each: one more resident agent per CU, no per-agent table copy); every wave then
+// claims agents from a global queue (heaviest first when order_kernel ran) until it is empty, so a wave that
+// finishes a light agent immediately starts the next one and the launch ends when the LAST agent ends, not when
+// the slowest workgroup slot drains.  No workgroup barrier after the table load: the waves never synchronise.
+template <bool SOFT>
+__global__ __launch_bounds__(512, 1) void dmpc_solve_persist_kernel(StepParams P)
+{
+    double *shtab = (double *)dmpc_smem;
+    for (int i = threadIdx.x; i < 3 * 676; i += blockDim.x) {
+        const int c = i / 676, o = i - c * 676;
+        shtab[i] = (o < 675) ? P.tables[(size_t)c * 675 + o] : 0.0;
+    }
+    __syncthreads();
+    // readfirstlane: tells the compiler the wave index (and with it every LDS base address and every value read
+    // through one) is wave-uniform -- otherwise the solver's uniform branches are compiled as divergent ones
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    unsigned char *mine = (unsigned char *)__builtin_assume_aligned(dmpc_smem + 3 * 676 * 8 + (size_t)wave * P.lds_per_wave, 16);
+    const int total = P.S * P.c_count;
+    // First round: queue position wave * #workgroups + workgroup, i.e. the heaviest #workgroups agents each get a CU
+    // (and a SIMD) of their own instead of sharing one with the next-heaviest; later rounds come from the counter.
+    const int first_round = (int)(gridDim.x * (blockDim.x >> 6));
+    int idx = wave * (int)gridDim.x + (int)blockIdx.x;
+    for (;;) {
+        if (idx >= total) break;
+        // opaque copy of the lane id: keeps the compiler from hoisting the solver's per-lane constants out of this
+        // loop (they would stay live across the whole body and push the kernel into scratch spills)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        step_body<1, SOFT>(P, ln, idx, total, mine, shtab);
+        LSYNC();
+        int nxt = 0;
+        if (lane == 0) nxt = atomicAdd(P.counter, 1);
+        idx = first_round + __builtin_amdgcn_readfirstlane(nxt);
+    }
+}
 
 // --------------------------------------------------------------------------------------------
 // small layout / bookkeeping kernels

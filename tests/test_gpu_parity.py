@@ -130,3 +130,26 @@ def test_checkcoll_helper_matches_scan():
     viol, mind, vc = api.CheckCollSoftDMPC(l3[:, 8, 1], l3, 2, 9, E1, kw["rmin"], 2)
     r = orc.rows_one(oracle_params("bound", kw), g["l"], 1, g["pk"][1, 12], g["vk"][1, 12])
     assert r["viol_k"] == 9 and viol.any() and int(vc.sum()) == r["nrows"]
+
+
+@pytest.mark.parametrize("variant", ["hard", "bound", "softall"])
+def test_persistent_and_per_agent_solve_kernels_are_bitwise_identical(variant, monkeypatch):
+    """The solve phase has two launch forms (one agent per workgroup / persistent waves claiming agents from a queue
+    with the cost tables shared per workgroup); the choice depends on the launch size only and must not change a bit."""
+    import multiagent_planning_amd as mp
+    from multiagent_planning_amd import workload as wl
+    cfg = wl.CONFIGS["C2"]
+    N, S = 60, 9
+    kw = wl.solver_kwargs(cfg, N)
+    po, pf = wl.make_scenes(cfg, S, N, wl.SEED0 + 17)
+    outs = []
+    for env in ("DMPC_NO_PERSIST", "DMPC_FORCE_PERSIST"):
+        monkeypatch.setenv(env, "1")
+        d = mp.Dmpc(variant, **kw)            # the switches are read when the context is created
+        monkeypatch.delenv(env)
+        l, _, _ = d.init_batch(po, pf)
+        z = np.zeros_like(po)
+        outs.append(d.step_batch(l, po, z, z, pf))
+    for k in ("p", "v", "a", "status", "info"):
+        assert np.array_equal(outs[0][k], outs[1][k]), k
+    assert (outs[0]["status"] & 1).any()
