@@ -248,11 +248,15 @@ def main():
         achieved = (S * C) * b_alg / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
         traffic = None
         tj = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tj) and G == 1:
+        if os.path.exists(tj) and G == 1:   # PMC counters cannot be read inside the timed run: the committed rocprofv3 passes of this workload
             try:
-                traffic = json.load(open(tj)).get("hbm_bytes_per_launch")
+                jt = json.load(open(tj))
+                if jt.get("solves_per_launch") == S * C:
+                    traffic = jt.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+        kname = "dmpc_solve_persist_kernel" if S * C >= 16 * ncu * 8 else "dmpc_solve_kernel"
         line = {
             "metric": "agent-QP solves/sec (K=15 horizon)",
             "value": value, "unit": "solves/s", "n_gpus": (1 if emu else G), "steps": args.steps, "warmup": args.warmup,
@@ -267,7 +271,7 @@ def main():
                        "exchange_verified": exchange_ok},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "dmpc_solve_kernel", "kernel_ms_avg": kern_ms, "launches": n_launch,
+                         "kernel": kname, "kernel_ms_avg": kern_ms, "launches": n_launch,
                          "other_kernels_ms_avg": {"dmpc_scan_kernel+order_kernel": scan_ms},
                          "alg_bytes_per_solve": b_alg, "solves_per_launch": S * C,
                          "note": "on-chip bound (dependent LDS/VALU chains of the active-set iterations); compulsory HBM "

@@ -449,7 +449,11 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
             const double sh = (double)(kc + 1) * P.h;
             const double a0x = A.po[0] + sh * A.vo[0], a0y = A.po[1] + sh * A.vo[1], a0z = A.po[2] + sh * A.vo[2];
             const double x0 = dx, x1 = dy, x2 = dz * P.e2z;   // diff = E2*(p - pj)
-            nrows_ref += __popcll(__ballot(sel));               // the reference's row count (branch record)
+            {
+                const unsigned long long m0 = __ballot(sel);
+                if (m0 == 0ull) return;                         // no neighbour of this chunk is close at this step
+                nrows_ref += __popcll(m0);                      // the reference's row count (branch record)
+            }
             // Exact pruning: with |a| <= alim the position at step kc stays in the box
             // A0_kc x0 +- alim (kc h)^2/2, so a row whose linearised distance cannot drop below rmin anywhere in
             // that box can never become active; dropping it (and its slack, which stays 0) leaves the minimiser
@@ -529,6 +533,7 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
         // step; per-step "any neighbour inside rmin" bits are OR-reduced across the wave afterwards.
         unsigned anyb = 0;
         double mind0 = 1e300;
+        const double rmin2_hi = rmin * rmin * (1.0 + 1e-9);
         for (int r = 0; r < G; ++r) {
             const double *base = P.lT + ((size_t)(r * S + scene) * N3) * C;
             for (int j0 = 0; j0 < C; j0 += 64) {
@@ -553,15 +558,24 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
                         const double px = L.own_s[3 * k], py = L.own_s[3 * k + 1], pz = L.own_s[3 * k + 2];
                         const double dx = px - nx[u], dy = py - ny[u], dz = pz - nz[u];
                         const double ez = dz * P.e1z;
-                        const double dist = sqrt(dx * dx + dy * dy + ez * ez);
+                        const double d2 = dx * dx + dy * dy + ez * ez;
+                        // The IEEE square root (a dozen instructions in fp64) is taken only when some lane of the
+                        // wave can pass the distance test: d2 is first compared against a slightly inflated squared
+                        // threshold (a superset), the exact `norm(...) < r` decision is then made on sqrt(d2) itself.
                         if (var == VAR_HARD) {
                             // solveHardDMPC.m:18-22 + CollConstrHardDMPC.m:19: every k, neighbours with dist < 1.
                             // (rows are emitted neighbour-chunk-major here; the reference's k-major order only
                             //  changes tie breaks of the active-set path, not the unique minimiser)
-                            emit_row(valid && dist < 1.0, k, dx, dy, dz, dist, px, py, pz);
+                            if (__any(valid && d2 < 1.0 + 1e-9)) {
+                                const double dist = sqrt(d2);
+                                emit_row(valid && dist < 1.0, k, dx, dy, dz, dist, px, py, pz);
+                            }
                         } else {
-                            if (valid && dist < rmin) anyb |= (1u << k);           // CheckCollSoftDMPC.m:11
-                            if (k == 0 && valid) mind0 = fmin(mind0, dist);
+                            if (__any(valid && d2 < rmin2_hi)) {
+                                const double dist = sqrt(d2);
+                                if (valid && dist < rmin) anyb |= (1u << k);       // CheckCollSoftDMPC.m:11
+                            }
+                            if (k == 0 && valid) mind0 = fmin(mind0, d2);           // squared; the root is taken once below
                         }
                     }
                 }
@@ -575,7 +589,7 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
                 if (!((anyb >> k) & 1u)) continue;
                 if (var == VAR_ALL3) violation = true;   // solveSoftDMPCall.m:22 (some_violation)
                 if (coll_check && k == 0) {
-                    mind0 = wave_min(mind0);
+                    mind0 = sqrt(wave_min(mind0));   // min of the roots == root of the min (sqrt is monotone)
                     if (mind0 < rmin - 0.05) { status = ST_COLL; viol_k = 1; break; }   // :25-31
                 }
                 if (skip_k1 && k == 0) continue;          // solveSoftDMPCbound2.m:29-31
