@@ -92,9 +92,16 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if G > 1 and not emu:
+    # DMPC_BENCH_FORCE_DIST=1: run the RCCL calls of the multi-rank path with a world of one (functional check of
+    # the collectives' arguments on a single-GPU box)
+    use_dist = (G > 1 and not emu) or (bool(os.environ.get("DMPC_BENCH_FORCE_DIST")) and not emu)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo" if share else "nccl", rank=rank, world_size=G)
+        os.environ.setdefault("MASTER_PORT", "29517")
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=G)
+        else:   # device_id binds the RCCL communicator to this rank's GPU up front (no device guessing in barrier())
+            dist.init_process_group("nccl", rank=rank, world_size=G, device_id=dev)
 
     cfg = wl.CONFIGS[args.config]
     C = args.agents_per_gpu
@@ -125,7 +132,7 @@ def main():
         dmpc.step_device(S, G, C, rank, lT.data_ptr(), x_p.data_ptr(), x_v.data_ptr(), x_a.data_ptr(), p_f.data_ptr(),
                          p_out.data_ptr(), v_out.data_ptr(), a_out.data_ptr(), lT_next.data_ptr(), status.data_ptr(),
                          info.data_ptr(), stream)
-        if G > 1 and not emu:   # the per-step exchange: every rank publishes its agents' new predictions
+        if use_dist:   # the per-step exchange: every rank publishes its agents' new predictions
             if share:
                 h_in = lT_next.cpu()
                 h_out = torch.empty((G,) + tuple(h_in.shape), dtype=h_in.dtype)
@@ -135,7 +142,7 @@ def main():
                 dist.all_gather_into_tensor(lT_gath.view(-1), lT_next.view(-1))
 
     def barrier():
-        if G > 1 and not emu:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -151,14 +158,14 @@ def main():
     kern_ms, scan_ms, n_launch = dmpc.profile_read2()
     dmpc.profile(False)
     elapsed = t1 - t0
-    if G > 1 and not emu:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     # outside the timed region: the gathered table is the same on every rank and holds this rank's chunk in its slot
     exchange_ok = None
-    if G > 1 and not emu:
+    if use_dist:
         ck = lT_gath.view(torch.int64).sum(dtype=torch.int64)    # bit-pattern checksum
         ck = torch.stack([ck, -ck]).to("cpu" if share else dev)
         dist.all_reduce(ck, op=dist.ReduceOp.MAX)
@@ -307,9 +314,18 @@ def main():
             line["cpu_baseline"] = {"value": one, "unit": "solves/s", "cores": 1, "kind": "port",
                                     "sample": f"{s_i} scene(s) x {N} agents of the same captured step, oracle/dmpc_oracle.c (dense Goldfarb-Idnani), 1 thread",
                                     "all_cores": {"value": allc, "threads": min(ncpu, N), "host_cpus": ncpu}}
-        print(json.dumps(line))
-    if G > 1 and not emu:
+    if use_dist:
         dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line is the LAST thing on stdout: flush whatever the native libraries (RCCL's version banner) still
+        # hold in C stdio buffers first
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":
