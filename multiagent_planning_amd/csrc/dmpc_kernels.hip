@@ -176,38 +176,6 @@ __device__ __forceinline__ double sdot_self(const Lds &L, const Cdesc &p)
     return v;
 }
 
-// x(lambda): a = a_unc - H^-1 N lam, w = Lambda a ; written to a_s / w_s.  eps for live slack rows.
-__device__ __forceinline__ void primal(const Lds &L, int lane, int q, int nr, bool soft, double a_unc, double w_unc,
-                                       double &a, double &w)
-{
-    const int k = lane / 3, ax = lane - 3 * k;
-    a = a_unc; w = w_unc;
-    if (lane < 45) {
-        for (int j = 0; j < q; ++j) {
-            const int ty = L.s_ty[j];
-            if (ty > TY_COLL) continue;   // slack-only constraints do not touch a
-            const int kb = L.s_kb[j];
-            const double coef = L.s_lam[j] * L.s_vec[3 * j + ax];
-            if (ty < TY_POSHI) { a -= coef * L.tabH[k * 15 + kb]; w -= coef * L.tabM[kb * 15 + k]; }
-            else { a -= coef * L.tabM[k * 15 + kb]; w -= coef * L.tabP[k * 15 + kb]; }
-        }
-        L.a_s[lane] = a; L.w_s[lane] = w;
-    }
-    if (soft) {
-        for (int i = lane; i < nr; i += 64) {
-            double e = 0.0;
-            if (L.r_fl[i] & RF_LIVE) {
-                double acc = L.r_st[i];
-                for (int j = 0; j < q; ++j)
-                    if (L.s_ty[j] >= TY_COLL && L.s_idx[j] == i) acc += L.s_lam[j] * L.s_ss[j];
-                e = -0.5 * acc;
-            }
-            L.r_eps[i] = e;
-        }
-    }
-    LSYNC();
-}
-
 // ---- inverse factor storage: upper-triangular T, column-major, column j zero-padded to a multiple of 8 rows:
 //   T[i][j] (i <= j) at Tp[tcol(j) + i],  tcol(j) = 8 (g+1)(j - 4g), g = j/8;  rows j+1 .. 8*ceil((j+1)/8)-1 are ZERO.
 // The padding lets the column dot products run in unmasked groups of 8 (a lane either owns the whole group
@@ -693,7 +661,7 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
         rcw[c] = row_weight(rcx0[c], rcx1[c], rcx2[c], rckc[c], rcsd[c]);
     }
     const long long tk2 = clock64();
-    long long tkA = 0, tkB = 0, tkC = 0, tkD = 0, tkE = 0, tkF = 0, tkG = 0, tkH = 0;
+    long long tkA = 0, tkB = 0, tkC = 0, tkD = 0, tkE = 0, tkF = 0, tkG = 0;
     // ---------------------------------------------------------------- a7: dual active-set solve
     const bool ladder = (var == VAR_BOUND || var == VAR_BOUND2 || var == VAR_ALL3);
     const int max_tries = P.max_tries > 0 ? P.max_tries : 30;
