@@ -49,7 +49,7 @@ struct dmpc_ctx {
     int64_t solves = 0;
     int max_lds_set = 0;
     // scratch for the host-pointer entry points
-    DevBuf rowbuf, rowkc, hdr, order, bbox, counter;
+    DevBuf rowbuf, rowkc, hdr, order, bbox, counter, flag_list;
     int num_cu = 0;
     int no_persist = getenv("DMPC_NO_PERSIST") ? 1 : 0;   // tuning: one-agent-per-workgroup solve launches
     int max_lds_persist = 0;
@@ -371,7 +371,7 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     {
         const size_t agents = (size_t)S * c_count;
         if (ctx->rowbuf.ensure(agents * P.nrmax * (soft ? 7 : 4) * 8) || ctx->rowkc.ensure(agents * P.nrmax * 4) ||
-            ctx->hdr.ensure(agents * 8 * 4) || ctx->order.ensure(agents * 4) || ctx->counter.ensure(16))
+            ctx->hdr.ensure(agents * 8 * 4) || ctx->order.ensure(agents * 4) || ctx->counter.ensure(16) || ctx->flag_list.ensure(agents * 4))
             FAIL(ctx, "device allocation failed (row scratch)");
         P.rowbuf = ctx->rowbuf.as<double>(); P.rowkc = ctx->rowkc.as<int>(); P.hdr = ctx->hdr.as<int>();
     }
@@ -415,16 +415,16 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     // phase 1: persistent waves (one workgroup per CU, shared tables, agents claimed from a queue) when at least two
     // waves fit next to the shared tables; otherwise one agent per workgroup
     const size_t LDS_CU = 160 * 1024;
-    auto solve_launch = [&](int qcap, size_t lds_plain, int tier) -> int {
-        const size_t per = (persist_wave_bytes(P.nrmax, soft, qcap) + 15) & ~(size_t)15;
+    auto persist_waves = [&](int qcap, size_t &per) -> int {
+        per = (persist_wave_bytes(P.nrmax, soft, qcap) + 15) & ~(size_t)15;
         int pw = (int)((LDS_CU - PERSIST_TABLE_BYTES) / per);
-        if (pw > 8) pw = 8;
+        return pw > 8 ? 8 : pw;
+    };
+    auto solve_launch = [&](int qcap, size_t lds_plain, int tier, bool want_persist) -> int {
+        size_t per = 0;
+        const int pw = persist_waves(qcap, per);
         const int total = S * c_count;
-        // Measured on C2 (hard, 100 agents/scene): persistent waves win once the launch is deep enough to be
-        // throughput-bound (+6 % at 102 400 agents: 8 instead of 7 resident agents per CU), while short launches are
-        // bound by their single slowest agent, which runs ~4 % faster in the leaner one-agent-per-workgroup kernel.
-        const bool deep = (long)total >= 16L * ctx->num_cu * pw;
-        if (ctx->no_persist || pw < 2 || ctx->num_cu < 1 || (!deep && !ctx->force_persist)) {
+        if (!want_persist || ctx->no_persist || pw < 2 || ctx->num_cu < 1) {
             if (soft) hipLaunchKernelGGL(dmpc_solve_kernel<true>, grid, block, lds_plain, st, P);
             else hipLaunchKernelGGL(dmpc_solve_kernel<false>, grid, block, lds_plain, st, P);
             return 0;
@@ -443,10 +443,21 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
         else hipLaunchKernelGGL(dmpc_solve_persist_kernel<false>, dim3((unsigned)wgs), dim3((unsigned)(64 * pw)), lds, st, P);
         return 0;
     };
-    if (solve_launch(q1, lds1, 0)) return -1;
+    // Measured on C2 (hard, 100 agents/scene): persistent waves win once the launch is deep enough to be
+    // throughput-bound (+6 % at 102 400 agents: 8 instead of 7 resident agents per CU), while short launches are
+    // bound by their single slowest agent, which runs ~4 % faster in the leaner one-agent-per-workgroup kernel.
+    size_t per1 = 0, per2 = 0;
+    const int pw1 = persist_waves(q1, per1), pw2 = persist_waves(q2, per2);
+    const bool deep = (long)S * c_count >= 16L * ctx->num_cu * (pw1 > 0 ? pw1 : 1);
+    // tier 2 as persistent waves over the flagged list (nearly always empty: the launch then costs a few microseconds
+    // instead of one workgroup per agent just to find out that there is nothing to do)
+    const bool t2_list = two_tier && !ctx->no_persist && pw2 >= 2 && ctx->num_cu >= 1;
+    if (t2_list) { P.flag_count = ctx->counter.as<int>() + 2; P.flag_list = ctx->flag_list.as<int>(); }
+    if (solve_launch(q1, lds1, 0, deep || ctx->force_persist)) return -1;
     if (two_tier) {   // tier 2: only agents flagged ST_QOVER do any work
         P.qcap = q2; P.only_flagged = 1; P.qover_bit = ST_CAPACITY;
-        if (solve_launch(q2, lds2, 1)) return -1;
+        if (t2_list) { P.order = ctx->flag_list.as<int>(); P.flag_list = nullptr; }
+        if (solve_launch(q2, lds2, 1, t2_list)) return -1;
     }
     HIPCHK(ctx, hipGetLastError());
     if (ctx->profile) {

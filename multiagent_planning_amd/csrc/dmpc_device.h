@@ -35,6 +35,7 @@ struct StepParams {
     const int *order;       // solve-phase launch order (agent ids, heaviest first) or null
     int *counter;           // persistent solve kernel: queue head (zeroed before the launch)
     int lds_per_wave;       // persistent solve kernel: bytes of LDS per wave (after the shared tables)
+    int *flag_count, *flag_list;   // tier 1 -> tier 2: number / ids of the agents whose working set overflowed (or null)
     double *dbg;            // optional per-iteration trace of agent dbg_agent (development aid)
     int dbg_agent, dbg_cap;
 };

@@ -1046,7 +1046,11 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
             if (rc == 0) { solved = true; break; }
             if (rc == 2) {   // tier 1: flag for the tier-2 relaunch (and record the ladder position); last tier: capacity error
                 status |= P.qover_bit;
-                if (lane == 0) { hdr[6] = tries - 1; hdr[7] = iters_total; hdr[4] |= 2; }
+                if (lane == 0) {
+                    hdr[6] = tries - 1; hdr[7] = iters_total; hdr[4] |= 2;
+                    // tier 1: append to the list the tier-2 launch works through (order irrelevant: scheduling only)
+                    if (P.flag_list && P.qover_bit == ST_QOVER) P.flag_list[atomicAdd(P.flag_count, 1)] = gid;
+                }
                 break;
             }
             if (rc == 3) { status |= ST_ITERCAP; break; }
@@ -1138,6 +1142,9 @@ __global__ __launch_bounds__(64, SOLVE_WAVES_PER_SIMD) void dmpc_solve_kernel(St
 template <bool SOFT>
 __global__ __launch_bounds__(512, 1) void dmpc_solve_persist_kernel(StepParams P)
 {
+    // tier 2 works through the list of agents tier 1 flagged (P.order points at it); usually it is empty
+    const int total = P.only_flagged ? *P.flag_count : P.S * P.c_count;
+    if (total == 0) return;
     double *shtab = (double *)dmpc_smem;
     for (int i = threadIdx.x; i < 3 * 676; i += blockDim.x) {
         const int c = i / 676, o = i - c * 676;
@@ -1148,7 +1155,6 @@ __global__ __launch_bounds__(512, 1) void dmpc_solve_persist_kernel(StepParams P
     // through one) is wave-uniform -- otherwise the solver's uniform branches are compiled as divergent ones
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     unsigned char *mine = (unsigned char *)__builtin_assume_aligned(dmpc_smem + 3 * 676 * 8 + (size_t)wave * P.lds_per_wave, 16);
-    const int total = P.S * P.c_count;
     // First round: queue position wave * #workgroups + workgroup, i.e. the heaviest #workgroups agents each get a CU
     // (and a SIMD) of their own instead of sharing one with the next-heaviest; later rounds come from the counter.
     const int first_round = (int)(gridDim.x * (blockDim.x >> 6));
