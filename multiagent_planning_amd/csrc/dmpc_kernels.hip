@@ -294,6 +294,101 @@ __device__ __forceinline__ void set_member(const Lds &L, int lane, int ty, int i
     }
 }
 
+// Retry-ladder certificate (bounded-slack variants).  The rows of one horizon step k constrain only w_k = (Lambda a)_k,
+// and with |a| <= alim the reachable set of w_k is EXACTLY the box |w_k| <= alim ((k+1) h)^2 / 2 per axis (cut by the
+// workspace bounds of that step).  With every slack at its lower bound slb*f the rows are the half-spaces
+// -xi.w <= b - sd slb f; if their intersection with the box is empty the QP is infeasible at that ladder level.  A
+// bounded non-empty polytope has an edge on the intersection line of two of its planes, so it is empty iff on every
+// such line the interval cut out by the other planes is empty: one lane per plane pair (<= 26 rows + 6 faces), one
+// pass over the planes each.  Conservative (row subset, 1e-7 relative margin): a level it does not reject is still
+// decided by the active-set iteration.  For solveSoftDMPCbound/bound2 all rows sit on ONE step, so the test is
+// nearly exact and the ladder jumps straight to the first level that can work instead of proving 2-3 levels
+// infeasible with 100+ iterations each.  Only the first 128 rows are used.  Out of line: it runs for a handful
+// of agents per launch and must not cost the solver's hot loop any registers.
+__device__ __attribute__((noinline)) bool ladder_level_infeasible(const double *__restrict__ r_xi, const double *__restrict__ r_b,
+                                                                  const double *__restrict__ r_sd, const double *__restrict__ r_slb,
+                                                                  const int *__restrict__ r_kc, int nr, double *pl, double h,
+                                                                  double alim, double f, double whi_l, double wlo_l, int lane)
+{
+    const int kc0 = lane < nr ? r_kc[lane] : -1, kc1 = lane + 64 < nr ? r_kc[lane + 64] : -1;
+    bool empty_any = false;
+    for (int k = 0; k < K && !empty_any; ++k) {
+        const bool s0 = (lane < nr) && kc0 == k, s1 = (lane + 64 < nr) && kc1 == k;
+        const unsigned long long m0 = __ballot(s0), m1 = __ballot(s1);
+        const int c0 = __popcll(m0), m = c0 + __popcll(m1);
+        if (m == 0) continue;
+        const int M = m < 26 ? m : 26;
+        const double sh = (double)(k + 1) * h, R = 0.5 * alim * sh * sh;
+        LSYNC();
+        {
+            const int p0 = lanes_below(m0, lane), p1 = c0 + lanes_below(m1, lane);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const bool sel = c ? s1 : s0;
+                const int pp = c ? p1 : p0;
+                if (sel && pp < 26) {
+                    const int i = lane + 64 * c;
+                    const double x0 = r_xi[3 * i], x1 = r_xi[3 * i + 1], x2 = r_xi[3 * i + 2];
+                    const double rhs = r_b[i] - r_sd[i] * r_slb[i] * f;
+                    const double sn = 1.0 / ((fabs(x0) + fabs(x1) + fabs(x2)) * R + fabs(rhs) + 1e-300);
+                    pl[4 * pp] = -x0 * sn; pl[4 * pp + 1] = -x1 * sn; pl[4 * pp + 2] = -x2 * sn; pl[4 * pp + 3] = rhs * sn;
+                }
+            }
+            // box faces of step k: w <= min(R, whi), -w <= min(R, -wlo); the bounds of component (k, ax) live in lane 3k + ax
+            if (lane >= 3 * k && lane < 3 * k + 3) {
+                const int ax = lane - 3 * k;
+                const double hi = fmin(R, whi_l), lo = fmax(-R, wlo_l), sn = 0.5 / R;
+                double *fc = pl + 4 * (M + 2 * ax);
+                fc[0] = ax == 0 ? sn : 0.0; fc[1] = ax == 1 ? sn : 0.0; fc[2] = ax == 2 ? sn : 0.0; fc[3] = hi * sn;
+                fc[4] = -fc[0]; fc[5] = -fc[1]; fc[6] = -fc[2]; fc[7] = -lo * sn;
+            }
+        }
+        LSYNC();
+        const int Mt = M + 6, npair = Mt * (Mt - 1) / 2;
+        double best = INFINITY;     // smallest emptiness gap over the lines seen by this lane
+        bool found = false;
+        for (int base = 0; base < npair && !found; base += 64) {
+            const int pr = base + lane;
+            const bool valid = pr < npair;
+            const int n = Mt, prc = valid ? pr : 0;
+            int ii = (int)((2.0f * n - 1.0f - sqrtf((2.0f * n - 1.0f) * (2.0f * n - 1.0f) - 8.0f * (float)prc)) * 0.5f);
+            ii = ii < 0 ? 0 : (ii > n - 2 ? n - 2 : ii);
+            while (ii > 0 && ii * (2 * n - ii - 1) / 2 > prc) --ii;
+            while (ii < n - 2 && (ii + 1) * (2 * n - ii - 2) / 2 <= prc) ++ii;
+            int jj = prc - ii * (2 * n - ii - 1) / 2 + ii + 1;
+            jj = jj > n - 1 ? n - 1 : jj;
+            const double a0 = pl[4 * ii], a1 = pl[4 * ii + 1], a2 = pl[4 * ii + 2], ab = pl[4 * ii + 3];
+            const double b0 = pl[4 * jj], b1 = pl[4 * jj + 1], b2 = pl[4 * jj + 2], bb = pl[4 * jj + 3];
+            // line: direction d = a x b (normalised), point w0 = (ab (b x d) + bb (d x a)) / |a x b|^2
+            double d0 = a1 * b2 - a2 * b1, d1 = a2 * b0 - a0 * b2, d2 = a0 * b1 - a1 * b0;
+            const double dd = d0 * d0 + d1 * d1 + d2 * d2;
+            const double na2 = a0 * a0 + a1 * a1 + a2 * a2, nb2 = b0 * b0 + b1 * b1 + b2 * b2;
+            const bool ok = valid && dd > 1e-16 * na2 * nb2;      // not (nearly) parallel planes
+            const double idd = ok ? 1.0 / dd : 0.0;
+            const double w0 = (ab * (b1 * d2 - b2 * d1) + bb * (d1 * a2 - d2 * a1)) * idd,
+                         w1 = (ab * (b2 * d0 - b0 * d2) + bb * (d2 * a0 - d0 * a2)) * idd,
+                         w2 = (ab * (b0 * d1 - b1 * d0) + bb * (d0 * a1 - d1 * a0)) * idd;
+            const double idn = ok ? rsqrt(dd) : 0.0;
+            d0 *= idn; d1 *= idn; d2 *= idn;
+            double lo = -INFINITY, hi = INFINITY, par = -INFINITY;   // par: worst violation among planes parallel to the line
+            for (int c = 0; c < Mt; ++c) {
+                const double c0_ = pl[4 * c], c1 = pl[4 * c + 1], c2 = pl[4 * c + 2];
+                const double g = c0_ * d0 + c1 * d1 + c2 * d2;                        // slope along the line
+                const double r = pl[4 * c + 3] - (c0_ * w0 + c1 * w1 + c2 * w2);      // slack at w0 (relative units)
+                if (g > 1e-12) hi = fmin(hi, r / g);
+                else if (g < -1e-12) lo = fmax(lo, r / g);
+                else par = fmax(par, -r);
+            }
+            const double gap = fmax((lo - hi) / R, par);   // positive = the line misses the polytope
+            if (ok) best = fmin(best, gap);
+            found = __any(ok && gap <= 1e-9);
+        }
+        if (!found && wave_min(best) > 1e-7) empty_any = true;
+    }
+LSYNC();
+return empty_any;
+}
+
 // --------------------------------------------------------------------------------------------
 // the step kernel: grid = S * C workgroups of 64 threads
 // --------------------------------------------------------------------------------------------
@@ -663,7 +758,8 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
     const long long tk2 = clock64();
     long long tkA = 0, tkB = 0, tkC = 0, tkD = 0, tkE = 0, tkF = 0, tkG = 0;
     // ---------------------------------------------------------------- a7: dual active-set solve
-    const bool ladder = (var == VAR_BOUND || var == VAR_BOUND2 || var == VAR_ALL3);
+    const bool ladder = soft && (var == VAR_BOUND || var == VAR_BOUND2 || var == VAR_ALL3);
+    constexpr int LADDER_CERT_AFTER = 16;
     const int max_tries = P.max_tries > 0 ? P.max_tries : 30;
     // a tier-2 relaunch resumes the retry ladder where tier 1 left it (the row data in global memory already
     // carries the doublings of the tries that were proven infeasible)
@@ -778,8 +874,15 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
             int nlive = 0;                  // live slack variables (instantiated eps): the problem has 45 + nlive variables
             bool fresh = true;              // primal == x(lambda) with refined lambda
             int since_sync = 0;
+            bool cert_done = false;
             for (;;) {
                 const long long tq0 = clock64();
+                // a try that is still running after LADDER_CERT_AFTER iterations: ask the certificate once whether this
+                // ladder level can work at all
+                if (soft && ladder && violation && !cert_done && iters >= LADDER_CERT_AFTER) {
+                    cert_done = true;
+                    if (ladder_level_infeasible(L.r_xi, L.r_b, L.r_sd, L.r_slb, L.r_kc, nr, L.rr_s, P.h, P.alim, 1.0, whi_l, wlo_l, lane)) { rc = 1; break; }
+                }
                 // ---- most violated constraint not in the working set
                 double bestv = tol, bests = 0.0; int bestc = -1;   // raw violation, weighted score, constraint code
                 // candidate: violated by more than tol and with a larger weighted violation than the lane's best so far
@@ -1056,8 +1159,13 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
             if (rc == 3) { status |= ST_ITERCAP; break; }
             // infeasible: retry ladder (solveSoftDMPCbound.m:147-153): lb_eps *= 2, term *= 2
             if (ladder && violation) {
-                for (int i = lane; i < nr; i += 64) { L.r_slb[i] *= 2.0; L.r_st[i] *= 2.0; }
-                rcslb[0] *= 2.0; rcslb[1] *= 2.0;
+                // next level, plus every further level the per-step certificate rejects (counted as tries, like the
+                // reference would have spent them)
+                double f = 2.0;
+                while (tries < max_tries - 1 &&
+                       ladder_level_infeasible(L.r_xi, L.r_b, L.r_sd, L.r_slb, L.r_kc, nr, L.rr_s, P.h, P.alim, f, whi_l, wlo_l, lane)) { f *= 2.0; ++tries; }
+                for (int i = lane; i < nr; i += 64) { L.r_slb[i] *= f; L.r_st[i] *= f; }
+                rcslb[0] *= f; rcslb[1] *= f;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 LSYNC();
