@@ -230,9 +230,9 @@ def main():
         cfgT = dict(wl.CONFIGS["C4"])
         kwT = wl.solver_kwargs(cfgT, 100)
         dT = mp.Dmpc("bound", device=local_rank, **kwT)
-        poT, pfT = wl.make_scenes(cfgT, 8, 100, wl.SEED0 + 100)
+        poT, pfT = wl.make_scenes(cfgT, 512, 100, wl.SEED0 + 100)
         dT.transition(poT[:1], pfT[:1], 10, cfgT["error_tol"])   # warm-up
-        for St in (1, 8):
+        for St in (1, 8, 512):
             tt = time.perf_counter()
             resT = dT.transition(poT[:St], pfT[:St], 151, cfgT["error_tol"])
             dtT = time.perf_counter() - tt

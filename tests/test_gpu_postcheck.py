@@ -166,3 +166,17 @@ def test_postcheck_mask_and_run_trial():
         ref = PC.postcheck(tr["pk"][s][:, :n], tr["vk"][s][:, :n], tr["ak"][s][:, :n], pf[s], kw["h"], kw["rmin"], kw["c"])
         assert abs(tr["totdist"][s] - ref["totdist"]) < 1e-9 and tr["violation"][s] == ref["violation"]
         assert tr["traj_time"][s] == pytest.approx(ref["traj_time"], abs=1e-12) and tr["traj_time"][s] > 0
+
+
+def test_failure_rate_experiment_statistics():
+    """test/failure_rate.m end to end at two swarm sizes: N = 20 always succeeds, N = 100 succeeds in 94 % of the
+    reference's 50 recorded trials (failure_rate2.mat) -- 128 random trials here must land in the same region."""
+    cfg = wl.CONFIGS["C4"]
+    for N, lo, hi in ((20, 1.0, 1.0), (100, 0.80, 0.995)):
+        kw = wl.solver_kwargs(cfg, N)
+        po, pf = wl.make_scenes(cfg, 128, N, wl.SEED0 + 7 * N)
+        res = driver.run_trial(mp.Dmpc("bound", **kw), po, pf, 151, cfg["error_tol"])
+        p = res["success"].mean()
+        assert lo <= p <= hi, (N, p)
+        assert not res["failed_goal"].any()                      # the reference's failures are infeasibility / collisions, not timeouts
+        assert (res["success"] == (res["feasible"] & ~res["failed_goal"] & (res["violation"] == 0))).all()
