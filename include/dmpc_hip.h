@@ -232,6 +232,22 @@ int dmpc_trajectories2file(const char *path, int N, int N_cmd, int T, double h_s
 int dmpc_test2file(const char *path, int n_cluster, int n_vehicles, int n_trials, const double *cluster_size,
                    const double *num_vehicles, const double *times);
 
+/* f-2: the reference's start/goal generators for S scenes at once.
+ * dmpc_random_test     == randomTest.m:1-60: N starts and, independently, N goals uniform in [pmin, pmax], each
+ *                         farther than rmin (|E1 (p_i - p_j)|_2, E1 = diag(1,1,1/c)) from the earlier points of its
+ *                         set; rejection sampling, <= 200000 tries per point, else the set restarts.
+ * dmpc_random_exchange == randomExchange.m:1-57: starts as above with the Euclidean distance, goals = starts
+ *                         permuted by the .m's draw-without-replacement rule (no agent keeps its own start).
+ * po, pf: [S][N][3].  MATLAB's global rand stream cannot be reproduced: draws come from a counter-based stream
+ * (splitmix64 of seed, scene, set, draw index), so a (seed, S, N, box, rmin) tuple always gives the same scenes.
+ * The _device form writes [2][S][N][3] (starts, then goals) to device memory on the caller's stream. */
+int dmpc_random_test(dmpc_ctx *ctx, int S, int N, const double *pmin, const double *pmax, double rmin, double c,
+                     uint64_t seed, double *po, double *pf);
+int dmpc_random_exchange(dmpc_ctx *ctx, int S, int N, const double *pmin, const double *pmax, double rmin, uint64_t seed,
+                         double *po, double *pf);
+int dmpc_random_sets_device(dmpc_ctx *ctx, int S, int N, const double *pmin, const double *pmax, double rmin, double c,
+                            uint64_t seed, int exchange, double *d_po_pf, void *stream);
+
 /* number of agent-QP solves launched by this context so far (for throughput accounting) */
 int64_t dmpc_solve_count(const dmpc_ctx *ctx);
 

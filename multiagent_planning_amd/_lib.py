@@ -25,7 +25,7 @@ ABI_SYMBOLS = [
     "dmpc_table_from_rows_device", "dmpc_advance_device", "dmpc_transition", "dmpc_solve_count",
     "dmpc_profile", "dmpc_profile_read", "dmpc_profile_read2", "dmpc_rows_one", "dmpc_postcheck",
     "dmpc_coll_rows", "dmpc_coll_rows_device", "dmpc_add_coll_constr", "dmpc_add_coll_constr_device",
-    "dmpc_trajectories2file", "dmpc_test2file",
+    "dmpc_trajectories2file", "dmpc_test2file", "dmpc_random_test", "dmpc_random_exchange", "dmpc_random_sets_device",
 ]
 
 
@@ -91,6 +91,9 @@ def load():
                                               i64, vp, vp]
     L.dmpc_trajectories2file.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_double, dp, dp, dp, dp, dp, dp, dp]
     L.dmpc_test2file.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, dp, dp, dp]
+    L.dmpc_random_test.argtypes = [vp, C.c_int, C.c_int, dp, dp, C.c_double, C.c_double, C.c_uint64, dp, dp]
+    L.dmpc_random_exchange.argtypes = [vp, C.c_int, C.c_int, dp, dp, C.c_double, C.c_uint64, dp, dp]
+    L.dmpc_random_sets_device.argtypes = [vp, C.c_int, C.c_int, dp, dp, C.c_double, C.c_double, C.c_uint64, C.c_int, vp, vp]
     L.dmpc_postcheck.argtypes = [vp, C.c_int, C.c_int, C.c_int, ip, ip, dp, dp, dp, dp, C.c_double, C.c_double, C.c_double,
                                  dp, dp, ip, dp, ip, dp, dp, dp, C.c_int]
     L.dmpc_solve_count.restype = C.c_int64
@@ -265,6 +268,19 @@ class Dmpc:
         if p_i is not None:
             out["p"] = p_i
         return out
+
+    # ---- start / goal generators (randomTest.m, randomExchange.m) on the device ---------------
+    def random_test(self, S, N, pmin, pmax, rmin, c, seed):
+        """S scenes of randomTest(N,pmin,pmax,rmin,E1,order=2): (po, pf) each [S,N,3]."""
+        po, pf = np.zeros((S, N, 3)), np.zeros((S, N, 3))
+        self._chk(self._L.dmpc_random_test(self._ctx, S, N, _dp(_f(pmin)), _dp(_f(pmax)), float(rmin), float(c), int(seed), _dp(po), _dp(pf)))
+        return po, pf
+
+    def random_exchange(self, S, N, pmin, pmax, rmin, seed):
+        """S scenes of randomExchange(N,pmin,pmax,rmin): (po, pf) each [S,N,3]."""
+        po, pf = np.zeros((S, N, 3)), np.zeros((S, N, 3))
+        self._chk(self._L.dmpc_random_exchange(self._ctx, S, N, _dp(_f(pmin)), _dp(_f(pmax)), float(rmin), int(seed), _dp(po), _dp(pf)))
+        return po, pf
 
     # ---- dense collision rows (CollConstr* / AddCollConstr helpers) --------------------------
     def coll_rows(self, l, sel, k_cmp, k_blk, p, a0, rmin, c, A):

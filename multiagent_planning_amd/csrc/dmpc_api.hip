@@ -18,7 +18,8 @@
 
 #include "dmpc_kernels.hip"
 #include "dmpc_postcheck.hip"
-#include "dmpc_rowbuild.hip"   // single translation unit: kernels + host ABI
+#include "dmpc_rowbuild.hip"
+#include "dmpc_generators.hip"   // single translation unit: kernels + host ABI
 
 using namespace dmpc;
 
@@ -63,7 +64,7 @@ struct dmpc_ctx {
     DevBuf rows, lT, lT2, xp, xv, xa, pf, po, pout, vout, aout, status, info, hist_p, hist_v, hist_a, flags;
     int hist_S = 0, hist_N = 0, hist_KT = 0;   // shape of the histories left resident by the last dmpc_transition
     DevBuf pc_p, pc_v, pc_a, pc_M, pc_w, pc_scene, pc_agent, pc_interp;   // post-check work buffers
-    DevBuf rb_A, rb_l, rb_sel, rb_out, rb_bin, rb_po;                     // dense row builders (host-pointer entries)
+    DevBuf rb_A, rb_l, rb_sel, rb_out, rb_bin, rb_po, gen_out;                     // dense row builders (host-pointer entries)
     // profiling
     int profile = 0;
     double *dbg = nullptr; int dbg_agent = -1, dbg_cap = 0;   // development trace (dmpc_debug_trace)
@@ -1035,3 +1036,59 @@ extern "C" int dmpc_add_coll_constr(dmpc_ctx *ctx, int K, int N, const double *p
 }
 
 #include "dmpc_fileio.hip"
+
+
+// ---------------------------------------------------------------------------------------------
+// start / goal generators (randomTest.m, randomExchange.m)
+// ---------------------------------------------------------------------------------------------
+static int random_sets(dmpc_ctx *ctx, const char *who, int S, int N, const double *pmin, const double *pmax, double rmin, double c,
+                       uint64_t seed, int exchange, double *d_out, hipStream_t st)
+{
+    if (S < 1 || N < 1 || !pmin || !pmax || !(rmin >= 0) || !(c > 0)) FAIL(ctx, std::string(who) + ": bad arguments");
+    for (int d = 0; d < 3; ++d) if (!(pmax[d] > pmin[d])) FAIL(ctx, std::string(who) + ": empty box");
+    const size_t lds = (size_t)N * 24 + (exchange ? (size_t)N * 8 : 0);
+    if (lds > 150 * 1024) FAIL(ctx, std::string(who) + ": at most ~4800 agents per scene");
+    HIPCHK(ctx, hipFuncSetAttribute((const void *)gen::random_points_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int waves = exchange ? S : 2 * S;
+    hipLaunchKernelGGL(gen::random_points_kernel, dim3((unsigned)waves), dim3(64), lds, st, S, N, 2, exchange, pmin[0], pmin[1], pmin[2],
+                       pmax[0], pmax[1], pmax[2], rmin, 1.0 / c, seed, d_out);
+    HIPCHK(ctx, hipGetLastError());
+    return 0;
+}
+
+static int random_host(dmpc_ctx *ctx, const char *who, int S, int N, const double *pmin, const double *pmax, double rmin, double c,
+                       uint64_t seed, int exchange, double *po, double *pf)
+{
+    if (!ctx) { g_err = std::string(who) + ": ctx is NULL"; return -1; }
+    if (!po || !pf || S < 1 || N < 1) FAIL(ctx, std::string(who) + ": bad arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t one = (size_t)S * N * 24;
+    if (ctx->gen_out.ensure(2 * one)) FAIL(ctx, "device allocation failed");
+    if (random_sets(ctx, who, S, N, pmin, pmax, rmin, c, seed, exchange, ctx->gen_out.as<double>(), ctx->stream)) return -1;
+    HIPCHK(ctx, hipMemcpyAsync(po, ctx->gen_out.p, one, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(pf, ctx->gen_out.as<char>() + one, one, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+extern "C" int dmpc_random_test(dmpc_ctx *ctx, int S, int N, const double *pmin, const double *pmax, double rmin, double c,
+                                uint64_t seed, double *po, double *pf)
+{
+    return random_host(ctx, "dmpc_random_test", S, N, pmin, pmax, rmin, c, seed, 0, po, pf);
+}
+
+extern "C" int dmpc_random_exchange(dmpc_ctx *ctx, int S, int N, const double *pmin, const double *pmax, double rmin, uint64_t seed,
+                                    double *po, double *pf)
+{
+    return random_host(ctx, "dmpc_random_exchange", S, N, pmin, pmax, rmin, 1.0, seed, 1, po, pf);
+}
+
+extern "C" int dmpc_random_sets_device(dmpc_ctx *ctx, int S, int N, const double *pmin, const double *pmax, double rmin, double c,
+                                       uint64_t seed, int exchange, double *d_po_pf, void *stream)
+{
+    if (!ctx) { g_err = "dmpc_random_sets_device: ctx is NULL"; return -1; }
+    if (!d_po_pf) FAIL(ctx, "dmpc_random_sets_device: bad arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    return random_sets(ctx, "dmpc_random_sets_device", S, N, pmin, pmax, rmin, exchange ? 1.0 : c, seed, exchange ? 1 : 0, d_po_pf,
+                       (hipStream_t)stream);
+}

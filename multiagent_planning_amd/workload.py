@@ -68,7 +68,7 @@ def random_exchange(N, pmin, pmax, rmin, rng=None):
             perm[i] = N - 1
             array.remove(N - 1)
         else:
-            j = int(rng.integers(0, len(aux)))
+            j = int(rng.integers(0, N - 1 - i))      # randi([1 N-i]) with the .m's 1-based i
             perm[i] = aux[j]
             array.remove(aux[j])
     return po, po[perm]
@@ -121,3 +121,14 @@ def make_scenes(cfg, S, N=None, seed=None):
         else:
             po[s], pf[s] = random_test(N, kw["pmin"], kw["pmax"], cfg["rmin_init"], cfg["c"], rng)
     return po, pf
+
+
+def make_scenes_device(dmpc, cfg, S, N=None, seed=None):
+    """make_scenes with the rejection sampling done on the GPU (dmpc_random_test / dmpc_random_exchange): S scenes in
+    one launch, one wave per point set.  Same algorithm, its own counter-based stream (seeded like make_scenes)."""
+    N = N or cfg["N"]
+    kw = solver_kwargs(cfg, N)
+    seed = SEED0 if seed is None else seed
+    if cfg.get("generator") == "random_exchange":
+        return dmpc.random_exchange(S, N, kw["pmin"], kw["pmax"], cfg["rmin_init"], seed)
+    return dmpc.random_test(S, N, kw["pmin"], kw["pmax"], cfg["rmin_init"], cfg["c"], seed)

@@ -48,3 +48,20 @@ def test_host_helpers_match_m_files():
     pk = np.zeros((3, 5, 2)); pk[:, 4, 0] = [1, 1, 1]; pk[:, 4, 1] = [2, 2, 2]
     pf = np.array([[1, 1, 1.005], [2, 2, 2]]).T.reshape(1, 3, 2)
     assert api.ReachedGoal(pk, pf, 5, 0.01, 2) and not api.ReachedGoal(pk, pf, 5, 0.001, 2)
+
+
+def test_generator_restatement_properties():
+    """oracle/generators.py (the checker of the device generators): separation, box, derangement, determinism."""
+    from oracle import generators as G
+    pmin, pmax = (-2.0, -2.0, 0.2), (2.0, 2.0, 2.2)
+    po, pf = G.random_test(2, 25, pmin, pmax, 0.35, 2.0, 5)
+    e1 = np.array([1, 1, 0.5])
+    for p in (po[0], pf[1]):
+        d = np.sqrt((((p[:, None] - p[None]) * e1) ** 2).sum(-1)) + np.eye(25) * 9
+        assert d.min() > 0.35 and (p >= pmin).all() and (p <= pmax).all()
+    again = G.random_test(2, 25, pmin, pmax, 0.35, 2.0, 5)
+    assert np.array_equal(again[0], po) and np.array_equal(again[1], pf)
+    xo, xf = G.random_exchange(3, 9, pmin, pmax, 0.5, 2)
+    for s in range(3):
+        idx = [int(np.where((xo[s] == g).all(axis=1))[0][0]) for g in xf[s]]
+        assert sorted(idx) == list(range(9)) and all(i != j for i, j in enumerate(idx))
