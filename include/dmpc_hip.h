@@ -37,7 +37,15 @@ enum {
     DMPC_VAR_ONDEMAND = 4, /* solveHardDMPCOnDemand.m:1                                         */
     DMPC_VAR_ELLIP = 5,    /* solveEllipDMPC.m:1                                                */
     DMPC_VAR_SOFTALL = 6,  /* solveSoftDMPC.m:1             (test/success_test_softdmpc.m:90)   */
-    DMPC_VAR_REPAIR = 7    /* solveSoftDMPCrepair.m:1       (test/comp_repair.m:93)             */
+    DMPC_VAR_REPAIR = 7,   /* solveSoftDMPCrepair.m:1       (test/comp_repair.m:93)             */
+    /* the C++ flavour, DMPC::solveQPv2 (dmpc/cpp/dmpc.cpp:803-1287) with _k_factor = 0 / -1 (main.cpp:37-38):
+     * bound / bound2 with the near-neighbour radius rmin*(1+(float)k/k_hor) (:418), slack bounds [-0.01f, 0] doubled on
+     * retry together with term (<= 20 retries, :1079-1088), no early return on a first-step collision (DMPC_ST_COLL is
+     * reported NEXT TO a solution, :419-424) and no in-bounds test.  All members of the C++ class are floats
+     * (dmpc.h:191-205): pass h, rmin, c, alim as (double)(float) values and term = -1e6, Q1 = 1000, S1 = 100 (:846,942-945)
+     * to reproduce its arithmetic. */
+    DMPC_VAR_CPP = 8,
+    DMPC_VAR_CPP2 = 9
 };
 
 /* per-agent status bits (the reference's feasible/success, outbound, coll flags) */

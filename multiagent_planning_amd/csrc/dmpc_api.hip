@@ -97,7 +97,7 @@ static int check_params(const dmpc_params *p, std::string &why)
     if (!p) { why = "params is NULL"; return -1; }
     if (p->K != K) { why = "only K = k_hor = 15 is supported (the value every reference script uses)"; return -1; }
     if (p->order != 2) { why = "only ellipsoid order 2 is supported (the value every reference script uses)"; return -1; }
-    if (p->variant < 0 || p->variant > DMPC_VAR_REPAIR) { why = "unknown variant"; return -1; }
+    if (p->variant < 0 || p->variant > DMPC_VAR_CPP2) { why = "unknown variant"; return -1; }
     if (!(p->h > 0) || !(p->rmin > 0) || !(p->c > 0) || !(p->alim > 0)) { why = "h, rmin, c, alim must be positive"; return -1; }
     for (int d = 0; d < 3; ++d)
         if (!(p->pmax[d] > p->pmin[d])) { why = "pmax must exceed pmin"; return -1; }
@@ -316,7 +316,8 @@ extern "C" int dmpc_profile(dmpc_ctx *ctx, int enable)
 
 static bool variant_soft(int v)
 {
-    return v == DMPC_VAR_BOUND || v == DMPC_VAR_BOUND2 || v == DMPC_VAR_ALL3 || v == DMPC_VAR_SOFTALL || v == DMPC_VAR_REPAIR;
+    return v == DMPC_VAR_BOUND || v == DMPC_VAR_BOUND2 || v == DMPC_VAR_ALL3 || v == DMPC_VAR_SOFTALL || v == DMPC_VAR_REPAIR ||
+           v == DMPC_VAR_CPP || v == DMPC_VAR_CPP2;
 }
 
 // row capacity per agent.  Rows live in global scratch (40-64 B each); LDS only holds 4-12 B per row
@@ -329,7 +330,7 @@ static int row_capacity(int variant, int N)
     switch (variant) {
     case DMPC_VAR_HARD: want = (long)K * nb; cap = 640; break;     // every k, neighbours with d < 1 (CollConstrHardDMPC.m:19), after exact pruning
     case DMPC_VAR_ALL3: want = 3 * nb; cap = 384; break;           // three steps x neighbours with d < 3 rmin
-    case DMPC_VAR_BOUND: case DMPC_VAR_BOUND2: case DMPC_VAR_ONDEMAND: want = nb; cap = 128; break;   // d < 3 rmin only
+    case DMPC_VAR_BOUND: case DMPC_VAR_BOUND2: case DMPC_VAR_ONDEMAND: case DMPC_VAR_CPP: case DMPC_VAR_CPP2: want = nb; cap = 128; break;   // d < 3 rmin only
     default: want = nb; cap = 4096; break;                         // ellip / softall / repair: all N-1 neighbours
     }
     long r = want < cap ? want : cap;

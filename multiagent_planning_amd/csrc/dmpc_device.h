@@ -12,7 +12,8 @@ constexpr int QMAX = 64;      // working-set capacity (slots of the inverse fact
 __host__ __device__ inline int t_doubles(int qcap) { const int c = (qcap + 7) & ~7; const int g = c >> 3; return 8 * (g + 1) * (c - 4 * g) + 64; }
 constexpr int ITER_CAP = 4000;
 
-enum { VAR_BOUND = 0, VAR_BOUND2 = 1, VAR_ALL3 = 2, VAR_HARD = 3, VAR_ONDEMAND = 4, VAR_ELLIP = 5, VAR_SOFTALL = 6, VAR_REPAIR = 7 };
+enum { VAR_BOUND = 0, VAR_BOUND2 = 1, VAR_ALL3 = 2, VAR_HARD = 3, VAR_ONDEMAND = 4, VAR_ELLIP = 5, VAR_SOFTALL = 6, VAR_REPAIR = 7,
+       VAR_CPP = 8, VAR_CPP2 = 9 /* dmpc/cpp solveQPv2 with _k_factor 0 / -1 */ };
 enum { ST_SOLVED = 1, ST_OUTBOUND = 2, ST_COLL = 4, ST_INFEAS = 8, ST_CAPACITY = 16, ST_ITERCAP = 32,
        ST_QOVER = 64 /* internal: tier-1 working set overflowed, tier 2 re-solves */ };
 

@@ -481,9 +481,11 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
     int ladder_start = 0;   // first retry-ladder level that is not certainly infeasible (soft ladder variants)
     bool rows_exist = false, violation = false;
     const double rmin = P.rmin;
-    const bool near_sel = (var == VAR_BOUND || var == VAR_BOUND2 || var == VAR_ALL3 || var == VAR_ONDEMAND);
+    const bool cppv = (var == VAR_CPP || var == VAR_CPP2);   // dmpc/cpp solveQPv2 flavour (dmpc.cpp:803-1287)
+    const bool near_sel = (var == VAR_BOUND || var == VAR_BOUND2 || var == VAR_ALL3 || var == VAR_ONDEMAND || cppv);
     const bool coll_check = (var == VAR_BOUND || var == VAR_BOUND2 || var == VAR_ALL3 || var == VAR_REPAIR);
-    const bool skip_k1 = (var == VAR_BOUND2 || var == VAR_ALL3 || var == VAR_REPAIR);
+    const bool skip_k1 = (var == VAR_BOUND2 || var == VAR_ALL3 || var == VAR_REPAIR || var == VAR_CPP2);
+    bool coll_flag = false;
     // own horizon box (uniform) for the neighbour culling, PHASE 0 only
     double obx0 = 0, obx1 = 0, oby0 = 0, oby1 = 0, obz0 = 0, obz1 = 0;
     if (PHASE == 0) {
@@ -532,12 +534,12 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
                     const double lin_max = lin_min + 2.0 * (fabs(x0) + fabs(x1) + fabs(x2)) * hw;
                     if (!soft) {
                         if (lin_max < dist * rmin - 1e-9) cert_infeasible = true;
-                    } else if (var == VAR_BOUND || var == VAR_BOUND2 || var == VAR_ALL3) {
+                    } else if (var == VAR_BOUND || var == VAR_BOUND2 || var == VAR_ALL3 || cppv) {
                         // Soft rows with a bounded slack (coefficient dist): the row needs
                         //   lin >= dist*(rmin + eps),  eps >= slb * 2^t at ladder level t (solveSoftDMPCbound.m:147-153),
                         // so every level with lin_max < dist*(rmin + slb 2^t) is certainly infeasible and the
                         // retry ladder can start at the first level that passes this necessary test.
-                        double slb_t = (var == VAR_BOUND) ? -0.05 : -0.01;
+                        double slb_t = (var == VAR_BOUND) ? -0.05 : (cppv ? -(double)0.01f : -0.01);
                         int t = 0;
                         while (t < 40 && lin_max < dist * (rmin + slb_t) - 1e-9) { slb_t *= 2.0; ++t; }
                         if (t > ladder_start) ladder_start = t;
@@ -555,6 +557,7 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
                     if (soft) {
                     double sd = dist, st = P.term, slb = -0.05;
                     if (var == VAR_BOUND2 || var == VAR_ALL3) slb = -0.01;           // bound2:77, all:92
+                    else if (cppv) slb = -(double)0.01f;                              // dmpc.cpp:907-914,1079: -eps <= lim, float lim = 0.01
                     else if (var == VAR_SOFTALL) { sd = 1.0; st = -1e5; slb = -INFINITY; }  // solveSoftDMPC.m:21,65
                     else if (var == VAR_REPAIR) { st = P.term / dist; slb = -INFINITY; }    // repair:77,81
                     L.r_sd[pos] = sd; L.r_st[pos] = st; L.r_slb[pos] = slb;
@@ -651,9 +654,11 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
             for (int k = 0; k < K; ++k) {
                 if (!((anyb >> k) & 1u)) continue;
                 if (var == VAR_ALL3) violation = true;   // solveSoftDMPCall.m:22 (some_violation)
-                if (coll_check && k == 0) {
+                if ((coll_check || cppv) && k == 0) {
                     mind0 = sqrt(wave_min(mind0));   // min of the roots == root of the min (sqrt is monotone)
-                    if (mind0 < rmin - 0.05) { status = ST_COLL; viol_k = 1; break; }   // :25-31
+                    if (coll_check && mind0 < rmin - 0.05) { status = ST_COLL; viol_k = 1; break; }   // :25-31
+                    // cpp: `dist < _rmin - _collision_tol` (floats) raises execution_ended, the build goes on (dmpc.cpp:419-424)
+                    if (cppv && mind0 < (double)((float)rmin - 0.05f)) coll_flag = true;
                 }
                 if (skip_k1 && k == 0) continue;          // solveSoftDMPCbound2.m:29-31
                 viol_k = k + 1; violation = true; rows_exist = true;
@@ -661,8 +666,11 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
                     const int k0 = (k == 1) ? k : k - 1, k1 = (k == K - 1) ? k : k + 1;
                     for (int kk = k0; kk <= k1; ++kk) build_rows(k, kk, kk, 3.0 * rmin, false);
                 } else {
-                    const int kc = (var == VAR_BOUND2) ? k - 1 : k;   // CollConstrSoftDMPC2.m:8
-                    build_rows(k, k, kc, 3.0 * rmin, !near_sel);
+                    const int kc = (var == VAR_BOUND2 || var == VAR_CPP2) ? k - 1 : k;   // CollConstrSoftDMPC2.m:8; dmpc.cpp:516
+                    // neighbour radius: 3 rmin (CheckCollSoftDMPC.m:12); cpp: _rmin*(1+(float)k/_k_hor) in float arithmetic
+                    // (dmpc.cpp:418) -- __f*_rn keep the three float operations unfused
+                    const double near_r = cppv ? (double)__fmul_rn((float)rmin, __fadd_rn(1.0f, __fdiv_rn((float)k, (float)K))) : 3.0 * rmin;
+                    build_rows(k, k, kc, near_r, !near_sel);
                 }
                 break;
             }
@@ -672,7 +680,7 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
         if (__any(cert_infeasible)) status |= ST_INFEAS;
         if (lane == 0) {
             hdr[0] = nr; hdr[1] = nrows_ref; hdr[2] = viol_k; hdr[3] = status;
-            hdr[4] = violation ? 1 : 0; hdr[5] = rows_exist ? 1 : 0; hdr[6] = 0; hdr[7] = 0;
+            hdr[4] = (violation ? 1 : 0) | (coll_flag ? 4 : 0); hdr[5] = rows_exist ? 1 : 0; hdr[6] = 0; hdr[7] = 0;
         }
         {
             const int ls = (int)wave_max((double)ladder_start);
@@ -758,9 +766,9 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
     const long long tk2 = clock64();
     long long tkA = 0, tkB = 0, tkC = 0, tkD = 0, tkE = 0, tkF = 0, tkG = 0;
     // ---------------------------------------------------------------- a7: dual active-set solve
-    const bool ladder = soft && (var == VAR_BOUND || var == VAR_BOUND2 || var == VAR_ALL3);
+    const bool ladder = soft && (var == VAR_BOUND || var == VAR_BOUND2 || var == VAR_ALL3 || cppv);
     constexpr int LADDER_CERT_AFTER = 16;
-    const int max_tries = P.max_tries > 0 ? P.max_tries : 30;
+    const int max_tries = P.max_tries > 0 ? P.max_tries : (cppv ? 21 : 30);   // cpp: one solve + 20 retries (dmpc.cpp:1081)
     // a tier-2 relaunch resumes the retry ladder where tier 1 left it (the row data in global memory already
     // carries the doublings of the tries that were proven infeasible)
     // hdr[6] = retry-ladder levels already known to be infeasible (certified by the scan, or proven by a
@@ -1198,7 +1206,8 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
         a_out = a;
     }
     if (solved) {
-        const bool ob_check = !(var == VAR_ELLIP || var == VAR_SOFTALL);
+        const bool ob_check = !(var == VAR_ELLIP || var == VAR_SOFTALL || cppv);   // solveQPv2 has no in-bounds test
+        if (hdr[4] & 4) status |= ST_COLL;   // cpp: collision noticed at the first step, solution still returned
         if (ob_check) {   // is_inbounds.m:2-5 on p(:,1)
             const double tolb = 50e-3;
             bool bad = false;

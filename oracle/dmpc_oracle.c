@@ -461,7 +461,17 @@ typedef struct {
     int nblocks;    /* number of row blocks (all3: up to 3, else 1; hard: K) */
     int rows_exist; /* ~isempty(Ain_coll) in the .m sense */
     int violation;  /* any(violation) / some_violation flag used for slack augmentation */
+    int coll_flag;  /* cpp flavour: collision at the first step noticed, solve continues (dmpc.cpp:419-424) */
 } scan_t;
+
+/* dmpc.cpp:418  `_rmin*(1+(float)k/_k_hor)`: every operand is a float, so is the product (volatile: no contraction) */
+static double cpp_near_radius(double rmin, int k0, int K)
+{
+    volatile float q = (float)k0 / (float)K;
+    volatile float one_q = 1.0f + q;
+    volatile float r = (float)rmin * one_q;
+    return (double)r;
+}
 
 /* solveSoftDMPCbound.m:21-38 and the corresponding loops of the other variants */
 static scan_t scan_and_rows(const ctx_t *c, const orc_params *prm, int N, int n, const double *l,
@@ -485,9 +495,10 @@ static scan_t scan_and_rows(const ctx_t *c, const orc_params *prm, int N, int n,
         sc.nblocks = K;
         return sc;
     }
-    const int soft_near = (var == ORC_BOUND || var == ORC_BOUND2 || var == ORC_ALL3 || var == ORC_ONDEMAND);
+    const int cpp = (var == ORC_CPP || var == ORC_CPP2);
+    const int soft_near = (var == ORC_BOUND || var == ORC_BOUND2 || var == ORC_ALL3 || var == ORC_ONDEMAND || cpp);
     const int coll_check = (var == ORC_BOUND || var == ORC_BOUND2 || var == ORC_ALL3 || var == ORC_REPAIR);
-    const int skip_k1 = (var == ORC_BOUND2 || var == ORC_ALL3 || var == ORC_REPAIR);
+    const int skip_k1 = (var == ORC_BOUND2 || var == ORC_ALL3 || var == ORC_REPAIR || var == ORC_CPP2);
     unsigned char *sel = (unsigned char *)malloc((size_t)N);
     for (int k = 1; k <= K; ++k) {
         int any = 0, cnt = 0;
@@ -498,10 +509,15 @@ static scan_t scan_and_rows(const ctx_t *c, const orc_params *prm, int N, int n,
             double d = edist(&own[3 * (k - 1)], &l[(size_t)j * n3 + 3 * (k - 1)], prm->c);
             if (d < rmin) any = 1;               /* CheckCollSoftDMPC.m:11 */
             if (d < mind) mind = d;
-            if (soft_near ? (d < rmin * (3)) : 1) { sel[j] = 1; cnt++; } /* CheckCollSoftDMPC.m:12 */
+            /* CheckCollSoftDMPC.m:12; cpp: viol_constr = dist < _rmin*(1+(float)k/_k_hor), float arithmetic, k 0-based
+             * (dmpc.cpp:418; _rmin is a float member, dmpc.h:196) */
+            const double near_r = cpp ? cpp_near_radius(rmin, k - 1, K) : rmin * (3);
+            if (soft_near ? (d < near_r) : 1) { sel[j] = 1; cnt++; }
         }
         if (!any) continue;
         if (var == ORC_ALL3) sc.violation = 1; /* solveSoftDMPCall.m:22: some_violation set before the k==1 tests */
+        /* cpp: `dist < _rmin - _collision_tol` (floats) only raises execution_ended, the build goes on (dmpc.cpp:419-424) */
+        if (cpp && k == 1 && mind < (double)((float)rmin - 0.05f)) sc.coll_flag = 1;
         if (coll_check && k == 1 && mind < rmin - 0.05) { /* solveSoftDMPCbound.m:25-31 */
             sc.status = ORC_ST_COLL;
             sc.viol_k = 1;
@@ -524,7 +540,7 @@ static scan_t scan_and_rows(const ctx_t *c, const orc_params *prm, int N, int n,
                     if (sel[j]) build_row(c, prm, l, n, j, ks[t], ks[t], x0, R);
         } else {
             sc.nblocks = 1;
-            int kc = (var == ORC_BOUND2) ? k - 1 : k; /* CollConstrSoftDMPC2.m:8 */
+            int kc = (var == ORC_BOUND2 || var == ORC_CPP2) ? k - 1 : k; /* CollConstrSoftDMPC2.m:8; dmpc.cpp:516 k_ctr = k + _k_factor */
             for (int j = 0; j < N; ++j)
                 if (sel[j]) build_row(c, prm, l, n, j, k, kc, x0, R);
         }
@@ -556,6 +572,8 @@ static slackcfg_t slack_cfg(const orc_params *prm)
     case ORC_BOUND2: s.has_slack = 1; s.coef_is_dist = 1; s.lb = -0.01; s.lin = prm->term; break;  /* bound2:77 */
     case ORC_ALL3: s.has_slack = 1; s.coef_is_dist = 1; s.lb = -0.01; s.lin = prm->term; break;    /* all:92 */
     case ORC_SOFTALL: s.has_slack = 1; s.coef_is_dist = 0; s.lb = -INFINITY; s.lin = -1e5; s.ub_as_row = 1; break; /* solveSoftDMPC.m:21,65 */
+    case ORC_CPP: case ORC_CPP2: /* dmpc.cpp:907-914: eps <= 0, -eps <= lim with float lim = 0.01 (:1079); term = -1e6 via params */
+        s.has_slack = 1; s.coef_is_dist = 1; s.lb = -(double)0.01f; s.lin = prm->term; break;
     case ORC_REPAIR: s.has_slack = 1; s.coef_is_dist = 1; s.lb = -INFINITY; s.lin = prm->term; s.lin_over_dist = 1; break; /* repair:33,77,81 */
     default: break;
     }
@@ -665,8 +683,10 @@ static int solve_ctx(ctx_t *c, const orc_params *prm, int N, int n, const double
     info[ORC_I_CASE] = which;
     hcase_t *hc = ctx_case(c, qw, sw);
     slackcfg_t sl = slack_cfg(prm);
-    const int ladder = (prm->variant == ORC_BOUND || prm->variant == ORC_BOUND2 || prm->variant == ORC_ALL3);
-    int max_tries = prm->max_tries > 0 ? prm->max_tries : (prm->variant == ORC_REPAIR ? 10 : 30);
+    const int cppv = (prm->variant == ORC_CPP || prm->variant == ORC_CPP2);
+    const int ladder = (prm->variant == ORC_BOUND || prm->variant == ORC_BOUND2 || prm->variant == ORC_ALL3 || cppv);
+    /* cpp: one solve + `while (status && tries < 20)` retries (dmpc.cpp:1081) */
+    int max_tries = prm->max_tries > 0 ? prm->max_tries : (prm->variant == ORC_REPAIR ? 10 : (cppv ? 21 : 30));
     double lbs = sl.lb, lin = sl.lin;
     int tries = 0, status = ORC_ST_INFEAS;
     while (tries < max_tries) {
@@ -725,7 +745,8 @@ static int solve_ctx(ctx_t *c, const orc_params *prm, int N, int n, const double
             info[ORC_I_NSLACK] = nsl;
             info[ORC_I_NACTIVE] = nact;
             status = ORC_ST_SOLVED;
-            const int ob_check = !(prm->variant == ORC_ELLIP || prm->variant == ORC_SOFTALL);
+            const int ob_check = !(prm->variant == ORC_ELLIP || prm->variant == ORC_SOFTALL || cppv); /* solveQPv2 has no in-bounds test */
+            if (sc.coll_flag) status |= ORC_ST_COLL;
             if (ob_check && !in_bounds(p, prm->pmin, prm->pmax)) status |= ORC_ST_OUTBOUND; /* :125-128 */
             free(x); free(lam); qp_free(&qp);
             tries++;

@@ -32,7 +32,9 @@ enum {
     ORC_ONDEMAND = 4,   /* solveHardDMPCOnDemand.m     */
     ORC_ELLIP = 5,      /* solveEllipDMPC.m            */
     ORC_SOFTALL = 6,    /* solveSoftDMPC.m             */
-    ORC_REPAIR = 7      /* solveSoftDMPCrepair.m       */
+    ORC_REPAIR = 7,     /* solveSoftDMPCrepair.m       */
+    ORC_CPP = 8,        /* dmpc/cpp DMPC::solveQPv2, _k_factor = 0  (dmpc.cpp:803-1287) */
+    ORC_CPP2 = 9        /* dmpc/cpp DMPC::solveQPv2, _k_factor = -1                      */
 };
 
 /* status bits returned per agent */
@@ -47,7 +49,7 @@ typedef struct {
     int K;          /* horizon length k_hor (15)                         */
     int variant;    /* ORC_*                                             */
     int order;      /* ellipsoid order; only 2 is supported              */
-    int max_tries;  /* <=0: reference default (30; repair: 10)           */
+    int max_tries;  /* <=0: reference default (30; repair: 10; cpp: 21)  */
     double h;       /* time step                                         */
     double rmin;    /* collision radius                                  */
     double c;       /* E = diag(1,1,c)                                   */

@@ -99,3 +99,42 @@ def test_many_scenes_and_odd_sizes():
         for s in range(S):
             ref = orc.step(prm, l[s], po[s], z[s], z[s], pf[s])
             compare_to_oracle({k: v[s] for k, v in out.items()}, ref, 1e-9, f"N={N} scene {s}")
+
+
+def test_cpp_flavour_semantics():
+    """DMPC::solveQPv2 (dmpc/cpp/dmpc.cpp:803-1287) next to its MATLAB siblings: growing near-neighbour radius
+    rmin*(1+(float)k/k_hor), a first-step collision is flagged next to a solution, no in-bounds flag, 21 solves at most.
+    No output of that code path is recorded in the reference (parity unpinned): the checker is the oracle's literal
+    restatement of the C++ text."""
+    f32 = lambda x: float(np.float32(x))
+    kwc = dict(KW, h=f32(0.2), rmin=f32(0.35), c=f32(2.0), alim=f32(1.0), term=-1e6)
+    # first-step collision: bound returns COLL without outputs, cpp returns a solution AND the flag (dmpc.cpp:419-424)
+    po = np.array([[0.0, 0.0, 1.0], [0.2, 0.0, 1.0], [2.0, 2.0, 1.0]])
+    pf = np.array([[1.0, 0.0, 1.0], [-1.0, 0.0, 1.0], [0.0, 0.0, 1.0]])
+    z = np.zeros((3, 3))
+    l = init_table(po, pf)
+    for variant in ("cpp", "cpp2"):
+        d = mp.Dmpc(variant, **kwc)
+        out = d.step_batch(l, po, z, z, pf)
+        ref = orc.step(orc.make_params(variant, **kwc), l, po, z, z, pf)
+        compare_to_oracle(out, ref, 1e-9, variant)
+        assert out["status"][0] & mp.ST_COLL and out["status"][1] & mp.ST_COLL and out["status"][2] == 1
+        assert (out["status"][:2] & (mp.ST_SOLVED | mp.ST_INFEAS)).all()          # solved or proven infeasible, never silently dropped
+    # the neighbour radius: a neighbour at 1.5 rmin is a row for `bound` (3 rmin) at every step, for cpp only once
+    # rmin (1 + k/15) >= 1.5 rmin, i.e. from k = 8 (0-based) on; violation first seen at horizon step 3 -> no row there
+    rm = kwc["rmin"]
+    po = np.array([[0.0, 0.0, 1.0], [0.9 * rm, 0.0, 1.0], [0.0, 1.5 * rm, 1.0]])
+    pf = po.copy()
+    l = np.tile(po[:, None, :], (1, 15, 1)).reshape(3, 45)                  # everybody predicted to stay put
+    l3 = l.reshape(3, 15, 3).copy(); l3[1, :2, 0] = 1.2 * rm; l = l3.reshape(3, 45)   # agent 1 only comes close from step 3 on
+    rows_b = mp.Dmpc("bound", **kwc).rows_one(l, 0, po[0], z[0])
+    rows_c = mp.Dmpc("cpp", **kwc).rows_one(l, 0, po[0], z[0])
+    assert rows_b["viol_k"] == rows_c["viol_k"] == 3 and len(rows_b["kc"]) == 2 and len(rows_c["kc"]) == 1
+    ref_c = orc.rows_one(orc.make_params("cpp", **kwc), l, 0, po[0], z[0])
+    assert ref_c["nrows"] == 1 and np.abs(ref_c["b"][0] - rows_c["rhs"][0]) < 1e-12
+    # outbound is never reported by the C++ flavour
+    po = np.array([[2.49, 0.0, 1.0], [-2.0, 0.0, 1.0]])
+    pf = np.array([[0.0, 0.0, 1.0], [0.0, 1.0, 1.0]])
+    xv = np.array([[0.3, 0.0, 0.0], [0.0, 0.0, 0.0]])
+    out = mp.Dmpc("cpp", **kwc).step_batch(init_table(po, pf), po, xv, z[:2], pf)
+    assert not (out["status"] & mp.ST_OUTBOUND).any()
