@@ -214,6 +214,11 @@ int dmpc_coll_rows_device(dmpc_ctx *ctx, int K, int n_sel, const int32_t *d_sel,
                           int64_t a_cs, int ncols, double *d_Ain, int64_t o_rs, int64_t o_cs, double *d_bin, double *d_dist,
                           void *stream);
 
+/* dense form of structured rows as dmpc_rows_one returns them: Ain(r,:) = -(xi_r . A(3 kc_r - 2 .. 3 kc_r, :)), kc 1-based
+ * (`Ain_total(idx,:) = -diff_mat*Ain`, CollConstrSoftDMPC.m:24-27).  xi [nr][3], kc [nr]; A / Ain strided as above. */
+int dmpc_rows_dense(dmpc_ctx *ctx, int nr, const double *xi, const int32_t *kc, const double *A, int a_rows, int ncols,
+                    int64_t a_rs, int64_t a_cs, double *Ain, int64_t o_rs, int64_t o_cs);
+
 /* cup-SCP/AddCollConstr.m:1-31: the K N(N-1)/2 pairwise rows (pairs i<j in order, k fastest) of the coupled QP
  *     r = dist (rmin - dist) + diff.(p_i,k - p_j,k) - diff.(po_i - po_j)
  *     Ain(row,:) = -(diff . A(blk(i,k),:) - diff . A(blk(j,k),:)),  blk(i,k) = rows 3K(i-1)+3(k-1)+1..3;  bin = -r
@@ -255,6 +260,20 @@ int dmpc_random_exchange(dmpc_ctx *ctx, int S, int N, const double *pmin, const 
                          double *po, double *pf);
 int dmpc_random_sets_device(dmpc_ctx *ctx, int S, int N, const double *pmin, const double *pmax, double rmin, double c,
                             uint64_t seed, int exchange, double *d_po_pf, void *stream);
+
+/* Standalone forms of the path's small helpers (fused into the step kernels inside the solvers), for callers that
+ * invoke them on their own as the reference's scripts do.  Host pointers, synchronous.
+ *   dmpc_prop_state   propStatedmpc.m:1-8 (A_initp given): p = A_p a + A_initp [po;vo], v = A_v a + 1 (x) vo  -> pass
+ *                     off_v = vo; dec-iSCP/propState.m:1-10 (A_initp = NULL): new_p + repmat(po) -> pass off_p = po.
+ *                     A_p, A_v: [n_rows][n_cols] row-major, A_initp: [n_rows][6] or NULL; off_p/off_v: 3-vectors tiled
+ *                     over the rows (or NULL).
+ *   dmpc_is_inbounds  is_inbounds.m:1-6 on npts points [npts][3] (5 cm tolerance)
+ *   dmpc_reached_goal ReachedGoal.m:1-11: max_i |p_i - pf_i| < error_tol, p, pf [N][3] */
+int dmpc_prop_state(dmpc_ctx *ctx, int n_rows, int n_cols, const double *A_p, const double *A_v, const double *A_initp,
+                    const double *po, const double *vo, const double *off_p, const double *off_v, const double *a,
+                    double *p, double *v);
+int dmpc_is_inbounds(dmpc_ctx *ctx, int npts, const double *p, const double *pmin, const double *pmax, int32_t *inbounds);
+int dmpc_reached_goal(dmpc_ctx *ctx, int N, const double *p, const double *pf, double error_tol, int32_t *reached);
 
 /* number of agent-QP solves launched by this context so far (for throughput accounting) */
 int64_t dmpc_solve_count(const dmpc_ctx *ctx);

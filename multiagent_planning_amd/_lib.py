@@ -26,6 +26,7 @@ ABI_SYMBOLS = [
     "dmpc_profile", "dmpc_profile_read", "dmpc_profile_read2", "dmpc_rows_one", "dmpc_postcheck",
     "dmpc_coll_rows", "dmpc_coll_rows_device", "dmpc_add_coll_constr", "dmpc_add_coll_constr_device",
     "dmpc_trajectories2file", "dmpc_test2file", "dmpc_random_test", "dmpc_random_exchange", "dmpc_random_sets_device",
+    "dmpc_prop_state", "dmpc_is_inbounds", "dmpc_reached_goal", "dmpc_rows_dense",
 ]
 
 
@@ -94,6 +95,10 @@ def load():
     L.dmpc_random_test.argtypes = [vp, C.c_int, C.c_int, dp, dp, C.c_double, C.c_double, C.c_uint64, dp, dp]
     L.dmpc_random_exchange.argtypes = [vp, C.c_int, C.c_int, dp, dp, C.c_double, C.c_uint64, dp, dp]
     L.dmpc_random_sets_device.argtypes = [vp, C.c_int, C.c_int, dp, dp, C.c_double, C.c_double, C.c_uint64, C.c_int, vp, vp]
+    L.dmpc_rows_dense.argtypes = [vp, C.c_int, dp, ip, dp, C.c_int, C.c_int, i64, i64, dp, i64, i64]
+    L.dmpc_prop_state.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, dp, dp, dp, dp]
+    L.dmpc_is_inbounds.argtypes = [vp, C.c_int, dp, dp, dp, ip]
+    L.dmpc_reached_goal.argtypes = [vp, C.c_int, dp, dp, C.c_double, ip]
     L.dmpc_postcheck.argtypes = [vp, C.c_int, C.c_int, C.c_int, ip, ip, dp, dp, dp, dp, C.c_double, C.c_double, C.c_double,
                                  dp, dp, ip, dp, ip, dp, dp, dp, C.c_int]
     L.dmpc_solve_count.restype = C.c_int64
@@ -269,6 +274,31 @@ class Dmpc:
             out["p"] = p_i
         return out
 
+    # ---- standalone small helpers (propStatedmpc.m, propState.m, is_inbounds.m, ReachedGoal.m) -----------
+    def prop_state(self, A_p, A_v, a, A_initp=None, po=None, vo=None, off_p=None, off_v=None):
+        A_p, A_v, a = _f(A_p), _f(A_v), _f(np.ravel(a))
+        n_rows, n_cols = A_p.shape
+        assert A_v.shape == A_p.shape and a.size == n_cols
+        nul = C.POINTER(C.c_double)()
+        opt = lambda x: _dp(_f(np.ravel(x))) if x is not None else nul
+        A0 = _f(A_initp) if A_initp is not None else None
+        p, v = np.zeros(n_rows), np.zeros(n_rows)
+        self._chk(self._L.dmpc_prop_state(self._ctx, n_rows, n_cols, _dp(A_p), _dp(A_v), _dp(A0) if A0 is not None else nul, opt(po), opt(vo),
+                                          opt(off_p), opt(off_v), _dp(a), _dp(p), _dp(v)))
+        return p, v
+
+    def is_inbounds(self, p, pmin, pmax):
+        p = _f(np.asarray(p, float).reshape(-1, 3))
+        out = np.zeros(1, dtype=np.int32)
+        self._chk(self._L.dmpc_is_inbounds(self._ctx, p.shape[0], _dp(p), _dp(_f(np.ravel(pmin))), _dp(_f(np.ravel(pmax))), _ip(out)))
+        return bool(out[0])
+
+    def reached_goal(self, p, pf, error_tol):
+        p, pf = _f(np.asarray(p, float).reshape(-1, 3)), _f(np.asarray(pf, float).reshape(-1, 3))
+        out = np.zeros(1, dtype=np.int32)
+        self._chk(self._L.dmpc_reached_goal(self._ctx, p.shape[0], _dp(p), _dp(pf), float(error_tol), _ip(out)))
+        return bool(out[0])
+
     # ---- start / goal generators (randomTest.m, randomExchange.m) on the device ---------------
     def random_test(self, S, N, pmin, pmax, rmin, c, seed):
         """S scenes of randomTest(N,pmin,pmax,rmin,E1,order=2): (po, pf) each [S,N,3]."""
@@ -297,6 +327,15 @@ class Dmpc:
         self._chk(self._L.dmpc_coll_rows(self._ctx, K, N_obs, n_sel, _ip(sel), _dp(l), int(k_cmp), int(k_blk), _dp(_f(p)), _dp(_f(a0)),
                                          float(rmin), float(c), base, a_rows, ncols, rs, cs, _dp(Ain), ncols, 1, _dp(b), _dp(d)))
         return Ain, b, d
+
+    def rows_dense(self, xi, kc, A):
+        """structured rows (xi [nr,3], kc [nr] 1-based) -> dense Ain [nr, ncols] = -(xi . A(3kc-2:3kc, :))."""
+        xi, A = _f(np.asarray(xi, float).reshape(-1, 3)), np.ascontiguousarray(A, dtype=np.float64)
+        kc = np.ascontiguousarray(kc, dtype=np.int32)
+        nr, (a_rows, ncols) = xi.shape[0], A.shape
+        Ain = np.zeros((nr, ncols))
+        self._chk(self._L.dmpc_rows_dense(self._ctx, nr, _dp(xi), _ip(kc), _dp(A), a_rows, ncols, ncols, 1, _dp(Ain), ncols, 1))
+        return Ain
 
     def add_coll_constr(self, p, po, rmin, c, A, out_order="C"):
         """cup-SCP pairwise rows: p [N,K,3], po [N,3], A [3KN, ncols] -> (Ain [K N(N-1)/2, ncols], bin).

@@ -140,59 +140,62 @@ def getModelMats(h, k_hor):
 
 def propStatedmpc(po, vo, a, A_initp, A_p, A_v):
     """[p,v] = propStatedmpc(po,vo,a,A_initp,A_p,A_v)  (propStatedmpc.m:1-8); stacked 3K vectors.
-    (Inside the solvers this step is fused into the HIP kernel; this standalone form is plain host
-    linear algebra on caller-supplied matrices, exactly the two products of the .m file.)"""
-    a = np.ravel(a)
-    x0 = np.r_[np.ravel(po), np.ravel(vo)]
-    return A_p @ a + A_initp @ x0, A_v @ a + np.tile(np.ravel(vo), a.size // 3)
+    (Inside the solvers this step is fused into the HIP kernel; the standalone form runs the same two products on
+    the device through dmpc_prop_state.)"""
+    return _rowctx().prop_state(A_p, A_v, a, A_initp=A_initp, po=po, vo=vo, off_v=vo)
 
 
 def propState(po, a, A_p, A_v, K):
     """[p,v] = propState(po,a,A_p,A_v,K)  (dec-iSCP/propState.m:1-10): zero initial velocity, the
     initial state prepended."""
-    a = np.ravel(a)
-    po = np.ravel(po)
-    new_p, new_v = A_p @ a, A_v @ a
-    return np.r_[po, new_p + np.tile(po, K - 1)], np.r_[np.zeros(3), new_v]
+    po = np.ravel(po).astype(float)
+    new_p, new_v = _rowctx().prop_state(A_p, A_v, a, off_p=po)           # new_p + repmat(po', K-1, 1)
+    return np.r_[po, new_p], np.r_[np.zeros(3), new_v]
 
 
 def initDMPC(po, pf, h, k_hor, K):
-    """[p,v,a] = initDMPC(po,pf,h,k_hor,K)  (initDMPC.m:1-13), 3 x k_hor each."""
-    po, pf = np.ravel(po).astype(float), np.ravel(pf).astype(float)
-    t = np.arange(k_hor) * h
-    p = po[:, None] + 1 * t[None, :] * (pf - po)[:, None] / 10
-    return p, np.zeros((3, k_hor)), np.zeros((3, k_hor))
+    """[p,v,a] = initDMPC(po,pf,h,k_hor,K)  (initDMPC.m:1-13), 3 x k_hor each (dmpc_init_batch)."""
+    if int(k_hor) != 15:
+        raise NotImplementedError("horizon k_hor = 15 only (SURVEY.md section 8)")
+    d = _ctx("bound", h, k_hor, 0.35, (0, 0, 0), (1, 1, 1), 1.0, 1000.0, 100.0, np.diag([1.0, 1.0, 0.5]), 2, -5e4)
+    p, v, a = d.init_batch(np.ravel(po).astype(float)[None, None, :], np.ravel(pf).astype(float)[None, None, :])
+    f = lambda x: np.ascontiguousarray(np.asarray(x).reshape(k_hor, 3).T)
+    return f(p), f(v), f(a)
 
 
 def is_inbounds(p, pmin, pmax):
-    """inbounds = is_inbounds(p,pmin,pmax)  (is_inbounds.m:1-6)."""
-    p = np.asarray(p, float).reshape(3, -1)
-    tol = 50e-3
-    return bool(np.all(p.max(axis=1) < np.ravel(pmax) + tol) and np.all(p.min(axis=1) > np.ravel(pmin) - tol))
+    """inbounds = is_inbounds(p,pmin,pmax)  (is_inbounds.m:1-6); p is 3 x n."""
+    return _rowctx().is_inbounds(np.asarray(p, float).reshape(3, -1).T, pmin, pmax)
 
 
 def ReachedGoal(p, pf, length_t, error_tol, N):
     """pass = ReachedGoal(p,pf,length_t,error_tol,N)  (ReachedGoal.m:1-11); p is 3 x T x N, pf 1 x 3 x N."""
     p = np.asarray(p, float)
     if N > 1:
-        differ = p[:, length_t - 1, :] - np.asarray(pf, float).reshape(3, N)
+        cur, goal = p[:, length_t - 1, :].T, np.asarray(pf, float).reshape(3, N).T
     else:
-        differ = p[:, length_t - 1].reshape(3, 1) - np.ravel(pf).reshape(3, 1)
-    return bool(np.sqrt((differ ** 2).sum(axis=0)).max() < error_tol)
+        cur, goal = p[:, length_t - 1].reshape(1, 3), np.ravel(pf).reshape(1, 3)
+    return _rowctx().reached_goal(cur, goal, error_tol)
 
 
 # ---- a5/a6 helpers -------------------------------------------------------------------------------
 
 def CheckCollSoftDMPC(p, l, n, k, E1, rmin, order):
     """[violation,min_dist,viol_constr] = CheckCollSoftDMPC(p,l,n,k,E1,rmin,order)  (CheckCollSoftDMPC.m:1-17).
-    Host mirror of one scan step (inside the solvers the whole scan runs fused on the GPU)."""
+    One scan step on its own (inside the solvers the whole scan runs fused in dmpc_scan_kernel): the ellipsoidal
+    distances come from the device row builder (dmpc_coll_rows), the two thresholds are applied to them here."""
     l = np.asarray(l, float)
     N = l.shape[2]
-    d = np.linalg.norm(np.asarray(E1) @ (np.ravel(p)[:, None] - l[:, k - 1, :]), ord=order, axis=0)
-    mask = np.arange(N) != (n - 1)
-    violation = np.where(mask, d < rmin, False).astype(float)
-    viol_constr = np.where(mask, d < rmin * 3, False).astype(float)
-    return violation, float(d[mask].min()) if mask.any() else np.inf, viol_constr
+    E1 = np.asarray(E1, float)
+    c = _c_of(E1, E1 @ E1, order)
+    others = [j for j in range(N) if j != n - 1]
+    d = np.full(N, np.inf)
+    if others:
+        _, _, dist = _rowctx().coll_rows(_obst(l), others, k - 1, 0, np.ravel(p), np.zeros(3), rmin, c, np.zeros((3, 1)))
+        d[others] = dist
+    violation = (d < rmin).astype(float)
+    viol_constr = (d < rmin * 3).astype(float)
+    return violation, float(d.min()) if others else np.inf, viol_constr
 
 
 def collision_rows(variant, po, vo, n, h, l, K, rmin, pmin, pmax, alim, Q1, S1, E1, order, term=-5e4):
@@ -203,12 +206,12 @@ def collision_rows(variant, po, vo, n, h, l, K, rmin, pmin, pmax, alim, Q1, S1, 
     r = d.rows_one(_table(l), int(n) - 1, np.ravel(po), np.ravel(vo))
     Lam = _lib.model_matrices(h, K)[0]
     nr = len(r["kc"])
-    Ain = np.zeros((nr, 3 * K))
-    for i in range(nr):
-        kc = int(r["kc"][i])
-        Ain[i] = -(r["xi"][i] @ Lam[3 * kc - 3:3 * kc, :])   # -diff_mat*Ain  (CollConstrSoftDMPC.m:27)
-    c = 1.0 / float(np.asarray(E1)[2, 2])
-    dist = np.sqrt(r["xi"][:, 0] ** 2 + r["xi"][:, 1] ** 2 + (r["xi"][:, 2] * c) ** 2)
+    Ain = _rowctx().rows_dense(r["xi"], r["kc"], Lam)   # -diff_mat*Ain (CollConstrSoftDMPC.m:27) on the device
+    if variant in ("bound", "bound2", "all3", "repair", "cpp", "cpp2"):
+        dist = r["slack_coef"].copy()                 # the slack column is diag(prev_dist) in these variants
+    else:                                              # recovered from xi = E2 (p - p_j): |E1 (p - p_j)|
+        c = 1.0 / float(np.asarray(E1)[2, 2])
+        dist = np.sqrt(r["xi"][:, 0] ** 2 + r["xi"][:, 1] ** 2 + (r["xi"][:, 2] * c) ** 2)
     return Ain, r["rhs"].copy(), dist, r["viol_k"], int(bool(r["status"] & ST_COLL))
 
 

@@ -64,7 +64,7 @@ struct dmpc_ctx {
     DevBuf rows, lT, lT2, xp, xv, xa, pf, po, pout, vout, aout, status, info, hist_p, hist_v, hist_a, flags;
     int hist_S = 0, hist_N = 0, hist_KT = 0;   // shape of the histories left resident by the last dmpc_transition
     DevBuf pc_p, pc_v, pc_a, pc_M, pc_w, pc_scene, pc_agent, pc_interp;   // post-check work buffers
-    DevBuf rb_A, rb_l, rb_sel, rb_out, rb_bin, rb_po, gen_out;                     // dense row builders (host-pointer entries)
+    DevBuf rb_A, rb_l, rb_sel, rb_out, rb_bin, rb_po, gen_out, hp_in, hp_out;                     // dense row builders (host-pointer entries)
     // profiling
     int profile = 0;
     double *dbg = nullptr; int dbg_agent = -1, dbg_cap = 0;   // development trace (dmpc_debug_trace)
@@ -981,6 +981,34 @@ extern "C" int dmpc_coll_rows(dmpc_ctx *ctx, int K, int N_obs, int n_sel, const 
     return 0;
 }
 
+extern "C" int dmpc_rows_dense(dmpc_ctx *ctx, int nr, const double *xi, const int32_t *kc, const double *A, int a_rows, int ncols,
+                               int64_t a_rs, int64_t a_cs, double *Ain, int64_t o_rs, int64_t o_cs)
+{
+    if (!ctx) { g_err = "dmpc_rows_dense: ctx is NULL"; return -1; }
+    if (nr < 0 || a_rows < 3 || ncols < 1 || a_rs < 1 || a_cs < 1 || o_rs < 1 || o_cs < 1 || !A || !Ain) FAIL(ctx, "dmpc_rows_dense: bad arguments");
+    if (nr == 0) return 0;
+    if (!xi || !kc) FAIL(ctx, "dmpc_rows_dense: bad arguments");
+    for (int r = 0; r < nr; ++r)
+        if (kc[r] < 1 || 3 * kc[r] > a_rows) FAIL(ctx, "dmpc_rows_dense: constraint block outside A");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const size_t a_ext = strided_extent(a_rows, ncols, a_rs, a_cs), o_ext = strided_extent(nr, ncols, o_rs, o_cs);
+    if (ctx->rb_A.ensure(a_ext * 8) || ctx->rb_l.ensure((size_t)nr * 24) || ctx->rb_sel.ensure((size_t)nr * 4) || ctx->rb_out.ensure(o_ext * 8))
+        FAIL(ctx, "device allocation failed");
+    HIPCHK(ctx, hipMemcpyAsync(ctx->rb_A.p, A, a_ext * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->rb_l.p, xi, (size_t)nr * 24, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->rb_sel.p, kc, (size_t)nr * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemsetAsync(ctx->rb_out.p, 0, o_ext * 8, st));
+    const size_t tot = (size_t)nr * ncols;
+    hipLaunchKernelGGL(rb::xi_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, nr, (const double *)ctx->rb_l.as<double>(),
+                       (const int *)ctx->rb_sel.as<int>(), (const double *)ctx->rb_A.as<double>(), (long)a_rs, (long)a_cs, ncols,
+                       ctx->rb_out.as<double>(), (long)o_rs, (long)o_cs);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(Ain, ctx->rb_out.p, o_ext * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    return 0;
+}
+
 extern "C" int dmpc_add_coll_constr_device(dmpc_ctx *ctx, int K, int N, const double *d_p, const double *d_po, double rmin, double c,
                                            const double *d_A, int64_t a_rs, int64_t a_cs, int ncols, double *d_Ain, int64_t o_rs,
                                            int64_t o_cs, double *d_bin, void *stream)
@@ -1092,4 +1120,127 @@ extern "C" int dmpc_random_sets_device(dmpc_ctx *ctx, int S, int N, const double
     HIPCHK(ctx, hipSetDevice(ctx->device));
     return random_sets(ctx, "dmpc_random_sets_device", S, N, pmin, pmax, rmin, exchange ? 1.0 : c, seed, exchange ? 1 : 0, d_po_pf,
                        (hipStream_t)stream);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// standalone forms of the small helpers of the path (propStatedmpc.m, dec-iSCP/propState.m, is_inbounds.m,
+// ReachedGoal.m): inside the solvers they are fused into the step kernels; callers that invoke them on their own
+// (the reference's scripts do) get the same arithmetic on the device.  Host pointers, synchronous.
+// ---------------------------------------------------------------------------------------------
+namespace hp {
+// p = A_p a + A_initp x0 + tile(off_p), v = A_v a + tile(off_v); one thread per output row
+__global__ void prop_state_kernel(int n_rows, int n_cols, const double *__restrict__ A_p, const double *__restrict__ A_v,
+                                  const double *__restrict__ A_initp, const double *__restrict__ x0, const double *__restrict__ off,
+                                  const double *__restrict__ a, double *__restrict__ p, double *__restrict__ v)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rows) return;
+    double sp = 0.0, sv = 0.0;
+    for (int j = 0; j < n_cols; ++j) {
+        sp += A_p[(size_t)i * n_cols + j] * a[j];
+        sv += A_v[(size_t)i * n_cols + j] * a[j];
+    }
+    if (A_initp) {
+        double s0 = 0.0;
+        for (int u = 0; u < 6; ++u) s0 += A_initp[(size_t)i * 6 + u] * x0[u];
+        sp += s0;
+    }
+    p[i] = sp + off[i % 3];
+    v[i] = sv + off[3 + i % 3];
+}
+// is_inbounds.m:2-5: every coordinate of every point strictly inside [pmin - 5 cm, pmax + 5 cm]
+__global__ void inbounds_kernel(int npts, const double *__restrict__ p, const double *__restrict__ lim, int *__restrict__ bad)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 3 * npts) return;
+    const int d = i % 3;
+    const double tol = 50e-3;
+    if (!(p[i] < lim[3 + d] + tol) || !(p[i] > lim[d] - tol)) atomicOr(bad, 1);
+}
+// ReachedGoal.m:2-10: max_i |p_i - pf_i| < error_tol
+__global__ void reached_kernel(int N, const double *__restrict__ p, const double *__restrict__ pf, double tol, int *__restrict__ bad)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const double dx = p[3 * i] - pf[3 * i], dy = p[3 * i + 1] - pf[3 * i + 1], dz = p[3 * i + 2] - pf[3 * i + 2];
+    if (!(sqrt(dx * dx + dy * dy + dz * dz) < tol)) atomicOr(bad, 1);
+}
+}   // namespace hp
+
+extern "C" int dmpc_prop_state(dmpc_ctx *ctx, int n_rows, int n_cols, const double *A_p, const double *A_v, const double *A_initp,
+                               const double *po, const double *vo, const double *off_p, const double *off_v, const double *a,
+                               double *p, double *v)
+{
+    if (!ctx) { g_err = "dmpc_prop_state: ctx is NULL"; return -1; }
+    if (n_rows < 1 || n_cols < 1 || !A_p || !A_v || !a || !p || !v || (A_initp && (!po || !vo))) FAIL(ctx, "dmpc_prop_state: bad arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const size_t nA = (size_t)n_rows * n_cols;
+    // layout of the staging buffer: A_p | A_v | A_initp | x0(6) | off(6) | a
+    const size_t tot = 2 * nA + (size_t)n_rows * 6 + 12 + n_cols;
+    if (ctx->hp_in.ensure(tot * 8) || ctx->hp_out.ensure((size_t)n_rows * 16 + 16)) FAIL(ctx, "device allocation failed");
+    double *d = ctx->hp_in.as<double>();
+    double *dAp = d, *dAv = d + nA, *dA0 = dAv + nA, *dx0 = dA0 + (size_t)n_rows * 6, *doff = dx0 + 6, *da = doff + 6;
+    double x0[6] = {0, 0, 0, 0, 0, 0}, off[6] = {0, 0, 0, 0, 0, 0};
+    for (int u = 0; u < 3; ++u) {
+        if (po) x0[u] = po[u];
+        if (vo) x0[3 + u] = vo[u];
+        if (off_p) off[u] = off_p[u];
+        if (off_v) off[3 + u] = off_v[u];
+    }
+    HIPCHK(ctx, hipMemcpyAsync(dAp, A_p, nA * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(dAv, A_v, nA * 8, hipMemcpyHostToDevice, st));
+    if (A_initp) HIPCHK(ctx, hipMemcpyAsync(dA0, A_initp, (size_t)n_rows * 48, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(dx0, x0, 48, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(doff, off, 48, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(da, a, (size_t)n_cols * 8, hipMemcpyHostToDevice, st));
+    double *dp = ctx->hp_out.as<double>(), *dv = dp + n_rows;
+    hipLaunchKernelGGL(hp::prop_state_kernel, dim3((unsigned)((n_rows + 63) / 64)), dim3(64), 0, st, n_rows, n_cols, (const double *)dAp,
+                       (const double *)dAv, A_initp ? (const double *)dA0 : (const double *)nullptr, (const double *)dx0,
+                       (const double *)doff, (const double *)da, dp, dv);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(p, dp, (size_t)n_rows * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(v, dv, (size_t)n_rows * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    return 0;
+}
+
+static int flag_kernel_common(dmpc_ctx *ctx, const char *who, int count3, const double *p, int extra_n, const double *extra,
+                              int which, double tol, int32_t *out)
+{
+    if (!ctx) { g_err = std::string(who) + ": ctx is NULL"; return -1; }
+    if (count3 < 1 || !p || !extra || !out) FAIL(ctx, std::string(who) + ": bad arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    if (ctx->hp_in.ensure(((size_t)count3 + extra_n) * 8) || ctx->hp_out.ensure(16)) FAIL(ctx, "device allocation failed");
+    double *dp = ctx->hp_in.as<double>(), *dx = dp + count3;
+    int *bad = ctx->hp_out.as<int>();
+    HIPCHK(ctx, hipMemcpyAsync(dp, p, (size_t)count3 * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(dx, extra, (size_t)extra_n * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemsetAsync(bad, 0, 4, st));
+    if (which == 0)
+        hipLaunchKernelGGL(hp::inbounds_kernel, dim3((unsigned)((count3 + 255) / 256)), dim3(256), 0, st, count3 / 3, (const double *)dp,
+                           (const double *)dx, bad);
+    else
+        hipLaunchKernelGGL(hp::reached_kernel, dim3((unsigned)((count3 / 3 + 255) / 256)), dim3(256), 0, st, count3 / 3, (const double *)dp,
+                           (const double *)dx, tol, bad);
+    HIPCHK(ctx, hipGetLastError());
+    int32_t b = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&b, bad, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    *out = b ? 0 : 1;
+    return 0;
+}
+
+extern "C" int dmpc_is_inbounds(dmpc_ctx *ctx, int npts, const double *p, const double *pmin, const double *pmax, int32_t *inbounds)
+{
+    if (!pmin || !pmax) { g_err = "dmpc_is_inbounds: bad arguments"; return -1; }
+    const double lim[6] = {pmin[0], pmin[1], pmin[2], pmax[0], pmax[1], pmax[2]};
+    return flag_kernel_common(ctx, "dmpc_is_inbounds", 3 * npts, p, 6, lim, 0, 0.0, inbounds);
+}
+
+extern "C" int dmpc_reached_goal(dmpc_ctx *ctx, int N, const double *p, const double *pf, double error_tol, int32_t *reached)
+{
+    return flag_kernel_common(ctx, "dmpc_reached_goal", 3 * N, p, 3 * N, pf, 1, error_tol, reached);
 }

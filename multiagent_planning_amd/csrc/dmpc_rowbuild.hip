@@ -49,6 +49,17 @@ __global__ void coll_rows_kernel(int n_sel, const int *__restrict__ sel, int K, 
     if (c == 0) { bin[r] = -g.r; if (dist) dist[r] = g.dist; }
 }
 
+// dense form of structured rows (xi_r, kc_r) as dmpc_rows_one returns them: out[r][c] = -(xi_r . A[3 (kc_r - 1) + (0..2)][c])
+__global__ void xi_rows_kernel(int nr, const double *__restrict__ xi, const int *__restrict__ kc, const double *__restrict__ A,
+                               long a_rs, long a_cs, int ncols, double *__restrict__ out, long o_rs, long o_cs)
+{
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (size_t)nr * ncols) return;
+    const int r = (int)(e / ncols), c = (int)(e - (size_t)r * ncols);
+    const double *Ab = A + (size_t)(3 * (kc[r] - 1)) * a_rs + (size_t)c * a_cs;
+    out[(size_t)r * o_rs + (size_t)c * o_cs] = -(xi[3 * r] * Ab[0] + xi[3 * r + 1] * Ab[a_rs] + xi[3 * r + 2] * Ab[2 * a_rs]);
+}
+
 // cup-SCP pairwise rows: row (i < j, k), k fastest (AddCollConstr.m:8-29):
 //   r = dist (rmin - dist) + diff.(pi_k - pj_k) - diff.(po_i - po_j);  Ain = -(diff . A[blk(i,k)] - diff . A[blk(j,k)])
 __global__ void add_coll_rows_kernel(int N, int K, const double *__restrict__ p, const double *__restrict__ po, double rmin,

@@ -162,3 +162,26 @@ def test_transition_outcomes_n20():
         # recorded states obey the reference's dynamics identity p_{k+1} = p_k + h v_k + h^2/2 a_{k+1}
         vk, ak, h = res["vk"][s][:, :KT], res["ak"][s][:, :KT], cfg["h"]
         assert np.abs(pk[:, 1:] - (pk[:, :-1] + h * vk[:, :-1] + h * h / 2 * ak[:, 1:])).max() < 1e-12
+
+
+def test_small_helpers_match_m_files():
+    """initDMPC.m, is_inbounds.m, propStatedmpc.m, dec-iSCP/propState.m, ReachedGoal.m in their standalone (device) form."""
+    p, v, a = api.initDMPC([0, 0, 1], [10, 0, 1], 0.2, 15, 101)
+    assert p.shape == (3, 15) and np.allclose(p[0], np.arange(15) * 0.2) and (p[2] == 1).all() and not v.any() and not a.any()
+    assert api.is_inbounds([2.54, 0, 1], [-2.5, -2.5, 0.2], [2.5, 2.5, 2.2])
+    assert not api.is_inbounds([2.56, 0, 1], [-2.5, -2.5, 0.2], [2.5, 2.5, 2.2])
+    assert not api.is_inbounds(np.array([[0, 0], [0, 0], [1, 0.14]]), [-2.5, -2.5, 0.2], [2.5, 2.5, 2.2])     # second point below the floor
+    A_p, A_v, A0 = api.getModelMats(0.2, 15)
+    rng = np.random.default_rng(0)
+    acc, po, vo = rng.normal(size=45), rng.normal(size=3), rng.normal(size=3)
+    pp, vv = api.propStatedmpc(po, vo, acc, A0, A_p, A_v)
+    assert np.abs(pp - (A_p @ acc + A0 @ np.r_[po, vo])).max() < 1e-13          # propStatedmpc.m:3
+    assert np.abs(vv - (A_v @ acc + np.tile(vo, 15))).max() < 1e-13             # propStatedmpc.m:4
+    K = 16                                                                      # dec-iSCP: A_p is 3(K-1) x 3(K-1)... here 45 x 45
+    p2, v2 = api.propState(po, acc, A_p, A_v, K)
+    assert p2.shape == (48,) and np.array_equal(p2[:3], po) and not v2[:3].any()
+    assert np.abs(p2[3:] - (A_p @ acc + np.tile(po, K - 1))).max() < 1e-13 and np.abs(v2[3:] - A_v @ acc).max() < 1e-13
+    pk = np.zeros((3, 5, 2)); pk[:, 4, 0] = [1, 1, 1]; pk[:, 4, 1] = [2, 2, 2]
+    pf = np.array([[1, 1, 1.005], [2, 2, 2]]).T.reshape(1, 3, 2)
+    assert api.ReachedGoal(pk, pf, 5, 0.01, 2) and not api.ReachedGoal(pk, pf, 5, 0.001, 2)
+    assert api.ReachedGoal(pk[:, :, 0], pf[:, :, 0], 5, 0.01, 1)

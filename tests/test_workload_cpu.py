@@ -34,20 +34,17 @@ def test_c1_is_the_fixed_diagonal_swap():
     assert po.shape == (1, 4, 3) and tuple(po[0, 0]) == (1.501, 1.5, 1.5) and tuple(pf[0, 0]) == (-1.5, -1.5, 1.5)
 
 
-def test_host_helpers_match_m_files():
-    p, v, a = api.initDMPC([0, 0, 1], [10, 0, 1], 0.2, 15, 101)
-    assert p.shape == (3, 15) and np.allclose(p[0], np.arange(15) * 0.2) and not v.any() and not a.any()
-    assert api.is_inbounds([2.54, 0, 1], [-2.5, -2.5, 0.2], [2.5, 2.5, 2.2])
-    assert not api.is_inbounds([2.56, 0, 1], [-2.5, -2.5, 0.2], [2.5, 2.5, 2.2])
-    A_p, A_v, A0 = api.getModelMats(0.2, 15)
-    acc = np.ones(45)
-    pp, vv = api.propStatedmpc([0, 0, 0], [1, 0, 0], acc, A0, A_p, A_v)
-    # p_k = k h v0 + (k h)^2/2 for unit acceleration
-    k = np.arange(1, 16)
-    assert np.allclose(pp[0::3], k * 0.2 + (k * 0.2) ** 2 / 2) and np.allclose(vv[0::3], 1 + k * 0.2)
-    pk = np.zeros((3, 5, 2)); pk[:, 4, 0] = [1, 1, 1]; pk[:, 4, 1] = [2, 2, 2]
-    pf = np.array([[1, 1, 1.005], [2, 2, 2]]).T.reshape(1, 3, 2)
-    assert api.ReachedGoal(pk, pf, 5, 0.01, 2) and not api.ReachedGoal(pk, pf, 5, 0.001, 2)
+def test_small_helpers_fail_loudly_without_a_gpu():
+    """the standalone helpers (initDMPC, is_inbounds, propStatedmpc, ReachedGoal, ...) run on the device like the rest
+    of the path: on a box without a GPU they raise, they never fall back to host arithmetic."""
+    import pytest
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by tests/test_gpu_api.py")
+    with pytest.raises(RuntimeError):
+        api.is_inbounds([0, 0, 1], [-2.5, -2.5, 0.2], [2.5, 2.5, 2.2])
+    with pytest.raises(RuntimeError):
+        api.initDMPC([0, 0, 1], [10, 0, 1], 0.2, 15, 101)
 
 
 def test_generator_restatement_properties():
