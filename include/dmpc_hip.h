@@ -55,7 +55,8 @@ enum {
     DMPC_ST_COLL = 4,      /* already collided at horizon step 1 (solveSoftDMPCbound.m:25-31)    */
     DMPC_ST_INFEAS = 8,    /* QP infeasible after the retry ladder (solveSoftDMPCbound.m:102-155) */
     DMPC_ST_CAPACITY = 16, /* internal capacity exceeded (rows / active set): result NOT valid   */
-    DMPC_ST_ITERCAP = 32   /* iteration cap hit: result NOT valid                                */
+    DMPC_ST_ITERCAP = 32,  /* iteration cap hit: result NOT valid                                */
+    DMPC_ST_REACHED = 256  /* scene_status of dmpc_transition only: all agents reached their goals */
 };
 
 /* info[] : 8 int32 per agent */
@@ -168,7 +169,8 @@ int dmpc_advance_device(dmpc_ctx *ctx, int count, const double *p_out, const dou
  * swap l = new_l and the ReachedGoal.m test.  Host pointers.
  * po,pf: [S][N][3]; pk,vk,ak: [S][N][K_T_max][3] (written up to K_T_used[s]);
  * K_T_used[S]: number of MPC steps taken per scene; scene_status[S]: OR of agent status bits at
- * the step where the scene stopped (DMPC_ST_SOLVED only = ran to goal / K_T_max). */
+ * the step where the scene stopped; DMPC_ST_SOLVED | DMPC_ST_REACHED = every agent within error_tol of its goal
+ * (ReachedGoal.m), DMPC_ST_SOLVED alone = ran to K_T_max without reaching (failed_goal, failure_rate.m:131-134). */
 int dmpc_transition(dmpc_ctx *ctx, int S, int N, const double *po, const double *pf, int K_T_max,
                     double error_tol, double *pk, double *vk, double *ak, int32_t *K_T_used,
                     int32_t *scene_status);

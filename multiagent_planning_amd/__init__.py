@@ -4,4 +4,4 @@ Host-side mirror of the reference's MATLAB interface (`api`) over the C ABI of l
 (`_lib`).  See DESIGN.md / INTEGRATION.md at the repository root.
 """
 from ._lib import Dmpc, DmpcError, DmpcParams, make_params, model_matrices, posvel_matrix, VARIANTS  # noqa: F401
-from ._lib import ST_SOLVED, ST_OUTBOUND, ST_COLL, ST_INFEAS, ST_CAPACITY, ST_ITERCAP  # noqa: F401
+from ._lib import ST_SOLVED, ST_OUTBOUND, ST_COLL, ST_INFEAS, ST_CAPACITY, ST_ITERCAP, ST_REACHED  # noqa: F401

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libdmpc_hip.so")
 
 VARIANTS = dict(bound=0, bound2=1, all3=2, hard=3, ondemand=4, ellip=5, softall=6, repair=7, cpp=8, cpp2=9)
 ST_SOLVED, ST_OUTBOUND, ST_COLL, ST_INFEAS, ST_CAPACITY, ST_ITERCAP = 1, 2, 4, 8, 16, 32
+ST_REACHED = 256   # scene_status of transition(): every agent reached its goal
 INFO_LEN = 8
 I_VIOLK, I_NROWS, I_TRIES, I_CASE, I_ITERS, I_NSLACK, I_NACTIVE, I_MAXQ = range(8)
 K_HOR = 15

@@ -260,7 +260,9 @@ def CollConstr(p, po, k, l, Ain, rmin, E1, E2, order):
 def _dmpc_rows(p, po, vo, n, k, l, rmin, Ain, A_initp, E1, E2, order, sel, k_ctr):
     lo = _obst(l)
     c = _c_of(E1, E2, order)
-    a0 = np.asarray(A_initp, float)[3 * (k_ctr - 1):3 * k_ctr, :] @ np.r_[np.ravel(po), np.ravel(vo)]
+    # A_initp(3*(k_ctr-1)+1:3*k_ctr,:)*[po';vo'] (CollConstrSoftDMPC.m:21), on the device like the rest of the row
+    a0, _ = _rowctx().prop_state(np.zeros((3, 1)), np.zeros((3, 1)), [0.0], A_initp=np.asarray(A_initp, float)[3 * (k_ctr - 1):3 * k_ctr, :],
+                                 po=po, vo=vo)
     return _rowctx().coll_rows(lo, sel, k - 1, k_ctr - 1, np.ravel(p), a0, rmin, c, np.asarray(Ain, float))
 
 

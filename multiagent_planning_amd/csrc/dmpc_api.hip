@@ -788,7 +788,7 @@ extern "C" int dmpc_transition(dmpc_ctx *ctx, int S, int N, const double *po, co
                     if (stbits & ~DMPC_ST_SOLVED) {   // some agent failed: the reference aborts the trial
                         done[s] = 1; ndone++; K_T_used[s] = kk + 1; scene_status[s] = stbits;
                     } else if (reached) {             // ReachedGoal.m (failure_rate.m:125)
-                        done[s] = 1; ndone++; K_T_used[s] = kk + 1; scene_status[s] = DMPC_ST_SOLVED;
+                        done[s] = 1; ndone++; K_T_used[s] = kk + 1; scene_status[s] = DMPC_ST_SOLVED | DMPC_ST_REACHED;
                     }
                 }
         }

@@ -13,6 +13,8 @@ repacking, no other collective on the data path.  The goal / abort test is a tin
 """
 import numpy as np
 
+from ._lib import ST_REACHED, ST_SOLVED
+
 K3 = 45
 
 
@@ -53,9 +55,9 @@ def run_trial(dmpc, po, pf, K_T_max, error_tol=0.01, vmax=2.0, amax=1.0, Ts=0.01
     (`feasible && ~failed_goal && ~violation`); t/totdist/traj_time are NaN for failed scenes (:197-201)."""
     tr = dmpc.transition(po, pf, K_T_max, error_tol)
     S = tr["K_T_used"].shape[0]
-    feasible = tr["scene_status"] == 1
-    reached = feasible & (np.linalg.norm(tr["pk"][np.arange(S), :, tr["K_T_used"] - 1] - np.asarray(pf).reshape(S, -1, 3),
-                                         axis=-1) < error_tol).all(-1)                     # ReachedGoal.m
+    st = tr["scene_status"]
+    feasible = (st & ~ST_REACHED) == ST_SOLVED                 # no agent failed before the scene stopped
+    reached = feasible & ((st & ST_REACHED) != 0)              # ReachedGoal.m, evaluated on the device every step
     out = dict(tr, feasible=feasible, failed_goal=feasible & ~reached, violation=np.zeros(S, dtype=np.int32),
                totdist=np.full(S, np.nan), traj_time=np.full(S, np.nan), r_factor=np.full(S, np.nan))
     if reached.any():

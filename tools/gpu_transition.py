@@ -13,7 +13,7 @@ for N, S in [(20, 8), (100, 8), (200, 8), (100, 1)]:
     t0 = time.perf_counter()
     res = d.transition(po, pf, 151, cfg["error_tol"])
     dt = time.perf_counter() - t0
-    used = res["K_T_used"]; ok = res["scene_status"] == 1
+    used = res["K_T_used"]; ok = (res["scene_status"] & 1) == 1
     reached = [np.linalg.norm(res["pk"][s][:, used[s] - 1] - pf[s], axis=1).max() < cfg["error_tol"] for s in range(S)]
     nsolve = int(((used - 1) * N).sum())
     print(f"N={N:4d} S={S}: wall {dt*1e3:8.1f} ms for {S} transitions ({dt/S*1e3:.1f} ms each), MPC steps {used.tolist()}, "
