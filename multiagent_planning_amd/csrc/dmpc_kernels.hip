@@ -22,6 +22,15 @@
 
 #include "dmpc_device.h"
 
+// Phase timers of the development trace (tools/gpu_phase.py).  Reading the cycle counter is a scalar-memory
+// instruction whose result is awaited with s_waitcnt lgkmcnt(0) -- which also drains every LDS operation in
+// flight -- so the timers are compiled in only on request (make DEV_TIMERS=1).
+#ifdef DMPC_DEV_TIMERS
+#define DMPC_CLOCK() clock64()
+#else
+#define DMPC_CLOCK() 0LL
+#endif
+
 namespace dmpc {
 
 // --------------------------------------------------------------------------------------------
@@ -474,7 +483,7 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
         LSYNC();
     }
 
-    const long long tk0 = clock64();
+    const long long tk0 = DMPC_CLOCK();
     // ---------------------------------------------------------------- a5/a6: scan + rows
     int nr = 0, nrows_ref = 0, viol_k = 0, status = 0;
     bool cert_infeasible = false;
@@ -693,7 +702,7 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
     violation = (hdr[4] & 1) != 0; rows_exist = hdr[5] != 0;
     const int nrows_built = nrows_ref;
 
-    const long long tk1 = clock64();
+    const long long tk1 = DMPC_CLOCK();
     // ---------------------------------------------------------------- cost case + tables (a7, :43-58)
     int ccase = 2;
     {
@@ -763,7 +772,7 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
         rcsd[c] = soft ? L.r_sd[ii] : 0.0; rcslb[c] = soft ? L.r_slb[ii] : 0.0;
         rcw[c] = row_weight(rcx0[c], rcx1[c], rcx2[c], rckc[c], rcsd[c]);
     }
-    const long long tk2 = clock64();
+    const long long tk2 = DMPC_CLOCK();
     long long tkA = 0, tkB = 0, tkC = 0, tkD = 0, tkE = 0, tkF = 0, tkG = 0;
     // ---------------------------------------------------------------- a7: dual active-set solve
     const bool ladder = soft && (var == VAR_BOUND || var == VAR_BOUND2 || var == VAR_ALL3 || cppv);
@@ -884,7 +893,7 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
             int since_sync = 0;
             bool cert_done = false;
             for (;;) {
-                const long long tq0 = clock64();
+                const long long tq0 = DMPC_CLOCK();
                 // a try that is still running after LADDER_CERT_AFTER iterations: ask the certificate once whether this
                 // ladder level can work at all
                 if (soft && ladder && violation && !cert_done && iters >= LADDER_CERT_AFTER) {
@@ -956,7 +965,7 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
                     continue;
                 }
                 fresh = false;
-                const long long tqa = clock64(); tkA += tqa - tq0;
+                const long long tqa = DMPC_CLOCK(); tkA += tqa - tq0;
                 const int src = __ffsll((long long)wm) - 1;
                 const int pcode = readlane_i(bestc, src);
                 double vp = readlane_d(bestv, src);
@@ -989,11 +998,11 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
                 }
                 double lam_p = 0.0;
                 const double spp = sdot_self(L, p);
-                tkF += clock64() - tqa;
+                tkF += DMPC_CLOCK() - tqa;
                 // ---- inner loop: partial steps until p can be added
                 for (;;) {
                     if (++iters > ITER_CAP) { rc = 3; break; }
-                    const long long tq1 = clock64();
+                    const long long tq1 = DMPC_CLOCK();
                     const double sv = (lane < q) ? sdot_slot(L, lane, p) : 0.0;
                     L.xs_s[lane] = sv; LSYNC();
                     const double dvj = t_tmul(L.T, L.xs_s, lane, q, qcap);
@@ -1001,7 +1010,7 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
                     const double ri = t_mul(L.T, L.rr_s, lane, q, qcap);
                     LSYNC();
                     L.rr_s[lane] = ri;
-                    const long long tq2 = clock64(); tkB += tq2 - tq1;
+                    const long long tq2 = DMPC_CLOCK(); tkB += tq2 - tq1;
                     // masks of the slots that need a loop: collision rows (position-space normals that are not
                     // unit vectors) and slack-coupled constraints; boxes / position bounds are O(1) per lane
                     const int myty = (lane < q) ? L.s_ty[lane] : -1;
@@ -1079,7 +1088,7 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
                         if (p.si >= 0 && !p_row_has_slot && lane == 63) part += 0.5 * p.ss * p.ss;
                     }
                     const double delta = wave_sum(part);
-                    const long long tq3 = clock64(); tkC += tq3 - tq2;
+                    const long long tq3 = DMPC_CLOCK(); tkC += tq3 - tq2;
                     // more active constraints than variables is impossible: whatever round-off says, a constraint
                     // picked when the working set already spans all 45 + nlive variables is dependent
                     const bool dependent = !(delta > 1e-13 * spp) || q >= N3 + nlive;
@@ -1094,7 +1103,7 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
                     }
                     if (!(t < INFINITY)) { rc = 1; break; }
                     if (lane < q) L.s_lam[lane] -= t * ri;
-                    const long long tq4 = clock64(); tkD += tq4 - tq3;
+                    const long long tq4 = DMPC_CLOCK(); tkD += tq4 - tq3;
                     lam_p += t;
                     if (!dependent) {
                         vp -= t * delta;
@@ -1117,7 +1126,7 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
                         q++;
                         if (q > maxq) maxq = q;
                         LSYNC();
-                        tkE += clock64() - tq4;
+                        tkE += DMPC_CLOCK() - tq4;
                         break;
                     }
                     // partial step: drop the blocking constraint
@@ -1139,7 +1148,7 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
                             nlive--;
                         }
                     }
-                    tkG += clock64() - tq4;
+                    tkG += DMPC_CLOCK() - tq4;
                 }
                 if (rc) break;
                 // pin added while its collision row is not active: decoupled again -> drop both
@@ -1185,7 +1194,7 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
         if (!solved && !(status & (ST_CAPACITY | ST_ITERCAP | ST_QOVER))) status |= ST_INFEAS;
     }
 
-    const long long tk3 = clock64();
+    const long long tk3 = DMPC_CLOCK();
     // ---------------------------------------------------------------- a9/a10: propagate, outputs
     int nslack = 0;
     if (solved) {
@@ -1223,7 +1232,7 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
     }
     if (P.dbg && gid == P.dbg_agent && lane == 0) {
         double *d = P.dbg + (size_t)P.dbg_cap * 8 - 8;
-        d[0] = (double)(tk1 - tk0); d[1] = (double)(tk2 - tk1); d[2] = (double)(tk3 - tk2); d[3] = (double)(clock64() - tk3);
+        d[0] = (double)(tk1 - tk0); d[1] = (double)(tk2 - tk1); d[2] = (double)(tk3 - tk2); d[3] = (double)(DMPC_CLOCK() - tk3);
         d[4] = (double)tkA; d[5] = (double)tkB; d[6] = (double)tkC; d[7] = (double)iters_total;
         d[-8] = (double)tkD; d[-7] = (double)tkE; d[-6] = (double)tkF; d[-5] = (double)tkG;
     }

@@ -1,4 +1,4 @@
-"""development aid: phase cycle counts of typical agents of the C2 bench workload (fixed overhead vs iterations)."""
+"""development aid (phase cycle counts need a library built with `make -C multiagent_planning_amd/csrc DEV_TIMERS=1`): phase cycle counts of typical agents of the C2 bench workload (fixed overhead vs iterations)."""
 import sys, os, ctypes as C
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

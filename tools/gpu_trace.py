@@ -1,4 +1,4 @@
-"""development aid: dump the active-set iteration trace of one agent on the GPU."""
+"""development aid (phase cycle counts need a library built with `make -C multiagent_planning_amd/csrc DEV_TIMERS=1`): dump the active-set iteration trace of one agent on the GPU."""
 import sys, os, ctypes as C
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
