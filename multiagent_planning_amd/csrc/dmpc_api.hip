@@ -362,6 +362,8 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     P.variant = p.variant; P.S = S; P.G = G; P.C = C; P.g_local = g_local;
     P.c_first = c_first; P.c_count = c_count;
     P.nrmax = row_capacity(p.variant, G * C);
+    if (p.variant == DMPC_VAR_HARD && (G > 256 || C >= (1 << 20)))   // packing of the scan's candidate list
+        FAIL(ctx, "solveHardDMPC scan: at most 256 chunks of fewer than 2^20 agents");
     P.max_tries = p.max_tries;
     P.h = p.h; P.rmin = p.rmin; P.e1z = 1.0 / p.c; P.e2z = 1.0 / (p.c * p.c);
     P.alim = p.alim; P.Q1 = p.Q1; P.S1 = p.S1; P.term = p.term;

@@ -433,10 +433,12 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
 
     const int qcap = P.qcap;
     Lds L;
+    int *scan_cand = nullptr;
     {
         double *p = (double *)smem;
         if (PHASE == 0) {
             L.own_s = p; p += 48;
+            scan_cand = (int *)p;   // SCAN_CAND_CAP ints
             L.T = L.tabH = L.tabM = L.tabP = L.a_s = L.w_s = L.nu_s = L.yt_s = nullptr;
             L.s_vec = L.s_ss = L.s_d = L.s_lam = L.rr_s = L.xs_s = L.r_eps = nullptr;
             L.s_kb = L.s_ty = L.s_idx = nullptr; L.r_fl = nullptr;
@@ -606,6 +608,24 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
         // Scan (CheckCollSoftDMPC.m:7-15): all K distances of a neighbour are computed from loads issued
         // together (5 horizon steps = 15 coalesced wave loads per batch) instead of one dependent round per
         // step; per-step "any neighbour inside rmin" bits are OR-reduced across the wave afterwards.
+        int ncand = 0;
+        // second pass of the hard-row scan: one lane per buffered candidate
+        auto flush_candidates = [&]() {
+            LSYNC();
+            for (int b0 = 0; b0 < ncand; b0 += 64) {
+                const bool have = b0 + lane < ncand;
+                const int code = have ? scan_cand[b0 + lane] : 0;
+                const int kk = (code >> 28) & 15, rr = (code >> 20) & 255, jj = code & 0xfffff;
+                const double *nb = P.lT + ((size_t)(rr * S + scene) * N3 + 3 * kk) * C + jj;
+                const double px = L.own_s[3 * kk], py = L.own_s[3 * kk + 1], pz = L.own_s[3 * kk + 2];
+                const double dx = px - nb[0], dy = py - nb[(size_t)C], dz = pz - nb[2 * (size_t)C];
+                const double ez = dz * P.e1z;
+                const double dist = sqrt(dx * dx + dy * dy + ez * ez);
+                emit_row(have && dist < 1.0, kk, dx, dy, dz, dist, px, py, pz);
+            }
+            ncand = 0;
+            LSYNC();
+        };
         unsigned anyb = 0;
         double mind0 = 1e300;
         const double rmin2_hi = rmin * rmin * (1.0 + 1e-9);
@@ -639,11 +659,17 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
                         // threshold (a superset), the exact `norm(...) < r` decision is then made on sqrt(d2) itself.
                         if (var == VAR_HARD) {
                             // solveHardDMPC.m:18-22 + CollConstrHardDMPC.m:19: every k, neighbours with dist < 1.
-                            // (rows are emitted neighbour-chunk-major here; the reference's k-major order only
-                            //  changes tie breaks of the active-set path, not the unique minimiser)
-                            if (__any(valid && d2 < 1.0 + 1e-9)) {
-                                const double dist = sqrt(d2);
-                                emit_row(valid && dist < 1.0, k, dx, dy, dz, dist, px, py, pz);
+                            // Two passes: this loop only tests the 15 N distances and compacts the (neighbour, step)
+                            // candidates (about one in ten) into an LDS list; flush_candidates() then builds the rows of
+                            // 64 candidates at a time, so the row arithmetic runs on full waves instead of on a handful
+                            // of lanes per (chunk, step) pass.  Rows keep this loop's order (neighbour-chunk-major; the
+                            // reference's k-major order only changes tie breaks of the active-set path).
+                            const bool cand = valid && d2 < 1.0 + 1e-9;
+                            const unsigned long long cm = __ballot(cand);
+                            if (cm) {
+                                if (ncand + 64 > SCAN_CAND_CAP) flush_candidates();
+                                if (cand) scan_cand[ncand + lanes_below(cm, lane)] = (k << 28) | (r << 20) | jc;
+                                ncand += __popcll(cm);
                             }
                         } else {
                             if (__any(valid && d2 < rmin2_hi)) {
@@ -657,6 +683,7 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
             }
         }
         if (var == VAR_HARD) {
+            flush_candidates();
             rows_exist = (G * C > 1);   // preallocated zero rows make Ain_coll non-empty (CollConstrHardDMPC.m:3-4)
         } else {
             anyb = wave_or(anyb);
