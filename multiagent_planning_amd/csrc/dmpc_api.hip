@@ -412,7 +412,8 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     else hipLaunchKernelGGL(dmpc_scan_kernel<false>, grid, block, lds0, st, P);
     // heaviest-first launch order for the solve phase (skipped for tiny launches)
     if (S * c_count >= 512 && !ctx->no_lpt) {
-        hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, st, S * c_count, (const int *)P.hdr, ctx->order.as<int>());
+        const int total = S * c_count, nb = total >= 16384 ? 8 : 1;
+        hipLaunchKernelGGL(order_kernel, dim3((unsigned)nb), dim3(1024), 0, st, total, (const int *)P.hdr, ctx->order.as<int>());
         P.order = ctx->order.as<int>();
     }
     if (ctx->profile) HIPCHK(ctx, hipEventRecord(ev.t1, st));

@@ -1356,23 +1356,26 @@ __global__ void bbox_kernel(int total, int C, const double *__restrict__ lT, dou
 // Longest-processing-time-first launch order for the solve phase: agents are bucketed by the number of
 // collision rows the scan produced (a good proxy for active-set iterations) and the solve kernel takes
 // them heaviest first, so the long solves do not end up alone at the tail of the launch.  Pure scheduling:
-// results do not depend on the order.  One workgroup.
+// results do not depend on the order.  gridDim.x workgroups: workgroup b sorts the agents i = b (mod gridDim.x)
+// (statistically identical slices) and writes its r-th heaviest agent to position r * gridDim.x + b, so the
+// interleaved sequence is heaviest-first overall up to the differences between the slices.
 __global__ void order_kernel(int count, const int *__restrict__ hdr, int *__restrict__ order)
 {
     __shared__ int hist[256];
     __shared__ int offs[256];
+    const int nb = gridDim.x, b = blockIdx.x;
     for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
     __syncthreads();
-    for (int i = threadIdx.x; i < count; i += blockDim.x) {
+    for (int i = b + nb * (int)threadIdx.x; i < count; i += nb * (int)blockDim.x) {
         int key = hdr[(size_t)i * 8] >> 2; key = key > 255 ? 255 : key;
         atomicAdd(&hist[key], 1);
     }
     __syncthreads();
-    if (threadIdx.x == 0) { int acc = 0; for (int b = 255; b >= 0; --b) { offs[b] = acc; acc += hist[b]; } }
+    if (threadIdx.x == 0) { int acc = 0; for (int k = 255; k >= 0; --k) { offs[k] = acc; acc += hist[k]; } }
     __syncthreads();
-    for (int i = threadIdx.x; i < count; i += blockDim.x) {
+    for (int i = b + nb * (int)threadIdx.x; i < count; i += nb * (int)blockDim.x) {
         int key = hdr[(size_t)i * 8] >> 2; key = key > 255 ? 255 : key;
-        order[atomicAdd(&offs[key], 1)] = i;
+        order[(size_t)atomicAdd(&offs[key], 1) * nb + b] = i;
     }
 }
 
