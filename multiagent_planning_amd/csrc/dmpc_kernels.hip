@@ -756,14 +756,9 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
     if (lane < N3) {
         const double gax = sel3(A.pf, ax_l) - (sel3(A.po, ax_l) + (double)K * P.h * sel3(A.vo, ax_l));
         a_unc = 2.0 * qw * gax * L.tabM[k_l * 15 + (K - 1)] + 2.0 * sw * sel3(A.ao, ax_l) * L.tabH[k_l * 15];
-        L.a_s[lane] = a_unc;
+        // w_unc = Lambda a_unc from the same tables: L M1 = P1 and L H1^-1 = M1'
+        w_unc = 2.0 * qw * gax * L.tabP[k_l * 15 + (K - 1)] + 2.0 * sw * sel3(A.ao, ax_l) * L.tabM[k_l];
     }
-    LSYNC();
-    if (lane < N3) {
-        const double h2 = P.h * P.h;
-        for (int kk = 0; kk <= k_l; ++kk) w_unc += (0.5 * h2 + (double)(k_l - kk) * h2) * L.a_s[3 * kk + ax_l];   // getPosMat.m
-    }
-    LSYNC();
 
     // per-lane constants of component (k_l, ax_l): offset A0 x0, bounds of w = Lambda a, initial velocity.
     // (the uniform agent state is not needed inside the solver loop any more -> fewer live registers)
