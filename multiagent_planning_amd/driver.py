@@ -103,6 +103,49 @@ class ShardedStepper:
         return nxt, out, failed
 
 
+def run_transition_sharded(stepper, lT, x_p, x_v, x_a, pf, K_T_max, error_tol=0.01):
+    """The MPC loop of dmpc_soft_bound.m:115-148 / failure_rate.m:99-127 for THIS rank's agents of S scenes, with the
+    table exchanged by ShardedStepper.step every step.  A scene stops when one of its agents fails on any rank (the
+    reference `break`s the trial) or when every agent of every rank is within error_tol of its goal (ReachedGoal.m):
+    both tests are one all-reduce(MAX) of a [2,S] tensor per step.  Inputs are this rank's slices ([S,C,3]) and the full
+    chunked table; numpy (gloo) or torch CUDA tensors (RCCL).
+    Returns dict(pk [S,C,K_T_max,3] own histories, K_T_used [S], reached [S], failed [S], lT)."""
+    import torch
+    import torch.distributed as dist
+    tens = isinstance(x_p, torch.Tensor)
+    xp = torch.as_tensor(x_p).clone(); xv = torch.as_tensor(x_v).clone(); xa = torch.as_tensor(x_a).clone()
+    goal = torch.as_tensor(pf)
+    S, C = xp.shape[0], xp.shape[1]
+    pk = torch.zeros((S, C, K_T_max, 3), dtype=xp.dtype, device=xp.device)
+    pk[:, :, 0] = xp
+    used = torch.full((S,), K_T_max, dtype=torch.int64)
+    reached = torch.zeros(S, dtype=torch.bool); failed = torch.zeros(S, dtype=torch.bool)
+    done = torch.zeros(S, dtype=torch.bool)
+    for k in range(1, K_T_max):
+        lT, out, _ = stepper.step(lT, xp if tens else xp.numpy(), xv if tens else xv.numpy(), xa if tens else xa.numpy(),
+                                  goal if tens else goal.numpy())
+        st = torch.as_tensor(out["status"]); ok = (st & 1) == 1
+        p1, v1, a1 = (torch.as_tensor(out[q])[..., :3] for q in ("p", "v", "a"))
+        xp = torch.where(ok[..., None], p1, xp); xv = torch.where(ok[..., None], v1, xv); xa = torch.where(ok[..., None], a1, xa)
+        pk[:, :, k] = xp
+        flags = torch.stack([(~ok).any(dim=1).to(torch.float64),                                   # some agent failed
+                             (xp - goal).norm(dim=-1).max(dim=1).values.to(torch.float64)])        # farthest agent from its goal
+        flags = flags.to(xp.device)
+        if stepper.world > 1:
+            dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=stepper.group)
+        flags = flags.cpu()
+        fail_now, reach_now = flags[0] > 0, flags[1] < error_tol
+        newly = ~done & (fail_now | reach_now)
+        used[newly] = k + 1
+        failed |= ~done & fail_now
+        reached |= ~done & ~fail_now & reach_now
+        done |= newly
+        if bool(done.all()):
+            break
+    conv = (lambda t: t) if tens else (lambda t: t.numpy())
+    return dict(pk=conv(pk), K_T_used=used.numpy(), reached=reached.numpy(), failed=failed.numpy(), lT=lT)
+
+
 class GpuLocalStep:
     """local_step for ShardedStepper on a GPU: torch CUDA tensors in, HIP kernel through the C ABI."""
 

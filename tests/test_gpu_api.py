@@ -185,3 +185,27 @@ def test_small_helpers_match_m_files():
     pf = np.array([[1, 1, 1.005], [2, 2, 2]]).T.reshape(1, 3, 2)
     assert api.ReachedGoal(pk, pf, 5, 0.01, 2) and not api.ReachedGoal(pk, pf, 5, 0.001, 2)
     assert api.ReachedGoal(pk[:, :, 0], pf[:, :, 0], 5, 0.01, 1)
+
+
+def test_sharded_transition_loop_on_device_matches_dmpc_transition():
+    """driver.run_transition_sharded with the HIP local step (world of one, torch CUDA tensors) walks the same closed loop
+    as dmpc_transition: same number of MPC steps and bit-identical histories."""
+    import torch
+    cfg = wl.CONFIGS["C4"]
+    N, S, KT = 12, 3, 120
+    kw = wl.solver_kwargs(cfg, N)
+    po, pf = wl.make_scenes(cfg, S, N, wl.SEED0 + 77)
+    d = mp.Dmpc("bound", **kw)
+    ref = d.transition(po, pf, KT, cfg["error_tol"])
+    dev = torch.device("cuda", 0)
+    l, _, _ = d.init_batch(po, pf)
+    lT = torch.from_numpy(driver.rows_to_chunked(l, 1)).to(dev)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    stepper = driver.ShardedStepper(driver.GpuLocalStep(d, S, 1, N, dev), 0, 1)
+    res = driver.run_transition_sharded(stepper, lT, t(po), t(np.zeros_like(po)), t(np.zeros_like(po)), t(pf), KT, cfg["error_tol"])
+    assert np.array_equal(res["K_T_used"], ref["K_T_used"])
+    assert np.array_equal(res["reached"], (ref["scene_status"] & mp.ST_REACHED) != 0)
+    pk = res["pk"].cpu().numpy()
+    for s in range(S):
+        n = int(ref["K_T_used"][s])
+        assert np.array_equal(pk[s][:, :n], ref["pk"][s][:, :n])

@@ -99,3 +99,44 @@ def test_two_rank_gloo_equals_single_rank(tmp_path):
         x_v = np.where(ok[..., None], out["v"][..., :3], x_v)
         x_a = np.where(ok[..., None], out["a"][..., :3], x_a)
     assert np.array_equal(driver.chunked_to_rows(a), driver.chunked_to_rows(np.asarray(lT)))
+
+
+def _transition_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from multiagent_planning_amd import workload as wl
+    from helpers import init_table
+    cfg = wl.CONFIGS["C1"]
+    kw = wl.solver_kwargs(cfg)
+    po, pf = (np.asarray(cfg[k], float) for k in ("po", "pf"))
+    N = 4
+    C = N // world
+    sl = slice(rank * C, (rank + 1) * C)
+    lT = driver.rows_to_chunked(init_table(po, pf)[None], world)
+    stepper = driver.ShardedStepper(_oracle_local_step(kw, "bound", world), rank, world)
+    z = np.zeros((1, C, 3))
+    res = driver.run_transition_sharded(stepper, lT, po[None, sl], z, z, pf[None, sl], 60, cfg["error_tol"])
+    np.savez(os.path.join(out_dir, f"tr_{world}_{rank}.npz"), pk=res["pk"], used=res["K_T_used"], reached=res["reached"],
+             failed=res["failed"], lT=np.asarray(res["lT"]))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_closed_loop_transition_equals_single_rank(tmp_path):
+    """whole C1 transition (dmpc_soft_bound.m constants, 4 agents) with the agents split over 2 gloo ranks: same number of
+    MPC steps, same termination decision, bit-identical histories and final table as the unsharded loop."""
+    port = 31500 + (os.getpid() % 2000)
+    tmp.spawn(_transition_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    _transition_worker(0, 1, port + 1, str(tmp_path))
+    one = np.load(tmp_path / "tr_1_0.npz")
+    r0, r1 = np.load(tmp_path / "tr_2_0.npz"), np.load(tmp_path / "tr_2_1.npz")
+    assert one["reached"].all() and not one["failed"].any() and 20 < one["used"][0] < 60
+    for r in (r0, r1):
+        assert np.array_equal(r["used"], one["used"]) and np.array_equal(r["reached"], one["reached"]) and np.array_equal(r["failed"], one["failed"])
+    assert np.array_equal(np.concatenate([r0["pk"], r1["pk"]], axis=1), one["pk"])
+    assert np.array_equal(driver.chunked_to_rows(r0["lT"]), driver.chunked_to_rows(one["lT"])) and np.array_equal(r0["lT"], r1["lT"])
