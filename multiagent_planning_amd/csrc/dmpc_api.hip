@@ -38,6 +38,10 @@ struct DevBuf {
         return 0;
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    ~DevBuf() { release(); }   // every buffer of a context goes with it (dmpc_destroy selects the device first)
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
     template <class T> T *as() { return (T *)p; }
 };
 
@@ -283,12 +287,11 @@ extern "C" void dmpc_destroy(dmpc_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (auto &ev : ctx->events) { (void)hipEventDestroy(ev.t0); (void)hipEventDestroy(ev.t1); (void)hipEventDestroy(ev.t2); }
-    DevBuf *bufs[] = {&ctx->rowbuf, &ctx->rowkc, &ctx->hdr, &ctx->order, &ctx->bbox, &ctx->rows, &ctx->lT, &ctx->lT2, &ctx->xp, &ctx->xv, &ctx->xa, &ctx->pf, &ctx->po, &ctx->pout,
-                      &ctx->vout, &ctx->aout, &ctx->status, &ctx->info, &ctx->hist_p, &ctx->hist_v, &ctx->hist_a, &ctx->flags};
-    for (DevBuf *b : bufs) b->release();
+    if (ctx->dbg) (void)hipFree(ctx->dbg);
     if (ctx->d_tables) (void)hipFree(ctx->d_tables);
-    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
-    delete ctx;
+    hipStream_t st = ctx->stream;
+    delete ctx;   // releases every DevBuf
+    if (st) (void)hipStreamDestroy(st);
 }
 
 extern "C" int dmpc_set_params(dmpc_ctx *ctx, const dmpc_params *prm)
