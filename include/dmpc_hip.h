@@ -167,7 +167,8 @@ int dmpc_advance_device(dmpc_ctx *ctx, int count, const double *p_out, const dou
 /* Whole transition on one device: the `for k = 1:K_T` loop of dmpc_soft_bound.m:115-148 /
  * DMPC::solveParallelDMPCv2 (dmpc/cpp/dmpc.cpp:1656-1686) incl. initDMPC at k = 1, the table
  * swap l = new_l and the ReachedGoal.m test.  Host pointers.
- * po,pf: [S][N][3]; pk,vk,ak: [S][N][K_T_max][3] (written up to K_T_used[s]);
+ * po,pf: [S][N][3]; pk,vk,ak: [S][N][K_T_max][3] (written up to K_T_used[s]) or all three NULL: the histories
+ * then only stay on the device (for dmpc_postcheck) and the 3 x S*N*K_T_max*24-byte download is skipped;
  * K_T_used[S]: number of MPC steps taken per scene; scene_status[S]: OR of agent status bits at
  * the step where the scene stopped; DMPC_ST_SOLVED | DMPC_ST_REACHED = every agent within error_tol of its goal
  * (ReachedGoal.m), DMPC_ST_SOLVED alone = ran to K_T_max without reaching (failed_goal, failure_rate.m:131-134). */

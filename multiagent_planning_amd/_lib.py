@@ -232,16 +232,22 @@ class Dmpc:
         k = min(int(nr[0]), max_rows)
         return dict(xi=xi[:k], rhs=rhs[:k], slack_coef=sc[:k], kc=kc[:k], nrows=int(nr[0]), viol_k=int(vk[0]), status=int(st[0]))
 
-    def transition(self, po, pf, K_T_max, error_tol=0.01):
+    def transition(self, po, pf, K_T_max, error_tol=0.01, histories=True):
+        """histories=False: pk/vk/ak are not downloaded (they stay on the device for postcheck())."""
         po, pf = _f(po), _f(pf)
         shp = po.shape[:-1]
         S, N = (1, shp[0]) if len(shp) == 1 else shp
-        pk = np.zeros(shp + (K_T_max, 3))
-        vk, ak = np.zeros_like(pk), np.zeros_like(pk)
         used = np.zeros(S, dtype=np.int32)
         sst = np.zeros(S, dtype=np.int32)
-        self._chk(self._L.dmpc_transition(self._ctx, S, N, _dp(po), _dp(pf), int(K_T_max), float(error_tol), _dp(pk), _dp(vk),
-                                          _dp(ak), _ip(used), _ip(sst)))
+        if histories:
+            pk = np.zeros(shp + (K_T_max, 3))
+            vk, ak = np.zeros_like(pk), np.zeros_like(pk)
+            hp = (_dp(pk), _dp(vk), _dp(ak))
+        else:
+            pk = vk = ak = None
+            hp = (C.POINTER(C.c_double)(),) * 3
+        self._chk(self._L.dmpc_transition(self._ctx, S, N, _dp(po), _dp(pf), int(K_T_max), float(error_tol), hp[0], hp[1], hp[2],
+                                          _ip(used), _ip(sst)))
         return dict(pk=pk, vk=vk, ak=ak, K_T_used=used, scene_status=sst)
 
     def postcheck(self, K_T_used, pf, pk=None, vk=None, ak=None, KT_alloc=None, vmax=2.0, amax=1.0, Ts=0.01, interp=False,

@@ -737,7 +737,7 @@ extern "C" int dmpc_transition(dmpc_ctx *ctx, int S, int N, const double *po, co
                                int32_t *scene_status)
 {
     if (!ctx) { g_err = "dmpc_transition: ctx is NULL"; return -1; }
-    if (S < 1 || N < 1 || K_T_max < 2 || !po || !pf || !pk || !vk || !ak || !K_T_used || !scene_status)
+    if (S < 1 || N < 1 || K_T_max < 2 || !po || !pf || !K_T_used || !scene_status || ((pk || vk || ak) && !(pk && vk && ak)))
         FAIL(ctx, "dmpc_transition: bad arguments");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const size_t A = (size_t)S * N;
@@ -799,9 +799,11 @@ extern "C" int dmpc_transition(dmpc_ctx *ctx, int S, int N, const double *po, co
                 }
         }
     }
-    HIPCHK(ctx, hipMemcpyAsync(pk, ctx->hist_p.p, hist, hipMemcpyDeviceToHost, st));
-    HIPCHK(ctx, hipMemcpyAsync(vk, ctx->hist_v.p, hist, hipMemcpyDeviceToHost, st));
-    HIPCHK(ctx, hipMemcpyAsync(ak, ctx->hist_a.p, hist, hipMemcpyDeviceToHost, st));
+    if (pk) {   // the histories stay resident for dmpc_postcheck either way; the download is optional
+        HIPCHK(ctx, hipMemcpyAsync(pk, ctx->hist_p.p, hist, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipMemcpyAsync(vk, ctx->hist_v.p, hist, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipMemcpyAsync(ak, ctx->hist_a.p, hist, hipMemcpyDeviceToHost, st));
+    }
     HIPCHK(ctx, hipStreamSynchronize(st));
     ctx->hist_S = S; ctx->hist_N = N; ctx->hist_KT = K_T_max;
     return 0;

@@ -48,12 +48,12 @@ def run_transition(dmpc, po, pf, K_T_max, error_tol=0.01):
     return dmpc.transition(po, pf, K_T_max, error_tol)
 
 
-def run_trial(dmpc, po, pf, K_T_max, error_tol=0.01, vmax=2.0, amax=1.0, Ts=0.01):
+def run_trial(dmpc, po, pf, K_T_max, error_tol=0.01, vmax=2.0, amax=1.0, Ts=0.01, histories=True):
     """One trial of the reference's test scripts for S scenes (test/failure_rate.m:99-197): the transition loop,
     then -- for scenes that stayed feasible and reached their goals -- the post-checks, which read the histories
     the transition left on the device.  `success` is failure_rate.m:196
     (`feasible && ~failed_goal && ~violation`); t/totdist/traj_time are NaN for failed scenes (:197-201)."""
-    tr = dmpc.transition(po, pf, K_T_max, error_tol)
+    tr = dmpc.transition(po, pf, K_T_max, error_tol, histories=histories)   # histories=False: outcomes only, nothing big comes back
     S = tr["K_T_used"].shape[0]
     st = tr["scene_status"]
     feasible = (st & ~ST_REACHED) == ST_SOLVED                 # no agent failed before the scene stopped

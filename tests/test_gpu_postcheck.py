@@ -180,3 +180,15 @@ def test_failure_rate_experiment_statistics():
         assert lo <= p <= hi, (N, p)
         assert not res["failed_goal"].any()                      # the reference's failures are infeasibility / collisions, not timeouts
         assert (res["success"] == (res["feasible"] & ~res["failed_goal"] & (res["violation"] == 0))).all()
+
+
+def test_run_trial_without_history_download_gives_the_same_outcomes():
+    cfg = wl.CONFIGS["C4"]
+    N = 16
+    kw = wl.solver_kwargs(cfg, N)
+    po, pf = wl.make_scenes(cfg, 5, N, wl.SEED0 + 21)
+    a = driver.run_trial(mp.Dmpc("bound", **kw), po, pf, 151, cfg["error_tol"])
+    b = driver.run_trial(mp.Dmpc("bound", **kw), po, pf, 151, cfg["error_tol"], histories=False)
+    assert b["pk"] is None and a["pk"] is not None
+    for k in ("K_T_used", "scene_status", "success", "feasible", "violation", "totdist", "traj_time", "r_factor"):
+        assert np.array_equal(a[k], b[k], equal_nan=True), k
