@@ -59,10 +59,8 @@ struct dmpc_ctx {
     int no_persist = getenv("DMPC_NO_PERSIST") ? 1 : 0;   // tuning: one-agent-per-workgroup solve launches
     int max_lds_persist = 0;
     int force_persist = getenv("DMPC_FORCE_PERSIST") ? 1 : 0;   // tests: exercise the persistent kernel on small launches
-    // chunk-level bounding-box neighbour culling in the scan: measured SLOWER on C4 at MPC steps 2-4 (3 s horizon
-    // boxes of fast agents overlap almost every 64-neighbour chunk), so it is opt-in (DMPC_CULL=1) until the scan
-    // compacts survivors per neighbour
-    int no_cull = getenv("DMPC_CULL") ? 0 : 1;   // collision-row scratch + scan->solve header of the step kernels
+    // per-neighbour bounding-box culling in the scan of large scenes (DMPC_NO_CULL=1 disables it, for A/B runs)
+    int no_cull = getenv("DMPC_NO_CULL") ? 1 : 0;
     int no_lpt = getenv("DMPC_NO_LPT") ? 1 : 0;   // tuning: disable the heaviest-first solve order
     int single_tier = 0;         // 1: solve with the full working-set capacity in one launch
     DevBuf rows, lT, lT2, xp, xv, xa, pf, po, pout, vout, aout, status, info, hist_p, hist_v, hist_a, flags;
@@ -385,7 +383,11 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     P.dbg = ctx->dbg; P.dbg_agent = ctx->dbg_agent; P.dbg_cap = ctx->dbg_cap;
     const int q1 = ctx->single_tier ? full_qcap(p.variant) : tier1_qcap(p.variant), q2 = full_qcap(p.variant);
     const bool two_tier = q1 < q2;
-    const size_t lds0 = step_lds_bytes(P.nrmax, soft, q1, 0);
+    // neighbour list of the scan: a quarter of the scene (fast agents have long horizon boxes), 1024..8192 entries
+    int nbr_cap = 0;
+    if (G * C >= 256 && !ctx->no_cull) { nbr_cap = 1024; while (nbr_cap < G * C / 4 && nbr_cap < 8192) nbr_cap *= 2; }
+    P.nbr_cap = nbr_cap;
+    const size_t lds0 = step_lds_bytes(P.nrmax, soft, q1, 0, nbr_cap);
     const size_t lds1 = step_lds_bytes(P.nrmax, soft, q1, 1), lds2 = step_lds_bytes(P.nrmax, soft, q2, 1);
     const size_t ldsmax = lds2 > lds1 ? lds2 : lds1;
     if ((int)ldsmax > ctx->max_lds_set) {
@@ -402,7 +404,12 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     }
     const dim3 grid((unsigned)(S * c_count)), block(64);
     // neighbour culling boxes (worth it once a scene has more than a few chunks of neighbours)
-    if (G * C >= 256 && !ctx->no_cull) {
+    // only for the variants whose scan and rows have a finite neighbour radius (d < 1 for the hard rows, d < 3 rmin for the
+    // near-neighbour selections); solveEllipDMPC / solveSoftDMPC / solveSoftDMPCrepair take every neighbour
+    const bool finite_radius = p.variant == DMPC_VAR_HARD || p.variant == DMPC_VAR_BOUND || p.variant == DMPC_VAR_BOUND2 ||
+                               p.variant == DMPC_VAR_ALL3 || p.variant == DMPC_VAR_ONDEMAND || p.variant == DMPC_VAR_CPP ||
+                               p.variant == DMPC_VAR_CPP2;
+    if (G * C >= 256 && !ctx->no_cull && finite_radius) {
         const int total = G * S * C;
         if (ctx->bbox.ensure((size_t)total * 6 * 8)) FAIL(ctx, "device allocation failed (bbox)");
         hipLaunchKernelGGL(bbox_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, C, lT, ctx->bbox.as<double>());

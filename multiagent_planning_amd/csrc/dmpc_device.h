@@ -34,6 +34,7 @@ struct StepParams {
     int no_prune;           // 1: keep every row the reference builds (dmpc_rows_one); 0: exact pruning
     const double *bbox;     // [G][S][6][C] horizon bounding boxes (bbox_kernel) or null: neighbour culling in the scan
     const int *order;       // solve-phase launch order (agent ids, heaviest first) or null
+    int nbr_cap;            // scan: capacity of the LDS neighbour list (0: no list)
     int *counter;           // persistent solve kernel: queue head (zeroed before the launch)
     int lds_per_wave;       // persistent solve kernel: bytes of LDS per wave (after the shared tables)
     int *flag_count, *flag_list;   // tier 1 -> tier 2: number / ids of the agents whose working set overflowed (or null)
@@ -44,9 +45,9 @@ struct StepParams {
 constexpr int SCAN_CAND_CAP = 1024;   // (neighbour, step) candidates buffered per flush of the hard-row scan
 
 // bytes of dynamic LDS the step kernel carves for a given row capacity
-inline size_t step_lds_bytes(int nrmax, bool soft, int qcap, int phase)
+inline size_t step_lds_bytes(int nrmax, bool soft, int qcap, int phase, int nbr_cap = 0)
 {
-    if (phase == 0) return 48 * 8 + SCAN_CAND_CAP * 4;   // own prediction + candidate list of the all-k (hard) scan
+    if (phase == 0) return 48 * 8 + (SCAN_CAND_CAP + (size_t)nbr_cap) * 4;   // own prediction + candidate list of the all-k (hard) scan + neighbour list
     size_t dbl = (size_t)t_doubles(qcap) + 676 + 4 * 48 + 2 * 64 + 6 * (size_t)qcap + (soft ? (size_t)nrmax : 0);
     size_t bytes = dbl * 8 + 3 * (size_t)qcap * 4 + (size_t)nrmax;   // + slot ints + row flags (bytes)
     return (bytes + 15) & ~(size_t)15;

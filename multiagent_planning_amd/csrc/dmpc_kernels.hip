@@ -433,12 +433,13 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
 
     const int qcap = P.qcap;
     Lds L;
-    int *scan_cand = nullptr;
+    int *scan_cand = nullptr, *scan_nbr = nullptr;
     {
         double *p = (double *)smem;
         if (PHASE == 0) {
             L.own_s = p; p += 48;
             scan_cand = (int *)p;   // SCAN_CAND_CAP ints
+            scan_nbr = scan_cand + SCAN_CAND_CAP;   // P.nbr_cap ints
             L.T = L.tabH = L.tabM = L.tabP = L.a_s = L.w_s = L.nu_s = L.yt_s = nullptr;
             L.s_vec = L.s_ss = L.s_d = L.s_lam = L.rr_s = L.xs_s = L.r_eps = nullptr;
             L.s_kb = L.s_ty = L.s_idx = nullptr; L.r_fl = nullptr;
@@ -497,23 +498,57 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
     const bool coll_check = (var == VAR_BOUND || var == VAR_BOUND2 || var == VAR_ALL3 || var == VAR_REPAIR);
     const bool skip_k1 = (var == VAR_BOUND2 || var == VAR_ALL3 || var == VAR_REPAIR || var == VAR_CPP2);
     bool coll_flag = false;
-    // own horizon box (uniform) for the neighbour culling, PHASE 0 only
+    // own horizon box (uniform) for the neighbour culling; PHASE 0 with a neighbour list only
     double obx0 = 0, obx1 = 0, oby0 = 0, oby1 = 0, obz0 = 0, obz1 = 0;
-    if (PHASE == 0) {
+    if (PHASE == 0 && P.bbox && P.nbr_cap > 0) {
         const double v = (lane < N3) ? L.own_s[lane] : 0.0;
         const int ax = lane % 3;
         obx0 = wave_min((lane < N3 && ax == 0) ? v : INFINITY); obx1 = wave_max((lane < N3 && ax == 0) ? v : -INFINITY);
         oby0 = wave_min((lane < N3 && ax == 1) ? v : INFINITY); oby1 = wave_max((lane < N3 && ax == 1) ? v : -INFINITY);
         obz0 = wave_min((lane < N3 && ax == 2) ? v : INFINITY); obz1 = wave_max((lane < N3 && ax == 2) ? v : -INFINITY);
     }
-    // true if some neighbour of this 64-wide chunk can come within ellipsoidal distance R of the agent
-    auto chunk_may_hit = [&](int r, int jc, bool valid, double R) -> bool {
-        if (!P.bbox) return true;
-        const double *bb = P.bbox + ((size_t)(r * S + scene) * 6) * C + jc;
-        const double Rz = R / P.e1z;   // |dz|/c < R
-        const bool hit = valid && bb[0] <= obx1 + R && bb[(size_t)C] >= obx0 - R && bb[2 * (size_t)C] <= oby1 + R &&
-                         bb[3 * (size_t)C] >= oby0 - R && bb[4 * (size_t)C] <= obz1 + Rz && bb[5 * (size_t)C] >= obz0 - Rz;
-        return __any(hit);
+    // Neighbour compaction (large scenes): a neighbour can come within ellipsoidal distance R of the agent at some
+    // horizon step only if the bounding boxes of the two predicted horizons are within R per axis.  The survivors of
+    // that test (a few per cent at N = 10^3..10^4) are compacted, in increasing index order, into an LDS list, and
+    // the distance tests / row builders below walk the list instead of all N neighbours.  Conservative: results are
+    // unchanged.  nnbr < 0: no list (small scenes, variants that take every neighbour, or more survivors than fit).
+    int nnbr = -1;
+    if (PHASE == 0 && P.bbox && P.nbr_cap > 0) {
+        const double R = (var == VAR_HARD) ? 1.0 : 3.0 * rmin, Rz = R / P.e1z;   // |dz|/c < R; the cpp radius is <= 2 rmin
+        int cnt = 0;
+        bool fits = true;
+        for (int r = 0; r < G && fits; ++r)
+            for (int j0 = 0; j0 < C; j0 += 64) {
+                const int jj = j0 + lane;
+                const bool valid = jj < C && !(r == P.g_local && jj == cl);
+                const int jc = jj < C ? jj : C - 1;
+                const double *bb = P.bbox + ((size_t)(r * S + scene) * 6) * C + jc;
+                const bool hit = valid && bb[0] <= obx1 + R && bb[(size_t)C] >= obx0 - R && bb[2 * (size_t)C] <= oby1 + R &&
+                                 bb[3 * (size_t)C] >= oby0 - R && bb[4 * (size_t)C] <= obz1 + Rz && bb[5 * (size_t)C] >= obz0 - Rz;
+                const unsigned long long hm = __ballot(hit);
+                if (hm) {
+                    if (cnt + __popcll(hm) > P.nbr_cap) { fits = false; break; }
+                    if (hit) scan_nbr[cnt + lanes_below(hm, lane)] = (r << 20) | jc;
+                    cnt += __popcll(hm);
+                }
+            }
+        if (fits) nnbr = cnt;
+        LSYNC();
+    }
+    // the neighbours are walked 64 at a time: entry e0 + lane of the list, or neighbour (r, j0 + lane) of the table
+    const int cpad = (C + 63) & ~63;
+    const int n_entries = nnbr >= 0 ? nnbr : G * cpad;
+    auto entry = [&](int e0, int &r, int &jc) -> bool {
+        if (nnbr >= 0) {
+            const bool have = e0 + lane < nnbr;
+            const int code = have ? scan_nbr[e0 + lane] : 0;
+            r = code >> 20; jc = code & 0xfffff;
+            return have;
+        }
+        r = e0 / cpad;
+        const int jj = e0 - r * cpad + lane;
+        jc = jj < C ? jj : C - 1;   // clamped: loads are unconditional, results masked
+        return jj < C && !(r == P.g_local && jj == cl);
     };
 
     if (PHASE == 0) {
@@ -583,25 +618,21 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
         auto build_rows = [&](int ksel, int ke, int kc, double sel_r, bool sel_all) {
             const double qx = L.own_s[3 * ksel], qy = L.own_s[3 * ksel + 1], qz = L.own_s[3 * ksel + 2];
             const double px = L.own_s[3 * ke], py = L.own_s[3 * ke + 1], pz = L.own_s[3 * ke + 2];
-            for (int r = 0; r < G; ++r) {
-                const double *bsel = P.lT + ((size_t)(r * S + scene) * N3 + 3 * ksel) * C;
-                const double *base = P.lT + ((size_t)(r * S + scene) * N3 + 3 * ke) * C;
-                for (int j0 = 0; j0 < C; j0 += 64) {
-                    const int jj = j0 + lane;
-                    const bool valid = jj < C && !(r == P.g_local && jj == cl);
-                    const int jc = jj < C ? jj : C - 1;   // clamped: loads are unconditional, results masked
-                    if (!sel_all && !chunk_may_hit(r, jc, valid, sel_r)) continue;
-                    const double dx = px - base[jc], dy = py - base[(size_t)C + jc], dz = pz - base[2 * (size_t)C + jc];
-                    const double ez = dz * P.e1z;
-                    const double dist = sqrt(dx * dx + dy * dy + ez * ez);
-                    double dsel = dist;
-                    if (ksel != ke && !sel_all) {
-                        const double sx = qx - bsel[jc], sy = qy - bsel[(size_t)C + jc];
-                        const double sz = (qz - bsel[2 * (size_t)C + jc]) * P.e1z;
-                        dsel = sqrt(sx * sx + sy * sy + sz * sz);
-                    }
-                    emit_row(valid && (sel_all || dsel < sel_r), kc, dx, dy, dz, dist, px, py, pz);
+            for (int e0 = 0; e0 < n_entries; e0 += 64) {
+                int r, jc;
+                const bool valid = entry(e0, r, jc);
+                const double *nbp = P.lT + ((size_t)(r * S + scene) * N3) * C + jc;
+                const double *base = nbp + (size_t)(3 * ke) * C, *bsel = nbp + (size_t)(3 * ksel) * C;
+                const double dx = px - base[0], dy = py - base[(size_t)C], dz = pz - base[2 * (size_t)C];
+                const double ez = dz * P.e1z;
+                const double dist = sqrt(dx * dx + dy * dy + ez * ez);
+                double dsel = dist;
+                if (ksel != ke && !sel_all) {
+                    const double sx = qx - bsel[0], sy = qy - bsel[(size_t)C];
+                    const double sz = (qz - bsel[2 * (size_t)C]) * P.e1z;
+                    dsel = sqrt(sx * sx + sy * sy + sz * sz);
                 }
+                emit_row(valid && (sel_all || dsel < sel_r), kc, dx, dy, dz, dist, px, py, pz);
             }
         };
 
@@ -629,23 +660,20 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
         unsigned anyb = 0;
         double mind0 = 1e300;
         const double rmin2_hi = rmin * rmin * (1.0 + 1e-9);
-        for (int r = 0; r < G; ++r) {
-            const double *base = P.lT + ((size_t)(r * S + scene) * N3) * C;
-            for (int j0 = 0; j0 < C; j0 += 64) {
-                const int jj = j0 + lane;
-                const bool valid = jj < C && !(r == P.g_local && jj == cl);
-                const int jc = jj < C ? jj : C - 1;
-                // hard rows need d < 1; every other variant only needs to know about neighbours inside rmin here
-                if (!chunk_may_hit(r, jc, valid, var == VAR_HARD ? 1.0 : rmin)) continue;
+        {
+            for (int e0 = 0; e0 < n_entries; e0 += 64) {
+                int r, jc;
+                const bool valid = entry(e0, r, jc);
+                const double *base = P.lT + ((size_t)(r * S + scene) * N3) * C + jc;
     #pragma unroll 1
                 for (int kg = 0; kg < 3; ++kg) {   // not unrolled: keeps the scan's register footprint small
                     double nx[5], ny[5], nz[5];
     #pragma unroll
                     for (int u = 0; u < 5; ++u) {
                         const int k = 5 * kg + u;
-                        nx[u] = base[(size_t)(3 * k) * C + jc];
-                        ny[u] = base[(size_t)(3 * k + 1) * C + jc];
-                        nz[u] = base[(size_t)(3 * k + 2) * C + jc];
+                        nx[u] = base[(size_t)(3 * k) * C];
+                        ny[u] = base[(size_t)(3 * k + 1) * C];
+                        nz[u] = base[(size_t)(3 * k + 2) * C];
                     }
     #pragma unroll
                     for (int u = 0; u < 5; ++u) {
