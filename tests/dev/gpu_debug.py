@@ -1,8 +1,8 @@
 """ad-hoc GPU-vs-oracle comparison with diagnostics (development tool)."""
 import sys, os
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 import multiagent_planning_amd as mp
 from oracle import oracle as orc
 from helpers import load_golden, oracle_params, step14_inputs, ALL_VARIANTS

@@ -1,7 +1,7 @@
 """development aid: find agents flagged CAPACITY/ITERCAP in the emulated multi-GPU bench workload."""
 import sys, os
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import multiagent_planning_amd as mp
 from multiagent_planning_amd import workload as wl
 import bench
