@@ -54,7 +54,7 @@ struct dmpc_ctx {
     int64_t solves = 0;
     int max_lds_set = 0;
     // scratch for the host-pointer entry points
-    DevBuf rowbuf, rowkc, hdr, order, bbox, counter, flag_list;
+    DevBuf rowbuf, rowkc, hdr, order, bbox, counter, flag_list, scene_done;
     int num_cu = 0;
     int no_persist = getenv("DMPC_NO_PERSIST") ? 1 : 0;   // tuning: one-agent-per-workgroup solve launches
     int max_lds_persist = 0;
@@ -354,7 +354,8 @@ static int full_qcap(int variant) { return variant_soft(variant) ? QMAX : 48; }
 
 static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_first, int c_count, const double *lT,
                        const double *x_p, const double *x_v, const double *x_a, const double *pf, double *p_out,
-                       double *v_out, double *a_out, double *lT_next, int32_t *status, int32_t *info, hipStream_t st)
+                       double *v_out, double *a_out, double *lT_next, int32_t *status, int32_t *info, hipStream_t st,
+                       const int *scene_done = nullptr)
 {
     const dmpc_params &p = ctx->prm;
     const bool soft = variant_soft(p.variant);
@@ -387,6 +388,7 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     int nbr_cap = 0;
     if (G * C >= 256 && !ctx->no_cull) { nbr_cap = 1024; while (nbr_cap < G * C / 4 && nbr_cap < 8192) nbr_cap *= 2; }
     P.nbr_cap = nbr_cap;
+    P.scene_done = scene_done;
     const size_t lds0 = step_lds_bytes(P.nrmax, soft, q1, 0, nbr_cap);
     const size_t lds1 = step_lds_bytes(P.nrmax, soft, q1, 1), lds2 = step_lds_bytes(P.nrmax, soft, q2, 1);
     const size_t ldsmax = lds2 > lds1 ? lds2 : lds1;
@@ -751,13 +753,14 @@ extern "C" int dmpc_transition(dmpc_ctx *ctx, int S, int N, const double *po, co
     if (ensure_step_scratch(ctx, A, A)) return -1;
     const size_t hist = A * (size_t)K_T_max * 24;
     if (ctx->lT2.ensure(A * N3 * 8) || ctx->po.ensure(A * 24) || ctx->hist_p.ensure(hist) || ctx->hist_v.ensure(hist) ||
-        ctx->hist_a.ensure(hist) || ctx->flags.ensure((size_t)K_T_max * S * 8))
+        ctx->hist_a.ensure(hist) || ctx->flags.ensure((size_t)K_T_max * S * 8) || ctx->scene_done.ensure((size_t)S * 4))
         FAIL(ctx, "device allocation failed");
     hipStream_t st = ctx->stream;
     double *xp = ctx->xp.as<double>(), *xv = ctx->xv.as<double>(), *xa = ctx->xa.as<double>();
     HIPCHK(ctx, hipMemcpyAsync(ctx->po.p, po, A * 24, hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipMemcpyAsync(ctx->pf.p, pf, A * 24, hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipMemsetAsync(ctx->flags.p, 0, (size_t)K_T_max * S * 8, st));
+    HIPCHK(ctx, hipMemsetAsync(ctx->scene_done.p, 0, (size_t)S * 4, st));
     HIPCHK(ctx, hipMemsetAsync(ctx->hist_p.p, 0, hist, st));
     HIPCHK(ctx, hipMemsetAsync(ctx->hist_v.p, 0, hist, st));
     HIPCHK(ctx, hipMemsetAsync(ctx->hist_a.p, 0, hist, st));
@@ -779,14 +782,15 @@ extern "C" int dmpc_transition(dmpc_ctx *ctx, int S, int N, const double *po, co
     const int chunk = 8;   // host looks at the per-step flags every `chunk` MPC steps
     for (int k = 1; k < K_T_max && ndone < S; ++k) {
         if (launch_step(ctx, S, 1, N, 0, 0, N, cur, xp, xv, xa, ctx->pf.as<double>(), ctx->pout.as<double>(),
-                        ctx->vout.as<double>(), ctx->aout.as<double>(), nxt, ctx->status.as<int32_t>(), nullptr, st))
+                        ctx->vout.as<double>(), ctx->aout.as<double>(), nxt, ctx->status.as<int32_t>(), nullptr, st,
+                        ctx->scene_done.as<int>()))
             return -1;
         hipLaunchKernelGGL(advance_kernel, dim3(rb), dim3(256), 0, st, (int)A, ctx->pout.as<double>(), ctx->vout.as<double>(),
                            ctx->aout.as<double>(), (const int *)ctx->status.as<int32_t>(), xp, xv, xa);
         hipLaunchKernelGGL(record_kernel, dim3(rb), dim3(256), 0, st, S, N, K_T_max, k, xp, xv, xa, ctx->hist_p.as<double>(),
                            ctx->hist_v.as<double>(), ctx->hist_a.as<double>());
         hipLaunchKernelGGL(scene_reduce_kernel, dim3((unsigned)S), dim3(256), 0, st, N, error_tol, xp, ctx->pf.as<double>(),
-                           (const int *)ctx->status.as<int32_t>(), ctx->flags.as<int>() + (size_t)k * S * 2);
+                           (const int *)ctx->status.as<int32_t>(), ctx->flags.as<int>() + (size_t)k * S * 2, ctx->scene_done.as<int>());
         HIPCHK(ctx, hipGetLastError());
         std::swap(cur, nxt);   // l = new_l (dmpc_soft_bound.m:146)
         if (k % chunk == 0 || k == K_T_max - 1) {

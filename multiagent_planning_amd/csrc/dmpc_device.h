@@ -35,6 +35,7 @@ struct StepParams {
     const double *bbox;     // [G][S][6][C] horizon bounding boxes (bbox_kernel) or null: neighbour culling in the scan
     const int *order;       // solve-phase launch order (agent ids, heaviest first) or null
     int nbr_cap;            // scan: capacity of the LDS neighbour list (0: no list)
+    const int *scene_done;  // [S] or null: scenes of a transition that already stopped (reached their goals / failed): skipped
     int *counter;           // persistent solve kernel: queue head (zeroed before the launch)
     int lds_per_wave;       // persistent solve kernel: bytes of LDS per wave (after the shared tables)
     int *flag_count, *flag_list;   // tier 1 -> tier 2: number / ids of the agents whose working set overflowed (or null)

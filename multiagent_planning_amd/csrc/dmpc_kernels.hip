@@ -469,6 +469,12 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
     }
     int *hdr = P.hdr + (size_t)gid * 8;
     if (PHASE == 1 && P.only_flagged && !(P.status[gid] & ST_QOVER)) return;   // tier 2: only agents that overflowed tier 1
+    if (PHASE == 1 && (hdr[4] & 8)) return;                                       // agent of a scene that already stopped
+    if (PHASE == 0 && P.scene_done && P.scene_done[scene]) {
+        // the scene's transition is over (dmpc_transition): nothing to solve, the state stays frozen (status 0 = no update)
+        if (lane == 0) { hdr[0] = 0; hdr[1] = 0; hdr[2] = 0; hdr[3] = 0; hdr[4] = 8; hdr[5] = 0; hdr[6] = 0; hdr[7] = 0; P.status[gid] = 0; }
+        return;
+    }
 
     // ---------------------------------------------------------------- agent state (uniform)
     Agent A;
@@ -1457,7 +1463,7 @@ __global__ void record_kernel(int S, int N, int KT, int k, const double *__restr
 
 // one block per scene: flags[0] = ReachedGoal.m:3-11 (max_i ||p_i - pf_i|| < tol), flags[1] = OR of status bits
 __global__ void scene_reduce_kernel(int N, double tol, const double *__restrict__ x_p, const double *__restrict__ pf,
-                                    const int *__restrict__ status, int *flags)
+                                    const int *__restrict__ status, int *flags, int *scene_done)
 {
     __shared__ double smax[256];
     __shared__ int sor[256];
@@ -1475,7 +1481,12 @@ __global__ void scene_reduce_kernel(int N, double tol, const double *__restrict_
         if ((int)threadIdx.x < w) { smax[threadIdx.x] = fmax(smax[threadIdx.x], smax[threadIdx.x + w]); sor[threadIdx.x] |= sor[threadIdx.x + w]; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { flags[(size_t)s * 2] = smax[0] < tol ? 1 : 0; flags[(size_t)s * 2 + 1] = sor[0]; }
+    if (threadIdx.x == 0) {
+        const int reached = smax[0] < tol ? 1 : 0;
+        flags[(size_t)s * 2] = reached; flags[(size_t)s * 2 + 1] = sor[0];
+        // the trial of this scene is over (failure_rate.m:112-125): later steps skip it on the device as well
+        if (scene_done && (reached || (sor[0] & ~ST_SOLVED))) scene_done[s] = 1;
+    }
 }
 
 }  // namespace dmpc
