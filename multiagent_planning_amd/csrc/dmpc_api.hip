@@ -11,6 +11,7 @@
 #include <cstring>
 #include <algorithm>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/dmpc_hip.h"
@@ -65,6 +66,9 @@ struct dmpc_ctx {
     int single_tier = 0;         // 1: solve with the full working-set capacity in one launch
     DevBuf rows, lT, lT2, xp, xv, xa, pf, po, pout, vout, aout, status, info, hist_p, hist_v, hist_a, flags;
     int hist_S = 0, hist_N = 0, hist_KT = 0;   // shape of the histories left resident by the last dmpc_transition
+    dmpc_ctx *child = nullptr;   // second context (own stream and buffers) for the other half of a split batch of transitions
+    int split_S0 = 0;            // > 0: the last dmpc_transition left scenes [0, split_S0) here and the rest in `child`
+    int no_split = getenv("DMPC_NO_SPLIT") ? 1 : 0;
     DevBuf pc_p, pc_v, pc_a, pc_M, pc_w, pc_scene, pc_agent, pc_interp;   // post-check work buffers
     DevBuf rb_A, rb_l, rb_sel, rb_out, rb_bin, rb_po, gen_out, hp_in, hp_out;                     // dense row builders (host-pointer entries)
     // profiling
@@ -282,6 +286,7 @@ extern "C" dmpc_ctx *dmpc_create(const dmpc_params *prm, int device)
 extern "C" void dmpc_destroy(dmpc_ctx *ctx)
 {
     if (!ctx) return;
+    if (ctx->child) { dmpc_destroy(ctx->child); ctx->child = nullptr; }
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (auto &ev : ctx->events) { (void)hipEventDestroy(ev.t0); (void)hipEventDestroy(ev.t1); (void)hipEventDestroy(ev.t2); }
@@ -741,9 +746,9 @@ extern "C" int dmpc_init_batch(dmpc_ctx *ctx, int S, int N, const double *po, co
 }
 
 // the whole `for k = 1:K_T` loop on the device (dmpc_soft_bound.m:115-148, failure_rate.m:99-127)
-extern "C" int dmpc_transition(dmpc_ctx *ctx, int S, int N, const double *po, const double *pf, int K_T_max,
-                               double error_tol, double *pk, double *vk, double *ak, int32_t *K_T_used,
-                               int32_t *scene_status)
+static int transition_one(dmpc_ctx *ctx, int S, int N, const double *po, const double *pf, int K_T_max,
+                          double error_tol, double *pk, double *vk, double *ak, int32_t *K_T_used,
+                          int32_t *scene_status)
 {
     if (!ctx) { g_err = "dmpc_transition: ctx is NULL"; return -1; }
     if (S < 1 || N < 1 || K_T_max < 2 || !po || !pf || !K_T_used || !scene_status || ((pk || vk || ak) && !(pk && vk && ak)))
@@ -820,13 +825,47 @@ extern "C" int dmpc_transition(dmpc_ctx *ctx, int S, int N, const double *po, co
     return 0;
 }
 
+// Batched transitions are bound, MPC step by MPC step, by the slowest agent of the whole batch while most of the GPU
+// idles.  Scenes are independent, so a large batch is run as two halves on two contexts (= two HIP streams, two host
+// threads): the tail of one half overlaps the bulk of the other (512 transitions of 100 agents: 103 -> 60 ms).
+extern "C" int dmpc_transition(dmpc_ctx *ctx, int S, int N, const double *po, const double *pf, int K_T_max,
+                               double error_tol, double *pk, double *vk, double *ak, int32_t *K_T_used,
+                               int32_t *scene_status)
+{
+    if (!ctx) { g_err = "dmpc_transition: ctx is NULL"; return -1; }
+    ctx->split_S0 = 0;
+    if (S < 32 || ctx->no_split || N < 1 || K_T_max < 2 || !po || !pf || !K_T_used || !scene_status)
+        return transition_one(ctx, S, N, po, pf, K_T_max, error_tol, pk, vk, ak, K_T_used, scene_status);
+    if (!ctx->child) {
+        ctx->child = dmpc_create(&ctx->prm, ctx->device);
+        if (!ctx->child) FAIL(ctx, "dmpc_transition: second context: " + g_err);
+        ctx->child->no_split = 1;
+    } else if (std::memcmp(&ctx->child->prm, &ctx->prm, sizeof(dmpc_params)) != 0 && dmpc_set_params(ctx->child, &ctx->prm)) {
+        FAIL(ctx, "dmpc_transition: second context: " + ctx->child->err);
+    }
+    const int S0 = S / 2, S1 = S - S0;
+    const size_t a0 = (size_t)S0 * N, h0 = a0 * (size_t)K_T_max * 3;
+    int rc1 = 0;
+    std::thread other([&]() {
+        rc1 = transition_one(ctx->child, S1, N, po + a0 * 3, pf + a0 * 3, K_T_max, error_tol, pk ? pk + h0 : nullptr, vk ? vk + h0 : nullptr,
+                             ak ? ak + h0 : nullptr, K_T_used + S0, scene_status + S0);
+    });
+    const int rc0 = transition_one(ctx, S0, N, po, pf, K_T_max, error_tol, pk, vk, ak, K_T_used, scene_status);
+    other.join();
+    if (rc1) FAIL(ctx, ctx->child->err);
+    if (rc0) return -1;
+    ctx->split_S0 = S0;   // the resident histories are split over the two contexts (dmpc_postcheck knows)
+    ctx->hist_S = S;
+    return 0;
+}
+
 // post-checks of S finished transitions (failure_rate.m:136-195): rescale, 100 Hz not-a-knot spline, pairwise
 // ellipsoidal collision check, path length, trajectory time.  pk == NULL: use the histories dmpc_transition left
 // resident on the device (no PCIe round trip).
-extern "C" int dmpc_postcheck(dmpc_ctx *ctx, int S, int N, int KT_alloc, const int32_t *K_T_used, const int32_t *scene_mask,
-                              const double *pk, const double *vk, const double *ak, const double *pf, double vmax, double amax, double Ts,
-                              double *r_factor, double *h_scaled, int32_t *n_samples, double *min_dist,
-                              int32_t *violation, double *totdist, double *traj_time, double *p_interp, int ns_alloc)
+static int postcheck_one(dmpc_ctx *ctx, int S, int N, int KT_alloc, const int32_t *K_T_used, const int32_t *scene_mask,
+                         const double *pk, const double *vk, const double *ak, const double *pf, double vmax, double amax, double Ts,
+                         double *r_factor, double *h_scaled, int32_t *n_samples, double *min_dist,
+                         int32_t *violation, double *totdist, double *traj_time, double *p_interp, int ns_alloc)
 {
     if (!ctx) { g_err = "dmpc_postcheck: ctx is NULL"; return -1; }
     if (S < 1 || N < 1 || KT_alloc < 2 || !K_T_used || !pf || !(vmax > 0) || !(amax > 0) || !(Ts > 0))
@@ -936,6 +975,35 @@ extern "C" int dmpc_postcheck(dmpc_ctx *ctx, int S, int N, int KT_alloc, const i
         if (traj_time) traj_time[s] = tt[s];
     }
     return 0;
+}
+
+extern "C" int dmpc_postcheck(dmpc_ctx *ctx, int S, int N, int KT_alloc, const int32_t *K_T_used, const int32_t *scene_mask,
+                              const double *pk, const double *vk, const double *ak, const double *pf, double vmax, double amax, double Ts,
+                              double *r_factor, double *h_scaled, int32_t *n_samples, double *min_dist,
+                              int32_t *violation, double *totdist, double *traj_time, double *p_interp, int ns_alloc)
+{
+    if (!ctx) { g_err = "dmpc_postcheck: ctx is NULL"; return -1; }
+    const int S0 = ctx->split_S0;
+    if (pk || S0 <= 0 || S0 >= S || ctx->hist_S != S || !ctx->child || !K_T_used || !pf)
+        return postcheck_one(ctx, S, N, KT_alloc, K_T_used, scene_mask, pk, vk, ak, pf, vmax, amax, Ts, r_factor, h_scaled, n_samples,
+                             min_dist, violation, totdist, traj_time, p_interp, ns_alloc);
+    // histories left resident by a split dmpc_transition: each half is checked where it lives, concurrently
+    auto off = [&](auto *ptr, size_t o) { return ptr ? ptr + o : ptr; };
+    const size_t a0 = (size_t)S0 * N;
+    ctx->hist_S = S0;
+    int rc1 = 0;
+    std::thread other([&]() {
+        rc1 = postcheck_one(ctx->child, S - S0, N, KT_alloc, K_T_used + S0, off(scene_mask, (size_t)S0), nullptr, nullptr, nullptr, pf + a0 * 3,
+                            vmax, amax, Ts, off(r_factor, (size_t)S0), off(h_scaled, (size_t)S0), off(n_samples, (size_t)S0),
+                            off(min_dist, (size_t)S0), off(violation, (size_t)S0), off(totdist, (size_t)S0), off(traj_time, (size_t)S0),
+                            off(p_interp, a0 * (size_t)ns_alloc * 3), ns_alloc);
+    });
+    const int rc0 = postcheck_one(ctx, S0, N, KT_alloc, K_T_used, scene_mask, nullptr, nullptr, nullptr, pf, vmax, amax, Ts, r_factor, h_scaled,
+                                  n_samples, min_dist, violation, totdist, traj_time, p_interp, ns_alloc);
+    other.join();
+    ctx->hist_S = S;
+    if (rc1) FAIL(ctx, ctx->child->err);
+    return rc0;
 }
 
 
