@@ -171,7 +171,10 @@ int dmpc_advance_device(dmpc_ctx *ctx, int count, const double *p_out, const dou
  * then only stay on the device (for dmpc_postcheck) and the 3 x S*N*K_T_max*24-byte download is skipped;
  * K_T_used[S]: number of MPC steps taken per scene; scene_status[S]: OR of agent status bits at
  * the step where the scene stopped; DMPC_ST_SOLVED | DMPC_ST_REACHED = every agent within error_tol of its goal
- * (ReachedGoal.m), DMPC_ST_SOLVED alone = ran to K_T_max without reaching (failed_goal, failure_rate.m:131-134). */
+ * (ReachedGoal.m), DMPC_ST_SOLVED alone = ran to K_T_max without reaching (failed_goal, failure_rate.m:131-134).
+ * Batches of 32 or more scenes are run as two halves on two internal contexts (two HIP streams, one helper host thread
+ * for the duration of the call) so that the slow tail of one half overlaps the other; scenes are independent, results
+ * do not depend on the split (DMPC_NO_SPLIT=1 in the environment disables it). */
 int dmpc_transition(dmpc_ctx *ctx, int S, int N, const double *po, const double *pf, int K_T_max,
                     double error_tol, double *pk, double *vk, double *ak, int32_t *K_T_used,
                     int32_t *scene_status);
