@@ -427,8 +427,14 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     P.qcap = q1; P.only_flagged = 0; P.qover_bit = two_tier ? ST_QOVER : ST_CAPACITY;
     if (soft) hipLaunchKernelGGL(dmpc_scan_kernel<true>, grid, block, lds0, st, P);
     else hipLaunchKernelGGL(dmpc_scan_kernel<false>, grid, block, lds0, st, P);
-    // heaviest-first launch order for the solve phase (skipped for tiny launches)
-    if (S * c_count >= 512 && !ctx->no_lpt) {
+    // heaviest-first launch order for the solve phase.  Tiny launches do not need it.  For the slack-carrying variants
+    // the row count separates the few heavy agents from the many without rows and the order always pays (51 200 agents of
+    // solveSoftDMPCbound: 32.6 vs 28.1 M/s).  For the slack-free variants every agent has rows and their number predicts
+    // the solve time poorly (correlation 0.3): a deep (persistent-wave) launch is then better off with the natural
+    // order, which keeps the agents of a scene -- and their row scratch -- together (30.0 vs 28.3 M/s).
+    const bool natural_order = !soft && !ctx->no_persist && ctx->num_cu >= 1 &&
+                               (long)S * c_count >= 16L * ctx->num_cu * 8 && !ctx->force_persist;
+    if (S * c_count >= 512 && !ctx->no_lpt && !natural_order) {
         const int total = S * c_count, nb = total >= 16384 ? 8 : 1;
         hipLaunchKernelGGL(order_kernel, dim3((unsigned)nb), dim3(1024), 0, st, total, (const int *)P.hdr, ctx->order.as<int>());
         P.order = ctx->order.as<int>();
