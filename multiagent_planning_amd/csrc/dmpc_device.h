@@ -7,9 +7,15 @@ namespace dmpc {
 constexpr int K = 15;         // horizon k_hor (dmpc_soft_bound.m:13)
 constexpr int N3 = 3 * K;     // stacked acceleration / position vector length
 constexpr int QMAX = 64;      // working-set capacity (slots of the inverse factor T) == wave size
-// doubles of the zero-padded column-major upper-triangular factor for a given working-set capacity
-// (columns up to the next multiple of 8, plus slack for unconditional wave reads past the last column)
-__host__ __device__ inline int t_doubles(int qcap) { const int c = (qcap + 7) & ~7; const int g = c >> 3; return 8 * (g + 1) * (c - 4 * g) + 64; }
+// Inverse-factor storage: upper-triangular T, column-major; the 8 columns of group g = j/8 are zero-padded to 8(g+1)
+// rows and stored with a stride of 8(g+1)+1 doubles.  The ODD stride is for the LDS banks: in the transposed product
+// lane j walks down column j, and with the natural stride 8(g+1) all columns of a group start on the same few banks
+// (measured: 40 % of the LDS cycles of the solve kernel were bank-conflict replays).
+__host__ __device__ inline int tcol(int j) { const int g = j >> 3; return 8 * g * (4 * g + 5) + (8 * g + 9) * (j - 8 * g); }
+// doubles of T for a given working-set capacity (columns up to the next multiple of 8).  Unconditional wave reads run
+// past the last column by up to 63 doubles; their values are masked, and the vectors that follow T in the per-agent LDS
+// block (>= 4 x 48 doubles) are what they touch.
+__host__ __device__ inline int t_doubles(int qcap) { return tcol((qcap + 7) & ~7); }
 constexpr int ITER_CAP = 4000;
 
 enum { VAR_BOUND = 0, VAR_BOUND2 = 1, VAR_ALL3 = 2, VAR_HARD = 3, VAR_ONDEMAND = 4, VAR_ELLIP = 5, VAR_SOFTALL = 6, VAR_REPAIR = 7,

@@ -185,11 +185,9 @@ __device__ __forceinline__ double sdot_self(const Lds &L, const Cdesc &p)
     return v;
 }
 
-// ---- inverse factor storage: upper-triangular T, column-major, column j zero-padded to a multiple of 8 rows:
-//   T[i][j] (i <= j) at Tp[tcol(j) + i],  tcol(j) = 8 (g+1)(j - 4g), g = j/8;  rows j+1 .. 8*ceil((j+1)/8)-1 are ZERO.
+// ---- inverse factor storage: T[i][j] (i <= j) at Tp[tcol(j) + i] (dmpc_device.h); rows j+1 .. 8*ceil((j+1)/8)-1 are ZERO.
 // The padding lets the column dot products run in unmasked groups of 8 (a lane either owns the whole group
 // or skips it), and "lane i reads row i of column j" is a contiguous wave read.
-__device__ __forceinline__ int tcol(int j) { const int g = j >> 3; return 8 * (g + 1) * (j - 4 * g); }
 
 // y = T' x  (lane j gets y_j).  x is in the LDS staging vector xs[0..63] (zero beyond q).  Per group of 8:
 // 16 unconditional LDS reads with immediate offsets, one wait, 8 FMAs, one lane mask for the whole group.
@@ -215,7 +213,7 @@ __device__ __forceinline__ double t_mul(const double *Tp, const double *xs, int 
     const double *row = Tp + lane;
     for (int j0 = 0; j0 < q; j0 += 8) {
         double t[8], x[8];
-        const int c0 = tcol(j0), len = j0 + 8;   // the 8 columns of this group all have padded length j0 + 8
+        const int c0 = tcol(j0), len = j0 + 9;   // the 8 columns of this group are j0 + 9 doubles apart
 #pragma unroll
         for (int u = 0; u < 8; ++u) { t[u] = row[c0 + u * len]; x[u] = xs[j0 + u]; }
 #pragma unroll
