@@ -239,7 +239,7 @@ def main():
             usedT = resT["K_T_used"]
             secondary.append({"workload": f"{St} whole transition(s), 100 agents, solveSoftDMPCbound (failure_rate.m constants), closed "
                                           f"loop on device incl. initDMPC, table swap, ReachedGoal and host<->device copies",
-                              "wall_ms": dtT * 1e3, "ms_per_transition": dtT * 1e3 / St, "mpc_steps": [int(u) for u in usedT],
+                              "wall_ms": dtT * 1e3, "ms_per_transition": dtT * 1e3 / St, "mpc_steps": ([int(u) for u in usedT] if St <= 8 else {"min": int(min(usedT)), "mean": float(sum(usedT)) / St, "max": int(max(usedT))}),
                               "completed": int(((resT["scene_status"] & 256) != 0).sum()),
                               "value": float(((usedT - 1) * 100).sum() / dtT), "unit": "solves/s"})
         # restore the headline workload's last outputs for the statistics below

@@ -394,7 +394,7 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     if (G * C >= 256 && !ctx->no_cull) { nbr_cap = 1024; while (nbr_cap < G * C / 4 && nbr_cap < 8192) nbr_cap *= 2; }
     P.nbr_cap = nbr_cap;
     P.scene_done = scene_done;
-    const size_t lds0 = step_lds_bytes(P.nrmax, soft, q1, 0, nbr_cap);
+    const size_t lds0 = (step_lds_bytes(P.nrmax, soft, q1, 0, nbr_cap) + 15) & ~(size_t)15;
     const size_t lds1 = step_lds_bytes(P.nrmax, soft, q1, 1), lds2 = step_lds_bytes(P.nrmax, soft, q2, 1);
     const size_t ldsmax = lds2 > lds1 ? lds2 : lds1;
     if ((int)ldsmax > ctx->max_lds_set) {
@@ -425,8 +425,17 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     HIPCHK(ctx, hipMemsetAsync(ctx->counter.p, 0, 16, st));   // queue heads of the persistent solve launches
     // phase 0: scan + rows
     P.qcap = q1; P.only_flagged = 0; P.qover_bit = two_tier ? ST_QOVER : ST_CAPACITY;
-    if (soft) hipLaunchKernelGGL(dmpc_scan_kernel<true>, grid, block, lds0, st, P);
-    else hipLaunchKernelGGL(dmpc_scan_kernel<false>, grid, block, lds0, st, P);
+    {
+        // several independent waves per workgroup (fewer workgroups to dispatch), as many as fit the default 64 KB of
+        // dynamic LDS (the neighbour list of large scenes can take 37 KB per wave)
+        const int total = S * c_count;
+        int W = SCAN_WAVES_PER_WG;
+        while (W > 1 && lds0 * W > 64 * 1024) W >>= 1;
+        const dim3 sgrid((unsigned)((total + W - 1) / W)), sblock(64u * W);
+        P.lds_per_wave = (int)lds0;
+        if (soft) hipLaunchKernelGGL(dmpc_scan_kernel<true>, sgrid, sblock, lds0 * W, st, P);
+        else hipLaunchKernelGGL(dmpc_scan_kernel<false>, sgrid, sblock, lds0 * W, st, P);
+    }
     // heaviest-first launch order for the solve phase.  Tiny launches do not need it.  For the slack-carrying variants
     // the row count separates the few heavy agents from the many without rows and the order always pays (51 200 agents of
     // solveSoftDMPCbound: 32.6 vs 28.1 M/s).  For the slack-free variants every agent has rows and their number predicts

@@ -19,6 +19,7 @@
 // butterfly, so results are bit-reproducible and independent of how agents are sharded.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "dmpc_device.h"
 
@@ -93,11 +94,37 @@ __device__ __forceinline__ int lanes_below(unsigned long long mask, int lane)
     return __popcll(mask & ((1ull << lane) - 1ull));
 }
 
+// Division of a per-lane index by a wave-uniform divisor d (numerators below `bound`): multiplication by a rounded-up
+// 32-bit reciprocal where that is exact up to one (bound * d < 2^32), by a double reciprocal otherwise; one correction
+// step in either direction makes the result exact.
+struct UDiv {
+    unsigned d, magic;
+    double inv;
+    bool use_mulhi;
+    __device__ __forceinline__ UDiv(unsigned d_, unsigned bound) : d(d_ ? d_ : 1u)
+    {
+        magic = d > 1u ? (unsigned)(0x100000000ull / d) + 1u : 0u;
+        inv = 1.0 / (double)d;
+        use_mulhi = (unsigned long long)bound * d < 0x100000000ull;
+    }
+    __device__ __forceinline__ void divmod(unsigned e, int &q, int &rem) const
+    {
+        if (d == 1u) { q = (int)e; rem = 0; return; }
+        q = use_mulhi ? (int)__umulhi(e, magic) : (int)((double)e * inv);
+        rem = (int)(e - (unsigned)q * d);
+        if (rem < 0) { q -= 1; rem += (int)d; }
+        else if (rem >= (int)d) { q += 1; rem -= (int)d; }
+    }
+};
+
 __device__ __forceinline__ double sel3(const double *v, int ax) { return ax == 0 ? v[0] : (ax == 1 ? v[1] : v[2]); }
 
 // constraint types
 #ifndef SCAN_WAVES_PER_SIMD
 #define SCAN_WAVES_PER_SIMD 4
+#endif
+#ifndef SCAN_WAVES_PER_WG
+#define SCAN_WAVES_PER_WG 4
 #endif
 #ifndef SOLVE_WAVES_PER_SIMD
 #define SOLVE_WAVES_PER_SIMD 2
@@ -664,20 +691,85 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
         unsigned anyb = 0;
         double mind0 = 1e300;
         const double rmin2_hi = rmin * rmin * (1.0 + 1e-9);
-        {
+        if (var == VAR_HARD) {
+            // solveHardDMPC.m:18-22 + CollConstrHardDMPC.m:19: every k, neighbours with dist < 1.  Two passes.  The first
+            // only tests the 15 N distances and compacts the (step, neighbour) candidates -- about one in ten -- into an
+            // LDS list; flush_candidates() then builds the rows of 64 candidates at a time, so the row arithmetic runs on
+            // full waves.  The first pass walks the FLAT index e = k * ne + entry (step-major, the reference's row order),
+            // 64 pairs per round: every round is a full wave whatever N is (lanes = neighbours wastes 22 % of the issue
+            // slots at N = 100, and the scan is instruction-issue bound), a lane's three loads share one address
+            // computation, and runs of lanes with the same k still read contiguous table rows.
+            const unsigned ne = (unsigned)(nnbr >= 0 ? nnbr : G * C);
+            const unsigned total = ne * (unsigned)K;
+            // e / ne and entry / C by a uniform divisor (udiv below)
+            const UDiv div_ne(ne, total), div_c((unsigned)C, (unsigned)(G * C));
+            const size_t slab = (size_t)N3 * C;
+            auto pass = [&](auto single_tag) {
+                constexpr bool single = decltype(single_tag)::value;   // one chunk, no neighbour list: entry == neighbour index
+                constexpr int UR = 4;   // rounds in flight: the loads of four rounds are issued before the first is used
+                for (unsigned e0 = 0; e0 < total; e0 += 64 * UR) {
+                    double nx[UR], ny[UR], nz[UR];
+                    int kk[UR], code[UR];
+                    bool ok[UR];
+#pragma unroll
+                    for (int u = 0; u < UR; ++u) {
+                        const unsigned e = e0 + 64u * u + (unsigned)lane;
+                        int k, idx;
+                        div_ne.divmod(e, k, idx);
+                        bool valid = e < total;
+                        if (!valid) { k = 0; idx = 0; }
+                        int r = 0, jc = idx;
+                        if (!single) {
+                            if (nnbr >= 0) {
+                                const int c = scan_nbr[idx];
+                                r = c >> 20; jc = c & 0xfffff;
+                            } else {
+                                div_c.divmod((unsigned)idx, r, jc);
+                                valid = valid && !(r == P.g_local && jc == cl);
+                            }
+                        } else valid = valid && jc != cl;
+                        const double *nb = P.lT + ((size_t)(single ? P.g_local : r) * S + scene) * slab + (unsigned)(3 * k * C + jc);
+                        nx[u] = nb[0]; ny[u] = nb[(size_t)C]; nz[u] = nb[2 * (size_t)C];
+                        kk[u] = k; code[u] = (k << 28) | (r << 20) | jc; ok[u] = valid;
+                    }
+#pragma unroll
+                    for (int u = 0; u < UR; ++u) {
+                        if (e0 + 64u * u >= total) break;
+                        const int k = kk[u];
+                        const double px = L.own_s[3 * k], py = L.own_s[3 * k + 1], pz = L.own_s[3 * k + 2];
+                        const double dx = px - nx[u], dy = py - ny[u], dz = pz - nz[u];
+                        const double ez = dz * P.e1z;
+                        const double d2 = dx * dx + dy * dy + ez * ez;
+                        // squared distance against a slightly inflated threshold (a superset); the exact `norm(...) < 1`
+                        // decision is made on the IEEE square root in the second pass
+                        const bool cand = ok[u] && d2 < 1.0 + 1e-9;
+                        const unsigned long long cm = __ballot(cand);
+                        if (cm) {
+                            if (ncand + 64 > SCAN_CAND_CAP) flush_candidates();
+                            if (cand) scan_cand[ncand + lanes_below(cm, lane)] = code[u];
+                            ncand += __popcll(cm);
+                        }
+                    }
+                }
+            };
+            if (G == 1 && nnbr < 0) pass(std::true_type{});
+            else pass(std::false_type{});
+        } else {
             for (int e0 = 0; e0 < n_entries; e0 += 64) {
                 int r, jc;
                 const bool valid = entry(e0, r, jc);
                 const double *base = P.lT + ((size_t)(r * S + scene) * N3) * C + jc;
+                // the 45 component rows of a neighbour are C doubles apart: a running (uniform) offset, advanced by one
+                // 64-bit scalar add per load (written as (3k+c)*C the compiler spends five scalar instructions per load)
+                size_t roff = 0;
     #pragma unroll 1
                 for (int kg = 0; kg < 3; ++kg) {   // not unrolled: keeps the scan's register footprint small
                     double nx[5], ny[5], nz[5];
     #pragma unroll
                     for (int u = 0; u < 5; ++u) {
-                        const int k = 5 * kg + u;
-                        nx[u] = base[(size_t)(3 * k) * C];
-                        ny[u] = base[(size_t)(3 * k + 1) * C];
-                        nz[u] = base[(size_t)(3 * k + 2) * C];
+                        nx[u] = base[roff]; roff += (size_t)C; asm volatile("" : "+s"(roff));
+                        ny[u] = base[roff]; roff += (size_t)C; asm volatile("" : "+s"(roff));
+                        nz[u] = base[roff]; roff += (size_t)C; asm volatile("" : "+s"(roff));
                     }
     #pragma unroll
                     for (int u = 0; u < 5; ++u) {
@@ -689,27 +781,11 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
                         // The IEEE square root (a dozen instructions in fp64) is taken only when some lane of the
                         // wave can pass the distance test: d2 is first compared against a slightly inflated squared
                         // threshold (a superset), the exact `norm(...) < r` decision is then made on sqrt(d2) itself.
-                        if (var == VAR_HARD) {
-                            // solveHardDMPC.m:18-22 + CollConstrHardDMPC.m:19: every k, neighbours with dist < 1.
-                            // Two passes: this loop only tests the 15 N distances and compacts the (neighbour, step)
-                            // candidates (about one in ten) into an LDS list; flush_candidates() then builds the rows of
-                            // 64 candidates at a time, so the row arithmetic runs on full waves instead of on a handful
-                            // of lanes per (chunk, step) pass.  Rows keep this loop's order (neighbour-chunk-major; the
-                            // reference's k-major order only changes tie breaks of the active-set path).
-                            const bool cand = valid && d2 < 1.0 + 1e-9;
-                            const unsigned long long cm = __ballot(cand);
-                            if (cm) {
-                                if (ncand + 64 > SCAN_CAND_CAP) flush_candidates();
-                                if (cand) scan_cand[ncand + lanes_below(cm, lane)] = (k << 28) | (r << 20) | jc;
-                                ncand += __popcll(cm);
-                            }
-                        } else {
-                            if (__any(valid && d2 < rmin2_hi)) {
-                                const double dist = sqrt(d2);
-                                if (valid && dist < rmin) anyb |= (1u << k);       // CheckCollSoftDMPC.m:11
-                            }
-                            if (k == 0 && valid) mind0 = fmin(mind0, d2);           // squared; the root is taken once below
+                        if (__any(valid && d2 < rmin2_hi)) {
+                            const double dist = sqrt(d2);
+                            if (valid && dist < rmin) anyb |= (1u << k);       // CheckCollSoftDMPC.m:11
                         }
+                        if (k == 0 && valid) mind0 = fmin(mind0, d2);           // squared; the root is taken once below
                     }
                 }
             }
@@ -1302,10 +1378,20 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
 
 extern __shared__ __attribute__((aligned(16))) unsigned char dmpc_smem[];
 
+// Scan phase: blockDim.x / 64 independent waves per workgroup, one agent each (P.lds_per_wave bytes of LDS per wave).
+// Single-wave workgroups leave the launch bound by the workgroup dispatch rate (51 200 workgroups in ~180 us whatever the
+// waves do); the waves never synchronise.  The XCD-aware renumbering of step_body is applied to the workgroup index here.
 template <bool SOFT>
-__global__ __launch_bounds__(64, SCAN_WAVES_PER_SIMD) void dmpc_scan_kernel(StepParams P)
+__global__ __launch_bounds__(64 * SCAN_WAVES_PER_WG, SCAN_WAVES_PER_SIMD) void dmpc_scan_kernel(StepParams P)
 {
-    step_body<0, SOFT>(P, threadIdx.x, blockIdx.x, gridDim.x, dmpc_smem, nullptr);
+    const int W = (int)(blockDim.x >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63);
+    const int nb = (int)gridDim.x, x = (int)blockIdx.x & 7, y = (int)blockIdx.x >> 3;
+    int off = 0;
+    for (int xx = 0; xx < x; ++xx) off += (nb - xx + 7) >> 3;
+    const int agent = (off + y) * W + wave, total = P.S * P.c_count;
+    if (agent >= total) return;
+    step_body<0, SOFT>(P, lane, agent, total, dmpc_smem + (size_t)wave * P.lds_per_wave, P.tables /* any non-null: no second renumbering */);
 }
 template <bool SOFT>
 __global__ __launch_bounds__(64, SOLVE_WAVES_PER_SIMD) void dmpc_solve_kernel(StepParams P)
