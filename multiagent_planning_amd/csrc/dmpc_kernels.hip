@@ -94,26 +94,19 @@ __device__ __forceinline__ int lanes_below(unsigned long long mask, int lane)
     return __popcll(mask & ((1ull << lane) - 1ull));
 }
 
-// Division of a per-lane index by a wave-uniform divisor d (numerators below `bound`): multiplication by a rounded-up
-// 32-bit reciprocal where that is exact up to one (bound * d < 2^32), by a double reciprocal otherwise; one correction
-// step in either direction makes the result exact.
+// Division of a per-lane index (< 2^31) by a wave-uniform divisor d: product with the double reciprocal (off by at most
+// one), one correction step in either direction makes it exact.  Branch-free.
 struct UDiv {
-    unsigned d, magic;
+    int d;
     double inv;
-    bool use_mulhi;
-    __device__ __forceinline__ UDiv(unsigned d_, unsigned bound) : d(d_ ? d_ : 1u)
-    {
-        magic = d > 1u ? (unsigned)(0x100000000ull / d) + 1u : 0u;
-        inv = 1.0 / (double)d;
-        use_mulhi = (unsigned long long)bound * d < 0x100000000ull;
-    }
+    __device__ __forceinline__ explicit UDiv(unsigned d_) : d(d_ ? (int)d_ : 1), inv(1.0 / (double)(d_ ? d_ : 1u)) {}
     __device__ __forceinline__ void divmod(unsigned e, int &q, int &rem) const
     {
-        if (d == 1u) { q = (int)e; rem = 0; return; }
-        q = use_mulhi ? (int)__umulhi(e, magic) : (int)((double)e * inv);
-        rem = (int)(e - (unsigned)q * d);
-        if (rem < 0) { q -= 1; rem += (int)d; }
-        else if (rem >= (int)d) { q += 1; rem -= (int)d; }
+        int qq = (int)((double)e * inv);
+        int rr = (int)e - qq * d;
+        const int up = rr >= d ? 1 : 0, dn = rr < 0 ? 1 : 0;
+        q = qq + up - dn;
+        rem = rr - (up - dn) * d;
     }
 };
 
@@ -701,23 +694,26 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
             // computation, and runs of lanes with the same k still read contiguous table rows.
             const unsigned ne = (unsigned)(nnbr >= 0 ? nnbr : G * C);
             const unsigned total = ne * (unsigned)K;
-            // e / ne and entry / C by a uniform divisor (udiv below)
-            const UDiv div_ne(ne, total), div_c((unsigned)C, (unsigned)(G * C));
+            // (k, entry) of a lane advance by 64 pairs per round: running counters with one wrap test, no division in the
+            // loop (64 = step_q * ne + step_r; lanes past the end have k >= K)
+            const UDiv div_ne(ne), div_c((unsigned)C);
+            const int step_q = (int)(64u / (ne ? ne : 1u)), step_r = (int)(64u - (unsigned)step_q * ne);
             const size_t slab = (size_t)N3 * C;
             auto pass = [&](auto single_tag) {
                 constexpr bool single = decltype(single_tag)::value;   // one chunk, no neighbour list: entry == neighbour index
                 constexpr int UR = 4;   // rounds in flight: the loads of four rounds are issued before the first is used
+                int k_run, idx_run;
+                div_ne.divmod((unsigned)lane, k_run, idx_run);
                 for (unsigned e0 = 0; e0 < total; e0 += 64 * UR) {
                     double nx[UR], ny[UR], nz[UR];
                     int kk[UR], code[UR];
                     bool ok[UR];
 #pragma unroll
                     for (int u = 0; u < UR; ++u) {
-                        const unsigned e = e0 + 64u * u + (unsigned)lane;
-                        int k, idx;
-                        div_ne.divmod(e, k, idx);
-                        bool valid = e < total;
-                        if (!valid) { k = 0; idx = 0; }
+                        bool valid = k_run < K;
+                        const int k = valid ? k_run : 0, idx = valid ? idx_run : 0;
+                        idx_run += step_r; k_run += step_q;
+                        if (idx_run >= (int)ne) { idx_run -= (int)ne; k_run += 1; }
                         int r = 0, jc = idx;
                         if (!single) {
                             if (nnbr >= 0) {
