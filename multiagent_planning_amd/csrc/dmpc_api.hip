@@ -51,6 +51,7 @@ struct dmpc_ctx {
     hipStream_t stream = nullptr;
     dmpc_params prm{};
     double *d_tables = nullptr;   // [3][3][225]
+    double hsum[3] = {0, 0, 0};   // per cost case: sum of |H1(i,j)| (dual-bound certificate of the slack-free variants)
     std::string err;
     int64_t solves = 0;
     int max_lds_set = 0;
@@ -173,7 +174,7 @@ extern "C" int dmpc_posvel_matrix(double h, int Kh, double *Aaug)
 
 // H1 = 2(q l_K l_K' + s D1'D1 + I)  (per-axis block of solveSoftDMPCbound.m:98); returns
 // H1^-1, M1 = H1^-1 L', P1 = L H1^-1 L' (row-major 15x15 each)
-static void build_case_tables(double h, double q, double s, double *out /*675*/)
+static void build_case_tables(double h, double q, double s, double *out /*675*/, double *hsum = nullptr)
 {
     long double L[K][K], H[K][K], Hi[K][K], C[K][K];
     for (int i = 0; i < K; ++i)
@@ -185,6 +186,12 @@ static void build_case_tables(double h, double q, double s, double *out /*675*/)
             else if (i == j + 1 || j == i + 1) dd = -1.0L;
             H[i][j] = 2.0L * ((long double)q * L[K - 1][i] * L[K - 1][j] + (long double)s * dd + (i == j ? 1.0L : 0.0L));
         }
+    if (hsum) {   // sum of |H(i,j)|, rounded up: max over |a| <= alim of a'Ha/2 is at most alim^2/2 times this
+        long double t = 0.0L;
+        for (int i = 0; i < K; ++i)
+            for (int j = 0; j < K; ++j) t += fabsl(H[i][j]);
+        *hsum = (double)(t * (1.0L + 1e-12L));
+    }
     // Cholesky H = C C'
     memset(C, 0, sizeof(C));
     for (int j = 0; j < K; ++j) {
@@ -243,9 +250,9 @@ static int upload_tables(dmpc_ctx *ctx)
 {
     std::vector<double> t(3 * 675);
     const dmpc_params &p = ctx->prm;
-    build_case_tables(p.h, 1000.0, 10.0, &t[0]);                                         // far   (:44-47)
-    build_case_tables(p.h, 10000.0, 10.0, &t[675]);                                      // near  (:49-52)
-    build_case_tables(p.h, p.Q1, (p.variant == DMPC_VAR_ALL3) ? 10.0 : p.S1, &t[1350]);  // coll  (:54-57; all:71)
+    build_case_tables(p.h, 1000.0, 10.0, &t[0], &ctx->hsum[0]);                                         // far   (:44-47)
+    build_case_tables(p.h, 10000.0, 10.0, &t[675], &ctx->hsum[1]);                                      // near  (:49-52)
+    build_case_tables(p.h, p.Q1, (p.variant == DMPC_VAR_ALL3) ? 10.0 : p.S1, &t[1350], &ctx->hsum[2]);  // coll  (:54-57; all:71)
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_tables, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
@@ -376,6 +383,7 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     P.alim = p.alim; P.Q1 = p.Q1; P.S1 = p.S1; P.term = p.term;
     for (int d = 0; d < 3; ++d) { P.pmin[d] = p.pmin[d]; P.pmax[d] = p.pmax[d]; }
     P.tables = ctx->d_tables;
+    for (int i = 0; i < 3; ++i) P.hsum[i] = ctx->hsum[i];
     P.lT = lT; P.x_p = x_p; P.x_v = x_v; P.x_a = x_a; P.pf = pf;
     P.p_out = p_out; P.v_out = v_out; P.a_out = a_out; P.lT_next = lT_next;
     P.status = status; P.info = info;
@@ -703,6 +711,7 @@ extern "C" int dmpc_rows_one(dmpc_ctx *ctx, int N, int n, const double *l, const
     P.alim = p.alim; P.Q1 = p.Q1; P.S1 = p.S1; P.term = p.term;
     for (int d = 0; d < 3; ++d) { P.pmin[d] = p.pmin[d]; P.pmax[d] = p.pmax[d]; }
     P.tables = ctx->d_tables; P.lT = ctx->lT.as<double>();
+    for (int i = 0; i < 3; ++i) P.hsum[i] = ctx->hsum[i];
     P.x_p = ctx->xp.as<double>(); P.x_v = ctx->xv.as<double>(); P.x_a = ctx->xa.as<double>(); P.pf = ctx->pf.as<double>();
     P.status = ctx->status.as<int32_t>(); P.no_prune = 1; P.qcap = QMAX; P.qover_bit = ST_CAPACITY;
     const size_t per = (size_t)P.nrmax * (soft ? 7 : 4);

@@ -27,6 +27,7 @@ struct StepParams {
     int variant, S, G, C, g_local, nrmax, max_tries, c_first, c_count, qcap;
     double h, rmin, e1z, e2z, alim, Q1, S1, term;
     double pmin[3], pmax[3];
+    double hsum[3];         // per cost case: sum of |H1(i,j)| (bound of the cost over the acceleration box, dual-bound certificate)
     const double *tables;   // [3 cost cases][H1^-1 | H1^-1 L' | L H1^-1 L'][15*15]
     const double *lT;       // [G][S][3K][C]
     const double *x_p, *x_v, *x_a, *pf;   // [S][c_count][3]  (agents c_first .. c_first+c_count-1 of chunk g_local)

@@ -864,6 +864,27 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
         w_unc = 2.0 * qw * gax * L.tabP[k_l * 15 + (K - 1)] + 2.0 * sw * sel3(A.ao, ax_l) * L.tabM[k_l];
     }
 
+    // Dual-bound certificate (slack-free variants).  The iterate of the dual active-set method minimises the cost over
+    // its working set, so its cost value `dual` is a lower bound of the constrained optimum, rising with every step by
+    // t delta (lambda_p + t/2).  Every feasible point lies in the box |a| <= alim, where the cost is at most
+    //   fbound = 3/2 alim^2 sum|H1(i,j)| + alim sum|f_i|;
+    // once `dual` exceeds that the QP is infeasible -- the multipliers of an infeasible QP grow geometrically, and this
+    // cuts the long tail of the proof (numpy model, C2: 30 % of the iterations spent on infeasible agents, the longest
+    // proofs 52 -> 37 and 46 -> 23).  dual starts at f(a_unc) = f'a_unc / 2.
+    double dual = 0.0, fbound = INFINITY;
+    if (!soft) {
+        double f_l = 0.0;
+        if (lane < N3) {
+            const double gax = sel3(A.pf, ax_l) - (sel3(A.po, ax_l) + (double)K * P.h * sel3(A.vo, ax_l));
+            const double LKk = 0.5 * P.h * P.h + (double)(K - 1 - k_l) * P.h * P.h;   // Lambda(K, k)
+            f_l = -2.0 * qw * LKk * gax - ((k_l == 0) ? 2.0 * sw * sel3(A.ao, ax_l) : 0.0);
+        }
+        dual = 0.5 * wave_sum(f_l * a_unc);
+        const double fabs_sum = wave_sum(fabs(f_l));
+        fbound = 1.5 * P.alim * P.alim * P.hsum[ccase] + P.alim * fabs_sum;
+        fbound += 1e-6 * (fabs(fbound) + fabs(dual));   // margin for the rounding of the running sum
+    }
+
     // per-lane constants of component (k_l, ax_l): offset A0 x0, bounds of w = Lambda a, initial velocity.
     // (the uniform agent state is not needed inside the solver loop any more -> fewer live registers)
     double p0_l = 0.0, whi_l = 0.0, wlo_l = 0.0, vo_l = 0.0;
@@ -1232,6 +1253,10 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
                     const long long tq4 = DMPC_CLOCK(); tkD += tq4 - tq3;
                     lam_p += t;
                     if (!dependent) {
+                        if (!soft) {
+                            dual += t * delta * (lam_p - 0.5 * t);
+                            if (dual > fbound) { rc = 1; break; }   // no point of the acceleration box costs this much
+                        }
                         vp -= t * delta;
                         // primal step x -= t z
                         a -= t * za; w -= t * zw;
