@@ -904,13 +904,17 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
     auto row_weight = [&](double x0, double x1, double x2, int kc, double sd) {
         return rsqrt(L.tabP[kc * 16] * (x0 * x0 + x1 * x1 + x2 * x2) + (soft ? 0.5 * sd * sd : 0.0));
     };
-    // Register cache of the first 128 collision rows (2 per lane): the row data is constant during the solve
-    // and most agents have fewer rows than that, so the per-iteration violation scan and the descriptor of a
-    // newly picked row need no global-memory round trip.  Rows 128+ are streamed from the L2-resident scratch.
+    // Register cache of the first collision rows (RC per lane): the row data is constant during the solve and most
+    // agents have fewer rows than that, so the per-iteration violation scan and the descriptor of a newly picked row
+    // need no global-memory round trip.  The rest is streamed from the L2-resident scratch.  Slack-free rows are 4
+    // doubles and the hard variants build ~100 of them: 2 per lane.  Slack rows are 7 doubles, the near-neighbour
+    // variants build ~10, and two per lane made the slack kernels spill registers into scratch memory: 1 per lane.
+    constexpr int RC = soft ? 1 : 2;
     double rcx0[2], rcx1[2], rcx2[2], rcb[2], rcsd[2], rcslb[2], rcw[2];
     int rckc[2];
+    rcx0[1] = rcx1[1] = rcx2[1] = rcb[1] = rcsd[1] = rcslb[1] = rcw[1] = 0.0; rckc[1] = 0;
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
+    for (int c = 0; c < RC; ++c) {
         const int i = lane + 64 * c;
         const bool in = i < nr;
         const int ii = in ? i : 0;
@@ -1061,7 +1065,7 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
                     if (!(cmask & 8u)) CAND(c3, wpos_l, (TY_POSLO << 16) | lane);
                 }
 #pragma unroll
-                for (int c = 0; c < 2; ++c) {   // rows held in registers
+                for (int c = 0; c < RC; ++c) {   // rows held in registers
                     const int i = lane + 64 * c;
                     if (i < nr) {
                         const int fl = L.r_fl[i], kc = rckc[c];
@@ -1076,7 +1080,7 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
                         if (!(fl & RF_COLL)) CAND(v, rcw[c], (TY_COLL << 16) | i);
                     }
                 }
-                for (int i = lane + 128; i < nr; i += 64) {   // the rest streams from the global scratch
+                for (int i = lane + 64 * RC; i < nr; i += 64) {   // the rest streams from the global scratch
                     const int fl = L.r_fl[i], kc = L.r_kc[i];
                     const double x0 = L.r_xi[3 * i], x1 = L.r_xi[3 * i + 1], x2 = L.r_xi[3 * i + 2];
                     double v = -(x0 * L.w_s[3 * kc] + x1 * L.w_s[3 * kc + 1] + x2 * L.w_s[3 * kc + 2]) - L.r_b[i];
@@ -1119,9 +1123,9 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
                 Cdesc p;
                 {
                     const int pty = pcode >> 16, pidx = pcode & 0xffff;
-                    if (pty >= TY_COLL && pidx < 128) {   // row data from the owning lane's registers
+                    if (pty >= TY_COLL && pidx < 64 * RC) {   // row data from the owning lane's registers
                         const int ol = pidx & 63;
-                        const bool hi = pidx >= 64;
+                        const bool hi = RC > 1 && pidx >= 64;
                         p.ty = pty; p.idx = pidx; p.kb = 0; p.isA = 0; p.si = -1; p.v0 = p.v1 = p.v2 = 0.0; p.ss = 0.0; p.d = 0.0;
                         if (pty == TY_COLL) {
                             p.kb = readlane_i(hi ? rckc[1] : rckc[0], ol);
