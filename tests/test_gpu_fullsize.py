@@ -145,3 +145,36 @@ def test_c4_bound_10000_agents_sharded_in_8_chunks():
     idx = np.concatenate([rng.permutation(viol)[:20], rng.integers(0, N, 10)])
     o1 = {k: v[0] for k, v in one.items()}
     _sample_vs_oracle("bound", kw, l[0], po[0], z[0], z[0], pf[0], o1, idx, 1e-9, "C4")
+
+
+@pytest.mark.parametrize("N,G", [(120, 3), (320, 4)])
+def test_hard_rows_in_chunked_layouts(N, G):
+    """solveHardDMPC on the multi-rank layout lT[G][S][45][C]: the flat (step, neighbour) scan pass without a neighbour
+    list (N < 256: entries enumerated over all G chunks) and with the bounding-box list (N >= 256).  Every rank's share
+    must equal the single-chunk run bit for bit, and a sample of agents the oracle."""
+    import torch
+    cfg, S = wl.CONFIGS["C2"], 2
+    C = N // G
+    kw = wl.solver_kwargs(cfg, N)
+    po, pf = wl.make_scenes(cfg, S, N, wl.SEED0 + 11)
+    d = mp.Dmpc("hard", **kw)
+    l, _, _ = d.init_batch(po, pf)
+    z = np.zeros_like(po)
+    one = d.step_batch(l, po, z, z, pf)
+    ok = _properties(one, l, po, z, kw, "hard", f"hard N={N}")
+    assert 0.3 < ok.mean() <= 1.0
+    dev = torch.device("cuda", 0)
+    lT = torch.from_numpy(driver.rows_to_chunked(l, G)).to(dev)
+    for r in range(G):
+        sl = slice(r * C, (r + 1) * C)
+        loc = driver.GpuLocalStep(d, S, G, C, dev)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a[:, sl])).to(dev)
+        out = loc(lT, t(po), t(z), t(z), t(pf), r)
+        torch.cuda.synchronize()
+        for k in ("p", "a", "status"):
+            assert np.array_equal(out[k].cpu().numpy(), one[k][:, sl]), (k, r)
+        assert np.array_equal(out["info"].cpu().numpy()[..., :4], one["info"][:, sl, :4]), r   # branch record incl. row counts
+    rng = np.random.default_rng(3)
+    idx = rng.integers(0, N, 12)
+    o1 = {k: v[0] for k, v in one.items()}
+    _sample_vs_oracle("hard", kw, l[0], po[0], z[0], z[0], pf[0], o1, idx, 1e-9, f"hard N={N}")
