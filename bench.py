@@ -281,8 +281,8 @@ def main():
                          "kernel": kname, "kernel_ms_avg": kern_ms, "launches": n_launch,
                          "other_kernels_ms_avg": {"dmpc_scan_kernel+order_kernel": scan_ms},
                          "alg_bytes_per_solve": b_alg, "solves_per_launch": S * C,
-                         "note": "on-chip bound (dependent LDS/VALU chains of the active-set iterations); compulsory HBM "
-                                 "traffic is ~1.5 KB/solve, so the HBM fraction is small by construction"},
+                         "note": "on-chip, instruction-issue bound (~11 k instructions per solve, 0.7 issued per SIMD slot; profiles/README.md); "
+                                 "compulsory HBM traffic is ~1.5 KB/solve, so the HBM fraction is small by construction"},
             "workload_stats": {"solved_frac": float((st & 1).mean()), "infeasible_frac": float(((st & 8) != 0).mean()),
                                "invalid": int(((st & 48) != 0).sum()), "mean_iters": float(inf[..., 4].mean()),
                                "max_iters": int(inf[..., 4].max()), "mean_rows": float(inf[..., 1].mean()),
