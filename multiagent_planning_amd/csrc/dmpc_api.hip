@@ -75,6 +75,7 @@ struct dmpc_ctx {
     // profiling
     int profile = 0;
     double *dbg = nullptr; int dbg_agent = -1, dbg_cap = 0;   // development trace (dmpc_debug_trace)
+    DevBuf forced_order; int forced_n = 0;                    // development aid (dmpc_debug_set_order)
     struct Ev { hipEvent_t t0, t1, t2; };   // step start | scan+order done | solve tiers done
     std::vector<Ev> events;
     double prof_scan_ms_sum = 0.0;
@@ -444,14 +445,9 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
         if (soft) hipLaunchKernelGGL(dmpc_scan_kernel<true>, sgrid, sblock, lds0 * W, st, P);
         else hipLaunchKernelGGL(dmpc_scan_kernel<false>, sgrid, sblock, lds0 * W, st, P);
     }
-    // heaviest-first launch order for the solve phase.  Tiny launches do not need it.  For the slack-carrying variants
-    // the row count separates the few heavy agents from the many without rows and the order always pays (51 200 agents of
-    // solveSoftDMPCbound: 32.6 vs 28.1 M/s).  For the slack-free variants every agent has rows and their number predicts
-    // the solve time poorly (correlation 0.3): a deep (persistent-wave) launch is then better off with the natural
-    // order, which keeps the agents of a scene -- and their row scratch -- together (30.0 vs 28.3 M/s).
-    const bool natural_order = !soft && !ctx->no_persist && ctx->num_cu >= 1 &&
-                               (long)S * c_count >= 16L * ctx->num_cu * 8 && !ctx->force_persist;
-    if (S * c_count >= 512 && !ctx->no_lpt && !natural_order) {
+    // heaviest-first launch order for the solve phase (key left by the scan in hdr[7]).  Tiny launches do not need it.
+    if (ctx->forced_n == S * c_count) P.order = ctx->forced_order.as<int>();   // development aid: externally supplied launch order
+    else if (S * c_count >= 512 && !ctx->no_lpt) {
         const int total = S * c_count, nb = total >= 16384 ? 8 : 1;
         hipLaunchKernelGGL(order_kernel, dim3((unsigned)nb), dim3(1024), 0, st, total, (const int *)P.hdr, ctx->order.as<int>());
         P.order = ctx->order.as<int>();
@@ -528,6 +524,21 @@ extern "C" int dmpc_debug_trace(dmpc_ctx *ctx, int agent, int cap, double *host_
     if (agent >= 0 && cap > 0) {
         HIPCHK(ctx, hipMalloc((void **)&ctx->dbg, sizeof(double) * 8 * cap));
         HIPCHK(ctx, hipMemset(ctx->dbg, 0, sizeof(double) * 8 * cap));
+    }
+    return 0;
+}
+
+// development aid (not part of the public header): force the solve launch order (a permutation of the S*c_count agents
+// of the next launches; n = 0 returns to the built-in policy).  Used to measure what an ideal order would give.
+extern "C" int dmpc_debug_set_order(dmpc_ctx *ctx, const int *host_order, int n)
+{
+    if (!ctx) return -1;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ctx->forced_n = 0;
+    if (n > 0 && host_order) {
+        if (ctx->forced_order.ensure(sizeof(int) * (size_t)n)) { ctx->err = "dmpc_debug_set_order: out of device memory"; return -1; }
+        HIPCHK(ctx, hipMemcpy(ctx->forced_order.p, host_order, sizeof(int) * (size_t)n, hipMemcpyHostToDevice));
+        ctx->forced_n = n;
     }
     return 0;
 }

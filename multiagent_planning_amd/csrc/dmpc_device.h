@@ -55,7 +55,7 @@ constexpr int SCAN_CAND_CAP = 1024;   // (neighbour, step) candidates buffered p
 // bytes of dynamic LDS the step kernel carves for a given row capacity
 inline size_t step_lds_bytes(int nrmax, bool soft, int qcap, int phase, int nbr_cap = 0)
 {
-    if (phase == 0) return 48 * 8 + (SCAN_CAND_CAP + (size_t)nbr_cap) * 4;   // own prediction + candidate list of the all-k (hard) scan + neighbour list
+    if (phase == 0) return 96 * 8 + (SCAN_CAND_CAP + (size_t)nbr_cap) * 4;   // own prediction, unconstrained minimiser + candidate list of the all-k (hard) scan + neighbour list
     size_t dbl = (size_t)t_doubles(qcap) + 676 + 4 * 48 + 2 * 64 + 6 * (size_t)qcap + (soft ? (size_t)nrmax : 0);
     size_t bytes = dbl * 8 + 3 * (size_t)qcap * 4 + (size_t)nrmax;   // + slot ints + row flags (bytes)
     return (bytes + 15) & ~(size_t)15;
