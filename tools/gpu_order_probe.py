@@ -66,5 +66,11 @@ run("steps_viol", np.argsort(-tile(sv), kind="stable"))
 run("steps_viol - 3 m_min", np.argsort(-(tile(sv) - 3 * tile(mmin)), kind="stable"))
 k2 = tile(sv) * 4 + ((tile(mmin) < 0.1) * 3 + ((tile(mmin) >= 0.1) & (tile(mmin) < 0.25)) * 2 + ((tile(mmin) >= 0.25) & (tile(mmin) < 0.5)) * 1)
 run("steps_viol*4 + tightness class", np.argsort(-k2, kind="stable"))
+tc = (tile(mmin) < 0.1) * 3 + ((tile(mmin) >= 0.1) & (tile(mmin) < 0.25)) * 2 + ((tile(mmin) >= 0.25) & (tile(mmin) < 0.5)) * 1
+svt, nrt = tile(sv), tile(nr)
+for name, key in (("sv*4+tc, rows tie-break", (svt * 4 + tc) * 1000 + nrt), ("sv*8 + tc*2 + (rows>150)", svt * 8 + tc * 2 + (nrt > 150)),
+                  ("sv*3 + tc*2", svt * 3 + tc * 2), ("sv*2 + tc", svt * 2 + tc), ("sv*4+tc + rows/40", svt * 4 + tc + nrt / 40.0),
+                  ("sv + 4*(1-mmin)", svt + 4 * (1 - tile(mmin))), ("sv + 8*(1-mmin)", svt + 8 * (1 - tile(mmin))), ("sv^1.5*4+tc", svt ** 1.5 * 4 + tc)):
+    run(name, np.argsort(-key, kind="stable"))
 res = run("natural again", None)
 assert np.array_equal(res["status"], ref["status"])
