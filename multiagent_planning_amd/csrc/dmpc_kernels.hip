@@ -965,6 +965,7 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
     // ---------------------------------------------------------------- a7: dual active-set solve
     const bool ladder = soft && (var == VAR_BOUND || var == VAR_BOUND2 || var == VAR_ALL3 || cppv);
     constexpr int LADDER_CERT_AFTER = 16;
+    constexpr int FARKAS_AFTER = 8;   // Farkas test of the multipliers against the acceleration box from this iteration on
     const int max_tries = P.max_tries > 0 ? P.max_tries : (cppv ? 21 : 30);   // cpp: one solve + 20 retries (dmpc.cpp:1081)
     // a tier-2 relaunch resumes the retry ladder where tier 1 left it (the row data in global memory already
     // carries the doublings of the tries that were proven infeasible)
@@ -1005,6 +1006,12 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
             a = a_unc; w = w_unc;
             if (lane < N3) { L.a_s[lane] = a; L.w_s[lane] = w; }
             if (soft) for (int i = lane; i < nr; i += 64) L.r_eps[i] = 0.0;
+            // Gradient of the cost at the iterate, g = H x + f (slack-free variants): 0 at the unconstrained minimiser, and
+            // a step x -= t z changes it by -t H z = -t nu.  By stationarity g = -(N_W lambda + n_p lambda_p) with
+            // lambda >= 0, so every feasible point a satisfies g.a >= g.x (+ lambda_p v_p): the multipliers are a Farkas
+            // certificate as soon as even the best point of the box |a| <= alim misses that, alim |g|_1 < g.x.  It
+            // accounts for all 90 acceleration bounds at once, where the active-set iteration adds them one by one.
+            double g_l = 0.0;
             unsigned cslot = 0xffffffffu;   // component lane: slots of its BOXHI | BOXLO | POSHI | POSLO (0xff = none)
             LSYNC();
             // x(lambda) re-derived from the multipliers with the same O(1)-per-lane assembly the step direction
@@ -1039,6 +1046,7 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
 #pragma unroll
                     for (int kk = 0; kk < K; ++kk) nu = fma((kk >= k_l) ? (0.5 * h2 + (double)(kk - k_l) * h2) : 0.0, yv[kk], nu);
                     L.nu_s[lane] = nu;
+                    if (!soft) g_l = nu;   // H x(lambda) + f = -N_W lambda
                 }
                 LSYNC();
                 if (lane < N3) {
@@ -1297,6 +1305,13 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
                         if (!soft) {
                             dual += t * delta * (lam_p - 0.5 * t);
                             if (dual > fbound) { rc = 1; break; }   // no point of the acceleration box costs this much
+                            g_l -= t * nu;
+                            if (iters >= FARKAS_AFTER) {
+                                const double an = a - t * za;   // the iterate after this step
+                                const double ga = g_l * an, gb = P.alim * fabs(g_l);
+                                // g.x - alim |g|_1 with a relative margin for the residual of the active rows
+                                if (wave_sum(ga - gb - 1e-6 * (fabs(ga) + gb)) > 0.0) { rc = 1; break; }
+                            }
                         }
                         vp -= t * delta;
                         // primal step x -= t z
