@@ -1218,8 +1218,11 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
                     // and delta = nu' H^-1 nu = z'Hz.  When p is (nearly) dependent on W, nu is small and the
                     // round-off of r enters delta squared -- this makes the dependence / infeasibility test
                     // reliable (a cancelling form such as spp - s'r is not).
-                    double Uacc = 0.0, Yacc = 0.0;
+                    // (one predicated region for the three stages: the lanes >= 45 take no part, and the LDS hand-offs between
+                    // the stages only need program order inside the wave)
+                    double nu = 0.0, part = 0.0, za = 0.0, zw = 0.0;
                     if (lane < N3) {
+                        double Uacc = 0.0, Yacc = 0.0;
                         const double vpax = ax_l == 0 ? p.v0 : (ax_l == 1 ? p.v1 : p.v2);
                         if (p.ty <= TY_COLL && p.kb == k_l) { if (p.isA) Uacc += vpax; else Yacc += vpax; }
                         const unsigned s0 = cslot & 0xffu, s1 = (cslot >> 8) & 0xffu, s2 = (cslot >> 16) & 0xffu, s3 = cslot >> 24;
@@ -1232,10 +1235,7 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
                             if (L.s_kb[j] == k_l) Yacc -= L.rr_s[j] * L.s_vec[3 * j + ax_l];
                         }
                         L.yt_s[lane] = Yacc;
-                    }
-                    LSYNC();
-                    double nu = 0.0;
-                    if (lane < N3) {
+                        LSYNC();
                         const double h2 = P.h * P.h;
                         nu = Uacc;
                         double yv[K];
@@ -1247,10 +1247,7 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
                             nu = fma(cf, yv[kk], nu);
                         }
                         L.nu_s[lane] = nu;
-                    }
-                    LSYNC();
-                    double part = 0.0, za = 0.0, zw = 0.0;
-                    if (lane < N3) {
+                        LSYNC();
 #pragma unroll
                         for (int kg = 0; kg < 3; ++kg) {   // 15 loads in flight per group
                             double nk[5], th[5], tm[5];
