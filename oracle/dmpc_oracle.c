@@ -904,3 +904,47 @@ int orc_rows_one(const orc_params *prm, int N, int n, const double *l, const dou
     ctx_free(c);
     return 0;
 }
+
+/* The literal dense QP of agent n at retry-ladder level `level` (lb_eps and term doubled `level` times,
+ * solveSoftDMPCbound.m:147-153), exported for solver-independent certificates in tests/ (KKT by NNLS, infeasibility by
+ * an LP): min 1/2 x'Hx + f'x s.t. C x <= d, x = [a; eps].  First call with H == NULL to get the sizes (*n_out, *m_out).
+ * H: n x n (acceleration block = 2(A'QA + Delta'S Delta + R), slack block 2 I, :85-86,98), C: m x n row-major.
+ * Returns ORC_ST_COLL when the variant returns before building a QP, 0 otherwise. */
+int orc_assemble_one(const orc_params *prm, int N, int n, const double *l, const double po[3], const double vo[3],
+                     const double ao[3], const double pf[3], int level, int *n_out, int *m_out, int *ncoll_out,
+                     double *H, double *f, double *C, double *d)
+{
+    if (prm->order != 2 || prm->K < 1 || prm->K > MAXK) return -1;
+    ctx_t *c = ctx_new(prm->h, prm->K);
+    const int n3 = c->n3;
+    double x0[6] = {po[0], po[1], po[2], vo[0], vo[1], vo[2]};
+    rows_t R;
+    memset(&R, 0, sizeof(R));
+    scan_t sc = scan_and_rows(c, prm, N, n, l, x0, &R);
+    int rc = 0;
+    if (sc.status & ORC_ST_COLL) { rc = ORC_ST_COLL; *n_out = 0; *m_out = 0; if (ncoll_out) *ncoll_out = 0; goto out; }
+    {
+        double qw, sw;
+        int which;
+        cost_case(prm, &sc, po, pf, &qw, &sw, &which);
+        hcase_t *hc = ctx_case(c, qw, sw);
+        slackcfg_t sl = slack_cfg(prm);
+        qp_t qp;
+        assemble(c, prm, &R, &sc, &sl, qw, sw, ldexp(sl.lb, level), ldexp(sl.lin, level), x0, ao, pf, &qp);
+        *n_out = qp.n; *m_out = qp.m;
+        if (ncoll_out) *ncoll_out = R.nrows;
+        if (H) {
+            memset(H, 0, sizeof(double) * (size_t)qp.n * qp.n);
+            for (int i = 0; i < n3; ++i) memcpy(&H[(size_t)i * qp.n], &hc->H[(size_t)i * n3], sizeof(double) * n3);
+            for (int i = n3; i < qp.n; ++i) H[(size_t)i * qp.n + i] = 2.0;
+            memcpy(f, qp.f, sizeof(double) * qp.n);
+            memcpy(C, qp.C, sizeof(double) * (size_t)qp.m * qp.n);
+            memcpy(d, qp.d, sizeof(double) * qp.m);
+        }
+        qp_free(&qp);
+    }
+out:
+    free(R.G); free(R.b); free(R.dist);
+    ctx_free(c);
+    return rc;
+}

@@ -98,6 +98,12 @@ int orc_rows_one(const orc_params *prm, int N, int n, const double *l, const dou
 int orc_qp_dense(int n, int m, const double *G, const double *g, const double *C, const double *d,
                  double *x, double *lam, int *iters);
 
+/* the literal dense QP of agent n at retry-ladder level `level` (min 1/2 x'Hx + f'x s.t. Cx <= d, x = [a; eps]) for the
+ * solver-independent certificates of tests/ (KKT by NNLS, infeasibility by an LP).  Call with H == NULL for the sizes. */
+int orc_assemble_one(const orc_params *prm, int N, int n, const double *l, const double po[3], const double vo[3],
+                     const double ao[3], const double pf[3], int level, int *n_out, int *m_out, int *ncoll_out,
+                     double *H, double *f, double *C, double *d);
+
 #ifdef __cplusplus
 }
 #endif

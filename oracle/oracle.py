@@ -56,6 +56,7 @@ def lib(path=None):
         L.orc_eval_one.argtypes = [C.POINTER(Params), C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, dp, dp]
         L.orc_rows_one.argtypes = [C.POINTER(Params), C.c_int, C.c_int, dp, dp, dp, C.c_int, dp, dp, dp, ip, ip, ip]
         L.orc_qp_dense.argtypes = [C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, ip]
+        L.orc_assemble_one.argtypes = [C.POINTER(Params), C.c_int, C.c_int, dp, dp, dp, dp, dp, C.c_int, ip, ip, ip, dp, dp, dp, dp]
         if path is not None:
             return L
         _lib = L
@@ -156,3 +157,19 @@ def rows_one(prm, l, n, po, vo, max_rows=4096):
     assert rc == 0
     k = min(nr.value, max_rows)
     return dict(G=G[:k], b=b[:k], dist=dist[:k], nrows=nr.value, viol_k=vk.value, status=st.value)
+
+
+def assemble_one(prm, l, n, po, vo, ao, pf, level=0):
+    """The literal dense QP of agent n at retry-ladder level `level`: dict(H, f, C, d, ncoll) with
+    min 1/2 x'Hx + f'x s.t. Cx <= d, x = [a; eps]; None when the variant returns `coll` before building a QP."""
+    l, po, vo, ao, pf = _f(l), _f(po), _f(vo), _f(ao), _f(pf)
+    nn, mm, nc = C.c_int(0), C.c_int(0), C.c_int(0)
+    null = C.POINTER(C.c_double)()
+    rc = lib().orc_assemble_one(C.byref(prm), l.shape[0], n, _dp(l), _dp(po), _dp(vo), _dp(ao), _dp(pf), level,
+                                C.byref(nn), C.byref(mm), C.byref(nc), null, null, null, null)
+    if rc != 0:
+        return None
+    H, f, Cm, d = np.zeros((nn.value, nn.value)), np.zeros(nn.value), np.zeros((mm.value, nn.value)), np.zeros(mm.value)
+    lib().orc_assemble_one(C.byref(prm), l.shape[0], n, _dp(l), _dp(po), _dp(vo), _dp(ao), _dp(pf), level,
+                           C.byref(nn), C.byref(mm), C.byref(nc), _dp(H), _dp(f), _dp(Cm), _dp(d))
+    return dict(H=H, f=f, C=Cm, d=d, ncoll=nc.value)
