@@ -50,7 +50,7 @@ struct dmpc_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     dmpc_params prm{};
-    double *d_tables = nullptr;   // [3][3][225]
+    double *d_tables = nullptr;   // [3][900] Gram tables + [225] Lambda' table (dmpc_device.h: TAB_DOUBLES)
     double hsum[3] = {0, 0, 0};   // per cost case: sum of |H1(i,j)| (dual-bound certificate of the slack-free variants)
     std::string err;
     int64_t solves = 0;
@@ -247,13 +247,28 @@ static void build_case_tables(double h, double q, double s, double *out /*675*/,
         }
 }
 
+// the device tables: per cost case the symmetric 30x30 Gram table over (space, step) -- G[A i][A j] = H1^-1, G[A i][W j] =
+// (H1^-1 L')(i,j), G[W i][W j] = L H1^-1 L' -- then Lt[k][kk] = Lambda(kk,k)
 static int upload_tables(dmpc_ctx *ctx)
 {
-    std::vector<double> t(3 * 675);
+    std::vector<double> t(TAB_DOUBLES, 0.0);
     const dmpc_params &p = ctx->prm;
-    build_case_tables(p.h, 1000.0, 10.0, &t[0], &ctx->hsum[0]);                                         // far   (:44-47)
-    build_case_tables(p.h, 10000.0, 10.0, &t[675], &ctx->hsum[1]);                                      // near  (:49-52)
-    build_case_tables(p.h, p.Q1, (p.variant == DMPC_VAR_ALL3) ? 10.0 : p.S1, &t[1350], &ctx->hsum[2]);  // coll  (:54-57; all:71)
+    const double qs[3] = {1000.0, 10000.0, p.Q1};                                             // far (:44-47), near (:49-52), coll (:54-57)
+    const double ss[3] = {10.0, 10.0, (p.variant == DMPC_VAR_ALL3) ? 10.0 : p.S1};            // all:71
+    for (int c = 0; c < 3; ++c) {
+        double hmp[675];
+        build_case_tables(p.h, qs[c], ss[c], hmp, &ctx->hsum[c]);
+        double *G = &t[(size_t)c * TAB_CASE_DOUBLES];
+        for (int i = 0; i < K; ++i)
+            for (int j = 0; j < K; ++j) {
+                G[i * 30 + j] = hmp[i * K + j];
+                G[i * 30 + 15 + j] = hmp[225 + i * K + j];
+                G[(15 + j) * 30 + i] = hmp[225 + i * K + j];
+                G[(15 + i) * 30 + 15 + j] = hmp[450 + i * K + j];
+            }
+    }
+    for (int k = 0; k < K; ++k)
+        for (int kk = k; kk < K; ++kk) t[3 * TAB_CASE_DOUBLES + k * K + kk] = p.h * p.h / 2 + (double)(kk - k) * p.h * p.h;
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_tables, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
@@ -282,7 +297,7 @@ extern "C" dmpc_ctx *dmpc_create(const dmpc_params *prm, int device)
     ctx->device = device;
     ctx->prm = *prm;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipMalloc((void **)&ctx->d_tables, sizeof(double) * 3 * 675) != hipSuccess || upload_tables(ctx) != 0) {
+        hipMalloc((void **)&ctx->d_tables, sizeof(double) * TAB_DOUBLES) != hipSuccess || upload_tables(ctx) != 0) {
         g_err = "dmpc_create: device initialisation failed: " + ctx->err;
         dmpc_destroy(ctx);
         return nullptr;
@@ -356,11 +371,13 @@ static int row_capacity(int variant, int N)
 // whose working set outgrows it are flagged and re-solved by a tier-2 launch with the full capacity
 static int tier1_qcap(int variant)
 {
-    static const int env = getenv("DMPC_TIER1_QCAP") ? atoi(getenv("DMPC_TIER1_QCAP")) : 0;   // tuning override
-    if (env >= 8) return env < 64 ? (env & ~7) : 64;
-    // solveHardDMPC builds rows for every horizon step: working sets routinely approach the 45-variable
-    // limit, so a small first tier would only add a second pass; every other variant stays far below 32
-    return variant == DMPC_VAR_HARD ? 48 : 32;
+    // the capacity is a template parameter of the solve kernels: 32 / 64 (slack-carrying variants), 48 (slack-free)
+    static const int env = getenv("DMPC_TIER1_QCAP") ? atoi(getenv("DMPC_TIER1_QCAP")) : 0;   // tuning override (tests: 64 = single tier)
+    if (env == 64 && variant_soft(variant)) return 64;
+    // slack-free variants (hard, ondemand, ellip): 45 variables => at most 45 independent active rows, one tier of 48;
+    // solveHardDMPC builds rows for every horizon step and its working sets routinely approach that limit.
+    // slack-carrying variants stay far below 32 in the first tier
+    return variant_soft(variant) ? 32 : 48;
 }
 // hard: 45 variables => at most 45 independent active rows; 48 leaves room for a numerically near-dependent addition
 static int full_qcap(int variant) { return variant_soft(variant) ? QMAX : 48; }
@@ -403,12 +420,13 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     if (G * C >= 256 && !ctx->no_cull) { nbr_cap = 1024; while (nbr_cap < G * C / 4 && nbr_cap < 8192) nbr_cap *= 2; }
     P.nbr_cap = nbr_cap;
     P.scene_done = scene_done;
-    const size_t lds0 = (step_lds_bytes(P.nrmax, soft, q1, 0, nbr_cap) + 15) & ~(size_t)15;
-    const size_t lds1 = step_lds_bytes(P.nrmax, soft, q1, 1), lds2 = step_lds_bytes(P.nrmax, soft, q2, 1);
+    const size_t lds0 = scan_lds_bytes(nbr_cap);
+    const size_t lds1 = solve_lds_bytes(P.nrmax, soft, q1, false), lds2 = solve_lds_bytes(P.nrmax, soft, q2, false);
     const size_t ldsmax = lds2 > lds1 ? lds2 : lds1;
     if ((int)ldsmax > ctx->max_lds_set) {
-        HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsmax));
-        HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsmax));
+        HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_kernel<true, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsmax));
+        HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_kernel<true, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsmax));
+        HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_kernel<false, 48>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsmax));
         ctx->max_lds_set = (int)ldsmax;
     }
     dmpc_ctx::Ev ev{nullptr, nullptr, nullptr};
@@ -457,31 +475,41 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     // waves fit next to the shared tables; otherwise one agent per workgroup
     const size_t LDS_CU = 160 * 1024;
     auto persist_waves = [&](int qcap, size_t &per) -> int {
-        per = (persist_wave_bytes(P.nrmax, soft, qcap) + 15) & ~(size_t)15;
+        per = solve_lds_bytes(P.nrmax, soft, qcap, true);
         int pw = (int)((LDS_CU - PERSIST_TABLE_BYTES) / per);
         return pw > 8 ? 8 : pw;
+    };
+    // the working-set capacity is a template parameter of the solve kernels
+    auto launch_plain = [&](int qcap, size_t lds) {
+        if (soft && qcap == 32) hipLaunchKernelGGL((dmpc_solve_kernel<true, 32>), grid, block, lds, st, P);
+        else if (soft) hipLaunchKernelGGL((dmpc_solve_kernel<true, 64>), grid, block, lds, st, P);
+        else hipLaunchKernelGGL((dmpc_solve_kernel<false, 48>), grid, block, lds, st, P);
+    };
+    auto launch_persist = [&](int qcap, dim3 g, dim3 b, size_t lds) {
+        if (soft && qcap == 32) hipLaunchKernelGGL((dmpc_solve_persist_kernel<true, 32>), g, b, lds, st, P);
+        else if (soft) hipLaunchKernelGGL((dmpc_solve_persist_kernel<true, 64>), g, b, lds, st, P);
+        else hipLaunchKernelGGL((dmpc_solve_persist_kernel<false, 48>), g, b, lds, st, P);
     };
     auto solve_launch = [&](int qcap, size_t lds_plain, int tier, bool want_persist) -> int {
         size_t per = 0;
         const int pw = persist_waves(qcap, per);
         const int total = S * c_count;
         if (!want_persist || ctx->no_persist || pw < 2 || ctx->num_cu < 1) {
-            if (soft) hipLaunchKernelGGL(dmpc_solve_kernel<true>, grid, block, lds_plain, st, P);
-            else hipLaunchKernelGGL(dmpc_solve_kernel<false>, grid, block, lds_plain, st, P);
+            launch_plain(qcap, lds_plain);
             return 0;
         }
         const size_t lds = PERSIST_TABLE_BYTES + (size_t)pw * per;
         if ((int)lds > ctx->max_lds_persist) {
-            HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_persist_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_persist_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_persist_kernel<true, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_persist_kernel<true, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_persist_kernel<false, 48>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             ctx->max_lds_persist = (int)lds;
         }
         P.counter = ctx->counter.as<int>() + tier;
         P.lds_per_wave = (int)per;
         int wgs = (total + pw - 1) / pw;
         if (wgs > ctx->num_cu) wgs = ctx->num_cu;
-        if (soft) hipLaunchKernelGGL(dmpc_solve_persist_kernel<true>, dim3((unsigned)wgs), dim3((unsigned)(64 * pw)), lds, st, P);
-        else hipLaunchKernelGGL(dmpc_solve_persist_kernel<false>, dim3((unsigned)wgs), dim3((unsigned)(64 * pw)), lds, st, P);
+        launch_persist(qcap, dim3((unsigned)wgs), dim3((unsigned)(64 * pw)), lds);
         return 0;
     };
     // Measured on C2 (hard, 100 agents/scene): persistent waves win once the launch is deep enough to be
@@ -728,8 +756,9 @@ extern "C" int dmpc_rows_one(dmpc_ctx *ctx, int N, int n, const double *l, const
     const size_t per = (size_t)P.nrmax * (soft ? 7 : 4);
     if (ctx->rowbuf.ensure(per * 8) || ctx->rowkc.ensure((size_t)P.nrmax * 4) || ctx->hdr.ensure(32)) FAIL(ctx, "device allocation failed");
     P.rowbuf = ctx->rowbuf.as<double>(); P.rowkc = ctx->rowkc.as<int>(); P.hdr = ctx->hdr.as<int>();
-    if (soft) hipLaunchKernelGGL(dmpc_scan_kernel<true>, dim3(1), dim3(64), step_lds_bytes(P.nrmax, soft, QMAX, 0), st, P);
-    else hipLaunchKernelGGL(dmpc_scan_kernel<false>, dim3(1), dim3(64), step_lds_bytes(P.nrmax, soft, QMAX, 0), st, P);
+    P.lds_per_wave = (int)scan_lds_bytes(0);
+    if (soft) hipLaunchKernelGGL(dmpc_scan_kernel<true>, dim3(1), dim3(64), scan_lds_bytes(0), st, P);
+    else hipLaunchKernelGGL(dmpc_scan_kernel<false>, dim3(1), dim3(64), scan_lds_bytes(0), st, P);
     HIPCHK(ctx, hipGetLastError());
     int hdr[8];
     HIPCHK(ctx, hipMemcpyAsync(hdr, ctx->hdr.p, 32, hipMemcpyDeviceToHost, st));

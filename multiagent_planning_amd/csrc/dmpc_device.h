@@ -11,11 +11,11 @@ constexpr int QMAX = 64;      // working-set capacity (slots of the inverse fact
 // rows and stored with a stride of 8(g+1)+1 doubles.  The ODD stride is for the LDS banks: in the transposed product
 // lane j walks down column j, and with the natural stride 8(g+1) all columns of a group start on the same few banks
 // (measured: 40 % of the LDS cycles of the solve kernel were bank-conflict replays).
-__host__ __device__ inline int tcol(int j) { const int g = j >> 3; return 8 * g * (4 * g + 5) + (8 * g + 9) * (j - 8 * g); }
+__host__ __device__ constexpr int tcol(int j) { return 8 * (j >> 3) * (4 * (j >> 3) + 5) + (8 * (j >> 3) + 9) * (j - 8 * (j >> 3)); }
 // doubles of T for a given working-set capacity (columns up to the next multiple of 8).  Unconditional wave reads run
 // past the last column by up to 63 doubles; their values are masked, and the vectors that follow T in the per-agent LDS
 // block (>= 4 x 48 doubles) are what they touch.
-__host__ __device__ inline int t_doubles(int qcap) { return tcol((qcap + 7) & ~7); }
+__host__ __device__ constexpr int t_doubles(int qcap) { return tcol((qcap + 7) & ~7); }
 constexpr int ITER_CAP = 4000;
 
 enum { VAR_BOUND = 0, VAR_BOUND2 = 1, VAR_ALL3 = 2, VAR_HARD = 3, VAR_ONDEMAND = 4, VAR_ELLIP = 5, VAR_SOFTALL = 6, VAR_REPAIR = 7,
@@ -28,7 +28,7 @@ struct StepParams {
     double h, rmin, e1z, e2z, alim, Q1, S1, term;
     double pmin[3], pmax[3];
     double hsum[3];         // per cost case: sum of |H1(i,j)| (bound of the cost over the acceleration box, dual-bound certificate)
-    const double *tables;   // [3 cost cases][H1^-1 | H1^-1 L' | L H1^-1 L'][15*15]
+    const double *tables;   // [3 cost cases][30x30 Gram table G] + [15x15 Lambda' table]  (TAB_DOUBLES; see dmpc_solve.hip)
     const double *lT;       // [G][S][3K][C]
     const double *x_p, *x_v, *x_a, *pf;   // [S][c_count][3]  (agents c_first .. c_first+c_count-1 of chunk g_local)
     double *p_out, *v_out, *a_out;        // [S][c_count][3K]
@@ -52,16 +52,27 @@ struct StepParams {
 
 constexpr int SCAN_CAND_CAP = 1024;   // (neighbour, step) candidates buffered per flush of the hard-row scan
 
-// bytes of dynamic LDS the step kernel carves for a given row capacity
-inline size_t step_lds_bytes(int nrmax, bool soft, int qcap, int phase, int nbr_cap = 0)
+// Precomputed tables (host: build_case_tables, dmpc_api.hip).  Per cost case one symmetric 30x30 Gram table over the
+// index (space, step), space A = acceleration components (0..14), space W = position components (15..29):
+//   G[A i][A j] = H1^-1(i,j),  G[A i][W j] = (H1^-1 L')(i,j),  G[W i][W j] = (L H1^-1 L')(i,j);
+// then Lt[k][kk] = Lambda(kk,k) (15x15, the same for every case).
+constexpr int TAB_CASE_DOUBLES = 900;
+constexpr int TAB_L_DOUBLES = 225;
+constexpr int TAB_DOUBLES = 3 * TAB_CASE_DOUBLES + TAB_L_DOUBLES;   // 2925
+
+// bytes of dynamic LDS of one scan wave: own prediction, unconstrained minimiser + candidate list of the all-k (hard) scan +
+// neighbour list
+inline size_t scan_lds_bytes(int nbr_cap) { return (96 * 8 + (SCAN_CAND_CAP + (size_t)nbr_cap) * 4 + 15) & ~(size_t)15; }
+// bytes of LDS of one solve wave (layout: SolveLds in dmpc_solve.hip; `persist`: the tables are shared by the workgroup)
+inline size_t solve_lds_bytes(int nrmax, bool soft, int qcap, bool persist)
 {
-    if (phase == 0) return 96 * 8 + (SCAN_CAND_CAP + (size_t)nbr_cap) * 4;   // own prediction, unconstrained minimiser + candidate list of the all-k (hard) scan + neighbour list
-    size_t dbl = (size_t)t_doubles(qcap) + 676 + 4 * 48 + 2 * 64 + 6 * (size_t)qcap + (soft ? (size_t)nrmax : 0);
-    size_t bytes = dbl * 8 + 3 * (size_t)qcap * 4 + (size_t)nrmax;   // + slot ints + row flags (bytes)
+    size_t dbl = (size_t)t_doubles(qcap) + 4 * 48 + 2 * 64 + 5 * (size_t)qcap + (soft ? (size_t)qcap : 0) + (size_t)qcap / 2;
+    if (!persist) dbl += TAB_CASE_DOUBLES + TAB_L_DOUBLES + 1;
+    if (soft) dbl += (size_t)nrmax;                 // r_eps
+    const size_t bytes = dbl * 8 + (size_t)nrmax;   // + row flags (bytes)
     return (bytes + 15) & ~(size_t)15;
 }
-// persistent solve kernel: the tables are shared by the workgroup (3 cost cases x 676 doubles at the front)
-constexpr size_t PERSIST_TABLE_BYTES = 3 * 676 * 8;
-inline size_t persist_wave_bytes(int nrmax, bool soft, int qcap) { return step_lds_bytes(nrmax, soft, qcap, 1) - 676 * 8; }
+// persistent solve kernel: the tables at the front of the workgroup's LDS
+constexpr size_t PERSIST_TABLE_BYTES = ((size_t)TAB_DOUBLES * 8 + 15) & ~(size_t)15;
 
 }  // namespace dmpc

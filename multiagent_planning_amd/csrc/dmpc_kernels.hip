@@ -13,24 +13,17 @@
 //                (T T' = (N' H^-1 N)^-1), kept in LDS and updated by column append / Givens deletes.
 //                Slack variables (solveSoftDMPCbound.m:60-88) are explicit but their eps<=0 pins are
 //                instantiated lazily, so the working set only holds what is really active.
+//                (dmpc_solve.hip, included below)
 //   prop   (a9)  propStatedmpc.m:3-4, is_inbounds.m:2-5 (a10), outputs + next table chunk.
 //
-// All arithmetic is fp64 (the reference is MATLAB double).  No atomics: every reduction is a fixed
-// butterfly, so results are bit-reproducible and independent of how agents are sharded.
+// All arithmetic is fp64 (the reference is MATLAB double).  The data path has no atomics: every reduction is a
+// fixed butterfly, so results are bit-reproducible and independent of how agents are sharded.  (Atomics only
+// serve scheduling: the queue head of the persistent waves, the tier-2 list, the histograms of order_kernel.)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <type_traits>
 
 #include "dmpc_device.h"
-
-// Phase timers of the development trace (tools/gpu_phase.py).  Reading the cycle counter is a scalar-memory
-// instruction whose result is awaited with s_waitcnt lgkmcnt(0) -- which also drains every LDS operation in
-// flight -- so the timers are compiled in only on request (make DEV_TIMERS=1).
-#ifdef DMPC_DEV_TIMERS
-#define DMPC_CLOCK() clock64()
-#else
-#define DMPC_CLOCK() 0LL
-#endif
 
 namespace dmpc {
 
@@ -126,200 +119,18 @@ enum { TY_BOXHI = 0, TY_BOXLO = 1, TY_POSHI = 2, TY_POSLO = 3, TY_COLL = 4, TY_S
 // row flags
 enum { RF_COLL = 1, RF_SLKU = 2, RF_SLKL = 4, RF_LIVE = 8 };
 
+// what the scan phase addresses: its LDS vectors and the per-agent slice of the global row scratch
 struct Lds {
-    double *T;      // zero-padded column-major upper-triangular inverse Cholesky factor (t_doubles(qcap))
-    double *tabH, *tabM, *tabP;  // 15x15: H1^-1, H1^-1 L', L H1^-1 L'
-    double *a_s, *w_s, *own_s, *nu_s, *yt_s;   // 48 each
-    double *s_vec;  // QMAX x 3
-    double *s_ss, *s_d, *s_lam, *rr_s, *xs_s;
+    double *w_s, *own_s;
     double *r_xi;   // nrmax x 3
     double *r_b;
-    double *r_sd, *r_st, *r_slb, *r_eps;  // soft variants only
-    int *s_kb, *s_ty, *s_idx;
+    double *r_sd, *r_st, *r_slb;  // soft variants only
     int *r_kc;
-    unsigned char *r_fl;
-};
-
-// uniform description of one constraint
-struct Cdesc {
-    int ty, idx, kb, isA, si;
-    double v0, v1, v2, ss, d;
 };
 
 struct Agent {   // wave-uniform agent data
     double po[3], vo[3], ao[3], pf[3];
-    double whi0[3], wlo0[3];   // pmax - po, pmin - po (w bounds at k: whi0 - (k+1) h vo)
 };
-
-__device__ __forceinline__ Cdesc make_desc(int ty, int idx, const Lds &L, double whi_l, double wlo_l, const StepParams &P, bool soft)
-{
-    Cdesc c;
-    c.ty = ty; c.idx = idx; c.kb = 0; c.isA = 0; c.si = -1;
-    c.v0 = c.v1 = c.v2 = 0.0; c.ss = 0.0; c.d = 0.0;
-    if (ty < TY_COLL) {
-        const int k = idx / 3, ax = idx - 3 * k;
-        const double sgn = (ty == TY_BOXHI || ty == TY_POSHI) ? 1.0 : -1.0;
-        c.kb = k; c.isA = (ty < TY_POSHI);
-        c.v0 = ax == 0 ? sgn : 0.0; c.v1 = ax == 1 ? sgn : 0.0; c.v2 = ax == 2 ? sgn : 0.0;
-        if (c.isA) c.d = P.alim;
-        else {
-            // bounds of w = Lambda a for component idx are held by lane idx (whi_l / wlo_l)
-            c.d = (ty == TY_POSHI) ? readlane_d(whi_l, idx) : -readlane_d(wlo_l, idx);
-            (void)ax;
-        }
-    } else if (ty == TY_COLL) {
-        c.kb = L.r_kc[idx];
-        c.v0 = -L.r_xi[3 * idx]; c.v1 = -L.r_xi[3 * idx + 1]; c.v2 = -L.r_xi[3 * idx + 2];
-        c.d = L.r_b[idx];
-        if (soft) { c.si = idx; c.ss = L.r_sd[idx]; }
-    } else if (ty == TY_SLKU) {
-        c.si = idx; c.ss = 1.0; c.d = 0.0;
-    } else {
-        c.si = idx; c.ss = -1.0; c.d = -L.r_slb[idx];
-    }
-    return c;
-}
-
-// n_j' H^-1 n_p for the slot held by this lane (j) against the uniform constraint p
-__device__ __forceinline__ double sdot_slot(const Lds &L, int j, const Cdesc &p)
-{
-    const int kb = L.s_kb[j], ty = L.s_ty[j];
-    const int isA = ty < TY_POSHI;
-    const double dot3 = L.s_vec[3 * j] * p.v0 + L.s_vec[3 * j + 1] * p.v1 + L.s_vec[3 * j + 2] * p.v2;
-    double tab;
-    if (isA && p.isA) tab = L.tabH[kb * 15 + p.kb];
-    else if (isA) tab = L.tabM[kb * 15 + p.kb];
-    else if (p.isA) tab = L.tabM[p.kb * 15 + kb];
-    else tab = L.tabP[kb * 15 + p.kb];
-    double v = tab * dot3;
-    if (ty >= TY_COLL && p.si >= 0 && L.s_idx[j] == p.si && L.s_ss[j] != 0.0) v += 0.5 * L.s_ss[j] * p.ss;
-    return v;
-}
-
-__device__ __forceinline__ double sdot_self(const Lds &L, const Cdesc &p)
-{
-    const double dot3 = p.v0 * p.v0 + p.v1 * p.v1 + p.v2 * p.v2;
-    const double tab = p.isA ? L.tabH[p.kb * 15 + p.kb] : L.tabP[p.kb * 15 + p.kb];
-    double v = tab * dot3;
-    if (p.si >= 0) v += 0.5 * p.ss * p.ss;
-    return v;
-}
-
-// ---- inverse factor storage: T[i][j] (i <= j) at Tp[tcol(j) + i] (dmpc_device.h); rows j+1 .. 8*ceil((j+1)/8)-1 are ZERO.
-// The padding lets the column dot products run in unmasked groups of 8 (a lane either owns the whole group
-// or skips it), and "lane i reads row i of column j" is a contiguous wave read.
-
-// y = T' x  (lane j gets y_j).  x is in the LDS staging vector xs[0..63] (zero beyond q).  Per group of 8:
-// 16 unconditional LDS reads with immediate offsets, one wait, 8 FMAs, one lane mask for the whole group.
-__device__ __forceinline__ double t_tmul(const double *Tp, const double *xs, int lane, int q, int qcap)
-{
-    double acc = 0.0;
-    const double *col = Tp + tcol(lane < qcap ? lane : qcap - 1);
-    for (int i0 = 0; i0 < q; i0 += 8) {
-        double t[8], x[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { t[u] = col[i0 + u]; x[u] = xs[i0 + u]; }
-        double g = 0.0;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) g = fma(t[u], x[u], g);
-        acc += (i0 <= lane && lane < q) ? g : 0.0;
-    }
-    return acc;
-}
-// y = T x  (lane i gets y_i): column-oriented accumulation, lane mask i <= j per element
-__device__ __forceinline__ double t_mul(const double *Tp, const double *xs, int lane, int q, int qcap)
-{
-    double acc = 0.0;
-    const double *row = Tp + lane;
-    for (int j0 = 0; j0 < q; j0 += 8) {
-        double t[8], x[8];
-        const int c0 = tcol(j0), len = j0 + 9;   // the 8 columns of this group are j0 + 9 doubles apart
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { t[u] = row[c0 + u * len]; x[u] = xs[j0 + u]; }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) acc = fma((lane <= j0 + u && j0 + u < q) ? t[u] : 0.0, x[u], acc);   // columns >= q are uninitialised
-    }
-    return (lane < q) ? acc : 0.0;
-}
-
-// value n_j'x - d_j of the slot owned by this lane
-__device__ __forceinline__ double slot_value(const Lds &L, int j, const double *av, const double *wv, const double *ev)
-{
-    const int kb = L.s_kb[j], ty = L.s_ty[j];
-    const double *base = (ty < TY_POSHI) ? av : wv;
-    double v = L.s_vec[3 * j] * base[3 * kb] + L.s_vec[3 * j + 1] * base[3 * kb + 1] + L.s_vec[3 * j + 2] * base[3 * kb + 2];
-    if (ty >= TY_COLL && L.s_ss[j] != 0.0) v += L.s_ss[j] * ev[L.s_idx[j]];
-    return v;
-}
-
-// delete slot l from the working set: Givens rotations on adjacent columns zero row l of T
-// left-to-right; row l and the last column then drop out (stable inverse-factor downdate).  Fused
-// with the row deletion so that the packed storage never needs the transient fill-in: each lane
-// carries its row of the "current right column" in a register.
-__device__ __forceinline__ void remove_slot(const Lds &L, int lane, int &q, int l, unsigned &cslot)
-{
-    // per-component slot indices: the removed slot disappears, higher slots move down by one
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        const unsigned v = (cslot >> (8 * b)) & 0xffu;
-        if (v != 0xffu) {
-            const unsigned nv = (v == (unsigned)l) ? 0xffu : (v > (unsigned)l ? v - 1 : v);
-            cslot = (cslot & ~(0xffu << (8 * b))) | (nv << (8 * b));
-        }
-    }
-    double carry = (lane <= l) ? L.T[tcol(l) + lane] : 0.0;
-    double right = (q - 1 > l && lane <= l + 1) ? L.T[tcol(l + 1) + lane] : 0.0;
-    for (int j = l; j < q - 1; ++j) {
-        // prefetch the next column while this rotation is computed (the chain through lane l is the latency)
-        const double next = (j + 2 < q && lane <= j + 2) ? L.T[tcol(j + 2) + lane] : 0.0;
-        const double a_ = readlane_d(carry, l), b_ = readlane_d(right, l);
-        const double n2 = a_ * a_ + b_ * b_;
-        double cc = 1.0, ss = 0.0;
-        if (n2 > 1e-300) { const double inv = rsqrt(n2); cc = b_ * inv; ss = a_ * inv; }
-        const double nl = cc * carry - ss * right;
-        const double nr_ = ss * carry + cc * right;
-        if (lane <= j + 1 && lane != l) L.T[tcol(j) + (lane < l ? lane : lane - 1)] = nl;
-        carry = nr_;
-        right = next;
-    }
-    // shift slot records
-    const bool mv = lane > l && lane < q;
-    double v0 = 0, v1 = 0, v2 = 0, ss = 0, d = 0, lam = 0; int kb = 0, ty = 0, idx = 0;
-    if (mv) {
-        v0 = L.s_vec[3 * lane]; v1 = L.s_vec[3 * lane + 1]; v2 = L.s_vec[3 * lane + 2];
-        ss = L.s_ss[lane]; d = L.s_d[lane]; lam = L.s_lam[lane];
-        kb = L.s_kb[lane]; ty = L.s_ty[lane]; idx = L.s_idx[lane];
-    }
-    LSYNC();
-    if (mv) {
-        const int t = lane - 1;
-        L.s_vec[3 * t] = v0; L.s_vec[3 * t + 1] = v1; L.s_vec[3 * t + 2] = v2;
-        L.s_ss[t] = ss; L.s_d[t] = d; L.s_lam[t] = lam;
-        L.s_kb[t] = kb; L.s_ty[t] = ty; L.s_idx[t] = idx;
-    }
-    q -= 1;
-    LSYNC();
-}
-
-__device__ __forceinline__ void write_slot(const Lds &L, int lane, int q, const Cdesc &p, double lam)
-{
-    if (lane == 0) {
-        L.s_vec[3 * q] = p.v0; L.s_vec[3 * q + 1] = p.v1; L.s_vec[3 * q + 2] = p.v2;
-        L.s_ss[q] = p.ss; L.s_d[q] = p.d; L.s_lam[q] = lam;
-        L.s_kb[q] = p.kb; L.s_ty[q] = p.ty; L.s_idx[q] = p.idx;
-    }
-}
-
-// mark / unmark a constraint as member of the working set
-__device__ __forceinline__ void set_member(const Lds &L, int lane, int ty, int idx, bool on, unsigned &cmask)
-{
-    if (ty < TY_COLL) {
-        if (lane == idx) cmask = on ? (cmask | (1u << ty)) : (cmask & ~(1u << ty));
-    } else if (lane == 0) {
-        const int bit = (ty == TY_COLL) ? RF_COLL : (ty == TY_SLKU ? RF_SLKU : RF_SLKL);
-        L.r_fl[idx] = on ? (L.r_fl[idx] | bit) : (L.r_fl[idx] & ~bit);
-    }
-}
 
 // Retry-ladder certificate (bounded-slack variants).  The rows of one horizon step k constrain only w_k = (Lambda a)_k,
 // and with |a| <= alim the reachable set of w_k is EXACTLY the box |w_k| <= alim ((k+1) h)^2 / 2 per axis (cut by the
@@ -417,64 +228,30 @@ return empty_any;
 }
 
 // --------------------------------------------------------------------------------------------
-// the step kernel: grid = S * C workgroups of 64 threads
+// the MPC step: a scan launch (a5/a6) and a solve launch (a7-a10, dmpc_solve.hip)
 // --------------------------------------------------------------------------------------------
-// PHASE 0: scan + collision rows (a5/a6) -> global row scratch + 8-int header per agent
-// PHASE 1: QP solve + propagate + outputs (a7-a10), reading the header and the rows
-// Splitting the step keeps the solver's register and LDS footprint free of the scan's needs (more
-// resident agents per CU) and lets the solver be re-launched for the few agents that overflow the
-// tier-1 working-set capacity.
-// `bidx` of `nblocks`: the workgroup's index (one-agent-per-workgroup launches) or the queue position a persistent
-// wave just claimed; `smem`: this wave's LDS; `shtab`: the workgroup-shared copy of the three cost-case tables
-// (persistent solve kernel) or null (tables are copied into the wave's own LDS).
-template <int PHASE, bool SOFT>
-__device__ __forceinline__ void step_body(const StepParams &P, const int lane, const int bidx, const int nblocks,
-                                          unsigned char *smem, const double *shtab)
+// scan + collision rows (a5/a6) -> global row scratch + 8-int header per agent.  Splitting the step keeps the solver's
+// register and LDS footprint free of the scan's needs (more resident agents per CU) and lets the solver be re-launched
+// for the few agents that overflow the tier-1 working-set capacity.
+// `vb`: the agent's index in the launch (already renumbered XCD-aware by the kernel); `smem`: this wave's LDS.
+template <bool SOFT>
+__device__ __forceinline__ void scan_body(const StepParams &P, const int lane, const int vb, unsigned char *smem)
 {
     const int S = P.S, G = P.G, C = P.C, nrmax = P.nrmax;
-    // XCD-aware mapping: workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8, private L2
-    // each), so renumber them such that every XCD works on whole scenes: a scene's prediction table is then
-    // fetched into ONE L2 instead of eight.  Pure performance remap (a bijection on [0, gridDim)).
-    int vb = bidx;
-    if (!shtab) {
-        const int nb = nblocks, x = bidx & 7, y = bidx >> 3;
-        int off = 0;
-        for (int xx = 0; xx < x; ++xx) off += (nb - xx + 7) >> 3;
-        vb = off + y;
-    }
-    if (PHASE == 1 && P.order) vb = P.order[bidx];   // heaviest agents first (order_kernel)
     const int scene = vb / P.c_count, ci = vb - scene * P.c_count;
     const int cl = P.c_first + ci;                                     // agent inside chunk g_local
     const int gid = scene * P.c_count + ci;                            // index into the launch's arrays
     const int var = P.variant;
     constexpr bool soft = SOFT;   // slack-carrying variants (bound, bound2, all3, softall, repair) vs hard rows (hard, ondemand, ellip)
 
-    const int qcap = P.qcap;
     Lds L;
     int *scan_cand = nullptr, *scan_nbr = nullptr;
     {
         double *p = (double *)smem;
-        if (PHASE == 0) {
-            L.own_s = p; p += 48;
-            L.w_s = p; p += 48;   // unconstrained minimiser in position space (launch-order key of the slack-free variants)
-            scan_cand = (int *)p;   // SCAN_CAND_CAP ints
-            scan_nbr = scan_cand + SCAN_CAND_CAP;   // P.nbr_cap ints
-            L.T = L.tabH = L.tabM = L.tabP = L.a_s = L.nu_s = L.yt_s = nullptr;
-            L.s_vec = L.s_ss = L.s_d = L.s_lam = L.rr_s = L.xs_s = L.r_eps = nullptr;
-            L.s_kb = L.s_ty = L.s_idx = nullptr; L.r_fl = nullptr;
-        } else {
-            L.T = p; p += t_doubles(qcap);
-            if (!shtab) { L.tabH = p; p += 225; L.tabM = p; p += 225; L.tabP = p; p += 226; }   // 676: keep 16-B alignment of what follows
-            else L.tabH = L.tabM = L.tabP = nullptr;   // set once the cost case is known
-            L.a_s = p; p += 48; L.w_s = p; p += 48; L.nu_s = p; p += 48; L.yt_s = p; p += 48; L.own_s = nullptr;
-            L.rr_s = p; p += 64; L.xs_s = p; p += 64;
-            L.s_vec = p; p += 3 * qcap;
-            L.s_ss = p; p += qcap; L.s_d = p; p += qcap; L.s_lam = p; p += qcap;
-            if (soft) { L.r_eps = p; p += nrmax; } else L.r_eps = nullptr;
-            int *ip = (int *)p;
-            L.s_kb = ip; ip += qcap; L.s_ty = ip; ip += qcap; L.s_idx = ip; ip += qcap;
-            L.r_fl = (unsigned char *)ip;   // nrmax bytes
-        }
+        L.own_s = p; p += 48;
+        L.w_s = p; p += 48;   // unconstrained minimiser in position space (launch-order key of the slack-free variants)
+        scan_cand = (int *)p;   // SCAN_CAND_CAP ints
+        scan_nbr = scan_cand + SCAN_CAND_CAP;   // P.nbr_cap ints
         // Collision rows live in a per-agent slice of a GLOBAL scratch buffer (L2-resident; lane = row, so
         // every access is a coalesced wave load): keeping them out of LDS is what lets several times more
         // agents be resident per CU.  Only the per-row working-set flags and the slack values stay in LDS.
@@ -487,9 +264,7 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
         L.r_kc = P.rowkc + (size_t)gid * nrmax;
     }
     int *hdr = P.hdr + (size_t)gid * 8;
-    if (PHASE == 1 && P.only_flagged && !(P.status[gid] & ST_QOVER)) return;   // tier 2: only agents that overflowed tier 1
-    if (PHASE == 1 && (hdr[4] & 8)) return;                                       // agent of a scene that already stopped
-    if (PHASE == 0 && P.scene_done && P.scene_done[scene]) {
+    if (P.scene_done && P.scene_done[scene]) {
         // the scene's transition is over (dmpc_transition): nothing to solve, the state stays frozen (status 0 = no update)
         if (lane == 0) { hdr[0] = 0; hdr[1] = 0; hdr[2] = 0; hdr[3] = 0; hdr[4] = 8; hdr[5] = 0; hdr[6] = 0; hdr[7] = 0; P.status[gid] = 0; }
         return;
@@ -501,17 +276,12 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
     for (int d = 0; d < 3; ++d) {
         A.po[d] = P.x_p[3 * gid + d]; A.vo[d] = P.x_v[3 * gid + d];
         A.ao[d] = P.x_a[3 * gid + d]; A.pf[d] = P.pf[3 * gid + d];
-        A.whi0[d] = P.pmax[d] - A.po[d];
-        A.wlo0[d] = P.pmin[d] - A.po[d];
     }
     // own previous prediction: prev_p = l(:,:,n)  (solveSoftDMPCbound.m:6)
     const double *lT_own = P.lT + ((size_t)(P.g_local * S + scene) * N3) * C + cl;
-    if (PHASE == 0) {
-        if (lane < N3) L.own_s[lane] = lT_own[(size_t)lane * C];
-        LSYNC();
-    }
+    if (lane < N3) L.own_s[lane] = lT_own[(size_t)lane * C];
+    LSYNC();
 
-    const long long tk0 = DMPC_CLOCK();
     // ---------------------------------------------------------------- a5/a6: scan + rows
     int nr = 0, nrows_ref = 0, viol_k = 0, status = 0;
     bool cert_infeasible = false;
@@ -523,9 +293,9 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
     const bool coll_check = (var == VAR_BOUND || var == VAR_BOUND2 || var == VAR_ALL3 || var == VAR_REPAIR);
     const bool skip_k1 = (var == VAR_BOUND2 || var == VAR_ALL3 || var == VAR_REPAIR || var == VAR_CPP2);
     bool coll_flag = false;
-    // own horizon box (uniform) for the neighbour culling; PHASE 0 with a neighbour list only
+    // own horizon box (uniform) for the neighbour culling; with a neighbour list only
     double obx0 = 0, obx1 = 0, oby0 = 0, oby1 = 0, obz0 = 0, obz1 = 0;
-    if (PHASE == 0 && P.bbox && P.nbr_cap > 0) {
+    if (P.bbox && P.nbr_cap > 0) {
         const double v = (lane < N3) ? L.own_s[lane] : 0.0;
         const int ax = lane % 3;
         obx0 = wave_min((lane < N3 && ax == 0) ? v : INFINITY); obx1 = wave_max((lane < N3 && ax == 0) ? v : -INFINITY);
@@ -538,7 +308,7 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
     // the distance tests / row builders below walk the list instead of all N neighbours.  Conservative: results are
     // unchanged.  nnbr < 0: no list (small scenes, variants that take every neighbour, or more survivors than fit).
     int nnbr = -1;
-    if (PHASE == 0 && P.bbox && P.nbr_cap > 0) {
+    if (P.bbox && P.nbr_cap > 0) {
         const double R = (var == VAR_HARD) ? 1.0 : 3.0 * rmin, Rz = R / P.e1z;   // |dz|/c < R; the cpp radius is <= 2 rmin
         int cnt = 0;
         bool fits = true;
@@ -579,17 +349,18 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
     // Launch-order key of the slack-free variants (see order_kernel): which horizon steps have a row that is violated
     // at the unconstrained minimiser, and how tight the tightest row is against the reachable box.
     unsigned key_steps = 0, key_tight = 0;
-    if (PHASE == 0 && !soft) {
-        // w_unc = Lambda a_unc of the collision cost case (rows exist): 2 q g P1[k][K-1] + 2 s ao M1[0][k]
+    if (!soft) {
+        // w_unc = Lambda a_unc of the collision cost case (rows exist): 2 q g P1[k][K-1] + 2 s ao M1[0][k]  (Gram table
+        // of case 2: G[W k][W K-1] and G[W k][A 0])
         if (lane < N3) {
             const int k = lane / 3, ax = lane - 3 * k;
-            const double *tb = P.tables + 2 * 675;
+            const double *tb = P.tables + 2 * TAB_CASE_DOUBLES;
             const double gax = sel3(A.pf, ax) - (sel3(A.po, ax) + (double)K * P.h * sel3(A.vo, ax));
-            L.w_s[lane] = 2.0 * P.Q1 * gax * tb[450 + k * 15 + (K - 1)] + 2.0 * P.S1 * sel3(A.ao, ax) * tb[225 + k];
+            L.w_s[lane] = 2.0 * P.Q1 * gax * tb[(15 + k) * 30 + 15 + (K - 1)] + 2.0 * P.S1 * sel3(A.ao, ax) * tb[(15 + k) * 30];
         }
         LSYNC();
     }
-    if (PHASE == 0) {
+    {
         // appends the rows of horizon step ke (evaluated positions) constraining step kc for every
         // neighbour with dist < sel_r (or all), in increasing neighbour index (CollConstrSoftDMPC.m:11-31)
         // one collision row, CollConstrSoftDMPC.m:16-28: neighbour offset (dx,dy,dz) and ellipsoidal distance at
@@ -863,598 +634,19 @@ __device__ __forceinline__ void step_body(const StepParams &P, const int lane, c
             }
             if (lane == 0) hdr[7] = key > 255 ? 255 : key;
         }
-        return;
-    }
-    // PHASE 1: pick up the scan's branch record
-    nr = hdr[0]; nrows_ref = hdr[1]; viol_k = hdr[2]; status = hdr[3];
-    violation = (hdr[4] & 1) != 0; rows_exist = hdr[5] != 0;
-    const int nrows_built = nrows_ref;
-
-    const long long tk1 = DMPC_CLOCK();
-    // ---------------------------------------------------------------- cost case + tables (a7, :43-58)
-    int ccase = 2;
-    {
-        const double dn = sqrt((A.po[0] - A.pf[0]) * (A.po[0] - A.pf[0]) + (A.po[1] - A.pf[1]) * (A.po[1] - A.pf[1]) +
-                               (A.po[2] - A.pf[2]) * (A.po[2] - A.pf[2]));
-        const bool far = (var == VAR_ELLIP) ? (dn > 1.0) : (dn >= 1.0);
-        if (!rows_exist && far) ccase = 0;
-        else if (!rows_exist && dn < 1.0) ccase = 1;
-    }
-    const double qw = ccase == 0 ? 1000.0 : (ccase == 1 ? 10000.0 : P.Q1);
-    const double sw = ccase == 2 ? ((var == VAR_ALL3) ? 10.0 : P.S1) : 10.0;
-    if (!shtab) {
-        const double *src = P.tables + (size_t)ccase * 675;
-        for (int i = lane; i < 675; i += 64) L.tabH[i] = src[i];   // tabH, tabM, tabP are contiguous
-    } else {
-        L.tabH = const_cast<double *>(shtab) + (size_t)ccase * 676; L.tabM = L.tabH + 225; L.tabP = L.tabH + 450;
-    }
-    LSYNC();
-
-    const int k_l = lane / 3, ax_l = lane - 3 * k_l;
-    // unconstrained minimiser per axis: a_unc = -H1^-1 f,  f = -2(q L_K'(pf - A0_K x0) + s [ao;0..])
-    //   => a_unc(k) = 2 q g M1[k][K-1] + 2 s ao H1inv[k][0],  g = pf - (po + K h vo)      (:88/:93)
-    double a_unc = 0.0, w_unc = 0.0;
-    if (lane < N3) {
-        const double gax = sel3(A.pf, ax_l) - (sel3(A.po, ax_l) + (double)K * P.h * sel3(A.vo, ax_l));
-        a_unc = 2.0 * qw * gax * L.tabM[k_l * 15 + (K - 1)] + 2.0 * sw * sel3(A.ao, ax_l) * L.tabH[k_l * 15];
-        // w_unc = Lambda a_unc from the same tables: L M1 = P1 and L H1^-1 = M1'
-        w_unc = 2.0 * qw * gax * L.tabP[k_l * 15 + (K - 1)] + 2.0 * sw * sel3(A.ao, ax_l) * L.tabM[k_l];
-    }
-
-    // Dual-bound certificate (slack-free variants).  The iterate of the dual active-set method minimises the cost over
-    // its working set, so its cost value `dual` is a lower bound of the constrained optimum, rising with every step by
-    // t delta (lambda_p + t/2).  Every feasible point lies in the box |a| <= alim, where the cost is at most
-    //   fbound = 3/2 alim^2 sum|H1(i,j)| + alim sum|f_i|;
-    // once `dual` exceeds that the QP is infeasible -- the multipliers of an infeasible QP grow geometrically, and this
-    // cuts the long tail of the proof (numpy model, C2: 30 % of the iterations spent on infeasible agents, the longest
-    // proofs 52 -> 37 and 46 -> 23).  dual starts at f(a_unc) = f'a_unc / 2.
-    double dual = 0.0, fbound = INFINITY;
-    if (!soft) {
-        double f_l = 0.0;
-        if (lane < N3) {
-            const double gax = sel3(A.pf, ax_l) - (sel3(A.po, ax_l) + (double)K * P.h * sel3(A.vo, ax_l));
-            const double LKk = 0.5 * P.h * P.h + (double)(K - 1 - k_l) * P.h * P.h;   // Lambda(K, k)
-            f_l = -2.0 * qw * LKk * gax - ((k_l == 0) ? 2.0 * sw * sel3(A.ao, ax_l) : 0.0);
-        }
-        dual = 0.5 * wave_sum(f_l * a_unc);
-        const double fabs_sum = wave_sum(fabs(f_l));
-        fbound = 1.5 * P.alim * P.alim * P.hsum[ccase] + P.alim * fabs_sum;
-        fbound += 1e-6 * (fabs(fbound) + fabs(dual));   // margin for the rounding of the running sum
-    }
-
-    // per-lane constants of component (k_l, ax_l): offset A0 x0, bounds of w = Lambda a, initial velocity.
-    // (the uniform agent state is not needed inside the solver loop any more -> fewer live registers)
-    double p0_l = 0.0, whi_l = 0.0, wlo_l = 0.0, vo_l = 0.0;
-    if (lane < N3) {
-        vo_l = sel3(A.vo, ax_l);
-        p0_l = sel3(A.po, ax_l) + (double)(k_l + 1) * P.h * vo_l;               // A_initp(k,:) [po;vo]
-        whi_l = sel3(A.whi0, ax_l) - (double)(k_l + 1) * P.h * vo_l;           // pmax - A0 x0  (:72)
-        wlo_l = sel3(A.wlo0, ax_l) - (double)(k_l + 1) * P.h * vo_l;
-    }
-    // Pivot weights.  The entering constraint is the one farthest from feasibility in the metric of the problem,
-    // violation / |n|_{H^-1} (the H-norm distance to its hyperplane), not the largest raw violation: rows in position
-    // space and unit box rows live on very different scales, and the raw rule keeps adding (and later dropping) box
-    // rows one by one.  Measured on the C2 scenes (numpy model of this solver): 42 % fewer active-set iterations in
-    // total, the longest infeasibility proof 107 -> 67.  The minimiser does not depend on the pivot order.
-    double wbox_l = 0.0, wpos_l = 0.0;
-    if (lane < N3) { wbox_l = rsqrt(L.tabH[k_l * 16]); wpos_l = rsqrt(L.tabP[k_l * 16]); }
-    auto row_weight = [&](double x0, double x1, double x2, int kc, double sd) {
-        return rsqrt(L.tabP[kc * 16] * (x0 * x0 + x1 * x1 + x2 * x2) + (soft ? 0.5 * sd * sd : 0.0));
-    };
-    // Register cache of the first collision rows (RC per lane): the row data is constant during the solve and most
-    // agents have fewer rows than that, so the per-iteration violation scan and the descriptor of a newly picked row
-    // need no global-memory round trip.  The rest is streamed from the L2-resident scratch.  Slack-free rows are 4
-    // doubles and the hard variants build ~100 of them: 2 per lane.  Slack rows are 7 doubles, the near-neighbour
-    // variants build ~10, and two per lane made the slack kernels spill registers into scratch memory: 1 per lane.
-    constexpr int RC = soft ? 1 : 2;
-    double rcx0[2], rcx1[2], rcx2[2], rcb[2], rcsd[2], rcslb[2], rcw[2];
-    int rckc[2];
-    rcx0[1] = rcx1[1] = rcx2[1] = rcb[1] = rcsd[1] = rcslb[1] = rcw[1] = 0.0; rckc[1] = 0;
-#pragma unroll
-    for (int c = 0; c < RC; ++c) {
-        const int i = lane + 64 * c;
-        const bool in = i < nr;
-        const int ii = in ? i : 0;
-        rcx0[c] = L.r_xi[3 * ii]; rcx1[c] = L.r_xi[3 * ii + 1]; rcx2[c] = L.r_xi[3 * ii + 2];
-        rcb[c] = L.r_b[ii]; rckc[c] = L.r_kc[ii];
-        rcsd[c] = soft ? L.r_sd[ii] : 0.0; rcslb[c] = soft ? L.r_slb[ii] : 0.0;
-        rcw[c] = row_weight(rcx0[c], rcx1[c], rcx2[c], rckc[c], rcsd[c]);
-    }
-    const long long tk2 = DMPC_CLOCK();
-    long long tkA = 0, tkB = 0, tkC = 0, tkD = 0, tkE = 0, tkF = 0, tkG = 0;
-    // ---------------------------------------------------------------- a7: dual active-set solve
-    const bool ladder = soft && (var == VAR_BOUND || var == VAR_BOUND2 || var == VAR_ALL3 || cppv);
-    constexpr int LADDER_CERT_AFTER = 16;
-    constexpr int FARKAS_AFTER = 8;   // Farkas test of the multipliers against the acceleration box from this iteration on
-    const int max_tries = P.max_tries > 0 ? P.max_tries : (cppv ? 21 : 30);   // cpp: one solve + 20 retries (dmpc.cpp:1081)
-    // a tier-2 relaunch resumes the retry ladder where tier 1 left it (the row data in global memory already
-    // carries the doublings of the tries that were proven infeasible)
-    // hdr[6] = retry-ladder levels already known to be infeasible (certified by the scan, or proven by a
-    // tier-1 launch that then overflowed); hdr[4] bit 1 = the row data in global memory is already scaled
-    int tries = hdr[6], iters_total = (P.only_flagged ? hdr[7] : 0), maxq = 0, q = 0;
-    const bool rows_scaled = (hdr[4] & 2) != 0;
-    bool solved = false;
-    double a = 0.0, w = 0.0;
-    const double tol = 1e-10;
-
-    if (status & ST_INFEAS) tries = 1;   // certified infeasible by the scan (single attempt, no ladder: hard rows only)
-    if (tries > 0 && !rows_scaled && !(status & ST_INFEAS)) {
-        // skip the ladder levels the scan certified infeasible: lb_eps *= 2, term *= 2 per level (:147-153)
-        if (tries >= max_tries) { status |= ST_INFEAS; tries = max_tries; }
-        else {
-            const double f = ldexp(1.0, tries);
-            for (int i = lane; i < nr; i += 64) { L.r_slb[i] *= f; L.r_st[i] *= f; }
-            rcslb[0] *= f; rcslb[1] *= f;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        }
-    }
-    if (!(status & (ST_COLL | ST_CAPACITY | ST_INFEAS))) {
-        while (tries < max_tries) {
-            tries++;
-            // reset working set
-            q = 0;
-            unsigned cmask = 0;
-            for (int i = lane; i < nr; i += 64) L.r_fl[i] = 0;
-            LSYNC();
-            int rc = 0;   // 0 running/ok, 1 infeasible, 2 capacity, 3 itercap
-            int iters = 0;
-            // x(lambda = 0): the unconstrained minimiser.  From here on the primal (a, w in registers,
-            // w_s / r_eps in LDS) is updated INCREMENTALLY with the step direction z = H^-1 nu that the
-            // dependence test needs anyway; it is re-derived from the multipliers (and the active-set
-            // residual refined) before the solution is accepted and every 32 changes of the working set.
-            a = a_unc; w = w_unc;
-            if (lane < N3) { L.a_s[lane] = a; L.w_s[lane] = w; }
-            if (soft) for (int i = lane; i < nr; i += 64) L.r_eps[i] = 0.0;
-            // Gradient of the cost at the iterate, g = H x + f (slack-free variants): 0 at the unconstrained minimiser, and
-            // a step x -= t z changes it by -t H z = -t nu.  By stationarity g = -(N_W lambda + n_p lambda_p) with
-            // lambda >= 0, so every feasible point a satisfies g.a >= g.x (+ lambda_p v_p): the multipliers are a Farkas
-            // certificate as soon as even the best point of the box |a| <= alim misses that, alim |g|_1 < g.x.  It
-            // accounts for all 90 acceleration bounds at once, where the active-set iteration adds them one by one.
-            double g_l = 0.0;
-            unsigned cslot = 0xffffffffu;   // component lane: slots of its BOXHI | BOXLO | POSHI | POSLO (0xff = none)
-            LSYNC();
-            // x(lambda) re-derived from the multipliers with the same O(1)-per-lane assembly the step direction
-            // uses: nu = -N_W lambda (boxes / position bounds through the per-component slot indices, collision
-            // rows through a short mask loop), then a = a_unc + H^-1 nu, w = w_unc + Lambda H^-1 nu, and
-            // eps = -(st + sum lambda sigma)/2 for live slack rows.
-            auto primal_fast = [&]() {
-                L.rr_s[lane] = (lane < q) ? L.s_lam[lane] : 0.0;
-                const int myty = (lane < q) ? L.s_ty[lane] : -1;
-                const unsigned long long cmk = __ballot(myty == TY_COLL);
-                const unsigned long long smk = soft ? __ballot(myty >= TY_COLL && L.s_ss[lane < q ? lane : 0] != 0.0) : 0ull;
-                LSYNC();
-                double Uacc = 0.0, Yacc = 0.0;
-                if (lane < N3) {
-                    const unsigned s0 = cslot & 0xffu, s1 = (cslot >> 8) & 0xffu, s2 = (cslot >> 16) & 0xffu, s3 = cslot >> 24;
-                    if (s0 != 0xffu) Uacc -= L.rr_s[s0];
-                    if (s1 != 0xffu) Uacc += L.rr_s[s1];
-                    if (s2 != 0xffu) Yacc -= L.rr_s[s2];
-                    if (s3 != 0xffu) Yacc += L.rr_s[s3];
-                    for (unsigned long long m = cmk; m; m &= m - 1) {
-                        const int j = __ffsll((long long)m) - 1;
-                        if (L.s_kb[j] == k_l) Yacc -= L.rr_s[j] * L.s_vec[3 * j + ax_l];
-                    }
-                    L.yt_s[lane] = Yacc;
-                }
-                LSYNC();
-                if (lane < N3) {
-                    const double h2 = P.h * P.h;
-                    double nu = Uacc, yv[K];
-#pragma unroll
-                    for (int kk = 0; kk < K; ++kk) yv[kk] = L.yt_s[3 * kk + ax_l];
-#pragma unroll
-                    for (int kk = 0; kk < K; ++kk) nu = fma((kk >= k_l) ? (0.5 * h2 + (double)(kk - k_l) * h2) : 0.0, yv[kk], nu);
-                    L.nu_s[lane] = nu;
-                    if (!soft) g_l = nu;   // H x(lambda) + f = -N_W lambda
-                }
-                LSYNC();
-                if (lane < N3) {
-                    double za = 0.0, zw = 0.0;
-#pragma unroll
-                    for (int kg = 0; kg < 3; ++kg) {
-                        double nk[5], th[5], tm[5];
-#pragma unroll
-                        for (int u = 0; u < 5; ++u) {
-                            const int kk = 5 * kg + u;
-                            nk[u] = L.nu_s[3 * kk + ax_l]; th[u] = L.tabH[k_l * 15 + kk]; tm[u] = L.tabM[kk * 15 + k_l];
-                        }
-#pragma unroll
-                        for (int u = 0; u < 5; ++u) { za = fma(th[u], nk[u], za); zw = fma(tm[u], nk[u], zw); }
-                    }
-                    a = a_unc + za; w = w_unc + zw;
-                    L.a_s[lane] = a; L.w_s[lane] = w;
-                }
-                if (soft) {
-                    // live rows without any slot in W: unconstrained slack -st/2; rows that are not live: 0
-                    for (int i = lane; i < nr; i += 64) {
-                        const int fl = L.r_fl[i];
-                        if (!(fl & RF_LIVE)) L.r_eps[i] = 0.0;
-                        else if (!(fl & (RF_COLL | RF_SLKU | RF_SLKL))) L.r_eps[i] = -0.5 * L.r_st[i];
-                    }
-                    const bool mine = (smk >> lane) & 1ull;
-                    const int myrow = mine ? L.s_idx[lane] : -1;
-                    bool owner = mine;
-                    double acc = 0.0;
-                    for (unsigned long long m = smk; m; m &= m - 1) {
-                        const int j = __ffsll((long long)m) - 1;
-                        if (L.s_idx[j] == myrow) { acc += L.rr_s[j] * L.s_ss[j]; if (j < lane) owner = false; }
-                    }
-                    if (owner) L.r_eps[myrow] = -0.5 * (L.r_st[myrow] + acc);
-                }
-                LSYNC();
-            };
-            int nlive = 0;                  // live slack variables (instantiated eps): the problem has 45 + nlive variables
-            bool fresh = true;              // primal == x(lambda) with refined lambda
-            int since_sync = 0;
-            bool cert_done = false;
-            for (;;) {
-                const long long tq0 = DMPC_CLOCK();
-                // a try that is still running after LADDER_CERT_AFTER iterations: ask the certificate once whether this
-                // ladder level can work at all
-                if (soft && ladder && violation && !cert_done && iters >= LADDER_CERT_AFTER) {
-                    cert_done = true;
-                    if (ladder_level_infeasible(L.r_xi, L.r_b, L.r_sd, L.r_slb, L.r_kc, nr, L.rr_s, P.h, P.alim, 1.0, whi_l, wlo_l, lane)) { rc = 1; break; }
-                }
-                // ---- most violated constraint not in the working set
-                double bestv = tol, bests = 0.0; int bestc = -1;   // raw violation, weighted score, constraint code
-                // candidate: violated by more than tol and with a larger weighted violation than the lane's best so far
-#define CAND(v_, w_, code_) do { const double v__ = (v_); const double s__ = v__ * (w_); \
-                                 if (v__ > tol && s__ > bests) { bests = s__; bestv = v__; bestc = (code_); } } while (0)
-                if (lane < N3) {
-                    const double c0 = a - P.alim, c1 = -a - P.alim;
-                    const double c2 = w - whi_l, c3 = wlo_l - w;
-                    if (!(cmask & 1u)) CAND(c0, wbox_l, (TY_BOXHI << 16) | lane);
-                    if (!(cmask & 2u)) CAND(c1, wbox_l, (TY_BOXLO << 16) | lane);
-                    if (!(cmask & 4u)) CAND(c2, wpos_l, (TY_POSHI << 16) | lane);
-                    if (!(cmask & 8u)) CAND(c3, wpos_l, (TY_POSLO << 16) | lane);
-                }
-#pragma unroll
-                for (int c = 0; c < RC; ++c) {   // rows held in registers
-                    const int i = lane + 64 * c;
-                    if (i < nr) {
-                        const int fl = L.r_fl[i], kc = rckc[c];
-                        double v = -(rcx0[c] * L.w_s[3 * kc] + rcx1[c] * L.w_s[3 * kc + 1] + rcx2[c] * L.w_s[3 * kc + 2]) - rcb[c];
-                        if (soft && (fl & RF_LIVE)) {
-                            const double e = L.r_eps[i];
-                            v += rcsd[c] * e;
-                            if (!(fl & RF_SLKU)) CAND(e, 1.4142135623730951, (TY_SLKU << 16) | i);   // |n|^2 = 1/2
-                            const double lo = rcslb[c] - e;   // -eps <= -slb
-                            if (!(fl & RF_SLKL)) CAND(lo, 1.4142135623730951, (TY_SLKL << 16) | i);
-                        }
-                        if (!(fl & RF_COLL)) CAND(v, rcw[c], (TY_COLL << 16) | i);
-                    }
-                }
-                for (int i = lane + 64 * RC; i < nr; i += 64) {   // the rest streams from the global scratch
-                    const int fl = L.r_fl[i], kc = L.r_kc[i];
-                    const double x0 = L.r_xi[3 * i], x1 = L.r_xi[3 * i + 1], x2 = L.r_xi[3 * i + 2];
-                    double v = -(x0 * L.w_s[3 * kc] + x1 * L.w_s[3 * kc + 1] + x2 * L.w_s[3 * kc + 2]) - L.r_b[i];
-                    if (soft && (fl & RF_LIVE)) {
-                        const double e = L.r_eps[i];
-                        v += L.r_sd[i] * e;
-                        if (!(fl & RF_SLKU)) CAND(e, 1.4142135623730951, (TY_SLKU << 16) | i);
-                        const double lo = L.r_slb[i] - e;   // -eps <= -slb
-                        if (!(fl & RF_SLKL)) CAND(lo, 1.4142135623730951, (TY_SLKL << 16) | i);
-                    }
-                    if (!(fl & RF_COLL) && v > tol) CAND(v, row_weight(x0, x1, x2, kc, soft ? L.r_sd[i] : 0.0), (TY_COLL << 16) | i);
-                }
-#undef CAND
-                const double smax = wave_max(bests);
-                const unsigned long long wm = __ballot(bestc >= 0 && bests == smax);
-                if (wm == 0ull) {
-                    if (q == 0 || fresh) break;   // optimal
-                    // verification: primal from the multipliers, refine the active-set residual, re-check
-                    primal_fast();
-                    for (int pass = 0; pass < 3; ++pass) {
-                        double rho = (lane < q) ? (slot_value(L, lane, L.a_s, L.w_s, L.r_eps) - L.s_d[lane]) : 0.0;
-                        const double mx = wave_max(fabs(rho));
-                        if (!(mx > 1e-13)) break;
-                        L.xs_s[lane] = rho; LSYNC();
-                        const double dvj = t_tmul(L.T, L.xs_s, lane, q, qcap);
-                        L.rr_s[lane] = dvj; LSYNC();
-                        const double ri = t_mul(L.T, L.rr_s, lane, q, qcap);
-                        if (lane < q) L.s_lam[lane] += ri;
-                        LSYNC();
-                        primal_fast();
-                    }
-                    fresh = true;
-                    continue;
-                }
-                fresh = false;
-                const long long tqa = DMPC_CLOCK(); tkA += tqa - tq0;
-                const int src = __ffsll((long long)wm) - 1;
-                const int pcode = readlane_i(bestc, src);
-                double vp = readlane_d(bestv, src);
-                Cdesc p;
-                {
-                    const int pty = pcode >> 16, pidx = pcode & 0xffff;
-                    if (pty >= TY_COLL && pidx < 64 * RC) {   // row data from the owning lane's registers
-                        const int ol = pidx & 63;
-                        const bool hi = RC > 1 && pidx >= 64;
-                        p.ty = pty; p.idx = pidx; p.kb = 0; p.isA = 0; p.si = -1; p.v0 = p.v1 = p.v2 = 0.0; p.ss = 0.0; p.d = 0.0;
-                        if (pty == TY_COLL) {
-                            p.kb = readlane_i(hi ? rckc[1] : rckc[0], ol);
-                            p.v0 = -readlane_d(hi ? rcx0[1] : rcx0[0], ol); p.v1 = -readlane_d(hi ? rcx1[1] : rcx1[0], ol);
-                            p.v2 = -readlane_d(hi ? rcx2[1] : rcx2[0], ol); p.d = readlane_d(hi ? rcb[1] : rcb[0], ol);
-                            if (soft) { p.si = pidx; p.ss = readlane_d(hi ? rcsd[1] : rcsd[0], ol); }
-                        } else if (pty == TY_SLKU) { p.si = pidx; p.ss = 1.0; }
-                        else { p.si = pidx; p.ss = -1.0; p.d = -readlane_d(hi ? rcslb[1] : rcslb[0], ol); }
-                    } else p = make_desc(pty, pidx, L, whi_l, wlo_l, P, soft);
-                }
-                // lazily instantiate the eps<=0 pin of a soft row that becomes active (S(u,u) = 1/2)
-                if (p.ty == TY_COLL && p.si >= 0 && !(L.r_fl[p.idx] & RF_LIVE)) {
-                    if (q >= qcap - 1) { rc = 2; break; }
-                    Cdesc u = make_desc(TY_SLKU, p.idx, L, whi_l, wlo_l, P, soft);
-                    if (lane < ((q + 8) & ~7)) L.T[tcol(q) + lane] = (lane == q) ? 1.4142135623730951 : 0.0;   // column + zero padding
-                    if (lane == 0) L.r_fl[p.idx] |= (RF_LIVE | RF_SLKU);
-                    nlive++;
-                    write_slot(L, lane, q, u, -L.r_st[p.idx]);
-                    q++;
-                    LSYNC();
-                }
-                double lam_p = 0.0;
-                const double spp = sdot_self(L, p);
-                tkF += DMPC_CLOCK() - tqa;
-                // ---- inner loop: partial steps until p can be added
-                for (;;) {
-                    if (++iters > ITER_CAP) { rc = 3; break; }
-                    const long long tq1 = DMPC_CLOCK();
-                    const double sv = (lane < q) ? sdot_slot(L, lane, p) : 0.0;
-                    L.xs_s[lane] = sv; LSYNC();
-                    const double dvj = t_tmul(L.T, L.xs_s, lane, q, qcap);
-                    L.rr_s[lane] = dvj; LSYNC();
-                    const double ri = t_mul(L.T, L.rr_s, lane, q, qcap);
-                    LSYNC();
-                    L.rr_s[lane] = ri;
-                    const long long tq2 = DMPC_CLOCK(); tkB += tq2 - tq1;
-                    // masks of the slots that need a loop: collision rows (position-space normals that are not
-                    // unit vectors) and slack-coupled constraints; boxes / position bounds are O(1) per lane
-                    const int myty = (lane < q) ? L.s_ty[lane] : -1;
-                    const unsigned long long cmk = __ballot(myty == TY_COLL);
-                    const unsigned long long smk = soft ? __ballot(myty >= TY_COLL && L.s_ss[lane < q ? lane : 0] != 0.0) : 0ull;
-                    LSYNC();
-                    // residual nu = n_p - N_W r, assembled EXPLICITLY as one vector in a-space
-                    //   nu_a = U + Lambda' Y   (U: box part, Y: position/collision part),  nu_eps per live slack
-                    // and delta = nu' H^-1 nu = z'Hz.  When p is (nearly) dependent on W, nu is small and the
-                    // round-off of r enters delta squared -- this makes the dependence / infeasibility test
-                    // reliable (a cancelling form such as spp - s'r is not).
-                    // (one predicated region for the three stages: the lanes >= 45 take no part, and the LDS hand-offs between
-                    // the stages only need program order inside the wave)
-                    double nu = 0.0, part = 0.0, za = 0.0, zw = 0.0;
-                    if (lane < N3) {
-                        double Uacc = 0.0, Yacc = 0.0;
-                        const double vpax = ax_l == 0 ? p.v0 : (ax_l == 1 ? p.v1 : p.v2);
-                        if (p.ty <= TY_COLL && p.kb == k_l) { if (p.isA) Uacc += vpax; else Yacc += vpax; }
-                        const unsigned s0 = cslot & 0xffu, s1 = (cslot >> 8) & 0xffu, s2 = (cslot >> 16) & 0xffu, s3 = cslot >> 24;
-                        if (s0 != 0xffu) Uacc -= L.rr_s[s0];   // BOXHI: vec = +e
-                        if (s1 != 0xffu) Uacc += L.rr_s[s1];   // BOXLO: vec = -e
-                        if (s2 != 0xffu) Yacc -= L.rr_s[s2];   // POSHI
-                        if (s3 != 0xffu) Yacc += L.rr_s[s3];   // POSLO
-                        for (unsigned long long m = cmk; m; m &= m - 1) {
-                            const int j = __ffsll((long long)m) - 1;
-                            if (L.s_kb[j] == k_l) Yacc -= L.rr_s[j] * L.s_vec[3 * j + ax_l];
-                        }
-                        L.yt_s[lane] = Yacc;
-                        LSYNC();
-                        const double h2 = P.h * P.h;
-                        nu = Uacc;
-                        double yv[K];
-#pragma unroll
-                        for (int kk = 0; kk < K; ++kk) yv[kk] = L.yt_s[3 * kk + ax_l];
-#pragma unroll
-                        for (int kk = 0; kk < K; ++kk) {
-                            const double cf = (kk >= k_l) ? (0.5 * h2 + (double)(kk - k_l) * h2) : 0.0;   // Lambda(kk,k)
-                            nu = fma(cf, yv[kk], nu);
-                        }
-                        L.nu_s[lane] = nu;
-                        LSYNC();
-#pragma unroll
-                        for (int kg = 0; kg < 3; ++kg) {   // 15 loads in flight per group
-                            double nk[5], th[5], tm[5];
-#pragma unroll
-                            for (int u = 0; u < 5; ++u) {
-                                const int kk = 5 * kg + u;
-                                nk[u] = L.nu_s[3 * kk + ax_l]; th[u] = L.tabH[k_l * 15 + kk]; tm[u] = L.tabM[kk * 15 + k_l];
-                            }
-#pragma unroll
-                            for (int u = 0; u < 5; ++u) { za = fma(th[u], nk[u], za); zw = fma(tm[u], nk[u], zw); }
-                        }
-                        part = nu * za;
-                    }
-                    // slack part: nu_eps(row) = sigma_p[si_p==row] - sum_j r_j sigma_j[si_j==row]; H_eps^-1 = 1/2.
-                    // Each slack-coupled slot lane gathers its row's value; the lowest such slot of a row
-                    // accounts for it (and for the eps update below).
-                    double nue = 0.0; bool owner = false;
-                    bool p_row_has_slot = false;
-                    if (soft) {
-                        const bool mine = (smk >> lane) & 1ull;
-                        const int myrow = mine ? L.s_idx[lane] : -1;
-                        owner = mine;
-                        if (mine && p.si == myrow) nue += p.ss;
-                        for (unsigned long long m = smk; m; m &= m - 1) {
-                            const int j = __ffsll((long long)m) - 1;
-                            const int rj = L.s_idx[j];
-                            if (rj == myrow) { nue -= L.rr_s[j] * L.s_ss[j]; if (j < lane) owner = false; }
-                            if (rj == p.si) p_row_has_slot = true;
-                        }
-                        if (owner) part += 0.5 * nue * nue;
-                        if (p.si >= 0 && !p_row_has_slot && lane == 63) part += 0.5 * p.ss * p.ss;
-                    }
-                    const double delta = wave_sum(part);
-                    const long long tq3 = DMPC_CLOCK(); tkC += tq3 - tq2;
-                    // more active constraints than variables is impossible: whatever round-off says, a constraint
-                    // picked when the working set already spans all 45 + nlive variables is dependent
-                    const bool dependent = !(delta > 1e-13 * spp) || q >= N3 + nlive;
-                    const double t2 = dependent ? INFINITY : vp / delta;
-                    // ratio test on the multipliers
-                    const double ratio = (lane < q && ri > 0.0) ? (L.s_lam[lane] / ri) : INFINITY;
-                    const double t1 = wave_min(ratio);
-                    const double t = fmin(t1, t2);
-                    if (P.dbg && gid == P.dbg_agent && lane == 0 && iters <= P.dbg_cap) {
-                        double *d = P.dbg + (size_t)(iters - 1) * 8;
-                        d[0] = (double)pcode; d[1] = (double)q; d[2] = delta; d[3] = spp; d[4] = t1; d[5] = t2; d[6] = vp; d[7] = lam_p;
-                    }
-                    if (!(t < INFINITY)) { rc = 1; break; }
-                    if (lane < q) L.s_lam[lane] -= t * ri;
-                    const long long tq4 = DMPC_CLOCK(); tkD += tq4 - tq3;
-                    lam_p += t;
-                    if (!dependent) {
-                        if (!soft) {
-                            dual += t * delta * (lam_p - 0.5 * t);
-                            if (dual > fbound) { rc = 1; break; }   // no point of the acceleration box costs this much
-                            g_l -= t * nu;
-                            if (iters >= FARKAS_AFTER) {
-                                const double an = a - t * za;   // the iterate after this step
-                                const double ga = g_l * an, gb = P.alim * fabs(g_l);
-                                // g.x - alim |g|_1 with a relative margin for the residual of the active rows
-                                if (wave_sum(ga - gb - 1e-6 * (fabs(ga) + gb)) > 0.0) { rc = 1; break; }
-                            }
-                        }
-                        vp -= t * delta;
-                        // primal step x -= t z
-                        a -= t * za; w -= t * zw;
-                        if (lane < N3) { L.a_s[lane] = a; L.w_s[lane] = w; }
-                        if (soft) {
-                            if (owner) L.r_eps[L.s_idx[lane]] -= t * 0.5 * nue;
-                            if (p.si >= 0 && !p_row_has_slot && lane == 63) L.r_eps[p.si] -= t * 0.5 * p.ss;
-                        }
-                    }
-                    if (t2 <= t1) {
-                        // full step: append p (new column of T = [-r/rho ; 1/rho])
-                        if (q >= qcap) { rc = 2; break; }
-                        const double irho = 1.0 / sqrt(delta);
-                        if (lane < ((q + 8) & ~7)) L.T[tcol(q) + lane] = (lane < q) ? (-ri * irho) : ((lane == q) ? irho : 0.0);
-                        write_slot(L, lane, q, p, lam_p);
-                        set_member(L, lane, p.ty, p.idx, true, cmask);
-                        if (p.ty < TY_COLL && lane == p.idx) cslot = (cslot & ~(0xffu << (8 * p.ty))) | ((unsigned)q << (8 * p.ty));
-                        q++;
-                        if (q > maxq) maxq = q;
-                        LSYNC();
-                        tkE += DMPC_CLOCK() - tq4;
-                        break;
-                    }
-                    // partial step: drop the blocking constraint
-                    const unsigned long long bm = __ballot(lane < q && ri > 0.0 && ratio == t1);
-                    const int l = __ffsll((long long)bm) - 1;
-                    const int dty = L.s_ty[l], didx = L.s_idx[l];
-                    LSYNC();
-                    set_member(L, lane, dty, didx, false, cmask);
-                    remove_slot(L, lane, q, l, cslot);
-                    // de-instantiate the pin of a soft row whose collision row just left the set
-                    if (soft && dty == TY_COLL && didx != ((p.ty == TY_COLL) ? p.idx : -1)) {
-                        const int fl = L.r_fl[didx];
-                        if ((fl & RF_LIVE) && (fl & RF_SLKU) && !(fl & RF_SLKL)) {
-                            const unsigned long long um = __ballot(lane < q && L.s_ty[lane] == TY_SLKU && L.s_idx[lane] == didx);
-                            const int ul = __ffsll((long long)um) - 1;
-                            LSYNC();
-                            if (lane == 0) { L.r_fl[didx] = 0; L.r_eps[didx] = 0.0; }
-                            remove_slot(L, lane, q, ul, cslot);
-                            nlive--;
-                        }
-                    }
-                    tkG += DMPC_CLOCK() - tq4;
-                }
-                if (rc) break;
-                // pin added while its collision row is not active: decoupled again -> drop both
-                if (soft && p.ty == TY_SLKU && !(L.r_fl[p.idx] & (RF_COLL | RF_SLKL))) {
-                    const unsigned long long um = __ballot(lane < q && L.s_ty[lane] == TY_SLKU && L.s_idx[lane] == p.idx);
-                    const int ul = __ffsll((long long)um) - 1;
-                    LSYNC();
-                    if (lane == 0) { L.r_fl[p.idx] = 0; L.r_eps[p.idx] = 0.0; }
-                    remove_slot(L, lane, q, ul, cslot);
-                    nlive--;
-                }
-                if (((++since_sync) & 31) == 0) primal_fast();   // periodic re-sync with x(lambda)
-            }
-            iters_total += iters;
-            if (rc == 0) { solved = true; break; }
-            if (rc == 2) {   // tier 1: flag for the tier-2 relaunch (and record the ladder position); last tier: capacity error
-                status |= P.qover_bit;
-                if (lane == 0) {
-                    hdr[6] = tries - 1; hdr[7] = iters_total; hdr[4] |= 2;
-                    // tier 1: append to the list the tier-2 launch works through (order irrelevant: scheduling only)
-                    if (P.flag_list && P.qover_bit == ST_QOVER) P.flag_list[atomicAdd(P.flag_count, 1)] = gid;
-                }
-                break;
-            }
-            if (rc == 3) { status |= ST_ITERCAP; break; }
-            // infeasible: retry ladder (solveSoftDMPCbound.m:147-153): lb_eps *= 2, term *= 2
-            if (ladder && violation) {
-                // next level, plus every further level the per-step certificate rejects (counted as tries, like the
-                // reference would have spent them)
-                double f = 2.0;
-                while (tries < max_tries - 1 &&
-                       ladder_level_infeasible(L.r_xi, L.r_b, L.r_sd, L.r_slb, L.r_kc, nr, L.rr_s, P.h, P.alim, f, whi_l, wlo_l, lane)) { f *= 2.0; ++tries; }
-                for (int i = lane; i < nr; i += 64) { L.r_slb[i] *= f; L.r_st[i] *= f; }
-                rcslb[0] *= f; rcslb[1] *= f;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                LSYNC();
-                continue;
-            }
-            if (ladder || var == VAR_REPAIR) tries = (var == VAR_REPAIR && P.max_tries <= 0) ? 10 : max_tries;
-            break;
-        }
-        if (!solved && !(status & (ST_CAPACITY | ST_ITERCAP | ST_QOVER))) status |= ST_INFEAS;
-    }
-
-    const long long tk3 = DMPC_CLOCK();
-    // ---------------------------------------------------------------- a9/a10: propagate, outputs
-    int nslack = 0;
-    if (solved) {
-        status |= ST_SOLVED;
-        if (soft) {
-            int cnt = 0;
-            for (int i = lane; i < nr; i += 64) cnt += (L.r_eps[i] < -1e-12) ? 1 : 0;
-            nslack = (int)wave_sum((double)cnt);
-        }
-    }
-    double p_out = 0.0, v_out = 0.0, a_out = 0.0;
-    if (solved && lane < N3) {
-        // p = A_p a + A_initp [po;vo] ; v = A_v a + vo   (propStatedmpc.m:3-4)
-        p_out = w + p0_l;
-        double sv = 0.0;
-        for (int kk = 0; kk <= k_l; ++kk) sv += L.a_s[3 * kk + ax_l];
-        v_out = P.h * sv + vo_l;
-        a_out = a;
-    }
-    if (solved) {
-        const bool ob_check = !(var == VAR_ELLIP || var == VAR_SOFTALL || cppv);   // solveQPv2 has no in-bounds test
-        if (hdr[4] & 4) status |= ST_COLL;   // cpp: collision noticed at the first step, solution still returned
-        if (ob_check) {   // is_inbounds.m:2-5 on p(:,1)
-            const double tolb = 50e-3;
-            bool bad = false;
-            if (lane < 3) bad = !(p_out < sel3(P.pmax, lane) + tolb) || !(p_out > sel3(P.pmin, lane) - tolb);
-            if (__any(bad)) status |= ST_OUTBOUND;
-        }
-    }
-    if (lane < N3) {
-        P.p_out[(size_t)gid * N3 + lane] = p_out;
-        P.v_out[(size_t)gid * N3 + lane] = v_out;
-        P.a_out[(size_t)gid * N3 + lane] = a_out;
-        if (P.lT_next) P.lT_next[((size_t)scene * N3 + lane) * C + cl] = solved ? p_out : lT_own[(size_t)lane * C];
-    }
-    if (P.dbg && gid == P.dbg_agent && lane == 0) {
-        double *d = P.dbg + (size_t)P.dbg_cap * 8 - 8;
-        d[0] = (double)(tk1 - tk0); d[1] = (double)(tk2 - tk1); d[2] = (double)(tk3 - tk2); d[3] = (double)(DMPC_CLOCK() - tk3);
-        d[4] = (double)tkA; d[5] = (double)tkB; d[6] = (double)tkC; d[7] = (double)iters_total;
-        d[-8] = (double)tkD; d[-7] = (double)tkE; d[-6] = (double)tkF; d[-5] = (double)tkG;
-    }
-    if (lane == 0) {
-        P.status[gid] = status;
-        if (P.info) {
-            int *inf = P.info + (size_t)gid * 8;
-            inf[0] = viol_k; inf[1] = nrows_built; inf[2] = tries; inf[3] = ccase;
-            inf[4] = iters_total; inf[5] = nslack; inf[6] = solved ? q : 0; inf[7] = maxq;
-        }
     }
 }
 
 extern __shared__ __attribute__((aligned(16))) unsigned char dmpc_smem[];
 
+#include "dmpc_solve.hip"
+
 // Scan phase: blockDim.x / 64 independent waves per workgroup, one agent each (P.lds_per_wave bytes of LDS per wave).
 // Single-wave workgroups leave the launch bound by the workgroup dispatch rate (51 200 workgroups in ~180 us whatever the
-// waves do); the waves never synchronise.  The XCD-aware renumbering of step_body is applied to the workgroup index here.
+// waves do); the waves never synchronise.
+// XCD-aware mapping: workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8, private L2 each), so they are
+// renumbered such that every XCD works on whole scenes: a scene's prediction table is then fetched into ONE L2 instead of
+// eight.  Pure performance remap (a bijection on [0, gridDim)).
 template <bool SOFT>
 __global__ __launch_bounds__(64 * SCAN_WAVES_PER_WG, SCAN_WAVES_PER_SIMD) void dmpc_scan_kernel(StepParams P)
 {
@@ -1465,36 +657,33 @@ __global__ __launch_bounds__(64 * SCAN_WAVES_PER_WG, SCAN_WAVES_PER_SIMD) void d
     for (int xx = 0; xx < x; ++xx) off += (nb - xx + 7) >> 3;
     const int agent = (off + y) * W + wave, total = P.S * P.c_count;
     if (agent >= total) return;
-    step_body<0, SOFT>(P, lane, agent, total, dmpc_smem + (size_t)wave * P.lds_per_wave, P.tables /* any non-null: no second renumbering */);
+    scan_body<SOFT>(P, lane, agent, dmpc_smem + (size_t)wave * P.lds_per_wave);
 }
-template <bool SOFT>
+// Solve phase, one agent per 64-thread workgroup (shallow launches: bound by their slowest agent)
+template <bool SOFT, int QCAP>
 __global__ __launch_bounds__(64, SOLVE_WAVES_PER_SIMD) void dmpc_solve_kernel(StepParams P)
 {
-    step_body<1, SOFT>(P, threadIdx.x, blockIdx.x, gridDim.x, dmpc_smem, nullptr);
+    solve_body<SOFT, QCAP, false>(P, threadIdx.x, blockIdx.x, gridDim.x, dmpc_smem, nullptr);
 }
 
-// Persistent form of the solve phase: one workgroup of up to 8 independent waves per CU.  The three cost-case
-// table sets (16 KB) are staged in LDS ONCE per workgroup and shared by its waves instead of being copied into
-// every agent's own LDS (5.4 KB each: one more resident agent per CU, no per-agent table copy); every wave then
-// claims agents from a global queue (heaviest first when order_kernel ran) until it is empty, so a wave that
-// finishes a light agent immediately starts the next one and the launch ends when the LAST agent ends, not when
-// the slowest workgroup slot drains.  No workgroup barrier after the table load: the waves never synchronise.
-template <bool SOFT>
+// Persistent form of the solve phase: one workgroup of up to 8 independent waves per CU.  The Gram tables of the three
+// cost cases and the Lambda table (23 KB) are staged in LDS ONCE per workgroup and shared by its waves; every wave then
+// claims agents from a global queue (heaviest first when order_kernel ran) until it is empty, so a wave that finishes a
+// light agent immediately starts the next one and the launch ends when the LAST agent ends, not when the slowest
+// workgroup slot drains.  No workgroup barrier after the table load: the waves never synchronise.
+template <bool SOFT, int QCAP>
 __global__ __launch_bounds__(512, 1) void dmpc_solve_persist_kernel(StepParams P)
 {
     // tier 2 works through the list of agents tier 1 flagged (P.order points at it); usually it is empty
     const int total = P.only_flagged ? *P.flag_count : P.S * P.c_count;
     if (total == 0) return;
     double *shtab = (double *)dmpc_smem;
-    for (int i = threadIdx.x; i < 3 * 676; i += blockDim.x) {
-        const int c = i / 676, o = i - c * 676;
-        shtab[i] = (o < 675) ? P.tables[(size_t)c * 675 + o] : 0.0;
-    }
+    for (int i = threadIdx.x; i < TAB_DOUBLES; i += blockDim.x) shtab[i] = P.tables[i];
     __syncthreads();
     // readfirstlane: tells the compiler the wave index (and with it every LDS base address and every value read
     // through one) is wave-uniform -- otherwise the solver's uniform branches are compiled as divergent ones
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    unsigned char *mine = (unsigned char *)__builtin_assume_aligned(dmpc_smem + 3 * 676 * 8 + (size_t)wave * P.lds_per_wave, 16);
+    unsigned char *mine = (unsigned char *)__builtin_assume_aligned(dmpc_smem + PERSIST_TABLE_BYTES + (size_t)wave * P.lds_per_wave, 16);
     // First round: queue position wave * #workgroups + workgroup, i.e. the heaviest #workgroups agents each get a CU
     // (and a SIMD) of their own instead of sharing one with the next-heaviest; later rounds come from the counter.
     const int first_round = (int)(gridDim.x * (blockDim.x >> 6));
@@ -1505,7 +694,7 @@ __global__ __launch_bounds__(512, 1) void dmpc_solve_persist_kernel(StepParams P
         // loop (they would stay live across the whole body and push the kernel into scratch spills)
         int ln = lane;
         asm volatile("" : "+v"(ln));
-        step_body<1, SOFT>(P, ln, idx, total, mine, shtab);
+        solve_body<SOFT, QCAP, true>(P, ln, idx, total, mine, shtab);
         LSYNC();
         int nxt = 0;
         if (lane == 0) nxt = atomicAdd(P.counter, 1);

@@ -1,0 +1,786 @@
+// dmpc_solve.hip -- the QP phase of one MPC step (a7-a10): included by dmpc_kernels.hip inside namespace dmpc.
+//
+//   solveSoftDMPCbound.m:43-160 and the seven sibling solvers: cost case, (H, f), the QP by a dual active-set
+//   (Goldfarb-Idnani) method in Schur-complement form, the retry ladder, propStatedmpc.m:3-4, is_inbounds.m:2-5.
+//
+// One 64-lane wave owns one agent.  Round-2 form of the iteration (the kernel is instruction-issue bound, so the
+// instruction count per active-set iteration is what this layout is built around):
+//   * the working-set capacity QCAP is a template parameter: every LDS object of the solver sits at a compile-time
+//     offset from the wave's base (immediate offsets in the ds_ instructions, no address arithmetic, few live SGPRs);
+//   * ONE symmetric 30x30 "Gram" table G per cost case over the index (space, step): space A = acceleration
+//     components, space W = position components:  G[A i][A j] = H1^-1(i,j), G[A i][W j] = (H1^-1 L')(i,j),
+//     G[W i][W j] = (L H1^-1 L')(i,j).  n_i' H^-1 n_j of any two constraints is G[gi_i][gi_j] x a 3-dot, with no
+//     case distinction on the constraint types; z = H^-1 nu and Lambda z are rows k and 15+k of G against nu;
+//   * the inverse factor T keeps the padded column-major layout with the odd column stride; every LDS value of a wave
+//     is finite (the region is zeroed once), vectors are exactly zero beyond q, so T x and T'x run in unmasked groups
+//     of 8 with ONE lane mask per group;
+//   * box and workspace bounds of one component are mutually exclusive pairs (a <= alim and -a <= alim are never
+//     active together): one candidate and one slot lookup per pair;
+//   * collision slots enter the residual through a per-lane mask of the slots that constrain the lane's own horizon
+//     step (a loop of max-slots-per-step rounds instead of one round per collision slot of the working set);
+//   * the pivot score is compared in fp32 (one DPP max per step instead of a two-register fp64 butterfly); the
+//     violation, the step lengths and every quantity that reaches the result stay fp64.
+// All arithmetic that reaches an output is fp64; no atomics; fixed-order reductions => bit-reproducible.
+
+template <bool SOFT, int QCAP, bool PERSIST>
+struct SolveLds {   // offsets in doubles from the wave's LDS base
+    static constexpr int T = 0;
+    static constexpr int A = t_doubles(QCAP);
+    static constexpr int W = A + 48;
+    static constexpr int Y = W + 48;
+    static constexpr int NU = Y + 48;
+    static constexpr int RR = NU + 48;
+    static constexpr int XS = RR + 64;
+    static constexpr int SVEC = XS + 64;
+    static constexpr int SD = SVEC + 3 * QCAP;
+    static constexpr int SLAM = SD + QCAP;
+    static constexpr int SSS = SLAM + QCAP;
+    static constexpr int META = SSS + (SOFT ? QCAP : 0);   // QCAP ints
+    static constexpr int TAB = META + QCAP / 2;             // one-agent-per-workgroup form: own copy of G (900) + Lt (225)
+    static constexpr int VAR = TAB + (PERSIST ? 0 : TAB_CASE_DOUBLES + TAB_L_DOUBLES + 1);   // r_eps (soft: nrmax doubles), r_fl (nrmax bytes)
+};
+
+#define DMPC_DPP_MAXF(v, CTRL, RM)                                                                                      \
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, RM, 0xf, false)))
+__device__ __forceinline__ float wave_max_f(float v)
+{
+    DMPC_DPP_MAXF(v, 0x111, 0xf);
+    DMPC_DPP_MAXF(v, 0x112, 0xf);
+    DMPC_DPP_MAXF(v, 0x114, 0xf);
+    DMPC_DPP_MAXF(v, 0x118, 0xf);
+    DMPC_DPP_MAXF(v, 0x142, 0xa);
+    DMPC_DPP_MAXF(v, 0x143, 0xc);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// uniform description of one constraint
+struct Cd {
+    int ty, idx, gi, si;     // type, index (component or row), Gram index (space, step), slack row (-1: none)
+    double v0, v1, v2, ss, d;
+};
+
+// y = T' x  (lane j gets y_j; 0 for j >= q).  x in the LDS vector xs (zero beyond q).
+template <int QCAP>
+__device__ __forceinline__ double t_tmul2(const double *Tp, const double *xs, int lane, int q)
+{
+    double acc = 0.0;
+    const double *col = Tp + tcol(lane < QCAP ? lane : QCAP - 1);
+    for (int i0 = 0; i0 < q; i0 += 8) {
+        double t[8], x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { t[u] = col[i0 + u]; x[u] = xs[i0 + u]; }
+        double g = 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) g = fma(t[u], x[u], g);
+        acc += (i0 <= lane) ? g : 0.0;
+    }
+    return (lane < q) ? acc : 0.0;
+}
+// y = T x  (lane i gets y_i; 0 for i >= q).  The 8 columns of group g hold rows 0 .. 8(g+1)-1 (zeros below the diagonal),
+// so a lane either owns the whole group or skips it; columns >= q only meet x_j = 0.
+template <int QCAP>
+__device__ __forceinline__ double t_mul2(const double *Tp, const double *xs, int lane, int q)
+{
+    double acc = 0.0;
+    const double *row = Tp + lane;
+    for (int j0 = 0; j0 < q; j0 += 8) {
+        double t[8], x[8];
+        const int c0 = tcol(j0), len = j0 + 9;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { t[u] = row[c0 + u * len]; x[u] = xs[j0 + u]; }
+        double g = 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) g = fma(t[u], x[u], g);
+        acc += (lane < j0 + 8) ? g : 0.0;
+    }
+    return (lane < q) ? acc : 0.0;
+}
+
+// delete slot l: Givens rotations on adjacent columns zero row l of T left-to-right; row l and the last column drop out.
+// Fused with the row deletion (each lane carries its row of the "current right column" in a register).
+template <bool SOFT, int QCAP, bool PERSIST>
+__device__ __forceinline__ void remove_slot2(double *B, int lane, int &q, int l, unsigned &cslot, unsigned long long &cm)
+{
+    using SL = SolveLds<SOFT, QCAP, PERSIST>;
+    double *T = B + SL::T;
+    int *s_meta = (int *)(B + SL::META);
+    // per-component slot indices (2 bytes: box slot, position slot; 0xff = none) and the per-step collision-slot mask:
+    // the removed slot disappears, higher slots move down by one
+    {
+        const unsigned b0 = cslot & 0xffu, b1 = (cslot >> 8) & 0xffu;
+        const unsigned n0 = (b0 == (unsigned)l) ? 0xffu : ((b0 > (unsigned)l && b0 != 0xffu) ? b0 - 1u : b0);
+        const unsigned n1 = (b1 == (unsigned)l) ? 0xffu : ((b1 > (unsigned)l && b1 != 0xffu) ? b1 - 1u : b1);
+        cslot = (cslot & 0xffff0000u) | n0 | (n1 << 8);
+        if (n0 != b0 && n0 == 0xffu) cslot &= ~0x00030000u;   // the box pair's member bits
+        if (n1 != b1 && n1 == 0xffu) cslot &= ~0x000c0000u;   // the position pair's member bits
+        const unsigned long long lo = cm & ((1ull << l) - 1ull), hi = (cm >> (l + 1)) << l;
+        cm = lo | hi;
+    }
+    double carry = (lane <= l) ? T[tcol(l) + lane] : 0.0;
+    double right = (q - 1 > l && lane <= l + 1) ? T[tcol(l + 1) + lane] : 0.0;
+    for (int j = l; j < q - 1; ++j) {
+        const double next = (j + 2 < q && lane <= j + 2) ? T[tcol(j + 2) + lane] : 0.0;
+        const double a_ = readlane_d(carry, l), b_ = readlane_d(right, l);
+        const double n2 = a_ * a_ + b_ * b_;
+        double cc = 1.0, ss = 0.0;
+        if (n2 > 1e-300) { const double inv = rsqrt(n2); cc = b_ * inv; ss = a_ * inv; }
+        const double nl = cc * carry - ss * right;
+        const double nr_ = ss * carry + cc * right;
+        if (lane <= j + 1 && lane != l) T[tcol(j) + (lane < l ? lane : lane - 1)] = nl;
+        carry = nr_;
+        right = next;
+    }
+    // the column that dropped out: back to zero up to the end of its group (keeps "zero below the diagonal" for the next append)
+    if (lane < ((q + 7) & ~7)) T[tcol(q - 1) + lane] = 0.0;
+    const bool mv = lane > l && lane < q;
+    double v0 = 0, v1 = 0, v2 = 0, ss = 0, d = 0, lam = 0; int meta = 0;
+    if (mv) {
+        v0 = B[SL::SVEC + 3 * lane]; v1 = B[SL::SVEC + 3 * lane + 1]; v2 = B[SL::SVEC + 3 * lane + 2];
+        d = B[SL::SD + lane]; lam = B[SL::SLAM + lane]; meta = s_meta[lane];
+        if (SOFT) ss = B[SL::SSS + lane];
+    }
+    LSYNC();
+    if (mv) {
+        const int t = lane - 1;
+        B[SL::SVEC + 3 * t] = v0; B[SL::SVEC + 3 * t + 1] = v1; B[SL::SVEC + 3 * t + 2] = v2;
+        B[SL::SD + t] = d; B[SL::SLAM + t] = lam; s_meta[t] = meta;
+        if (SOFT) B[SL::SSS + t] = ss;
+    }
+    q -= 1;
+    LSYNC();
+}
+
+// `bidx`: the workgroup's index (one-agent-per-workgroup launches, renumbered XCD-aware here) or the queue position a
+// persistent wave just claimed; `smem`: this wave's LDS; `shtab`: the workgroup-shared tables (persistent form).
+template <bool SOFT, int QCAP, bool PERSIST>
+__device__ __forceinline__ void solve_body(const StepParams &P, const int lane, const int bidx, const int nblocks,
+                                           unsigned char *smem, const double *shtab)
+{
+    using SL = SolveLds<SOFT, QCAP, PERSIST>;
+    constexpr bool soft = SOFT;
+    const int S = P.S, C = P.C, nrmax = P.nrmax, var = P.variant;
+    int vb = bidx;
+    if (!PERSIST) {   // XCD-aware renumbering (see step_body)
+        const int nb = nblocks, x = bidx & 7, y = bidx >> 3;
+        int off = 0;
+        for (int xx = 0; xx < x; ++xx) off += (nb - xx + 7) >> 3;
+        vb = off + y;
+    }
+    if (P.order) vb = P.order[bidx];   // heaviest agents first (order_kernel) / tier-2 list
+    const int scene = vb / P.c_count, ci = vb - scene * P.c_count;
+    const int cl = P.c_first + ci;
+    const int gid = scene * P.c_count + ci;
+
+    double *B = (double *)smem;
+    double *r_eps = B + SL::VAR;                                                   // soft variants: nrmax doubles
+    unsigned char *r_fl = (unsigned char *)(B + SL::VAR + (soft ? nrmax : 0));     // nrmax bytes
+    int *s_meta = (int *)(B + SL::META);
+    // collision rows: per-agent slice of the global scratch written by the scan kernel (lane = row: coalesced)
+    const size_t per = (size_t)nrmax * (soft ? 7 : 4);
+    double *g_rows = P.rowbuf + (size_t)gid * per;
+    double *r_xi = g_rows, *r_b = g_rows + 3 * (size_t)nrmax;
+    double *r_sd = soft ? r_b + nrmax : nullptr, *r_st = soft ? r_b + 2 * (size_t)nrmax : nullptr, *r_slb = soft ? r_b + 3 * (size_t)nrmax : nullptr;
+    int *r_kc = P.rowkc + (size_t)gid * nrmax;
+    int *hdr = P.hdr + (size_t)gid * 8;
+    if (P.only_flagged && !(P.status[gid] & ST_QOVER)) return;   // tier 2: only agents that overflowed tier 1
+    if (hdr[4] & 8) return;                                       // agent of a scene that already stopped
+
+    // ---------------------------------------------------------------- agent state (uniform)
+    double po[3], vo[3], ao[3], pf[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        po[d] = P.x_p[3 * gid + d]; vo[d] = P.x_v[3 * gid + d];
+        ao[d] = P.x_a[3 * gid + d]; pf[d] = P.pf[3 * gid + d];
+    }
+    const double *lT_own = P.lT + ((size_t)(P.g_local * S + scene) * N3) * C + cl;
+
+    // the scan's branch record
+    int nr = hdr[0], status = hdr[3];
+    const int nrows_built = hdr[1], viol_k = hdr[2];
+    const bool violation = (hdr[4] & 1) != 0, rows_exist = hdr[5] != 0;
+    const bool cppv = (var == VAR_CPP || var == VAR_CPP2);
+
+    // ---------------------------------------------------------------- cost case + tables (a7, :43-58)
+    int ccase = 2;
+    {
+        const double dn = sqrt((po[0] - pf[0]) * (po[0] - pf[0]) + (po[1] - pf[1]) * (po[1] - pf[1]) + (po[2] - pf[2]) * (po[2] - pf[2]));
+        const bool far = (var == VAR_ELLIP) ? (dn > 1.0) : (dn >= 1.0);
+        if (!rows_exist && far) ccase = 0;
+        else if (!rows_exist && dn < 1.0) ccase = 1;
+    }
+    const double qw = ccase == 0 ? 1000.0 : (ccase == 1 ? 10000.0 : P.Q1);
+    const double sw = ccase == 2 ? ((var == VAR_ALL3) ? 10.0 : P.S1) : 10.0;
+    const double *G, *Lt;
+    if (PERSIST) { G = shtab + (size_t)ccase * TAB_CASE_DOUBLES; Lt = shtab + 3 * TAB_CASE_DOUBLES; }
+    else {
+        const double *src = P.tables + (size_t)ccase * TAB_CASE_DOUBLES, *srcl = P.tables + 3 * TAB_CASE_DOUBLES;
+        for (int i = lane; i < TAB_CASE_DOUBLES; i += 64) B[SL::TAB + i] = src[i];
+        for (int i = lane; i < TAB_L_DOUBLES; i += 64) B[SL::TAB + TAB_CASE_DOUBLES + i] = srcl[i];
+        G = B + SL::TAB; Lt = G + TAB_CASE_DOUBLES;
+    }
+    // Every LDS value the solver can touch must be finite: the matrix-vector products read whole groups of 8 unmasked
+    // (stale columns only ever meet x_j = 0).  The region starts at zero for every agent, so a non-finite input of one
+    // agent cannot reach the next agent of a persistent wave.
+    for (int i = lane; i < SL::TAB; i += 64) B[i] = 0.0;
+    LSYNC();
+
+    const int k_l = lane < N3 ? lane / 3 : 0, ax_l = lane < N3 ? lane - 3 * k_l : 0;
+    const bool comp = lane < N3;
+    // unconstrained minimiser per axis: a_unc = -H1^-1 f,  f = -2(q L_K'(pf - A0_K x0) + s [ao;0..])
+    //   => a_unc(k) = 2 q g (H1^-1 L')[k][K-1] + 2 s ao H1^-1[k][0],  g = pf - (po + K h vo)      (:88/:93)
+    double a_unc = 0.0, w_unc = 0.0;
+    const double gax = comp ? (sel3(pf, ax_l) - (sel3(po, ax_l) + (double)K * P.h * sel3(vo, ax_l))) : 0.0;
+    const double ao_l = comp ? sel3(ao, ax_l) : 0.0;
+    if (comp) {
+        a_unc = 2.0 * qw * gax * G[k_l * 30 + 15 + (K - 1)] + 2.0 * sw * ao_l * G[k_l * 30];
+        // w_unc = Lambda a_unc from the same table
+        w_unc = 2.0 * qw * gax * G[(15 + k_l) * 30 + 15 + (K - 1)] + 2.0 * sw * ao_l * G[(15 + k_l) * 30];
+    }
+
+    // Dual-bound certificate (slack-free variants): the iterate of the dual method minimises the cost over its working
+    // set, so its cost value `dual` is a lower bound of the constrained optimum, rising with every step by
+    // t delta (lambda_p + t/2).  Every feasible point lies in the box |a| <= alim, where the cost is at most
+    //   fbound = 3/2 alim^2 sum|H1(i,j)| + alim sum|f_i|; once `dual` exceeds that the QP is infeasible.
+    double dual = 0.0, fbound = INFINITY;
+    if (!soft) {
+        double f_l = 0.0;
+        if (comp) {
+            const double LKk = 0.5 * P.h * P.h + (double)(K - 1 - k_l) * P.h * P.h;   // Lambda(K, k)
+            f_l = -2.0 * qw * LKk * gax - ((k_l == 0) ? 2.0 * sw * ao_l : 0.0);
+        }
+        dual = 0.5 * wave_sum(f_l * a_unc);
+        const double fabs_sum = wave_sum(fabs(f_l));
+        fbound = 1.5 * P.alim * P.alim * P.hsum[ccase] + P.alim * fabs_sum;
+        fbound += 1e-6 * (fabs(fbound) + fabs(dual));
+    }
+
+    // per-lane constants of component (k_l, ax_l)
+    double p0_l = 0.0, whi_l = 0.0, wlo_l = 0.0, vo_l = 0.0;
+    float wbox_f = 0.f, wpos_f = 0.f;
+    if (comp) {
+        vo_l = sel3(vo, ax_l);
+        const double sh = (double)(k_l + 1) * P.h * vo_l;
+        p0_l = sel3(po, ax_l) + sh;                              // A_initp(k,:) [po;vo]
+        whi_l = sel3(P.pmax, ax_l) - sel3(po, ax_l) - sh;        // pmax - A0 x0  (:72)
+        wlo_l = sel3(P.pmin, ax_l) - sel3(po, ax_l) - sh;
+        // pivot weights: the entering constraint is the one farthest from feasibility in the metric of the problem,
+        // violation / |n|_{H^-1} (compared in fp32: the choice only orders the pivots)
+        wbox_f = (float)rsqrt(G[k_l * 31]); wpos_f = (float)rsqrt(G[(15 + k_l) * 31]);
+    }
+    // Register cache of the first collision rows (RC per lane; the rest is streamed from the L2-resident scratch)
+    constexpr int RC = soft ? 1 : 2;
+    double rcx0[2], rcx1[2], rcx2[2], rcb[2], rcsd[2], rcslb[2];
+    float rcw[2];
+    int rckc[2];
+    rcx0[1] = rcx1[1] = rcx2[1] = rcb[1] = rcsd[1] = rcslb[1] = 0.0; rcw[1] = 0.f; rckc[1] = 0;
+    auto row_weight = [&](double x0, double x1, double x2, int kc, double sd) -> float {
+        return (float)rsqrt(G[(15 + kc) * 31] * (x0 * x0 + x1 * x1 + x2 * x2) + (soft ? 0.5 * sd * sd : 0.0));
+    };
+#pragma unroll
+    for (int c = 0; c < RC; ++c) {
+        const int i = lane + 64 * c;
+        const int ii = i < nr ? i : 0;
+        rcx0[c] = r_xi[3 * ii]; rcx1[c] = r_xi[3 * ii + 1]; rcx2[c] = r_xi[3 * ii + 2];
+        rcb[c] = r_b[ii]; rckc[c] = r_kc[ii];
+        rcsd[c] = soft ? r_sd[ii] : 0.0; rcslb[c] = soft ? r_slb[ii] : 0.0;
+        rcw[c] = row_weight(rcx0[c], rcx1[c], rcx2[c], rckc[c], rcsd[c]);
+    }
+
+    // ---------------------------------------------------------------- a7: dual active-set solve
+    const bool ladder = soft && (var == VAR_BOUND || var == VAR_BOUND2 || var == VAR_ALL3 || cppv);
+    constexpr int LADDER_CERT_AFTER = 16;
+    constexpr int FARKAS_AFTER = 8;
+    const int max_tries = P.max_tries > 0 ? P.max_tries : (cppv ? 21 : 30);
+    // hdr[6] = retry-ladder levels already known to be infeasible (certified by the scan, or proven by a tier-1 launch
+    // that then overflowed); hdr[4] bit 1 = the row data in global memory is already scaled
+    int tries = hdr[6], iters_total = (P.only_flagged ? hdr[7] : 0), maxq = 0, q = 0;
+    const bool rows_scaled = (hdr[4] & 2) != 0;
+    bool solved = false;
+    double a = 0.0, w = 0.0;
+    const double tol = 1e-10;
+
+    if (status & ST_INFEAS) tries = 1;   // certified infeasible by the scan (single attempt: hard rows only)
+    if (soft && tries > 0 && !rows_scaled && !(status & ST_INFEAS)) {
+        if (tries >= max_tries) { status |= ST_INFEAS; tries = max_tries; }
+        else {
+            const double f = ldexp(1.0, tries);
+            for (int i = lane; i < nr; i += 64) { r_slb[i] *= f; r_st[i] *= f; }
+            rcslb[0] *= f; rcslb[1] *= f;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+    }
+    if (!(status & (ST_COLL | ST_CAPACITY | ST_INFEAS))) {
+        while (tries < max_tries) {
+            tries++;
+            q = 0;
+            // cslot: byte 0 = slot of the component's box constraint (0xff none), byte 1 = slot of its workspace bound,
+            // bits 16..19 = membership of BOXHI | BOXLO | POSHI | POSLO; cm: collision slots that constrain step k_l
+            unsigned cslot = 0x0000ffffu;
+            unsigned long long cm = 0ull;
+            for (int i = lane; i < nr; i += 64) r_fl[i] = 0;
+            int rc = 0;   // 0 running/ok, 1 infeasible, 2 capacity, 3 itercap
+            int iters = 0;
+            a = a_unc; w = w_unc;
+            if (comp) { B[SL::A + lane] = a; B[SL::W + lane] = w; }
+            if (soft) for (int i = lane; i < nr; i += 64) r_eps[i] = 0.0;
+            double g_l = 0.0;   // gradient of the cost at the iterate (slack-free variants): Farkas test against the box
+            LSYNC();
+
+            // nu = sgn * n_p - N_W r assembled as one vector in a-space, from the vector r in B[RR]:
+            //   nu_a = U + Lambda' Y   (U: box part, Y: position/collision part)
+            // returns nu for this lane's component; Y is staged in B[Y], nu is left in B[NU]
+            auto residual = [&](const double pU, const double pY) -> double {
+                double nu = 0.0;
+                if (comp) {
+                    const unsigned sb = cslot & 0xffu, sp = (cslot >> 8) & 0xffu;
+                    // slot 63 is never used (QCAP <= 48 ... 64 with r[63] = 0 only for QCAP < 64: guarded below)
+                    const double rb = B[SL::RR + (sb < 64u ? sb : 63u)], rp = B[SL::RR + (sp < 64u ? sp : 63u)];
+                    double U = pU, Y = pY;
+                    // BOXHI: vec = +e, BOXLO: vec = -e  (nu -= r * vec)
+                    U += (sb == 0xffu) ? 0.0 : ((cslot & 0x10000u) ? -rb : rb);
+                    Y += (sp == 0xffu) ? 0.0 : ((cslot & 0x40000u) ? -rp : rp);
+                    unsigned long long m = cm;
+                    while (__any(m != 0ull)) {
+                        const bool have = m != 0ull;
+                        const int j = have ? (__ffsll((long long)m) - 1) : 0;
+                        const double rj = B[SL::RR + j], vj = B[SL::SVEC + 3 * j + ax_l];
+                        Y -= have ? rj * vj : 0.0;
+                        m &= m - 1ull;
+                    }
+                    B[SL::Y + lane] = Y;
+                    LSYNC();
+                    nu = U;
+                    double yv[K], lt[K];
+#pragma unroll
+                    for (int kk = 0; kk < K; ++kk) { yv[kk] = B[SL::Y + 3 * kk + ax_l]; lt[kk] = Lt[k_l * 15 + kk]; }
+#pragma unroll
+                    for (int kk = 0; kk < K; ++kk) nu = fma(lt[kk], yv[kk], nu);
+                    B[SL::NU + lane] = nu;
+                    LSYNC();
+                }
+                return nu;
+            };
+            // z = H^-1 nu (za) and Lambda z (zw) for this lane's component, from B[NU]
+            auto direction = [&](double &za, double &zw) {
+                za = 0.0; zw = 0.0;
+                if (comp) {
+#pragma unroll
+                    for (int kg = 0; kg < 3; ++kg) {
+                        double nk[5], th[5], tm[5];
+#pragma unroll
+                        for (int u = 0; u < 5; ++u) {
+                            const int kk = 5 * kg + u;
+                            nk[u] = B[SL::NU + 3 * kk + ax_l]; th[u] = G[k_l * 30 + kk]; tm[u] = G[(15 + k_l) * 30 + kk];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 5; ++u) { za = fma(th[u], nk[u], za); zw = fma(tm[u], nk[u], zw); }
+                    }
+                }
+            };
+            // x(lambda) re-derived from the multipliers: nu = -N_W lambda, a = a_unc + H^-1 nu, w = w_unc + Lambda H^-1 nu,
+            // eps = -(st + sum lambda sigma)/2 for live slack rows
+            auto primal_fast = [&]() {
+                B[SL::RR + lane] = (lane < q) ? B[SL::SLAM + lane] : 0.0;
+                unsigned long long smk = 0ull;
+                if (soft) {
+                    const int mt = (lane < q) ? ((s_meta[lane] >> 8) & 0xff) : -1;
+                    smk = __ballot(mt >= TY_COLL && B[SL::SSS + (lane < q ? lane : 0)] != 0.0);
+                }
+                LSYNC();
+                const double nu = residual(0.0, 0.0);
+                if (!soft) g_l = nu;   // H x(lambda) + f = -N_W lambda
+                double za, zw;
+                direction(za, zw);
+                if (comp) {
+                    a = a_unc + za; w = w_unc + zw;
+                    B[SL::A + lane] = a; B[SL::W + lane] = w;
+                }
+                if (soft) {
+                    for (int i = lane; i < nr; i += 64) {
+                        const int fl = r_fl[i];
+                        if (!(fl & RF_LIVE)) r_eps[i] = 0.0;
+                        else if (!(fl & (RF_COLL | RF_SLKU | RF_SLKL))) r_eps[i] = -0.5 * r_st[i];
+                    }
+                    const bool mine = (smk >> lane) & 1ull;
+                    const int myrow = mine ? (s_meta[lane] >> 16) : -1;
+                    bool owner = mine;
+                    double acc = 0.0;
+                    for (unsigned long long m = smk; m; m &= m - 1) {
+                        const int j = __ffsll((long long)m) - 1;
+                        if ((s_meta[j] >> 16) == myrow) { acc += B[SL::RR + j] * B[SL::SSS + j]; if (j < lane) owner = false; }
+                    }
+                    if (owner) r_eps[myrow] = -0.5 * (r_st[myrow] + acc);
+                }
+                LSYNC();
+            };
+            // value n_j'x - d_j of the slot owned by this lane
+            auto slot_value = [&](int j) -> double {
+                const int meta = s_meta[j], gi = meta & 0xff;
+                const int kb = gi >= 15 ? gi - 15 : gi;
+                const double *base = B + (gi >= 15 ? SL::W : SL::A) + 3 * kb;
+                double v = B[SL::SVEC + 3 * j] * base[0] + B[SL::SVEC + 3 * j + 1] * base[1] + B[SL::SVEC + 3 * j + 2] * base[2];
+                if (soft) { const double ss = B[SL::SSS + j]; if (((meta >> 8) & 0xff) >= TY_COLL && ss != 0.0) v += ss * r_eps[meta >> 16]; }
+                return v - B[SL::SD + j];
+            };
+            auto write_slot = [&](const Cd &p, double lam) {
+                if (lane == 0) {
+                    B[SL::SVEC + 3 * q] = p.v0; B[SL::SVEC + 3 * q + 1] = p.v1; B[SL::SVEC + 3 * q + 2] = p.v2;
+                    B[SL::SD + q] = p.d; B[SL::SLAM + q] = lam;
+                    if (soft) B[SL::SSS + q] = p.ss;
+                    s_meta[q] = p.gi | (p.ty << 8) | (p.idx << 16);
+                }
+            };
+            auto slack_desc = [&](int ty, int idx) -> Cd {
+                Cd c;
+                c.ty = ty; c.idx = idx; c.gi = 0; c.si = idx; c.v0 = c.v1 = c.v2 = 0.0;
+                if (ty == TY_SLKU) { c.ss = 1.0; c.d = 0.0; } else { c.ss = -1.0; c.d = -r_slb[idx]; }
+                return c;
+            };
+
+            int nlive = 0;
+            bool fresh = true;              // primal == x(lambda) with refined lambda
+            int since_sync = 0;
+            bool cert_done = false;
+            for (;;) {
+                if (soft && ladder && violation && !cert_done && iters >= LADDER_CERT_AFTER) {
+                    cert_done = true;
+                    if (ladder_level_infeasible(r_xi, r_b, r_sd, r_slb, r_kc, nr, B + SL::RR, P.h, P.alim, 1.0, whi_l, wlo_l, lane)) { rc = 1; break; }
+                }
+                // ---- most violated constraint not in the working set (score = violation / |n|_{H^-1}, fp32)
+                double bestv = 0.0; float bests = 0.f; int bestc = -1;
+#define CAND(v_, w_, code_) do { const double v__ = (v_); const float s__ = (float)v__ * (w_); \
+                                 if (v__ > tol && s__ > bests) { bests = s__; bestv = v__; bestc = (code_); } } while (0)
+                if (comp) {
+                    // a <= alim and -a <= alim are violated one at a time: one candidate for the pair (not while a member is active)
+                    const bool hi = a > 0.0;
+                    if (!(cslot & 0x30000u)) CAND(fabs(a) - P.alim, wbox_f, ((hi ? TY_BOXHI : TY_BOXLO) << 16) | lane);
+                    const double c2 = w - whi_l, c3 = wlo_l - w;
+                    if (!(cslot & 0xc0000u)) CAND(fmax(c2, c3), wpos_f, ((c2 > c3 ? TY_POSHI : TY_POSLO) << 16) | lane);
+                }
+#pragma unroll
+                for (int c = 0; c < RC; ++c) {   // rows held in registers
+                    const int i = lane + 64 * c;
+                    if (i < nr) {
+                        const int fl = r_fl[i], kc = rckc[c];
+                        double v = -(rcx0[c] * B[SL::W + 3 * kc] + rcx1[c] * B[SL::W + 3 * kc + 1] + rcx2[c] * B[SL::W + 3 * kc + 2]) - rcb[c];
+                        if (soft && (fl & RF_LIVE)) {
+                            const double e = r_eps[i];
+                            v += rcsd[c] * e;
+                            if (!(fl & RF_SLKU)) CAND(e, 1.4142135f, (TY_SLKU << 16) | i);   // |n|^2 = 1/2
+                            const double lo = rcslb[c] - e;   // -eps <= -slb
+                            if (!(fl & RF_SLKL)) CAND(lo, 1.4142135f, (TY_SLKL << 16) | i);
+                        }
+                        if (!(fl & RF_COLL)) CAND(v, rcw[c], (TY_COLL << 16) | i);
+                    }
+                }
+                for (int i = lane + 64 * RC; i < nr; i += 64) {   // the rest streams from the global scratch
+                    const int fl = r_fl[i], kc = r_kc[i];
+                    const double x0 = r_xi[3 * i], x1 = r_xi[3 * i + 1], x2 = r_xi[3 * i + 2];
+                    double v = -(x0 * B[SL::W + 3 * kc] + x1 * B[SL::W + 3 * kc + 1] + x2 * B[SL::W + 3 * kc + 2]) - r_b[i];
+                    if (soft && (fl & RF_LIVE)) {
+                        const double e = r_eps[i];
+                        v += r_sd[i] * e;
+                        if (!(fl & RF_SLKU)) CAND(e, 1.4142135f, (TY_SLKU << 16) | i);
+                        const double lo = r_slb[i] - e;
+                        if (!(fl & RF_SLKL)) CAND(lo, 1.4142135f, (TY_SLKL << 16) | i);
+                    }
+                    if (!(fl & RF_COLL) && v > tol) CAND(v, row_weight(x0, x1, x2, kc, soft ? r_sd[i] : 0.0), (TY_COLL << 16) | i);
+                }
+#undef CAND
+                const float smax = wave_max_f(bests);
+                const unsigned long long wm = __ballot(bestc >= 0 && bests == smax);
+                if (wm == 0ull) {
+                    if (q == 0 || fresh) break;   // optimal
+                    // verification: primal from the multipliers, refine the active-set residual, re-check
+                    primal_fast();
+                    for (int pass = 0; pass < 3; ++pass) {
+                        const double rho = (lane < q) ? slot_value(lane) : 0.0;
+                        const double mx = wave_max(fabs(rho));
+                        if (!(mx > 1e-13)) break;
+                        B[SL::XS + lane] = rho; LSYNC();
+                        const double dvj = t_tmul2<QCAP>(B + SL::T, B + SL::XS, lane, q);
+                        B[SL::RR + lane] = dvj; LSYNC();
+                        const double ri = t_mul2<QCAP>(B + SL::T, B + SL::RR, lane, q);
+                        if (lane < q) B[SL::SLAM + lane] += ri;
+                        LSYNC();
+                        primal_fast();
+                    }
+                    fresh = true;
+                    continue;
+                }
+                fresh = false;
+                const int src = __ffsll((long long)wm) - 1;
+                const int pcode = readlane_i(bestc, src);
+                double vp = readlane_d(bestv, src);
+                Cd p;
+                {
+                    const int pty = pcode >> 16, pidx = pcode & 0xffff;
+                    p.ty = pty; p.idx = pidx; p.gi = 0; p.si = -1; p.v0 = p.v1 = p.v2 = 0.0; p.ss = 0.0; p.d = 0.0;
+                    if (pty < TY_COLL) {
+                        const int k = pidx / 3, ax = pidx - 3 * k;
+                        const double sgn = (pty == TY_BOXHI || pty == TY_POSHI) ? 1.0 : -1.0;
+                        p.gi = (pty < TY_POSHI) ? k : 15 + k;
+                        p.v0 = ax == 0 ? sgn : 0.0; p.v1 = ax == 1 ? sgn : 0.0; p.v2 = ax == 2 ? sgn : 0.0;
+                        p.d = (pty < TY_POSHI) ? P.alim : ((pty == TY_POSHI) ? readlane_d(whi_l, pidx) : -readlane_d(wlo_l, pidx));
+                    } else if (pidx < 64 * RC) {   // row data from the owning lane's registers
+                        const int ol = pidx & 63;
+                        const bool hi = RC > 1 && pidx >= 64;
+                        if (pty == TY_COLL) {
+                            p.gi = 15 + readlane_i(hi ? rckc[1] : rckc[0], ol);
+                            p.v0 = -readlane_d(hi ? rcx0[1] : rcx0[0], ol); p.v1 = -readlane_d(hi ? rcx1[1] : rcx1[0], ol);
+                            p.v2 = -readlane_d(hi ? rcx2[1] : rcx2[0], ol); p.d = readlane_d(hi ? rcb[1] : rcb[0], ol);
+                            if (soft) { p.si = pidx; p.ss = readlane_d(hi ? rcsd[1] : rcsd[0], ol); }
+                        } else if (pty == TY_SLKU) { p.si = pidx; p.ss = 1.0; }
+                        else { p.si = pidx; p.ss = -1.0; p.d = -readlane_d(hi ? rcslb[1] : rcslb[0], ol); }
+                    } else if (pty == TY_COLL) {
+                        p.gi = 15 + r_kc[pidx];
+                        p.v0 = -r_xi[3 * pidx]; p.v1 = -r_xi[3 * pidx + 1]; p.v2 = -r_xi[3 * pidx + 2];
+                        p.d = r_b[pidx];
+                        if (soft) { p.si = pidx; p.ss = r_sd[pidx]; }
+                    } else p = slack_desc(pty, pidx);
+                }
+                // lazily instantiate the eps<=0 pin of a soft row that becomes active (S(u,u) = 1/2)
+                if (soft && p.ty == TY_COLL && !(r_fl[p.idx] & RF_LIVE)) {
+                    if (q >= QCAP - 1) { rc = 2; break; }
+                    const Cd u = slack_desc(TY_SLKU, p.idx);
+                    if (lane < ((q + 8) & ~7)) B[SL::T + tcol(q) + lane] = (lane == q) ? 1.4142135623730951 : 0.0;
+                    if (lane == 0) r_fl[p.idx] |= (RF_LIVE | RF_SLKU);
+                    nlive++;
+                    write_slot(u, -r_st[p.idx]);
+                    q++;
+                    LSYNC();
+                }
+                double lam_p = 0.0;
+                // n_p' H^-1 n_p
+                const double spp = G[p.gi * 31] * (p.v0 * p.v0 + p.v1 * p.v1 + p.v2 * p.v2) + ((soft && p.si >= 0) ? 0.5 * p.ss * p.ss : 0.0);
+                const bool p_isA = p.ty < TY_POSHI;
+                // ---- inner loop: partial steps until p can be added
+                for (;;) {
+                    if (++iters > ITER_CAP) { rc = 3; break; }
+                    // s = N_W' H^-1 n_p on the slot lanes
+                    double sv = 0.0;
+                    int mymeta = 0;
+                    if (lane < q) {
+                        mymeta = s_meta[lane];
+                        const int gj = mymeta & 0xff;
+                        const double dot3 = B[SL::SVEC + 3 * lane] * p.v0 + B[SL::SVEC + 3 * lane + 1] * p.v1 + B[SL::SVEC + 3 * lane + 2] * p.v2;
+                        sv = G[gj * 30 + p.gi] * dot3;
+                        if (soft) {
+                            const double ssj = B[SL::SSS + lane];
+                            if (((mymeta >> 8) & 0xff) >= TY_COLL && p.si >= 0 && (mymeta >> 16) == p.si && ssj != 0.0) sv += 0.5 * ssj * p.ss;
+                        }
+                    }
+                    B[SL::XS + lane] = sv; LSYNC();
+                    const double dvj = t_tmul2<QCAP>(B + SL::T, B + SL::XS, lane, q);
+                    B[SL::RR + lane] = dvj; LSYNC();
+                    const double ri = t_mul2<QCAP>(B + SL::T, B + SL::RR, lane, q);
+                    LSYNC();
+                    B[SL::RR + lane] = ri;
+                    unsigned long long smk = 0ull;
+                    if (soft) smk = __ballot(lane < q && ((mymeta >> 8) & 0xff) >= TY_COLL && B[SL::SSS + (lane < q ? lane : 0)] != 0.0);
+                    LSYNC();
+                    // residual nu = n_p - N_W r (explicit: when p is nearly dependent on W, nu is small and the round-off of r
+                    // enters delta squared -- this makes the dependence / infeasibility test reliable), z = H^-1 nu, delta = nu'z
+                    double pU = 0.0, pY = 0.0;
+                    if (comp && p.ty <= TY_COLL && (p.gi >= 15 ? p.gi - 15 : p.gi) == k_l) {
+                        const double vpax = ax_l == 0 ? p.v0 : (ax_l == 1 ? p.v1 : p.v2);
+                        if (p_isA) pU = vpax; else pY = vpax;
+                    }
+                    const double nu = residual(pU, pY);
+                    double za, zw;
+                    direction(za, zw);
+                    double part = nu * za;
+                    // slack part: nu_eps(row) = sigma_p[si_p==row] - sum_j r_j sigma_j[si_j==row]; H_eps^-1 = 1/2
+                    double nue = 0.0; bool owner = false;
+                    bool p_row_has_slot = false;
+                    if (soft) {
+                        const bool mine = (smk >> lane) & 1ull;
+                        const int myrow = mine ? (mymeta >> 16) : -1;
+                        owner = mine;
+                        if (mine && p.si == myrow) nue += p.ss;
+                        for (unsigned long long m = smk; m; m &= m - 1) {
+                            const int j = __ffsll((long long)m) - 1;
+                            const int rj = s_meta[j] >> 16;
+                            if (rj == myrow) { nue -= B[SL::RR + j] * B[SL::SSS + j]; if (j < lane) owner = false; }
+                            if (rj == p.si) p_row_has_slot = true;
+                        }
+                        if (owner) part += 0.5 * nue * nue;
+                        if (p.si >= 0 && !p_row_has_slot && lane == 63) part += 0.5 * p.ss * p.ss;
+                    }
+                    const double delta = wave_sum(part);
+                    // more active constraints than variables is impossible: whatever round-off says, a constraint picked when
+                    // the working set already spans all 45 + nlive variables is dependent
+                    const bool dependent = !(delta > 1e-13 * spp) || q >= N3 + nlive;
+                    const double t2 = dependent ? INFINITY : vp / delta;
+                    const double ratio = (lane < q && ri > 0.0) ? (B[SL::SLAM + lane] / ri) : INFINITY;
+                    const double t1 = wave_min(ratio);
+                    const double t = fmin(t1, t2);
+#ifdef DMPC_DEV_TRACE
+                    if (P.dbg && gid == P.dbg_agent && lane == 0 && iters <= P.dbg_cap) {
+                        double *d = P.dbg + (size_t)(iters - 1) * 8;
+                        d[0] = (double)pcode; d[1] = (double)q; d[2] = delta; d[3] = spp; d[4] = t1; d[5] = t2; d[6] = vp; d[7] = lam_p;
+                    }
+#endif
+                    if (!(t < INFINITY)) { rc = 1; break; }
+                    if (lane < q) B[SL::SLAM + lane] -= t * ri;
+                    lam_p += t;
+                    if (!dependent) {
+                        if (!soft) {
+                            dual += t * delta * (lam_p - 0.5 * t);
+                            if (dual > fbound) { rc = 1; break; }   // no point of the acceleration box costs this much
+                            // gradient of the cost at the iterate, g = H x + f = -(N_W lambda + n_p lambda_p) with lambda >= 0:
+                            // every feasible point a satisfies g.a >= g.x; when even the best point of the box misses that,
+                            // alim |g|_1 < g.x, the multipliers are a Farkas certificate of infeasibility
+                            g_l -= t * nu;
+                            if (iters >= FARKAS_AFTER) {
+                                const double an = a - t * za;
+                                const double ga = g_l * an, gb = P.alim * fabs(g_l);
+                                if (wave_sum(ga - gb - 1e-6 * (fabs(ga) + gb)) > 0.0) { rc = 1; break; }
+                            }
+                        }
+                        vp -= t * delta;
+                        a -= t * za; w -= t * zw;
+                        if (comp) { B[SL::A + lane] = a; B[SL::W + lane] = w; }
+                        if (soft) {
+                            if (owner) r_eps[mymeta >> 16] -= t * 0.5 * nue;
+                            if (p.si >= 0 && !p_row_has_slot && lane == 63) r_eps[p.si] -= t * 0.5 * p.ss;
+                        }
+                    }
+                    if (t2 <= t1) {
+                        // full step: append p (new column of T = [-r/rho ; 1/rho], zero below the diagonal)
+                        if (q >= QCAP) { rc = 2; break; }
+                        const double irho = rsqrt(delta);
+                        if (lane < ((q + 8) & ~7)) B[SL::T + tcol(q) + lane] = (lane < q) ? (-ri * irho) : ((lane == q) ? irho : 0.0);
+                        write_slot(p, lam_p);
+                        if (p.ty < TY_COLL) {
+                            if (lane == p.idx) {
+                                if (p_isA) cslot = (cslot & ~0xffu) | (unsigned)q | (p.ty == TY_BOXHI ? 0x10000u : 0x20000u);
+                                else cslot = (cslot & ~0xff00u) | ((unsigned)q << 8) | (p.ty == TY_POSHI ? 0x40000u : 0x80000u);
+                            }
+                        } else {
+                            if (lane == 0) {
+                                const int bit = (p.ty == TY_COLL) ? RF_COLL : (p.ty == TY_SLKU ? RF_SLKU : RF_SLKL);
+                                r_fl[p.idx] |= bit;
+                            }
+                            if (p.ty == TY_COLL && comp && k_l == p.gi - 15) cm |= 1ull << q;
+                        }
+                        q++;
+                        if (q > maxq) maxq = q;
+                        LSYNC();
+                        break;
+                    }
+                    // partial step: drop the blocking constraint
+                    const unsigned long long bm = __ballot(lane < q && ri > 0.0 && ratio == t1);
+                    const int l = __ffsll((long long)bm) - 1;
+                    const int dmeta = s_meta[l];
+                    const int dty = (dmeta >> 8) & 0xff, didx = dmeta >> 16;
+                    LSYNC();
+                    if (dty >= TY_COLL && lane == 0) {
+                        const int bit = (dty == TY_COLL) ? RF_COLL : (dty == TY_SLKU ? RF_SLKU : RF_SLKL);
+                        r_fl[didx] &= ~bit;
+                    }
+                    remove_slot2<SOFT, QCAP, PERSIST>(B, lane, q, l, cslot, cm);
+                    // de-instantiate the pin of a soft row whose collision row just left the set
+                    if (soft && dty == TY_COLL && didx != ((p.ty == TY_COLL) ? p.idx : -1)) {
+                        const int fl = r_fl[didx];
+                        if ((fl & RF_LIVE) && (fl & RF_SLKU) && !(fl & RF_SLKL)) {
+                            const int mm = (lane < q) ? s_meta[lane] : 0;
+                            const unsigned long long um = __ballot(lane < q && ((mm >> 8) & 0xff) == TY_SLKU && (mm >> 16) == didx);
+                            const int ul = __ffsll((long long)um) - 1;
+                            LSYNC();
+                            if (lane == 0) { r_fl[didx] = 0; r_eps[didx] = 0.0; }
+                            remove_slot2<SOFT, QCAP, PERSIST>(B, lane, q, ul, cslot, cm);
+                            nlive--;
+                        }
+                    }
+                    LSYNC();
+                }
+                if (rc) break;
+                // pin added while its collision row is not active: decoupled again -> drop both
+                if (soft && p.ty == TY_SLKU && !(r_fl[p.idx] & (RF_COLL | RF_SLKL))) {
+                    const int mm = (lane < q) ? s_meta[lane] : 0;
+                    const unsigned long long um = __ballot(lane < q && ((mm >> 8) & 0xff) == TY_SLKU && (mm >> 16) == p.idx);
+                    const int ul = __ffsll((long long)um) - 1;
+                    LSYNC();
+                    if (lane == 0) { r_fl[p.idx] = 0; r_eps[p.idx] = 0.0; }
+                    remove_slot2<SOFT, QCAP, PERSIST>(B, lane, q, ul, cslot, cm);
+                    nlive--;
+                }
+                if (((++since_sync) & 31) == 0) primal_fast();   // periodic re-sync with x(lambda)
+            }
+            iters_total += iters;
+            if (rc == 0) { solved = true; break; }
+            if (rc == 2) {   // tier 1: flag for the tier-2 relaunch (and record the ladder position); last tier: capacity error
+                status |= P.qover_bit;
+                if (lane == 0) {
+                    hdr[6] = tries - 1; hdr[7] = iters_total; hdr[4] |= 2;
+                    // tier 1: append to the list the tier-2 launch works through (order irrelevant: scheduling only)
+                    if (P.flag_list && P.qover_bit == ST_QOVER) P.flag_list[atomicAdd(P.flag_count, 1)] = gid;
+                }
+                break;
+            }
+            if (rc == 3) { status |= ST_ITERCAP; break; }
+            // infeasible: retry ladder (solveSoftDMPCbound.m:147-153): lb_eps *= 2, term *= 2
+            if (soft && ladder && violation) {
+                double f = 2.0;
+                while (tries < max_tries - 1 &&
+                       ladder_level_infeasible(r_xi, r_b, r_sd, r_slb, r_kc, nr, B + SL::RR, P.h, P.alim, f, whi_l, wlo_l, lane)) { f *= 2.0; ++tries; }
+                for (int i = lane; i < nr; i += 64) { r_slb[i] *= f; r_st[i] *= f; }
+                rcslb[0] *= f; rcslb[1] *= f;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                LSYNC();
+                continue;
+            }
+            if (ladder || var == VAR_REPAIR) tries = (var == VAR_REPAIR && P.max_tries <= 0) ? 10 : max_tries;
+            break;
+        }
+        if (!solved && !(status & (ST_CAPACITY | ST_ITERCAP | ST_QOVER))) status |= ST_INFEAS;
+    }
+
+    // ---------------------------------------------------------------- a9/a10: propagate, outputs
+    int nslack = 0;
+    if (solved) {
+        status |= ST_SOLVED;
+        if (soft) {
+            int cnt = 0;
+            for (int i = lane; i < nr; i += 64) cnt += (r_eps[i] < -1e-12) ? 1 : 0;
+            nslack = (int)wave_sum((double)cnt);
+        }
+    }
+    double p_out = 0.0, v_out = 0.0, a_out = 0.0;
+    if (solved && comp) {
+        // p = A_p a + A_initp [po;vo] ; v = A_v a + vo   (propStatedmpc.m:3-4)
+        p_out = w + p0_l;
+        double sv = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < K; ++kk) { const double ak = B[SL::A + 3 * kk + ax_l]; sv += (kk <= k_l) ? ak : 0.0; }
+        v_out = P.h * sv + vo_l;
+        a_out = a;
+    }
+    if (solved) {
+        const bool ob_check = !(var == VAR_ELLIP || var == VAR_SOFTALL || cppv);   // solveQPv2 has no in-bounds test
+        if (hdr[4] & 4) status |= ST_COLL;   // cpp: collision noticed at the first step, solution still returned
+        if (ob_check) {   // is_inbounds.m:2-5 on p(:,1)
+            const double tolb = 50e-3;
+            bool bad = false;
+            if (lane < 3) bad = !(p_out < sel3(P.pmax, lane) + tolb) || !(p_out > sel3(P.pmin, lane) - tolb);
+            if (__any(bad)) status |= ST_OUTBOUND;
+        }
+    }
+    if (comp) {
+        P.p_out[(size_t)gid * N3 + lane] = p_out;
+        P.v_out[(size_t)gid * N3 + lane] = v_out;
+        P.a_out[(size_t)gid * N3 + lane] = a_out;
+        if (P.lT_next) P.lT_next[((size_t)scene * N3 + lane) * C + cl] = solved ? p_out : lT_own[(size_t)lane * C];
+    }
+    if (lane == 0) {
+        P.status[gid] = status;
+        if (P.info) {
+            int *inf = P.info + (size_t)gid * 8;
+            inf[0] = viol_k; inf[1] = nrows_built; inf[2] = tries; inf[3] = ccase;
+            inf[4] = iters_total; inf[5] = nslack; inf[6] = solved ? q : 0; inf[7] = maxq;
+        }
+    }
+}
