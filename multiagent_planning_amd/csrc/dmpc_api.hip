@@ -64,6 +64,7 @@ struct dmpc_ctx {
     // per-neighbour bounding-box culling in the scan of large scenes (DMPC_NO_CULL=1 disables it, for A/B runs)
     int no_cull = getenv("DMPC_NO_CULL") ? 1 : 0;
     int no_lpt = getenv("DMPC_NO_LPT") ? 1 : 0;   // tuning: disable the heaviest-first solve order
+    int iter_cap = getenv("DMPC_ITER_CAP") ? atoi(getenv("DMPC_ITER_CAP")) : ITER_CAP;   // development: cap the active-set iterations (agents beyond it end DMPC_ST_ITERCAP)
     int single_tier = 0;         // 1: solve with the full working-set capacity in one launch
     DevBuf rows, lT, lT2, xp, xv, xa, pf, po, pout, vout, aout, status, info, hist_p, hist_v, hist_a, flags;
     int hist_S = 0, hist_N = 0, hist_KT = 0;   // shape of the histories left resident by the last dmpc_transition
@@ -413,6 +414,7 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
         P.rowbuf = ctx->rowbuf.as<double>(); P.rowkc = ctx->rowkc.as<int>(); P.hdr = ctx->hdr.as<int>();
     }
     P.dbg = ctx->dbg; P.dbg_agent = ctx->dbg_agent; P.dbg_cap = ctx->dbg_cap;
+    P.iter_cap = ctx->iter_cap;
     const int q1 = ctx->single_tier ? full_qcap(p.variant) : tier1_qcap(p.variant), q2 = full_qcap(p.variant);
     const bool two_tier = q1 < q2;
     // neighbour list of the scan: a quarter of the scene (fast agents have long horizon boxes), 1024..8192 entries
@@ -505,7 +507,7 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
             HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_persist_kernel<false, 48>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             ctx->max_lds_persist = (int)lds;
         }
-        P.counter = ctx->counter.as<int>() + tier;
+        P.counter = getenv("DMPC_STATIC_QUEUE") ? nullptr : ctx->counter.as<int>() + tier;
         P.lds_per_wave = (int)per;
         int wgs = (total + pw - 1) / pw;
         if (wgs > ctx->num_cu) wgs = ctx->num_cu;

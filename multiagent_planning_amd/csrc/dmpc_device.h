@@ -48,6 +48,7 @@ struct StepParams {
     int *flag_count, *flag_list;   // tier 1 -> tier 2: number / ids of the agents whose working set overflowed (or null)
     double *dbg;            // optional per-iteration trace of agent dbg_agent (development aid)
     int dbg_agent, dbg_cap;
+    int iter_cap;           // active-set iteration cap per try (ITER_CAP; development runs lower it to measure the per-iteration cost)
 };
 
 constexpr int SCAN_CAND_CAP = 1024;   // (neighbour, step) candidates buffered per flush of the hard-row scan
@@ -66,7 +67,7 @@ inline size_t scan_lds_bytes(int nbr_cap) { return (96 * 8 + (SCAN_CAND_CAP + (s
 // bytes of LDS of one solve wave (layout: SolveLds in dmpc_solve.hip; `persist`: the tables are shared by the workgroup)
 inline size_t solve_lds_bytes(int nrmax, bool soft, int qcap, bool persist)
 {
-    size_t dbl = (size_t)t_doubles(qcap) + 4 * 48 + 2 * 64 + 5 * (size_t)qcap + (soft ? (size_t)qcap : 0) + (size_t)qcap / 2;
+    size_t dbl = (size_t)t_doubles(qcap) + 2 * 48 + 2 * 64 + (soft ? 2 * 48 : 0) + 5 * (size_t)qcap + (soft ? (size_t)qcap : 0) + (size_t)qcap / 2;
     if (!persist) dbl += TAB_CASE_DOUBLES + TAB_L_DOUBLES + 1;
     if (soft) dbl += (size_t)nrmax;                 // r_eps
     const size_t bytes = dbl * 8 + (size_t)nrmax;   // + row flags (bytes)

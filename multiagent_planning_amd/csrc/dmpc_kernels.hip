@@ -666,7 +666,7 @@ __global__ __launch_bounds__(64, SOLVE_WAVES_PER_SIMD) void dmpc_solve_kernel(St
     solve_body<SOFT, QCAP, false>(P, threadIdx.x, blockIdx.x, gridDim.x, dmpc_smem, nullptr);
 }
 
-// Persistent form of the solve phase: one workgroup of up to 8 independent waves per CU.  The Gram tables of the three
+// Persistent form of the solve phase: one workgroup of up to 8 independent waves per CU (two per SIMD).  The Gram tables of the three
 // cost cases and the Lambda table (23 KB) are staged in LDS ONCE per workgroup and shared by its waves; every wave then
 // claims agents from a global queue (heaviest first when order_kernel ran) until it is empty, so a wave that finishes a
 // light agent immediately starts the next one and the launch ends when the LAST agent ends, not when the slowest
@@ -684,21 +684,39 @@ __global__ __launch_bounds__(512, 1) void dmpc_solve_persist_kernel(StepParams P
     // through one) is wave-uniform -- otherwise the solver's uniform branches are compiled as divergent ones
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     unsigned char *mine = (unsigned char *)__builtin_assume_aligned(dmpc_smem + PERSIST_TABLE_BYTES + (size_t)wave * P.lds_per_wave, 16);
-    // First round: queue position wave * #workgroups + workgroup, i.e. the heaviest #workgroups agents each get a CU
-    // (and a SIMD) of their own instead of sharing one with the next-heaviest; later rounds come from the counter.
-    const int first_round = (int)(gridDim.x * (blockDim.x >> 6));
-    int idx = wave * (int)gridDim.x + (int)blockIdx.x;
+    // The queue.  First round: position wave * #workgroups + workgroup, i.e. the heaviest #waves agents each get a wave (and
+    // the heaviest #workgroups a CU) of their own.  Later positions are claimed with TICKETS from one global counter.  An
+    // atomic on one address costs ~12 ns of serialised service on this part (51 200 single claims = 0.6 ms, measured: the
+    // launch could not end sooner whatever the solver did), and its result takes microseconds to arrive; so
+    //   * a ticket stands for one position where the agents are heavy (the #waves positions after the first round) and
+    //     where the launch ends (the last #waves positions: a fine-grained tail), and for 4 adjacent positions in between
+    //     (the light bulk): 3-4x fewer atomics, at most one light chunk of imbalance;
+    //   * the next ticket is claimed BEFORE the current agent is solved and read after it: its latency hides behind the solve.
+    const int nw = (int)(gridDim.x * (blockDim.x >> 6));
+    const int rest = total > nw ? total - nw : 0;
+    const int T1 = rest < nw ? rest : nw;
+    const int T3 = (rest - T1) < nw ? (rest - T1) : nw;
+    const int mid = rest - T1 - T3, T2 = (mid + 3) >> 2;
+    int pos = wave * (int)gridDim.x + (int)blockIdx.x, left = 0;
     for (;;) {
-        if (idx >= total) break;
+        if (pos >= total) break;
+        int tkv = 0;
+        if (P.counter && left == 0 && lane == 0) tkv = atomicAdd(P.counter, 1);
         // opaque copy of the lane id: keeps the compiler from hoisting the solver's per-lane constants out of this
         // loop (they would stay live across the whole body and push the kernel into scratch spills)
         int ln = lane;
         asm volatile("" : "+v"(ln));
-        solve_body<SOFT, QCAP, true>(P, ln, idx, total, mine, shtab);
+        solve_body<SOFT, QCAP, true>(P, ln, pos, total, mine, shtab);
         LSYNC();
-        int nxt = 0;
-        if (lane == 0) nxt = atomicAdd(P.counter, 1);
-        idx = first_round + __builtin_amdgcn_readfirstlane(nxt);
+        if (!P.counter) { pos += nw; continue; }   // static round-robin over the (sorted) queue (development)
+        if (left > 0) { pos++; left--; continue; }
+        const int t = __builtin_amdgcn_readfirstlane(tkv);
+        if (t < T1) pos = nw + t;
+        else if (t < T1 + T2) {
+            pos = nw + T1 + 4 * (t - T1);
+            const int end = nw + T1 + mid;
+            left = (end - pos < 4 ? end - pos : 4) - 1;
+        } else pos = nw + T1 + mid + (t - T1 - T2);
     }
 }
 

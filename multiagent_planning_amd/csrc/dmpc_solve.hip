@@ -27,11 +27,13 @@ struct SolveLds {   // offsets in doubles from the wave's LDS base
     static constexpr int T = 0;
     static constexpr int A = t_doubles(QCAP);
     static constexpr int W = A + 48;
-    static constexpr int Y = W + 48;
-    static constexpr int NU = Y + 48;
-    static constexpr int RR = NU + 48;
+    static constexpr int RR = W + 48;
     static constexpr int XS = RR + 64;
-    static constexpr int SVEC = XS + 64;
+    // slack-free variants: Y lives where x (the input of T'x) was, nu where r was -- both are dead by then; the slack
+    // bookkeeping of the soft variants still reads r after nu is written, so they keep separate vectors
+    static constexpr int Y = SOFT ? XS + 64 : XS;
+    static constexpr int NU = SOFT ? Y + 48 : RR;
+    static constexpr int SVEC = SOFT ? NU + 48 : XS + 64;
     static constexpr int SD = SVEC + 3 * QCAP;
     static constexpr int SLAM = SD + QCAP;
     static constexpr int SSS = SLAM + QCAP;
@@ -40,17 +42,58 @@ struct SolveLds {   // offsets in doubles from the wave's LDS base
     static constexpr int VAR = TAB + (PERSIST ? 0 : TAB_CASE_DOUBLES + TAB_L_DOUBLES + 1);   // r_eps (soft: nrmax doubles), r_fl (nrmax bytes)
 };
 
-#define DMPC_DPP_MAXF(v, CTRL, RM)                                                                                      \
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, RM, 0xf, false)))
+// wave-wide maximum of non-NaN floats: v_max_f32 with the DPP operand folded in (lanes without a source keep their
+// value), two wait states between a VALU write and the DPP read of the same register
 __device__ __forceinline__ float wave_max_f(float v)
 {
-    DMPC_DPP_MAXF(v, 0x111, 0xf);
-    DMPC_DPP_MAXF(v, 0x112, 0xf);
-    DMPC_DPP_MAXF(v, 0x114, 0xf);
-    DMPC_DPP_MAXF(v, 0x118, 0xf);
-    DMPC_DPP_MAXF(v, 0x142, 0xa);
-    DMPC_DPP_MAXF(v, 0x143, 0xc);
+    asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                 "s_nop 1" : "+v"(v));
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// Wave-wide sum / maximum of NON-NEGATIVE-identity reductions with bound_ctrl DPP moves: a lane without a source reads 0,
+// which is the identity of the sum (and of the maximum of non-negative values), so no identity register has to be
+// initialised per step (2 of the 5 instructions of a step in the generic form of dmpc_kernels.hip).  All rows take part in
+// the two row_bcast steps; lane 63 ends with (r3 + r2) + (r0 + r1).  Fixed order => bit-reproducible.
+template <int CTRL>
+__device__ __forceinline__ double dpp0_d(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum0(double v)
+{
+    v += dpp0_d<0x111>(v); v += dpp0_d<0x112>(v); v += dpp0_d<0x114>(v); v += dpp0_d<0x118>(v);
+    v += dpp0_d<0x142>(v); v += dpp0_d<0x143>(v);
+    return readlane_d(v, 63);
+}
+// v_max_f64 without the canonicalising self-maximum the compiler puts in front of fmax() (inputs are never NaN here)
+__device__ __forceinline__ double max_raw(double a, double b)
+{
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double wave_max0(double v)   // v >= 0 on every lane
+{
+    v = max_raw(v, dpp0_d<0x111>(v)); v = max_raw(v, dpp0_d<0x112>(v)); v = max_raw(v, dpp0_d<0x114>(v));
+    v = max_raw(v, dpp0_d<0x118>(v)); v = max_raw(v, dpp0_d<0x142>(v)); v = max_raw(v, dpp0_d<0x143>(v));
+    return readlane_d(v, 63);
+}
+
+// the kernel's StepParams argument as it lies in the kernel-argument segment (first and only argument of every solve kernel);
+// the empty asm keeps the compiler from recognising the pointer, so fields read through it are loaded where they are used
+__device__ __forceinline__ const StepParams *kernarg_params()
+{
+    const void *p = (const void *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return (const StepParams *)p;
 }
 
 // uniform description of one constraint
@@ -59,39 +102,42 @@ struct Cd {
     double v0, v1, v2, ss, d;
 };
 
-// y = T' x  (lane j gets y_j; 0 for j >= q).  x in the LDS vector xs (zero beyond q).
-template <int QCAP>
-__device__ __forceinline__ double t_tmul2(const double *Tp, const double *xs, int lane, int q)
+// y = T' x  (lane j gets y_j; 0 for j >= q).  x is the LDS vector at offset XOFF (zero beyond q).  Groups of 8 with one
+// lane mask per group; two FMA chains per group (half the dependent latency).
+template <int QCAP, int TOFF, int XOFF>
+__device__ __forceinline__ double t_tmul2(const double *B, int lane, int q)
 {
     double acc = 0.0;
-    const double *col = Tp + tcol(lane < QCAP ? lane : QCAP - 1);
+    const double *col = B + TOFF + tcol(lane < QCAP ? lane : QCAP - 1);
+    const double *xs = B + XOFF;
     for (int i0 = 0; i0 < q; i0 += 8) {
         double t[8], x[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) { t[u] = col[i0 + u]; x[u] = xs[i0 + u]; }
-        double g = 0.0;
+        double s0 = t[0] * x[0], s1 = t[1] * x[1];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) g = fma(t[u], x[u], g);
-        acc += (i0 <= lane) ? g : 0.0;
+        for (int u = 2; u < 8; u += 2) { s0 = fma(t[u], x[u], s0); s1 = fma(t[u + 1], x[u + 1], s1); }
+        acc += (i0 <= lane) ? (s0 + s1) : 0.0;
     }
     return (lane < q) ? acc : 0.0;
 }
 // y = T x  (lane i gets y_i; 0 for i >= q).  The 8 columns of group g hold rows 0 .. 8(g+1)-1 (zeros below the diagonal),
 // so a lane either owns the whole group or skips it; columns >= q only meet x_j = 0.
-template <int QCAP>
-__device__ __forceinline__ double t_mul2(const double *Tp, const double *xs, int lane, int q)
+template <int QCAP, int TOFF, int XOFF>
+__device__ __forceinline__ double t_mul2(const double *B, int lane, int q)
 {
     double acc = 0.0;
-    const double *row = Tp + lane;
+    const double *row = B + TOFF + lane;
+    const double *xs = B + XOFF;
     for (int j0 = 0; j0 < q; j0 += 8) {
         double t[8], x[8];
         const int c0 = tcol(j0), len = j0 + 9;
 #pragma unroll
         for (int u = 0; u < 8; ++u) { t[u] = row[c0 + u * len]; x[u] = xs[j0 + u]; }
-        double g = 0.0;
+        double s0 = t[0] * x[0], s1 = t[1] * x[1];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) g = fma(t[u], x[u], g);
-        acc += (lane < j0 + 8) ? g : 0.0;
+        for (int u = 2; u < 8; u += 2) { s0 = fma(t[u], x[u], s0); s1 = fma(t[u + 1], x[u + 1], s1); }
+        acc += (lane < j0 + 8) ? (s0 + s1) : 0.0;
     }
     return (lane < q) ? acc : 0.0;
 }
@@ -158,7 +204,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
 {
     using SL = SolveLds<SOFT, QCAP, PERSIST>;
     constexpr bool soft = SOFT;
-    const int S = P.S, C = P.C, nrmax = P.nrmax, var = P.variant;
+    const int nrmax = P.nrmax, var = P.variant;
     int vb = bidx;
     if (!PERSIST) {   // XCD-aware renumbering (see step_body)
         const int nb = nblocks, x = bidx & 7, y = bidx >> 3;
@@ -171,7 +217,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
     const int cl = P.c_first + ci;
     const int gid = scene * P.c_count + ci;
 
-    double *B = (double *)smem;
+    double *B = (double *)__builtin_assume_aligned(smem, 16);
     double *r_eps = B + SL::VAR;                                                   // soft variants: nrmax doubles
     unsigned char *r_fl = (unsigned char *)(B + SL::VAR + (soft ? nrmax : 0));     // nrmax bytes
     int *s_meta = (int *)(B + SL::META);
@@ -192,7 +238,6 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
         po[d] = P.x_p[3 * gid + d]; vo[d] = P.x_v[3 * gid + d];
         ao[d] = P.x_a[3 * gid + d]; pf[d] = P.pf[3 * gid + d];
     }
-    const double *lT_own = P.lT + ((size_t)(P.g_local * S + scene) * N3) * C + cl;
 
     // the scan's branch record
     int nr = hdr[0], status = hdr[3];
@@ -211,7 +256,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
     const double qw = ccase == 0 ? 1000.0 : (ccase == 1 ? 10000.0 : P.Q1);
     const double sw = ccase == 2 ? ((var == VAR_ALL3) ? 10.0 : P.S1) : 10.0;
     const double *G, *Lt;
-    if (PERSIST) { G = shtab + (size_t)ccase * TAB_CASE_DOUBLES; Lt = shtab + 3 * TAB_CASE_DOUBLES; }
+    if (PERSIST) { G = shtab + ccase * TAB_CASE_DOUBLES; Lt = shtab + 3 * TAB_CASE_DOUBLES; }
     else {
         const double *src = P.tables + (size_t)ccase * TAB_CASE_DOUBLES, *srcl = P.tables + 3 * TAB_CASE_DOUBLES;
         for (int i = lane; i < TAB_CASE_DOUBLES; i += 64) B[SL::TAB + i] = src[i];
@@ -248,19 +293,17 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
             const double LKk = 0.5 * P.h * P.h + (double)(K - 1 - k_l) * P.h * P.h;   // Lambda(K, k)
             f_l = -2.0 * qw * LKk * gax - ((k_l == 0) ? 2.0 * sw * ao_l : 0.0);
         }
-        dual = 0.5 * wave_sum(f_l * a_unc);
-        const double fabs_sum = wave_sum(fabs(f_l));
+        dual = 0.5 * wave_sum0(f_l * a_unc);
+        const double fabs_sum = wave_sum0(fabs(f_l));
         fbound = 1.5 * P.alim * P.alim * P.hsum[ccase] + P.alim * fabs_sum;
         fbound += 1e-6 * (fabs(fbound) + fabs(dual));
     }
 
     // per-lane constants of component (k_l, ax_l)
-    double p0_l = 0.0, whi_l = 0.0, wlo_l = 0.0, vo_l = 0.0;
+    double whi_l = 0.0, wlo_l = 0.0;
     float wbox_f = 0.f, wpos_f = 0.f;
     if (comp) {
-        vo_l = sel3(vo, ax_l);
-        const double sh = (double)(k_l + 1) * P.h * vo_l;
-        p0_l = sel3(po, ax_l) + sh;                              // A_initp(k,:) [po;vo]
+        const double sh = (double)(k_l + 1) * P.h * sel3(vo, ax_l);   // A_initp(k,:) [po;vo] - po
         whi_l = sel3(P.pmax, ax_l) - sel3(po, ax_l) - sh;        // pmax - A0 x0  (:72)
         wlo_l = sel3(P.pmin, ax_l) - sel3(po, ax_l) - sh;
         // pivot weights: the entering constraint is the one farthest from feasibility in the metric of the problem,
@@ -318,7 +361,10 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
             // bits 16..19 = membership of BOXHI | BOXLO | POSHI | POSLO; cm: collision slots that constrain step k_l
             unsigned cslot = 0x0000ffffu;
             unsigned long long cm = 0ull;
-            for (int i = lane; i < nr; i += 64) r_fl[i] = 0;
+            // working-set membership of the collision rows: slack-free variants keep the bits of the register-cached rows in
+            // a register of the owning lane (bit c = row lane + 64 c), the rest (and all flags of the soft variants) in LDS bytes
+            unsigned rcfl = 0;
+            for (int i = lane + (soft ? 0 : 64 * RC); i < nr; i += 64) r_fl[i] = 0;
             int rc = 0;   // 0 running/ok, 1 infeasible, 2 capacity, 3 itercap
             int iters = 0;
             a = a_unc; w = w_unc;
@@ -334,12 +380,12 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                 double nu = 0.0;
                 if (comp) {
                     const unsigned sb = cslot & 0xffu, sp = (cslot >> 8) & 0xffu;
-                    // slot 63 is never used (QCAP <= 48 ... 64 with r[63] = 0 only for QCAP < 64: guarded below)
-                    const double rb = B[SL::RR + (sb < 64u ? sb : 63u)], rp = B[SL::RR + (sp < 64u ? sp : 63u)];
-                    double U = pU, Y = pY;
-                    // BOXHI: vec = +e, BOXLO: vec = -e  (nu -= r * vec)
-                    U += (sb == 0xffu) ? 0.0 : ((cslot & 0x10000u) ? -rb : rb);
-                    Y += (sp == 0xffu) ? 0.0 : ((cslot & 0x40000u) ? -rp : rp);
+                    const double rb = B[SL::RR + (sb & 63u)], rp = B[SL::RR + (sp & 63u)];
+                    // BOXHI: vec = +e, BOXLO: vec = -e  (nu -= r * vec): sign from the member bits, 0 without a slot
+                    const double fb = (cslot & 0x10000u) ? -1.0 : ((cslot & 0x20000u) ? 1.0 : 0.0);
+                    const double fp = (cslot & 0x40000u) ? -1.0 : ((cslot & 0x80000u) ? 1.0 : 0.0);
+                    const double U = fma(fb, rb, pU);
+                    double Y = fma(fp, rp, pY);
                     unsigned long long m = cm;
                     while (__any(m != 0ull)) {
                         const bool have = m != 0ull;
@@ -351,11 +397,15 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                     B[SL::Y + lane] = Y;
                     LSYNC();
                     nu = U;
-                    double yv[K], lt[K];
 #pragma unroll
-                    for (int kk = 0; kk < K; ++kk) { yv[kk] = B[SL::Y + 3 * kk + ax_l]; lt[kk] = Lt[k_l * 15 + kk]; }
+                    for (int kg = 0; kg < 3; ++kg) {   // 10 loads in flight per group
+                        double yv[5], lt[5];
 #pragma unroll
-                    for (int kk = 0; kk < K; ++kk) nu = fma(lt[kk], yv[kk], nu);
+                        for (int u = 0; u < 5; ++u) { yv[u] = B[SL::Y + 3 * (5 * kg + u) + ax_l]; lt[u] = Lt[k_l * 15 + 5 * kg + u]; }
+#pragma unroll
+                        for (int u = 0; u < 5; ++u) nu = fma(lt[u], yv[u], nu);
+                    }
+                    LSYNC();   // (slack-free variants: nu overwrites r, Y overwrote x)
                     B[SL::NU + lane] = nu;
                     LSYNC();
                 }
@@ -462,7 +512,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                 for (int c = 0; c < RC; ++c) {   // rows held in registers
                     const int i = lane + 64 * c;
                     if (i < nr) {
-                        const int fl = r_fl[i], kc = rckc[c];
+                        const int fl = soft ? (int)r_fl[i] : (int)((rcfl >> c) & 1u), kc = rckc[c];
                         double v = -(rcx0[c] * B[SL::W + 3 * kc] + rcx1[c] * B[SL::W + 3 * kc + 1] + rcx2[c] * B[SL::W + 3 * kc + 2]) - rcb[c];
                         if (soft && (fl & RF_LIVE)) {
                             const double e = r_eps[i];
@@ -496,12 +546,12 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                     primal_fast();
                     for (int pass = 0; pass < 3; ++pass) {
                         const double rho = (lane < q) ? slot_value(lane) : 0.0;
-                        const double mx = wave_max(fabs(rho));
+                        const double mx = wave_max0(fabs(rho));
                         if (!(mx > 1e-13)) break;
                         B[SL::XS + lane] = rho; LSYNC();
-                        const double dvj = t_tmul2<QCAP>(B + SL::T, B + SL::XS, lane, q);
+                        const double dvj = t_tmul2<QCAP, SL::T, SL::XS>(B, lane, q);
                         B[SL::RR + lane] = dvj; LSYNC();
-                        const double ri = t_mul2<QCAP>(B + SL::T, B + SL::RR, lane, q);
+                        const double ri = t_mul2<QCAP, SL::T, SL::RR>(B, lane, q);
                         if (lane < q) B[SL::SLAM + lane] += ri;
                         LSYNC();
                         primal_fast();
@@ -557,7 +607,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                 const bool p_isA = p.ty < TY_POSHI;
                 // ---- inner loop: partial steps until p can be added
                 for (;;) {
-                    if (++iters > ITER_CAP) { rc = 3; break; }
+                    if (++iters > P.iter_cap) { rc = 3; break; }
                     // s = N_W' H^-1 n_p on the slot lanes
                     double sv = 0.0;
                     int mymeta = 0;
@@ -572,9 +622,9 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                         }
                     }
                     B[SL::XS + lane] = sv; LSYNC();
-                    const double dvj = t_tmul2<QCAP>(B + SL::T, B + SL::XS, lane, q);
+                    const double dvj = t_tmul2<QCAP, SL::T, SL::XS>(B, lane, q);
                     B[SL::RR + lane] = dvj; LSYNC();
-                    const double ri = t_mul2<QCAP>(B + SL::T, B + SL::RR, lane, q);
+                    const double ri = t_mul2<QCAP, SL::T, SL::RR>(B, lane, q);
                     LSYNC();
                     B[SL::RR + lane] = ri;
                     unsigned long long smk = 0ull;
@@ -608,13 +658,16 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                         if (owner) part += 0.5 * nue * nue;
                         if (p.si >= 0 && !p_row_has_slot && lane == 63) part += 0.5 * p.ss * p.ss;
                     }
-                    const double delta = wave_sum(part);
+                    const double delta = wave_sum0(part);
                     // more active constraints than variables is impossible: whatever round-off says, a constraint picked when
                     // the working set already spans all 45 + nlive variables is dependent
                     const bool dependent = !(delta > 1e-13 * spp) || q >= N3 + nlive;
                     const double t2 = dependent ? INFINITY : vp / delta;
-                    const double ratio = (lane < q && ri > 0.0) ? (B[SL::SLAM + lane] / ri) : INFINITY;
-                    const double t1 = wave_min(ratio);
+                    // ratio test on the multipliers: the blocking slot maximises r_j / lambda_j (identity 0: one bound_ctrl
+                    // DPP maximum instead of a minimum with an infinity identity); t1 = 1 / max
+                    const double iratio = (lane < q && ri > 0.0) ? (ri / B[SL::SLAM + lane]) : 0.0;
+                    const double imax = wave_max0(iratio);
+                    const double t1 = 1.0 / imax;   // inf when no multiplier decreases
                     const double t = fmin(t1, t2);
 #ifdef DMPC_DEV_TRACE
                     if (P.dbg && gid == P.dbg_agent && lane == 0 && iters <= P.dbg_cap) {
@@ -636,7 +689,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                             if (iters >= FARKAS_AFTER) {
                                 const double an = a - t * za;
                                 const double ga = g_l * an, gb = P.alim * fabs(g_l);
-                                if (wave_sum(ga - gb - 1e-6 * (fabs(ga) + gb)) > 0.0) { rc = 1; break; }
+                                if (wave_sum0(ga - gb - 1e-6 * (fabs(ga) + gb)) > 0.0) { rc = 1; break; }
                             }
                         }
                         vp -= t * delta;
@@ -659,7 +712,8 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                                 else cslot = (cslot & ~0xff00u) | ((unsigned)q << 8) | (p.ty == TY_POSHI ? 0x40000u : 0x80000u);
                             }
                         } else {
-                            if (lane == 0) {
+                            if (!soft && p.idx < 64 * RC) { if (lane == (p.idx & 63)) rcfl |= 1u << (p.idx >> 6); }
+                            else if (lane == 0) {
                                 const int bit = (p.ty == TY_COLL) ? RF_COLL : (p.ty == TY_SLKU ? RF_SLKU : RF_SLKL);
                                 r_fl[p.idx] |= bit;
                             }
@@ -671,14 +725,17 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                         break;
                     }
                     // partial step: drop the blocking constraint
-                    const unsigned long long bm = __ballot(lane < q && ri > 0.0 && ratio == t1);
+                    const unsigned long long bm = __ballot(lane < q && ri > 0.0 && iratio == imax);
                     const int l = __ffsll((long long)bm) - 1;
                     const int dmeta = s_meta[l];
                     const int dty = (dmeta >> 8) & 0xff, didx = dmeta >> 16;
                     LSYNC();
-                    if (dty >= TY_COLL && lane == 0) {
-                        const int bit = (dty == TY_COLL) ? RF_COLL : (dty == TY_SLKU ? RF_SLKU : RF_SLKL);
-                        r_fl[didx] &= ~bit;
+                    if (dty >= TY_COLL) {
+                        if (!soft && didx < 64 * RC) { if (lane == (didx & 63)) rcfl &= ~(1u << (didx >> 6)); }
+                        else if (lane == 0) {
+                            const int bit = (dty == TY_COLL) ? RF_COLL : (dty == TY_SLKU ? RF_SLKU : RF_SLKL);
+                            r_fl[didx] &= ~bit;
+                        }
                     }
                     remove_slot2<SOFT, QCAP, PERSIST>(B, lane, q, l, cslot, cm);
                     // de-instantiate the pin of a soft row whose collision row just left the set
@@ -740,23 +797,29 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
     }
 
     // ---------------------------------------------------------------- a9/a10: propagate, outputs
+    // The launch parameters the output stage needs are read again from the kernel-argument segment (scalar loads through an
+    // opaque pointer) instead of staying live in SGPRs across the solver loop, where they were spilled to VGPR lanes.
+    const StepParams &Q = *kernarg_params();
     int nslack = 0;
     if (solved) {
         status |= ST_SOLVED;
         if (soft) {
             int cnt = 0;
             for (int i = lane; i < nr; i += 64) cnt += (r_eps[i] < -1e-12) ? 1 : 0;
-            nslack = (int)wave_sum((double)cnt);
+            nslack = (int)wave_sum0((double)cnt);
         }
     }
     double p_out = 0.0, v_out = 0.0, a_out = 0.0;
     if (solved && comp) {
-        // p = A_p a + A_initp [po;vo] ; v = A_v a + vo   (propStatedmpc.m:3-4)
+        // p = A_p a + A_initp [po;vo] ; v = A_v a + vo   (propStatedmpc.m:3-4); the state is read again here instead of
+        // being kept in registers across the solve
+        const double po_l = Q.x_p[3 * gid + ax_l], vo_l = Q.x_v[3 * gid + ax_l];
+        const double p0_l = po_l + (double)(k_l + 1) * Q.h * vo_l;   // A_initp(k,:) [po;vo]
         p_out = w + p0_l;
         double sv = 0.0;
 #pragma unroll
         for (int kk = 0; kk < K; ++kk) { const double ak = B[SL::A + 3 * kk + ax_l]; sv += (kk <= k_l) ? ak : 0.0; }
-        v_out = P.h * sv + vo_l;
+        v_out = Q.h * sv + vo_l;
         a_out = a;
     }
     if (solved) {
@@ -765,20 +828,25 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
         if (ob_check) {   // is_inbounds.m:2-5 on p(:,1)
             const double tolb = 50e-3;
             bool bad = false;
-            if (lane < 3) bad = !(p_out < sel3(P.pmax, lane) + tolb) || !(p_out > sel3(P.pmin, lane) - tolb);
+            if (lane < 3) bad = !(p_out < sel3(Q.pmax, lane) + tolb) || !(p_out > sel3(Q.pmin, lane) - tolb);
             if (__any(bad)) status |= ST_OUTBOUND;
         }
     }
     if (comp) {
-        P.p_out[(size_t)gid * N3 + lane] = p_out;
-        P.v_out[(size_t)gid * N3 + lane] = v_out;
-        P.a_out[(size_t)gid * N3 + lane] = a_out;
-        if (P.lT_next) P.lT_next[((size_t)scene * N3 + lane) * C + cl] = solved ? p_out : lT_own[(size_t)lane * C];
+        Q.p_out[(size_t)gid * N3 + lane] = p_out;
+        Q.v_out[(size_t)gid * N3 + lane] = v_out;
+        Q.a_out[(size_t)gid * N3 + lane] = a_out;
+        if (Q.lT_next) {
+            // next table chunk [S][3K][C]: uniform 64-bit base, 32-bit per-lane offset; unsolved agents keep their old prediction
+            const int Cq = Q.C;
+            const double *own = Q.lT + ((size_t)(Q.g_local * Q.S + scene) * N3) * Cq + cl;
+            Q.lT_next[(size_t)scene * N3 * Cq + cl + (size_t)(unsigned)(lane * Cq)] = solved ? p_out : own[(size_t)(unsigned)(lane * Cq)];
+        }
     }
     if (lane == 0) {
-        P.status[gid] = status;
-        if (P.info) {
-            int *inf = P.info + (size_t)gid * 8;
+        Q.status[gid] = status;
+        if (Q.info) {
+            int *inf = Q.info + (size_t)gid * 8;
             inf[0] = viol_k; inf[1] = nrows_built; inf[2] = tries; inf[3] = ccase;
             inf[4] = iters_total; inf[5] = nslack; inf[6] = solved ? q : 0; inf[7] = maxq;
         }
