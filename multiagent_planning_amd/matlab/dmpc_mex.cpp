@@ -1,7 +1,8 @@
 // dmpc_mex.cpp -- MEX gateway binding libdmpc_hip.so (include/dmpc_hip.h) into MATLAB.
 //
-// Build on a MATLAB host (mex.h is NOT available in the build container, so this file is compiled
-// there, not here):   mex -I../../include dmpc_mex.cpp -L.. -ldmpc_hip
+// Build on a MATLAB host:   mex -I../../include dmpc_mex.cpp -L.. -ldmpc_hip
+// (MATLAB's mex.h is not in the build container; there the gateway is compiled and EXECUTED against the mock MEX runtime
+// of tests/mock_mex/ -- tests/test_mex_gateway.py.)
 //
 // One gateway, dispatched on a command string, keeps ONE persistent context per parameter set:
 //   [p,v,a,status,info] = dmpc_mex('solve_one', params, l, n, po, vo, ao, pf)
@@ -10,6 +11,14 @@
 //   [Lambda,Av,A0,Delta] = dmpc_mex('model_matrices', params)
 //   [Ain,bin,dist] = dmpc_mex('coll_rows', params, l, sel0, k_cmp0, k_blk0, p, a0, rmin, c, A)     (0-based indices)
 //   [Ain,bin]      = dmpc_mex('add_coll_constr', params, p, po, rmin, c, A)
+//   Aaug           = dmpc_mex('posvel_matrix', params)                                  getPosVelMat.m (12 x 3K)
+//   [p,v,a]        = dmpc_mex('init_batch', params, po, pf)                             initDMPC.m for N agents (3 x K x N each)
+//   [p,v]          = dmpc_mex('prop_state', params, A_p, A_v, A_initp|[], po, vo, a)    propStatedmpc.m / dec-iSCP propState.m
+//   [xi,rhs,dist,kc,viol_k,coll] = dmpc_mex('rows_one', params, l, n, po, vo)           CheckCollSoftDMPC + CollConstr*DMPC rows
+//   Ain            = dmpc_mex('rows_dense', params, xi, kc, A)                          -diff_mat*A of structured rows
+//   [pk,vk,ak,K_T_used,scene_status] = dmpc_mex('transition', params, po, pf, K_T_max, error_tol)   the whole k-loop on the GPU
+//   [po,pf]        = dmpc_mex('random_test', params, N, pmin, pmax, rmin, c, seed)      randomTest.m
+//   [po,pf]        = dmpc_mex('random_exchange', params, N, pmin, pmax, rmin, seed)     randomExchange.m
 // `params` is a struct with the fields of dmpc_params (variant as the DMPC_VAR_* integer).
 // The signature-preserving wrappers (solveSoftDMPCbound.m, ...) in this directory call 'solve_one'
 // and convert status bits into the reference's [] + flag conventions.
@@ -77,6 +86,13 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
         // .m wrappers undo (Lambda, A_v, Delta) / A0 is created 6 x 3K and transposed there
         dmpc_model_matrices(&p, mxGetPr(plhs[0]), mxGetPr(Av), mxGetPr(A0), mxGetPr(Dl));
         if (nlhs > 1) plhs[1] = Av; if (nlhs > 2) plhs[2] = A0; if (nlhs > 3) plhs[3] = Dl;
+        return;
+    }
+    if (!std::strcmp(cmd, "posvel_matrix")) {   // getPosVelMat.m:24 (host computation)
+        mxArray *t = mxCreateDoubleMatrix(n3, 12, mxREAL);   // row-major 12 x 3K == column-major 3K x 12
+        dmpc_posvel_matrix(p.h, p.K, mxGetPr(t));
+        plhs[0] = mxCreateDoubleMatrix(12, n3, mxREAL);
+        for (int i = 0; i < 12; ++i) for (int j = 0; j < n3; ++j) mxGetPr(plhs[0])[i + 12 * j] = mxGetPr(t)[(size_t)i * n3 + j];
         return;
     }
     dmpc_ctx *ctx = context(p);
@@ -176,6 +192,107 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
                                  mxGetPr(prhs[6]), ncols, 1, 3 * K * N, mxGetPr(plhs[0]), 1, (int64_t)nrows, mxGetPr(b)))
             mexErrMsgIdAndTxt("dmpc:add_coll_constr", "%s", dmpc_last_error(ctx));
         if (nlhs > 1) plhs[1] = b;
+        return;
+    }
+    if (!std::strcmp(cmd, "init_batch")) {   // initDMPC.m:1-13 for every agent of one scene
+        need(nrhs == 4, "init_batch: (cmd, params, po, pf)");
+        const int N = (int)(mxGetNumberOfElements(prhs[2]) / 3);
+        need(N >= 1 && mxGetNumberOfElements(prhs[2]) == (size_t)3 * N && mxGetNumberOfElements(prhs[3]) == (size_t)3 * N, "po, pf must be 3 x N");
+        const mwSize d3[3] = {3, (mwSize)p.K, (mwSize)N};
+        plhs[0] = mxCreateNumericArray(3, d3, mxDOUBLE_CLASS, mxREAL);
+        mxArray *v = mxCreateNumericArray(3, d3, mxDOUBLE_CLASS, mxREAL), *a = mxCreateNumericArray(3, d3, mxDOUBLE_CLASS, mxREAL);
+        if (dmpc_init_batch(ctx, 1, N, mxGetPr(prhs[2]), mxGetPr(prhs[3]), mxGetPr(plhs[0]), mxGetPr(v), mxGetPr(a)))
+            mexErrMsgIdAndTxt("dmpc:init", "%s", dmpc_last_error(ctx));
+        if (nlhs > 1) plhs[1] = v; if (nlhs > 2) plhs[2] = a;
+        return;
+    }
+    if (!std::strcmp(cmd, "prop_state")) {   // propStatedmpc.m:1-8 (A_initp given) / dec-iSCP/propState.m:1-10 (A_initp = [])
+        need(nrhs == 8, "prop_state: (cmd, params, A_p, A_v, A_initp, po, vo, a)");
+        const int rows = (int)mxGetM(prhs[2]), cols = (int)mxGetN(prhs[2]);
+        need((int)mxGetM(prhs[3]) == rows && (int)mxGetN(prhs[3]) == cols, "A_p, A_v must have the same shape");
+        need((int)mxGetNumberOfElements(prhs[7]) == cols, "a must have one element per column of A_p");
+        const bool with_init = mxGetNumberOfElements(prhs[4]) > 0;
+        if (with_init) need((int)mxGetM(prhs[4]) == rows && (int)mxGetN(prhs[4]) == 6, "A_initp must be rows x 6");
+        // the C ABI takes row-major matrices: transpose the column-major MATLAB operands
+        std::string buf((size_t)(2 * rows * cols + rows * 6) * sizeof(double), '\0');
+        double *Ap = (double *)&buf[0], *Av = Ap + (size_t)rows * cols, *A0 = Av + (size_t)rows * cols;
+        const double *mp = mxGetPr(prhs[2]), *mv = mxGetPr(prhs[3]);
+        for (int i = 0; i < rows; ++i)
+            for (int j = 0; j < cols; ++j) { Ap[(size_t)i * cols + j] = mp[i + (size_t)j * rows]; Av[(size_t)i * cols + j] = mv[i + (size_t)j * rows]; }
+        if (with_init) { const double *m0 = mxGetPr(prhs[4]); for (int i = 0; i < rows; ++i) for (int j = 0; j < 6; ++j) A0[i * 6 + j] = m0[i + (size_t)j * rows]; }
+        plhs[0] = mxCreateDoubleMatrix(rows, 1, mxREAL);
+        mxArray *v = mxCreateDoubleMatrix(rows, 1, mxREAL);
+        const double *po = mxGetPr(prhs[5]), *vo = mxGetPr(prhs[6]);
+        // propStatedmpc: v = A_v a + repmat(vo); propState: p = A_p a + repmat(po), v = A_v a
+        if (dmpc_prop_state(ctx, rows, cols, Ap, Av, with_init ? A0 : nullptr, with_init ? po : nullptr, with_init ? vo : nullptr,
+                            with_init ? nullptr : po, with_init ? vo : nullptr, mxGetPr(prhs[7]), mxGetPr(plhs[0]), mxGetPr(v)))
+            mexErrMsgIdAndTxt("dmpc:prop_state", "%s", dmpc_last_error(ctx));
+        if (nlhs > 1) plhs[1] = v;
+        return;
+    }
+    if (!std::strcmp(cmd, "rows_one")) {   // CheckCollSoftDMPC.m + CollConstr*DMPC.m of the context's variant, structured rows
+        need(nrhs == 6, "rows_one: (cmd, params, l, n, po, vo)");
+        const mwSize *dl = mxGetDimensions(prhs[2]);
+        need(mxGetNumberOfDimensions(prhs[2]) == 3 && dl[0] == 3 && (int)dl[1] == p.K, "l must be 3 x K x N");
+        const int N = (int)dl[2], n = (int)mxGetScalar(prhs[3]);
+        const int cap = (p.variant == DMPC_VAR_HARD ? p.K : (p.variant == DMPC_VAR_ALL3 ? 3 : 1)) * (N > 1 ? N - 1 : 1);
+        std::string buf((size_t)cap * (5 * sizeof(double) + sizeof(int32_t)) + 8, '\0');
+        double *xi = (double *)&buf[0], *rhs = xi + (size_t)3 * cap, *sc = rhs + cap;
+        int32_t *kc = (int32_t *)(sc + cap), nr = 0, vk = 0, st = 0;
+        if (dmpc_rows_one(ctx, N, n - 1, mxGetPr(prhs[2]), mxGetPr(prhs[4]), mxGetPr(prhs[5]), cap, xi, rhs, sc, kc, &nr, &vk, &st))
+            mexErrMsgIdAndTxt("dmpc:rows", "%s", dmpc_last_error(ctx));
+        const int m = nr < cap ? nr : cap;
+        plhs[0] = mxCreateDoubleMatrix(3, m, mxREAL);
+        std::memcpy(mxGetPr(plhs[0]), xi, (size_t)3 * m * sizeof(double));
+        mxArray *b = mxCreateDoubleMatrix(m, 1, mxREAL), *d = mxCreateDoubleMatrix(m, 1, mxREAL), *k = mxCreateDoubleMatrix(m, 1, mxREAL);
+        for (int i = 0; i < m; ++i) { mxGetPr(b)[i] = rhs[i]; mxGetPr(d)[i] = sc[i]; mxGetPr(k)[i] = (double)kc[i]; }
+        if (nlhs > 1) plhs[1] = b; if (nlhs > 2) plhs[2] = d; if (nlhs > 3) plhs[3] = k;
+        if (nlhs > 4) plhs[4] = mxCreateDoubleScalar((double)vk);
+        if (nlhs > 5) plhs[5] = mxCreateDoubleScalar((double)((st & DMPC_ST_COLL) != 0));
+        return;
+    }
+    if (!std::strcmp(cmd, "rows_dense")) {   // Ain_total(idx,:) = -diff_mat*Ain (CollConstrSoftDMPC.m:24-27)
+        need(nrhs == 5, "rows_dense: (cmd, params, xi, kc, A)");
+        const int nr = (int)mxGetNumberOfElements(prhs[3]);
+        need((int)mxGetNumberOfElements(prhs[2]) == 3 * nr, "xi must be 3 x nr");
+        const int a_rows = (int)mxGetM(prhs[4]), ncols = (int)mxGetN(prhs[4]);
+        std::string kb((size_t)nr * sizeof(int32_t) + 4, '\0');
+        int32_t *kc = (int32_t *)&kb[0];
+        for (int i = 0; i < nr; ++i) kc[i] = (int32_t)mxGetPr(prhs[3])[i];
+        plhs[0] = mxCreateDoubleMatrix(nr, ncols, mxREAL);
+        if (nr > 0 && dmpc_rows_dense(ctx, nr, mxGetPr(prhs[2]), kc, mxGetPr(prhs[4]), a_rows, ncols, 1, a_rows, mxGetPr(plhs[0]), 1, nr))
+            mexErrMsgIdAndTxt("dmpc:rows_dense", "%s", dmpc_last_error(ctx));
+        return;
+    }
+    if (!std::strcmp(cmd, "transition")) {   // the whole `for k = 1:K_T` loop (dmpc_soft_bound.m:115-148) of one trial
+        need(nrhs == 6, "transition: (cmd, params, po, pf, K_T_max, error_tol)");
+        const int N = (int)(mxGetNumberOfElements(prhs[2]) / 3), KT = (int)mxGetScalar(prhs[4]);
+        need(N >= 1 && mxGetNumberOfElements(prhs[3]) == (size_t)3 * N && KT >= 2, "po, pf must be 3 x N, K_T_max >= 2");
+        const mwSize d3[3] = {3, (mwSize)KT, (mwSize)N};
+        plhs[0] = mxCreateNumericArray(3, d3, mxDOUBLE_CLASS, mxREAL);
+        mxArray *v = mxCreateNumericArray(3, d3, mxDOUBLE_CLASS, mxREAL), *a = mxCreateNumericArray(3, d3, mxDOUBLE_CLASS, mxREAL);
+        int32_t used = 0, sst = 0;
+        if (dmpc_transition(ctx, 1, N, mxGetPr(prhs[2]), mxGetPr(prhs[3]), KT, mxGetScalar(prhs[5]), mxGetPr(plhs[0]), mxGetPr(v),
+                            mxGetPr(a), &used, &sst))
+            mexErrMsgIdAndTxt("dmpc:transition", "%s", dmpc_last_error(ctx));
+        if (nlhs > 1) plhs[1] = v; if (nlhs > 2) plhs[2] = a;
+        if (nlhs > 3) plhs[3] = mxCreateDoubleScalar((double)used);
+        if (nlhs > 4) plhs[4] = mxCreateDoubleScalar((double)sst);
+        return;
+    }
+    if (!std::strcmp(cmd, "random_test") || !std::strcmp(cmd, "random_exchange")) {   // randomTest.m / randomExchange.m
+        const bool ex = cmd[7] == 'e';
+        need(nrhs == (ex ? 7 : 8), ex ? "random_exchange: (cmd, params, N, pmin, pmax, rmin, seed)" : "random_test: (cmd, params, N, pmin, pmax, rmin, c, seed)");
+        const int N = (int)mxGetScalar(prhs[2]);
+        need(N >= 1 && mxGetNumberOfElements(prhs[3]) == 3 && mxGetNumberOfElements(prhs[4]) == 3, "pmin, pmax must have 3 elements");
+        plhs[0] = mxCreateDoubleMatrix(3, N, mxREAL);
+        mxArray *pf = mxCreateDoubleMatrix(3, N, mxREAL);
+        const int rc = ex ? dmpc_random_exchange(ctx, 1, N, mxGetPr(prhs[3]), mxGetPr(prhs[4]), mxGetScalar(prhs[5]), (uint64_t)mxGetScalar(prhs[6]),
+                                                 mxGetPr(plhs[0]), mxGetPr(pf))
+                          : dmpc_random_test(ctx, 1, N, mxGetPr(prhs[3]), mxGetPr(prhs[4]), mxGetScalar(prhs[5]), mxGetScalar(prhs[6]),
+                                             (uint64_t)mxGetScalar(prhs[7]), mxGetPr(plhs[0]), mxGetPr(pf));
+        if (rc) mexErrMsgIdAndTxt("dmpc:random", "%s", dmpc_last_error(ctx));
+        if (nlhs > 1) plhs[1] = pf;
         return;
     }
     mexErrMsgIdAndTxt("dmpc:cmd", "unknown command %s", cmd);

@@ -9,6 +9,7 @@
  */
 #include "dmpc_oracle.h"
 
+#include <malloc.h>
 #include <math.h>
 #include <pthread.h>
 #include <stdlib.h>
@@ -947,4 +948,58 @@ out:
     free(R.G); free(R.b); free(R.dist);
     ctx_free(c);
     return rc;
+}
+
+/* CPU baseline helper (bench.py, cpu_baseline leg): S independent scenes of N agents each, SCENE-parallel -- thread t solves
+ * scenes t, t + T, ... with its own context (the scenes of a batch are independent problems, so this is how a host would
+ * run a Monte-Carlo batch; the reference's own agent-cluster threads inside one scene, dmpc.cpp:1600-1625, are orc_step's
+ * nthreads).  Arrays are [S][N][...] as in orc_step. */
+typedef struct {
+    const orc_params *prm;
+    int S, N, t, T;
+    const double *l, *x_p, *x_v, *x_a, *pf;
+    double *p, *v, *a;
+    int *status, *info;
+} swork_t;
+
+static void *scene_worker(void *arg)
+{
+    swork_t *w = (swork_t *)arg;
+    ctx_t *c = ctx_new(w->prm->h, w->prm->K);
+    const int n3 = c->n3, N = w->N;
+    for (int s = w->t; s < w->S; s += w->T) {
+        const size_t o3 = (size_t)s * N * 3, o45 = (size_t)s * N * n3;
+        for (int i = 0; i < N; ++i)
+            w->status[(size_t)s * N + i] =
+                solve_ctx(c, w->prm, N, i, w->l + o45, &w->x_p[o3 + 3 * i], &w->x_v[o3 + 3 * i], &w->x_a[o3 + 3 * i], &w->pf[o3 + 3 * i],
+                          &w->p[o45 + (size_t)i * n3], &w->v[o45 + (size_t)i * n3], &w->a[o45 + (size_t)i * n3],
+                          w->info ? &w->info[((size_t)s * N + i) * ORC_INFO_LEN] : NULL, NULL);
+    }
+    ctx_free(c);
+    return NULL;
+}
+
+int orc_step_scenes(const orc_params *prm, int S, int N, const double *l, const double *x_p, const double *x_v, const double *x_a,
+                    const double *pf, double *p, double *v, double *a, int *status, int *info, int nthreads)
+{
+    if (prm->order != 2 || prm->K < 1 || prm->K > MAXK || S < 1) return -1;
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > S) nthreads = S;
+    /* the dense QP of every solve is allocated and freed (as the reference's scripts do): keep those blocks in the per-thread
+     * heap arenas instead of mmap/munmap per solve, which serialises all threads on the process's memory-map lock */
+    mallopt(M_MMAP_THRESHOLD, 1 << 28);
+    mallopt(M_TRIM_THRESHOLD, 1 << 29);
+    swork_t *w = (swork_t *)calloc(nthreads, sizeof(swork_t));
+    pthread_t *th = (pthread_t *)calloc(nthreads, sizeof(pthread_t));
+    for (int t = 0; t < nthreads; ++t) {
+        swork_t ww = {prm, S, N, t, nthreads, l, x_p, x_v, x_a, pf, p, v, a, status, info};
+        w[t] = ww;
+    }
+    if (nthreads == 1) scene_worker(&w[0]);
+    else {
+        for (int t = 0; t < nthreads; ++t) pthread_create(&th[t], NULL, scene_worker, &w[t]);
+        for (int t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
+    }
+    free(w); free(th);
+    return 0;
 }

@@ -104,6 +104,10 @@ int orc_assemble_one(const orc_params *prm, int N, int n, const double *l, const
                      const double ao[3], const double pf[3], int level, int *n_out, int *m_out, int *ncoll_out,
                      double *H, double *f, double *C, double *d);
 
+/* S independent scenes of N agents, scene-parallel over nthreads host threads (the CPU baseline of bench.py) */
+int orc_step_scenes(const orc_params *prm, int S, int N, const double *l, const double *x_p, const double *x_v, const double *x_a,
+                    const double *pf, double *p, double *v, double *a, int *status, int *info, int nthreads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -57,6 +57,7 @@ def lib(path=None):
         L.orc_rows_one.argtypes = [C.POINTER(Params), C.c_int, C.c_int, dp, dp, dp, C.c_int, dp, dp, dp, ip, ip, ip]
         L.orc_qp_dense.argtypes = [C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, ip]
         L.orc_assemble_one.argtypes = [C.POINTER(Params), C.c_int, C.c_int, dp, dp, dp, dp, dp, C.c_int, ip, ip, ip, dp, dp, dp, dp]
+        L.orc_step_scenes.argtypes = [C.POINTER(Params), C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, dp, dp, ip, ip, C.c_int]
         if path is not None:
             return L
         _lib = L
@@ -173,3 +174,17 @@ def assemble_one(prm, l, n, po, vo, ao, pf, level=0):
     lib().orc_assemble_one(C.byref(prm), l.shape[0], n, _dp(l), _dp(po), _dp(vo), _dp(ao), _dp(pf), level,
                            C.byref(nn), C.byref(mm), C.byref(nc), _dp(H), _dp(f), _dp(Cm), _dp(d))
     return dict(H=H, f=f, C=Cm, d=d, ncoll=nc.value)
+
+
+def step_scenes(prm, l, x_p, x_v, x_a, pf, nthreads=1):
+    """S independent scenes ([S,N,...] arrays), scene-parallel over `nthreads` host threads (bench.py's CPU baseline)."""
+    l, x_p, x_v, x_a, pf = _f(l), _f(x_p), _f(x_v), _f(x_a), _f(pf)
+    S, N = l.shape[0], l.shape[1]
+    n3 = 3 * prm.K
+    p, v, a = np.zeros((S, N, n3)), np.zeros((S, N, n3)), np.zeros((S, N, n3))
+    status = np.zeros((S, N), dtype=np.int32)
+    info = np.zeros((S, N, INFO_LEN), dtype=np.int32)
+    rc = lib().orc_step_scenes(C.byref(prm), S, N, _dp(l), _dp(x_p), _dp(x_v), _dp(x_a), _dp(pf), _dp(p), _dp(v), _dp(a),
+                               _ip(status), _ip(info), nthreads)
+    assert rc == 0
+    return dict(status=status, p=p, v=v, a=a, info=info)
