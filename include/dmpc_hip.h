@@ -16,8 +16,10 @@
  *   - return value: 0 = ok, <0 = API/runtime error (text via dmpc_last_error); numerical
  *     outcomes are reported per agent in status[] (DMPC_ST_* bits) and info[] (DMPC_I_*).
  *   - entry points are synchronous unless noted; one HIP stream per context; a context may be
- *     used from one host thread at a time, distinct contexts are independent
- *     (dmpc/cpp/cluster_test.cpp:40 runs up to 10 solver threads).
+ *     used from one host thread at a time and has ONE step in flight at a time (the *_device entry
+ *     points share per-context scratch: do not issue them on two streams of one context
+ *     concurrently); distinct contexts are independent (dmpc/cpp/cluster_test.cpp:40 runs up to
+ *     10 solver threads).
  */
 #ifndef DMPC_HIP_H
 #define DMPC_HIP_H
@@ -178,6 +180,38 @@ int dmpc_advance_device(dmpc_ctx *ctx, int count, const double *p_out, const dou
 int dmpc_transition(dmpc_ctx *ctx, int S, int N, const double *po, const double *pf, int K_T_max,
                     double error_tol, double *pk, double *vk, double *ak, int32_t *K_T_used,
                     int32_t *scene_status);
+
+/* Multi-GPU: the agents of every scene sharded over the GPUs of one node, ONE PROCESS (rank) PER GPU, each with its own
+ * context.  Replaces the thread clusters of DMPC::solveParallelDMPCv2 (dmpc/cpp/dmpc.cpp:1570-1686): contiguous agent ranges,
+ * N/G each, the first N mod G one more (:1600-1625; dmpc_partition), every cluster reading the previous predictions of all
+ * agents (`prev_obs = obs` after the join, :1671-1681; `l = new_l`, dmpc/matlab/dmpc_soft_bound.m:146).  The join is one
+ * RCCL all-gather over xGMI per MPC step on the context's stream, the termination test (ReachedGoal.m / the abort of
+ * test/failure_rate.m:112-125) a second tiny one grouped with it.
+ *   dmpc_comm_unique_id   rank 0: a 128-byte id (ncclGetUniqueId) to hand to every rank by any out-of-band means
+ *   dmpc_comm_init        every rank: joins the communicator (ncclCommInitRank on the context's device); nranks = 1 works
+ *   dmpc_comm_destroy     leaves it (dmpc_destroy does this too)
+ * A context without a communicator behaves as rank 0 of 1 (the exchange is a device copy).
+ * Table layout for N agents on G ranks: lT[G][S][3K][Cmax], Cmax = ceil(N/G); the last column of the chunks of the short
+ * ranks is padding that is never read. */
+int dmpc_partition(int N, int G, int rank, int32_t *lo, int32_t *count, int32_t *cmax);
+int dmpc_comm_unique_id(char *id128);
+int dmpc_comm_init(dmpc_ctx *ctx, const char *id128, int nranks, int rank);
+int dmpc_comm_destroy(dmpc_ctx *ctx);
+
+/* One MPC step of this rank's agents + the exchange (cluster_solvev2 + the join, dmpc.cpp:1656-1686,1792-1841).  Device
+ * pointers, asynchronous on `stream`: x_p, x_v, x_a, pf: [S][count][3] and p_out, v_out, a_out: [S][count][3K] of this
+ * rank's `count` agents (dmpc_partition); lT, lT_next: the whole table [G][S][3K][Cmax] before / after the step -- every
+ * rank's new predictions arrive in its slot of lT_next by the all-gather.  status [S][count], info [S][count][8] or NULL. */
+int dmpc_step_sharded_device(dmpc_ctx *ctx, int S, int N, const double *lT, const double *x_p, const double *x_v,
+                             const double *x_a, const double *pf, double *p_out, double *v_out, double *a_out,
+                             double *lT_next, int32_t *status, int32_t *info, void *stream);
+
+/* The whole transition (dmpc_transition) sharded: every rank passes the SAME start/goal sets po, pf [S][N][3] (host) and gets
+ * the histories pk, vk, ak [S][count][K_T_max][3] of ITS agents (or NULL), and the same K_T_used[S] / scene_status[S] as the
+ * other ranks (a scene stops on every rank at the step where any agent of any rank fails or all agents reached their
+ * goals: the rule of dmpc_transition).  Results do not depend on the number of ranks (bit for bit). */
+int dmpc_transition_sharded(dmpc_ctx *ctx, int S, int N, const double *po, const double *pf, int K_T_max, double error_tol,
+                            double *pk, double *vk, double *ak, int32_t *K_T_used, int32_t *scene_status);
 
 /* f-1: the post-checks the reference runs after every transition -- test/failure_rate.m:136-195 (identical
  * blocks: test/comp_kctr.m:141-205, test/comp_hardsoft2.m:140-204, dmpc/matlab/dmpc_soft_bound.m:152-190):

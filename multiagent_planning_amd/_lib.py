@@ -28,6 +28,8 @@ ABI_SYMBOLS = [
     "dmpc_coll_rows", "dmpc_coll_rows_device", "dmpc_add_coll_constr", "dmpc_add_coll_constr_device",
     "dmpc_trajectories2file", "dmpc_test2file", "dmpc_random_test", "dmpc_random_exchange", "dmpc_random_sets_device",
     "dmpc_prop_state", "dmpc_is_inbounds", "dmpc_reached_goal", "dmpc_rows_dense",
+    "dmpc_partition", "dmpc_comm_unique_id", "dmpc_comm_init", "dmpc_comm_destroy", "dmpc_step_sharded_device",
+    "dmpc_transition_sharded",
 ]
 
 
@@ -102,6 +104,12 @@ def load():
     L.dmpc_reached_goal.argtypes = [vp, C.c_int, dp, dp, C.c_double, ip]
     L.dmpc_postcheck.argtypes = [vp, C.c_int, C.c_int, C.c_int, ip, ip, dp, dp, dp, dp, C.c_double, C.c_double, C.c_double,
                                  dp, dp, ip, dp, ip, dp, dp, dp, C.c_int]
+    L.dmpc_partition.argtypes = [C.c_int, C.c_int, C.c_int, ip, ip, ip]
+    L.dmpc_comm_unique_id.argtypes = [C.c_char_p]
+    L.dmpc_comm_init.argtypes = [vp, C.c_char_p, C.c_int, C.c_int]
+    L.dmpc_comm_destroy.argtypes = [vp]
+    L.dmpc_step_sharded_device.argtypes = [vp, C.c_int, C.c_int] + [vp] * 12
+    L.dmpc_transition_sharded.argtypes = [vp, C.c_int, C.c_int, dp, dp, C.c_int, C.c_double, dp, dp, dp, ip, ip]
     L.dmpc_solve_count.restype = C.c_int64
     L.dmpc_solve_count.argtypes = [vp]
     L.dmpc_profile.argtypes = [vp, C.c_int]
@@ -158,6 +166,14 @@ def posvel_matrix(h, K):
     if L.dmpc_posvel_matrix(float(h), int(K), _dp(A)) != 0:
         raise DmpcError(L.dmpc_last_error(None).decode())
     return A
+
+
+def partition(N, G, rank):
+    """(lo, count, cmax) of rank's contiguous cluster (dmpc/cpp/dmpc.cpp:1600-1625; dmpc_partition of the C ABI: host arithmetic)"""
+    lo, cnt, cmax = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    if load().dmpc_partition(int(N), int(G), int(rank), C.byref(lo), C.byref(cnt), C.byref(cmax)):
+        raise DmpcError(load().dmpc_last_error(None).decode())
+    return lo.value, cnt.value, cmax.value
 
 
 class Dmpc:
@@ -249,6 +265,42 @@ class Dmpc:
         self._chk(self._L.dmpc_transition(self._ctx, S, N, _dp(po), _dp(pf), int(K_T_max), float(error_tol), hp[0], hp[1], hp[2],
                                           _ip(used), _ip(sst)))
         return dict(pk=pk, vk=vk, ak=ak, K_T_used=used, scene_status=sst)
+
+    # ---- multi-GPU (one process per GPU): dmpc_multigpu.hip ----
+    @staticmethod
+    def comm_unique_id():
+        """rank 0: the 128-byte RCCL id every rank passes to comm_init (hand it over by any out-of-band means)"""
+        buf = C.create_string_buffer(128)
+        if load().dmpc_comm_unique_id(buf):
+            raise DmpcError(load().dmpc_last_error(None).decode())
+        return buf.raw
+
+    def comm_init(self, id128, nranks, rank):
+        self._chk(self._L.dmpc_comm_init(self._ctx, bytes(id128), int(nranks), int(rank)))
+        self.nranks, self.rank = int(nranks), int(rank)
+
+    def comm_destroy(self):
+        self._L.dmpc_comm_destroy(self._ctx)
+        self.nranks, self.rank = 1, 0
+
+    def step_sharded_device(self, S, N, lT, x_p, x_v, x_a, pf, p_out, v_out, a_out, lT_next, status, info, stream=0):
+        self._chk(self._L.dmpc_step_sharded_device(self._ctx, S, N, lT, x_p, x_v, x_a, pf, p_out, v_out, a_out, lT_next, status, info, stream))
+
+    def transition_sharded(self, po, pf, K_T_max, error_tol=0.01, histories=True):
+        """dmpc_transition_sharded: po, pf [S,N,3] (the same on every rank); returns this rank's histories [S,count,K_T_max,3]."""
+        po, pf = _f(po), _f(pf)
+        S, N = po.shape[0], po.shape[1]
+        lo, cnt, cmax = partition(N, getattr(self, "nranks", 1), getattr(self, "rank", 0))
+        used, sst = np.zeros(S, dtype=np.int32), np.zeros(S, dtype=np.int32)
+        if histories:
+            pk = np.zeros((S, cnt, K_T_max, 3)); vk, ak = np.zeros_like(pk), np.zeros_like(pk)
+            hp = (_dp(pk), _dp(vk), _dp(ak))
+        else:
+            pk = vk = ak = None
+            hp = (C.POINTER(C.c_double)(),) * 3
+        self._chk(self._L.dmpc_transition_sharded(self._ctx, S, N, _dp(po), _dp(pf), int(K_T_max), float(error_tol), hp[0], hp[1], hp[2],
+                                                  _ip(used), _ip(sst)))
+        return dict(pk=pk, vk=vk, ak=ak, K_T_used=used, scene_status=sst, lo=lo, count=cnt)
 
     def postcheck(self, K_T_used, pf, pk=None, vk=None, ak=None, KT_alloc=None, vmax=2.0, amax=1.0, Ts=0.01, interp=False,
                   mask=None):

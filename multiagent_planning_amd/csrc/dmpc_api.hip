@@ -72,6 +72,10 @@ struct dmpc_ctx {
     int split_S0 = 0;            // > 0: the last dmpc_transition left scenes [0, split_S0) here and the rest in `child`
     int no_split = getenv("DMPC_NO_SPLIT") ? 1 : 0;
     DevBuf pc_p, pc_v, pc_a, pc_M, pc_w, pc_scene, pc_agent, pc_interp;   // post-check work buffers
+    // multi-GPU (dmpc_multigpu.hip): RCCL communicator of this rank, exchange buffers
+    void *comm = nullptr;
+    int nranks = 1, rank = 0;
+    DevBuf sendbuf, mg_pf, mg_floc, mg_fall;
     DevBuf rb_A, rb_l, rb_sel, rb_out, rb_bin, rb_po, gen_out, hp_in, hp_out;                     // dense row builders (host-pointer entries)
     // profiling
     int profile = 0;
@@ -311,6 +315,7 @@ extern "C" void dmpc_destroy(dmpc_ctx *ctx)
 {
     if (!ctx) return;
     if (ctx->child) { dmpc_destroy(ctx->child); ctx->child = nullptr; }
+    if (ctx->comm) (void)dmpc_comm_destroy(ctx);
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (auto &ev : ctx->events) { (void)hipEventDestroy(ev.t0); (void)hipEventDestroy(ev.t1); (void)hipEventDestroy(ev.t2); }
@@ -386,7 +391,7 @@ static int full_qcap(int variant) { return variant_soft(variant) ? QMAX : 48; }
 static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_first, int c_count, const double *lT,
                        const double *x_p, const double *x_v, const double *x_a, const double *pf, double *p_out,
                        double *v_out, double *a_out, double *lT_next, int32_t *status, int32_t *info, hipStream_t st,
-                       const int *scene_done = nullptr)
+                       const int *scene_done = nullptr, int short_from = 0)
 {
     const dmpc_params &p = ctx->prm;
     const bool soft = variant_soft(p.variant);
@@ -422,6 +427,7 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     if (G * C >= 256 && !ctx->no_cull) { nbr_cap = 1024; while (nbr_cap < G * C / 4 && nbr_cap < 8192) nbr_cap *= 2; }
     P.nbr_cap = nbr_cap;
     P.scene_done = scene_done;
+    P.short_from = short_from;   // unequal clusters: chunks from here on hold C-1 agents (dmpc_multigpu.hip)
     const size_t lds0 = scan_lds_bytes(nbr_cap);
     const size_t lds1 = solve_lds_bytes(P.nrmax, soft, q1, false), lds2 = solve_lds_bytes(P.nrmax, soft, q2, false);
     const size_t ldsmax = lds2 > lds1 ? lds2 : lds1;
@@ -1218,6 +1224,7 @@ extern "C" int dmpc_add_coll_constr(dmpc_ctx *ctx, int K, int N, const double *p
 }
 
 #include "dmpc_fileio.hip"
+#include "dmpc_multigpu.hip"
 
 
 // ---------------------------------------------------------------------------------------------

@@ -48,6 +48,7 @@ struct StepParams {
     int *flag_count, *flag_list;   // tier 1 -> tier 2: number / ids of the agents whose working set overflowed (or null)
     double *dbg;            // optional per-iteration trace of agent dbg_agent (development aid)
     int dbg_agent, dbg_cap;
+    int short_from;         // unequal clusters: chunks r >= short_from hold C-1 agents (last column = padding); 0: all chunks hold C
     int iter_cap;           // active-set iteration cap per try (ITER_CAP; development runs lower it to measure the per-iteration cost)
 };
 

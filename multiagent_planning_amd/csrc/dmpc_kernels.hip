@@ -315,7 +315,7 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
         for (int r = 0; r < G && fits; ++r)
             for (int j0 = 0; j0 < C; j0 += 64) {
                 const int jj = j0 + lane;
-                const bool valid = jj < C && !(r == P.g_local && jj == cl);
+                const bool valid = jj < C - ((P.short_from && r >= P.short_from) ? 1 : 0) && !(r == P.g_local && jj == cl);
                 const int jc = jj < C ? jj : C - 1;
                 const double *bb = P.bbox + ((size_t)(r * S + scene) * 6) * C + jc;
                 const bool hit = valid && bb[0] <= obx1 + R && bb[(size_t)C] >= obx0 - R && bb[2 * (size_t)C] <= oby1 + R &&
@@ -343,7 +343,9 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
         r = e0 / cpad;
         const int jj = e0 - r * cpad + lane;
         jc = jj < C ? jj : C - 1;   // clamped: loads are unconditional, results masked
-        return jj < C && !(r == P.g_local && jj == cl);
+        // unequal clusters (dmpc.cpp:1600-1625: the first N mod G clusters hold one agent more): the chunks from
+        // P.short_from on use C-1 columns, their last column is padding
+        return jj < C - ((P.short_from && r >= P.short_from) ? 1 : 0) && !(r == P.g_local && jj == cl);
     };
 
     // Launch-order key of the slack-free variants (see order_kernel): which horizon steps have a row that is violated
@@ -517,7 +519,7 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
                                 r = c >> 20; jc = c & 0xfffff;
                             } else {
                                 div_c.divmod((unsigned)idx, r, jc);
-                                valid = valid && !(r == P.g_local && jc == cl);
+                                valid = valid && !(r == P.g_local && jc == cl) && jc < C - ((P.short_from && r >= P.short_from) ? 1 : 0);
                             }
                         } else valid = valid && jc != cl;
                         const double *nb = P.lT + ((size_t)(single ? P.g_local : r) * S + scene) * slab + (unsigned)(3 * k * C + jc);
@@ -583,7 +585,7 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
         }
         if (var == VAR_HARD) {
             flush_candidates();
-            rows_exist = (G * C > 1);   // preallocated zero rows make Ain_coll non-empty (CollConstrHardDMPC.m:3-4)
+            rows_exist = (G * C - (P.short_from ? G - P.short_from : 0) > 1);   // preallocated zero rows make Ain_coll non-empty (CollConstrHardDMPC.m:3-4)
         } else {
             anyb = wave_or(anyb);
             for (int k = 0; k < K; ++k) {
