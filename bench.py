@@ -109,6 +109,29 @@ def main():
     S = args.scenes
     kw = wl.solver_kwargs(cfg, N)
     dmpc = mp.Dmpc(cfg["variant"], device=local_rank, **kw)
+    # the per-step exchange runs INSIDE the library (dmpc_step_sharded_device: solve + ncclAllGather on one stream); the RCCL id
+    # of the library's communicator travels through torch.distributed.  If the library cannot set its communicator up, the
+    # exchange falls back to torch.distributed's all-gather (and the JSON line says so).
+    exchange = "none"
+    if use_dist and not share:
+        exchange = "torch.distributed all_gather_into_tensor"
+        try:
+            idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(mp.Dmpc.comm_unique_id()), dtype=torch.uint8))
+            dist.broadcast(idt, src=0)
+            dmpc.comm_init(bytes(idt.cpu().numpy().tobytes()), G, rank)
+            okf = torch.ones(1, dtype=torch.int32, device=dev)
+            exchange = "in-library RCCL all-gather (dmpc_step_sharded_device)"
+        except Exception as e:   # noqa: BLE001
+            okf = torch.zeros(1, dtype=torch.int32, device=dev)
+            sys.stderr.write(f"[bench] rank {rank}: library communicator unavailable ({e}); using torch.distributed\n")
+        dist.all_reduce(okf, op=dist.ReduceOp.MIN)     # all ranks take the same path
+        if int(okf.item()) == 0:
+            exchange = "torch.distributed all_gather_into_tensor"
+    elif share:
+        exchange = "gloo (shared-GPU functional check)"
+    in_lib = exchange.startswith("in-library")
 
     # ---- synthetic inputs: captured congested step (identical on every rank: deterministic) ----
     l, xp, xv, xa, pf, alive = capture_state(dmpc, cfg, S, N, args.capture_step, wl.SEED0 + 2)
@@ -129,6 +152,10 @@ def main():
     info = torch.zeros((S, C, 8), dtype=torch.int32, device=dev)
 
     def one_step():
+        if in_lib:     # solve of this rank's cluster + the all-gather of the new predictions, both enqueued by the library
+            dmpc.step_sharded_device(S, N, lT.data_ptr(), x_p.data_ptr(), x_v.data_ptr(), x_a.data_ptr(), p_f.data_ptr(), p_out.data_ptr(),
+                                     v_out.data_ptr(), a_out.data_ptr(), lT_gath.data_ptr(), status.data_ptr(), info.data_ptr(), stream)
+            return
         dmpc.step_device(S, G, C, rank, lT.data_ptr(), x_p.data_ptr(), x_v.data_ptr(), x_a.data_ptr(), p_f.data_ptr(),
                          p_out.data_ptr(), v_out.data_ptr(), a_out.data_ptr(), lT_next.data_ptr(), status.data_ptr(),
                          info.data_ptr(), stream)
@@ -169,6 +196,10 @@ def main():
         ck = lT_gath.view(torch.int64).sum(dtype=torch.int64)    # bit-pattern checksum
         ck = torch.stack([ck, -ck]).to("cpu" if share else dev)
         dist.all_reduce(ck, op=dist.ReduceOp.MAX)
+        if in_lib:   # this rank's slot must hold what a plain (unsharded-API) solve of its chunk writes
+            dmpc.step_device(S, G, C, rank, lT.data_ptr(), x_p.data_ptr(), x_v.data_ptr(), x_a.data_ptr(), p_f.data_ptr(), p_out.data_ptr(),
+                             v_out.data_ptr(), a_out.data_ptr(), lT_next.data_ptr(), status.data_ptr(), info.data_ptr(), stream)
+            torch.cuda.synchronize()
         exchange_ok = bool(torch.equal(lT_gath[rank], lT_next)) and int(ck[0].item()) == -int(ck[1].item())
 
     solves_per_step = S * N if not emu else S * C
@@ -275,7 +306,7 @@ def main():
                                    f"{int(alive.sum())}/{S} scenes still alive there)",
                        "agents_per_scene": N, "scenes": S, "solves_per_step": solves_per_step,
                        "parallelism": f"agents sharded x{G}, all-gather per step" if G > 1 else "single GPU",
-                       "exchange_verified": exchange_ok},
+                       "exchange": exchange, "exchange_verified": exchange_ok},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": kname, "kernel_ms_avg": kern_ms, "launches": n_launch,

@@ -30,17 +30,30 @@ def partition(N, G):
     return out
 
 
+def agent_failed(status):
+    """The abort rule of a trial, shared with dmpc_transition / dmpc_transition_sharded of the C ABI (`stbits & ~DMPC_ST_SOLVED`):
+    an agent fails the scene unless its status is exactly SOLVED -- infeasible, collided, capacity, and also a SOLVED agent
+    whose first step leaves the workspace (SOLVED|OUTBOUND) or that noticed a collision (SOLVED|COLL, the cpp flavour)."""
+    return status != ST_SOLVED
+
+
 def rows_to_chunked(rows, G):
-    """[S,N,45] rows -> lT[G,S,45,C] (N = G*C)."""
+    """[S,N,45] rows -> lT[G,S,45,Cmax], the rank-major table of the C ABI: contiguous clusters as partition(), Cmax =
+    ceil(N/G); the last column of the short clusters' chunks is zero padding that nothing reads."""
     S, N, _ = rows.shape
-    C = N // G
-    assert C * G == N, "equal chunks required (pad the scene to a multiple of the rank count)"
-    return np.ascontiguousarray(rows.reshape(S, G, C, K3).transpose(1, 0, 3, 2))
+    parts = partition(N, G)
+    cmax = parts[0][1] - parts[0][0]
+    lT = np.zeros((G, S, K3, cmax), dtype=rows.dtype)
+    for g, (lo, hi) in enumerate(parts):
+        lT[g, :, :, :hi - lo] = rows[:, lo:hi].transpose(0, 2, 1)
+    return lT
 
 
-def chunked_to_rows(lT):
-    G, S, _, C = lT.shape
-    return np.ascontiguousarray(lT.transpose(1, 0, 3, 2).reshape(S, G * C, K3))
+def chunked_to_rows(lT, N=None):
+    """inverse of rows_to_chunked; N = number of agents (default G*Cmax: equal clusters)"""
+    G, S, _, cmax = lT.shape
+    N = G * cmax if N is None else N
+    return np.ascontiguousarray(np.concatenate([lT[g, :, :, :hi - lo].transpose(0, 2, 1) for g, (lo, hi) in enumerate(partition(N, G))], axis=1))
 
 
 def run_transition(dmpc, po, pf, K_T_max, error_tol=0.01):
@@ -86,18 +99,23 @@ class ShardedStepper:
         ok = (out["status"] & 1) == 1
         own = lT_full[self.rank]                                        # [S,45,C]
         newp = out["p"].transpose(-1, -2) if isinstance(out["p"], torch.Tensor) else np.swapaxes(out["p"], -1, -2)
+        cnt = newp.shape[-1]                                            # this rank's cluster (<= Cmax columns of its chunk)
         if isinstance(newp, torch.Tensor):
-            chunk = torch.where(ok[:, None, :], newp, own).contiguous()
+            chunk = own.clone()
+            chunk[..., :cnt] = torch.where(ok[:, None, :], newp, own[..., :cnt])
+            chunk = chunk.contiguous()
         else:
-            chunk = torch.from_numpy(np.ascontiguousarray(np.where(ok[:, None, :], newp, own)))
+            ch = np.array(own, copy=True)
+            ch[..., :cnt] = np.where(ok[:, None, :], newp, own[..., :cnt])
+            chunk = torch.from_numpy(np.ascontiguousarray(ch))
         if self.world > 1:
             nxt = torch.empty((self.world,) + tuple(chunk.shape), dtype=chunk.dtype, device=chunk.device)
             dist.all_gather_into_tensor(nxt.view(-1), chunk.view(-1), group=self.group)   # rank-major == table layout
-            flag = torch.tensor([int((~ok).any())], dtype=torch.int32, device=chunk.device)
+            flag = torch.tensor([int(agent_failed(out["status"]).any())], dtype=torch.int32, device=chunk.device)
             dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)   # abort test (failure_rate.m:112-123)
             failed = bool(flag.item())
         else:
-            nxt, failed = chunk[None], bool((~ok).any())
+            nxt, failed = chunk[None], bool(agent_failed(out["status"]).any())
         if not isinstance(lT_full, torch.Tensor):
             nxt = nxt.numpy()
         return nxt, out, failed
@@ -128,7 +146,7 @@ def run_transition_sharded(stepper, lT, x_p, x_v, x_a, pf, K_T_max, error_tol=0.
         p1, v1, a1 = (torch.as_tensor(out[q])[..., :3] for q in ("p", "v", "a"))
         xp = torch.where(ok[..., None], p1, xp); xv = torch.where(ok[..., None], v1, xv); xa = torch.where(ok[..., None], a1, xa)
         pk[:, :, k] = xp
-        flags = torch.stack([(~ok).any(dim=1).to(torch.float64),                                   # some agent failed
+        flags = torch.stack([agent_failed(st).any(dim=1).to(torch.float64),                        # some agent failed
                              (xp - goal).norm(dim=-1).max(dim=1).values.to(torch.float64)])        # farthest agent from its goal
         flags = flags.to(xp.device)
         if stepper.world > 1:

@@ -33,19 +33,20 @@ def test_chunked_layout_roundtrip():
     assert lT[2, 1, 7, 1] == rows[1, 2 * 2 + 1, 7]
 
 
-def _oracle_local_step(kw, variant, G):
+def _oracle_local_step(kw, variant, G, N=None):
     from oracle import oracle as orc
     prm = orc.make_params(variant, **kw)
 
     def local_step(lT_full, x_p, x_v, x_a, pf, g_local):
-        rows = driver.chunked_to_rows(np.asarray(lT_full))
-        S, N, _ = rows.shape
-        C = N // G
+        rows = driver.chunked_to_rows(np.asarray(lT_full), N)
+        S, Nn, _ = rows.shape
+        lo, hi = driver.partition(Nn, G)[g_local]
+        C = hi - lo
         p = np.zeros((S, C, 45)); v = np.zeros_like(p); a = np.zeros_like(p)
         status = np.zeros((S, C), dtype=np.int32)
         for s in range(S):
             for ci in range(C):
-                n = g_local * C + ci
+                n = lo + ci
                 r = orc.solve_one(prm, rows[s], n, x_p[s, ci], x_v[s, ci], x_a[s, ci], pf[s, ci])
                 status[s, ci] = r["status"]
                 if r["status"] & 1:
@@ -140,3 +141,52 @@ def test_two_rank_closed_loop_transition_equals_single_rank(tmp_path):
         assert np.array_equal(r["used"], one["used"]) and np.array_equal(r["reached"], one["reached"]) and np.array_equal(r["failed"], one["failed"])
     assert np.array_equal(np.concatenate([r0["pk"], r1["pk"]], axis=1), one["pk"])
     assert np.array_equal(driver.chunked_to_rows(r0["lT"]), driver.chunked_to_rows(one["lT"])) and np.array_equal(r0["lT"], r1["lT"])
+
+
+def _unequal_worker(rank, world, port, out_dir, shrink):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from multiagent_planning_amd import workload as wl
+    from helpers import init_table
+    cfg = wl.CONFIGS["C4"]
+    N = 7
+    kw = wl.solver_kwargs(cfg, 20)
+    if shrink:   # a workspace the straight-line starts leave at once: SOLVED|OUTBOUND on the first solve
+        kw["pmax"] = (kw["pmax"][0], kw["pmax"][1], 0.6 * kw["pmax"][2])
+    po, pf = wl.make_scenes(cfg, 1, N, wl.SEED0 + 77)
+    po, pf = po[0], pf[0]
+    lo, hi = driver.partition(N, world)[rank]
+    lT = driver.rows_to_chunked(init_table(po, pf)[None], world)
+    stepper = driver.ShardedStepper(_oracle_local_step(kw, "bound2" if shrink else "bound", world, N), rank, world)
+    z = np.zeros((1, hi - lo, 3))
+    res = driver.run_transition_sharded(stepper, lT, po[None, lo:hi], z, z, pf[None, lo:hi], 12, cfg["error_tol"])
+    np.savez(os.path.join(out_dir, f"un_{int(shrink)}_{world}_{rank}.npz"), pk=res["pk"], used=res["K_T_used"], reached=res["reached"],
+             failed=res["failed"], rows=driver.chunked_to_rows(np.asarray(res["lT"]), N))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("shrink", [False, True])
+def test_three_rank_unequal_clusters_equal_single_rank(tmp_path, shrink):
+    """7 agents on 3 gloo ranks -- clusters of 3, 2, 2 agents as dmpc.cpp:1600-1625, padded rank-major table -- against the
+    unsharded loop: same histories, table and stop decision.  shrink: the workspace is cut so that agents leave it on their
+    first solve; bound2 reports SOLVED|OUTBOUND and the trial must stop there on EVERY rank (the abort rule shared with
+    dmpc_transition: any status other than exactly SOLVED)."""
+    port = 33500 + (os.getpid() % 2000) + (7 if shrink else 0)
+    tmp.spawn(_unequal_worker, args=(3, port, str(tmp_path), shrink), nprocs=3, join=True)
+    _unequal_worker(0, 1, port + 1, str(tmp_path), shrink)
+    one = np.load(tmp_path / f"un_{int(shrink)}_1_0.npz")
+    rs = [np.load(tmp_path / f"un_{int(shrink)}_3_{r}.npz") for r in range(3)]
+    for r in rs:
+        assert np.array_equal(r["used"], one["used"]) and np.array_equal(r["failed"], one["failed"]) and np.array_equal(r["reached"], one["reached"])
+        assert np.array_equal(r["rows"], one["rows"])
+    assert np.array_equal(np.concatenate([r["pk"] for r in rs], axis=1), one["pk"])
+    if shrink:
+        assert one["failed"].all() and one["used"][0] == 2     # stopped at the first solve
+    else:
+        assert not one["failed"].any() and one["used"][0] == 12
