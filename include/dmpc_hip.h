@@ -92,10 +92,20 @@ typedef struct {
 
 typedef struct dmpc_ctx dmpc_ctx;
 
-/* Create a solver context on HIP device `device` (>= 0).  Replaces the constants/precompute
- * preamble of dmpc/matlab/dmpc_soft_bound.m:80-108 and the DMPC ctor dmpc/cpp/dmpc.cpp:19-75.
+/* arithmetic of a context */
+enum {
+    DMPC_PREC_F64 = 0,   /* everything fp64 (the reference is MATLAB double)                                          */
+    DMPC_PREC_MIXED = 1  /* the prediction table is kept in fp32 and the scan + collision rows (a5/a6) are computed in
+                          * fp32; the QP itself (cost, factor, multipliers, propagation) and all inputs / outputs stay
+                          * fp64.  Host-pointer entry points (dmpc_step_batch, dmpc_solve_one, dmpc_transition); the
+                          * device-layout and multi-GPU entry points take fp64 tables only.  BASELINE configs[4].    */
+};
+
+/* Create a solver context on HIP device `device` (>= 0; -1 = the calling thread's current HIP device -- with one process
+ * per GPU that is "this rank's GPU").  Replaces the constants/precompute preamble of dmpc/matlab/dmpc_soft_bound.m:80-108
+ * and the DMPC ctor dmpc/cpp/dmpc.cpp:19-75.  precision: DMPC_PREC_*.
  * Returns NULL on failure (no device, bad parameters); dmpc_last_error(NULL) has the text. */
-dmpc_ctx *dmpc_create(const dmpc_params *prm, int device);
+dmpc_ctx *dmpc_create(const dmpc_params *prm, int device, int precision);
 void dmpc_destroy(dmpc_ctx *ctx);
 const char *dmpc_last_error(const dmpc_ctx *ctx);
 

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libdmpc_hip.so")
 
 VARIANTS = dict(bound=0, bound2=1, all3=2, hard=3, ondemand=4, ellip=5, softall=6, repair=7, cpp=8, cpp2=9)
 ST_SOLVED, ST_OUTBOUND, ST_COLL, ST_INFEAS, ST_CAPACITY, ST_ITERCAP = 1, 2, 4, 8, 16, 32
+PRECISIONS = dict(f64=0, mixed=1)
 ST_REACHED = 256   # scene_status of transition(): every agent reached its goal
 INFO_LEN = 8
 I_VIOLK, I_NROWS, I_TRIES, I_CASE, I_ITERS, I_NSLACK, I_NACTIVE, I_MAXQ = range(8)
@@ -69,7 +70,7 @@ def load():
     dp, ip, vp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_void_p
     pp = C.POINTER(DmpcParams)
     L.dmpc_create.restype = vp
-    L.dmpc_create.argtypes = [pp, C.c_int]
+    L.dmpc_create.argtypes = [pp, C.c_int, C.c_int]
     L.dmpc_destroy.restype = None
     L.dmpc_destroy.argtypes = [vp]
     L.dmpc_last_error.restype = C.c_char_p
@@ -179,10 +180,12 @@ def partition(N, G, rank):
 class Dmpc:
     """One solver context on one HIP device (wraps dmpc_create/dmpc_destroy)."""
 
-    def __init__(self, variant="bound", device=0, **kw):
+    def __init__(self, variant="bound", device=0, precision="f64", **kw):
+        """precision: "f64" (DMPC_PREC_F64) or "mixed" (DMPC_PREC_MIXED: fp32 table / scan / rows, fp64 QP)"""
         self._L = load()
         self.prm = make_params(variant, **kw)
-        self._ctx = self._L.dmpc_create(C.byref(self.prm), int(device))
+        self.precision = precision
+        self._ctx = self._L.dmpc_create(C.byref(self.prm), int(device), PRECISIONS[precision])
         if not self._ctx:
             raise DmpcError(self._L.dmpc_last_error(None).decode())
         self.device = device

@@ -48,6 +48,7 @@ struct DevBuf {
 
 struct dmpc_ctx {
     int device = 0;
+    int precision = DMPC_PREC_F64;   // DMPC_PREC_MIXED: fp32 table / scan / rows, fp64 QP (host-pointer entry points)
     hipStream_t stream = nullptr;
     dmpc_params prm{};
     double *d_tables = nullptr;   // [3][900] Gram tables + [225] Lambda' table (dmpc_device.h: TAB_DOUBLES)
@@ -66,6 +67,7 @@ struct dmpc_ctx {
     int no_lpt = getenv("DMPC_NO_LPT") ? 1 : 0;   // tuning: disable the heaviest-first solve order
     int iter_cap = getenv("DMPC_ITER_CAP") ? atoi(getenv("DMPC_ITER_CAP")) : ITER_CAP;   // development: cap the active-set iterations (agents beyond it end DMPC_ST_ITERCAP)
     int single_tier = 0;         // 1: solve with the full working-set capacity in one launch
+    DevBuf lTf, lTf2;            // mixed precision: fp32 copies of the tables the scan reads
     DevBuf rows, lT, lT2, xp, xv, xa, pf, po, pout, vout, aout, status, info, hist_p, hist_v, hist_a, flags;
     int hist_S = 0, hist_N = 0, hist_KT = 0;   // shape of the histories left resident by the last dmpc_transition
     dmpc_ctx *child = nullptr;   // second context (own stream and buffers) for the other half of a split batch of transitions
@@ -285,10 +287,11 @@ static int upload_tables(dmpc_ctx *ctx)
 
 extern "C" const char *dmpc_last_error(const dmpc_ctx *ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
 
-extern "C" dmpc_ctx *dmpc_create(const dmpc_params *prm, int device)
+extern "C" dmpc_ctx *dmpc_create(const dmpc_params *prm, int device, int precision)
 {
     std::string why;
     if (check_params(prm, why)) { g_err = "dmpc_create: " + why; return nullptr; }
+    if (precision != DMPC_PREC_F64 && precision != DMPC_PREC_MIXED) { g_err = "dmpc_create: precision must be DMPC_PREC_F64 or DMPC_PREC_MIXED"; return nullptr; }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0) {
@@ -296,10 +299,12 @@ extern "C" dmpc_ctx *dmpc_create(const dmpc_params *prm, int device)
                 "); this library has no CPU fallback";
         return nullptr;
     }
+    if (device == -1 && hipGetDevice(&device) != hipSuccess) device = 0;   // -1: the calling thread's current HIP device
     if (device < 0 || device >= ndev) { g_err = "dmpc_create: device index out of range"; return nullptr; }
     if (hipSetDevice(device) != hipSuccess) { g_err = "dmpc_create: hipSetDevice failed"; return nullptr; }
     dmpc_ctx *ctx = new dmpc_ctx();
     ctx->device = device;
+    ctx->precision = precision;
     ctx->prm = *prm;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc((void **)&ctx->d_tables, sizeof(double) * TAB_DOUBLES) != hipSuccess || upload_tables(ctx) != 0) {
@@ -391,7 +396,7 @@ static int full_qcap(int variant) { return variant_soft(variant) ? QMAX : 48; }
 static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_first, int c_count, const double *lT,
                        const double *x_p, const double *x_v, const double *x_a, const double *pf, double *p_out,
                        double *v_out, double *a_out, double *lT_next, int32_t *status, int32_t *info, hipStream_t st,
-                       const int *scene_done = nullptr, int short_from = 0)
+                       const int *scene_done = nullptr, int short_from = 0, const float *lTf = nullptr)
 {
     const dmpc_params &p = ctx->prm;
     const bool soft = variant_soft(p.variant);
@@ -408,7 +413,8 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     for (int d = 0; d < 3; ++d) { P.pmin[d] = p.pmin[d]; P.pmax[d] = p.pmax[d]; }
     P.tables = ctx->d_tables;
     for (int i = 0; i < 3; ++i) P.hsum[i] = ctx->hsum[i];
-    P.lT = lT; P.x_p = x_p; P.x_v = x_v; P.x_a = x_a; P.pf = pf;
+    // mixed precision: the scan reads the fp32 copy lTf of the table; lT (fp64, chunk g_local) is the solve's fallback
+    P.lT = lTf ? (const double *)lTf : lT; P.own_prev = lTf ? lT + (size_t)g_local * S * N3 * C : nullptr; P.x_p = x_p; P.x_v = x_v; P.x_a = x_a; P.pf = pf;
     P.p_out = p_out; P.v_out = v_out; P.a_out = a_out; P.lT_next = lT_next;
     P.status = status; P.info = info;
     {
@@ -454,7 +460,8 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     if (G * C >= 256 && !ctx->no_cull && finite_radius) {
         const int total = G * S * C;
         if (ctx->bbox.ensure((size_t)total * 6 * 8)) FAIL(ctx, "device allocation failed (bbox)");
-        hipLaunchKernelGGL(bbox_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, C, lT, ctx->bbox.as<double>());
+        if (lTf) hipLaunchKernelGGL(bbox_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, C, lTf, ctx->bbox.as<double>());
+        else hipLaunchKernelGGL(bbox_kernel<double>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, C, lT, ctx->bbox.as<double>());
         P.bbox = ctx->bbox.as<double>();
     }
     HIPCHK(ctx, hipMemsetAsync(ctx->counter.p, 0, 16, st));   // queue heads of the persistent solve launches
@@ -468,8 +475,13 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
         while (W > 1 && lds0 * W > 64 * 1024) W >>= 1;
         const dim3 sgrid((unsigned)((total + W - 1) / W)), sblock(64u * W);
         P.lds_per_wave = (int)lds0;
-        if (soft) hipLaunchKernelGGL(dmpc_scan_kernel<true>, sgrid, sblock, lds0 * W, st, P);
-        else hipLaunchKernelGGL(dmpc_scan_kernel<false>, sgrid, sblock, lds0 * W, st, P);
+        if (lTf) {
+            if (soft) hipLaunchKernelGGL((dmpc_scan_kernel<true, float>), sgrid, sblock, lds0 * W, st, P);
+            else hipLaunchKernelGGL((dmpc_scan_kernel<false, float>), sgrid, sblock, lds0 * W, st, P);
+        } else {
+            if (soft) hipLaunchKernelGGL((dmpc_scan_kernel<true, double>), sgrid, sblock, lds0 * W, st, P);
+            else hipLaunchKernelGGL((dmpc_scan_kernel<false, double>), sgrid, sblock, lds0 * W, st, P);
+        }
     }
     // heaviest-first launch order for the solve phase (key left by the scan in hdr[7]).  Tiny launches do not need it.
     if (ctx->forced_n == S * c_count) P.order = ctx->forced_order.as<int>();   // development aid: externally supplied launch order
@@ -618,6 +630,7 @@ extern "C" int dmpc_step_device(dmpc_ctx *ctx, int S, int G, int C, int g_local,
     if (!ctx) { g_err = "dmpc_step_device: ctx is NULL"; return -1; }
     if (S < 1 || G < 1 || C < 1 || g_local < 0 || g_local >= G) FAIL(ctx, "dmpc_step_device: bad S/G/C/g_local");
     if (!lT || !x_p || !x_v || !x_a || !pf || !p_out || !v_out || !a_out || !status) FAIL(ctx, "dmpc_step_device: NULL pointer");
+    if (ctx->precision != DMPC_PREC_F64) FAIL(ctx, "dmpc_step_device: device-layout entry points take fp64 tables (DMPC_PREC_F64 contexts only)");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     return launch_step(ctx, S, G, C, g_local, 0, C, lT, x_p, x_v, x_a, pf, p_out, v_out, a_out, lT_next, status, info,
                        (hipStream_t)stream);
@@ -669,6 +682,15 @@ static int ensure_step_scratch(dmpc_ctx *ctx, size_t agents_table, size_t agents
     return 0;
 }
 
+// mixed precision: fp32 copy of a table (n doubles) for the scan
+static int table_f32(dmpc_ctx *ctx, const double *src, DevBuf &dst, size_t n, hipStream_t st)
+{
+    if (dst.ensure(n * 4)) FAIL(ctx, "device allocation failed (fp32 table)");
+    const unsigned blocks = (unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    hipLaunchKernelGGL(table_to_f32_kernel, dim3(blocks), dim3(256), 0, st, n, src, dst.as<float>());
+    return 0;
+}
+
 extern "C" int dmpc_step_batch(dmpc_ctx *ctx, int S, int N, const double *l, const double *x_p, const double *x_v,
                                const double *x_a, const double *pf, double *p_out, double *v_out, double *a_out,
                                int32_t *status, int32_t *info)
@@ -686,9 +708,12 @@ extern "C" int dmpc_step_batch(dmpc_ctx *ctx, int S, int N, const double *l, con
     HIPCHK(ctx, hipMemcpyAsync(ctx->xa.p, x_a, A * 24, hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipMemcpyAsync(ctx->pf.p, pf, A * 24, hipMemcpyHostToDevice, st));
     if (dmpc_table_from_rows_device(ctx, S, 1, N, ctx->rows.as<double>(), ctx->lT.as<double>(), st)) return -1;
+    const bool mixed = ctx->precision == DMPC_PREC_MIXED;
+    if (mixed && table_f32(ctx, ctx->lT.as<double>(), ctx->lTf, A * N3, st)) return -1;
     if (launch_step(ctx, S, 1, N, 0, 0, N, ctx->lT.as<double>(), ctx->xp.as<double>(), ctx->xv.as<double>(),
                     ctx->xa.as<double>(), ctx->pf.as<double>(), ctx->pout.as<double>(), ctx->vout.as<double>(),
-                    ctx->aout.as<double>(), nullptr, ctx->status.as<int32_t>(), ctx->info.as<int32_t>(), st))
+                    ctx->aout.as<double>(), nullptr, ctx->status.as<int32_t>(), ctx->info.as<int32_t>(), st, nullptr, 0,
+                    mixed ? ctx->lTf.as<float>() : nullptr))
         return -1;
     HIPCHK(ctx, hipMemcpyAsync(p_out, ctx->pout.p, A * N3 * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipMemcpyAsync(v_out, ctx->vout.p, A * N3 * 8, hipMemcpyDeviceToHost, st));
@@ -715,9 +740,12 @@ extern "C" int dmpc_solve_one(dmpc_ctx *ctx, int N, int n, const double *l, cons
     HIPCHK(ctx, hipMemcpyAsync(ctx->xa.p, ao, 24, hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipMemcpyAsync(ctx->pf.p, pf, 24, hipMemcpyHostToDevice, st));
     if (dmpc_table_from_rows_device(ctx, 1, 1, N, ctx->rows.as<double>(), ctx->lT.as<double>(), st)) return -1;
+    const bool mixed = ctx->precision == DMPC_PREC_MIXED;
+    if (mixed && table_f32(ctx, ctx->lT.as<double>(), ctx->lTf, (size_t)N * N3, st)) return -1;
     if (launch_step(ctx, 1, 1, N, 0, n, 1, ctx->lT.as<double>(), ctx->xp.as<double>(), ctx->xv.as<double>(),
                     ctx->xa.as<double>(), ctx->pf.as<double>(), ctx->pout.as<double>(), ctx->vout.as<double>(),
-                    ctx->aout.as<double>(), nullptr, ctx->status.as<int32_t>(), ctx->info.as<int32_t>(), st))
+                    ctx->aout.as<double>(), nullptr, ctx->status.as<int32_t>(), ctx->info.as<int32_t>(), st, nullptr, 0,
+                    mixed ? ctx->lTf.as<float>() : nullptr))
         return -1;
     HIPCHK(ctx, hipMemcpyAsync(p, ctx->pout.p, N3 * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipMemcpyAsync(v, ctx->vout.p, N3 * 8, hipMemcpyDeviceToHost, st));
@@ -765,8 +793,8 @@ extern "C" int dmpc_rows_one(dmpc_ctx *ctx, int N, int n, const double *l, const
     if (ctx->rowbuf.ensure(per * 8) || ctx->rowkc.ensure((size_t)P.nrmax * 4) || ctx->hdr.ensure(32)) FAIL(ctx, "device allocation failed");
     P.rowbuf = ctx->rowbuf.as<double>(); P.rowkc = ctx->rowkc.as<int>(); P.hdr = ctx->hdr.as<int>();
     P.lds_per_wave = (int)scan_lds_bytes(0);
-    if (soft) hipLaunchKernelGGL(dmpc_scan_kernel<true>, dim3(1), dim3(64), scan_lds_bytes(0), st, P);
-    else hipLaunchKernelGGL(dmpc_scan_kernel<false>, dim3(1), dim3(64), scan_lds_bytes(0), st, P);
+    if (soft) hipLaunchKernelGGL((dmpc_scan_kernel<true, double>), dim3(1), dim3(64), scan_lds_bytes(0), st, P);
+    else hipLaunchKernelGGL((dmpc_scan_kernel<false, double>), dim3(1), dim3(64), scan_lds_bytes(0), st, P);
     HIPCHK(ctx, hipGetLastError());
     int hdr[8];
     HIPCHK(ctx, hipMemcpyAsync(hdr, ctx->hdr.p, 32, hipMemcpyDeviceToHost, st));
@@ -852,15 +880,17 @@ static int transition_one(dmpc_ctx *ctx, int S, int N, const double *po, const d
     hipLaunchKernelGGL(record_kernel, dim3(rb), dim3(256), 0, st, S, N, K_T_max, 0, xp, xv, xa, ctx->hist_p.as<double>(),
                        ctx->hist_v.as<double>(), ctx->hist_a.as<double>());
     double *cur = ctx->lT.as<double>(), *nxt = ctx->lT2.as<double>();
+    const bool mixed = ctx->precision == DMPC_PREC_MIXED;   // the scan of every step reads an fp32 copy of the current table
     std::vector<int32_t> flags((size_t)K_T_max * S * 2, 0);
     std::vector<int> done(S, 0);
     for (int s = 0; s < S; ++s) { K_T_used[s] = K_T_max; scene_status[s] = DMPC_ST_SOLVED; }
     int ndone = 0;
     const int chunk = 8;   // host looks at the per-step flags every `chunk` MPC steps
     for (int k = 1; k < K_T_max && ndone < S; ++k) {
+        if (mixed && table_f32(ctx, cur, ctx->lTf, A * N3, st)) return -1;
         if (launch_step(ctx, S, 1, N, 0, 0, N, cur, xp, xv, xa, ctx->pf.as<double>(), ctx->pout.as<double>(),
                         ctx->vout.as<double>(), ctx->aout.as<double>(), nxt, ctx->status.as<int32_t>(), nullptr, st,
-                        ctx->scene_done.as<int>()))
+                        ctx->scene_done.as<int>(), 0, mixed ? ctx->lTf.as<float>() : nullptr))
             return -1;
         hipLaunchKernelGGL(advance_kernel, dim3(rb), dim3(256), 0, st, (int)A, ctx->pout.as<double>(), ctx->vout.as<double>(),
                            ctx->aout.as<double>(), (const int *)ctx->status.as<int32_t>(), xp, xv, xa);
@@ -909,7 +939,7 @@ extern "C" int dmpc_transition(dmpc_ctx *ctx, int S, int N, const double *po, co
     if (S < 32 || ctx->no_split || N < 1 || K_T_max < 2 || !po || !pf || !K_T_used || !scene_status)
         return transition_one(ctx, S, N, po, pf, K_T_max, error_tol, pk, vk, ak, K_T_used, scene_status);
     if (!ctx->child) {
-        ctx->child = dmpc_create(&ctx->prm, ctx->device);
+        ctx->child = dmpc_create(&ctx->prm, ctx->device, ctx->precision);
         if (!ctx->child) FAIL(ctx, "dmpc_transition: second context: " + g_err);
         ctx->child->no_split = 1;
     } else if (std::memcmp(&ctx->child->prm, &ctx->prm, sizeof(dmpc_params)) != 0 && dmpc_set_params(ctx->child, &ctx->prm)) {

@@ -29,7 +29,8 @@ struct StepParams {
     double pmin[3], pmax[3];
     double hsum[3];         // per cost case: sum of |H1(i,j)| (bound of the cost over the acceleration box, dual-bound certificate)
     const double *tables;   // [3 cost cases][30x30 Gram table G] + [15x15 Lambda' table]  (TAB_DOUBLES; see dmpc_solve.hip)
-    const double *lT;       // [G][S][3K][C]
+    const double *lT;       // [G][S][3K][C]; mixed precision: the scan reads it as a float table (same layout)
+    const double *own_prev; // mixed precision: fp64 predictions of chunk g_local [S][3K][C] (the solve's fallback for unsolved agents), else null
     const double *x_p, *x_v, *x_a, *pf;   // [S][c_count][3]  (agents c_first .. c_first+c_count-1 of chunk g_local)
     double *p_out, *v_out, *a_out;        // [S][c_count][3K]
     double *lT_next;                      // [S][3K][C] or null

@@ -234,7 +234,7 @@ return empty_any;
 // register and LDS footprint free of the scan's needs (more resident agents per CU) and lets the solver be re-launched
 // for the few agents that overflow the tier-1 working-set capacity.
 // `vb`: the agent's index in the launch (already renumbered XCD-aware by the kernel); `smem`: this wave's LDS.
-template <bool SOFT>
+template <bool SOFT, typename TT>
 __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, const int vb, unsigned char *smem)
 {
     const int S = P.S, G = P.G, C = P.C, nrmax = P.nrmax;
@@ -244,12 +244,21 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
     const int var = P.variant;
     constexpr bool soft = SOFT;   // slack-carrying variants (bound, bound2, all3, softall, repair) vs hard rows (hard, ondemand, ellip)
 
+    // `real`: the arithmetic (and table) type of the scan and the row builder -- double, or float in the mixed-precision mode
+    // (fp32 table, distance tests and rows; the QP itself stays fp64: rows are stored as doubles)
+    using real = TT;
+    const TT *const tab = (const TT *)P.lT;
+    const real rmin = (real)P.rmin, h_ = (real)P.h, e1z = (real)P.e1z, e2z = (real)P.e2z, alim_ = (real)P.alim;
+    // safety margin of the exact pruning / certificates: far below any geometric quantity in fp64, a few float roundings of a
+    // workspace-sized coordinate in the mixed mode
+    constexpr real MARG = std::is_same<TT, float>::value ? (real)2e-5 : (real)1e-9;
     Lds L;
+    real *own_s, *w_s;
     int *scan_cand = nullptr, *scan_nbr = nullptr;
     {
         double *p = (double *)smem;
-        L.own_s = p; p += 48;
-        L.w_s = p; p += 48;   // unconstrained minimiser in position space (launch-order key of the slack-free variants)
+        own_s = (real *)p; p += 48;
+        w_s = (real *)p; p += 48;   // unconstrained minimiser in position space (launch-order key of the slack-free variants)
         scan_cand = (int *)p;   // SCAN_CAND_CAP ints
         scan_nbr = scan_cand + SCAN_CAND_CAP;   // P.nbr_cap ints
         // Collision rows live in a per-agent slice of a GLOBAL scratch buffer (L2-resident; lane = row, so
@@ -278,29 +287,32 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
         A.ao[d] = P.x_a[3 * gid + d]; A.pf[d] = P.pf[3 * gid + d];
     }
     // own previous prediction: prev_p = l(:,:,n)  (solveSoftDMPCbound.m:6)
-    const double *lT_own = P.lT + ((size_t)(P.g_local * S + scene) * N3) * C + cl;
-    if (lane < N3) L.own_s[lane] = lT_own[(size_t)lane * C];
+    const TT *lT_own = tab + ((size_t)(P.g_local * S + scene) * N3) * C + cl;
+    if (lane < N3) own_s[lane] = lT_own[(size_t)lane * C];
     LSYNC();
+    real po_[3], vo_[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { po_[d] = (real)A.po[d]; vo_[d] = (real)A.vo[d]; }
 
     // ---------------------------------------------------------------- a5/a6: scan + rows
     int nr = 0, nrows_ref = 0, viol_k = 0, status = 0;
     bool cert_infeasible = false;
     int ladder_start = 0;   // first retry-ladder level that is not certainly infeasible (soft ladder variants)
     bool rows_exist = false, violation = false;
-    const double rmin = P.rmin;
     const bool cppv = (var == VAR_CPP || var == VAR_CPP2);   // dmpc/cpp solveQPv2 flavour (dmpc.cpp:803-1287)
     const bool near_sel = (var == VAR_BOUND || var == VAR_BOUND2 || var == VAR_ALL3 || var == VAR_ONDEMAND || cppv);
     const bool coll_check = (var == VAR_BOUND || var == VAR_BOUND2 || var == VAR_ALL3 || var == VAR_REPAIR);
     const bool skip_k1 = (var == VAR_BOUND2 || var == VAR_ALL3 || var == VAR_REPAIR || var == VAR_CPP2);
     bool coll_flag = false;
     // own horizon box (uniform) for the neighbour culling; with a neighbour list only
-    double obx0 = 0, obx1 = 0, oby0 = 0, oby1 = 0, obz0 = 0, obz1 = 0;
+    real obx0 = 0, obx1 = 0, oby0 = 0, oby1 = 0, obz0 = 0, obz1 = 0;
     if (P.bbox && P.nbr_cap > 0) {
-        const double v = (lane < N3) ? L.own_s[lane] : 0.0;
+        const real v = (lane < N3) ? own_s[lane] : 0.0;
         const int ax = lane % 3;
-        obx0 = wave_min((lane < N3 && ax == 0) ? v : INFINITY); obx1 = wave_max((lane < N3 && ax == 0) ? v : -INFINITY);
-        oby0 = wave_min((lane < N3 && ax == 1) ? v : INFINITY); oby1 = wave_max((lane < N3 && ax == 1) ? v : -INFINITY);
-        obz0 = wave_min((lane < N3 && ax == 2) ? v : INFINITY); obz1 = wave_max((lane < N3 && ax == 2) ? v : -INFINITY);
+        const double vd = (double)v;
+        obx0 = (real)wave_min((lane < N3 && ax == 0) ? vd : INFINITY); obx1 = (real)wave_max((lane < N3 && ax == 0) ? vd : -INFINITY);
+        oby0 = (real)wave_min((lane < N3 && ax == 1) ? vd : INFINITY); oby1 = (real)wave_max((lane < N3 && ax == 1) ? vd : -INFINITY);
+        obz0 = (real)wave_min((lane < N3 && ax == 2) ? vd : INFINITY); obz1 = (real)wave_max((lane < N3 && ax == 2) ? vd : -INFINITY);
     }
     // Neighbour compaction (large scenes): a neighbour can come within ellipsoidal distance R of the agent at some
     // horizon step only if the bounding boxes of the two predicted horizons are within R per axis.  The survivors of
@@ -309,7 +321,7 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
     // unchanged.  nnbr < 0: no list (small scenes, variants that take every neighbour, or more survivors than fit).
     int nnbr = -1;
     if (P.bbox && P.nbr_cap > 0) {
-        const double R = (var == VAR_HARD) ? 1.0 : 3.0 * rmin, Rz = R / P.e1z;   // |dz|/c < R; the cpp radius is <= 2 rmin
+        const real R = (var == VAR_HARD) ? 1.0 : 3.0 * rmin, Rz = R / e1z;   // |dz|/c < R; the cpp radius is <= 2 rmin
         int cnt = 0;
         bool fits = true;
         for (int r = 0; r < G && fits; ++r)
@@ -357,8 +369,8 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
         if (lane < N3) {
             const int k = lane / 3, ax = lane - 3 * k;
             const double *tb = P.tables + 2 * TAB_CASE_DOUBLES;
-            const double gax = sel3(A.pf, ax) - (sel3(A.po, ax) + (double)K * P.h * sel3(A.vo, ax));
-            L.w_s[lane] = 2.0 * P.Q1 * gax * tb[(15 + k) * 30 + 15 + (K - 1)] + 2.0 * P.S1 * sel3(A.ao, ax) * tb[(15 + k) * 30];
+            const double gax = sel3(A.pf, ax) - (sel3(A.po, ax) + (double)K * h_ * sel3(A.vo, ax));
+            w_s[lane] = (real)(2.0 * P.Q1 * gax * tb[(15 + k) * 30 + 15 + (K - 1)] + 2.0 * P.S1 * sel3(A.ao, ax) * tb[(15 + k) * 30]);
         }
         LSYNC();
     }
@@ -367,10 +379,10 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
         // neighbour with dist < sel_r (or all), in increasing neighbour index (CollConstrSoftDMPC.m:11-31)
         // one collision row, CollConstrSoftDMPC.m:16-28: neighbour offset (dx,dy,dz) and ellipsoidal distance at
         // the evaluation step (own position px,py,pz), constraining horizon step kc; compacted by ballot
-        auto emit_row = [&](bool sel, int kc, double dx, double dy, double dz, double dist, double px, double py, double pz) {
-            const double sh = (double)(kc + 1) * P.h;
-            const double a0x = A.po[0] + sh * A.vo[0], a0y = A.po[1] + sh * A.vo[1], a0z = A.po[2] + sh * A.vo[2];
-            const double x0 = dx, x1 = dy, x2 = dz * P.e2z;   // diff = E2*(p - pj)
+        auto emit_row = [&](bool sel, int kc, real dx, real dy, real dz, real dist, real px, real py, real pz) {
+            const real sh = (real)(kc + 1) * h_;
+            const real a0x = po_[0] + sh * vo_[0], a0y = po_[1] + sh * vo_[1], a0z = po_[2] + sh * vo_[2];
+            const real x0 = dx, x1 = dy, x2 = dz * e2z;   // diff = E2*(p - pj)
             {
                 const unsigned long long m0 = __ballot(sel);
                 if (m0 == 0ull) return;                         // no neighbour of this chunk is close at this step
@@ -381,32 +393,32 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
             // that box can never become active; dropping it (and its slack, which stays 0) leaves the minimiser
             // unchanged.  Margin 1e-9 keeps borderline rows.
             {
-                const double hw = 0.5 * P.alim * sh * sh;
+                const real hw = 0.5 * alim_ * sh * sh;
                 if (!soft && sel) {
                     // the row reads  xi.w_kc >= rr  for the position offset w = Lambda a;  |w_kc| <= hw per axis
                     // (the right-hand side of the row without the reference's division: dist (xi.p / dist) = xi.p)
-                    const double rr = dist * (rmin - dist) + (x0 * px + x1 * py + x2 * pz) - (x0 * a0x + x1 * a0y + x2 * a0z);
-                    const double rng = (fabs(x0) + fabs(x1) + fabs(x2)) * hw;
-                    if (rr - (x0 * L.w_s[3 * kc] + x1 * L.w_s[3 * kc + 1] + x2 * L.w_s[3 * kc + 2]) > 1e-10) key_steps |= 1u << kc;
+                    const real rr = dist * (rmin - dist) + (x0 * px + x1 * py + x2 * pz) - (x0 * a0x + x1 * a0y + x2 * a0z);
+                    const real rng = (fabs(x0) + fabs(x1) + fabs(x2)) * hw;
+                    if (rr - (x0 * w_s[3 * kc] + x1 * w_s[3 * kc + 1] + x2 * w_s[3 * kc + 2]) > (real)0.1 * MARG) key_steps |= 1u << kc;
                     key_tight |= (rr > 0.8 * rng) ? 8u : ((rr > 0.5 * rng) ? 4u : ((rr > 0.0) ? 2u : 1u));
                 }
-                const double lin_min = x0 * (a0x - (px - dx)) + x1 * (a0y - (py - dy)) + x2 * (a0z - (pz - dz)) - (fabs(x0) + fabs(x1) + fabs(x2)) * hw;
-                if (lin_min >= dist * rmin + 1e-9 && !P.no_prune) sel = false;
+                const real lin_min = x0 * (a0x - (px - dx)) + x1 * (a0y - (py - dy)) + x2 * (a0z - (pz - dz)) - (fabs(x0) + fabs(x1) + fabs(x2)) * hw;
+                if (lin_min >= dist * rmin + MARG && !P.no_prune) sel = false;
                 // Exact infeasibility certificate for rows without slack: if even the BEST point of the
                 // reachable box violates the row (max of the linearised distance < dist*rmin), no acceleration
                 // within |a| <= alim satisfies it -> the QP is infeasible; the long active-set proof is skipped.
                 if (sel) {
-                    const double lin_max = lin_min + 2.0 * (fabs(x0) + fabs(x1) + fabs(x2)) * hw;
+                    const real lin_max = lin_min + 2.0 * (fabs(x0) + fabs(x1) + fabs(x2)) * hw;
                     if (!soft) {
-                        if (lin_max < dist * rmin - 1e-9) cert_infeasible = true;
+                        if (lin_max < dist * rmin - MARG) cert_infeasible = true;
                     } else if (var == VAR_BOUND || var == VAR_BOUND2 || var == VAR_ALL3 || cppv) {
                         // Soft rows with a bounded slack (coefficient dist): the row needs
                         //   lin >= dist*(rmin + eps),  eps >= slb * 2^t at ladder level t (solveSoftDMPCbound.m:147-153),
                         // so every level with lin_max < dist*(rmin + slb 2^t) is certainly infeasible and the
                         // retry ladder can start at the first level that passes this necessary test.
-                        double slb_t = (var == VAR_BOUND) ? -0.05 : (cppv ? -(double)0.01f : -0.01);
+                        real slb_t = (var == VAR_BOUND) ? -0.05 : (cppv ? -(real)0.01f : -0.01);
                         int t = 0;
-                        while (t < 40 && lin_max < dist * (rmin + slb_t) - 1e-9) { slb_t *= 2.0; ++t; }
+                        while (t < 40 && lin_max < dist * (rmin + slb_t) - MARG) { slb_t *= 2.0; ++t; }
                         if (t > ladder_start) ladder_start = t;
                     }
                 }
@@ -415,14 +427,14 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
             const int pos = nr + lanes_below(m, lane);
             if (sel && pos < nrmax) {
                 // r = dist*(rmin - dist + diff*p/dist) - diff*A_initp(kc)*[po;vo]   (:21)
-                const double rr = dist * (rmin - dist + (x0 * px + x1 * py + x2 * pz) / dist) - (x0 * a0x + x1 * a0y + x2 * a0z);
+                const real rr = dist * (rmin - dist + (x0 * px + x1 * py + x2 * pz) / dist) - (x0 * a0x + x1 * a0y + x2 * a0z);
                 L.r_xi[3 * pos] = x0; L.r_xi[3 * pos + 1] = x1; L.r_xi[3 * pos + 2] = x2;
                 L.r_b[pos] = -rr;
                 L.r_kc[pos] = kc;
                     if (soft) {
-                    double sd = dist, st = P.term, slb = -0.05;
+                    real sd = dist, st = P.term, slb = -0.05;
                     if (var == VAR_BOUND2 || var == VAR_ALL3) slb = -0.01;           // bound2:77, all:92
-                    else if (cppv) slb = -(double)0.01f;                              // dmpc.cpp:907-914,1079: -eps <= lim, float lim = 0.01
+                    else if (cppv) slb = -(real)0.01f;                              // dmpc.cpp:907-914,1079: -eps <= lim, float lim = 0.01
                     else if (var == VAR_SOFTALL) { sd = 1.0; st = -1e5; slb = -INFINITY; }  // solveSoftDMPC.m:21,65
                     else if (var == VAR_REPAIR) { st = P.term / dist; slb = -INFINITY; }    // repair:77,81
                     L.r_sd[pos] = sd; L.r_st[pos] = st; L.r_slb[pos] = slb;
@@ -434,21 +446,21 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
         // rows of horizon step ke (positions evaluated there) constraining step kc for every neighbour whose
         // distance AT STEP ksel is < sel_r (viol_constr of CheckCollSoftDMPC.m:12) or for all neighbours,
         // in increasing neighbour index (CollConstrSoftDMPC.m:11-31)
-        auto build_rows = [&](int ksel, int ke, int kc, double sel_r, bool sel_all) {
-            const double qx = L.own_s[3 * ksel], qy = L.own_s[3 * ksel + 1], qz = L.own_s[3 * ksel + 2];
-            const double px = L.own_s[3 * ke], py = L.own_s[3 * ke + 1], pz = L.own_s[3 * ke + 2];
+        auto build_rows = [&](int ksel, int ke, int kc, real sel_r, bool sel_all) {
+            const real qx = own_s[3 * ksel], qy = own_s[3 * ksel + 1], qz = own_s[3 * ksel + 2];
+            const real px = own_s[3 * ke], py = own_s[3 * ke + 1], pz = own_s[3 * ke + 2];
             for (int e0 = 0; e0 < n_entries; e0 += 64) {
                 int r, jc;
                 const bool valid = entry(e0, r, jc);
-                const double *nbp = P.lT + ((size_t)(r * S + scene) * N3) * C + jc;
-                const double *base = nbp + (size_t)(3 * ke) * C, *bsel = nbp + (size_t)(3 * ksel) * C;
-                const double dx = px - base[0], dy = py - base[(size_t)C], dz = pz - base[2 * (size_t)C];
-                const double ez = dz * P.e1z;
-                const double dist = sqrt(dx * dx + dy * dy + ez * ez);
-                double dsel = dist;
+                const real *nbp = tab + ((size_t)(r * S + scene) * N3) * C + jc;
+                const real *base = nbp + (size_t)(3 * ke) * C, *bsel = nbp + (size_t)(3 * ksel) * C;
+                const real dx = px - base[0], dy = py - base[(size_t)C], dz = pz - base[2 * (size_t)C];
+                const real ez = dz * e1z;
+                const real dist = sqrt(dx * dx + dy * dy + ez * ez);
+                real dsel = dist;
                 if (ksel != ke && !sel_all) {
-                    const double sx = qx - bsel[0], sy = qy - bsel[(size_t)C];
-                    const double sz = (qz - bsel[2 * (size_t)C]) * P.e1z;
+                    const real sx = qx - bsel[0], sy = qy - bsel[(size_t)C];
+                    const real sz = (qz - bsel[2 * (size_t)C]) * e1z;
                     dsel = sqrt(sx * sx + sy * sy + sz * sz);
                 }
                 emit_row(valid && (sel_all || dsel < sel_r), kc, dx, dy, dz, dist, px, py, pz);
@@ -466,19 +478,19 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
                 const bool have = b0 + lane < ncand;
                 const int code = have ? scan_cand[b0 + lane] : 0;
                 const int kk = (code >> 28) & 15, rr = (code >> 20) & 255, jj = code & 0xfffff;
-                const double *nb = P.lT + ((size_t)(rr * S + scene) * N3 + 3 * kk) * C + jj;
-                const double px = L.own_s[3 * kk], py = L.own_s[3 * kk + 1], pz = L.own_s[3 * kk + 2];
-                const double dx = px - nb[0], dy = py - nb[(size_t)C], dz = pz - nb[2 * (size_t)C];
-                const double ez = dz * P.e1z;
-                const double dist = sqrt(dx * dx + dy * dy + ez * ez);
+                const real *nb = tab + ((size_t)(rr * S + scene) * N3 + 3 * kk) * C + jj;
+                const real px = own_s[3 * kk], py = own_s[3 * kk + 1], pz = own_s[3 * kk + 2];
+                const real dx = px - nb[0], dy = py - nb[(size_t)C], dz = pz - nb[2 * (size_t)C];
+                const real ez = dz * e1z;
+                const real dist = sqrt(dx * dx + dy * dy + ez * ez);
                 emit_row(have && dist < 1.0, kk, dx, dy, dz, dist, px, py, pz);
             }
             ncand = 0;
             LSYNC();
         };
         unsigned anyb = 0;
-        double mind0 = 1e300;
-        const double rmin2_hi = rmin * rmin * (1.0 + 1e-9);
+        real mind0 = INFINITY;
+        const real rmin2_hi = rmin * rmin * ((real)1.0 + (real)4.0 * MARG);
         if (var == VAR_HARD) {
             // solveHardDMPC.m:18-22 + CollConstrHardDMPC.m:19: every k, neighbours with dist < 1.  Two passes.  The first
             // only tests the 15 N distances and compacts the (step, neighbour) candidates -- about one in ten -- into an
@@ -503,7 +515,7 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
                     // room for a whole group of rounds is made BEFORE its loads are issued, so that the row builder never
                     // runs with the group's registers live
                     if (ncand + 64 * UR > SCAN_CAND_CAP) flush_candidates();
-                    double nx[UR], ny[UR], nz[UR];
+                    real nx[UR], ny[UR], nz[UR];
                     int kk[UR], code[UR];
                     bool ok[UR];
 #pragma unroll
@@ -522,7 +534,7 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
                                 valid = valid && !(r == P.g_local && jc == cl) && jc < C - ((P.short_from && r >= P.short_from) ? 1 : 0);
                             }
                         } else valid = valid && jc != cl;
-                        const double *nb = P.lT + ((size_t)(single ? P.g_local : r) * S + scene) * slab + (unsigned)(3 * k * C + jc);
+                        const real *nb = tab + ((size_t)(single ? P.g_local : r) * S + scene) * slab + (unsigned)(3 * k * C + jc);
                         nx[u] = nb[0]; ny[u] = nb[(size_t)C]; nz[u] = nb[2 * (size_t)C];
                         kk[u] = k; code[u] = (k << 28) | (r << 20) | jc; ok[u] = valid;
                     }
@@ -530,13 +542,13 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
                     for (int u = 0; u < UR; ++u) {
                         if (e0 + 64u * u >= total) break;
                         const int k = kk[u];
-                        const double px = L.own_s[3 * k], py = L.own_s[3 * k + 1], pz = L.own_s[3 * k + 2];
-                        const double dx = px - nx[u], dy = py - ny[u], dz = pz - nz[u];
-                        const double ez = dz * P.e1z;
-                        const double d2 = dx * dx + dy * dy + ez * ez;
+                        const real px = own_s[3 * k], py = own_s[3 * k + 1], pz = own_s[3 * k + 2];
+                        const real dx = px - nx[u], dy = py - ny[u], dz = pz - nz[u];
+                        const real ez = dz * e1z;
+                        const real d2 = dx * dx + dy * dy + ez * ez;
                         // squared distance against a slightly inflated threshold (a superset); the exact `norm(...) < 1`
                         // decision is made on the IEEE square root in the second pass
-                        const bool cand = ok[u] && d2 < 1.0 + 1e-9;
+                        const bool cand = ok[u] && d2 < (real)1.0 + (real)4.0 * MARG;
                         const unsigned long long cm = __ballot(cand);
                         if (cm) {
                             if (cand) scan_cand[ncand + lanes_below(cm, lane)] = code[u];
@@ -551,13 +563,13 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
             for (int e0 = 0; e0 < n_entries; e0 += 64) {
                 int r, jc;
                 const bool valid = entry(e0, r, jc);
-                const double *base = P.lT + ((size_t)(r * S + scene) * N3) * C + jc;
+                const real *base = tab + ((size_t)(r * S + scene) * N3) * C + jc;
                 // the 45 component rows of a neighbour are C doubles apart: a running (uniform) offset, advanced by one
                 // 64-bit scalar add per load (written as (3k+c)*C the compiler spends five scalar instructions per load)
                 size_t roff = 0;
     #pragma unroll 1
                 for (int kg = 0; kg < 3; ++kg) {   // not unrolled: keeps the scan's register footprint small
-                    double nx[5], ny[5], nz[5];
+                    real nx[5], ny[5], nz[5];
     #pragma unroll
                     for (int u = 0; u < 5; ++u) {
                         nx[u] = base[roff]; roff += (size_t)C; asm volatile("" : "+s"(roff));
@@ -567,15 +579,15 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
     #pragma unroll
                     for (int u = 0; u < 5; ++u) {
                         const int k = 5 * kg + u;
-                        const double px = L.own_s[3 * k], py = L.own_s[3 * k + 1], pz = L.own_s[3 * k + 2];
-                        const double dx = px - nx[u], dy = py - ny[u], dz = pz - nz[u];
-                        const double ez = dz * P.e1z;
-                        const double d2 = dx * dx + dy * dy + ez * ez;
+                        const real px = own_s[3 * k], py = own_s[3 * k + 1], pz = own_s[3 * k + 2];
+                        const real dx = px - nx[u], dy = py - ny[u], dz = pz - nz[u];
+                        const real ez = dz * e1z;
+                        const real d2 = dx * dx + dy * dy + ez * ez;
                         // The IEEE square root (a dozen instructions in fp64) is taken only when some lane of the
                         // wave can pass the distance test: d2 is first compared against a slightly inflated squared
                         // threshold (a superset), the exact `norm(...) < r` decision is then made on sqrt(d2) itself.
                         if (__any(valid && d2 < rmin2_hi)) {
-                            const double dist = sqrt(d2);
+                            const real dist = sqrt(d2);
                             if (valid && dist < rmin) anyb |= (1u << k);       // CheckCollSoftDMPC.m:11
                         }
                         if (k == 0 && valid) mind0 = fmin(mind0, d2);           // squared; the root is taken once below
@@ -592,10 +604,10 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
                 if (!((anyb >> k) & 1u)) continue;
                 if (var == VAR_ALL3) violation = true;   // solveSoftDMPCall.m:22 (some_violation)
                 if ((coll_check || cppv) && k == 0) {
-                    mind0 = sqrt(wave_min(mind0));   // min of the roots == root of the min (sqrt is monotone)
+                    mind0 = sqrt((real)wave_min((double)mind0));   // min of the roots == root of the min (sqrt is monotone)
                     if (coll_check && mind0 < rmin - 0.05) { status = ST_COLL; viol_k = 1; break; }   // :25-31
                     // cpp: `dist < _rmin - _collision_tol` (floats) raises execution_ended, the build goes on (dmpc.cpp:419-424)
-                    if (cppv && mind0 < (double)((float)rmin - 0.05f)) coll_flag = true;
+                    if (cppv && mind0 < (real)((float)rmin - 0.05f)) coll_flag = true;
                 }
                 if (skip_k1 && k == 0) continue;          // solveSoftDMPCbound2.m:29-31
                 viol_k = k + 1; violation = true; rows_exist = true;
@@ -606,7 +618,7 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
                     const int kc = (var == VAR_BOUND2 || var == VAR_CPP2) ? k - 1 : k;   // CollConstrSoftDMPC2.m:8; dmpc.cpp:516
                     // neighbour radius: 3 rmin (CheckCollSoftDMPC.m:12); cpp: _rmin*(1+(float)k/_k_hor) in float arithmetic
                     // (dmpc.cpp:418) -- __f*_rn keep the three float operations unfused
-                    const double near_r = cppv ? (double)__fmul_rn((float)rmin, __fadd_rn(1.0f, __fdiv_rn((float)k, (float)K))) : 3.0 * rmin;
+                    const real near_r = cppv ? (real)__fmul_rn((float)rmin, __fadd_rn(1.0f, __fdiv_rn((float)k, (float)K))) : 3.0 * rmin;
                     build_rows(k, k, kc, near_r, !near_sel);
                 }
                 break;
@@ -649,7 +661,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char dmpc_smem[];
 // XCD-aware mapping: workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8, private L2 each), so they are
 // renumbered such that every XCD works on whole scenes: a scene's prediction table is then fetched into ONE L2 instead of
 // eight.  Pure performance remap (a bijection on [0, gridDim)).
-template <bool SOFT>
+template <bool SOFT, typename TT>
 __global__ __launch_bounds__(64 * SCAN_WAVES_PER_WG, SCAN_WAVES_PER_SIMD) void dmpc_scan_kernel(StepParams P)
 {
     const int W = (int)(blockDim.x >> 6);
@@ -659,7 +671,7 @@ __global__ __launch_bounds__(64 * SCAN_WAVES_PER_WG, SCAN_WAVES_PER_SIMD) void d
     for (int xx = 0; xx < x; ++xx) off += (nb - xx + 7) >> 3;
     const int agent = (off + y) * W + wave, total = P.S * P.c_count;
     if (agent >= total) return;
-    scan_body<SOFT>(P, lane, agent, dmpc_smem + (size_t)wave * P.lds_per_wave);
+    scan_body<SOFT, TT>(P, lane, agent, dmpc_smem + (size_t)wave * P.lds_per_wave);
 }
 // Solve phase, one agent per 64-thread workgroup (shallow launches: bound by their slowest agent)
 template <bool SOFT, int QCAP>
@@ -730,18 +742,19 @@ __global__ __launch_bounds__(512, 1) void dmpc_solve_persist_kernel(StepParams P
 // The scan culls whole neighbour chunks with it (a neighbour can come within R of the agent at some step
 // only if the boxes are within R per axis), which turns the O(K N) table reads per agent into O(N) 48-B
 // box reads plus the few chunks that really contain near neighbours.  Conservative => results unchanged.
-__global__ void bbox_kernel(int total, int C, const double *__restrict__ lT, double *__restrict__ bbox)
+template <typename TT>
+__global__ void bbox_kernel(int total, int C, const TT *__restrict__ lT, double *__restrict__ bbox)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;   // enumerates (g*S + s)*C + c
     if (i >= total) return;
     const int c = i % C;
     const size_t gs = (size_t)(i / C);
-    const double *src = lT + gs * N3 * C + c;
+    const TT *src = lT + gs * N3 * C + c;
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
     for (int k = 0; k < K; ++k)
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            const double v = src[(size_t)(3 * k + a) * C];
+            const double v = (double)src[(size_t)(3 * k + a) * C];
             lo[a] = fmin(lo[a], v); hi[a] = fmax(hi[a], v);
         }
     double *dst = bbox + gs * 6 * C + c;
@@ -788,6 +801,12 @@ __global__ void table_from_rows_kernel(int S, int G, int C, const double *__rest
         const int g = (int)(u / S);
         lT[t] = rows[((size_t)s * (G * C) + (size_t)g * C + c) * N3 + j];
     }
+}
+
+// mixed precision: the fp32 copy of a table the scan of the next step reads
+__global__ void table_to_f32_kernel(size_t n, const double *__restrict__ src, float *__restrict__ dst)
+{
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) dst[t] = (float)src[t];
 }
 
 // x <- first horizon column for solved agents (dmpc_soft_bound.m:132-134)

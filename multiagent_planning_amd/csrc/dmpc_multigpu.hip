@@ -177,6 +177,7 @@ extern "C" int dmpc_step_sharded_device(dmpc_ctx *ctx, int S, int N, const doubl
     int32_t lo = 0, cnt = 0, cmax = 0;
     if (S < 1 || dmpc_partition(N, G, rank, &lo, &cnt, &cmax)) FAIL(ctx, "dmpc_step_sharded_device: bad S / N for this communicator");
     if (!lT || !x_p || !x_v || !x_a || !pf || !p_out || !v_out || !a_out || !lT_next || !status) FAIL(ctx, "dmpc_step_sharded_device: NULL pointer");
+    if (ctx->precision != DMPC_PREC_F64) FAIL(ctx, "dmpc_step_sharded_device: DMPC_PREC_F64 contexts only");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
     const size_t chunk = (size_t)S * N3 * cmax;
@@ -198,6 +199,7 @@ extern "C" int dmpc_transition_sharded(dmpc_ctx *ctx, int S, int N, const double
     if (S < 1 || K_T_max < 2 || !po || !pf || !K_T_used || !scene_status || ((pk || vk || ak) && !(pk && vk && ak)) ||
         dmpc_partition(N, G, rank, &lo, &cnt, &cmax))
         FAIL(ctx, "dmpc_transition_sharded: bad arguments");
+    if (ctx->precision != DMPC_PREC_F64) FAIL(ctx, "dmpc_transition_sharded: DMPC_PREC_F64 contexts only");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const size_t A = (size_t)S * N, Aown = (size_t)S * cnt, tab = (size_t)G * S * N3 * cmax, chunk = (size_t)S * N3 * cmax;
     const size_t hist = Aown * (size_t)K_T_max * 24;

@@ -839,7 +839,8 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
         if (Q.lT_next) {
             // next table chunk [S][3K][C]: uniform 64-bit base, 32-bit per-lane offset; unsolved agents keep their old prediction
             const int Cq = Q.C;
-            const double *own = Q.lT + ((size_t)(Q.g_local * Q.S + scene) * N3) * Cq + cl;
+            // (mixed precision: Q.lT is the fp32 table of the scan; the fp64 predictions of this chunk are in Q.own_prev)
+            const double *own = Q.own_prev ? Q.own_prev + (size_t)scene * N3 * Cq + cl : Q.lT + ((size_t)(Q.g_local * Q.S + scene) * N3) * Cq + cl;
             Q.lT_next[(size_t)scene * N3 * Cq + cl + (size_t)(unsigned)(lane * Cq)] = solved ? p_out : own[(size_t)(unsigned)(lane * Cq)];
         }
     }

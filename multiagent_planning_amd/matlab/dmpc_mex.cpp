@@ -57,7 +57,7 @@ static dmpc_params read_params(const mxArray *s)
 static dmpc_ctx *context(const dmpc_params &p)
 {
     if (!g_ctx) {
-        g_ctx = dmpc_create(&p, 0);
+        g_ctx = dmpc_create(&p, 0, DMPC_PREC_F64);
         if (!g_ctx) mexErrMsgIdAndTxt("dmpc:create", "%s", dmpc_last_error(nullptr));
         g_prm = p;
         mexAtExit(cleanup);

@@ -44,7 +44,7 @@ def test_posvel_matrix():
 def test_bad_params_rejected():
     L = _lib.load()
     p = _lib.make_params("bound", K=10)
-    assert not L.dmpc_create(ctypes.byref(p), 0)
+    assert not L.dmpc_create(ctypes.byref(p), 0, 0)
     assert b"K" in L.dmpc_last_error(None)
 
 
