@@ -426,7 +426,10 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     }
     P.dbg = ctx->dbg; P.dbg_agent = ctx->dbg_agent; P.dbg_cap = ctx->dbg_cap;
     P.iter_cap = ctx->iter_cap;
-    const int q1 = ctx->single_tier ? full_qcap(p.variant) : tier1_qcap(p.variant), q2 = full_qcap(p.variant);
+    // shallow launches (a scene or a few: bound by the latency of their slowest agent, LDS is no constraint) solve with the
+    // full working-set capacity in one launch; deep launches use the small first tier and re-solve the few that outgrow it
+    const bool shallow = (long)S * c_count < 16L * (ctx->num_cu > 0 ? ctx->num_cu : 256) * 8 && !ctx->force_persist && !getenv("DMPC_TIER1_QCAP");
+    const int q1 = (ctx->single_tier || shallow) ? full_qcap(p.variant) : tier1_qcap(p.variant), q2 = full_qcap(p.variant);
     const bool two_tier = q1 < q2;
     // neighbour list of the scan: a quarter of the scene (fast agents have long horizon boxes), 1024..8192 entries
     int nbr_cap = 0;
@@ -464,7 +467,7 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
         else hipLaunchKernelGGL(bbox_kernel<double>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, C, lT, ctx->bbox.as<double>());
         P.bbox = ctx->bbox.as<double>();
     }
-    HIPCHK(ctx, hipMemsetAsync(ctx->counter.p, 0, 16, st));   // queue heads of the persistent solve launches
+    if (!shallow) HIPCHK(ctx, hipMemsetAsync(ctx->counter.p, 0, 16, st));   // queue heads of the persistent solve launches
     // phase 0: scan + rows
     P.qcap = q1; P.only_flagged = 0; P.qover_bit = two_tier ? ST_QOVER : ST_CAPACITY;
     {
@@ -537,10 +540,10 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     // bound by their single slowest agent, which runs ~4 % faster in the leaner one-agent-per-workgroup kernel.
     size_t per1 = 0, per2 = 0;
     const int pw1 = persist_waves(q1, per1), pw2 = persist_waves(q2, per2);
-    const bool deep = (long)S * c_count >= 16L * ctx->num_cu * (pw1 > 0 ? pw1 : 1);
+    const bool deep = !shallow && (long)S * c_count >= 16L * ctx->num_cu * (pw1 > 0 ? pw1 : 1);
     // tier 2 as persistent waves over the flagged list (nearly always empty: the launch then costs a few microseconds
     // instead of one workgroup per agent just to find out that there is nothing to do)
-    const bool t2_list = two_tier && !ctx->no_persist && pw2 >= 2 && ctx->num_cu >= 1;
+    const bool t2_list = two_tier && !shallow && !ctx->no_persist && pw2 >= 2 && ctx->num_cu >= 1;
     if (t2_list) { P.flag_count = ctx->counter.as<int>() + 2; P.flag_list = ctx->flag_list.as<int>(); }
     if (solve_launch(q1, lds1, 0, deep || ctx->force_persist)) return -1;
     if (two_tier) {   // tier 2: only agents flagged ST_QOVER do any work
@@ -892,12 +895,11 @@ static int transition_one(dmpc_ctx *ctx, int S, int N, const double *po, const d
                         ctx->vout.as<double>(), ctx->aout.as<double>(), nxt, ctx->status.as<int32_t>(), nullptr, st,
                         ctx->scene_done.as<int>(), 0, mixed ? ctx->lTf.as<float>() : nullptr))
             return -1;
-        hipLaunchKernelGGL(advance_kernel, dim3(rb), dim3(256), 0, st, (int)A, ctx->pout.as<double>(), ctx->vout.as<double>(),
-                           ctx->aout.as<double>(), (const int *)ctx->status.as<int32_t>(), xp, xv, xa);
-        hipLaunchKernelGGL(record_kernel, dim3(rb), dim3(256), 0, st, S, N, K_T_max, k, xp, xv, xa, ctx->hist_p.as<double>(),
-                           ctx->hist_v.as<double>(), ctx->hist_a.as<double>());
-        hipLaunchKernelGGL(scene_reduce_kernel, dim3((unsigned)S), dim3(256), 0, st, N, error_tol, xp, ctx->pf.as<double>(),
-                           (const int *)ctx->status.as<int32_t>(), ctx->flags.as<int>() + (size_t)k * S * 2, ctx->scene_done.as<int>());
+        // state advance + history column + scene verdict in one launch
+        hipLaunchKernelGGL(post_step_kernel, dim3((unsigned)S), dim3(N >= 256 ? 256 : 128), 0, st, N, K_T_max, k, error_tol,
+                           (const double *)ctx->pout.as<double>(), (const double *)ctx->vout.as<double>(), (const double *)ctx->aout.as<double>(),
+                           (const int *)ctx->status.as<int32_t>(), xp, xv, xa, (const double *)ctx->pf.as<double>(), ctx->hist_p.as<double>(),
+                           ctx->hist_v.as<double>(), ctx->hist_a.as<double>(), ctx->flags.as<int>() + (size_t)k * S * 2, ctx->scene_done.as<int>());
         HIPCHK(ctx, hipGetLastError());
         std::swap(cur, nxt);   // l = new_l (dmpc_soft_bound.m:146)
         if (k % chunk == 0 || k == K_T_max - 1) {

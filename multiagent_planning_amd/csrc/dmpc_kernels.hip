@@ -847,6 +847,45 @@ __global__ void record_kernel(int S, int N, int KT, int k, const double *__restr
     pk[o] = x_p[i]; vk[o] = x_v[i]; ak[o] = x_a[i];
 }
 
+// The three small kernels that follow a solve in a transition, in one launch (one block per scene; a 100-agent step is
+// latency bound, and three launches cost more than their work): x <- first horizon column of the solved agents
+// (dmpc_soft_bound.m:132-134), the history column k (pk/vk/ak(:,k,n)), then the scene verdict as scene_reduce_kernel.
+__global__ void post_step_kernel(int N, int KT, int k, double tol, const double *__restrict__ p, const double *__restrict__ v,
+                                 const double *__restrict__ a, const int *__restrict__ status, double *x_p, double *x_v, double *x_a,
+                                 const double *__restrict__ pf, double *pk, double *vk, double *ak, int *flags, int *scene_done)
+{
+    __shared__ double smax[256];
+    __shared__ int sor[256];
+    const int s = blockIdx.x;
+    double m = 0.0; int o = 0;
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+        const size_t ag = (size_t)s * N + i, b = ag * 3;
+        const int st = status[ag];
+        double xp[3], xv[3], xa[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            if (st & ST_SOLVED) { xp[d] = p[ag * N3 + d]; xv[d] = v[ag * N3 + d]; xa[d] = a[ag * N3 + d]; x_p[b + d] = xp[d]; x_v[b + d] = xv[d]; x_a[b + d] = xa[d]; }
+            else { xp[d] = x_p[b + d]; xv[d] = x_v[b + d]; xa[d] = x_a[b + d]; }
+            const size_t ho = (ag * KT + k) * 3 + d;
+            pk[ho] = xp[d]; vk[ho] = xv[d]; ak[ho] = xa[d];
+        }
+        const double dx = xp[0] - pf[b], dy = xp[1] - pf[b + 1], dz = xp[2] - pf[b + 2];
+        m = fmax(m, sqrt(dx * dx + dy * dy + dz * dz));
+        o |= st;
+    }
+    smax[threadIdx.x] = m; sor[threadIdx.x] = o;
+    __syncthreads();
+    for (int w = blockDim.x / 2; w >= 1; w >>= 1) {
+        if ((int)threadIdx.x < w) { smax[threadIdx.x] = fmax(smax[threadIdx.x], smax[threadIdx.x + w]); sor[threadIdx.x] |= sor[threadIdx.x + w]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const int reached = smax[0] < tol ? 1 : 0;
+        flags[(size_t)s * 2] = reached; flags[(size_t)s * 2 + 1] = sor[0];
+        if (scene_done && (reached || (sor[0] & ~ST_SOLVED))) scene_done[s] = 1;
+    }
+}
+
 // one block per scene: flags[0] = ReachedGoal.m:3-11 (max_i ||p_i - pf_i|| < tol), flags[1] = OR of status bits
 __global__ void scene_reduce_kernel(int N, double tol, const double *__restrict__ x_p, const double *__restrict__ pf,
                                     const int *__restrict__ status, int *flags, int *scene_done)

@@ -244,14 +244,12 @@ extern "C" int dmpc_transition_sharded(dmpc_ctx *ctx, int S, int N, const double
         if (launch_step(ctx, S, G, cmax, rank, 0, cnt, cur, xp, xv, xa, own_pf, ctx->pout.as<double>(), ctx->vout.as<double>(),
                         ctx->aout.as<double>(), ctx->sendbuf.as<double>(), ctx->status.as<int32_t>(), nullptr, st, ctx->scene_done.as<int>(), rem))
             return -1;
-        hipLaunchKernelGGL(advance_kernel, dim3(sb), dim3(256), 0, st, (int)Aown, ctx->pout.as<double>(), ctx->vout.as<double>(), ctx->aout.as<double>(),
-                           (const int *)ctx->status.as<int32_t>(), xp, xv, xa);
-        hipLaunchKernelGGL(record_kernel, dim3(sb), dim3(256), 0, st, S, (int)cnt, K_T_max, k, xp, xv, xa, ctx->hist_p.as<double>(),
-                           ctx->hist_v.as<double>(), ctx->hist_a.as<double>());
-        // this rank's verdict per scene (all own agents at their goals / OR of their status bits), then the exchange:
-        // predictions into the next table, verdicts of all ranks next to them
-        hipLaunchKernelGGL(scene_reduce_kernel, dim3((unsigned)S), dim3(256), 0, st, (int)cnt, error_tol, xp, own_pf, (const int *)ctx->status.as<int32_t>(),
-                           ctx->mg_floc.as<int>(), (int *)nullptr);
+        // state advance + history column + this rank's verdict per scene (all own agents at their goals / OR of their status
+        // bits) in one launch, then the exchange: predictions into the next table, verdicts of all ranks next to them
+        hipLaunchKernelGGL(post_step_kernel, dim3((unsigned)S), dim3(cnt >= 256 ? 256 : 128), 0, st, (int)cnt, K_T_max, k, error_tol,
+                           (const double *)ctx->pout.as<double>(), (const double *)ctx->vout.as<double>(), (const double *)ctx->aout.as<double>(),
+                           (const int *)ctx->status.as<int32_t>(), xp, xv, xa, (const double *)own_pf, ctx->hist_p.as<double>(), ctx->hist_v.as<double>(),
+                           ctx->hist_a.as<double>(), ctx->mg_floc.as<int>(), (int *)nullptr);
         HIPCHK(ctx, hipGetLastError());
         if (exchange(ctx, ctx->sendbuf.as<double>(), nxt, chunk, ctx->mg_floc.as<int>(), ctx->mg_fall.as<int>(), S * 2, st)) return -1;
         hipLaunchKernelGGL(mg::combine_flags_kernel, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, st, G, S, (const int *)ctx->mg_fall.as<int>(),

@@ -209,3 +209,22 @@ def test_sharded_transition_loop_on_device_matches_dmpc_transition():
     for s in range(S):
         n = int(ref["K_T_used"][s])
         assert np.array_equal(pk[s][:, :n], ref["pk"][s][:, :n])
+
+
+@pytest.mark.parametrize("S", [40, 288])
+def test_transition_batches_of_every_depth_equal_single_scene_runs(S):
+    """dmpc_transition picks its launch form by the depth of the batch (one-agent workgroups with one working-set tier for
+    shallow batches, persistent waves with a ticket queue and a second tier for deep ones, split halves from 32 scenes on);
+    whatever it picks, a scene must come out exactly as when it runs alone.  288 x 100 agents sits between the two regimes."""
+    cfg = wl.CONFIGS["C4"]
+    N = 100
+    kw = wl.solver_kwargs(cfg, N)
+    po, pf = wl.make_scenes(cfg, S, N, wl.SEED0 + 55)
+    d = mp.Dmpc("bound", **kw)
+    big = d.transition(po, pf, 151, cfg["error_tol"])
+    assert ((big["scene_status"] & mp.ST_REACHED) != 0).mean() > 0.8
+    for s in (0, S // 2, S - 1):
+        one = mp.Dmpc("bound", **kw).transition(po[s:s + 1], pf[s:s + 1], 151, cfg["error_tol"])
+        assert int(one["K_T_used"][0]) == int(big["K_T_used"][s]) and int(one["scene_status"][0]) == int(big["scene_status"][s]), s
+        u = int(one["K_T_used"][0])      # (columns past the stop hold the frozen state in a batch, zeros in a single run)
+        assert np.array_equal(one["pk"][0][:, :u], big["pk"][s][:, :u]) and np.array_equal(one["ak"][0][:, :u], big["ak"][s][:, :u]), s
