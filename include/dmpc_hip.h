@@ -88,6 +88,11 @@ typedef struct {
     double Q1, S1;     /* collision-case weights                                             */
     double term;       /* linear slack penalty (negative)                                    */
     double pmin[3], pmax[3];
+    /* Weights of the two collision-free cost cases.  0 = the constants hard-coded at the reference's HEAD
+     * (solveSoftDMPCbound.m:44-52, dmpc.cpp:922-938): far from the goal Q = 1000, within 1 m Q = 10000, S = 10 in both.
+     * Earlier revisions of dmpc/cpp used other values: the recorded dmpc/cpp_results/trajectories (200-agents).txt is
+     * reproduced to its 6 printed digits with Qfar = 100, Qnear = 1000 (tests/test_oracle_golden.py). */
+    double Qfar, Qnear, Sfree;
 } dmpc_params;
 
 typedef struct dmpc_ctx dmpc_ctx;

@@ -40,6 +40,7 @@ class DmpcParams(C.Structure):
         ("h", C.c_double), ("rmin", C.c_double), ("c", C.c_double), ("alim", C.c_double),
         ("Q1", C.c_double), ("S1", C.c_double), ("term", C.c_double),
         ("pmin", C.c_double * 3), ("pmax", C.c_double * 3),
+        ("Qfar", C.c_double), ("Qnear", C.c_double), ("Sfree", C.c_double),
     ]
 
 
@@ -121,7 +122,7 @@ def load():
 
 
 def make_params(variant="bound", K=K_HOR, h=0.2, rmin=0.35, c=2.0, alim=1.0, Q1=1000.0, S1=100.0, term=-5e4,
-                pmin=(-2.5, -2.5, 0.2), pmax=(2.5, 2.5, 2.2), order=2, max_tries=0):
+                pmin=(-2.5, -2.5, 0.2), pmax=(2.5, 2.5, 2.2), order=2, max_tries=0, Qfar=0.0, Qnear=0.0, Sfree=0.0):
     p = DmpcParams()
     p.K, p.order, p.max_tries = int(K), int(order), int(max_tries)
     p.variant = VARIANTS[variant] if isinstance(variant, str) else int(variant)
@@ -129,6 +130,7 @@ def make_params(variant="bound", K=K_HOR, h=0.2, rmin=0.35, c=2.0, alim=1.0, Q1=
     for i in range(3):
         p.pmin[i] = float(pmin[i])
         p.pmax[i] = float(pmax[i])
+    p.Qfar, p.Qnear, p.Sfree = float(Qfar), float(Qnear), float(Sfree)
     return p
 
 

@@ -260,8 +260,9 @@ static int upload_tables(dmpc_ctx *ctx)
 {
     std::vector<double> t(TAB_DOUBLES, 0.0);
     const dmpc_params &p = ctx->prm;
-    const double qs[3] = {1000.0, 10000.0, p.Q1};                                             // far (:44-47), near (:49-52), coll (:54-57)
-    const double ss[3] = {10.0, 10.0, (p.variant == DMPC_VAR_ALL3) ? 10.0 : p.S1};            // all:71
+    const double sfree = p.Sfree > 0 ? p.Sfree : 10.0;
+    const double qs[3] = {p.Qfar > 0 ? p.Qfar : 1000.0, p.Qnear > 0 ? p.Qnear : 10000.0, p.Q1};   // far (:44-47), near (:49-52), coll (:54-57)
+    const double ss[3] = {sfree, sfree, (p.variant == DMPC_VAR_ALL3) ? 10.0 : p.S1};             // all:71
     for (int c = 0; c < 3; ++c) {
         double hmp[675];
         build_case_tables(p.h, qs[c], ss[c], hmp, &ctx->hsum[c]);
@@ -410,6 +411,7 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     P.max_tries = p.max_tries;
     P.h = p.h; P.rmin = p.rmin; P.e1z = 1.0 / p.c; P.e2z = 1.0 / (p.c * p.c);
     P.alim = p.alim; P.Q1 = p.Q1; P.S1 = p.S1; P.term = p.term;
+    P.Qfar = p.Qfar > 0 ? p.Qfar : 1000.0; P.Qnear = p.Qnear > 0 ? p.Qnear : 10000.0; P.Sfree = p.Sfree > 0 ? p.Sfree : 10.0;
     for (int d = 0; d < 3; ++d) { P.pmin[d] = p.pmin[d]; P.pmax[d] = p.pmax[d]; }
     P.tables = ctx->d_tables;
     for (int i = 0; i < 3; ++i) P.hsum[i] = ctx->hsum[i];

@@ -26,6 +26,7 @@ enum { ST_SOLVED = 1, ST_OUTBOUND = 2, ST_COLL = 4, ST_INFEAS = 8, ST_CAPACITY =
 struct StepParams {
     int variant, S, G, C, g_local, nrmax, max_tries, c_first, c_count, qcap;
     double h, rmin, e1z, e2z, alim, Q1, S1, term;
+    double Qfar, Qnear, Sfree;   // weights of the collision-free cost cases (HEAD: 1000, 10000, 10)
     double pmin[3], pmax[3];
     double hsum[3];         // per cost case: sum of |H1(i,j)| (bound of the cost over the acceleration box, dual-bound certificate)
     const double *tables;   // [3 cost cases][30x30 Gram table G] + [15x15 Lambda' table]  (TAB_DOUBLES; see dmpc_solve.hip)

@@ -253,8 +253,8 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
         if (!rows_exist && far) ccase = 0;
         else if (!rows_exist && dn < 1.0) ccase = 1;
     }
-    const double qw = ccase == 0 ? 1000.0 : (ccase == 1 ? 10000.0 : P.Q1);
-    const double sw = ccase == 2 ? ((var == VAR_ALL3) ? 10.0 : P.S1) : 10.0;
+    const double qw = ccase == 0 ? P.Qfar : (ccase == 1 ? P.Qnear : P.Q1);
+    const double sw = ccase == 2 ? ((var == VAR_ALL3) ? 10.0 : P.S1) : P.Sfree;
     const double *G, *Lt;
     if (PERSIST) { G = shtab + ccase * TAB_CASE_DOUBLES; Lt = shtab + 3 * TAB_CASE_DOUBLES; }
     else {

@@ -51,6 +51,9 @@ static dmpc_params read_params(const mxArray *s)
     p.Q1 = field(s, "Q1"); p.S1 = field(s, "S1"); p.term = field(s, "term");
     const double *pmin = mxGetPr(mxGetField(s, 0, "pmin")), *pmax = mxGetPr(mxGetField(s, 0, "pmax"));
     for (int d = 0; d < 3; ++d) { p.pmin[d] = pmin[d]; p.pmax[d] = pmax[d]; }
+    // optional: weights of the collision-free cost cases (0 = the reference's HEAD constants)
+    const mxArray *qf = mxGetField(s, 0, "Qfar"), *qn = mxGetField(s, 0, "Qnear"), *sf = mxGetField(s, 0, "Sfree");
+    p.Qfar = qf ? mxGetScalar(qf) : 0.0; p.Qnear = qn ? mxGetScalar(qn) : 0.0; p.Sfree = sf ? mxGetScalar(sf) : 0.0;
     return p;
 }
 

@@ -657,8 +657,9 @@ static void cost_case(const orc_params *prm, const scan_t *sc, const double po[3
     double dn = sqrt((po[0] - pf[0]) * (po[0] - pf[0]) + (po[1] - pf[1]) * (po[1] - pf[1]) +
                      (po[2] - pf[2]) * (po[2] - pf[2]));
     int far = (prm->variant == ORC_ELLIP) ? (dn > 1) : (dn >= 1); /* solveEllipDMPC.m:26 uses > */
-    if (!sc->rows_exist && far) { *qw = 1000; *sw = 10; *which = 0; }          /* :43-47 */
-    else if (!sc->rows_exist && dn < 1) { *qw = 10000; *sw = 10; *which = 1; } /* :48-52 */
+    const double sfree = prm->Sfree > 0 ? prm->Sfree : 10;
+    if (!sc->rows_exist && far) { *qw = prm->Qfar > 0 ? prm->Qfar : 1000; *sw = sfree; *which = 0; }          /* :43-47 */
+    else if (!sc->rows_exist && dn < 1) { *qw = prm->Qnear > 0 ? prm->Qnear : 10000; *sw = sfree; *which = 1; } /* :48-52 */
     else { *qw = prm->Q1; *sw = (prm->variant == ORC_ALL3) ? 10 : prm->S1; *which = 2; } /* :53-57; all:71 */
 }
 

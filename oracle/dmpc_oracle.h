@@ -57,6 +57,7 @@ typedef struct {
     double Q1, S1;  /* collision-case weights                            */
     double term;    /* linear slack penalty (negative)                   */
     double pmin[3], pmax[3];
+    double Qfar, Qnear, Sfree; /* collision-free cost cases; 0 = HEAD constants 1000 / 10000 / 10 (solveSoftDMPCbound.m:44-52) */
 } orc_params;
 
 /* info[] layout (8 ints per agent) */

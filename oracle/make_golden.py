@@ -106,9 +106,28 @@ def convert_postcheck(path, name, idx, stride=4):
     print("wrote", name, "N=%d KT=%d ns=%d" % (N, out["pk"].shape[1], out["n_samples"]))
 
 
+def convert_cpp_dump(name):
+    """dmpc/cpp_results/trajectories (200-agents).txt -- the ONE recorded output of the C++ flavour (DMPC::solveQPv2,
+    dmpc/cpp/dmpc.cpp:803-1287; written by DMPC::trajectories2file, :2088-2126, from main.cpp's solveParallelDMPCv2 run with
+    k_factor 0): 200 agents x 83 un-rescaled MPC steps, 6 significant digits.  Kept: the start/goal sets and the first
+    three columns of every agent (initial state, and the states after the first and second solve).  Only the FIRST solve is
+    an equality oracle (later ones depend on prediction tables the file does not hold).  The constants that reproduce it
+    were fitted in this container (the file predates HEAD): collision-free cost cases Q = 100 far from the goal (gain
+    a_1/(pf-po) = 0.1206946 against the file's 0.120694; HEAD's 1000 gives 0.1217269) and Q = 1000 within 1 m, collision
+    case Q = 100, S = 100; everything else as main.cpp:13-16 (h 0.2, k_hor 15, c 2, rmin 0.35, alim 1, box z <= 5.2)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from multiagent_planning_amd import resultio
+    r = resultio.read_trajectories(os.path.join(REF, "dmpc/cpp_results/trajectories (200-agents).txt"))
+    out = dict(N=200, h=0.2, c=2.0, rmin=0.35, alim=1.0, pmin=r["pmin"], pmax=r["pmax"], po=r["po"], pf=r["pf"],
+               pk=r["pk"][:, :3], vk=r["vk"][:, :3], ak=r["ak"][:, :3], Qfar=100.0, Qnear=1000.0, Q=100.0, S=100.0, term=-1e6)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, {k: np.shape(v) for k, v in out.items()})
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("reference not present; fixtures are already committed")
     convert("data/failure_rate/failure_rate2.mat", "failure_rate2_bound", "bound")
     convert("data/comp_kctr/comp_kctr_3.mat", "comp_kctr_3_bound2", "bound2")
     convert_postcheck("data/comp_kctr/comp_kctr_2.mat", "postcheck_comp_kctr_2", "2")
+    convert_cpp_dump("cpp_dump_200_first_solve")

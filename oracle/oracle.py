@@ -24,6 +24,7 @@ class Params(C.Structure):
         ("h", C.c_double), ("rmin", C.c_double), ("c", C.c_double), ("alim", C.c_double),
         ("Q1", C.c_double), ("S1", C.c_double), ("term", C.c_double),
         ("pmin", C.c_double * 3), ("pmax", C.c_double * 3),
+        ("Qfar", C.c_double), ("Qnear", C.c_double), ("Sfree", C.c_double),
     ]
 
 
@@ -77,10 +78,11 @@ def _f(a):
 
 
 def make_params(variant, K=15, h=0.2, rmin=0.35, c=2.0, alim=1.0, Q1=1000.0, S1=100.0, term=-5e4,
-                pmin=(-2.5, -2.5, 0.2), pmax=(2.5, 2.5, 2.2), max_tries=0):
+                pmin=(-2.5, -2.5, 0.2), pmax=(2.5, 2.5, 2.2), max_tries=0, Qfar=0.0, Qnear=0.0, Sfree=0.0):
     p = Params()
     p.K, p.variant, p.order, p.max_tries = K, VARIANTS[variant] if isinstance(variant, str) else variant, 2, max_tries
     p.h, p.rmin, p.c, p.alim, p.Q1, p.S1, p.term = h, rmin, c, alim, Q1, S1, term
+    p.Qfar, p.Qnear, p.Sfree = Qfar, Qnear, Sfree
     for i in range(3):
         p.pmin[i] = float(pmin[i])
         p.pmax[i] = float(pmax[i])

@@ -178,3 +178,20 @@ def test_launch_order_is_pure_scheduling():
         for k in ("p", "v", "a", "status", "info"):
             assert np.array_equal(out[k], ref[k]), k
     assert L.dmpc_debug_set_order(d._ctx, None, 0) == 0
+
+
+def test_cpp_flavour_against_the_recorded_200_agent_dump():
+    """f-4: the HIP path of DMPC::solveQPv2 (variant cpp) against the reference's own recorded output,
+    dmpc/cpp_results/trajectories (200-agents).txt (first solve of all 200 agents; constants of that revision:
+    tests/test_oracle_golden.py), and against the oracle on the same inputs."""
+    from test_oracle_golden import _cpp_dump, check_cpp_dump_first_solve
+    g, kw = _cpp_dump()
+    N = int(g["N"])
+    z = np.zeros((N, 3))
+    d = mp.Dmpc("cpp", **kw)
+    l, _, _ = d.init_batch(g["po"], g["pf"])
+    out = d.step_batch(l, g["po"], z, z, g["pf"])
+    assert (out["status"] == 1).all()
+    check_cpp_dump_first_solve(out["a"][:, :3], out["info"][:, 0], g, "GPU cpp")
+    ref = orc.step(orc.make_params("cpp", **kw), l, g["po"], z, z, g["pf"], nthreads=8)
+    compare_to_oracle(out, ref, 1e-9, "cpp dump")
