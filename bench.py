@@ -265,7 +265,7 @@ def main():
         dT.transition(poT[:1], pfT[:1], 10, cfgT["error_tol"])   # warm-up
         for St in (1, 8, 512):
             tt = time.perf_counter()
-            resT = dT.transition(poT[:St], pfT[:St], 151, cfgT["error_tol"])
+            resT = dT.transition(poT[:St], pfT[:St], cfgT["K_T"], cfgT["error_tol"])
             dtT = time.perf_counter() - tt
             usedT = resT["K_T_used"]
             secondary.append({"workload": f"{St} whole transition(s), 100 agents, solveSoftDMPCbound (failure_rate.m constants), closed "

@@ -184,6 +184,15 @@ int dmpc_advance_device(dmpc_ctx *ctx, int count, const double *p_out, const dou
 /* Whole transition on one device: the `for k = 1:K_T` loop of dmpc_soft_bound.m:115-148 /
  * DMPC::solveParallelDMPCv2 (dmpc/cpp/dmpc.cpp:1656-1686) incl. initDMPC at k = 1, the table
  * swap l = new_l and the ReachedGoal.m test.  Host pointers.
+ * K_T_max = number of history COLUMNS, the initial state (k = 1, initDMPC) included: at most K_T_max - 1 solves per agent.
+ * `for k = 1:K_T` of dmpc_soft_bound.m:115 is K_T_max = K_T; `while ~reached_goal && k < max_K` of test/failure_rate.m:99
+ * records max_K - 1 columns: pass K_T_max = max_K - 1.  ReachedGoal.m is evaluated on every column, the first included.
+ * A scene stops at the first step where any agent's status is not exactly DMPC_ST_SOLVED (infeasible, collided, out of
+ * the workspace): stricter than failure_rate.m, which only aborts on `~feasible` and -- solveSoftDMPCbound keeping
+ * feasible = 1 on outbound -- carries on with a partially updated table after an outbound first step (:112-126).
+ * A QP that is infeasible without any collision row is reported DMPC_ST_INFEAS at once: the reference retries it up to 30
+ * times with quadprog's ConstraintTolerance doubled each time (solveSoftDMPCbound.m:140-146) and may end up accepting a
+ * bound-violating point, typically reported `outbound` instead.
  * po,pf: [S][N][3]; pk,vk,ak: [S][N][K_T_max][3] (written up to K_T_used[s]) or all three NULL: the histories
  * then only stay on the device (for dmpc_postcheck) and the 3 x S*N*K_T_max*24-byte download is skipped;
  * K_T_used[S]: number of MPC steps taken per scene; scene_status[S]: OR of agent status bits at
@@ -330,7 +339,9 @@ int dmpc_prop_state(dmpc_ctx *ctx, int n_rows, int n_cols, const double *A_p, co
 int dmpc_is_inbounds(dmpc_ctx *ctx, int npts, const double *p, const double *pmin, const double *pmax, int32_t *inbounds);
 int dmpc_reached_goal(dmpc_ctx *ctx, int N, const double *p, const double *pf, double error_tol, int32_t *reached);
 
-/* number of agent-QP solves launched by this context so far (for throughput accounting) */
+/* Agent-steps LAUNCHED by this context so far (incl. the half of a split dmpc_transition batch that runs on the internal
+ * second context).  An upper bound of the QPs actually solved: agents of scenes that already stopped are skipped on the
+ * device, and agents the scan certifies infeasible never enter the solver; per-agent outcomes are in status[]. */
 int64_t dmpc_solve_count(const dmpc_ctx *ctx);
 
 /* Roofline instrumentation: with dmpc_profile(ctx,1) every step-kernel launch is bracketed by HIP

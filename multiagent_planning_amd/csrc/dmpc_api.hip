@@ -342,7 +342,7 @@ extern "C" int dmpc_set_params(dmpc_ctx *ctx, const dmpc_params *prm)
     return upload_tables(ctx);
 }
 
-extern "C" int64_t dmpc_solve_count(const dmpc_ctx *ctx) { return ctx ? ctx->solves : 0; }
+extern "C" int64_t dmpc_solve_count(const dmpc_ctx *ctx) { return ctx ? ctx->solves + (ctx->child ? ctx->child->solves : 0) : 0; }
 
 extern "C" int dmpc_profile(dmpc_ctx *ctx, int enable)
 {
@@ -884,6 +884,10 @@ static int transition_one(dmpc_ctx *ctx, int S, int N, const double *po, const d
     const unsigned rb = (unsigned)((A * 3 + 255) / 256);
     hipLaunchKernelGGL(record_kernel, dim3(rb), dim3(256), 0, st, S, N, K_T_max, 0, xp, xv, xa, ctx->hist_p.as<double>(),
                        ctx->hist_v.as<double>(), ctx->hist_a.as<double>());
+    // ReachedGoal is also evaluated on the initDMPC column (failure_rate.m:125 runs after k = 1 as well)
+    HIPCHK(ctx, hipMemsetD32Async((hipDeviceptr_t)ctx->status.p, DMPC_ST_SOLVED, A, st));
+    hipLaunchKernelGGL(scene_reduce_kernel, dim3((unsigned)S), dim3(256), 0, st, N, error_tol, xp, ctx->pf.as<double>(),
+                       (const int *)ctx->status.as<int32_t>(), ctx->flags.as<int>(), ctx->scene_done.as<int>());
     double *cur = ctx->lT.as<double>(), *nxt = ctx->lT2.as<double>();
     const bool mixed = ctx->precision == DMPC_PREC_MIXED;   // the scan of every step reads an fp32 copy of the current table
     std::vector<int32_t> flags((size_t)K_T_max * S * 2, 0);
@@ -905,7 +909,7 @@ static int transition_one(dmpc_ctx *ctx, int S, int N, const double *po, const d
         HIPCHK(ctx, hipGetLastError());
         std::swap(cur, nxt);   // l = new_l (dmpc_soft_bound.m:146)
         if (k % chunk == 0 || k == K_T_max - 1) {
-            const int k0 = ((k - 1) / chunk) * chunk + 1;
+            const int k0 = k <= chunk ? 0 : ((k - 1) / chunk) * chunk + 1;   // (the first window includes the initDMPC column)
             HIPCHK(ctx, hipMemcpyAsync(&flags[(size_t)k0 * S * 2], ctx->flags.as<int>() + (size_t)k0 * S * 2,
                                        (size_t)(k - k0 + 1) * S * 8, hipMemcpyDeviceToHost, st));
             HIPCHK(ctx, hipStreamSynchronize(st));

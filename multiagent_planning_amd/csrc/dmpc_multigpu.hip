@@ -235,6 +235,13 @@ extern "C" int dmpc_transition_sharded(dmpc_ctx *ctx, int S, int N, const double
     hipLaunchKernelGGL(record_kernel, dim3(sb), dim3(256), 0, st, S, (int)cnt, K_T_max, 0, xp, xv, xa, ctx->hist_p.as<double>(),
                        ctx->hist_v.as<double>(), ctx->hist_a.as<double>());
     double *cur = ctx->lT.as<double>(), *nxt = ctx->lT2.as<double>();
+    // ReachedGoal on the initDMPC column (as dmpc_transition): own verdicts, exchanged with a throw-away table exchange
+    HIPCHK(ctx, hipMemsetD32Async((hipDeviceptr_t)ctx->status.p, DMPC_ST_SOLVED, Aown, st));
+    hipLaunchKernelGGL(scene_reduce_kernel, dim3((unsigned)S), dim3(256), 0, st, (int)cnt, error_tol, xp, own_pf, (const int *)ctx->status.as<int32_t>(),
+                       ctx->mg_floc.as<int>(), (int *)nullptr);
+    if (exchange(ctx, ctx->sendbuf.as<double>(), nxt, chunk, ctx->mg_floc.as<int>(), ctx->mg_fall.as<int>(), S * 2, st)) return -1;
+    hipLaunchKernelGGL(mg::combine_flags_kernel, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, st, G, S, (const int *)ctx->mg_fall.as<int>(),
+                       ctx->flags.as<int>(), ctx->scene_done.as<int>());
     std::vector<int32_t> flags((size_t)K_T_max * S * 2, 0);
     std::vector<int> done(S, 0);
     for (int s = 0; s < S; ++s) { K_T_used[s] = K_T_max; scene_status[s] = DMPC_ST_SOLVED; }
@@ -256,7 +263,7 @@ extern "C" int dmpc_transition_sharded(dmpc_ctx *ctx, int S, int N, const double
                            ctx->flags.as<int>() + (size_t)k * S * 2, ctx->scene_done.as<int>());
         std::swap(cur, nxt);   // l = new_l (dmpc_soft_bound.m:146)
         if (k % chunk_steps == 0 || k == K_T_max - 1) {
-            const int k0 = ((k - 1) / chunk_steps) * chunk_steps + 1;
+            const int k0 = k <= chunk_steps ? 0 : ((k - 1) / chunk_steps) * chunk_steps + 1;
             HIPCHK(ctx, hipMemcpyAsync(&flags[(size_t)k0 * S * 2], ctx->flags.as<int>() + (size_t)k0 * S * 2, (size_t)(k - k0 + 1) * S * 8,
                                        hipMemcpyDeviceToHost, st));
             HIPCHK(ctx, hipStreamSynchronize(st));

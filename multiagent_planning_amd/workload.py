@@ -89,7 +89,7 @@ CONFIGS = {
                rmin_init=0.75, error_tol=0.05, K_T=101, generator="random_exchange", box="density"),
     # test/failure_rate.m:7-99 -- the primary soft variant, sharded across GPUs
     "C4": dict(variant="bound", N=10000, h=0.2, rmin=0.35, c=2.0, alim=1.0, Q1=1000.0, S1=100.0, term=-5e4,
-               rmin_init=0.35, error_tol=0.01, K_T=151, generator="random_test", box="density"),
+               rmin_init=0.35, error_tol=0.01, K_T=150, generator="random_test", box="density"),   # max_K = 151, `k < max_K`: 150 columns
     # test/comp_repair.m:19-29,93 -- repair heuristic, dense box
     "C5": dict(variant="repair", N=200, h=0.2, rmin=0.5, c=1.5, alim=0.5, Q1=1000.0, S1=100.0, term=-1e6,
                rmin_init=0.75, error_tol=0.05, K_T=101, generator="random_test", box="density"),

@@ -228,3 +228,16 @@ def test_transition_batches_of_every_depth_equal_single_scene_runs(S):
         assert int(one["K_T_used"][0]) == int(big["K_T_used"][s]) and int(one["scene_status"][0]) == int(big["scene_status"][s]), s
         u = int(one["K_T_used"][0])      # (columns past the stop hold the frozen state in a batch, zeros in a single run)
         assert np.array_equal(one["pk"][0][:, :u], big["pk"][s][:, :u]) and np.array_equal(one["ak"][0][:, :u], big["ak"][s][:, :u]), s
+
+
+def test_reached_goal_is_checked_on_the_first_column_too():
+    """agents that start at their goals: ReachedGoal holds on the initDMPC column (failure_rate.m:125 tests it after k = 1),
+    the transition ends with one column and no solve"""
+    kw = wl.solver_kwargs(wl.CONFIGS["C4"], 20)
+    po, _ = wl.make_scenes(wl.CONFIGS["C4"], 2, 20, wl.SEED0 + 91)
+    pf = po.copy()
+    pf[1, 3] += 0.5        # scene 1 has one agent with somewhere to go
+    for fn in ("transition", "transition_sharded"):
+        r = getattr(mp.Dmpc("bound", **kw), fn)(po, pf, 40, 0.01)
+        assert int(r["K_T_used"][0]) == 1 and int(r["scene_status"][0]) == (mp.ST_SOLVED | mp.ST_REACHED), fn
+        assert int(r["K_T_used"][1]) > 1, fn

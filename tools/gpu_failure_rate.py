@@ -15,7 +15,7 @@ for N in sorted(RECORDED):
     t0 = time.perf_counter()
     po, pf = wl.make_scenes_device(d, cfg, S, N, wl.SEED0 + 7 * N) if os.environ.get("DEVICE_SCENES", "1") == "1" else wl.make_scenes(cfg, S, N, wl.SEED0 + 7 * N)
     t1 = time.perf_counter()
-    res = driver.run_trial(d, po, pf, 151, cfg["error_tol"], histories=False)
+    res = driver.run_trial(d, po, pf, cfg["K_T"], cfg["error_tol"], histories=False)
     t2 = time.perf_counter()
     p = res["success"].mean()
     se = np.sqrt(max(p * (1 - p), 1e-9) / S)

@@ -12,7 +12,7 @@ for cfgname, variant in (("C4", "bound"), ("C2", "hard")):
     d.transition(po, pf, 10, cfg["error_tol"])
     best = 1e9
     for rep in range(5):
-        t = time.perf_counter(); r = d.transition(po, pf, 151, cfg["error_tol"], histories=False); dt = time.perf_counter() - t
+        t = time.perf_counter(); r = d.transition(po, pf, cfg["K_T"], cfg["error_tol"], histories=False); dt = time.perf_counter() - t
         best = min(best, dt)
     steps = int(r["K_T_used"][0]) - 1
     print(f"{cfgname} {variant}: {steps} MPC steps, {best * 1e3:.2f} ms, {best / max(steps, 1) * 1e6:.1f} us per step, status {int(r['scene_status'][0])}")

@@ -11,7 +11,7 @@ for N, S in [(20, 8), (100, 8), (200, 8), (100, 1)]:
     po, pf = wl.make_scenes(cfg, S, N, wl.SEED0 + N)
     d.transition(po[:1], pf[:1], 10, cfg["error_tol"])   # warm-up (allocations, module load)
     t0 = time.perf_counter()
-    res = d.transition(po, pf, 151, cfg["error_tol"])
+    res = d.transition(po, pf, cfg["K_T"], cfg["error_tol"])
     dt = time.perf_counter() - t0
     used = res["K_T_used"]; ok = (res["scene_status"] & 1) == 1
     reached = [np.linalg.norm(res["pk"][s][:, used[s] - 1] - pf[s], axis=1).max() < cfg["error_tol"] for s in range(S)]

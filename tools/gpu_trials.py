@@ -12,9 +12,9 @@ for S in [int(x) for x in (sys.argv[2:] or ["1", "8", "64", "512"])]:
     po, pf = wl.make_scenes(cfg, S, N, wl.SEED0 + 100)
     driver.run_trial(d, po[:1], pf[:1], 12, cfg["error_tol"])
     t0 = time.perf_counter()
-    tr = d.transition(po, pf, 151, cfg["error_tol"])
+    tr = d.transition(po, pf, cfg["K_T"], cfg["error_tol"])
     t1 = time.perf_counter()
-    res = driver.run_trial(d, po, pf, 151, cfg["error_tol"])
+    res = driver.run_trial(d, po, pf, cfg["K_T"], cfg["error_tol"])
     t2 = time.perf_counter()
     used = tr["K_T_used"]
     print(f"N={N} S={S:4d}: transition {1e3*(t1-t0):8.1f} ms ({1e3*(t1-t0)/S:7.3f} ms each); trial (transition+post-checks) {1e3*(t2-t1):8.1f} ms; "
