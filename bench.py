@@ -205,36 +205,42 @@ def main():
     solves_per_step = S * N if not emu else S * C
     value = solves_per_step * args.steps / elapsed
 
-    # secondary workload (reported, not the headline): the reference's primary variant solveSoftDMPCbound
-    # (test/failure_rate.m) on the same start/goal sets, MPC step 12 of the live transitions
+    # secondary workloads (reported, not the headline)
     secondary = None
     if not args.no_secondary and G == 1 and rank == 0:
-        cfg2 = dict(cfg, variant="bound")
-        d2 = mp.Dmpc("bound", device=local_rank, **kw)
-        l2, xp2, xv2, xa2, pf2, alive2 = capture_state(d2, cfg2, S, N, 12, wl.SEED0 + 2)
-        rows2 = dev_t(l2)
-        lT2 = torch.empty((1, S, 45, C), dtype=torch.float64, device=dev)
-        d2.table_from_rows_device(S, 1, C, rows2.data_ptr(), lT2.data_ptr(), stream)
-        t2 = [dev_t(a_) for a_ in (xp2, xv2, xa2, pf2)]
-        def step2():
-            d2.step_device(S, 1, C, 0, lT2.data_ptr(), t2[0].data_ptr(), t2[1].data_ptr(), t2[2].data_ptr(), t2[3].data_ptr(),
-                           p_out.data_ptr(), v_out.data_ptr(), a_out.data_ptr(), lT_next.data_ptr(), status.data_ptr(),
-                           info.data_ptr(), stream)
-        for _ in range(3):
-            step2()
-        torch.cuda.synchronize()
-        tt = time.perf_counter()
-        for _ in range(args.steps):
-            step2()
-        torch.cuda.synchronize()
-        el2 = time.perf_counter() - tt
-        st2 = status.cpu().numpy(); inf2 = info.cpu().numpy()
-        secondary = [{"workload": f"{C} agents/scene, variant bound (solveSoftDMPCbound, failure_rate.m constants), {S} scenes, "
-                                  f"replay of MPC step 12 ({int(alive2.sum())}/{S} scenes alive)",
-                      "value": S * N * args.steps / el2, "unit": "solves/s", "ms_per_step": el2 / args.steps * 1e3,
-                      "solved_frac": float((st2 & 1).mean()), "mean_iters": float(inf2[..., 4].mean()),
-                      "max_iters": int(inf2[..., 4].max()), "max_tries": int(inf2[..., 2].max()), "invalid": int(((st2 & 48) != 0).sum()),
-                      "mean_rows": float(inf2[..., 1].mean())}]
+        secondary = []
+
+        def replay(variant, what, cap_step):
+            """steady-state replay of a captured MPC step of the same start/goal sets with another solver variant"""
+            dv = mp.Dmpc(variant, device=local_rank, **kw)
+            lv, xpv, xvv, xav, pfv, alivev = capture_state(dv, dict(cfg, variant=variant), S, N, cap_step, wl.SEED0 + 2)
+            rowsv = dev_t(lv)
+            lTv = torch.empty((1, S, 45, C), dtype=torch.float64, device=dev)
+            dv.table_from_rows_device(S, 1, C, rowsv.data_ptr(), lTv.data_ptr(), stream)
+            tv = [dev_t(a_) for a_ in (xpv, xvv, xav, pfv)]
+            def stepv():
+                dv.step_device(S, 1, C, 0, lTv.data_ptr(), tv[0].data_ptr(), tv[1].data_ptr(), tv[2].data_ptr(), tv[3].data_ptr(),
+                               p_out.data_ptr(), v_out.data_ptr(), a_out.data_ptr(), lT_next.data_ptr(), status.data_ptr(),
+                               info.data_ptr(), stream)
+            for _ in range(3):
+                stepv()
+            torch.cuda.synchronize()
+            tt = time.perf_counter()
+            for _ in range(args.steps):
+                stepv()
+            torch.cuda.synchronize()
+            el = time.perf_counter() - tt
+            stv = status.cpu().numpy(); infv = info.cpu().numpy()
+            secondary.append({"workload": f"{C} agents/scene, variant {variant} ({what}), {S} scenes, replay of MPC step {cap_step} "
+                                          f"({int(alivev.sum())}/{S} scenes alive)",
+                              "value": S * N * args.steps / el, "unit": "solves/s", "ms_per_step": el / args.steps * 1e3,
+                              "solved_frac": float((stv & 1).mean()), "infeasible_frac": float(((stv & 8) != 0).mean()),
+                              "mean_iters": float(infv[..., 4].mean()), "max_iters": int(infv[..., 4].max()), "max_tries": int(infv[..., 2].max()),
+                              "invalid": int(((stv & 48) != 0).sum()), "mean_rows": float(infv[..., 1].mean())})
+        # the reference's primary variant (test/failure_rate.m) at MPC step 12 of the live transitions, and the second C2 variant
+        # SURVEY.md 8d names (test/comp_hardsoft2.m:247: solveHardDMPCOnDemand; like solveHardDMPC it dies at its first solve)
+        replay("bound", "solveSoftDMPCbound, failure_rate.m constants", 12)
+        replay("ondemand", "solveHardDMPCOnDemand", 12)
         # the same headline workload at a small batch: a 64-scene launch is bound by its slowest agent, not by throughput
         if S > 64:
             S3 = 64
@@ -273,6 +279,28 @@ def main():
                               "wall_ms": dtT * 1e3, "ms_per_transition": dtT * 1e3 / St, "mpc_steps": ([int(u) for u in usedT] if St <= 8 else {"min": int(min(usedT)), "mean": float(sum(usedT)) / St, "max": int(max(usedT))}),
                               "completed": int(((resT["scene_status"] & 256) != 0).sum()),
                               "value": float(((usedT - 1) * 100).sum() / dtT), "unit": "solves/s"})
+        # ONE scene -- the literal "100 agents" of BASELINE configs[1] / the reference's own use: a step is bound by the latency of
+        # its slowest agent plus the launches.  Closed loop on the device (dmpc_transition), wall time per MPC step.
+        for vname, cname in (("bound", "C4"), ("hard", "C2")):
+            cfg1 = dict(wl.CONFIGS[cname]); kw1 = wl.solver_kwargs(cfg1, 100)
+            d1 = mp.Dmpc(vname, device=local_rank, **kw1)
+            po1, pf1 = wl.make_scenes(cfg1, 1, 100, wl.SEED0 + 100)
+            d1.transition(po1, pf1, 10, cfg1["error_tol"], histories=False)
+            best, res1 = 1e9, None
+            for _ in range(5):
+                tt = time.perf_counter(); res1 = d1.transition(po1, pf1, cfg1["K_T"], cfg1["error_tol"], histories=False); best = min(best, time.perf_counter() - tt)
+            steps1 = max(int(res1["K_T_used"][0]) - 1, 1)
+            secondary.append({"workload": f"ONE scene of 100 agents, variant {vname}, whole transition on the device: wall time per MPC step",
+                              "us_per_mpc_step": best / steps1 * 1e6, "mpc_steps": steps1, "scene_status": int(res1["scene_status"][0]),
+                              "value": 100 * steps1 / best, "unit": "solves/s"})
+        # mixed precision (DMPC_PREC_MIXED: fp32 table, scan and rows; fp64 QP) against fp64 on whole transitions (BASELINE configs[4])
+        for prec in ("f64", "mixed"):
+            dm = mp.Dmpc("bound", device=local_rank, precision=prec, **kwT)
+            dm.transition(poT[:8], pfT[:8], 10, cfgT["error_tol"], histories=False)
+            tt = time.perf_counter(); rm = dm.transition(poT, pfT, cfgT["K_T"], cfgT["error_tol"], histories=False); dtm = time.perf_counter() - tt
+            secondary.append({"workload": f"512 whole transitions, 100 agents, solveSoftDMPCbound, precision {prec}, histories left on the device",
+                              "wall_ms": dtm * 1e3, "completed": int(((rm["scene_status"] & 256) != 0).sum()),
+                              "value": float(((rm["K_T_used"] - 1) * 100).sum() / dtm), "unit": "solves/s"})
         # restore the headline workload's last outputs for the statistics below
         one_step()
         torch.cuda.synchronize()
@@ -284,15 +312,18 @@ def main():
         # GPU (360 B per agent of the scene), state+goal 96 B, p/v/a horizons 1080 B, status 20 B
         b_alg = 360.0 * N / C + 1196.0
         achieved = (S * C) * b_alg / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-        traffic = None
-        tj = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tj) and G == 1:   # PMC counters cannot be read inside the timed run: the committed rocprofv3 passes of this workload
+        # PMC counters cannot be read inside the timed run: traffic and issue fractions come from the committed rocprofv3 passes of
+        # this same workload (profiles/r02_pmc_summary.json, made by tools/gpu_profile_round.sh + tools/profile_summary.py)
+        traffic, pmc = None, None
+        tj = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
+        if os.path.exists(tj) and G == 1:
             try:
                 jt = json.load(open(tj))
                 if jt.get("solves_per_launch") == S * C:
+                    pmc = jt
                     traffic = jt.get("hbm_bytes_per_launch")
             except Exception:
-                traffic = None
+                pmc = None
         ncu = torch.cuda.get_device_properties(dev).multi_processor_count
         kname = "dmpc_solve_persist_kernel" if S * C >= 16 * ncu * 8 else "dmpc_solve_kernel"
         line = {
@@ -312,8 +343,11 @@ def main():
                          "kernel": kname, "kernel_ms_avg": kern_ms, "launches": n_launch,
                          "other_kernels_ms_avg": {"dmpc_scan_kernel+order_kernel": scan_ms},
                          "alg_bytes_per_solve": b_alg, "solves_per_launch": S * C,
-                         "note": "on-chip, instruction-issue bound (~11 k instructions per solve, 0.7 issued per SIMD slot; profiles/README.md); "
-                                 "compulsory HBM traffic is ~1.5 KB/solve, so the HBM fraction is small by construction"},
+                         "secondary": (dict(pmc.get("issue", {}), instructions_per_solve=pmc.get("instructions_per_solve"),
+                                            whole_step_traffic=pmc.get("whole_step_bytes_per_launch"),
+                                            source="profiles/r02_pmc_summary.json (rocprofv3 passes of this workload)") if pmc else None),
+                         "note": "on-chip, instruction-issue bound (profiles/README.md): compulsory HBM traffic is ~1.5 KB/solve against "
+                                 "thousands of wave instructions, so the HBM fraction is small by construction; the issue fractions are in `secondary`"},
             "workload_stats": {"solved_frac": float((st & 1).mean()), "infeasible_frac": float(((st & 8) != 0).mean()),
                                "invalid": int(((st & 48) != 0).sum()), "mean_iters": float(inf[..., 4].mean()),
                                "max_iters": int(inf[..., 4].max()), "mean_rows": float(inf[..., 1].mean()),
