@@ -712,16 +712,31 @@ __global__ __launch_bounds__(512, 1) void dmpc_solve_persist_kernel(StepParams P
     const int T3 = (rest - T1) < nw ? (rest - T1) : nw;
     const int mid = rest - T1 - T3, T2 = (mid + 3) >> 2;
     int pos = wave * (int)gridDim.x + (int)blockIdx.x, left = 0;
+#ifdef DMPC_DEV_TRACE
+    // development: start / end time and agent count of every wave (dmpc_debug_trace with agent = -2)
+    const long long t_begin = wall_clock64();
+    int n_done = 0;
+#endif
     for (;;) {
         if (pos >= total) break;
+#ifdef DMPC_DEV_TRACE
+        n_done++;
+#endif
         int tkv = 0;
         if (P.counter && left == 0 && lane == 0) tkv = atomicAdd(P.counter, 1);
         // opaque copy of the lane id: keeps the compiler from hoisting the solver's per-lane constants out of this
         // loop (they would stay live across the whole body and push the kernel into scratch spills)
         int ln = lane;
         asm volatile("" : "+v"(ln));
+#ifdef DMPC_DEV_TRACE
+        const long long t_a = wall_clock64();
+#endif
         solve_body<SOFT, QCAP, true>(P, ln, pos, total, mine, shtab);
         LSYNC();
+#ifdef DMPC_DEV_TRACE
+        // development: start time and duration of every queue position (dmpc_debug_trace with agent = -3)
+        if (P.dbg && P.dbg_agent == -3 && lane == 0) { P.dbg[(size_t)pos * 2] = (double)t_a; P.dbg[(size_t)pos * 2 + 1] = (double)(wall_clock64() - t_a); }
+#endif
         if (!P.counter) { pos += nw; continue; }   // static round-robin over the (sorted) queue (development)
         if (left > 0) { pos++; left--; continue; }
         const int t = __builtin_amdgcn_readfirstlane(tkv);
@@ -732,6 +747,12 @@ __global__ __launch_bounds__(512, 1) void dmpc_solve_persist_kernel(StepParams P
             left = (end - pos < 4 ? end - pos : 4) - 1;
         } else pos = nw + T1 + mid + (t - T1 - T2);
     }
+#ifdef DMPC_DEV_TRACE
+    if (P.dbg && P.dbg_agent == -2 && lane == 0) {
+        double *d = P.dbg + ((size_t)blockIdx.x * (blockDim.x >> 6) + wave) * 3;
+        d[0] = (double)t_begin; d[1] = (double)wall_clock64(); d[2] = (double)n_done;
+    }
+#endif
 }
 
 // --------------------------------------------------------------------------------------------

@@ -19,3 +19,6 @@ for name, m in (("solved", (st & 1) == 1), ("infeasible", (st & 8) != 0)):
 print("iteration histogram (all):", np.bincount(np.minimum(it, 60) // 4)[:16], "(bins of 4)")
 print("peak working set > 32:", np.mean(mq > 32), " > 40:", np.mean(mq > 40), "max", mq.max())
 print("rows built: mean", out["info"][..., 1].mean())
+for thr in (24, 40, 60, 80):
+    m = it > thr
+    print(f"> {thr} iterations: {m.sum()} agents, infeasible {((st[m] & 8) != 0).sum()}, solved {((st[m] & 1) != 0).sum()}, share of all iterations {it[m].sum() / tot:.3f}")
