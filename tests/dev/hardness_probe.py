@@ -3,7 +3,7 @@ count (launch-order predictor for the persistent solve kernel)?"""
 import sys, os
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-from oracle import structured_model as sm
+import structured_model as sm   # tests/dev/structured_model.py (numpy model used by these probes only)
 from oracle import oracle as orc
 from multiagent_planning_amd import workload as wl
 
