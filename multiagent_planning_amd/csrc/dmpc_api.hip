@@ -65,6 +65,8 @@ struct dmpc_ctx {
     // per-neighbour bounding-box culling in the scan of large scenes (DMPC_NO_CULL=1 disables it, for A/B runs)
     int no_cull = getenv("DMPC_NO_CULL") ? 1 : 0;
     int no_lpt = getenv("DMPC_NO_LPT") ? 1 : 0;   // tuning: disable the heaviest-first solve order
+    int crash_min = getenv("DMPC_CRASH_MIN") ? atoi(getenv("DMPC_CRASH_MIN")) : CRASH_MIN_DEFAULT;   // see StepParams::crash_min
+    int ladder_warm = getenv("DMPC_LADDER_COLD") ? 0 : 1;   // tuning: restart every retry-ladder level from scratch
     int iter_cap = getenv("DMPC_ITER_CAP") ? atoi(getenv("DMPC_ITER_CAP")) : ITER_CAP;   // development: cap the active-set iterations (agents beyond it end DMPC_ST_ITERCAP)
     int single_tier = 0;         // 1: solve with the full working-set capacity in one launch
     DevBuf lTf, lTf2;            // mixed precision: fp32 copies of the tables the scan reads
@@ -388,9 +390,10 @@ static int tier1_qcap(int variant)
     if (env == 64 && variant_soft(variant)) return 64;
     // slack-free variants (hard, ondemand, ellip): 45 variables => at most 45 independent active rows, one tier of 48;
     // solveHardDMPC builds rows for every horizon step and its working sets routinely approach that limit.
-    // slack-carrying variants stay far below 32 in the first tier
+    // slack-carrying variants of small scenes stay far below 32 in the first tier
     return variant_soft(variant) ? 32 : 48;
 }
+
 // hard: 45 variables => at most 45 independent active rows; 48 leaves room for a numerically near-dependent addition
 static int full_qcap(int variant) { return variant_soft(variant) ? QMAX : 48; }
 
@@ -428,6 +431,10 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     }
     P.dbg = ctx->dbg; P.dbg_agent = ctx->dbg_agent; P.dbg_cap = ctx->dbg_cap;
     P.iter_cap = ctx->iter_cap;
+    P.ladder_warm = ctx->ladder_warm;
+    // measured: the crash start pays for the slack-carrying variants (C4, N = 10^4: solve launch -16 %) and costs on solveHardDMPC
+    // (C2: -16 % throughput: with rows at every horizon step the bounds violated at the unconstrained minimiser are a poor guess)
+    P.crash_min = (soft || getenv("DMPC_CRASH_MIN")) ? ctx->crash_min : 0;
     // shallow launches (a scene or a few: bound by the latency of their slowest agent, LDS is no constraint) solve with the
     // full working-set capacity in one launch; deep launches use the small first tier and re-solve the few that outgrow it
     const bool shallow = (long)S * c_count < 16L * (ctx->num_cu > 0 ? ctx->num_cu : 256) * 8 && !ctx->force_persist && !getenv("DMPC_TIER1_QCAP");

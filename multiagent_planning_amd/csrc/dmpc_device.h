@@ -17,6 +17,7 @@ __host__ __device__ constexpr int tcol(int j) { return 8 * (j >> 3) * (4 * (j >>
 // block (>= 4 x 48 doubles) are what they touch.
 __host__ __device__ constexpr int t_doubles(int qcap) { return tcol((qcap + 7) & ~7); }
 constexpr int ITER_CAP = 4000;
+constexpr int CRASH_MIN_DEFAULT = 4;
 
 enum { VAR_BOUND = 0, VAR_BOUND2 = 1, VAR_ALL3 = 2, VAR_HARD = 3, VAR_ONDEMAND = 4, VAR_ELLIP = 5, VAR_SOFTALL = 6, VAR_REPAIR = 7,
        VAR_CPP = 8, VAR_CPP2 = 9 /* dmpc/cpp solveQPv2 with _k_factor 0 / -1 */ };
@@ -51,6 +52,8 @@ struct StepParams {
     double *dbg;            // optional per-iteration trace of agent dbg_agent (development aid)
     int dbg_agent, dbg_cap;
     int short_from;         // unequal clusters: chunks r >= short_from hold C-1 agents (last column = padding); 0: all chunks hold C
+    int crash_min;          // crash start of the acceleration bounds when at least this many are violated at the unconstrained minimiser (0: never)
+    int ladder_warm;        // retry ladder: the next level starts from the working set of the failed one (0: from scratch)
     int iter_cap;           // active-set iteration cap per try (ITER_CAP; development runs lower it to measure the per-iteration cost)
 };
 

@@ -354,23 +354,45 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
         }
     }
     if (!(status & (ST_COLL | ST_CAPACITY | ST_INFEAS))) {
+        // cslot: byte 0 = slot of the component's box constraint (0xff none), byte 1 = slot of its workspace bound,
+        // bits 16..19 = membership of BOXHI | BOXLO | POSHI | POSLO; cm: collision slots that constrain step k_l
+        unsigned cslot = 0x0000ffffu;
+        unsigned long long cm = 0ull;
+        // working-set membership of the collision rows: slack-free variants keep the bits of the register-cached rows in
+        // a register of the owning lane (bit c = row lane + 64 c), the rest (and all flags of the soft variants) in LDS bytes
+        unsigned rcfl = 0;
+        int nlive = 0;
+        // retry ladder, warm: a ladder step changes only right-hand sides (the slack bounds) and the linear cost of the slacks,
+        // no constraint normal -- the factor T of the working set an infeasible try ends with stays valid for the next level.
+        // The next try keeps working set, factor and multipliers, solves the multipliers for the new level in one
+        // refinement pass, drops those that come out negative (the finish of the crash start) and continues from there.
+        bool warm = false;
         while (tries < max_tries) {
             tries++;
-            q = 0;
-            // cslot: byte 0 = slot of the component's box constraint (0xff none), byte 1 = slot of its workspace bound,
-            // bits 16..19 = membership of BOXHI | BOXLO | POSHI | POSLO; cm: collision slots that constrain step k_l
-            unsigned cslot = 0x0000ffffu;
-            unsigned long long cm = 0ull;
-            // working-set membership of the collision rows: slack-free variants keep the bits of the register-cached rows in
-            // a register of the owning lane (bit c = row lane + 64 c), the rest (and all flags of the soft variants) in LDS bytes
-            unsigned rcfl = 0;
-            for (int i = lane + (soft ? 0 : 64 * RC); i < nr; i += 64) r_fl[i] = 0;
             int rc = 0;   // 0 running/ok, 1 infeasible, 2 capacity, 3 itercap
             int iters = 0;
-            a = a_unc; w = w_unc;
-            if (comp) { B[SL::A + lane] = a; B[SL::W + lane] = w; }
-            if (soft) for (int i = lane; i < nr; i += 64) r_eps[i] = 0.0;
+            if (!warm) {
+                q = 0; cslot = 0x0000ffffu; cm = 0ull; rcfl = 0; nlive = 0;
+                for (int i = lane + (soft ? 0 : 64 * RC); i < nr; i += 64) r_fl[i] = 0;
+                a = a_unc; w = w_unc;
+                if (comp) { B[SL::A + lane] = a; B[SL::W + lane] = w; }
+                if (soft) for (int i = lane; i < nr; i += 64) r_eps[i] = 0.0;
+            }
             double g_l = 0.0;   // gradient of the cost at the iterate (slack-free variants): Farkas test against the box
+            // Crash start of the acceleration bounds.  Far from its goal an agent saturates most of its 45 bounds |a| <= alim, and
+            // the dual method would add them one full iteration each.  While `crash` is on, only those bounds are candidates and
+            // a candidate is APPENDED to the factor without a step (no residual, no direction, no ratio test: a third of an
+            // iteration); when no further bound is violated at the stale iterate the multipliers of the whole working set are
+            // solved at once (lambda += T T' rho, the refinement pass) and the primal re-derived.  Multipliers that come out
+            // negative are dropped and the crash ends; what it leaves is a working set with lambda >= 0 whose equality-constrained
+            // minimiser is the iterate -- a valid state of the dual method, which continues from there with every constraint.
+            // (slack-free variants: measured on solveHardDMPC, where rows sit on every horizon step, the guess is poor and the crash costs
+            // 16 % -- compiled out there)
+            bool crash = SOFT && (warm || (P.crash_min > 0 && __popcll(__ballot(comp && fabs(a_unc) - P.alim > tol)) >= P.crash_min));
+            bool crash_stop = warm;          // warm: straight to the finish (solve the multipliers of the kept working set)
+            const bool crash_box = !warm;    // every slot of the batch is an acceleration bound
+            int crash_rounds = 0, nfast = 0;
+            const double dual0 = dual;
             LSYNC();
 
             // nu = sgn * n_p - N_W r assembled as one vector in a-space, from the vector r in B[RR]:
@@ -488,12 +510,39 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                 return c;
             };
 
-            int nlive = 0;
-            bool fresh = true;              // primal == x(lambda) with refined lambda
+            // delete slot l from the working set, with the bookkeeping of its kind; the pin of a soft row whose collision row just
+            // left the set is de-instantiated with it (not for row `keep_row`: the entering constraint's own row)
+            auto drop_slot = [&](int l, int keep_row) {
+                const int dmeta = s_meta[l];
+                const int dty = (dmeta >> 8) & 0xff, didx = dmeta >> 16;
+                LSYNC();
+                if (dty >= TY_COLL) {
+                    if (!soft && didx < 64 * RC) { if (lane == (didx & 63)) rcfl &= ~(1u << (didx >> 6)); }
+                    else if (lane == 0) {
+                        const int bit = (dty == TY_COLL) ? RF_COLL : (dty == TY_SLKU ? RF_SLKU : RF_SLKL);
+                        r_fl[didx] &= ~bit;
+                    }
+                }
+                remove_slot2<SOFT, QCAP, PERSIST>(B, lane, q, l, cslot, cm);
+                if (soft && dty == TY_COLL && didx != keep_row) {
+                    const int fl = r_fl[didx];
+                    if ((fl & RF_LIVE) && (fl & RF_SLKU) && !(fl & RF_SLKL)) {
+                        const int mm = (lane < q) ? s_meta[lane] : 0;
+                        const unsigned long long um = __ballot(lane < q && ((mm >> 8) & 0xff) == TY_SLKU && (mm >> 16) == didx);
+                        const int ul = __ffsll((long long)um) - 1;
+                        LSYNC();
+                        if (lane == 0) { r_fl[didx] = 0; r_eps[didx] = 0.0; }
+                        remove_slot2<SOFT, QCAP, PERSIST>(B, lane, q, ul, cslot, cm);
+                        nlive--;
+                    }
+                }
+            };
+
+            bool fresh = !warm;             // primal == x(lambda) with refined lambda
             int since_sync = 0;
             bool cert_done = false;
             for (;;) {
-                if (soft && ladder && violation && !cert_done && iters >= LADDER_CERT_AFTER) {
+                if (soft && ladder && violation && !cert_done && iters - nfast >= LADDER_CERT_AFTER) {
                     cert_done = true;
                     if (ladder_level_infeasible(r_xi, r_b, r_sd, r_slb, r_kc, nr, B + SL::RR, P.h, P.alim, 1.0, whi_l, wlo_l, lane)) { rc = 1; break; }
                 }
@@ -501,13 +550,16 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                 double bestv = 0.0; float bests = 0.f; int bestc = -1;
 #define CAND(v_, w_, code_) do { const double v__ = (v_); const float s__ = (float)v__ * (w_); \
                                  if (v__ > tol && s__ > bests) { bests = s__; bestv = v__; bestc = (code_); } } while (0)
-                if (comp) {
+                // the crash ends its batch when nothing is left to append, when a multiplier had to be dropped, or short of the capacity
+                const bool crash_finish = crash && (crash_stop || q >= QCAP - 4);
+                if (comp && !crash_finish) {
                     // a <= alim and -a <= alim are violated one at a time: one candidate for the pair (not while a member is active)
                     const bool hi = a > 0.0;
                     if (!(cslot & 0x30000u)) CAND(fabs(a) - P.alim, wbox_f, ((hi ? TY_BOXHI : TY_BOXLO) << 16) | lane);
                     const double c2 = w - whi_l, c3 = wlo_l - w;
-                    if (!(cslot & 0xc0000u)) CAND(fmax(c2, c3), wpos_f, ((c2 > c3 ? TY_POSHI : TY_POSLO) << 16) | lane);
+                    if (!crash && !(cslot & 0xc0000u)) CAND(fmax(c2, c3), wpos_f, ((c2 > c3 ? TY_POSHI : TY_POSLO) << 16) | lane);
                 }
+                if (!crash) {
 #pragma unroll
                 for (int c = 0; c < RC; ++c) {   // rows held in registers
                     const int i = lane + 64 * c;
@@ -537,12 +589,16 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                     }
                     if (!(fl & RF_COLL) && v > tol) CAND(v, row_weight(x0, x1, x2, kc, soft ? r_sd[i] : 0.0), (TY_COLL << 16) | i);
                 }
+                }
 #undef CAND
                 const float smax = wave_max_f(bests);
                 const unsigned long long wm = __ballot(bestc >= 0 && bests == smax);
                 if (wm == 0ull) {
-                    if (q == 0 || fresh) break;   // optimal
+                    if (!crash && (q == 0 || fresh)) break;   // optimal
+                    const bool was_fresh = fresh;
                     // verification: primal from the multipliers, refine the active-set residual, re-check
+                    // (crash: the appended slots carry lambda = 0 and their violation at the stale iterate -- the same pass solves them)
+                    if (!fresh) {
                     primal_fast();
                     for (int pass = 0; pass < 3; ++pass) {
                         const double rho = (lane < q) ? slot_value(lane) : 0.0;
@@ -555,6 +611,26 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                         if (lane < q) B[SL::SLAM + lane] += ri;
                         LSYNC();
                         primal_fast();
+                    }
+                    }
+                    if (crash) {
+                        unsigned long long neg = __ballot(lane < q && B[SL::SLAM + (lane < q ? lane : 0)] < 0.0);
+                        if (neg != 0ull) {   // guessed bounds that do not belong: drop them (highest slot first), solve again, then leave the crash
+                            LSYNC();
+                            if (crash_box) {
+                                while (neg != 0ull) {
+                                    const int l = 63 - __clzll((long long)neg);
+                                    neg &= ~(1ull << l);
+                                    remove_slot2<SOFT, QCAP, PERSIST>(B, lane, q, l, cslot, cm);
+                                }
+                            } else drop_slot(63 - __clzll((long long)neg), -1);   // any kind of slot (and maybe its pin): one per pass
+                            crash_stop = true; fresh = false;
+                            continue;
+                        }
+                        if (was_fresh || crash_stop || ++crash_rounds >= 8) {
+                            crash = false;
+                            if (!soft) dual = dual0 + 0.5 * wave_sum0(g_l * (a - a_unc));   // cost at x(lambda): f(x_unc) + 1/2 nu' H^-1 nu
+                        }
                     }
                     fresh = true;
                     continue;
@@ -626,6 +702,18 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                     B[SL::RR + lane] = dvj; LSYNC();
                     const double ri = t_mul2<QCAP, SL::T, SL::RR>(B, lane, q);
                     LSYNC();
+                    if (crash) {   // append without a step: column [-r/rho; 1/rho] with rho^2 = s_pp - |T's|^2, lambda_p = 0 until the batch is solved
+                        const double dlt = spp - wave_sum0(dvj * dvj);
+                        if (!(dlt > 1e-9 * spp)) { crash_stop = true; break; }   // (distinct bounds are independent; guard only)
+                        const double irho = rsqrt(dlt);
+                        if (lane < ((q + 8) & ~7)) B[SL::T + tcol(q) + lane] = (lane < q) ? (-ri * irho) : ((lane == q) ? irho : 0.0);
+                        write_slot(p, 0.0);
+                        if (lane == p.idx) cslot = (cslot & ~0xffu) | (unsigned)q | (p.ty == TY_BOXHI ? 0x10000u : 0x20000u);
+                        q++; nfast++;
+                        if (q > maxq) maxq = q;
+                        LSYNC();
+                        break;
+                    }
                     B[SL::RR + lane] = ri;
                     unsigned long long smk = 0ull;
                     if (soft) smk = __ballot(lane < q && ((mymeta >> 8) & 0xff) >= TY_COLL && B[SL::SSS + (lane < q ? lane : 0)] != 0.0);
@@ -727,30 +815,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                     // partial step: drop the blocking constraint
                     const unsigned long long bm = __ballot(lane < q && ri > 0.0 && iratio == imax);
                     const int l = __ffsll((long long)bm) - 1;
-                    const int dmeta = s_meta[l];
-                    const int dty = (dmeta >> 8) & 0xff, didx = dmeta >> 16;
-                    LSYNC();
-                    if (dty >= TY_COLL) {
-                        if (!soft && didx < 64 * RC) { if (lane == (didx & 63)) rcfl &= ~(1u << (didx >> 6)); }
-                        else if (lane == 0) {
-                            const int bit = (dty == TY_COLL) ? RF_COLL : (dty == TY_SLKU ? RF_SLKU : RF_SLKL);
-                            r_fl[didx] &= ~bit;
-                        }
-                    }
-                    remove_slot2<SOFT, QCAP, PERSIST>(B, lane, q, l, cslot, cm);
-                    // de-instantiate the pin of a soft row whose collision row just left the set
-                    if (soft && dty == TY_COLL && didx != ((p.ty == TY_COLL) ? p.idx : -1)) {
-                        const int fl = r_fl[didx];
-                        if ((fl & RF_LIVE) && (fl & RF_SLKU) && !(fl & RF_SLKL)) {
-                            const int mm = (lane < q) ? s_meta[lane] : 0;
-                            const unsigned long long um = __ballot(lane < q && ((mm >> 8) & 0xff) == TY_SLKU && (mm >> 16) == didx);
-                            const int ul = __ffsll((long long)um) - 1;
-                            LSYNC();
-                            if (lane == 0) { r_fl[didx] = 0; r_eps[didx] = 0.0; }
-                            remove_slot2<SOFT, QCAP, PERSIST>(B, lane, q, ul, cslot, cm);
-                            nlive--;
-                        }
-                    }
+                    drop_slot(l, (p.ty == TY_COLL) ? p.idx : -1);
                     LSYNC();
                 }
                 if (rc) break;
@@ -785,6 +850,9 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                        ladder_level_infeasible(r_xi, r_b, r_sd, r_slb, r_kc, nr, B + SL::RR, P.h, P.alim, f, whi_l, wlo_l, lane)) { f *= 2.0; ++tries; }
                 for (int i = lane; i < nr; i += 64) { r_slb[i] *= f; r_st[i] *= f; }
                 rcslb[0] *= f; rcslb[1] *= f;
+                // warm start of the next level: the slack lower bounds in the working set get their new right-hand side (d = -lb)
+                warm = P.ladder_warm && q > 0;
+                if (warm && lane < q && ((s_meta[lane] >> 8) & 0xff) == TY_SLKL) B[SL::SD + lane] *= f;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 LSYNC();
