@@ -57,7 +57,7 @@ struct dmpc_ctx {
     int64_t solves = 0;
     int max_lds_set = 0;
     // scratch for the host-pointer entry points
-    DevBuf rowbuf, rowkc, hdr, order, bbox, counter, flag_list, scene_done;
+    DevBuf rowbuf, rowkc, hdr, order, bbox, nbr_list, nbr_cnt, lrow, counter, flag_list, scene_done;
     int num_cu = 0;
     int no_persist = getenv("DMPC_NO_PERSIST") ? 1 : 0;   // tuning: one-agent-per-workgroup solve launches
     int max_lds_persist = 0;
@@ -440,13 +440,9 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     const bool shallow = (long)S * c_count < 16L * (ctx->num_cu > 0 ? ctx->num_cu : 256) * 8 && !ctx->force_persist && !getenv("DMPC_TIER1_QCAP");
     const int q1 = (ctx->single_tier || shallow) ? full_qcap(p.variant) : tier1_qcap(p.variant), q2 = full_qcap(p.variant);
     const bool two_tier = q1 < q2;
-    // neighbour list of the scan: a quarter of the scene (fast agents have long horizon boxes), 1024..8192 entries
-    int nbr_cap = 0;
-    if (G * C >= 256 && !ctx->no_cull) { nbr_cap = 1024; while (nbr_cap < G * C / 4 && nbr_cap < 8192) nbr_cap *= 2; }
-    P.nbr_cap = nbr_cap;
     P.scene_done = scene_done;
     P.short_from = short_from;   // unequal clusters: chunks from here on hold C-1 agents (dmpc_multigpu.hip)
-    const size_t lds0 = scan_lds_bytes(nbr_cap);
+    const size_t lds0 = scan_lds_bytes();
     const size_t lds1 = solve_lds_bytes(P.nrmax, soft, q1, false), lds2 = solve_lds_bytes(P.nrmax, soft, q2, false);
     const size_t ldsmax = lds2 > lds1 ? lds2 : lds1;
     if ((int)ldsmax > ctx->max_lds_set) {
@@ -471,10 +467,27 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
                                p.variant == DMPC_VAR_CPP2;
     if (G * C >= 256 && !ctx->no_cull && finite_radius) {
         const int total = G * S * C;
-        if (ctx->bbox.ensure((size_t)total * 6 * 8)) FAIL(ctx, "device allocation failed (bbox)");
-        if (lTf) hipLaunchKernelGGL(bbox_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, C, lTf, ctx->bbox.as<double>());
-        else hipLaunchKernelGGL(bbox_kernel<double>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, C, lT, ctx->bbox.as<double>());
-        P.bbox = ctx->bbox.as<double>();
+        if (ctx->bbox.ensure((size_t)total * 6 * NSEG * 4)) FAIL(ctx, "device allocation failed (bbox)");
+        if (lTf) hipLaunchKernelGGL(bbox_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, C, lTf, ctx->bbox.as<float>());
+        else hipLaunchKernelGGL(bbox_kernel<double>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, C, lT, ctx->bbox.as<float>());
+        // neighbour lists from the boxes (nbr_kernel): up to 4096 entries per agent, within 1 GB of scratch
+        const size_t agents = (size_t)S * c_count;
+        long cap = ((long)G * C + 63) & ~63L;
+        if (cap > 4096) cap = 4096;
+        while (cap > 256 && agents * (size_t)cap * 4 > ((size_t)1 << 30)) cap >>= 1;
+        if (ctx->nbr_list.ensure(agents * (size_t)cap * 4) || ctx->nbr_cnt.ensure(agents * 4 * NBR_PARTS)) FAIL(ctx, "device allocation failed (neighbour lists)");
+        const double R = ((p.variant == DMPC_VAR_HARD) ? 1.0 : 3.0 * p.rmin) * 1.0001 + 1e-4;   // a little more than the scan's radius: conservative in fp32 too
+        const int nblk = (c_count + NBR_BLOCK - 1) / NBR_BLOCK;
+        hipLaunchKernelGGL(nbr_kernel, dim3((unsigned)(S * nblk * NBR_PARTS)), dim3(64), 0, st, S, G, C, g_local, c_first, c_count, short_from, (float)R, (float)(R * p.c),
+                           (const float *)ctx->bbox.as<float>(), (int)cap, ctx->nbr_list.as<int>(), ctx->nbr_cnt.as<int>());
+        P.nbr_cap = (int)cap; P.nbr_list = ctx->nbr_list.as<int>(); P.nbr_cnt = ctx->nbr_cnt.as<int>();
+        if (p.variant != DMPC_VAR_HARD) {   // the list walk of the per-step distance scan reads a neighbour-major copy of the table
+            const size_t tot = (size_t)total * 64;
+            if (ctx->lrow.ensure(tot * 4)) FAIL(ctx, "device allocation failed (neighbour-major table)");
+            if (lTf) hipLaunchKernelGGL(table_nbrmajor_kernel<float>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, tot, C, lTf, ctx->lrow.as<float>());
+            else hipLaunchKernelGGL(table_nbrmajor_kernel<double>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, tot, C, lT, ctx->lrow.as<float>());
+            P.lrow = ctx->lrow.p;
+        }
     }
     if (!shallow) HIPCHK(ctx, hipMemsetAsync(ctx->counter.p, 0, 16, st));   // queue heads of the persistent solve launches
     // phase 0: scan + rows
@@ -804,9 +817,9 @@ extern "C" int dmpc_rows_one(dmpc_ctx *ctx, int N, int n, const double *l, const
     const size_t per = (size_t)P.nrmax * (soft ? 7 : 4);
     if (ctx->rowbuf.ensure(per * 8) || ctx->rowkc.ensure((size_t)P.nrmax * 4) || ctx->hdr.ensure(32)) FAIL(ctx, "device allocation failed");
     P.rowbuf = ctx->rowbuf.as<double>(); P.rowkc = ctx->rowkc.as<int>(); P.hdr = ctx->hdr.as<int>();
-    P.lds_per_wave = (int)scan_lds_bytes(0);
-    if (soft) hipLaunchKernelGGL((dmpc_scan_kernel<true, double>), dim3(1), dim3(64), scan_lds_bytes(0), st, P);
-    else hipLaunchKernelGGL((dmpc_scan_kernel<false, double>), dim3(1), dim3(64), scan_lds_bytes(0), st, P);
+    P.lds_per_wave = (int)scan_lds_bytes();
+    if (soft) hipLaunchKernelGGL((dmpc_scan_kernel<true, double>), dim3(1), dim3(64), scan_lds_bytes(), st, P);
+    else hipLaunchKernelGGL((dmpc_scan_kernel<false, double>), dim3(1), dim3(64), scan_lds_bytes(), st, P);
     HIPCHK(ctx, hipGetLastError());
     int hdr[8];
     HIPCHK(ctx, hipMemcpyAsync(hdr, ctx->hdr.p, 32, hipMemcpyDeviceToHost, st));

@@ -18,6 +18,8 @@ __host__ __device__ constexpr int tcol(int j) { return 8 * (j >> 3) * (4 * (j >>
 __host__ __device__ constexpr int t_doubles(int qcap) { return tcol((qcap + 7) & ~7); }
 constexpr int ITER_CAP = 4000;
 constexpr int CRASH_MIN_DEFAULT = 4;
+constexpr int NBR_BLOCK = 8;    // nbr_kernel: agents per wave
+constexpr int NBR_PARTS = 4;    // nbr_kernel: the tiles of a scene are split over this many waves per agent block (N / NBR_BLOCK waves alone do not fill the chip)
 
 enum { VAR_BOUND = 0, VAR_BOUND2 = 1, VAR_ALL3 = 2, VAR_HARD = 3, VAR_ONDEMAND = 4, VAR_ELLIP = 5, VAR_SOFTALL = 6, VAR_REPAIR = 7,
        VAR_CPP = 8, VAR_CPP2 = 9 /* dmpc/cpp solveQPv2 with _k_factor 0 / -1 */ };
@@ -42,9 +44,11 @@ struct StepParams {
     int *hdr;               // [S*c_count][8] scan -> solve hand-off (row count, branch record)
     int only_flagged, qover_bit;
     int no_prune;           // 1: keep every row the reference builds (dmpc_rows_one); 0: exact pruning
-    const double *bbox;     // [G][S][6][C] horizon bounding boxes (bbox_kernel) or null: neighbour culling in the scan
     const int *order;       // solve-phase launch order (agent ids, heaviest first) or null
-    int nbr_cap;            // scan: capacity of the LDS neighbour list (0: no list)
+    int nbr_cap;            // capacity of an agent's neighbour list (ints)
+    int *nbr_list;          // [S*c_count][nbr_cap] neighbours that can come close, in increasing index order (nbr_kernel), or null
+    const void *lrow;       // neighbour-major copy of the table the scan reads (table_nbrmajor_kernel), with the lists; or null
+    const int *nbr_cnt;     // [S*c_count][NBR_PARTS] entries of each piece of a list; -1: did not fit (the scan walks the whole table)
     const int *scene_done;  // [S] or null: scenes of a transition that already stopped (reached their goals / failed): skipped
     int *counter;           // persistent solve kernel: queue head (zeroed before the launch)
     int lds_per_wave;       // persistent solve kernel: bytes of LDS per wave (after the shared tables)
@@ -69,7 +73,7 @@ constexpr int TAB_DOUBLES = 3 * TAB_CASE_DOUBLES + TAB_L_DOUBLES;   // 2925
 
 // bytes of dynamic LDS of one scan wave: own prediction, unconstrained minimiser + candidate list of the all-k (hard) scan +
 // neighbour list
-inline size_t scan_lds_bytes(int nbr_cap) { return (96 * 8 + (SCAN_CAND_CAP + (size_t)nbr_cap) * 4 + 15) & ~(size_t)15; }
+inline size_t scan_lds_bytes() { return (96 * 8 + (size_t)SCAN_CAND_CAP * 4 + 15) & ~(size_t)15; }
 // bytes of LDS of one solve wave (layout: SolveLds in dmpc_solve.hip; `persist`: the tables are shared by the workgroup)
 inline size_t solve_lds_bytes(int nrmax, bool soft, int qcap, bool persist)
 {

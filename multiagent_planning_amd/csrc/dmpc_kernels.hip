@@ -70,6 +70,20 @@ __device__ __forceinline__ double op_min(double a, double b) { return fmin(a, b)
 __device__ __forceinline__ double op_add(double a, double b) { return a + b; }
 DMPC_WAVE_REDUCE(wave_max, -INFINITY, op_max)
 DMPC_WAVE_REDUCE(wave_min, INFINITY, op_min)
+
+// value of lane + N of the same 16-lane row (row_shl DPP); lanes whose source falls off the row keep their own value
+template <int N>
+__device__ __forceinline__ double dpp_row_shl(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), 0x100 + N, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), 0x100 + N, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int N>
+__device__ __forceinline__ float dpp_row_shl(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x100 + N, 0xf, 0xf, false));
+}
 DMPC_WAVE_REDUCE(wave_sum, 0.0, op_add)
 __device__ __forceinline__ unsigned wave_or(unsigned v)
 {
@@ -254,13 +268,13 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
     constexpr real MARG = std::is_same<TT, float>::value ? (real)2e-5 : (real)1e-9;
     Lds L;
     real *own_s, *w_s;
-    int *scan_cand = nullptr, *scan_nbr = nullptr;
+    int *scan_cand = nullptr;
+    const int *scan_nbr = nullptr;
     {
         double *p = (double *)smem;
         own_s = (real *)p; p += 48;
         w_s = (real *)p; p += 48;   // unconstrained minimiser in position space (launch-order key of the slack-free variants)
         scan_cand = (int *)p;   // SCAN_CAND_CAP ints
-        scan_nbr = scan_cand + SCAN_CAND_CAP;   // P.nbr_cap ints
         // Collision rows live in a per-agent slice of a GLOBAL scratch buffer (L2-resident; lane = row, so
         // every access is a coalesced wave load): keeping them out of LDS is what lets several times more
         // agents be resident per CU.  Only the per-row working-set flags and the slack values stay in LDS.
@@ -304,43 +318,28 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
     const bool coll_check = (var == VAR_BOUND || var == VAR_BOUND2 || var == VAR_ALL3 || var == VAR_REPAIR);
     const bool skip_k1 = (var == VAR_BOUND2 || var == VAR_ALL3 || var == VAR_REPAIR || var == VAR_CPP2);
     bool coll_flag = false;
-    // own horizon box (uniform) for the neighbour culling; with a neighbour list only
-    real obx0 = 0, obx1 = 0, oby0 = 0, oby1 = 0, obz0 = 0, obz1 = 0;
-    if (P.bbox && P.nbr_cap > 0) {
-        const real v = (lane < N3) ? own_s[lane] : 0.0;
-        const int ax = lane % 3;
-        const double vd = (double)v;
-        obx0 = (real)wave_min((lane < N3 && ax == 0) ? vd : INFINITY); obx1 = (real)wave_max((lane < N3 && ax == 0) ? vd : -INFINITY);
-        oby0 = (real)wave_min((lane < N3 && ax == 1) ? vd : INFINITY); oby1 = (real)wave_max((lane < N3 && ax == 1) ? vd : -INFINITY);
-        obz0 = (real)wave_min((lane < N3 && ax == 2) ? vd : INFINITY); obz1 = (real)wave_max((lane < N3 && ax == 2) ? vd : -INFINITY);
-    }
-    // Neighbour compaction (large scenes): a neighbour can come within ellipsoidal distance R of the agent at some
+    // Neighbour list (large scenes, nbr_kernel): a neighbour can come within ellipsoidal distance R of the agent at some
     // horizon step only if the bounding boxes of the two predicted horizons are within R per axis.  The survivors of
-    // that test (a few per cent at N = 10^3..10^4) are compacted, in increasing index order, into an LDS list, and
-    // the distance tests / row builders below walk the list instead of all N neighbours.  Conservative: results are
-    // unchanged.  nnbr < 0: no list (small scenes, variants that take every neighbour, or more survivors than fit).
+    // that test (3 % of the scene at N = 10^4) come, in increasing index order, from the pre-pass; the distance tests /
+    // row builders below walk the list instead of all N neighbours.  Conservative: results are unchanged.
+    // nnbr < 0: no list (small scenes, variants that take every neighbour, or more survivors than the list holds).
     int nnbr = -1;
-    if (P.bbox && P.nbr_cap > 0) {
-        const real R = (var == VAR_HARD) ? 1.0 : 3.0 * rmin, Rz = R / e1z;   // |dz|/c < R; the cpp radius is <= 2 rmin
-        int cnt = 0;
+    if (P.nbr_cnt) {
+        // the pre-pass leaves the list in NBR_PARTS pieces (one per quarter of the scene, each in increasing neighbour order): close the gaps
+        int *lst = P.nbr_list + (size_t)gid * P.nbr_cap;
+        const int pcap = P.nbr_cap / NBR_PARTS;
+        int tot = 0;
         bool fits = true;
-        for (int r = 0; r < G && fits; ++r)
-            for (int j0 = 0; j0 < C; j0 += 64) {
-                const int jj = j0 + lane;
-                const bool valid = jj < C - ((P.short_from && r >= P.short_from) ? 1 : 0) && !(r == P.g_local && jj == cl);
-                const int jc = jj < C ? jj : C - 1;
-                const double *bb = P.bbox + ((size_t)(r * S + scene) * 6) * C + jc;
-                const bool hit = valid && bb[0] <= obx1 + R && bb[(size_t)C] >= obx0 - R && bb[2 * (size_t)C] <= oby1 + R &&
-                                 bb[3 * (size_t)C] >= oby0 - R && bb[4 * (size_t)C] <= obz1 + Rz && bb[5 * (size_t)C] >= obz0 - Rz;
-                const unsigned long long hm = __ballot(hit);
-                if (hm) {
-                    if (cnt + __popcll(hm) > P.nbr_cap) { fits = false; break; }
-                    if (hit) scan_nbr[cnt + lanes_below(hm, lane)] = (r << 20) | jc;
-                    cnt += __popcll(hm);
-                }
-            }
-        if (fits) nnbr = cnt;
-        LSYNC();
+        for (int q = 0; q < NBR_PARTS; ++q) {
+            const int n = P.nbr_cnt[(size_t)gid * NBR_PARTS + q];
+            if (n < 0) { fits = false; break; }
+            if (q > 0 && tot < q * pcap)
+                for (int i = lane; i < n; i += 64) lst[tot + i] = lst[q * pcap + i];   // moves down: a round's reads are at or above its writes
+            tot += n;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (fits) { nnbr = tot; scan_nbr = lst; }
     }
     // the neighbours are walked 64 at a time: entry e0 + lane of the list, or neighbour (r, j0 + lane) of the table
     const int cpad = (C + 63) & ~63;
@@ -559,6 +558,56 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
             };
             if (G == 1 && nnbr < 0) pass(std::true_type{});
             else pass(std::false_type{});
+        } else if (nnbr >= 0 && P.lrow) {
+            // Neighbour list: the walk is TRANSPOSED -- lanes = horizon components, one listed neighbour per step of the loop.
+            // With lanes = neighbours every table load of a round is a gather of 64 cache lines (45 of them per round: at
+            // N = 10^4 the list walk took 1-2 ms of gathers); here a neighbour's whole horizon is ONE coalesced 256-byte load
+            // from the neighbour-major fp32 copy of the table (table_nbrmajor_kernel: [chunk][scene][column][15 x (x, y, z, 0) + 4];
+            // 2.5 MB at N = 10^4: L2 resident), and the three squares of a step are summed with two row-shift DPP moves (groups
+            // of 4 lanes never straddle a row).  The fp32 distance only SELECTS (threshold widened by 1e-3, a hundred times the
+            // rounding of a workspace-sized coordinate); the decision dist < rmin is made on the table itself, with the
+            // arithmetic of the other walk, for the few (step, neighbour) pairs that pass.
+            const float *rt = (const float *)P.lrow;
+            constexpr int TW = 8;
+            const int k4 = lane >> 2, a4 = lane & 3;
+            const bool act = a4 < 3 && k4 < K;
+            const bool head = a4 == 0 && k4 < K;
+            const float ownc = act ? (float)own_s[3 * k4 + a4] : 0.f;
+            const float sc = act ? (a4 == 2 ? (float)e1z : 1.f) : 0.f;
+            const float thr = (float)(rmin * rmin) * 1.001f;
+            const int k3 = head ? 3 * k4 : 0;
+            for (int e0 = 0; e0 < nnbr; e0 += 64) {
+                const int codes = (e0 + lane < nnbr) ? scan_nbr[e0 + lane] : 0;
+                const int m = (nnbr - e0) < 64 ? (nnbr - e0) : 64;
+                for (int u0 = 0; u0 < m; u0 += TW) {
+                    float nv[TW];   // loads in flight
+                    int cu[TW];
+#pragma unroll
+                    for (int u = 0; u < TW; ++u) {
+                        const int uu = (u0 + u < m) ? u0 + u : m - 1;   // (a repeated neighbour changes nothing: OR and min)
+                        cu[u] = readlane_i(codes, uu);
+                        nv[u] = rt[((size_t)((cu[u] >> 20) * S + scene) * C + (cu[u] & 0xfffff)) * 64 + lane];
+                    }
+#pragma unroll
+                    for (int u = 0; u < TW; ++u) {
+                        const float d = (ownc - nv[u]) * sc;
+                        const float q2 = d * d;
+                        const float d2f = (q2 + dpp_row_shl<1>(q2)) + dpp_row_shl<2>(q2);   // lanes 4k: squared distance at step k
+                        const bool flag = head && d2f < thr;
+                        if (__any(flag)) {
+                            const real *nb = tab + ((size_t)((cu[u] >> 20) * S + scene) * N3 + k3) * C + (cu[u] & 0xfffff);
+                            if (flag) {
+                                const real dx = own_s[k3] - nb[0], dy = own_s[k3 + 1] - nb[(size_t)C], dz = own_s[k3 + 2] - nb[2 * (size_t)C];
+                                const real ez = dz * e1z;
+                                const real d2 = dx * dx + dy * dy + ez * ez;
+                                const real dist = sqrt(d2);
+                                if (dist < rmin) anyb |= (1u << k4);       // CheckCollSoftDMPC.m:11
+                                if (k4 == 0) mind0 = fmin(mind0, d2);       // (only ever used when some neighbour is inside rmin at k = 0)
+                            }
+                        }
+                    }
+                }
+            }
         } else {
             for (int e0 = 0; e0 < n_entries; e0 += 64) {
                 int r, jc;
@@ -759,28 +808,123 @@ __global__ __launch_bounds__(512, 1) void dmpc_solve_persist_kernel(StepParams P
 // small layout / bookkeeping kernels
 // --------------------------------------------------------------------------------------------
 
-// Axis-aligned bounding box of every agent's predicted horizon: bbox[G][S][6][C] = xmin,xmax,ymin,ymax,zmin,zmax.
-// The scan culls whole neighbour chunks with it (a neighbour can come within R of the agent at some step
-// only if the boxes are within R per axis), which turns the O(K N) table reads per agent into O(N) 48-B
-// box reads plus the few chunks that really contain near neighbours.  Conservative => results unchanged.
+// Axis-aligned bounding boxes of every agent's predicted horizon, one per third of the horizon (steps 0-4, 5-9, 10-14):
+// bbox[G][S][18][C] (fp32, rounded outwards) = per segment xmin,xmax,ymin,ymax,zmin,zmax.  A neighbour can come within R of the agent at step k only
+// if the boxes of the segment that holds k are within R per axis.  (One box for the whole horizon lets 20 % of a 10^4-agent
+// scene through once the agents move -- 4.3 m of horizon each; the three segments 4-5 times fewer.)
+constexpr int NSEG = 3, SEG_STEPS = K / NSEG;
+static_assert(NSEG * SEG_STEPS == K, "horizon segments");
 template <typename TT>
-__global__ void bbox_kernel(int total, int C, const TT *__restrict__ lT, double *__restrict__ bbox)
+__global__ void bbox_kernel(int total, int C, const TT *__restrict__ lT, float *__restrict__ bbox)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;   // enumerates (g*S + s)*C + c
     if (i >= total) return;
     const int c = i % C;
     const size_t gs = (size_t)(i / C);
     const TT *src = lT + gs * N3 * C + c;
-    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-    for (int k = 0; k < K; ++k)
+    float *dst = bbox + gs * (6 * NSEG) * C + c;   // fp32, rounded outwards: the boxes only ever have to be conservative
+    for (int sg = 0; sg < NSEG; ++sg) {
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        for (int k = sg * SEG_STEPS; k < (sg + 1) * SEG_STEPS; ++k)
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const double v = (double)src[(size_t)(3 * k + a) * C];
-            lo[a] = fmin(lo[a], v); hi[a] = fmax(hi[a], v);
+            for (int a = 0; a < 3; ++a) {
+                const double v = (double)src[(size_t)(3 * k + a) * C];
+                lo[a] = fmin(lo[a], v); hi[a] = fmax(hi[a], v);
+            }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { dst[(size_t)(6 * sg + 2 * a) * C] = __double2float_rd(lo[a]); dst[(size_t)(6 * sg + 2 * a + 1) * C] = __double2float_ru(hi[a]); }
+    }
+}
+
+// Neighbour-major fp32 copy of the prediction table for the list walk of the scan: out[chunk][scene][column][64] with element
+// 4k + axis = component (k, axis) of that neighbour's horizon, 0 in the fourth slot of every step and in the last four.
+template <typename TT>
+__global__ void table_nbrmajor_kernel(size_t total, int C, const TT *__restrict__ lT, float *__restrict__ out)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int l = (int)(t & 63), k4 = l >> 2, a4 = l & 3;
+    const size_t gc = t >> 6, gs = gc / (size_t)C, c = gc - gs * (size_t)C;
+    out[t] = (a4 < 3 && k4 < K) ? (float)lT[(gs * N3 + 3 * k4 + a4) * C + c] : 0.f;
+}
+
+// Neighbour lists of large scenes.  One wave takes NBR_BLOCK agents of a scene and streams the segment boxes of the whole
+// scene past them ONCE: a tile of 64 neighbours per round (lane = neighbour, 18 coalesced loads, the next tile's loads issued
+// before this one is tested), tested against the inflated boxes of the NBR_BLOCK agents (LDS broadcast); a neighbour whose
+// box overlaps in any segment is appended to the agent's list, in increasing neighbour order (ballot + prefix popcount).
+// The test used to sit in the scan kernel, one wave per agent: at N = 10^4 every one of the 10^4 waves streamed the boxes
+// through L2 (4.8 GB per step); here the stream is read N / NBR_BLOCK times, in fp32 (the pre-pass is bound by exactly that
+// stream: 18 values per neighbour and tile).
+// code = (chunk << 20) | column, as the scan decodes it.  cnt = -1: more survivors than `cap` (the scan walks the table).
+// Part q writes its survivors to the q-th quarter of every agent's list (cap / NBR_PARTS entries) and their number to
+// cnt_out[agent][q] (-1: did not fit); the scan kernel closes the gaps (the quarters are in increasing neighbour order).
+__global__ __launch_bounds__(64) void nbr_kernel(int S, int G, int C, int g_local, int c_first, int c_count, int short_from, float R, float Rz,
+                                                 const float *__restrict__ bbox, int cap, int *__restrict__ list, int *__restrict__ cnt_out)
+{
+    constexpr int NB = 6 * NSEG;
+    __shared__ float ob[NBR_BLOCK][NB];
+    const int nblk = (c_count + NBR_BLOCK - 1) / NBR_BLOCK;
+    const int part = blockIdx.x % NBR_PARTS, sb = blockIdx.x / NBR_PARTS;
+    const int scene = sb / nblk, b = sb - scene * nblk;
+    const int lane = threadIdx.x;
+    const int ci0 = b * NBR_BLOCK, na = (c_count - ci0) < NBR_BLOCK ? (c_count - ci0) : NBR_BLOCK;
+    for (int i = lane; i < NB * NBR_BLOCK; i += 64) {
+        const int a = i / NB, x = i - NB * a;
+        const int cl = c_first + ci0 + (a < na ? a : 0);
+        const float v = bbox[((size_t)(g_local * S + scene) * NB + x) * C + cl];
+        const float infl = (x % 6 < 4) ? R : Rz;
+        ob[a][x] = (x & 1) ? v + infl : v - infl;   // even: lower bound - R, odd: upper bound + R (R carries a 1e-4 margin: far above the fp32 rounding of these sums)
+    }
+    __syncthreads();
+    int cnt[NBR_BLOCK];
+    bool over[NBR_BLOCK];
+#pragma unroll
+    for (int a = 0; a < NBR_BLOCK; ++a) { cnt[a] = 0; over[a] = false; }
+    const size_t gid0 = (size_t)scene * c_count + ci0;
+    const int pcap = cap / NBR_PARTS;
+    const int tiles_per_chunk = (C + 63) >> 6, ntiles = G * tiles_per_chunk;
+    const int t_lo = (int)((long)ntiles * part / NBR_PARTS), t_hi = (int)((long)ntiles * (part + 1) / NBR_PARTS);
+    float cur[NB], nxt[NB];
+    auto load_tile = [&](int t, float *dst) {
+        const int r = t / tiles_per_chunk, j0 = (t - r * tiles_per_chunk) << 6;
+        const int jj = j0 + lane, jc = jj < C ? jj : C - 1;
+        const float *bb = bbox + ((size_t)(r * S + scene) * NB) * C + jc;
+#pragma unroll
+        for (int x = 0; x < NB; ++x) dst[x] = bb[(size_t)x * C];
+    };
+    if (t_lo < t_hi) load_tile(t_lo, cur);
+    for (int t = t_lo; t < t_hi; ++t) {
+        if (t + 1 < t_hi) load_tile(t + 1, nxt);
+        const int r = t / tiles_per_chunk, j0 = (t - r * tiles_per_chunk) << 6;
+        const int jj = j0 + lane, jc = jj < C ? jj : C - 1;
+        const bool valid = jj < C - ((short_from && r >= short_from) ? 1 : 0);   // unequal clusters: the last column of a short chunk is padding
+        const int code = (r << 20) | jc;
+#pragma unroll
+        for (int a = 0; a < NBR_BLOCK; ++a) {
+            if (a < na) {
+                bool hit = false;
+#pragma unroll
+                for (int sg = 0; sg < NSEG; ++sg)
+                    hit = hit || (cur[6 * sg] <= ob[a][6 * sg + 1] && cur[6 * sg + 1] >= ob[a][6 * sg] && cur[6 * sg + 2] <= ob[a][6 * sg + 3] &&
+                                  cur[6 * sg + 3] >= ob[a][6 * sg + 2] && cur[6 * sg + 4] <= ob[a][6 * sg + 5] && cur[6 * sg + 5] >= ob[a][6 * sg + 4]);
+                hit = hit && valid && !((r == g_local) && (jj == c_first + ci0 + a));
+                const unsigned long long hm = __ballot(hit);
+                if (hm != 0ull && !over[a]) {
+                    const int n = __popcll(hm);
+                    if (cnt[a] + n > pcap) over[a] = true;
+                    else {
+                        if (hit) list[(gid0 + a) * (size_t)cap + (size_t)part * pcap + cnt[a] + lanes_below(hm, lane)] = code;
+                        cnt[a] += n;
+                    }
+                }
+            }
         }
-    double *dst = bbox + gs * 6 * C + c;
 #pragma unroll
-    for (int a = 0; a < 3; ++a) { dst[(size_t)(2 * a) * C] = lo[a]; dst[(size_t)(2 * a + 1) * C] = hi[a]; }
+        for (int x = 0; x < NB; ++x) cur[x] = nxt[x];
+    }
+#pragma unroll
+    for (int a = 0; a < NBR_BLOCK; ++a)
+        if (a < na && lane == 0) cnt_out[(gid0 + a) * NBR_PARTS + part] = over[a] ? -1 : cnt[a];
 }
 
 // Longest-processing-time-first launch order for the solve phase: agents are bucketed by the key the scan left in
