@@ -68,6 +68,7 @@ struct dmpc_ctx {
     int crash_min = getenv("DMPC_CRASH_MIN") ? atoi(getenv("DMPC_CRASH_MIN")) : CRASH_MIN_DEFAULT;   // see StepParams::crash_min
     int ladder_warm = getenv("DMPC_LADDER_COLD") ? 0 : 1;   // tuning: restart every retry-ladder level from scratch
     int iter_cap = getenv("DMPC_ITER_CAP") ? atoi(getenv("DMPC_ITER_CAP")) : ITER_CAP;   // development: cap the active-set iterations (agents beyond it end DMPC_ST_ITERCAP)
+    int tier1_env = getenv("DMPC_TIER1_QCAP") ? atoi(getenv("DMPC_TIER1_QCAP")) : 0;   // tuning / tests: 32 = two tiers for the slack variants (any value: no shallow-launch shortcut)
     int single_tier = 0;         // 1: solve with the full working-set capacity in one launch
     DevBuf lTf, lTf2;            // mixed precision: fp32 copies of the tables the scan reads
     DevBuf rows, lT, lT2, xp, xv, xa, pf, po, pout, vout, aout, status, info, hist_p, hist_v, hist_a, flags;
@@ -381,21 +382,22 @@ static int row_capacity(int variant, int N)
     return (int)((r + 1) & ~1L);
 }
 
-// tier-1 working-set capacity of the solve kernel: small enough for high occupancy; the (few) agents
-// whose working set outgrows it are flagged and re-solved by a tier-2 launch with the full capacity
-static int tier1_qcap(int variant)
-{
-    // the capacity is a template parameter of the solve kernels: 32 / 64 (slack-carrying variants), 48 (slack-free)
-    static const int env = getenv("DMPC_TIER1_QCAP") ? atoi(getenv("DMPC_TIER1_QCAP")) : 0;   // tuning override (tests: 64 = single tier)
-    if (env == 64 && variant_soft(variant)) return 64;
-    // slack-free variants (hard, ondemand, ellip): 45 variables => at most 45 independent active rows, one tier of 48;
-    // solveHardDMPC builds rows for every horizon step and its working sets routinely approach that limit.
-    // slack-carrying variants of small scenes stay far below 32 in the first tier
-    return variant_soft(variant) ? 32 : 48;
-}
-
+// Working-set capacity of the first solve launch.  The capacity is a template parameter of the solve kernels: 32 / 64
+// (slack-carrying variants), 48 (slack-free: 45 variables => at most 45 independent active rows, one tier).
+// Two tiers (32 slots first -- 8 instead of 5 resident agents per CU -- and a second launch with 64 for the agents that outgrow
+// them) were the round-1 default for the slack variants.  Measured in round 2 (bench secondaries): the agents that overflow are
+// exactly the long ones (several retry-ladder levels, many active rows), and re-solving them in a second, serialized launch
+// costs more than the occupancy gives: 51 200 agents of solveSoftDMPCbound 1.38 -> 1.07 ms per step with ONE 64-slot tier;
+// whole transitions unchanged.  The two-tier path stays available (DMPC_TIER1_QCAP=32; tests keep it covered).
+static int tier1_qcap(const dmpc_ctx *ctx, int variant);
 // hard: 45 variables => at most 45 independent active rows; 48 leaves room for a numerically near-dependent addition
 static int full_qcap(int variant) { return variant_soft(variant) ? QMAX : 48; }
+
+static int tier1_qcap(const dmpc_ctx *ctx, int variant)
+{
+    if (!variant_soft(variant)) return 48;
+    return ctx->tier1_env == 32 ? 32 : QMAX;
+}
 
 static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_first, int c_count, const double *lT,
                        const double *x_p, const double *x_v, const double *x_a, const double *pf, double *p_out,
@@ -437,8 +439,8 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     P.crash_min = (soft || getenv("DMPC_CRASH_MIN")) ? ctx->crash_min : 0;
     // shallow launches (a scene or a few: bound by the latency of their slowest agent, LDS is no constraint) solve with the
     // full working-set capacity in one launch; deep launches use the small first tier and re-solve the few that outgrow it
-    const bool shallow = (long)S * c_count < 16L * (ctx->num_cu > 0 ? ctx->num_cu : 256) * 8 && !ctx->force_persist && !getenv("DMPC_TIER1_QCAP");
-    const int q1 = (ctx->single_tier || shallow) ? full_qcap(p.variant) : tier1_qcap(p.variant), q2 = full_qcap(p.variant);
+    const bool shallow = (long)S * c_count < 16L * (ctx->num_cu > 0 ? ctx->num_cu : 256) * 8 && !ctx->force_persist && !ctx->tier1_env;
+    const int q1 = (ctx->single_tier || shallow) ? full_qcap(p.variant) : tier1_qcap(ctx, p.variant), q2 = full_qcap(p.variant);
     const bool two_tier = q1 < q2;
     P.scene_done = scene_done;
     P.short_from = short_from;   // unequal clusters: chunks from here on hold C-1 agents (dmpc_multigpu.hip)

@@ -337,6 +337,9 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
     // hdr[6] = retry-ladder levels already known to be infeasible (certified by the scan, or proven by a tier-1 launch
     // that then overflowed); hdr[4] bit 1 = the row data in global memory is already scaled
     int tries = hdr[6], iters_total = (P.only_flagged ? hdr[7] : 0), maxq = 0, q = 0;
+#ifdef DMPC_DEV_TRACE
+    int dev_nfast = 0, dev_rounds = 0, dev_negdrops = 0;
+#endif
     const bool rows_scaled = (hdr[4] & 2) != 0;
     bool solved = false;
     double a = 0.0, w = 0.0;
@@ -624,6 +627,9 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                                     remove_slot2<SOFT, QCAP, PERSIST>(B, lane, q, l, cslot, cm);
                                 }
                             } else drop_slot(63 - __clzll((long long)neg), -1);   // any kind of slot (and maybe its pin): one per pass
+#ifdef DMPC_DEV_TRACE
+                            dev_negdrops++;
+#endif
                             crash_stop = true; fresh = false;
                             continue;
                         }
@@ -832,6 +838,9 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                 if (((++since_sync) & 31) == 0) primal_fast();   // periodic re-sync with x(lambda)
             }
             iters_total += iters;
+#ifdef DMPC_DEV_TRACE
+            dev_nfast += nfast; dev_rounds += crash_rounds;
+#endif
             if (rc == 0) { solved = true; break; }
             if (rc == 2) {   // tier 1: flag for the tier-2 relaunch (and record the ladder position); last tier: capacity error
                 status |= P.qover_bit;
@@ -918,6 +927,9 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
             int *inf = Q.info + (size_t)gid * 8;
             inf[0] = viol_k; inf[1] = nrows_built; inf[2] = tries; inf[3] = ccase;
             inf[4] = iters_total; inf[5] = nslack; inf[6] = solved ? q : 0; inf[7] = maxq;
+#ifdef DMPC_DEV_TRACE
+            if (Q.dbg_agent == -4) { inf[0] = dev_nfast; inf[1] = dev_rounds; inf[3] = dev_negdrops; }   // development: crash statistics in place of the branch record
+#endif
         }
     }
 }

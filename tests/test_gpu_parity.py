@@ -143,15 +143,25 @@ def test_persistent_and_per_agent_solve_kernels_are_bitwise_identical(variant, m
     kw = wl.solver_kwargs(cfg, N)
     po, pf = wl.make_scenes(cfg, S, N, wl.SEED0 + 17)
     outs = []
-    for env in ("DMPC_NO_PERSIST", "DMPC_FORCE_PERSIST"):
-        monkeypatch.setenv(env, "1")
+    # third form: two capacity tiers for the slack variants (32 slots first, the agents that outgrow them re-solved with 64)
+    for env in ({"DMPC_NO_PERSIST": "1"}, {"DMPC_FORCE_PERSIST": "1"}, {"DMPC_FORCE_PERSIST": "1", "DMPC_TIER1_QCAP": "32"}):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
         d = mp.Dmpc(variant, **kw)            # the switches are read when the context is created
-        monkeypatch.delenv(env)
+        for k_ in env:
+            monkeypatch.delenv(k_)
         l, _, _ = d.init_batch(po, pf)
         z = np.zeros_like(po)
         outs.append(d.step_batch(l, po, z, z, pf))
     for k in ("p", "v", "a", "status", "info"):
         assert np.array_equal(outs[0][k], outs[1][k]), k
+    # two tiers: an agent that outgrows the first tier is solved again from the start of its ladder level (no warm start
+    # across the hand-off), so its path -- not its minimiser -- differs: same status, trajectories to solver accuracy
+    assert np.array_equal(outs[0]["status"], outs[2]["status"])
+    for k in ("p", "v", "a"):
+        assert np.abs(outs[0][k] - outs[2][k]).max() <= 1e-9, k
+    # the tier hand-off re-solves an agent from the start of its ladder level: same branch record, more iterations counted
+    assert np.array_equal(outs[0]["info"][..., :4], outs[2]["info"][..., :4])
     assert (outs[0]["status"] & 1).any()
 
 
