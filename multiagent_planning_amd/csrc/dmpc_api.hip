@@ -382,13 +382,14 @@ static int row_capacity(int variant, int N)
     return (int)((r + 1) & ~1L);
 }
 
-// Working-set capacity of the first solve launch.  The capacity is a template parameter of the solve kernels: 32 / 64
+// Working-set capacity of the first solve launch.  The capacity is a template parameter of the solve kernels: 32 / 48 / 64
 // (slack-carrying variants), 48 (slack-free: 45 variables => at most 45 independent active rows, one tier).
-// Two tiers (32 slots first -- 8 instead of 5 resident agents per CU -- and a second launch with 64 for the agents that outgrow
-// them) were the round-1 default for the slack variants.  Measured in round 2 (bench secondaries): the agents that overflow are
-// exactly the long ones (several retry-ladder levels, many active rows), and re-solving them in a second, serialized launch
-// costs more than the occupancy gives: 51 200 agents of solveSoftDMPCbound 1.38 -> 1.07 ms per step with ONE 64-slot tier;
-// whole transitions unchanged.  The two-tier path stays available (DMPC_TIER1_QCAP=32; tests keep it covered).
+// Slack variants, deep launches: 48 slots first -- 17 KB of LDS per wave, still 8 resident agents per CU -- and a second launch
+// with 64 for the agents that outgrow them (none at N = 100; 4 in 10^4 at N = 10^4).  Round 1 used 32 slots first: the agents
+// that outgrow 32 are exactly the long ones (several retry-ladder levels, many active rows) and re-solving them in a second,
+// serialized launch cost more than anything else in the step.  Measured (bench secondaries, 51 200 agents of
+// solveSoftDMPCbound): 32/64 tiers 1.38 ms per step, one 64-slot tier (5 agents per CU) 1.07 ms, 48/64 tiers 1.02 ms;
+// 512 whole transitions 110 / 107 / 100 ms.  DMPC_TIER1_QCAP = 32 | 64 selects the other forms (tests cover the 32/64 hand-off).
 static int tier1_qcap(const dmpc_ctx *ctx, int variant);
 // hard: 45 variables => at most 45 independent active rows; 48 leaves room for a numerically near-dependent addition
 static int full_qcap(int variant) { return variant_soft(variant) ? QMAX : 48; }
@@ -396,7 +397,7 @@ static int full_qcap(int variant) { return variant_soft(variant) ? QMAX : 48; }
 static int tier1_qcap(const dmpc_ctx *ctx, int variant)
 {
     if (!variant_soft(variant)) return 48;
-    return ctx->tier1_env == 32 ? 32 : QMAX;
+    return (ctx->tier1_env == 32 || ctx->tier1_env == 64) ? ctx->tier1_env : 48;
 }
 
 static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_first, int c_count, const double *lT,
@@ -449,6 +450,7 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     const size_t ldsmax = lds2 > lds1 ? lds2 : lds1;
     if ((int)ldsmax > ctx->max_lds_set) {
         HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_kernel<true, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsmax));
+        HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_kernel<true, 48>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsmax));
         HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_kernel<true, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsmax));
         HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_kernel<false, 48>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsmax));
         ctx->max_lds_set = (int)ldsmax;
@@ -529,11 +531,13 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     // the working-set capacity is a template parameter of the solve kernels
     auto launch_plain = [&](int qcap, size_t lds) {
         if (soft && qcap == 32) hipLaunchKernelGGL((dmpc_solve_kernel<true, 32>), grid, block, lds, st, P);
+        else if (soft && qcap == 48) hipLaunchKernelGGL((dmpc_solve_kernel<true, 48>), grid, block, lds, st, P);
         else if (soft) hipLaunchKernelGGL((dmpc_solve_kernel<true, 64>), grid, block, lds, st, P);
         else hipLaunchKernelGGL((dmpc_solve_kernel<false, 48>), grid, block, lds, st, P);
     };
     auto launch_persist = [&](int qcap, dim3 g, dim3 b, size_t lds) {
         if (soft && qcap == 32) hipLaunchKernelGGL((dmpc_solve_persist_kernel<true, 32>), g, b, lds, st, P);
+        else if (soft && qcap == 48) hipLaunchKernelGGL((dmpc_solve_persist_kernel<true, 48>), g, b, lds, st, P);
         else if (soft) hipLaunchKernelGGL((dmpc_solve_persist_kernel<true, 64>), g, b, lds, st, P);
         else hipLaunchKernelGGL((dmpc_solve_persist_kernel<false, 48>), g, b, lds, st, P);
     };
@@ -548,6 +552,7 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
         const size_t lds = PERSIST_TABLE_BYTES + (size_t)pw * per;
         if ((int)lds > ctx->max_lds_persist) {
             HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_persist_kernel<true, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_persist_kernel<true, 48>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_persist_kernel<true, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_persist_kernel<false, 48>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             ctx->max_lds_persist = (int)lds;
