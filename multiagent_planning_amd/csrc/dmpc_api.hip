@@ -438,10 +438,14 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     // measured: the crash start pays for the slack-carrying variants (C4, N = 10^4: solve launch -16 %) and costs on solveHardDMPC
     // (C2: -16 % throughput: with rows at every horizon step the bounds violated at the unconstrained minimiser are a poor guess)
     P.crash_min = (soft || getenv("DMPC_CRASH_MIN")) ? ctx->crash_min : 0;
-    // shallow launches (a scene or a few: bound by the latency of their slowest agent, LDS is no constraint) solve with the
-    // full working-set capacity in one launch; deep launches use the small first tier and re-solve the few that outgrow it
-    const bool shallow = (long)S * c_count < 16L * (ctx->num_cu > 0 ? ctx->num_cu : 256) * 8 && !ctx->force_persist && !ctx->tier1_env;
-    const int q1 = (ctx->single_tier || shallow) ? full_qcap(p.variant) : tier1_qcap(ctx, p.variant), q2 = full_qcap(p.variant);
+    // tiny launches (a scene or a few, every agent resident at once: bound by the latency of their slowest agent, LDS is no
+    // constraint) solve with the full working-set capacity in one launch; larger ones use the first tier and re-solve the few
+    // agents that outgrow it (the smaller footprint also puts 6 instead of 4 one-agent workgroups on a CU: 512 transitions
+    // in two halves of 25 600 agents 75 -> 63 ms); from `shallow` up the first tier runs as persistent waves
+    const long ncu = ctx->num_cu > 0 ? ctx->num_cu : 256;
+    const bool tiny = (long)S * c_count < 8L * ncu && !ctx->force_persist && !ctx->tier1_env;
+    const bool shallow = (long)S * c_count < 16L * ncu * 8 && !ctx->force_persist && !ctx->tier1_env;
+    const int q1 = (ctx->single_tier || tiny) ? full_qcap(p.variant) : tier1_qcap(ctx, p.variant), q2 = full_qcap(p.variant);
     const bool two_tier = q1 < q2;
     P.scene_done = scene_done;
     P.short_from = short_from;   // unequal clusters: chunks from here on hold C-1 agents (dmpc_multigpu.hip)
@@ -493,7 +497,7 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
             P.lrow = ctx->lrow.p;
         }
     }
-    if (!shallow) HIPCHK(ctx, hipMemsetAsync(ctx->counter.p, 0, 16, st));   // queue heads of the persistent solve launches
+    if (!tiny) HIPCHK(ctx, hipMemsetAsync(ctx->counter.p, 0, 16, st));   // queue heads of the persistent solve launches
     // phase 0: scan + rows
     P.qcap = q1; P.only_flagged = 0; P.qover_bit = two_tier ? ST_QOVER : ST_CAPACITY;
     {
@@ -572,7 +576,7 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     const bool deep = !shallow && (long)S * c_count >= 16L * ctx->num_cu * (pw1 > 0 ? pw1 : 1);
     // tier 2 as persistent waves over the flagged list (nearly always empty: the launch then costs a few microseconds
     // instead of one workgroup per agent just to find out that there is nothing to do)
-    const bool t2_list = two_tier && !shallow && !ctx->no_persist && pw2 >= 2 && ctx->num_cu >= 1;
+    const bool t2_list = two_tier && !tiny && !ctx->no_persist && pw2 >= 2 && ctx->num_cu >= 1;
     if (t2_list) { P.flag_count = ctx->counter.as<int>() + 2; P.flag_list = ctx->flag_list.as<int>(); }
     if (solve_launch(q1, lds1, 0, deep || ctx->force_persist)) return -1;
     if (two_tier) {   // tier 2: only agents flagged ST_QOVER do any work

@@ -334,22 +334,22 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
     constexpr int LADDER_CERT_AFTER = 16;
     constexpr int FARKAS_AFTER = 8;
     const int max_tries = P.max_tries > 0 ? P.max_tries : (cppv ? 21 : 30);
-    // hdr[6] = retry-ladder levels already known to be infeasible (certified by the scan, or proven by a tier-1 launch
-    // that then overflowed); hdr[4] bit 1 = the row data in global memory is already scaled
-    int tries = hdr[6], iters_total = (P.only_flagged ? hdr[7] : 0), maxq = 0, q = 0;
-#ifdef DMPC_DEV_TRACE
-    int dev_nfast = 0, dev_rounds = 0, dev_negdrops = 0;
-#endif
-    const bool rows_scaled = (hdr[4] & 2) != 0;
+    // hdr[6] = retry-ladder levels the scan certified infeasible (the ladder starts behind them, the skipped tries counted).
+    // A first-tier launch that runs out of working-set slots hands the agent over UNTOUCHED (its row scalings undone, nothing
+    // recorded): the second tier repeats the whole solve, on the path an uninterrupted solve takes -- the result of an agent
+    // must not depend on how deep the launch was that it ran in.
+    int tries = hdr[6], iters_total = 0, maxq = 0, q = 0;
+    int scale_pow = 0;   // the rows' slack bound and penalty currently carry the factor 2^scale_pow
     bool solved = false;
     double a = 0.0, w = 0.0;
     const double tol = 1e-10;
 
     if (status & ST_INFEAS) tries = 1;   // certified infeasible by the scan (single attempt: hard rows only)
-    if (soft && tries > 0 && !rows_scaled && !(status & ST_INFEAS)) {
+    if (soft && tries > 0 && !(status & ST_INFEAS)) {
         if (tries >= max_tries) { status |= ST_INFEAS; tries = max_tries; }
         else {
             const double f = ldexp(1.0, tries);
+            scale_pow = tries;
             for (int i = lane; i < nr; i += 64) { r_slb[i] *= f; r_st[i] *= f; }
             rcslb[0] *= f; rcslb[1] *= f;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -554,7 +554,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
 #define CAND(v_, w_, code_) do { const double v__ = (v_); const float s__ = (float)v__ * (w_); \
                                  if (v__ > tol && s__ > bests) { bests = s__; bestv = v__; bestc = (code_); } } while (0)
                 // the crash ends its batch when nothing is left to append, when a multiplier had to be dropped, or short of the capacity
-                const bool crash_finish = crash && (crash_stop || q >= QCAP - 4);
+                const bool crash_finish = crash && (crash_stop || q >= (QCAP - 4 < 44 ? QCAP - 4 : 44));   // (the same for the 48- and 64-slot kernels: the path of an agent must not depend on the tier)
                 if (comp && !crash_finish) {
                     // a <= alim and -a <= alim are violated one at a time: one candidate for the pair (not while a member is active)
                     const bool hi = a > 0.0;
@@ -842,13 +842,15 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
             dev_nfast += nfast; dev_rounds += crash_rounds;
 #endif
             if (rc == 0) { solved = true; break; }
-            if (rc == 2) {   // tier 1: flag for the tier-2 relaunch (and record the ladder position); last tier: capacity error
+            if (rc == 2) {   // first tier: flag for the second-tier launch, rows back to what the scan wrote (exact: powers of two); last tier: capacity error
                 status |= P.qover_bit;
-                if (lane == 0) {
-                    hdr[6] = tries - 1; hdr[7] = iters_total; hdr[4] |= 2;
-                    // tier 1: append to the list the tier-2 launch works through (order irrelevant: scheduling only)
-                    if (P.flag_list && P.qover_bit == ST_QOVER) P.flag_list[atomicAdd(P.flag_count, 1)] = gid;
+                if (soft && scale_pow && P.qover_bit == ST_QOVER) {
+                    const double f = ldexp(1.0, -scale_pow);
+                    for (int i = lane; i < nr; i += 64) { r_slb[i] *= f; r_st[i] *= f; }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 }
+                // tier 1 appends the agent to the list the tier-2 launch works through (order irrelevant: scheduling only)
+                if (lane == 0 && P.flag_list && P.qover_bit == ST_QOVER) P.flag_list[atomicAdd(P.flag_count, 1)] = gid;
                 break;
             }
             if (rc == 3) { status |= ST_ITERCAP; break; }
@@ -859,6 +861,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                        ladder_level_infeasible(r_xi, r_b, r_sd, r_slb, r_kc, nr, B + SL::RR, P.h, P.alim, f, whi_l, wlo_l, lane)) { f *= 2.0; ++tries; }
                 for (int i = lane; i < nr; i += 64) { r_slb[i] *= f; r_st[i] *= f; }
                 rcslb[0] *= f; rcslb[1] *= f;
+                scale_pow += ilogb(f);
                 // warm start of the next level: the slack lower bounds in the working set get their new right-hand side (d = -lb)
                 warm = P.ladder_warm && q > 0;
                 if (warm && lane < q && ((s_meta[lane] >> 8) & 0xff) == TY_SLKL) B[SL::SD + lane] *= f;
