@@ -301,9 +301,78 @@ def main():
             secondary.append({"workload": f"512 whole transitions, 100 agents, solveSoftDMPCbound, precision {prec}, histories left on the device",
                               "wall_ms": dtm * 1e3, "completed": int(((rm["scene_status"] & 256) != 0).sum()),
                               "value": float(((rm["K_T_used"] - 1) * 100).sum() / dtm), "unit": "solves/s"})
+        # BASELINE configs[3] (C4): ONE scene of 10^4 agents, solveSoftDMPCbound -- the first MPC steps of the closed loop on the device
+        # (large scenes: neighbour pre-pass + list walk in the scan, crash start of the acceleration bounds in the solve)
+        cfg4 = dict(wl.CONFIGS["C4"]); N4 = 10000
+        kw4 = wl.solver_kwargs(cfg4, N4)
+        po4, pf4 = wl.make_scenes(cfg4, 1, N4, wl.SEED0 + 4)
+        d4 = mp.Dmpc("bound", device=local_rank, **kw4)
+        # (a whole transition stops at the first infeasible agent -- MPC step 4 of this scene; the steps are therefore driven from
+        # the host here, failed agents keeping their previous prediction, and timed with the library's HIP events)
+        l4, _, _ = d4.init_batch(po4, pf4)
+        x4p, x4v, x4a = po4.copy(), np.zeros_like(po4), np.zeros_like(po4)
+        sc4, so4, ok4 = [], [], []
+        for k4 in range(9):
+            d4.profile(True)
+            o4 = d4.step_batch(l4, x4p, x4v, x4a, pf4)
+            sms, cms, _ = d4.profile_read2()
+            sc4.append(cms); so4.append(sms)
+            okm = (o4["status"] == 1); ok4.append(float(okm.mean()))
+            l4 = np.where(okm[..., None], o4["p"], l4); x4p = np.where(okm[..., None], o4["p"][..., :3], x4p)
+            x4v = np.where(okm[..., None], o4["v"][..., :3], x4v); x4a = np.where(okm[..., None], o4["a"][..., :3], x4a)
+        secondary.append({"workload": f"C4: ONE scene of {N4} agents, solveSoftDMPCbound, MPC steps 2-10 (device time per step: scan incl. neighbour "
+                                      "pre-pass, solve incl. order and second tier; HIP events)",
+                          "scan_ms": [round(x, 3) for x in sc4], "solve_ms": [round(x, 3) for x in so4], "solved_frac": ok4,
+                          "ms_per_mpc_step": float(np.mean(sc4[1:]) + np.mean(so4[1:])), "first_step_ms": sc4[0] + so4[0],
+                          "value": N4 / ((np.mean(sc4[1:]) + np.mean(so4[1:])) * 1e-3), "unit": "solves/s"})
+        del d4
         # restore the headline workload's last outputs for the statistics below
         one_step()
         torch.cuda.synchronize()
+    # Strong scaling (multi-rank runs only): ONE C4 scene of 10^4 agents sharded over the G ranks (dmpc.cpp:1600-1625 clusters),
+    # whole closed loop inside the library (dmpc_transition_sharded: scan + solve of the own cluster + RCCL all-gather per step).
+    # Bounded by a timeout: a collective that never returns must not cost the headline line.
+    strong = None
+    if use_dist and in_lib and not args.no_secondary:
+        import threading
+        box = {}
+
+        def c4_strong():
+            try:
+                cfg4 = dict(wl.CONFIGS["C4"]); N4 = 10000
+                kw4 = wl.solver_kwargs(cfg4, N4)
+                po4, pf4 = wl.make_scenes(cfg4, 1, N4, wl.SEED0 + 4)   # deterministic: the same on every rank
+                torch.cuda.set_device(local_rank)
+                d4 = mp.Dmpc("bound", device=local_rank, **kw4)
+                idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+                if rank == 0:
+                    idt.copy_(torch.frombuffer(bytearray(mp.Dmpc.comm_unique_id()), dtype=torch.uint8))
+                dist.broadcast(idt, src=0)
+                d4.comm_init(bytes(idt.cpu().numpy().tobytes()), G, rank)
+                d4.transition_sharded(po4, pf4, 3, cfg4["error_tol"], histories=False)
+                dist.barrier(); torch.cuda.synchronize()
+                tt = time.perf_counter()
+                r4 = d4.transition_sharded(po4, pf4, 12, cfg4["error_tol"], histories=False)
+                torch.cuda.synchronize(); dist.barrier()
+                dt4 = time.perf_counter() - tt
+                tmax = torch.tensor([dt4], dtype=torch.float64, device=dev)
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                st4 = max(int(r4["K_T_used"][0]) - 1, 1)
+                box["r"] = {"workload": f"C4 strong scaling: ONE scene of {N4} agents sharded over {G} rank(s), solveSoftDMPCbound, first {st4} MPC "
+                                        "steps inside the library (dmpc_transition_sharded: RCCL all-gather of the table per step)",
+                            "n_gpus": G, "ms_per_mpc_step": float(tmax.item()) * 1e3 / st4, "mpc_steps": st4,
+                            "value": N4 * st4 / float(tmax.item()), "unit": "solves/s", "scaling": "strong"}
+                d4.comm_destroy()
+            except Exception as e:   # noqa: BLE001
+                box["r"] = {"workload": "C4 strong scaling", "error": str(e)[:200]}
+
+        th = threading.Thread(target=c4_strong, daemon=True)
+        th.start(); th.join(timeout=180.0)
+        strong = box.get("r", {"workload": "C4 strong scaling", "error": "timed out after 180 s"})
+        strong_hung = th.is_alive()
+    else:
+        strong_hung = False
+
     st = status.cpu().numpy()
     inf = info.cpu().numpy()
 
@@ -356,6 +425,8 @@ def main():
         }
         if not args.no_secondary and G == 1:
             line["secondary"] = secondary
+        if strong is not None:
+            line["strong_scaling"] = strong
         if not args.no_cpu_baseline and G == 1:
             # CPU baseline: the oracle (the literal dense QP of the .m files + dense Goldfarb-Idnani, oracle/dmpc_oracle.c) on
             # the same captured step, timed on this box's host cores.  The scenes of the batch are independent problems, so
@@ -395,7 +466,7 @@ def main():
                                               f"oracle/dmpc_oracle.c (literal dense QP + dense Goldfarb-Idnani), scene-parallel threads",
                                     "single_thread": sweep[0]["value"], "thread_sweep": sweep, "host_cpus": ncpu, "physical_cores": phys,
                                     "reference_style_8_clusters_in_one_scene": ref_style}
-    if use_dist:
+    if use_dist and not strong_hung:
         dist.destroy_process_group()
     if rank == 0:
         # the JSON line is the LAST thing on stdout: flush whatever the native libraries (RCCL's version banner) still
@@ -407,6 +478,8 @@ def main():
             pass
         sys.stdout.flush()
         print(json.dumps(line), flush=True)
+    if strong_hung:   # a collective of the strong-scaling extra never returned: leave without waiting for its thread
+        os._exit(0)
 
 
 if __name__ == "__main__":
