@@ -333,7 +333,13 @@ def main():
     # whole closed loop inside the library (dmpc_transition_sharded: scan + solve of the own cluster + RCCL all-gather per step).
     # Bounded by a timeout: a collective that never returns must not cost the headline line.
     strong = None
+    # only when the headline's exchange was verified on this rank AND on every other one (all ranks take the same branch)
+    run_strong = False
     if use_dist and in_lib and not args.no_secondary:
+        okx = torch.tensor([1 if exchange_ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(okx, op=dist.ReduceOp.MIN)
+        run_strong = int(okx.item()) == 1
+    if run_strong:
         import threading
         box = {}
 
