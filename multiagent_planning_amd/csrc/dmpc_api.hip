@@ -66,7 +66,6 @@ struct dmpc_ctx {
     int no_cull = getenv("DMPC_NO_CULL") ? 1 : 0;
     int no_lpt = getenv("DMPC_NO_LPT") ? 1 : 0;   // tuning: disable the heaviest-first solve order
     int crash_min = getenv("DMPC_CRASH_MIN") ? atoi(getenv("DMPC_CRASH_MIN")) : CRASH_MIN_DEFAULT;   // see StepParams::crash_min
-    int no_vrows = getenv("DMPC_NO_VROWS") ? 1 : 0;   // tuning: solveHardDMPC rows always materialized in the scratch
     int ladder_warm = getenv("DMPC_LADDER_COLD") ? 0 : 1;   // tuning: restart every retry-ladder level from scratch
     int iter_cap = getenv("DMPC_ITER_CAP") ? atoi(getenv("DMPC_ITER_CAP")) : ITER_CAP;   // development: cap the active-set iterations (agents beyond it end DMPC_ST_ITERCAP)
     int tier1_env = getenv("DMPC_TIER1_QCAP") ? atoi(getenv("DMPC_TIER1_QCAP")) : 0;   // tuning / tests: 32 = two tiers for the slack variants (any value: no shallow-launch shortcut)
@@ -436,7 +435,6 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     P.dbg = ctx->dbg; P.dbg_agent = ctx->dbg_agent; P.dbg_cap = ctx->dbg_cap;
     P.iter_cap = ctx->iter_cap;
     P.ladder_warm = ctx->ladder_warm;
-    P.virtual_rows = (p.variant == DMPC_VAR_HARD && !lTf && !ctx->no_vrows) ? 1 : 0;
     // measured: the crash start pays for the slack-carrying variants (C4, N = 10^4: solve launch -16 %) and costs on solveHardDMPC
     // (C2: -16 % throughput: with rows at every horizon step the bounds violated at the unconstrained minimiser are a poor guess)
     P.crash_min = (soft || getenv("DMPC_CRASH_MIN")) ? ctx->crash_min : 0;

@@ -18,7 +18,6 @@ __host__ __device__ constexpr int tcol(int j) { return 8 * (j >> 3) * (4 * (j >>
 __host__ __device__ constexpr int t_doubles(int qcap) { return tcol((qcap + 7) & ~7); }
 constexpr int ITER_CAP = 4000;
 constexpr int CRASH_MIN_DEFAULT = 4;
-constexpr int VROW_CAP = 128;   // = the register row cache of the slack-free solve kernels (2 rows per lane)
 constexpr int NBR_BLOCK = 8;    // nbr_kernel: agents per wave
 constexpr int NBR_PARTS = 4;    // nbr_kernel: the tiles of a scene are split over this many waves per agent block (N / NBR_BLOCK waves alone do not fill the chip)
 
@@ -44,7 +43,6 @@ struct StepParams {
     int *rowkc;             // [S*c_count][nrmax] constrained horizon step of each row
     int *hdr;               // [S*c_count][8] scan -> solve hand-off (row count, branch record)
     int only_flagged, qover_bit;
-    int virtual_rows;       // solveHardDMPC: rows below VROW_CAP travel from the scan to the solve as (step, neighbour) codes
     int no_prune;           // 1: keep every row the reference builds (dmpc_rows_one); 0: exact pruning
     const int *order;       // solve-phase launch order (agent ids, heaviest first) or null
     int nbr_cap;            // capacity of an agent's neighbour list (ints)

@@ -318,8 +318,6 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
     const bool coll_check = (var == VAR_BOUND || var == VAR_BOUND2 || var == VAR_ALL3 || var == VAR_REPAIR);
     const bool skip_k1 = (var == VAR_BOUND2 || var == VAR_ALL3 || var == VAR_REPAIR || var == VAR_CPP2);
     bool coll_flag = false;
-    // solveHardDMPC, fp64: the rows the solve kernel caches in registers are handed over as (step, neighbour) codes
-    const bool vrows = P.virtual_rows && !soft && var == VAR_HARD && std::is_same<TT, double>::value;
     // Neighbour list (large scenes, nbr_kernel): a neighbour can come within ellipsoidal distance R of the agent at some
     // horizon step only if the bounding boxes of the two predicted horizons are within R per axis.  The survivors of
     // that test (3 % of the scene at N = 10^4) come, in increasing index order, from the pre-pass; the distance tests /
@@ -380,7 +378,7 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
         // neighbour with dist < sel_r (or all), in increasing neighbour index (CollConstrSoftDMPC.m:11-31)
         // one collision row, CollConstrSoftDMPC.m:16-28: neighbour offset (dx,dy,dz) and ellipsoidal distance at
         // the evaluation step (own position px,py,pz), constraining horizon step kc; compacted by ballot
-        auto emit_row = [&](bool sel, int kc, real dx, real dy, real dz, real dist, real px, real py, real pz, int ncode) {
+        auto emit_row = [&](bool sel, int kc, real dx, real dy, real dz, real dist, real px, real py, real pz) {
             const real sh = (real)(kc + 1) * h_;
             const real a0x = po_[0] + sh * vo_[0], a0y = po_[1] + sh * vo_[1], a0z = po_[2] + sh * vo_[2];
             const real x0 = dx, x1 = dy, x2 = dz * e2z;   // diff = E2*(p - pj)
@@ -428,16 +426,10 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
             const int pos = nr + lanes_below(m, lane);
             if (sel && pos < nrmax) {
                 // r = dist*(rmin - dist + diff*p/dist) - diff*A_initp(kc)*[po;vo]   (:21)
-                if (vrows && pos < VROW_CAP) {
-                    // virtual row: (step, neighbour) only -- the solve kernel rebuilds xi and the right-hand side from the table when
-                    // it loads its register cache (the only place rows below VROW_CAP are ever read): 4 instead of 36 bytes
-                    L.r_kc[pos] = (int)((unsigned)kc | ((unsigned)ncode << 4));
-                } else {
                 const real rr = dist * (rmin - dist + (x0 * px + x1 * py + x2 * pz) / dist) - (x0 * a0x + x1 * a0y + x2 * a0z);
                 L.r_xi[3 * pos] = x0; L.r_xi[3 * pos + 1] = x1; L.r_xi[3 * pos + 2] = x2;
                 L.r_b[pos] = -rr;
                 L.r_kc[pos] = kc;
-                }
                     if (soft) {
                     real sd = dist, st = P.term, slb = -0.05;
                     if (var == VAR_BOUND2 || var == VAR_ALL3) slb = -0.01;           // bound2:77, all:92
@@ -470,7 +462,7 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
                     const real sz = (qz - bsel[2 * (size_t)C]) * e1z;
                     dsel = sqrt(sx * sx + sy * sy + sz * sz);
                 }
-                emit_row(valid && (sel_all || dsel < sel_r), kc, dx, dy, dz, dist, px, py, pz, 0);
+                emit_row(valid && (sel_all || dsel < sel_r), kc, dx, dy, dz, dist, px, py, pz);
             }
         };
 
@@ -490,7 +482,7 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
                 const real dx = px - nb[0], dy = py - nb[(size_t)C], dz = pz - nb[2 * (size_t)C];
                 const real ez = dz * e1z;
                 const real dist = sqrt(dx * dx + dy * dy + ez * ez);
-                emit_row(have && dist < 1.0, kk, dx, dy, dz, dist, px, py, pz, code & 0x0fffffff);
+                emit_row(have && dist < 1.0, kk, dx, dy, dz, dist, px, py, pz);
             }
             ncand = 0;
             LSYNC();
@@ -686,7 +678,7 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
         if (__any(cert_infeasible)) status |= ST_INFEAS;
         if (lane == 0) {
             hdr[0] = nr; hdr[1] = nrows_ref; hdr[2] = viol_k; hdr[3] = status;
-            hdr[4] = (violation ? 1 : 0) | (coll_flag ? 4 : 0) | (vrows ? 16 : 0); hdr[5] = rows_exist ? 1 : 0; hdr[6] = 0;
+            hdr[4] = (violation ? 1 : 0) | (coll_flag ? 4 : 0); hdr[5] = rows_exist ? 1 : 0; hdr[6] = 0;
         }
         {
             const int ls = (int)wave_max((double)ladder_start);

@@ -319,34 +319,12 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
     auto row_weight = [&](double x0, double x1, double x2, int kc, double sd) -> float {
         return (float)rsqrt(G[(15 + kc) * 31] * (x0 * x0 + x1 * x1 + x2 * x2) + (soft ? 0.5 * sd * sd : 0.0));
     };
-    static_assert(soft || 64 * RC == VROW_CAP, "virtual rows = the register row cache");
-    const bool vrows = !soft && (hdr[4] & 16) != 0;
 #pragma unroll
     for (int c = 0; c < RC; ++c) {
         const int i = lane + 64 * c;
         const int ii = i < nr ? i : 0;
-        if (vrows && i >= nr) {   // no row: nothing to decode (the slot of the scratch holds whatever an earlier step left)
-            rcx0[c] = rcx1[c] = rcx2[c] = rcb[c] = 0.0; rckc[c] = 0;
-        } else if (vrows) {
-            // virtual row (step, neighbour): xi and the right-hand side rebuilt from the prediction table with the scan's
-            // arithmetic (CollConstrHardDMPC.m:16-28 as in emit_row of dmpc_kernels.hip)
-            const unsigned code = (unsigned)r_kc[ii];
-            const int kc = (int)(code & 15u), rch = (int)(code >> 24), jc = (int)((code >> 4) & 0xfffffu);
-            const double *nb = P.lT + ((size_t)(rch * P.S + scene) * N3 + 3 * kc) * P.C + jc;
-            const double *ow = P.lT + ((size_t)(P.g_local * P.S + scene) * N3 + 3 * kc) * P.C + cl;
-            const double px = ow[0], py = ow[(size_t)P.C], pz = ow[2 * (size_t)P.C];
-            const double dx = px - nb[0], dy = py - nb[(size_t)P.C], dz = pz - nb[2 * (size_t)P.C];
-            const double ez = dz * P.e1z;
-            const double dist = sqrt(dx * dx + dy * dy + ez * ez);
-            const double sh = (double)(kc + 1) * P.h;
-            const double a0x = po[0] + sh * vo[0], a0y = po[1] + sh * vo[1], a0z = po[2] + sh * vo[2];
-            const double x0 = dx, x1 = dy, x2 = dz * P.e2z;
-            const double rr = dist * (P.rmin - dist + (x0 * px + x1 * py + x2 * pz) / dist) - (x0 * a0x + x1 * a0y + x2 * a0z);
-            rcx0[c] = x0; rcx1[c] = x1; rcx2[c] = x2; rcb[c] = -rr; rckc[c] = kc;
-        } else {
         rcx0[c] = r_xi[3 * ii]; rcx1[c] = r_xi[3 * ii + 1]; rcx2[c] = r_xi[3 * ii + 2];
         rcb[c] = r_b[ii]; rckc[c] = r_kc[ii];
-        }
         rcsd[c] = soft ? r_sd[ii] : 0.0; rcslb[c] = soft ? r_slb[ii] : 0.0;
         rcw[c] = row_weight(rcx0[c], rcx1[c], rcx2[c], rckc[c], rcsd[c]);
     }
