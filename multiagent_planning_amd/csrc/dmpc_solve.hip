@@ -340,6 +340,9 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
     // must not depend on how deep the launch was that it ran in.
     int tries = hdr[6], iters_total = 0, maxq = 0, q = 0;
     int scale_pow = 0;   // the rows' slack bound and penalty currently carry the factor 2^scale_pow
+#ifdef DMPC_DEV_TRACE
+    int dev_nfast = 0, dev_rounds = 0, dev_negdrops = 0;
+#endif
     bool solved = false;
     double a = 0.0, w = 0.0;
     const double tol = 1e-10;
