@@ -601,6 +601,15 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                 const unsigned long long wm = __ballot(bestc >= 0 && bests == smax);
                 if (wm == 0ull) {
                     if (!crash && (q == 0 || fresh)) break;   // optimal
+                    if (!crash) {
+                        // No constraint is violated at the (incrementally updated) iterate.  Round-off of the factor reaches the iterate
+                        // only through N_W: an error dr of r = T T's moves x by t H^-1 N_W dr, which shows in the values of the
+                        // active constraints (N_W' H^-1 N_W is non-singular).  If those are zero to round-off the iterate IS the
+                        // minimiser over its working set and nothing has to be re-derived (one reduction instead of the primal from the
+                        // multipliers, the refinement and a second violation scan)
+                        const double rho0 = (lane < q) ? slot_value(lane) : 0.0;
+                        if (!(wave_max0(fabs(rho0)) > 1e-13)) break;
+                    }
                     const bool was_fresh = fresh;
                     // verification: primal from the multipliers, refine the active-set residual, re-check
                     // (crash: the appended slots carry lambda = 0 and their violation at the stale iterate -- the same pass solves them)
