@@ -36,7 +36,7 @@ def test_sharded_transition_one_rank_equals_dmpc_transition(with_comm):
         d.comm_destroy()
 
 
-@pytest.mark.parametrize("variant,N,G", [("bound", 10, 3), ("hard", 100, 8), ("softall", 37, 2), ("hard", 301, 4)])
+@pytest.mark.parametrize("variant,N,G", [("bound", 10, 3), ("hard", 100, 8), ("softall", 37, 2), ("hard", 301, 4), ("bound", 700, 3), ("ondemand", 515, 8)])
 def test_sharded_step_ranks_in_turn_equal_the_unsharded_step(variant, N, G):
     """every rank of a G-rank job solves its cluster (dmpc.cpp:1600-1625: the first N mod G clusters one agent more) against the
     padded rank-major table; the union of the ranks' outputs and the exchanged next table equal the one-rank step bit for bit"""
