@@ -57,6 +57,8 @@ struct dmpc_ctx {
     int64_t solves = 0;
     int max_lds_set = 0;
     // scratch for the host-pointer entry points
+    DevBuf post_acc; int post_acc_S = 0, post_fused = 0;
+    int no_fuse = getenv("DMPC_NO_FUSE") ? 1 : 0;   // tuning: always launch post_step_kernel
     DevBuf rowbuf, rowkc, hdr, order, bbox, nbr_list, nbr_cnt, lrow, counter, flag_list, scene_done;
     int num_cu = 0;
     int no_persist = getenv("DMPC_NO_PERSIST") ? 1 : 0;   // tuning: one-agent-per-workgroup solve launches
@@ -394,6 +396,15 @@ static int tier1_qcap(const dmpc_ctx *ctx, int variant);
 // hard: 45 variables => at most 45 independent active rows; 48 leaves room for a numerically near-dependent addition
 static int full_qcap(int variant) { return variant_soft(variant) ? QMAX : 48; }
 
+// what follows a solve in a closed loop (post_step_kernel); launch_step folds it into the solve kernel when the launch is tiny and
+// single-tier, and reports that in ctx->post_fused
+struct PostStep {
+    int KT, k;
+    double tol;
+    double *xp, *xv, *xa, *pk, *vk, *ak;
+    int *flags, *done;
+};
+
 static int tier1_qcap(const dmpc_ctx *ctx, int variant)
 {
     if (!variant_soft(variant)) return 48;
@@ -403,7 +414,7 @@ static int tier1_qcap(const dmpc_ctx *ctx, int variant)
 static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_first, int c_count, const double *lT,
                        const double *x_p, const double *x_v, const double *x_a, const double *pf, double *p_out,
                        double *v_out, double *a_out, double *lT_next, int32_t *status, int32_t *info, hipStream_t st,
-                       const int *scene_done = nullptr, int short_from = 0, const float *lTf = nullptr)
+                       const int *scene_done = nullptr, int short_from = 0, const float *lTf = nullptr, const PostStep *post = nullptr)
 {
     const dmpc_params &p = ctx->prm;
     const bool soft = variant_soft(p.variant);
@@ -447,6 +458,20 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     const bool shallow = (long)S * c_count < 16L * ncu * 8 && !ctx->force_persist && !ctx->tier1_env;
     const int q1 = (ctx->single_tier || tiny) ? full_qcap(p.variant) : tier1_qcap(ctx, p.variant), q2 = full_qcap(p.variant);
     const bool two_tier = q1 < q2;
+    ctx->post_fused = 0;
+    if (post && tiny && !two_tier && g_local == 0 && G == 1 && !ctx->no_fuse) {
+        if (ctx->post_acc.ensure((size_t)S * 16 + 64)) FAIL(ctx, "device allocation failed (post-step accumulators)");
+        if (ctx->post_acc_S != S) {   // zero once per batch shape; the last wave of a scene leaves them zeroed again
+            HIPCHK(ctx, hipMemsetAsync(ctx->post_acc.p, 0, (size_t)S * 16 + 64, st));
+            ctx->post_acc_S = S;
+        }
+        P.post_on = 1; P.post_KT = post->KT; P.post_k = post->k; P.post_tol = post->tol;
+        P.post_xp = post->xp; P.post_xv = post->xv; P.post_xa = post->xa; P.post_pk = post->pk; P.post_vk = post->vk; P.post_ak = post->ak;
+        P.post_flags = post->flags; P.post_done = post->done;
+        P.post_max = ctx->post_acc.as<unsigned long long>();
+        P.post_or = (int *)(ctx->post_acc.as<unsigned long long>() + S); P.post_cnt = P.post_or + S;
+        ctx->post_fused = 1;
+    }
     P.scene_done = scene_done;
     P.short_from = short_from;   // unequal clusters: chunks from here on hold C-1 agents (dmpc_multigpu.hip)
     const size_t lds0 = scan_lds_bytes();
@@ -920,6 +945,7 @@ static int transition_one(dmpc_ctx *ctx, int S, int N, const double *po, const d
     hipLaunchKernelGGL(scene_reduce_kernel, dim3((unsigned)S), dim3(256), 0, st, N, error_tol, xp, ctx->pf.as<double>(),
                        (const int *)ctx->status.as<int32_t>(), ctx->flags.as<int>(), ctx->scene_done.as<int>());
     double *cur = ctx->lT.as<double>(), *nxt = ctx->lT2.as<double>();
+    ctx->post_acc_S = 0;   // the scene accumulators of the fused post-step start from zero in every transition
     const bool mixed = ctx->precision == DMPC_PREC_MIXED;   // the scan of every step reads an fp32 copy of the current table
     std::vector<int32_t> flags((size_t)K_T_max * S * 2, 0);
     std::vector<int> done(S, 0);
@@ -928,15 +954,19 @@ static int transition_one(dmpc_ctx *ctx, int S, int N, const double *po, const d
     const int chunk = 8;   // host looks at the per-step flags every `chunk` MPC steps
     for (int k = 1; k < K_T_max && ndone < S; ++k) {
         if (mixed && table_f32(ctx, cur, ctx->lTf, A * N3, st)) return -1;
+        const PostStep post{K_T_max, k, error_tol, xp, xv, xa, ctx->hist_p.as<double>(), ctx->hist_v.as<double>(), ctx->hist_a.as<double>(),
+                            ctx->flags.as<int>() + (size_t)k * S * 2, ctx->scene_done.as<int>()};
         if (launch_step(ctx, S, 1, N, 0, 0, N, cur, xp, xv, xa, ctx->pf.as<double>(), ctx->pout.as<double>(),
                         ctx->vout.as<double>(), ctx->aout.as<double>(), nxt, ctx->status.as<int32_t>(), nullptr, st,
-                        ctx->scene_done.as<int>(), 0, mixed ? ctx->lTf.as<float>() : nullptr))
+                        ctx->scene_done.as<int>(), 0, mixed ? ctx->lTf.as<float>() : nullptr, &post))
             return -1;
-        // state advance + history column + scene verdict in one launch
+        // state advance + history column + scene verdict in one launch (unless the solve kernel did them: tiny launches)
+        if (!ctx->post_fused)
         hipLaunchKernelGGL(post_step_kernel, dim3((unsigned)S), dim3(N >= 256 ? 256 : 128), 0, st, N, K_T_max, k, error_tol,
                            (const double *)ctx->pout.as<double>(), (const double *)ctx->vout.as<double>(), (const double *)ctx->aout.as<double>(),
                            (const int *)ctx->status.as<int32_t>(), xp, xv, xa, (const double *)ctx->pf.as<double>(), ctx->hist_p.as<double>(),
-                           ctx->hist_v.as<double>(), ctx->hist_a.as<double>(), ctx->flags.as<int>() + (size_t)k * S * 2, ctx->scene_done.as<int>());
+                           ctx->hist_v.as<double>(), ctx->hist_a.as<double>(), ctx->flags.as<int>() + (size_t)k * S * 2, ctx->scene_done.as<int>(),
+                           (const int *)ctx->scene_done.as<int>());
         HIPCHK(ctx, hipGetLastError());
         std::swap(cur, nxt);   // l = new_l (dmpc_soft_bound.m:146)
         if (k % chunk == 0 || k == K_T_max - 1) {

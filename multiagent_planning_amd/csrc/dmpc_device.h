@@ -49,6 +49,14 @@ struct StepParams {
     int *nbr_list;          // [S*c_count][nbr_cap] neighbours that can come close, in increasing index order (nbr_kernel), or null
     const void *lrow;       // neighbour-major copy of the table the scan reads (table_nbrmajor_kernel), with the lists; or null
     const int *nbr_cnt;     // [S*c_count][NBR_PARTS] entries of each piece of a list; -1: did not fit (the scan walks the whole table)
+    // closed loops, tiny launches: the step after the solve (state advance, history column, scene verdict: post_step_kernel) done by
+    // the solve kernel itself -- each wave for its agent, the last wave of a scene (a counter) for the verdict; post_on = 0: off
+    int post_on, post_KT, post_k;
+    double post_tol;
+    double *post_xp, *post_xv, *post_xa, *post_pk, *post_vk, *post_ak;
+    int *post_flags, *post_done;
+    unsigned long long *post_max;   // [S] bit pattern of the largest goal distance so far (non-negative doubles order like integers)
+    int *post_or, *post_cnt;        // [S] OR of the status words, number of agents accounted for
     const int *scene_done;  // [S] or null: scenes of a transition that already stopped (reached their goals / failed): skipped
     int *counter;           // persistent solve kernel: queue head (zeroed before the launch)
     int lds_per_wave;       // persistent solve kernel: bytes of LDS per wave (after the shared tables)

@@ -1017,11 +1017,15 @@ __global__ void record_kernel(int S, int N, int KT, int k, const double *__restr
 // (dmpc_soft_bound.m:132-134), the history column k (pk/vk/ak(:,k,n)), then the scene verdict as scene_reduce_kernel.
 __global__ void post_step_kernel(int N, int KT, int k, double tol, const double *__restrict__ p, const double *__restrict__ v,
                                  const double *__restrict__ a, const int *__restrict__ status, double *x_p, double *x_v, double *x_a,
-                                 const double *__restrict__ pf, double *pk, double *vk, double *ak, int *flags, int *scene_done)
+                                 const double *__restrict__ pf, double *pk, double *vk, double *ak, int *flags, int *scene_done,
+                                 const int *__restrict__ stopped)
 {
     __shared__ double smax[256];
     __shared__ int sor[256];
     const int s = blockIdx.x;
+    // a scene whose trial ended at an earlier step is left alone: its history columns stay zero, as the preallocated pk/vk/ak of
+    // the reference do after its `break` (failure_rate.m:112-125)
+    if (stopped && stopped[s]) return;
     double m = 0.0; int o = 0;
     for (int i = threadIdx.x; i < N; i += blockDim.x) {
         const size_t ag = (size_t)s * N + i, b = ag * 3;

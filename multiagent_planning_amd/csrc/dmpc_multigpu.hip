@@ -256,7 +256,7 @@ extern "C" int dmpc_transition_sharded(dmpc_ctx *ctx, int S, int N, const double
         hipLaunchKernelGGL(post_step_kernel, dim3((unsigned)S), dim3(cnt >= 256 ? 256 : 128), 0, st, (int)cnt, K_T_max, k, error_tol,
                            (const double *)ctx->pout.as<double>(), (const double *)ctx->vout.as<double>(), (const double *)ctx->aout.as<double>(),
                            (const int *)ctx->status.as<int32_t>(), xp, xv, xa, (const double *)own_pf, ctx->hist_p.as<double>(), ctx->hist_v.as<double>(),
-                           ctx->hist_a.as<double>(), ctx->mg_floc.as<int>(), (int *)nullptr);
+                           ctx->hist_a.as<double>(), ctx->mg_floc.as<int>(), (int *)nullptr, (const int *)ctx->scene_done.as<int>());
         HIPCHK(ctx, hipGetLastError());
         if (exchange(ctx, ctx->sendbuf.as<double>(), nxt, chunk, ctx->mg_floc.as<int>(), ctx->mg_fall.as<int>(), S * 2, st)) return -1;
         hipLaunchKernelGGL(mg::combine_flags_kernel, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, st, G, S, (const int *)ctx->mg_fall.as<int>(),

@@ -936,6 +936,35 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
             Q.lT_next[(size_t)scene * N3 * Cq + cl + (size_t)(unsigned)(lane * Cq)] = solved ? p_out : own[(size_t)(unsigned)(lane * Cq)];
         }
     }
+    if (Q.post_on) {
+        // the work of post_step_kernel for this agent (dmpc_soft_bound.m:132-134, the history column, ReachedGoal.m:3-11); the scene's
+        // maximum / OR / count are order-independent, so which wave finishes last changes nothing
+        double xn = 0.0, vn = 0.0, an = 0.0, e2 = 0.0;
+        if (lane < 3) {
+            const size_t b = (size_t)gid * 3 + lane;
+            xn = solved ? p_out : Q.post_xp[b]; vn = solved ? v_out : Q.post_xv[b]; an = solved ? a_out : Q.post_xa[b];
+            if (solved) { Q.post_xp[b] = xn; Q.post_xv[b] = vn; Q.post_xa[b] = an; }
+            const size_t ho = ((size_t)gid * Q.post_KT + Q.post_k) * 3 + lane;
+            Q.post_pk[ho] = xn; Q.post_vk[ho] = vn; Q.post_ak[ho] = an;
+            const double dd = xn - Q.pf[b];
+            e2 = dd * dd;
+        }
+        const double dx2 = readlane_d(e2, 0), dy2 = readlane_d(e2, 1), dz2 = readlane_d(e2, 2);
+        if (lane == 0) {
+            const double dist = sqrt(dx2 + dy2 + dz2);
+            atomicMax(Q.post_max + scene, (unsigned long long)__double_as_longlong(dist));
+            atomicOr(Q.post_or + scene, status);
+            __threadfence();
+            if (atomicAdd(Q.post_cnt + scene, 1) == Q.c_count - 1) {   // the scene's last agent of this step
+                const unsigned long long mb = atomicExch(Q.post_max + scene, 0ull);
+                const int orv = atomicExch(Q.post_or + scene, 0);
+                Q.post_cnt[scene] = 0;
+                const int reached = __longlong_as_double((long long)mb) < Q.post_tol ? 1 : 0;
+                Q.post_flags[(size_t)scene * 2] = reached; Q.post_flags[(size_t)scene * 2 + 1] = orv;
+                if (Q.post_done && (reached || (orv & ~ST_SOLVED))) Q.post_done[scene] = 1;
+            }
+        }
+    }
     if (lane == 0) {
         Q.status[gid] = status;
         if (Q.info) {
