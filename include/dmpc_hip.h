@@ -193,7 +193,7 @@ int dmpc_advance_device(dmpc_ctx *ctx, int count, const double *p_out, const dou
  * A QP that is infeasible without any collision row is reported DMPC_ST_INFEAS at once: the reference retries it up to 30
  * times with quadprog's ConstraintTolerance doubled each time (solveSoftDMPCbound.m:140-146) and may end up accepting a
  * bound-violating point, typically reported `outbound` instead.
- * po,pf: [S][N][3]; pk,vk,ak: [S][N][K_T_max][3] (written up to K_T_used[s]) or all three NULL: the histories
+ * po,pf: [S][N][3]; pk,vk,ak: [S][N][K_T_max][3] (written up to K_T_used[s]; the columns a scene never reached stay zero, like the preallocated arrays of the reference) or all three NULL: the histories
  * then only stay on the device (for dmpc_postcheck) and the 3 x S*N*K_T_max*24-byte download is skipped;
  * K_T_used[S]: number of MPC steps taken per scene; scene_status[S]: OR of agent status bits at
  * the step where the scene stopped; DMPC_ST_SOLVED | DMPC_ST_REACHED = every agent within error_tol of its goal
