@@ -126,6 +126,9 @@ __device__ __forceinline__ double sel3(const double *v, int ax) { return ax == 0
 #ifndef SCAN_WAVES_PER_WG
 #define SCAN_WAVES_PER_WG 4
 #endif
+#ifndef QUEUE_CHUNK
+#define QUEUE_CHUNK 2   // measured on the headline workload (M solves/s): 1: 45.8, 2: 47.7, 3: 46.6, 4: 46.5
+#endif
 #ifndef SOLVE_WAVES_PER_SIMD
 #define SOLVE_WAVES_PER_SIMD 2
 #endif
@@ -752,14 +755,16 @@ __global__ __launch_bounds__(512, 1) void dmpc_solve_persist_kernel(StepParams P
     // atomic on one address costs ~12 ns of serialised service on this part (51 200 single claims = 0.6 ms, measured: the
     // launch could not end sooner whatever the solver did), and its result takes microseconds to arrive; so
     //   * a ticket stands for one position where the agents are heavy (the #waves positions after the first round) and
-    //     where the launch ends (the last #waves positions: a fine-grained tail), and for 4 adjacent positions in between
-    //     (the light bulk): 3-4x fewer atomics, at most one light chunk of imbalance;
+    //     where the launch ends (the last #waves positions: a fine-grained tail), and for QUEUE_CHUNK adjacent positions in
+    //     between (the light bulk): fewer atomics, at most one light chunk of imbalance -- and a pre-claimed chunk waits behind
+    //     its wave's current agent, which is why the chunk is short;
     //   * the next ticket is claimed BEFORE the current agent is solved and read after it: its latency hides behind the solve.
     const int nw = (int)(gridDim.x * (blockDim.x >> 6));
     const int rest = total > nw ? total - nw : 0;
     const int T1 = rest < nw ? rest : nw;
     const int T3 = (rest - T1) < nw ? (rest - T1) : nw;
-    const int mid = rest - T1 - T3, T2 = (mid + 3) >> 2;
+    constexpr int CHUNK = QUEUE_CHUNK;
+    const int mid = rest - T1 - T3, T2 = (mid + CHUNK - 1) / CHUNK;
     int pos = wave * (int)gridDim.x + (int)blockIdx.x, left = 0;
 #ifdef DMPC_DEV_TRACE
     // development: start / end time and agent count of every wave (dmpc_debug_trace with agent = -2)
@@ -791,9 +796,9 @@ __global__ __launch_bounds__(512, 1) void dmpc_solve_persist_kernel(StepParams P
         const int t = __builtin_amdgcn_readfirstlane(tkv);
         if (t < T1) pos = nw + t;
         else if (t < T1 + T2) {
-            pos = nw + T1 + 4 * (t - T1);
+            pos = nw + T1 + CHUNK * (t - T1);
             const int end = nw + T1 + mid;
-            left = (end - pos < 4 ? end - pos : 4) - 1;
+            left = (end - pos < CHUNK ? end - pos : CHUNK) - 1;
         } else pos = nw + T1 + mid + (t - T1 - T2);
     }
 #ifdef DMPC_DEV_TRACE
