@@ -129,6 +129,12 @@ __device__ __forceinline__ double sel3(const double *v, int ax) { return ax == 0
 #ifndef QUEUE_CHUNK
 #define QUEUE_CHUNK 2   // measured on the headline workload (M solves/s): 1: 45.8, 2: 47.7, 3: 46.6, 4: 46.5
 #endif
+#ifndef QUEUE_T1
+#define QUEUE_T1 1
+#endif
+#ifndef QUEUE_T3
+#define QUEUE_T3 1
+#endif
 #ifndef SOLVE_WAVES_PER_SIMD
 #define SOLVE_WAVES_PER_SIMD 2
 #endif
@@ -761,8 +767,8 @@ __global__ __launch_bounds__(512, 1) void dmpc_solve_persist_kernel(StepParams P
     //   * the next ticket is claimed BEFORE the current agent is solved and read after it: its latency hides behind the solve.
     const int nw = (int)(gridDim.x * (blockDim.x >> 6));
     const int rest = total > nw ? total - nw : 0;
-    const int T1 = rest < nw ? rest : nw;
-    const int T3 = (rest - T1) < nw ? (rest - T1) : nw;
+    const int T1 = rest < QUEUE_T1 * nw ? rest : QUEUE_T1 * nw;
+    const int T3 = (rest - T1) < QUEUE_T3 * nw ? (rest - T1) : QUEUE_T3 * nw;
     constexpr int CHUNK = QUEUE_CHUNK;
     const int mid = rest - T1 - T3, T2 = (mid + CHUNK - 1) / CHUNK;
     int pos = wave * (int)gridDim.x + (int)blockIdx.x, left = 0;
