@@ -373,6 +373,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
         // The next try keeps working set, factor and multipliers, solves the multipliers for the new level in one
         // refinement pass, drops those that come out negative (the finish of the crash start) and continues from there.
         bool warm = false;
+        double cond_min = 1.0;
         while (tries < max_tries) {
             tries++;
             int rc = 0;   // 0 running/ok, 1 infeasible, 2 capacity, 3 itercap
@@ -398,6 +399,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
             bool crash_stop = warm;          // warm: straight to the finish (solve the multipliers of the kept working set)
             const bool crash_box = !warm;    // every slot of the batch is an acceleration bound
             int crash_rounds = 0, nfast = 0;
+            if (!warm) cond_min = 1.0;   // smallest delta / s_pp of a constraint appended to the current factor (1: empty factor)
             const double dual0 = dual;
             LSYNC();
 
@@ -724,6 +726,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                         const double dlt = spp - wave_sum0(dvj * dvj);
                         if (!(dlt > 1e-9 * spp)) { crash_stop = true; break; }   // (distinct bounds are independent; guard only)
                         const double irho = rsqrt(dlt);
+                        cond_min = fmin(cond_min, dlt / spp);
                         if (lane < ((q + 8) & ~7)) B[SL::T + tcol(q) + lane] = (lane < q) ? (-ri * irho) : ((lane == q) ? irho : 0.0);
                         write_slot(p, 0.0);
                         if (lane == p.idx) cslot = (cslot & ~0xffu) | (unsigned)q | (p.ty == TY_BOXHI ? 0x10000u : 0x20000u);
@@ -810,6 +813,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                         // full step: append p (new column of T = [-r/rho ; 1/rho], zero below the diagonal)
                         if (q >= QCAP) { rc = 2; break; }
                         const double irho = rsqrt(delta);
+                        cond_min = fmin(cond_min, delta / spp);
                         if (lane < ((q + 8) & ~7)) B[SL::T + tcol(q) + lane] = (lane < q) ? (-ri * irho) : ((lane == q) ? irho : 0.0);
                         write_slot(p, lam_p);
                         if (p.ty < TY_COLL) {
@@ -875,7 +879,11 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                 rcslb[0] *= f; rcslb[1] *= f;
                 scale_pow += ilogb(f);
                 // warm start of the next level: the slack lower bounds in the working set get their new right-hand side (d = -lb)
-                warm = P.ladder_warm && q > 0;
+                // ... but only a well-conditioned one: an infeasible try often ends in a nearly degenerate working set (a constraint
+                // appended with delta / s_pp of 1e-6 leaves a factor with 1e3-1e4 on its diagonal), and continuing on that factor
+                // loses the digits the next level needs (randomized campaign, solveSoftDMPCall: three nearly parallel rows per
+                // neighbour -- 6 of 28 796 agent-steps ended infeasible where a fresh factor finds the solution)
+                warm = P.ladder_warm && q > 0 && cond_min >= 1e-3;
                 if (warm && lane < q && ((s_meta[lane] >> 8) & 0xff) == TY_SLKL) B[SL::SD + lane] *= f;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");

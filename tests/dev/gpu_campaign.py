@@ -29,6 +29,9 @@ for it in range(nscen):
         continue
     po, pf = po[0], pf[0]
     for variant in ALL_VARIANTS:
+        if os.environ.get("CAMPAIGN_ONLY") and variant not in os.environ["CAMPAIGN_ONLY"].split(","):
+            rng.integers(2, 7)   # (keeps the random stream of the full campaign)
+            continue
         d = mp.Dmpc(variant, **kw); prm = orc.make_params(variant, **kw)
         l = init_table(po, pf); xp, xv, xa = po.copy(), np.zeros_like(po), np.zeros_like(po)
         # slack multipliers scale with |term|: eps = -(t + sum lambda sigma)/2 loses |term| * 1e-16 * cond absolutely
@@ -46,6 +49,8 @@ for it in range(nscen):
                 if e > tol: msg = f"l_inf {e:.2e}"
             if msg:
                 bad += 1
+                dm = np.where((out['status'] != ref['status']) | (out['info'][:, 2] != ref['info'][:, 2]))[0][:3]
+                msg += ' | agents ' + str([(int(a), int(out['status'][a]), int(ref['status'][a]), 'tries', int(out['info'][a, 2]), int(ref['info'][a, 2]), 'iters', int(out['info'][a, 4])) for a in dm])
                 print(f"MISMATCH scene {it} N={N} {cfgname} variant {variant} step {k+2}: {msg}", flush=True)
             okb = out["status"] & 1 == 1
             l = np.where(okb[:, None], out["p"], l); xp = np.where(okb[:, None], out["p"][:, :3], xp)

@@ -140,3 +140,43 @@ def test_campaign_slice():
                 xv = np.where(okb[:, None], out["v"][:, :3], xv); xa = np.where(okb[:, None], out["a"][:, :3], xa)
     print(f"campaign slice: {total} agent-steps compared, worst l_inf {worst:.2e}")
     assert total > 5000
+
+
+def test_campaign_warm_ladder_regressions():
+    """the six agent-steps of the full campaign (tests/dev/gpu_campaign.py, seed 1) on which a retry ladder warm-started from the
+    factor of an infeasible try went wrong (solveSoftDMPCall: nearly parallel rows leave a nearly degenerate factor): GPU against
+    the oracle on exactly those scenes, all MPC steps of their variant."""
+    want = {68, 120, 124, 150, 153, 159}
+    rng = np.random.default_rng(1)
+    seen = 0
+    for it in range(max(want) + 1):
+        N = int(rng.integers(2, 90))
+        cfgname = "C5" if rng.random() < 0.5 else "C2"
+        cfg = wl.CONFIGS[cfgname]
+        kw = wl.solver_kwargs(cfg, N)
+        if rng.random() < 0.3:
+            kw["pmin"] = tuple(np.asarray(kw["pmin"]) * [0.8, 0.8, 1]); kw["pmax"] = tuple(np.asarray(kw["pmax"]) * [0.8, 0.8, 1])
+        try:
+            po, pf = wl.make_scenes(dict(cfg), 1, N, int(rng.integers(1 << 30)))
+        except Exception:
+            continue
+        po, pf = po[0], pf[0]
+        for variant in ALL_VARIANTS:
+            nst = int(rng.integers(2, 7))            # (the campaign's random stream)
+            if it not in want or variant != "all3":
+                continue
+            d = mp.Dmpc(variant, **kw); prm = orc.make_params(variant, **kw)
+            l = init_table(po, pf); xp, xv, xa = po.copy(), np.zeros_like(po), np.zeros_like(po)
+            for k in range(nst):
+                out = d.step_batch(l, xp, xv, xa, pf); ref = orc.step(prm, l, xp, xv, xa, pf, nthreads=8)
+                what = f"campaign scene {it} N={N} {cfgname} all3 step {k + 2}"
+                assert np.array_equal(out["status"], ref["status"]), what
+                assert np.array_equal(out["info"][:, 2], ref["info"][:, 2]), what + ": retry-ladder count"
+                ok = (ref["status"] & 1) == 1
+                e = max((np.abs(out[key][ok] - ref[key][ok]).max() if ok.any() else 0.0) for key in ("p", "v", "a"))
+                assert e <= 1e-9 * max(1.0, abs(kw["term"]) / 5e4), f"{what}: l_inf {e:.2e}"
+                okb = out["status"] & 1 == 1
+                l = np.where(okb[:, None], out["p"], l); xp = np.where(okb[:, None], out["p"][:, :3], xp)
+                xv = np.where(okb[:, None], out["v"][:, :3], xv); xa = np.where(okb[:, None], out["a"][:, :3], xa)
+            seen += 1
+    assert seen == len(want)
