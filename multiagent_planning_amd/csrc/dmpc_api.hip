@@ -68,7 +68,10 @@ struct dmpc_ctx {
     int no_cull = getenv("DMPC_NO_CULL") ? 1 : 0;
     int no_lpt = getenv("DMPC_NO_LPT") ? 1 : 0;   // tuning: disable the heaviest-first solve order
     int crash_min = getenv("DMPC_CRASH_MIN") ? atoi(getenv("DMPC_CRASH_MIN")) : CRASH_MIN_DEFAULT;   // see StepParams::crash_min
-    int ladder_warm = getenv("DMPC_LADDER_COLD") ? 0 : 1;   // tuning: restart every retry-ladder level from scratch
+    // retry ladder: every level from scratch (default).  DMPC_LADDER_WARM=1 keeps working set, factor and multipliers across levels:
+    // faster (C4 ladder agents 100 -> 65 iterations) but NOT safe -- the randomized campaign found agent-steps of solveSoftDMPCall
+    // that end infeasible or off by 8e-4 on the factor an infeasible try leaves behind, even with a conditioning guard
+    int ladder_warm = getenv("DMPC_LADDER_WARM") ? 1 : 0;
     int iter_cap = getenv("DMPC_ITER_CAP") ? atoi(getenv("DMPC_ITER_CAP")) : ITER_CAP;   // development: cap the active-set iterations (agents beyond it end DMPC_ST_ITERCAP)
     int tier1_env = getenv("DMPC_TIER1_QCAP") ? atoi(getenv("DMPC_TIER1_QCAP")) : 0;   // tuning / tests: 32 = two tiers for the slack variants (any value: no shallow-launch shortcut)
     int single_tier = 0;         // 1: solve with the full working-set capacity in one launch

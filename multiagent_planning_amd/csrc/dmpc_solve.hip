@@ -397,8 +397,8 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
             // 16 % -- compiled out there)
             bool crash = SOFT && (warm || (P.crash_min > 0 && __popcll(__ballot(comp && fabs(a_unc) - P.alim > tol)) >= P.crash_min));
             bool crash_stop = warm;          // warm: straight to the finish (solve the multipliers of the kept working set)
-            const bool crash_box = !warm;    // every slot of the batch is an acceleration bound
-            int crash_rounds = 0, nfast = 0;
+            bool crash_box = !warm;          // every slot of the batch is an acceleration bound
+            int crash_rounds = 0, nfast = 0, accept_drops = 0;
             if (!warm) cond_min = 1.0;   // smallest delta / s_pp of a constraint appended to the current factor (1: empty factor)
             const double dual0 = dual;
             LSYNC();
@@ -603,7 +603,8 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                 const unsigned long long wm = __ballot(bestc >= 0 && bests == smax);
                 if (wm == 0ull) {
                     if (!crash && (q == 0 || fresh)) break;   // optimal
-                    if (!crash) {
+                    if (!crash && !soft) {
+                        // (slack-free variants; the slack variants carry multipliers of 1e5-1e6 and always take the full verification)
                         // No constraint is violated at the (incrementally updated) iterate.  Round-off of the factor reaches the iterate
                         // only through N_W: an error dr of r = T T's moves x by t H^-1 N_W dr, which shows in the values of the
                         // active constraints (N_W' H^-1 N_W is non-singular).  If those are zero to round-off the iterate IS the
@@ -629,6 +630,15 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                         LSYNC();
                         primal_fast();
                     }
+                    }
+                    if (SOFT && !crash && !was_fresh && accept_drops < 4) {   // (slack variants: the slack-free kernels keep `crash` a compile-time false)
+                        // acceptance: the refined multipliers must be non-negative.  At a degenerate vertex the incrementally updated
+                        // multipliers can drift and the refinement then uncovers a negative one: the point is feasible but not the
+                        // minimiser (randomized campaign, seed 2: one solveSoftDMPCall agent-step of 454 611, objective off by 2e-5).
+                        // Such a constraint is dropped through the finish of the crash start and the iteration goes on.
+                        const double lam = lane < q ? B[SL::SLAM + lane] : 0.0;
+                        const double lmax = wave_max0(fabs(lam));
+                        if (__any(lane < q && lam < -1e-9 * (1.0 + lmax))) { crash = true; crash_stop = true; crash_box = false; accept_drops++; }
                     }
                     if (crash) {
                         unsigned long long neg = __ballot(lane < q && B[SL::SLAM + (lane < q ? lane : 0)] < 0.0);

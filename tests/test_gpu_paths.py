@@ -2,8 +2,8 @@
 
 * neighbour lists of large scenes (nbr_kernel + transposed list walk on the fp32 neighbour-major table): conservative
   pre-filters, the decisions are made with the arithmetic of the plain walk => bit-identical to DMPC_NO_CULL=1;
-* crash start of the acceleration bounds and warm retry ladder: another path to the same (unique) minimiser => same statuses and
-  branch records, trajectories to solver accuracy against DMPC_CRASH_MIN=0 DMPC_LADDER_COLD=1."""
+* crash start of the acceleration bounds: another path to the same (unique) minimiser => same statuses and branch records,
+  trajectories to solver accuracy against DMPC_CRASH_MIN=0."""
 import numpy as np
 import pytest
 
@@ -61,7 +61,7 @@ def test_neighbour_list_overflow_falls_back_to_the_table(monkeypatch):
 
 
 @pytest.mark.parametrize("variant", ["bound", "bound2", "repair"])
-def test_crash_start_and_warm_ladder_reach_the_same_minimiser(variant, monkeypatch):
+def test_crash_start_reaches_the_same_minimiser(variant, monkeypatch):
     cfg = wl.CONFIGS["C4"]
     N, S = 400, 2
     kw = wl.solver_kwargs(cfg, 10000)          # the workspace of the 10^4-agent scene: far goals, most acceleration bounds saturate
@@ -72,7 +72,6 @@ def test_crash_start_and_warm_ladder_reach_the_same_minimiser(variant, monkeypat
     pf = lo + rng.random((S, N, 3)) * (hi - lo)
     new = _steps(variant, kw, po, pf, 3)
     monkeypatch.setenv("DMPC_CRASH_MIN", "0")
-    monkeypatch.setenv("DMPC_LADDER_COLD", "1")
     old = _steps(variant, kw, po, pf, 1)
     a, b = new[0], old[0]
     assert np.array_equal(a["status"], b["status"])
