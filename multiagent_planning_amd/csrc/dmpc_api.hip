@@ -506,6 +506,8 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
         if (ctx->bbox.ensure((size_t)total * 6 * NSEG * 4)) FAIL(ctx, "device allocation failed (bbox)");
         if (lTf) hipLaunchKernelGGL(bbox_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, C, lTf, ctx->bbox.as<float>());
         else hipLaunchKernelGGL(bbox_kernel<double>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, C, lT, ctx->bbox.as<float>());
+        if (C >= (1 << 20) || G > 2047)   // a list entry packs (chunk << 20) | column into an int
+            FAIL(ctx, "neighbour lists: at most 2047 chunks of fewer than 2^20 agents");
         // neighbour lists from the boxes (nbr_kernel): up to 4096 entries per agent, within 1 GB of scratch
         const size_t agents = (size_t)S * c_count;
         long cap = ((long)G * C + 63) & ~63L;
