@@ -115,17 +115,24 @@ def main():
     exchange = "none"
     if use_dist and not share:
         exchange = "torch.distributed all_gather_into_tensor"
-        try:
-            idt = torch.zeros(128, dtype=torch.uint8, device=dev)
-            if rank == 0:
-                idt.copy_(torch.frombuffer(bytearray(mp.Dmpc.comm_unique_id()), dtype=torch.uint8))
-            dist.broadcast(idt, src=0)
-            dmpc.comm_init(bytes(idt.cpu().numpy().tobytes()), G, rank)
-            okf = torch.ones(1, dtype=torch.int32, device=dev)
-            exchange = "in-library RCCL all-gather (dmpc_step_sharded_device)"
-        except Exception as e:   # noqa: BLE001
-            okf = torch.zeros(1, dtype=torch.int32, device=dev)
-            sys.stderr.write(f"[bench] rank {rank}: library communicator unavailable ({e}); using torch.distributed\n")
+        # (every rank takes part in every collective below whatever fails locally: a rank that skipped one would hang the others)
+        idt = torch.zeros(129, dtype=torch.uint8, device=dev)      # 128-byte id + "rank 0 has one" flag
+        if rank == 0:
+            try:
+                idt[:128].copy_(torch.frombuffer(bytearray(mp.Dmpc.comm_unique_id()), dtype=torch.uint8))
+                idt[128] = 1
+            except Exception as e:   # noqa: BLE001
+                sys.stderr.write(f"[bench] rank 0: no RCCL id from the library ({e})\n")
+        dist.broadcast(idt, src=0)
+        okf = torch.zeros(1, dtype=torch.int32, device=dev)
+        have_id = torch.tensor([int(idt[128].item())], dtype=torch.int32, device=dev)
+        if int(have_id.item()) == 1:      # the same on every rank: all of them enter comm_init (a collective) or none
+            try:
+                dmpc.comm_init(bytes(idt[:128].cpu().numpy().tobytes()), G, rank)
+                okf = torch.ones(1, dtype=torch.int32, device=dev)
+                exchange = "in-library RCCL all-gather (dmpc_step_sharded_device)"
+            except Exception as e:   # noqa: BLE001
+                sys.stderr.write(f"[bench] rank {rank}: library communicator unavailable ({e}); using torch.distributed\n")
         dist.all_reduce(okf, op=dist.ReduceOp.MIN)     # all ranks take the same path
         if int(okf.item()) == 0:
             exchange = "torch.distributed all_gather_into_tensor"
@@ -350,11 +357,16 @@ def main():
                 po4, pf4 = wl.make_scenes(cfg4, 1, N4, wl.SEED0 + 4)   # deterministic: the same on every rank
                 torch.cuda.set_device(local_rank)
                 d4 = mp.Dmpc("bound", device=local_rank, **kw4)
-                idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+                idt = torch.zeros(129, dtype=torch.uint8, device=dev)
                 if rank == 0:
-                    idt.copy_(torch.frombuffer(bytearray(mp.Dmpc.comm_unique_id()), dtype=torch.uint8))
+                    try:
+                        idt[:128].copy_(torch.frombuffer(bytearray(mp.Dmpc.comm_unique_id()), dtype=torch.uint8)); idt[128] = 1
+                    except Exception:   # noqa: BLE001
+                        pass
                 dist.broadcast(idt, src=0)
-                d4.comm_init(bytes(idt.cpu().numpy().tobytes()), G, rank)
+                if int(idt[128].item()) != 1:
+                    raise RuntimeError("no RCCL id from the library")
+                d4.comm_init(bytes(idt[:128].cpu().numpy().tobytes()), G, rank)
                 d4.transition_sharded(po4, pf4, 3, cfg4["error_tol"], histories=False)
                 dist.barrier(); torch.cuda.synchronize()
                 tt = time.perf_counter()
