@@ -72,16 +72,19 @@ struct dmpc_ctx {
     // faster (C4 ladder agents 100 -> 65 iterations) but NOT safe -- the randomized campaign found agent-steps of solveSoftDMPCall
     // that end infeasible or off by 8e-4 on the factor an infeasible try leaves behind, even with a conditioning guard
     int ladder_warm = getenv("DMPC_LADDER_WARM") ? 1 : 0;
+    int no_fast_exit = getenv("DMPC_NO_FAST_EXIT") ? 1 : 0;   // tests: every agent through the solve kernel (the unconstrained exit of the scan off)
     int iter_cap = getenv("DMPC_ITER_CAP") ? atoi(getenv("DMPC_ITER_CAP")) : ITER_CAP;   // development: cap the active-set iterations (agents beyond it end DMPC_ST_ITERCAP)
     int tier1_env = getenv("DMPC_TIER1_QCAP") ? atoi(getenv("DMPC_TIER1_QCAP")) : 0;   // tuning / tests: 32 = two tiers for the slack variants (any value: no shallow-launch shortcut)
     int single_tier = 0;         // 1: solve with the full working-set capacity in one launch
     DevBuf lTf, lTf2;            // mixed precision: fp32 copies of the tables the scan reads
     DevBuf rows, lT, lT2, xp, xv, xa, pf, po, pout, vout, aout, status, info, hist_p, hist_v, hist_a, flags;
     int hist_S = 0, hist_N = 0, hist_KT = 0;   // shape of the histories left resident by the last dmpc_transition
+    int pc_fallback_scenes = 0;   // last dmpc_postcheck: scenes of a cell-grid search that were searched again by brute force
     dmpc_ctx *child = nullptr;   // second context (own stream and buffers) for the other half of a split batch of transitions
     int split_S0 = 0;            // > 0: the last dmpc_transition left scenes [0, split_S0) here and the rest in `child`
     int no_split = getenv("DMPC_NO_SPLIT") ? 1 : 0;
     DevBuf pc_p, pc_v, pc_a, pc_M, pc_w, pc_scene, pc_agent, pc_interp;   // post-check work buffers
+    DevBuf pc_pts, pc_cell, pc_fill, pc_start, pc_sorted, pc_on;           // post-check, large scenes: cell grid of a batch of samples
     // multi-GPU (dmpc_multigpu.hip): RCCL communicator of this rank, exchange buffers
     void *comm = nullptr;
     int nranks = 1, rank = 0;
@@ -448,6 +451,8 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     }
     P.dbg = ctx->dbg; P.dbg_agent = ctx->dbg_agent; P.dbg_cap = ctx->dbg_cap;
     P.iter_cap = ctx->iter_cap;
+    // (not for solveHardDMPC: rows at every horizon step, 3 % of the agents would qualify and every scan would pay for the test)
+    P.fast_exit = (ctx->no_fast_exit || p.variant == DMPC_VAR_HARD) ? 0 : 1;
     P.ladder_warm = ctx->ladder_warm;
     // measured: the crash start pays for the slack-carrying variants (C4, N = 10^4: solve launch -16 %) and costs on solveHardDMPC
     // (C2: -16 % throughput: with rows at every horizon step the bounds violated at the unconstrained minimiser are a poor guess)
@@ -527,7 +532,8 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
             P.lrow = ctx->lrow.p;
         }
     }
-    if (!tiny) HIPCHK(ctx, hipMemsetAsync(ctx->counter.p, 0, 16, st));   // queue heads of the persistent solve launches
+    const bool run_order = ctx->forced_n != S * c_count && S * c_count >= 512 && !ctx->no_lpt;
+    if (!tiny || run_order) HIPCHK(ctx, hipMemsetAsync(ctx->counter.p, 0, 16, st));   // queue heads of the persistent solve launches, tier-2 count, live bound
     // phase 0: scan + rows
     P.qcap = q1; P.only_flagged = 0; P.qover_bit = two_tier ? ST_QOVER : ST_CAPACITY;
     {
@@ -548,10 +554,11 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     }
     // heaviest-first launch order for the solve phase (key left by the scan in hdr[7]).  Tiny launches do not need it.
     if (ctx->forced_n == S * c_count) P.order = ctx->forced_order.as<int>();   // development aid: externally supplied launch order
-    else if (S * c_count >= 512 && !ctx->no_lpt) {
+    else if (run_order) {
         const int total = S * c_count, nb = total >= 16384 ? 8 : 1;
-        hipLaunchKernelGGL(order_kernel, dim3((unsigned)nb), dim3(1024), 0, st, total, (const int *)P.hdr, ctx->order.as<int>());
+        hipLaunchKernelGGL(order_kernel, dim3((unsigned)nb), dim3(1024), 0, st, total, (const int *)P.hdr, ctx->order.as<int>(), ctx->counter.as<int>() + 3);
         P.order = ctx->order.as<int>();
+        P.live_bound = ctx->counter.as<int>() + 3;
     }
     if (ctx->profile) HIPCHK(ctx, hipEventRecord(ev.t1, st));
     // phase 1: persistent waves (one workgroup per CU, shared tables, agents claimed from a queue) when at least two
@@ -560,6 +567,9 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     auto persist_waves = [&](int qcap, size_t &per) -> int {
         per = solve_lds_bytes(P.nrmax, soft, qcap, true);
         int pw = (int)((LDS_CU - PERSIST_TABLE_BYTES) / per);
+#ifdef DMPC_DEV_PW   // development builds: fewer persistent waves per CU (how much does a long agent lose to the wave it shares a SIMD with?)
+        if (pw > DMPC_DEV_PW) pw = DMPC_DEV_PW;
+#endif
         return pw > 8 ? 8 : pw;
     };
     // the working-set capacity is a template parameter of the solve kernels
@@ -635,7 +645,7 @@ extern "C" int dmpc_debug_trace(dmpc_ctx *ctx, int agent, int cap, double *host_
     }
     if (ctx->dbg) { (void)hipFree(ctx->dbg); ctx->dbg = nullptr; }
     ctx->dbg_agent = agent; ctx->dbg_cap = cap;
-    if ((agent >= 0 || agent == -2 || agent == -3) && cap > 0) {
+    if ((agent >= 0 || agent == -2 || agent == -3 || agent == -5) && cap > 0) {
         HIPCHK(ctx, hipMalloc((void **)&ctx->dbg, sizeof(double) * 8 * cap));
         HIPCHK(ctx, hipMemset(ctx->dbg, 0, sizeof(double) * 8 * cap));
     }
@@ -1046,7 +1056,6 @@ static int postcheck_one(dmpc_ctx *ctx, int S, int N, int KT_alloc, const int32_
     if (!ctx) { g_err = "dmpc_postcheck: ctx is NULL"; return -1; }
     if (S < 1 || N < 1 || KT_alloc < 2 || !K_T_used || !pf || !(vmax > 0) || !(amax > 0) || !(Ts > 0))
         FAIL(ctx, "dmpc_postcheck: bad arguments");
-    if (N > 2048) FAIL(ctx, "dmpc_postcheck: at most 2048 agents per scene");
     std::vector<int32_t> kt(S);
     for (int s = 0; s < S; ++s) {
         const bool on = !scene_mask || scene_mask[s];
@@ -1113,7 +1122,59 @@ static int postcheck_one(dmpc_ctx *ctx, int S, int N, int KT_alloc, const int32_
         d_interp = ctx->pc_interp.as<double>();
         HIPCHK(ctx, hipMemsetAsync(d_interp, 0, A * (size_t)ns_alloc * 24, st));
     }
-    if (ns_max > 0)
+    // grid search of the large scenes: `grid_pass(scene_on)` runs every sample batch; scene_on = null: cell-grid search of all
+    // scenes, else brute force over the same batch positions for the scenes flagged in it
+    bool use_grid = N > PC_BRUTE_MAX && ns_max > 0;
+    pc::Grid g{};
+    double edge = 2.0 * ctx->prm.rmin;
+    int SB = 1, ncell = 1;
+    if (use_grid) {
+        const dmpc_params &pr = ctx->prm;
+        for (;;) {   // cells of `edge` (z: edge * c) over the workspace + 2 cells of margin, at most 32768 of them
+            g.nx = (int)std::ceil((pr.pmax[0] - pr.pmin[0]) / edge) + 2;
+            g.ny = (int)std::ceil((pr.pmax[1] - pr.pmin[1]) / edge) + 2;
+            g.nz = (int)std::ceil((pr.pmax[2] - pr.pmin[2]) / (edge * pr.c)) + 2;
+            if ((double)g.nx * g.ny * g.nz <= 32768.0) break;
+            edge *= 1.25;
+        }
+        g.x0 = pr.pmin[0] - edge; g.y0 = pr.pmin[1] - edge; g.z0 = pr.pmin[2] - edge * pr.c;
+        g.inv_e = 1.0 / edge; g.inv_ez = 1.0 / (edge * pr.c);
+        ncell = g.nx * g.ny * g.nz;
+        const double per_sample = (double)S * ((double)N * 36.0 + (double)ncell * 8.0 + 4.0);
+        SB = (int)std::floor(256.0 * 1048576.0 / per_sample);
+        SB = SB < 1 ? 1 : (SB > 256 ? 256 : SB);
+        if (SB > ns_max) SB = ns_max;
+        const size_t sbn = (size_t)S * SB;
+        if (ctx->pc_pts.ensure(sbn * N * 24) || ctx->pc_cell.ensure(sbn * N * 4) || ctx->pc_sorted.ensure(sbn * N * 4) ||
+            ctx->pc_fill.ensure(sbn * ncell * 4) || ctx->pc_start.ensure(sbn * ((size_t)ncell + 1) * 4) || ctx->pc_on.ensure((size_t)S * 4))
+            FAIL(ctx, "device allocation failed (post-check cell grid)");
+        HIPCHK(ctx, hipMemsetAsync(ctx->pc_fill.p, 0, sbn * ncell * 4, st));
+    }
+    auto grid_pass = [&](const int *scene_on) -> int {
+        const size_t sbn = (size_t)S * SB, tot = sbn * N;
+        for (int smp0 = 0; smp0 < ns_max; smp0 += SB) {
+            hipLaunchKernelGGL(pc::grid_eval_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, S, N, KT_alloc, (const int *)d_kt,
+                               (const double *)d_hs, (const int *)d_ns, Ts, smp0, SB, (const double *)dp, (const double *)ctx->pc_M.as<double>(), g,
+                               ctx->pc_pts.as<double>(), ctx->pc_cell.as<int>(), ctx->pc_fill.as<int>(), scene_on ? (double *)nullptr : d_interp, ns_alloc);
+            if (!scene_on) {
+                hipLaunchKernelGGL(pc::grid_scan_kernel, dim3((unsigned)sbn), dim3(1024), 0, st, ncell, ctx->pc_fill.as<int>(), ctx->pc_start.as<int>());
+                hipLaunchKernelGGL(pc::grid_scatter_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, tot, N, ncell,
+                                   (const int *)ctx->pc_cell.as<int>(), (const int *)ctx->pc_start.as<int>(), ctx->pc_fill.as<int>(), ctx->pc_sorted.as<int>());
+                HIPCHK(ctx, hipMemsetAsync(ctx->pc_fill.p, 0, sbn * ncell * 4, st));
+                hipLaunchKernelGGL(pc::grid_pairs_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)SB, (unsigned)S), dim3(256), 0, st, N, SB, g,
+                                   1.0 / ctx->prm.c, (const double *)ctx->pc_pts.as<double>(), (const int *)ctx->pc_cell.as<int>(),
+                                   (const int *)ctx->pc_start.as<int>(), (const int *)ctx->pc_sorted.as<int>(), d_min);
+            } else {
+                HIPCHK(ctx, hipMemsetAsync(ctx->pc_fill.p, 0, sbn * ncell * 4, st));   // (the evaluation counted again)
+                hipLaunchKernelGGL(pc::pairs_brute_pts_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)SB, (unsigned)S), dim3(256), 0, st, N, SB,
+                                   1.0 / ctx->prm.c, (const double *)ctx->pc_pts.as<double>(), (const int *)ctx->pc_cell.as<int>(), scene_on, d_min);
+            }
+            HIPCHK(ctx, hipGetLastError());
+        }
+        return 0;
+    };
+    if (use_grid) { if (grid_pass(nullptr)) return -1; }
+    else if (ns_max > 0)
     hipLaunchKernelGGL(pc::pairdist_kernel, dim3((unsigned)((ns_max + PC_SAMPLES_PER_BLOCK - 1) / PC_SAMPLES_PER_BLOCK), (unsigned)S),
                        dim3(256), (size_t)N * 24, st, N, KT_alloc, (const int *)d_kt, (const double *)d_hs, (const int *)d_ns, Ts,
                        1.0 / ctx->prm.c, (const double *)dp, (const double *)ctx->pc_M.as<double>(), d_min, d_interp, ns_alloc);
@@ -1126,6 +1187,21 @@ static int postcheck_one(dmpc_ctx *ctx, int S, int N, int KT_alloc, const int32_
                        d_tot, d_tt);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipMemcpyAsync(md.data(), d_min, (size_t)S * 8, hipMemcpyDeviceToHost, st));
+    if (use_grid) {
+        // scenes in which the grid found no pair closer than its cell edge: nothing is closer than that (no violation); the exact
+        // minimum, which the interface reports, takes the brute-force search over the same sample batches
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        std::vector<int> on(S, 0);
+        int n_on = 0;
+        for (int s = 0; s < S; ++s)
+            if (kt[s] && N > 1 && !(md[s] <= edge * edge)) { on[s] = 1; n_on++; }
+        ctx->pc_fallback_scenes = n_on;
+        if (n_on) {
+            HIPCHK(ctx, hipMemcpyAsync(ctx->pc_on.p, on.data(), (size_t)S * 4, hipMemcpyHostToDevice, st));
+            if (grid_pass(ctx->pc_on.as<int>())) return -1;
+            HIPCHK(ctx, hipMemcpyAsync(md.data(), d_min, (size_t)S * 8, hipMemcpyDeviceToHost, st));
+        }
+    }
     HIPCHK(ctx, hipMemcpyAsync(tot.data(), d_tot, (size_t)S * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipMemcpyAsync(tt.data(), d_tt, (size_t)S * 8, hipMemcpyDeviceToHost, st));
     if (p_interp) HIPCHK(ctx, hipMemcpyAsync(p_interp, d_interp, A * (size_t)ns_alloc * 24, hipMemcpyDeviceToHost, st));

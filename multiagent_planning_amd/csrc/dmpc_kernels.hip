@@ -155,6 +155,35 @@ struct Agent {   // wave-uniform agent data
     double po[3], vo[3], ao[3], pf[3];
 };
 
+// ---- arithmetic shared by the scan's unconstrained exit and the solver (explicit contractions: both kernels must produce the
+// ---- same bits for an agent whichever of them finishes it)
+// cost case of solveSoftDMPCbound.m:43-58 (0 far, 1 near, 2 collision rows)
+__device__ __forceinline__ int cost_case(int var, double d0, double d1, double d2 /* po - pf */, bool rows_exist)
+{
+    const double dn = sqrt(fma(d2, d2, fma(d1, d1, d0 * d0)));
+    const bool far = (var == VAR_ELLIP) ? (dn > 1.0) : (dn >= 1.0);
+    if (!rows_exist && far) return 0;
+    if (!rows_exist && dn < 1.0) return 1;
+    return 2;
+}
+// g = pf - (po + K h vo): what is left to the goal after coasting through the horizon (per axis)
+__device__ __forceinline__ double goal_gap(double pf, double po, double vo, double h) { return pf - fma((double)K * h, vo, po); }
+// a_unc(k) or w_unc(k) = 2 q g T1 + 2 s ao T2 with the two table entries of the component
+__device__ __forceinline__ double unc_entry(double qw, double sw, double gax, double ao, double t1, double t2)
+{
+    return fma(2.0 * qw * gax, t1, (2.0 * sw * ao) * t2);
+}
+// A_initp(k,:) [po;vo] of component (k, axis)
+__device__ __forceinline__ double init_pos(int k, double h, double vo, double po) { return fma((double)(k + 1) * h, vo, po); }
+// v(k) = h sum_{kk<=k} a(kk) + vo   (propStatedmpc.m:4); a_s: the stacked accelerations in LDS
+__device__ __forceinline__ double vel_out(const double *a_s, int k_l, int ax_l, double h, double vo)
+{
+    double sv = 0.0;
+#pragma unroll
+    for (int kk = 0; kk < K; ++kk) { const double ak = a_s[3 * kk + ax_l]; sv += (kk <= k_l) ? ak : 0.0; }
+    return fma(h, sv, vo);
+}
+
 // Retry-ladder certificate (bounded-slack variants).  The rows of one horizon step k constrain only w_k = (Lambda a)_k,
 // and with |a| <= alim the reachable set of w_k is EXACTLY the box |w_k| <= alim ((k+1) h)^2 / 2 per axis (cut by the
 // workspace bounds of that step).  With every slack at its lower bound slb*f the rows are the half-spaces
@@ -231,16 +260,21 @@ __device__ __attribute__((noinline)) bool ladder_level_infeasible(const double *
                          w2 = (ab * (b0 * d1 - b1 * d0) + bb * (d0 * a1 - d1 * a0)) * idd;
             const double idn = ok ? rsqrt(dd) : 0.0;
             d0 *= idn; d1 *= idn; d2 *= idn;
-            double lo = -INFINITY, hi = INFINITY, par = -INFINITY;   // par: worst violation among planes parallel to the line
+            // the interval [lo, hi] the other planes leave on the line, its ends kept as fractions with positive denominators
+            // (lo = ln / ld, hi = hn / hd; -inf and +inf are -1/0 and 1/0): candidates are compared by cross-multiplication, two
+            // divisions per line instead of one per plane (the certificate was 10-20 % of a long ladder solve)
+            double ln = -1.0, ld = 0.0, hn = 1.0, hd = 0.0, par = -INFINITY;   // par: worst violation among planes parallel to the line
+            const double2 *pl2 = (const double2 *)__builtin_assume_aligned(pl, 16);
             for (int c = 0; c < Mt; ++c) {
-                const double c0_ = pl[4 * c], c1 = pl[4 * c + 1], c2 = pl[4 * c + 2];
+                const double2 pa = pl2[2 * c], pb = pl2[2 * c + 1];
+                const double c0_ = pa.x, c1 = pa.y, c2 = pb.x;
                 const double g = c0_ * d0 + c1 * d1 + c2 * d2;                        // slope along the line
-                const double r = pl[4 * c + 3] - (c0_ * w0 + c1 * w1 + c2 * w2);      // slack at w0 (relative units)
-                if (g > 1e-12) hi = fmin(hi, r / g);
-                else if (g < -1e-12) lo = fmax(lo, r / g);
+                const double r = pb.y - (c0_ * w0 + c1 * w1 + c2 * w2);               // slack at w0 (relative units)
+                if (g > 1e-12) { if (r * hd < hn * g) { hn = r; hd = g; } }           // hi = min(hi, r / g)
+                else if (g < -1e-12) { if (-r * ld > ln * -g) { ln = -r; ld = -g; } } // lo = max(lo, r / g)
                 else par = fmax(par, -r);
             }
-            const double gap = fmax((lo - hi) / R, par);   // positive = the line misses the polytope
+            const double gap = fmax((ln / ld - hn / hd) / R, par);   // positive = the line misses the polytope
             if (ok) best = fmin(best, gap);
             found = __any(ok && gap <= 1e-9);
         }
@@ -706,6 +740,80 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
             }
             if (lane == 0) hdr[7] = key > 255 ? 255 : key;
         }
+        // ---- unconstrained exit.  Most agent-steps of a transition are trivial: no bound, workspace wall or collision row is violated
+        // at the unconstrained minimiser a_unc (closed form from the tables), so the active-set loop would stop before its first
+        // iteration.  Such an agent is finished HERE -- same arithmetic as the solver's set-up and output stage (the shared helpers
+        // above), its header flagged (hdr[4] & 16) -- and never enters the solve queue: the scan runs at twice the solver's
+        // occupancy and the agent's state is already in registers.  (43 % of the agents of the solveSoftDMPCbound replay of
+        // bench.py, nearly all of them once the swarm has spread out.)
+        if (P.fast_exit && status == 0 && !__any(cert_infeasible) && nr <= 128) {
+            const int ls = (int)wave_max((double)ladder_start);
+            const int ccase = cost_case(var, A.po[0] - A.pf[0], A.po[1] - A.pf[1], A.po[2] - A.pf[2], rows_exist);
+            const double qw = ccase == 0 ? P.Qfar : (ccase == 1 ? P.Qnear : P.Q1);
+            const double sw = ccase == 2 ? ((var == VAR_ALL3) ? 10.0 : P.S1) : P.Sfree;
+            const bool comp = lane < N3;
+            const int k_l = comp ? lane / 3 : 0, ax_l = comp ? lane - 3 * k_l : 0;
+            const double *tb = P.tables + (size_t)ccase * TAB_CASE_DOUBLES;
+            double a_unc = 0.0, w_unc = 0.0, p0_l = 0.0, vo_l = 0.0;
+            bool viol = false;
+            const double tol = 1e-10;
+            if (comp) {
+                const double gax = goal_gap(sel3(A.pf, ax_l), sel3(A.po, ax_l), sel3(A.vo, ax_l), P.h);
+                const double ao_l = sel3(A.ao, ax_l);
+                a_unc = unc_entry(qw, sw, gax, ao_l, tb[k_l * 30 + 15 + (K - 1)], tb[k_l * 30]);
+                w_unc = unc_entry(qw, sw, gax, ao_l, tb[(15 + k_l) * 30 + 15 + (K - 1)], tb[(15 + k_l) * 30]);
+                vo_l = sel3(A.vo, ax_l);
+                const double sh = (double)(k_l + 1) * P.h * vo_l;
+                const double whi = sel3(P.pmax, ax_l) - sel3(A.po, ax_l) - sh, wlo = sel3(P.pmin, ax_l) - sel3(A.po, ax_l) - sh;
+                p0_l = init_pos(k_l, P.h, vo_l, sel3(A.po, ax_l));
+                viol = (fabs(a_unc) - P.alim > tol) || (fmax(w_unc - whi, wlo - w_unc) > tol);
+            }
+            bool trivial = ls == 0 && !__any(viol);
+            double *a_s = (double *)smem, *wu_s = a_s + 48;   // (own prediction and key vector are dead by now)
+            if (trivial) {
+                LSYNC();
+                if (comp) { a_s[lane] = a_unc; wu_s[lane] = w_unc; }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the rows this wave wrote are read back
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                LSYNC();
+                bool rv = false;
+                for (int i = lane; i < nr; i += 64) {
+                    const int kc = L.r_kc[i];
+                    const double v = -(L.r_xi[3 * i] * wu_s[3 * kc] + L.r_xi[3 * i + 1] * wu_s[3 * kc + 1] + L.r_xi[3 * i + 2] * wu_s[3 * kc + 2]) - L.r_b[i];
+                    rv = rv || v > tol;
+                }
+                trivial = !__any(rv);
+            }
+            if (trivial) {
+                int st = ST_SOLVED | (coll_flag ? ST_COLL : 0);
+                const double p_out = w_unc + p0_l;
+                double v_out = 0.0;
+                if (comp) v_out = vel_out(a_s, k_l, ax_l, P.h, vo_l);
+                const bool ob_check = !(var == VAR_ELLIP || var == VAR_SOFTALL || cppv);   // (as the solver's output stage)
+                if (ob_check) {
+                    const double tolb = 50e-3;
+                    bool bad = false;
+                    if (lane < 3) bad = !(p_out < sel3(P.pmax, lane) + tolb) || !(p_out > sel3(P.pmin, lane) - tolb);
+                    if (__any(bad)) st |= ST_OUTBOUND;
+                }
+                if (comp) {
+                    P.p_out[(size_t)gid * N3 + lane] = p_out;
+                    P.v_out[(size_t)gid * N3 + lane] = v_out;
+                    P.a_out[(size_t)gid * N3 + lane] = a_unc;
+                    if (P.lT_next) P.lT_next[(size_t)scene * N3 * C + cl + (size_t)(unsigned)(lane * C)] = p_out;
+                }
+                if (lane == 0) {
+                    P.status[gid] = st;
+                    hdr[4] = (violation ? 1 : 0) | (coll_flag ? 4 : 0) | 16;
+                    hdr[7] = 0;
+                    if (P.info) {
+                        int *inf = P.info + (size_t)gid * 8;
+                        inf[0] = viol_k; inf[1] = nrows_ref; inf[2] = 1; inf[3] = ccase;
+                        inf[4] = 0; inf[5] = 0; inf[6] = 0; inf[7] = 0;
+                    }
+                }
+            }
+        }
     }
 }
 
@@ -735,7 +843,8 @@ __global__ __launch_bounds__(64 * SCAN_WAVES_PER_WG, SCAN_WAVES_PER_SIMD) void d
 template <bool SOFT, int QCAP>
 __global__ __launch_bounds__(64, SOLVE_WAVES_PER_SIMD) void dmpc_solve_kernel(StepParams P)
 {
-    solve_body<SOFT, QCAP, false>(P, threadIdx.x, blockIdx.x, gridDim.x, dmpc_smem, nullptr);
+    int no_ticket = 0;
+    solve_body<SOFT, QCAP, false>(P, threadIdx.x, blockIdx.x, gridDim.x, dmpc_smem, nullptr, nullptr, no_ticket);
 }
 
 // Persistent form of the solve phase: one workgroup of up to 8 independent waves per CU (two per SIMD).  The Gram tables of the three
@@ -747,7 +856,8 @@ template <bool SOFT, int QCAP>
 __global__ __launch_bounds__(512, 1) void dmpc_solve_persist_kernel(StepParams P)
 {
     // tier 2 works through the list of agents tier 1 flagged (P.order points at it); usually it is empty
-    const int total = P.only_flagged ? *P.flag_count : P.S * P.c_count;
+    int total = P.only_flagged ? *P.flag_count : P.S * P.c_count;
+    if (!P.only_flagged && P.live_bound) { const int lb = *P.live_bound; total = lb < total ? lb : total; }   // the rest of the order: agents the scan finished
     if (total == 0) return;
     double *shtab = (double *)dmpc_smem;
     for (int i = threadIdx.x; i < TAB_DOUBLES; i += blockDim.x) shtab[i] = P.tables[i];
@@ -771,41 +881,59 @@ __global__ __launch_bounds__(512, 1) void dmpc_solve_persist_kernel(StepParams P
     const int T3 = (rest - T1) < QUEUE_T3 * nw ? (rest - T1) : QUEUE_T3 * nw;
     constexpr int CHUNK = QUEUE_CHUNK;
     const int mid = rest - T1 - T3, T2 = (mid + CHUNK - 1) / CHUNK;
-    int pos = wave * (int)gridDim.x + (int)blockIdx.x, left = 0;
+    // The loop is pipelined over agents.  While agent i is solved the wave already holds the AGENT behind queue position
+    // i+1 (order[pos] loaded during the solve of agent i-1... i: off the critical path) and has the ticket of position i+2
+    // in flight: per agent one memory round trip is exposed (its set-up loads, all issued together by solve_body) instead of
+    // ticket -> order -> header -> state -> rows.  A wave holds at most two claimed positions ahead of the one it works on.
+    const bool dyn = P.counter != nullptr;
+    auto resolve = [&](int ps) -> int { return (ps < total && P.order) ? P.order[ps] : ps; };   // queue position -> agent
+    auto decode = [&](int t, int &left) -> int {   // ticket -> first position it stands for (+ `left` further ones)
+        left = 0;
+        if (t < T1) return nw + t;
+        if (t < T1 + T2) {
+            const int ps = nw + T1 + CHUNK * (t - T1), end = nw + T1 + mid;
+            left = (end - ps < CHUNK ? end - ps : CHUNK) - 1;
+            return ps;
+        }
+        return nw + T1 + mid + (t - T1 - T2);
+    };
+    int pos = wave * (int)gridDim.x + (int)blockIdx.x;   // first round: static
+    if (pos >= total) return;
+    int agent = resolve(pos);
+    // position after the first: a ticket (or the static stride); its agent is loaded during the first solve
+    int left = 0, pos_n, tkv = 0;
+    if (dyn) {
+        if (lane == 0) tkv = atomicAdd(P.counter, 1);
+        pos_n = decode(__builtin_amdgcn_readfirstlane(tkv), left);
+    } else pos_n = pos + nw;
 #ifdef DMPC_DEV_TRACE
     // development: start / end time and agent count of every wave (dmpc_debug_trace with agent = -2)
     const long long t_begin = wall_clock64();
     int n_done = 0;
 #endif
     for (;;) {
-        if (pos >= total) break;
 #ifdef DMPC_DEV_TRACE
         n_done++;
+        const long long t_a = wall_clock64();
 #endif
-        int tkv = 0;
-        if (P.counter && left == 0 && lane == 0) tkv = atomicAdd(P.counter, 1);
+        const int agent_n = resolve(pos_n);   // in flight during this solve
         // opaque copy of the lane id: keeps the compiler from hoisting the solver's per-lane constants out of this
         // loop (they would stay live across the whole body and push the kernel into scratch spills)
         int ln = lane;
         asm volatile("" : "+v"(ln));
-#ifdef DMPC_DEV_TRACE
-        const long long t_a = wall_clock64();
-#endif
-        solve_body<SOFT, QCAP, true>(P, ln, pos, total, mine, shtab);
+        const bool need_ticket = dyn && left == 0 && pos_n < total;
+        solve_body<SOFT, QCAP, true>(P, ln, agent, total, mine, shtab, need_ticket ? P.counter : nullptr, tkv);
         LSYNC();
 #ifdef DMPC_DEV_TRACE
         // development: start time and duration of every queue position (dmpc_debug_trace with agent = -3)
         if (P.dbg && P.dbg_agent == -3 && lane == 0) { P.dbg[(size_t)pos * 2] = (double)t_a; P.dbg[(size_t)pos * 2 + 1] = (double)(wall_clock64() - t_a); }
+        if (P.dbg && P.dbg_agent == -5 && lane == 0) { P.dbg[(size_t)agent * 2] = (double)t_a; P.dbg[(size_t)agent * 2 + 1] = (double)(wall_clock64() - t_a); }   // the same by AGENT
 #endif
-        if (!P.counter) { pos += nw; continue; }   // static round-robin over the (sorted) queue (development)
-        if (left > 0) { pos++; left--; continue; }
-        const int t = __builtin_amdgcn_readfirstlane(tkv);
-        if (t < T1) pos = nw + t;
-        else if (t < T1 + T2) {
-            pos = nw + T1 + CHUNK * (t - T1);
-            const int end = nw + T1 + mid;
-            left = (end - pos < CHUNK ? end - pos : CHUNK) - 1;
-        } else pos = nw + T1 + mid + (t - T1 - T2);
+        pos = pos_n; agent = agent_n;
+        if (pos >= total) break;
+        if (!dyn) pos_n = pos + nw;                      // static round-robin over the (sorted) queue (development)
+        else if (left > 0) { pos_n = pos + 1; left--; }
+        else pos_n = decode(__builtin_amdgcn_readfirstlane(tkv), left);
     }
 #ifdef DMPC_DEV_TRACE
     if (P.dbg && P.dbg_agent == -2 && lane == 0) {
@@ -944,22 +1072,29 @@ __global__ __launch_bounds__(64) void nbr_kernel(int S, int G, int C, int g_loca
 // results do not depend on the order.  gridDim.x workgroups: workgroup b sorts the agents i = b (mod gridDim.x)
 // (statistically identical slices) and writes its r-th heaviest agent to position r * gridDim.x + b, so the
 // interleaved sequence is heaviest-first overall up to the differences between the slices.
-__global__ void order_kernel(int count, const int *__restrict__ hdr, int *__restrict__ order)
+__global__ void order_kernel(int count, const int *__restrict__ hdr, int *__restrict__ order, int *__restrict__ live_bound)
 {
-    __shared__ int hist[256];
-    __shared__ int offs[256];
+    // (agents the scan already finished -- hdr[4] & 16 -- sort behind everything else: bucket 256.  Slice b puts its live agents at
+    // positions b, b + nb, ...: every position from nb * max_b(live agents of slice b) on holds a finished agent, and that bound
+    // is what the solve queue runs to.)
+    __shared__ int hist[257];
+    __shared__ int offs[257];
     const int nb = gridDim.x, b = blockIdx.x;
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
+    for (int i = threadIdx.x; i < 257; i += blockDim.x) hist[i] = 0;
     __syncthreads();
     for (int i = b + nb * (int)threadIdx.x; i < count; i += nb * (int)blockDim.x) {
-        const int key = hdr[(size_t)i * 8 + 7] & 255;
+        const int key = (hdr[(size_t)i * 8 + 4] & 16) ? 256 : 255 - (hdr[(size_t)i * 8 + 7] & 255);   // bucket: heaviest first
         atomicAdd(&hist[key], 1);
     }
     __syncthreads();
-    if (threadIdx.x == 0) { int acc = 0; for (int k = 255; k >= 0; --k) { offs[k] = acc; acc += hist[k]; } }
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int k = 0; k <= 256; ++k) { offs[k] = acc; acc += hist[k]; }
+        if (live_bound) atomicMax(live_bound, nb * offs[256]);
+    }
     __syncthreads();
     for (int i = b + nb * (int)threadIdx.x; i < count; i += nb * (int)blockDim.x) {
-        const int key = hdr[(size_t)i * 8 + 7] & 255;
+        const int key = (hdr[(size_t)i * 8 + 4] & 16) ? 256 : 255 - (hdr[(size_t)i * 8 + 7] & 255);
         order[(size_t)atomicAdd(&offs[key], 1) * nb + b] = i;
     }
 }

@@ -126,8 +126,21 @@ __device__ __forceinline__ double spline_eval(const double *__restrict__ y, cons
     const double b = (y1 - y0) / h - h * (2 * m0 + m1) / 6.0;
     return y0 + u * (b + u * (m0 / 2 + u * (m1 - m0) / (6.0 * h)));
 }
+// the same evaluation for the kernels below the #undefs
+__device__ __forceinline__ double spline_eval2(const double *__restrict__ y, const double *__restrict__ M, size_t o, int n, double h, double t)
+{
+    return spline_eval(y, M, o, n, h, t);
+}
 #undef Y
 #undef MM
+
+// squared ellipsoidal distance |E1 (p_i - p_j)|^2 of one pair (failure_rate.m:172): ONE expression with pinned contractions for
+// every kernel that evaluates it, so the brute-force and the cell-grid search return the same bits
+__device__ __forceinline__ double pair_d2(double xi, double yi, double zi, double xj, double yj, double zj, double cinv)
+{
+    const double dx = xi - xj, dy = yi - yj, dz = (zi - zj) * cinv;
+    return fma(dz, dz, fma(dy, dy, dx * dx));
+}
 
 #define PC_SAMPLES_PER_BLOCK 8
 // pairwise ellipsoidal distance at every 100 Hz sample (failure_rate.m:165-181): block = (sample group, scene);
@@ -157,11 +170,154 @@ __global__ void pairdist_kernel(int N, int KTa, const int *__restrict__ kt_used,
         for (int e = threadIdx.x; e < N * N; e += blockDim.x) {
             const int i = e / N, j = e - i * N;
             if (j <= i) continue;
-            const double dx = pos[3 * i] - pos[3 * j], dy = pos[3 * i + 1] - pos[3 * j + 1],
-                         dz = (pos[3 * i + 2] - pos[3 * j + 2]) * cinv;
-            m = fmin(m, dx * dx + dy * dy + dz * dz);
+            m = fmin(m, pair_d2(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2], pos[3 * j], pos[3 * j + 1], pos[3 * j + 2], cinv));
         }
         __syncthreads();
+    }
+    m = block_min(m, sh);
+    if (threadIdx.x == 0 && m < INFINITY) atomicMin(&mind2[s], (unsigned long long)__double_as_longlong(m));
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Large scenes (N > PC_BRUTE_MAX): the all-pairs search of failure_rate.m:170-181 is O(N^2) per 100 Hz sample -- 5e7 pairs x
+// 3 000 samples at N = 10^4.  Per (scene, sample) the agents are binned into a uniform grid whose cells are `edge` wide in
+// the metric of the check (x, y, z / c): two agents closer than `edge` lie in the same or in adjacent cells, so testing
+// the 27-neighbourhood finds EVERY pair with distance < edge, and each of those is evaluated with the exact fp64 expression
+// of the brute-force search.  Hence: if the minimum the grid search returns is <= edge it is the scene's exact minimum
+// (bit for bit what the brute force returns: a minimum does not depend on the order of its operands); if it is larger or no
+// pair was found at all, no pair is closer than edge >= 2 rmin -- the verdict "no violation" is already proven, and the
+// scene is searched again by brute force only to report the exact `min_dist`.  Cell indices are clamped to the grid, which
+// keeps adjacency (clamping is monotone and non-expansive), so positions outside the workspace cost candidates, not
+// correctness.  A batch of SB samples is processed per pass: evaluate + count, exclusive scan, scatter, search.
+struct Grid {
+    int nx, ny, nz;
+    double x0, y0, z0;      // lower corner
+    double inv_e, inv_ez;   // 1 / edge (x, y) and 1 / (edge c) (z)
+};
+#define PC_BRUTE_MAX 256
+
+// thread per (scene, sample of the batch, agent): spline position -> pts, cell -> cell_of, count -> fill
+__global__ void grid_eval_kernel(int S, int N, int KTa, const int *__restrict__ kt_used, const double *__restrict__ hs,
+                                 const int *__restrict__ ns, double Ts, int smp0, int SB, const double *__restrict__ y,
+                                 const double *__restrict__ M, Grid g, double *__restrict__ pts, int *__restrict__ cell_of,
+                                 int *__restrict__ fill, double *__restrict__ p_interp, int ns_alloc)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)S * SB * N) return;
+    const int i = (int)(t % N);
+    const int b = (int)((t / N) % SB), s = (int)(t / ((size_t)N * SB));
+    const int smp = smp0 + b;
+    if (smp >= ns[s]) { cell_of[t] = -1; return; }
+    const int n = kt_used[s];
+    const double h = hs[s], tt = smp * Ts;
+    const size_t o = ((size_t)s * N + i) * (size_t)KTa * 3;
+    const double x = spline_eval2(y, M, o, n, h, tt), yv = spline_eval2(y, M, o + 1, n, h, tt), z = spline_eval2(y, M, o + 2, n, h, tt);
+    pts[3 * t] = x; pts[3 * t + 1] = yv; pts[3 * t + 2] = z;
+    if (p_interp && smp < ns_alloc) {
+        double *d = p_interp + (((size_t)s * N + i) * ns_alloc + smp) * 3;
+        d[0] = x; d[1] = yv; d[2] = z;
+    }
+    int ix = (int)floor((x - g.x0) * g.inv_e), iy = (int)floor((yv - g.y0) * g.inv_e), iz = (int)floor((z - g.z0) * g.inv_ez);
+    ix = ix < 0 ? 0 : (ix >= g.nx ? g.nx - 1 : ix);
+    iy = iy < 0 ? 0 : (iy >= g.ny ? g.ny - 1 : iy);
+    iz = iz < 0 ? 0 : (iz >= g.nz ? g.nz - 1 : iz);
+    const int c = ix + g.nx * (iy + g.ny * iz);
+    cell_of[t] = c;
+    atomicAdd(&fill[((size_t)s * SB + b) * ((size_t)g.nx * g.ny * g.nz) + c], 1);
+}
+// block per (scene, sample): start[c] = number of agents in cells < c (ncell + 1 entries); the counts go back to zero
+__global__ void grid_scan_kernel(int ncell, int *__restrict__ fill, int *__restrict__ start)
+{
+    __shared__ int part[1024];
+    int *f = fill + (size_t)blockIdx.x * ncell, *st = start + (size_t)blockIdx.x * (ncell + 1);
+    const int per = (ncell + 1023) / 1024, lo = threadIdx.x * per, hi = lo + per < ncell ? lo + per : ncell;
+    int a = 0;
+    for (int c = lo; c < hi; ++c) a += f[c];
+    part[threadIdx.x] = a;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {   // inclusive scan of the partial sums
+        const int v = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = part[threadIdx.x] - a;
+    for (int c = lo; c < hi; ++c) { st[c] = run; run += f[c]; f[c] = 0; }
+    if (threadIdx.x == 1023) st[ncell] = part[1023];
+}
+// thread per (scene, sample, agent): slot of the agent in its cell (the order inside a cell is arbitrary: only a minimum is taken)
+__global__ void grid_scatter_kernel(size_t total, int N, int ncell, const int *__restrict__ cell_of, const int *__restrict__ start,
+                                    int *__restrict__ fill, int *__restrict__ sorted)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int c = cell_of[t];
+    if (c < 0) return;
+    const size_t sb = t / N;
+    const int slot = start[sb * (ncell + 1) + c] + atomicAdd(&fill[sb * ncell + c], 1);
+    sorted[sb * N + slot] = (int)(t % N);
+}
+// block = (tile of 256 agents i, sample, scene): every agent j > i of the 27 cells around i's
+__global__ void grid_pairs_kernel(int N, int SB, Grid g, double cinv, const double *__restrict__ pts, const int *__restrict__ cell_of,
+                                  const int *__restrict__ start, const int *__restrict__ sorted, unsigned long long *__restrict__ mind2)
+{
+    __shared__ double sh[256];
+    const int s = blockIdx.z, b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    const size_t sb = (size_t)s * SB + b, t = sb * N + i;
+    double m = INFINITY;
+    const int c = i < N ? cell_of[t] : -1;
+    if (c >= 0) {
+        const int ncell = g.nx * g.ny * g.nz;
+        const int ix = c % g.nx, iy = (c / g.nx) % g.ny, iz = c / (g.nx * g.ny);
+        const double xi = pts[3 * t], yi = pts[3 * t + 1], zi = pts[3 * t + 2];
+        const int *st = start + sb * (ncell + 1), *so = sorted + sb * N;
+        const double *pp = pts + sb * (size_t)N * 3;
+        const int x_lo = ix > 0 ? ix - 1 : 0, x_hi = ix + 1 < g.nx ? ix + 1 : g.nx - 1;
+        for (int dz = -1; dz <= 1; ++dz) {
+            const int z = iz + dz;
+            if (z < 0 || z >= g.nz) continue;
+            for (int dy = -1; dy <= 1; ++dy) {
+                const int yy = iy + dy;
+                if (yy < 0 || yy >= g.ny) continue;
+                const int base = g.nx * (yy + g.ny * z);
+                const int e0 = st[base + x_lo], e1 = st[base + x_hi + 1];   // x is the fastest cell index: three cells = one run
+                for (int e = e0; e < e1; ++e) {
+                    const int j = so[e];
+                    if (j <= i) continue;
+                    m = fmin(m, pair_d2(xi, yi, zi, pp[3 * j], pp[3 * j + 1], pp[3 * j + 2], cinv));
+                }
+            }
+        }
+    }
+    m = block_min(m, sh);
+    if (threadIdx.x == 0 && m < INFINITY) atomicMin(&mind2[s], (unsigned long long)__double_as_longlong(m));
+}
+// brute force over the positions of a batch (fallback of the grid search: scenes without any pair closer than `edge`):
+// block = (tile of 256 agents i, sample, scene); the tiles of j >= tile(i) stream through LDS
+__global__ void pairs_brute_pts_kernel(int N, int SB, double cinv, const double *__restrict__ pts, const int *__restrict__ cell_of,
+                                       const int *__restrict__ scene_on, unsigned long long *__restrict__ mind2)
+{
+    __shared__ double tile[256 * 3];
+    __shared__ double sh[256];
+    const int s = blockIdx.z, b = blockIdx.y, it = blockIdx.x;
+    if (!scene_on[s]) return;
+    const size_t sb = (size_t)s * SB + b;
+    if (cell_of[sb * N] < 0) return;   // sample beyond the end of this scene's transition
+    const double *pp = pts + sb * (size_t)N * 3;
+    const int i = it * 256 + threadIdx.x;
+    const bool vi = i < N;
+    const double xi = vi ? pp[3 * i] : 0.0, yi = vi ? pp[3 * i + 1] : 0.0, zi = vi ? pp[3 * i + 2] : 0.0;
+    double m = INFINITY;
+    for (int jt = it; jt * 256 < N; ++jt) {
+        const int j0 = jt * 256, cntj = N - j0 < 256 ? N - j0 : 256;
+        __syncthreads();
+        for (int e = threadIdx.x; e < cntj * 3; e += 256) tile[e] = pp[3 * (size_t)j0 + e];
+        __syncthreads();
+        if (vi)
+            for (int jj = 0; jj < cntj; ++jj) {
+                if (j0 + jj <= i) continue;
+                m = fmin(m, pair_d2(xi, yi, zi, tile[3 * jj], tile[3 * jj + 1], tile[3 * jj + 2], cinv));
+            }
     }
     m = block_min(m, sh);
     if (threadIdx.x == 0 && m < INFINITY) atomicMin(&mind2[s], (unsigned long long)__double_as_longlong(m));

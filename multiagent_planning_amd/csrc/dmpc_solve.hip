@@ -73,6 +73,14 @@ __device__ __forceinline__ double wave_sum0(double v)
     v += dpp0_d<0x142>(v); v += dpp0_d<0x143>(v);
     return readlane_d(v, 63);
 }
+// inclusive prefix sum over the lanes (lane j: v_0 + ... + v_j), the gfx9 DPP scan: row_shr 1/2/4/8 inside the 16-lane rows, then
+// the two row broadcasts (rows 1 and 3 take row 0's / row 2's total, rows 2 and 3 the total of the lower half).  Fixed order.
+__device__ __forceinline__ double wave_scan_sum(double v)
+{
+    v += dpp_d<0x111, 0xf>(0.0, v); v += dpp_d<0x112, 0xf>(0.0, v); v += dpp_d<0x114, 0xf>(0.0, v); v += dpp_d<0x118, 0xf>(0.0, v);
+    v += dpp_d<0x142, 0xa>(0.0, v); v += dpp_d<0x143, 0xc>(0.0, v);
+    return v;
+}
 // v_max_f64 without the canonicalising self-maximum the compiler puts in front of fmax() (inputs are never NaN here)
 __device__ __forceinline__ double max_raw(double a, double b)
 {
@@ -162,14 +170,34 @@ __device__ __forceinline__ void remove_slot2(double *B, int lane, int &q, int l,
         const unsigned long long lo = cm & ((1ull << l) - 1ull), hi = (cm >> (l + 1)) << l;
         cm = lo | hi;
     }
+    // The rotation of step j is fixed by row l alone: (a_j, b_j) = (current left column, column j+1) at row l, and the left
+    // column's entry after the rotation is sqrt(a_j^2 + b_j^2) = a_(j+1).  So a_j^2 is a running sum of squares of ORIGINAL
+    // entries of row l -- one wave prefix sum gives every rotation at once (lane j: cosine b_j / |.|, sine a_j / |.|), and
+    // the column sweep below carries only two multiply-adds per step on its dependent path (it used to read a_j, b_j out of
+    // the updated column and take a reciprocal square root per step: 150+ dependent cycles x the columns right of l, 18 % of a
+    // long solve).
+    {
+        const bool act = lane >= l && lane <= q - 2;
+        const double bj = act ? T[tcol(lane + 1) + l] : 0.0;
+        const double al = T[tcol(l) + l];
+        double val = bj * bj;
+        if (lane == l) val = fma(al, al, val);
+        const double Sj = wave_scan_sum(val);   // lane j: a_l^2 + b_l^2 + ... + b_j^2
+        B[SL::XS + lane] = Sj;
+        LSYNC();
+        // a_l is the diagonal entry as it stands (earlier rotations may have left it negative); every later a_j is a norm
+        const double aj = (lane == l) ? al : sqrt(B[SL::XS + (lane > 0 ? lane - 1 : 0)]);
+        double cc = 1.0, ss = 0.0;
+        if (Sj > 1e-300) { const double inv = rsqrt(Sj); cc = bj * inv; ss = aj * inv; }
+        LSYNC();
+        B[SL::XS + lane] = cc; B[SL::RR + lane] = ss;
+        LSYNC();
+    }
     double carry = (lane <= l) ? T[tcol(l) + lane] : 0.0;
     double right = (q - 1 > l && lane <= l + 1) ? T[tcol(l + 1) + lane] : 0.0;
     for (int j = l; j < q - 1; ++j) {
         const double next = (j + 2 < q && lane <= j + 2) ? T[tcol(j + 2) + lane] : 0.0;
-        const double a_ = readlane_d(carry, l), b_ = readlane_d(right, l);
-        const double n2 = a_ * a_ + b_ * b_;
-        double cc = 1.0, ss = 0.0;
-        if (n2 > 1e-300) { const double inv = rsqrt(n2); cc = b_ * inv; ss = a_ * inv; }
+        const double cc = B[SL::XS + j], ss = B[SL::RR + j];
         const double nl = cc * carry - ss * right;
         const double nr_ = ss * carry + cc * right;
         if (lane <= j + 1 && lane != l) T[tcol(j) + (lane < l ? lane : lane - 1)] = nl;
@@ -196,12 +224,52 @@ __device__ __forceinline__ void remove_slot2(double *B, int lane, int &q, int l,
     LSYNC();
 }
 
-// `bidx`: the workgroup's index (one-agent-per-workgroup launches, renumbered XCD-aware here) or the queue position a
-// persistent wave just claimed; `smem`: this wave's LDS; `shtab`: the workgroup-shared tables (persistent form).
+// Closed loops, tiny launches: the work of post_step_kernel for one agent (dmpc_soft_bound.m:132-134, the history column,
+// ReachedGoal.m:3-11), done by the wave that produced the agent's step; p_out, v_out, a_out: lanes 0..2 hold the first horizon column.
+// The scene's maximum / OR / count are order-independent, so which wave finishes last changes nothing.
+__device__ __forceinline__ void post_step_part(const StepParams &Q, const int lane, const int gid, const int scene, const bool solved,
+                                               const int status, const double p_out, const double v_out, const double a_out)
+{
+    {
+        double xn = 0.0, vn = 0.0, an = 0.0, e2 = 0.0;
+        if (lane < 3) {
+            const size_t b = (size_t)gid * 3 + lane;
+            xn = solved ? p_out : Q.post_xp[b]; vn = solved ? v_out : Q.post_xv[b]; an = solved ? a_out : Q.post_xa[b];
+            if (solved) { Q.post_xp[b] = xn; Q.post_xv[b] = vn; Q.post_xa[b] = an; }
+            const size_t ho = ((size_t)gid * Q.post_KT + Q.post_k) * 3 + lane;
+            Q.post_pk[ho] = xn; Q.post_vk[ho] = vn; Q.post_ak[ho] = an;
+            const double dd = xn - Q.pf[b];
+            e2 = dd * dd;
+        }
+        const double dx2 = readlane_d(e2, 0), dy2 = readlane_d(e2, 1), dz2 = readlane_d(e2, 2);
+        if (lane == 0) {
+            const double dist = sqrt(dx2 + dy2 + dz2);
+            atomicMax(Q.post_max + scene, (unsigned long long)__double_as_longlong(dist));
+            atomicOr(Q.post_or + scene, status);
+            __threadfence();
+            if (atomicAdd(Q.post_cnt + scene, 1) == Q.c_count - 1) {   // the scene's last agent of this step
+                const unsigned long long mb = atomicExch(Q.post_max + scene, 0ull);
+                const int orv = atomicExch(Q.post_or + scene, 0);
+                Q.post_cnt[scene] = 0;
+                const int reached = __longlong_as_double((long long)mb) < Q.post_tol ? 1 : 0;
+                Q.post_flags[(size_t)scene * 2] = reached; Q.post_flags[(size_t)scene * 2 + 1] = orv;
+                if (Q.post_done && (reached || (orv & ~ST_SOLVED))) Q.post_done[scene] = 1;
+            }
+        }
+    }
+}
+
+// `bidx`: the workgroup's index (one-agent-per-workgroup launches, renumbered XCD-aware and sent through the launch order
+// here) or -- persistent form -- the AGENT the wave is about to solve (the queue position already resolved through the order:
+// the persistent loop loads it one agent ahead); `smem`: this wave's LDS; `shtab`: the workgroup-shared tables (persistent
+// form); `claim`: queue head the persistent loop wants its next ticket from (or null) -- claimed into `ticket` once every global
+// load of the agent's set-up has been consumed (loads and returning atomics come back in issue order on this part: an atomic
+// issued ahead of the set-up loads would be waited for with the first of them).
 template <bool SOFT, int QCAP, bool PERSIST>
 __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, const int bidx, const int nblocks,
-                                           unsigned char *smem, const double *shtab)
+                                           unsigned char *smem, const double *shtab, int *claim, int &ticket)
 {
+#define after_loads() do { if (PERSIST && claim && lane == 0) ticket = atomicAdd(claim, 1); } while (0)
     using SL = SolveLds<SOFT, QCAP, PERSIST>;
     constexpr bool soft = SOFT;
     const int nrmax = P.nrmax, var = P.variant;
@@ -211,8 +279,8 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
         int off = 0;
         for (int xx = 0; xx < x; ++xx) off += (nb - xx + 7) >> 3;
         vb = off + y;
+        if (P.order) vb = P.order[bidx];   // heaviest agents first (order_kernel) / tier-2 list
     }
-    if (P.order) vb = P.order[bidx];   // heaviest agents first (order_kernel) / tier-2 list
     const int scene = vb / P.c_count, ci = vb - scene * P.c_count;
     const int cl = P.c_first + ci;
     const int gid = scene * P.c_count + ci;
@@ -228,31 +296,55 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
     double *r_sd = soft ? r_b + nrmax : nullptr, *r_st = soft ? r_b + 2 * (size_t)nrmax : nullptr, *r_slb = soft ? r_b + 3 * (size_t)nrmax : nullptr;
     int *r_kc = P.rowkc + (size_t)gid * nrmax;
     int *hdr = P.hdr + (size_t)gid * 8;
-    if (P.only_flagged && !(P.status[gid] & ST_QOVER)) return;   // tier 2: only agents that overflowed tier 1
-    if (hdr[4] & 8) return;                                       // agent of a scene that already stopped
 
-    // ---------------------------------------------------------------- agent state (uniform)
+    // ---------------------------------------------------------------- the global loads of the set-up in two rounds
+    // (hand-off header + agent state, then the register-cached rows, which need the row count: two memory round trips
+    // instead of a chain of four -- header flag, state, row count, rows.  Rows addressed without the count, i.e. reads of
+    // scratch the scan never wrote, were measured slower: those lines come cold from HBM and the whole set-up waits for them.)
+    struct { int x, y, z, w; } h0, h1;   // the scan's hand-off header: 8 ints
+    h0.x = hdr[0]; h0.y = hdr[1]; h0.z = hdr[2]; h0.w = hdr[3]; h1.x = hdr[4]; h1.y = hdr[5]; h1.z = hdr[6]; h1.w = hdr[7];
+    const int stq = P.only_flagged ? P.status[gid] : ST_QOVER;
     double po[3], vo[3], ao[3], pf[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         po[d] = P.x_p[3 * gid + d]; vo[d] = P.x_v[3 * gid + d];
         ao[d] = P.x_a[3 * gid + d]; pf[d] = P.pf[3 * gid + d];
     }
+    if (P.only_flagged && !(stq & ST_QOVER)) { after_loads(); return; }   // tier 2: only agents that overflowed tier 1
+    if (h1.x & 8) { after_loads(); return; }                              // agent of a scene that already stopped
+    if (h1.x & 16) {   // finished by the scan (unconstrained exit): nothing to solve; a fused post-step still takes its outputs
+        after_loads();
+        if (P.post_on) {
+            const StepParams &Q = *kernarg_params();
+            const int st_done = Q.status[gid];
+            double p1 = 0.0, v1 = 0.0, a1 = 0.0;
+            if (lane < 3) { p1 = Q.p_out[(size_t)gid * N3 + lane]; v1 = Q.v_out[(size_t)gid * N3 + lane]; a1 = Q.a_out[(size_t)gid * N3 + lane]; }
+            post_step_part(Q, lane, gid, scene, (st_done & ST_SOLVED) != 0, st_done, p1, v1, a1);
+        }
+        return;
+    }
 
     // the scan's branch record
-    int nr = hdr[0], status = hdr[3];
-    const int nrows_built = hdr[1], viol_k = hdr[2];
-    const bool violation = (hdr[4] & 1) != 0, rows_exist = hdr[5] != 0;
+    int nr = h0.x, status = h0.w;
+    const int nrows_built = h0.y, viol_k = h0.z;
+    const bool violation = (h1.x & 1) != 0, rows_exist = h1.y != 0;
     const bool cppv = (var == VAR_CPP || var == VAR_CPP2);
+    constexpr int RC = soft ? 1 : 2;   // register cache of the first collision rows (RC per lane; the rest is streamed from the L2-resident scratch)
+    double rcx0[2], rcx1[2], rcx2[2], rcb[2], rcsd[2], rcslb[2];
+    float rcw[2];
+    int rckc[2];
+    rcx0[1] = rcx1[1] = rcx2[1] = rcb[1] = rcsd[1] = rcslb[1] = 0.0; rcw[1] = 0.f; rckc[1] = 0;
+#pragma unroll
+    for (int c = 0; c < RC; ++c) {
+        const int i = lane + 64 * c;
+        const int ii = i < nr ? i : 0;
+        rcx0[c] = r_xi[3 * ii]; rcx1[c] = r_xi[3 * ii + 1]; rcx2[c] = r_xi[3 * ii + 2];
+        rcb[c] = r_b[ii]; rckc[c] = r_kc[ii];
+        rcsd[c] = soft ? r_sd[ii] : 0.0; rcslb[c] = soft ? r_slb[ii] : 0.0;
+    }
 
     // ---------------------------------------------------------------- cost case + tables (a7, :43-58)
-    int ccase = 2;
-    {
-        const double dn = sqrt((po[0] - pf[0]) * (po[0] - pf[0]) + (po[1] - pf[1]) * (po[1] - pf[1]) + (po[2] - pf[2]) * (po[2] - pf[2]));
-        const bool far = (var == VAR_ELLIP) ? (dn > 1.0) : (dn >= 1.0);
-        if (!rows_exist && far) ccase = 0;
-        else if (!rows_exist && dn < 1.0) ccase = 1;
-    }
+    const int ccase = cost_case(var, po[0] - pf[0], po[1] - pf[1], po[2] - pf[2], rows_exist);
     const double qw = ccase == 0 ? P.Qfar : (ccase == 1 ? P.Qnear : P.Q1);
     const double sw = ccase == 2 ? ((var == VAR_ALL3) ? 10.0 : P.S1) : P.Sfree;
     const double *G, *Lt;
@@ -274,12 +366,12 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
     // unconstrained minimiser per axis: a_unc = -H1^-1 f,  f = -2(q L_K'(pf - A0_K x0) + s [ao;0..])
     //   => a_unc(k) = 2 q g (H1^-1 L')[k][K-1] + 2 s ao H1^-1[k][0],  g = pf - (po + K h vo)      (:88/:93)
     double a_unc = 0.0, w_unc = 0.0;
-    const double gax = comp ? (sel3(pf, ax_l) - (sel3(po, ax_l) + (double)K * P.h * sel3(vo, ax_l))) : 0.0;
+    const double gax = comp ? goal_gap(sel3(pf, ax_l), sel3(po, ax_l), sel3(vo, ax_l), P.h) : 0.0;
     const double ao_l = comp ? sel3(ao, ax_l) : 0.0;
     if (comp) {
-        a_unc = 2.0 * qw * gax * G[k_l * 30 + 15 + (K - 1)] + 2.0 * sw * ao_l * G[k_l * 30];
+        a_unc = unc_entry(qw, sw, gax, ao_l, G[k_l * 30 + 15 + (K - 1)], G[k_l * 30]);
         // w_unc = Lambda a_unc from the same table
-        w_unc = 2.0 * qw * gax * G[(15 + k_l) * 30 + 15 + (K - 1)] + 2.0 * sw * ao_l * G[(15 + k_l) * 30];
+        w_unc = unc_entry(qw, sw, gax, ao_l, G[(15 + k_l) * 30 + 15 + (K - 1)], G[(15 + k_l) * 30]);
     }
 
     // Dual-bound certificate (slack-free variants): the iterate of the dual method minimises the cost over its working
@@ -300,34 +392,24 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
     }
 
     // per-lane constants of component (k_l, ax_l)
-    double whi_l = 0.0, wlo_l = 0.0;
+    double whi_l = 0.0, wlo_l = 0.0, p0_l = 0.0, vo_l = 0.0;
     float wbox_f = 0.f, wpos_f = 0.f;
     if (comp) {
         const double sh = (double)(k_l + 1) * P.h * sel3(vo, ax_l);   // A_initp(k,:) [po;vo] - po
+        vo_l = sel3(vo, ax_l);
+        p0_l = init_pos(k_l, P.h, vo_l, sel3(po, ax_l));               // A_initp(k,:) [po;vo]
         whi_l = sel3(P.pmax, ax_l) - sel3(po, ax_l) - sh;        // pmax - A0 x0  (:72)
         wlo_l = sel3(P.pmin, ax_l) - sel3(po, ax_l) - sh;
         // pivot weights: the entering constraint is the one farthest from feasibility in the metric of the problem,
         // violation / |n|_{H^-1} (compared in fp32: the choice only orders the pivots)
         wbox_f = (float)rsqrt(G[k_l * 31]); wpos_f = (float)rsqrt(G[(15 + k_l) * 31]);
     }
-    // Register cache of the first collision rows (RC per lane; the rest is streamed from the L2-resident scratch)
-    constexpr int RC = soft ? 1 : 2;
-    double rcx0[2], rcx1[2], rcx2[2], rcb[2], rcsd[2], rcslb[2];
-    float rcw[2];
-    int rckc[2];
-    rcx0[1] = rcx1[1] = rcx2[1] = rcb[1] = rcsd[1] = rcslb[1] = 0.0; rcw[1] = 0.f; rckc[1] = 0;
     auto row_weight = [&](double x0, double x1, double x2, int kc, double sd) -> float {
         return (float)rsqrt(G[(15 + kc) * 31] * (x0 * x0 + x1 * x1 + x2 * x2) + (soft ? 0.5 * sd * sd : 0.0));
     };
 #pragma unroll
-    for (int c = 0; c < RC; ++c) {
-        const int i = lane + 64 * c;
-        const int ii = i < nr ? i : 0;
-        rcx0[c] = r_xi[3 * ii]; rcx1[c] = r_xi[3 * ii + 1]; rcx2[c] = r_xi[3 * ii + 2];
-        rcb[c] = r_b[ii]; rckc[c] = r_kc[ii];
-        rcsd[c] = soft ? r_sd[ii] : 0.0; rcslb[c] = soft ? r_slb[ii] : 0.0;
-        rcw[c] = row_weight(rcx0[c], rcx1[c], rcx2[c], rckc[c], rcsd[c]);
-    }
+    for (int c = 0; c < RC; ++c) rcw[c] = row_weight(rcx0[c], rcx1[c], rcx2[c], rckc[c], rcsd[c]);
+    after_loads();
 
     // ---------------------------------------------------------------- a7: dual active-set solve
     const bool ladder = soft && (var == VAR_BOUND || var == VAR_BOUND2 || var == VAR_ALL3 || cppv);
@@ -338,10 +420,21 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
     // A first-tier launch that runs out of working-set slots hands the agent over UNTOUCHED (its row scalings undone, nothing
     // recorded): the second tier repeats the whole solve, on the path an uninterrupted solve takes -- the result of an agent
     // must not depend on how deep the launch was that it ran in.
-    int tries = hdr[6], iters_total = 0, maxq = 0, q = 0;
+    int tries = h1.z, iters_total = 0, maxq = 0, q = 0;
     int scale_pow = 0;   // the rows' slack bound and penalty currently carry the factor 2^scale_pow
 #ifdef DMPC_DEV_TRACE
     int dev_nfast = 0, dev_rounds = 0, dev_negdrops = 0;
+    // development: cycles of the traced agent by phase (s_memtime): 0 pivot scan, 1 pivot descriptor + pin, 2 s / T's / T T's,
+    // 3 residual + direction + delta, 4 ratio test + step + append, 5 drops, 6 verification / refinement, 7 ladder certificate +
+    // ladder step, 8 set-up; counts: 10 verifications, 11 drops, 12 certificate calls
+    long long phv[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long ph_last = __builtin_amdgcn_s_memtime();
+    const bool ph_on = P.dbg && gid == P.dbg_agent;
+#define PH(i_) do { const long long t__ = __builtin_amdgcn_s_memtime(); if (ph_on) phv[i_] += t__ - ph_last; ph_last = t__; } while (0)
+#define PHC(i_) do { if (ph_on) phv[i_] += 1; } while (0)
+#else
+#define PH(i_) do { } while (0)
+#define PHC(i_) do { } while (0)
 #endif
     bool solved = false;
     double a = 0.0, w = 0.0;
@@ -374,6 +467,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
         // refinement pass, drops those that come out negative (the finish of the crash start) and continues from there.
         bool warm = false;
         double cond_min = 1.0;
+        PH(8);
         while (tries < max_tries) {
             tries++;
             int rc = 0;   // 0 running/ok, 1 infeasible, 2 capacity, 3 itercap
@@ -416,13 +510,21 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                     const double fp = (cslot & 0x40000u) ? -1.0 : ((cslot & 0x80000u) ? 1.0 : 0.0);
                     const double U = fma(fb, rb, pU);
                     double Y = fma(fp, rp, pY);
+                    // (four collision slots per round: the eight LDS reads of a round are in flight together; solveSoftDMPCbound puts all
+                    // rows on ONE horizon step, whose three lanes then walk every collision slot of the working set here)
                     unsigned long long m = cm;
                     while (__any(m != 0ull)) {
-                        const bool have = m != 0ull;
-                        const int j = have ? (__ffsll((long long)m) - 1) : 0;
-                        const double rj = B[SL::RR + j], vj = B[SL::SVEC + 3 * j + ax_l];
-                        Y -= have ? rj * vj : 0.0;
-                        m &= m - 1ull;
+                        int jj[4]; bool hv[4]; double rj[4], vj[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            hv[u] = m != 0ull;
+                            jj[u] = hv[u] ? (__ffsll((long long)m) - 1) : 0;
+                            m &= m - 1ull;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { rj[u] = B[SL::RR + jj[u]]; vj[u] = B[SL::SVEC + 3 * jj[u] + ax_l]; }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) Y = hv[u] ? fma(-rj[u], vj[u], Y) : Y;
                     }
                     B[SL::Y + lane] = Y;
                     LSYNC();
@@ -552,7 +654,10 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
             for (;;) {
                 if (soft && ladder && violation && !cert_done && iters - nfast >= LADDER_CERT_AFTER) {
                     cert_done = true;
-                    if (ladder_level_infeasible(r_xi, r_b, r_sd, r_slb, r_kc, nr, B + SL::RR, P.h, P.alim, 1.0, whi_l, wlo_l, lane)) { rc = 1; break; }
+                    PH(4); PHC(12);
+                    const bool cert_inf = ladder_level_infeasible(r_xi, r_b, r_sd, r_slb, r_kc, nr, B + SL::RR, P.h, P.alim, 1.0, whi_l, wlo_l, lane);
+                    PH(7);
+                    if (cert_inf) { rc = 1; break; }
                 }
                 // ---- most violated constraint not in the working set (score = violation / |n|_{H^-1}, fp32)
                 double bestv = 0.0; float bests = 0.f; int bestc = -1;
@@ -601,7 +706,9 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
 #undef CAND
                 const float smax = wave_max_f(bests);
                 const unsigned long long wm = __ballot(bestc >= 0 && bests == smax);
+                PH(0);
                 if (wm == 0ull) {
+                    PHC(10);
                     if (!crash && (q == 0 || fresh)) break;   // optimal
                     if (!crash && !soft) {
                         // (slack-free variants; the slack variants carry multipliers of 1e5-1e6 and always take the full verification)
@@ -655,6 +762,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                             dev_negdrops++;
 #endif
                             crash_stop = true; fresh = false;
+                            PH(6);
                             continue;
                         }
                         if (was_fresh || crash_stop || ++crash_rounds >= 8) {
@@ -663,6 +771,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                         }
                     }
                     fresh = true;
+                    PH(6);
                     continue;
                 }
                 fresh = false;
@@ -707,6 +816,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                     q++;
                     LSYNC();
                 }
+                PH(1);
                 double lam_p = 0.0;
                 // n_p' H^-1 n_p
                 const double spp = G[p.gi * 31] * (p.v0 * p.v0 + p.v1 * p.v1 + p.v2 * p.v2) + ((soft && p.si >= 0) ? 0.5 * p.ss * p.ss : 0.0);
@@ -714,6 +824,15 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                 // ---- inner loop: partial steps until p can be added
                 for (;;) {
                     if (++iters > P.iter_cap) { rc = 3; break; }
+                    // An agent that has already taken many iterations is a long one, and the launch ends with the longest: its wave
+                    // gets issue priority over the wave it shares the SIMD with (which works through light agents and fills the slots
+                    // the long dependent chains of this one leave).  Scheduling only.
+                    {
+                        const int itall = iters_total + iters;
+                        if (itall == 6) __builtin_amdgcn_s_setprio(1);
+                        else if (itall == 20) __builtin_amdgcn_s_setprio(2);
+                        else if (itall == 40) __builtin_amdgcn_s_setprio(3);
+                    }
                     // s = N_W' H^-1 n_p on the slot lanes
                     double sv = 0.0;
                     int mymeta = 0;
@@ -732,6 +851,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                     B[SL::RR + lane] = dvj; LSYNC();
                     const double ri = t_mul2<QCAP, SL::T, SL::RR>(B, lane, q);
                     LSYNC();
+                    PH(2);
                     if (crash) {   // append without a step: column [-r/rho; 1/rho] with rho^2 = s_pp - |T's|^2, lambda_p = 0 until the batch is solved
                         const double dlt = spp - wave_sum0(dvj * dvj);
                         if (!(dlt > 1e-9 * spp)) { crash_stop = true; break; }   // (distinct bounds are independent; guard only)
@@ -778,6 +898,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                         if (p.si >= 0 && !p_row_has_slot && lane == 63) part += 0.5 * p.ss * p.ss;
                     }
                     const double delta = wave_sum0(part);
+                    PH(3);
                     // more active constraints than variables is impossible: whatever round-off says, a constraint picked when
                     // the working set already spans all 45 + nlive variables is dependent
                     const bool dependent = !(delta > 1e-13 * spp) || q >= N3 + nlive;
@@ -842,13 +963,16 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                         q++;
                         if (q > maxq) maxq = q;
                         LSYNC();
+                        PH(4);
                         break;
                     }
+                    PH(4); PHC(11);
                     // partial step: drop the blocking constraint
                     const unsigned long long bm = __ballot(lane < q && ri > 0.0 && iratio == imax);
                     const int l = __ffsll((long long)bm) - 1;
                     drop_slot(l, (p.ty == TY_COLL) ? p.idx : -1);
                     LSYNC();
+                    PH(5);
                 }
                 if (rc) break;
                 // pin added while its collision row is not active: decoupled again -> drop both
@@ -862,6 +986,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                     nlive--;
                 }
                 if (((++since_sync) & 31) == 0) primal_fast();   // periodic re-sync with x(lambda)
+                PH(4);
             }
             iters_total += iters;
 #ifdef DMPC_DEV_TRACE
@@ -882,6 +1007,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
             if (rc == 3) { status |= ST_ITERCAP; break; }
             // infeasible: retry ladder (solveSoftDMPCbound.m:147-153): lb_eps *= 2, term *= 2
             if (soft && ladder && violation) {
+                PH(4);
                 double f = 2.0;
                 while (tries < max_tries - 1 &&
                        ladder_level_infeasible(r_xi, r_b, r_sd, r_slb, r_kc, nr, B + SL::RR, P.h, P.alim, f, whi_l, wlo_l, lane)) { f *= 2.0; ++tries; }
@@ -898,6 +1024,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 LSYNC();
+                PH(7);
                 continue;
             }
             if (ladder || var == VAR_REPAIR) tries = (var == VAR_REPAIR && P.max_tries <= 0) ? 10 : max_tries;
@@ -909,6 +1036,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
     // ---------------------------------------------------------------- a9/a10: propagate, outputs
     // The launch parameters the output stage needs are read again from the kernel-argument segment (scalar loads through an
     // opaque pointer) instead of staying live in SGPRs across the solver loop, where they were spilled to VGPR lanes.
+    __builtin_amdgcn_s_setprio(0);
     const StepParams &Q = *kernarg_params();
     int nslack = 0;
     if (solved) {
@@ -921,20 +1049,15 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
     }
     double p_out = 0.0, v_out = 0.0, a_out = 0.0;
     if (solved && comp) {
-        // p = A_p a + A_initp [po;vo] ; v = A_v a + vo   (propStatedmpc.m:3-4); the state is read again here instead of
-        // being kept in registers across the solve
-        const double po_l = Q.x_p[3 * gid + ax_l], vo_l = Q.x_v[3 * gid + ax_l];
-        const double p0_l = po_l + (double)(k_l + 1) * Q.h * vo_l;   // A_initp(k,:) [po;vo]
+        // p = A_p a + A_initp [po;vo] ; v = A_v a + vo   (propStatedmpc.m:3-4); p0_l, vo_l: per-lane copies kept from the set-up
+        // (the uniform state would cost a dozen SGPRs across the solver loop, a second read a memory round trip here)
         p_out = w + p0_l;
-        double sv = 0.0;
-#pragma unroll
-        for (int kk = 0; kk < K; ++kk) { const double ak = B[SL::A + 3 * kk + ax_l]; sv += (kk <= k_l) ? ak : 0.0; }
-        v_out = Q.h * sv + vo_l;
+        v_out = vel_out(B + SL::A, k_l, ax_l, Q.h, vo_l);
         a_out = a;
     }
     if (solved) {
         const bool ob_check = !(var == VAR_ELLIP || var == VAR_SOFTALL || cppv);   // solveQPv2 has no in-bounds test
-        if (hdr[4] & 4) status |= ST_COLL;   // cpp: collision noticed at the first step, solution still returned
+        if (h1.x & 4) status |= ST_COLL;   // cpp: collision noticed at the first step, solution still returned
         if (ob_check) {   // is_inbounds.m:2-5 on p(:,1)
             const double tolb = 50e-3;
             bool bad = false;
@@ -954,35 +1077,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
             Q.lT_next[(size_t)scene * N3 * Cq + cl + (size_t)(unsigned)(lane * Cq)] = solved ? p_out : own[(size_t)(unsigned)(lane * Cq)];
         }
     }
-    if (Q.post_on) {
-        // the work of post_step_kernel for this agent (dmpc_soft_bound.m:132-134, the history column, ReachedGoal.m:3-11); the scene's
-        // maximum / OR / count are order-independent, so which wave finishes last changes nothing
-        double xn = 0.0, vn = 0.0, an = 0.0, e2 = 0.0;
-        if (lane < 3) {
-            const size_t b = (size_t)gid * 3 + lane;
-            xn = solved ? p_out : Q.post_xp[b]; vn = solved ? v_out : Q.post_xv[b]; an = solved ? a_out : Q.post_xa[b];
-            if (solved) { Q.post_xp[b] = xn; Q.post_xv[b] = vn; Q.post_xa[b] = an; }
-            const size_t ho = ((size_t)gid * Q.post_KT + Q.post_k) * 3 + lane;
-            Q.post_pk[ho] = xn; Q.post_vk[ho] = vn; Q.post_ak[ho] = an;
-            const double dd = xn - Q.pf[b];
-            e2 = dd * dd;
-        }
-        const double dx2 = readlane_d(e2, 0), dy2 = readlane_d(e2, 1), dz2 = readlane_d(e2, 2);
-        if (lane == 0) {
-            const double dist = sqrt(dx2 + dy2 + dz2);
-            atomicMax(Q.post_max + scene, (unsigned long long)__double_as_longlong(dist));
-            atomicOr(Q.post_or + scene, status);
-            __threadfence();
-            if (atomicAdd(Q.post_cnt + scene, 1) == Q.c_count - 1) {   // the scene's last agent of this step
-                const unsigned long long mb = atomicExch(Q.post_max + scene, 0ull);
-                const int orv = atomicExch(Q.post_or + scene, 0);
-                Q.post_cnt[scene] = 0;
-                const int reached = __longlong_as_double((long long)mb) < Q.post_tol ? 1 : 0;
-                Q.post_flags[(size_t)scene * 2] = reached; Q.post_flags[(size_t)scene * 2 + 1] = orv;
-                if (Q.post_done && (reached || (orv & ~ST_SOLVED))) Q.post_done[scene] = 1;
-            }
-        }
-    }
+    if (Q.post_on) post_step_part(Q, lane, gid, scene, solved, status, p_out, v_out, a_out);
     if (lane == 0) {
         Q.status[gid] = status;
         if (Q.info) {
@@ -990,8 +1085,14 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
             inf[0] = viol_k; inf[1] = nrows_built; inf[2] = tries; inf[3] = ccase;
             inf[4] = iters_total; inf[5] = nslack; inf[6] = solved ? q : 0; inf[7] = maxq;
 #ifdef DMPC_DEV_TRACE
+            if (ph_on && Q.dbg_cap >= 4) {
+                PH(9 > 8 ? 4 : 4);
+                double *d = Q.dbg + (size_t)(Q.dbg_cap - 2) * 8;
+                for (int u = 0; u < 13; ++u) d[u] = (double)phv[u];
+            }
             if (Q.dbg_agent == -4) { inf[0] = dev_nfast; inf[1] = dev_rounds; inf[3] = dev_negdrops; }   // development: crash statistics in place of the branch record
 #endif
         }
     }
 }
+#undef after_loads

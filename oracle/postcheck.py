@@ -36,17 +36,40 @@ def rescale(pk, vk, ak, r_factor, h_scaled):
     return pk, vk, ak
 
 
-def interp_check(pk, h_scaled, pf, rmin, c, Ts=0.01):
-    """failure_rate.m:165-194 on rescaled knots pk [N,KT,3]."""
+def min_dist_tree(p, c):
+    """The minimum of failure_rate.m:170-181 over all pairs and samples WITHOUT the O(N^2) loop: per sample a k-d tree on the
+    scaled points E1 p (scipy.spatial.cKDTree, nearest other point of every point).  Same quantity by an unrelated method --
+    what the large-scene tests compare the device's cell-grid search with (checked against the literal loop on small scenes,
+    tests/test_oracle_golden.py)."""
+    from scipy.spatial import cKDTree
+    e1 = np.array([1.0, 1.0, 1.0 / c])
+    best = np.inf
+    if p.shape[0] < 2:
+        return best
+    for s in range(p.shape[1]):
+        q = p[:, s, :] * e1
+        d, _ = cKDTree(q).query(q, k=2)
+        best = min(best, float(d[:, 1].min()))
+    return best
+
+
+def interp_check(pk, h_scaled, pf, rmin, c, Ts=0.01, pairs="literal"):
+    """failure_rate.m:165-194 on rescaled knots pk [N,KT,3].  pairs="tree": the pairwise minimum by min_dist_tree (large scenes)."""
     N, KT, _ = pk.shape
     tk, t = sample_times(KT, h_scaled, Ts)
-    p = np.stack([CubicSpline(tk, pk[i], axis=0, bc_type="not-a-knot")(t) for i in range(N)])   # [N, ns, 3]  (:165)
+    if KT >= 4:
+        p = np.moveaxis(CubicSpline(tk, np.moveaxis(pk, 1, 0), axis=0, bc_type="not-a-knot")(t), 0, 1)   # [N, ns, 3]  (:165)
+    else:
+        p = np.stack([CubicSpline(tk, pk[i], axis=0, bc_type="not-a-knot")(t) for i in range(N)])
     e1 = np.array([1.0, 1.0, 1.0 / c])
     min_dist = np.inf
-    for i in range(N):                                      # :170-181
-        d = np.sqrt((((p[i][None] - p) * e1) ** 2).sum(-1))
-        d[i] = np.inf
-        min_dist = min(min_dist, d.min())
+    if pairs == "tree":
+        min_dist = min_dist_tree(p, c)
+    else:
+        for i in range(N):                                      # :170-181
+            d = np.sqrt((((p[i][None] - p) * e1) ** 2).sum(-1))
+            d[i] = np.inf
+            min_dist = min(min_dist, d.min())
     totdist = float(np.sqrt((np.diff(p, axis=1) ** 2).sum(-1)).sum())   # :183
     dist_goal = np.sqrt(((p - np.asarray(pf)[:, None, :]) ** 2).sum(-1))   # :186-187
     time_index = np.zeros(N, dtype=int)
@@ -57,12 +80,12 @@ def interp_check(pk, h_scaled, pf, rmin, c, Ts=0.01):
                 traj_time=float(time_index.max() * Ts), n_samples=len(t), p=p)
 
 
-def postcheck(pk, vk, ak, pf, h, rmin, c, vmax=2.0, amax=1.0, Ts=0.01):
+def postcheck(pk, vk, ak, pf, h, rmin, c, vmax=2.0, amax=1.0, Ts=0.01, pairs="literal"):
     """pk, vk, ak: [N, KT, 3] un-rescaled MPC histories of ONE scene (columns 1..k-1 of the .m arrays);
     pf: [N,3].  Returns dict(r_factor, h_scaled, violation, min_dist, totdist, traj_time, n_samples, p, pk)."""
     r_factor, _, _ = scale_factor(vk, ak, vmax, amax)
     h_scaled = h / np.sqrt(r_factor)                        # :146
     pk2, vk2, ak2 = rescale(pk, vk, ak, r_factor, h_scaled)
-    out = interp_check(pk2, h_scaled, pf, rmin, c, Ts)
+    out = interp_check(pk2, h_scaled, pf, rmin, c, Ts, pairs)
     out.update(r_factor=float(r_factor), h_scaled=float(h_scaled), pk=pk2, vk=vk2, ak=ak2)
     return out

@@ -192,3 +192,91 @@ def test_run_trial_without_history_download_gives_the_same_outcomes():
     assert b["pk"] is None and a["pk"] is not None
     for k in ("K_T_used", "scene_status", "success", "feasible", "violation", "totdist", "traj_time", "r_factor"):
         assert np.array_equal(a[k], b[k], equal_nan=True), k
+
+
+# ---- large scenes: the cell-grid search (N > 256; failure_rate.m:170-181 is O(N^2) per sample) -------------------------------
+
+def _swarm_hist(rng, N, KT, side, speed=1.0):
+    """N agents spread over a cube of the given side (C4 density at side = N^(1/3)), smooth random motion for KT knots"""
+    a = rng.uniform(-1, 1, (N, KT, 3)) * speed
+    a[:, 0] = 0
+    v = np.zeros_like(a); p = np.zeros_like(a)
+    m = int(np.ceil(N ** (1.0 / 3.0)))     # jittered lattice: no two starts closer than 0.6 lattice steps
+    g = np.stack(np.meshgrid(*[np.arange(m)] * 3, indexing="ij"), -1).reshape(-1, 3)[rng.permutation(m ** 3)[:N]]
+    p[:, 0] = (g + 0.5 + rng.uniform(-0.2, 0.2, (N, 3))) * (side / m) + (-side / 2, -side / 2, 0.2)
+    for k in range(1, KT):
+        v[:, k] = v[:, k - 1] + 0.2 * a[:, k]
+        p[:, k] = p[:, k - 1] + 0.2 * v[:, k - 1] + 0.02 * a[:, k]
+    return p, v, a
+
+
+def _kw_for(N):
+    s = N ** (1.0 / 3.0)
+    return dict(KW, pmin=(-s / 2, -s / 2, 0.2), pmax=(s / 2, s / 2, s + 0.2))
+
+
+@pytest.mark.parametrize("N,KT", [(300, 9), (1000, 7), (10000, 5)])
+def test_postcheck_large_scene_grid_vs_oracle(N, KT):
+    """N = 10^3 and 10^4 (BASELINE configs C3/C4 sizes): min_dist / violation of the device's cell-grid search against the
+    oracle's k-d-tree search (oracle/postcheck.py: min_dist_tree, itself checked against the literal pair loop), everything else
+    against the literal restatement; then a planted near-miss and a planted collision between two far-apart indices."""
+    rng = np.random.default_rng(100 + N)
+    kw = _kw_for(N)
+    p, v, a = _swarm_hist(rng, N, KT, N ** (1.0 / 3.0))
+    pf = p[:, -1] + rng.normal(0, 0.02, (N, 3))
+    d = mp.Dmpc("bound", **kw)
+    for plant in (None, 0.31, 0.2):
+        if plant is not None:   # agent N-1 flies next to agent 3: same history, offset `plant` along x (ellipsoidal distance = plant)
+            p[N - 1] = p[3] + (plant, 0, 0); v[N - 1] = v[3]; a[N - 1] = a[3]
+        out = d.postcheck([KT], pf, p, v, a)
+        ref = PC.postcheck(p, v, a, pf, kw["h"], kw["rmin"], kw["c"], pairs="tree")
+        assert abs(out["min_dist"][0] - ref["min_dist"]) <= 1e-10, (N, plant, out["min_dist"][0], ref["min_dist"])
+        assert out["violation"][0] == ref["violation"]
+        assert out["n_samples"][0] == ref["n_samples"] and abs(out["r_factor"][0] - ref["r_factor"]) <= 1e-13 * ref["r_factor"]
+        assert abs(out["totdist"][0] - ref["totdist"]) <= 1e-10 * ref["totdist"]
+        assert out["traj_time"][0] == pytest.approx(ref["traj_time"], abs=1e-12)
+        if plant is not None:   # (the planted pair keeps its offset at every sample; some other pair may come closer still)
+            assert out["min_dist"][0] <= plant + 1e-9
+            if plant < kw["rmin"] - 0.05:
+                assert out["violation"][0] == 1
+
+
+def test_postcheck_grid_equals_brute_force_bit_for_bit():
+    """the same scene through the brute-force search (N <= 256: two half scenes padded apart) and through the grid (N = 400):
+    the pair that realises the minimum lies in one half, so both searches must return the SAME double"""
+    rng = np.random.default_rng(77)
+    KT = 8
+    kw = dict(KW, pmin=(-4, -4, 0.2), pmax=(12, 4, 4.2))
+    pA, vA, aA = _swarm_hist(rng, 200, KT, 2.5)
+    pB, vB, aB = _swarm_hist(rng, 200, KT, 2.5)
+    pB = pB + (8.0, 0, 0)                      # the halves never come near each other
+    d = mp.Dmpc("bound", **kw)
+    p, v, a = (np.concatenate(x) for x in ((pA, pB), (vA, vB), (aA, aB)))
+    whole = d.postcheck([KT], p[:, -1], p, v, a)
+    # the halves alone: r_factor differs per scene, so give each half the whole scene's limits by rescaling against the same extreme agent
+    halves = []
+    for q, w, b in ((pA, vA, aA), (pB, vB, aB)):
+        # append the globally extreme agent far away so that r_factor (a min over the scene) is the whole scene's
+        rf_agent = int(np.argmin(np.minimum(1.0 / np.sqrt((a ** 2).sum(-1) + 1e-300), 2.0 / np.sqrt((v ** 2).sum(-1) + 1e-300)).min(1)))
+        qq = np.concatenate((q, p[rf_agent:rf_agent + 1] + (0, 30.0, 0))); ww = np.concatenate((w, v[rf_agent:rf_agent + 1])); bb = np.concatenate((b, a[rf_agent:rf_agent + 1]))
+        halves.append(d.postcheck([KT], qq[:, -1], qq, ww, bb))
+    assert halves[0]["r_factor"][0] == whole["r_factor"][0] == halves[1]["r_factor"][0]
+    assert min(halves[0]["min_dist"][0], halves[1]["min_dist"][0]) == whole["min_dist"][0]
+
+
+def test_postcheck_sparse_large_scene_falls_back_to_brute_force():
+    """no pair within the grid's cell edge (2 rmin): 'no violation' is proven by the grid, the exact min_dist comes from the
+    brute-force pass over the same sample batches"""
+    N, KT = 343, 6
+    g = np.stack(np.meshgrid(*[np.arange(7) * 3.0] * 3, indexing="ij"), -1).reshape(-1, 3) + (-9.0, -9.0, 0.5)
+    rng = np.random.default_rng(9)
+    a = rng.uniform(-1, 1, (N, KT, 3)) * 0.5; a[:, 0] = 0
+    v = np.zeros_like(a); p = np.zeros_like(a); p[:, 0] = g
+    for k in range(1, KT):
+        v[:, k] = v[:, k - 1] + 0.2 * a[:, k]
+        p[:, k] = p[:, k - 1] + 0.2 * v[:, k - 1] + 0.02 * a[:, k]
+    kw = dict(KW, pmin=(-10, -10, 0.2), pmax=(10, 10, 20.0))
+    out = mp.Dmpc("bound", **kw).postcheck([KT], p[:, -1], p, v, a)
+    ref = PC.postcheck(p, v, a, p[:, -1], kw["h"], kw["rmin"], kw["c"])
+    assert ref["min_dist"] > 2 * kw["rmin"] and out["violation"][0] == 0
+    assert abs(out["min_dist"][0] - ref["min_dist"]) <= 1e-10

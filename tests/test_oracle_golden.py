@@ -192,3 +192,20 @@ def test_cpp_flavour_reproduces_the_recorded_200_agent_dump():
     head = orc.step(orc.make_params("cpp", **dict(kw, Qfar=0.0, Qnear=0.0, Q1=1000.0)), l, g["po"], z, z, g["pf"], nthreads=8)
     nov = out["info"][:, 0] == 0
     assert np.median(np.abs(head["a"][:, :3] - g["ak"][:, 1]).max(axis=1)[nov]) > 1e-3 > np.median(e[nov]) * 100
+
+
+def test_postcheck_tree_search_equals_literal_pair_loop():
+    """oracle/postcheck.py: the k-d-tree minimum used for the large-scene tests against the literal O(N^2) loop of
+    failure_rate.m:170-181"""
+    from oracle import postcheck as PC
+    rng = np.random.default_rng(1)
+    for N, KT in ((2, 5), (40, 8), (120, 6)):
+        a = rng.uniform(-1, 1, (N, KT, 3)); a[:, 0] = 0
+        v = np.zeros_like(a); p = np.zeros_like(a); p[:, 0] = rng.uniform(-2, 2, (N, 3))
+        for k in range(1, KT):
+            v[:, k] = v[:, k - 1] + 0.2 * a[:, k]
+            p[:, k] = p[:, k - 1] + 0.2 * v[:, k - 1] + 0.02 * a[:, k]
+        r1 = PC.postcheck(p, v, a, p[:, -1], 0.2, 0.35, 2.0)
+        r2 = PC.postcheck(p, v, a, p[:, -1], 0.2, 0.35, 2.0, pairs="tree")
+        assert abs(r1["min_dist"] - r2["min_dist"]) < 1e-13 and r1["violation"] == r2["violation"]
+        assert np.array_equal(r1["p"], r2["p"])
