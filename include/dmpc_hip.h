@@ -106,11 +106,26 @@ enum {
                           * device-layout and multi-GPU entry points take fp64 tables only.  BASELINE configs[4].    */
 };
 
-/* Create a solver context on HIP device `device` (>= 0; -1 = the calling thread's current HIP device -- with one process
- * per GPU that is "this rank's GPU").  Replaces the constants/precompute preamble of dmpc/matlab/dmpc_soft_bound.m:80-108
- * and the DMPC ctor dmpc/cpp/dmpc.cpp:19-75.  precision: DMPC_PREC_*.
+/* Create a solver context.  Replaces the constants/precompute preamble of dmpc/matlab/dmpc_soft_bound.m:80-108 and the DMPC ctor
+ * dmpc/cpp/dmpc.cpp:19-75.  precision: DMPC_PREC_*.
+ *   device >= 0           one HIP device.
+ *   DMPC_DEVICE_ALL  (-1) EVERY visible GPU, from this one process: the agents of each scene are sharded over the GPUs in the
+ *                         reference's contiguous thread clusters (DMPC::solveParallelDMPCv2, dmpc/cpp/dmpc.cpp:1600-1625: N/G each,
+ *                         the first N mod G one more), one internal host thread + stream + sub-context per GPU, and the join of
+ *                         every MPC step (`prev_obs = obs`, :1671-1681; `l = new_l`, dmpc_soft_bound.m:146) is a set of direct
+ *                         peer copies over xGMI, each rank writing its chunk of new predictions into every GPU's next table
+ *                         (one address space: no collective library involved; the one-process-per-GPU form below uses RCCL).
+ *                         The host-pointer entry points a MATLAB / C++ caller uses -- dmpc_transition, dmpc_step_batch,
+ *                         dmpc_postcheck on the resident histories -- work unchanged on such a context; the per-agent and helper
+ *                         entry points run on its first GPU; the device-pointer entry points (one device's memory) refuse it.
+ *                         With one visible GPU this is a plain context.  Results do not depend on the number of GPUs, bit for bit.
+ *   DMPC_DEVICE_CURRENT (-2) the calling thread's current HIP device (one process per GPU: "this rank's GPU").
  * Returns NULL on failure (no device, bad parameters); dmpc_last_error(NULL) has the text. */
+#define DMPC_DEVICE_ALL (-1)
+#define DMPC_DEVICE_CURRENT (-2)
 dmpc_ctx *dmpc_create(const dmpc_params *prm, int device, int precision);
+/* number of GPUs the context drives (1 unless created with DMPC_DEVICE_ALL on a multi-GPU node) */
+int dmpc_group_size(const dmpc_ctx *ctx);
 void dmpc_destroy(dmpc_ctx *ctx);
 const char *dmpc_last_error(const dmpc_ctx *ctx);
 
@@ -236,6 +251,13 @@ int dmpc_step_sharded_device(dmpc_ctx *ctx, int S, int N, const double *lT, cons
  * goals: the rule of dmpc_transition).  Results do not depend on the number of ranks (bit for bit). */
 int dmpc_transition_sharded(dmpc_ctx *ctx, int S, int N, const double *po, const double *pf, int K_T_max, double error_tol,
                             double *pk, double *vk, double *ak, int32_t *K_T_used, int32_t *scene_status);
+
+/* The same, followed by ONE all-gather per history array: every rank then also holds the scene-wide histories [S][N][K_T_max][3]
+ * on its device, which is what dmpc_postcheck(.., pk = NULL, ..) checks -- the post-checks of test/failure_rate.m:136-195 after a
+ * sharded transition, on any rank (pk, vk, ak still return the rank's own agents).  A DMPC_DEVICE_ALL context does this inside
+ * dmpc_transition. */
+int dmpc_transition_sharded_gather(dmpc_ctx *ctx, int S, int N, const double *po, const double *pf, int K_T_max, double error_tol,
+                                   double *pk, double *vk, double *ak, int32_t *K_T_used, int32_t *scene_status);
 
 /* f-1: the post-checks the reference runs after every transition -- test/failure_rate.m:136-195 (identical
  * blocks: test/comp_kctr.m:141-205, test/comp_hardsoft2.m:140-204, dmpc/matlab/dmpc_soft_bound.m:152-190):

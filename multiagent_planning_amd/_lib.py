@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "dmpc_trajectories2file", "dmpc_test2file", "dmpc_random_test", "dmpc_random_exchange", "dmpc_random_sets_device",
     "dmpc_prop_state", "dmpc_is_inbounds", "dmpc_reached_goal", "dmpc_rows_dense",
     "dmpc_partition", "dmpc_comm_unique_id", "dmpc_comm_init", "dmpc_comm_destroy", "dmpc_step_sharded_device",
-    "dmpc_transition_sharded",
+    "dmpc_transition_sharded", "dmpc_transition_sharded_gather", "dmpc_group_size",
 ]
 
 
@@ -112,6 +112,9 @@ def load():
     L.dmpc_comm_destroy.argtypes = [vp]
     L.dmpc_step_sharded_device.argtypes = [vp, C.c_int, C.c_int] + [vp] * 12
     L.dmpc_transition_sharded.argtypes = [vp, C.c_int, C.c_int, dp, dp, C.c_int, C.c_double, dp, dp, dp, ip, ip]
+    L.dmpc_transition_sharded_gather.argtypes = [vp, C.c_int, C.c_int, dp, dp, C.c_int, C.c_double, dp, dp, dp, ip, ip]
+    L.dmpc_group_size.argtypes = [vp]
+    L.dmpc_debug_emulate_devices.argtypes = [C.c_int]
     L.dmpc_solve_count.restype = C.c_int64
     L.dmpc_solve_count.argtypes = [vp]
     L.dmpc_profile.argtypes = [vp, C.c_int]
@@ -183,7 +186,9 @@ class Dmpc:
     """One solver context on one HIP device (wraps dmpc_create/dmpc_destroy)."""
 
     def __init__(self, variant="bound", device=0, precision="f64", **kw):
-        """precision: "f64" (DMPC_PREC_F64) or "mixed" (DMPC_PREC_MIXED: fp32 table / scan / rows, fp64 QP)"""
+        """precision: "f64" (DMPC_PREC_F64) or "mixed" (DMPC_PREC_MIXED: fp32 table / scan / rows, fp64 QP);
+        device: a HIP device index, DEVICE_ALL (-1: every visible GPU from this process, agents sharded over them) or
+        DEVICE_CURRENT (-2: the calling thread's current device)"""
         self._L = load()
         self.prm = make_params(variant, **kw)
         self.precision = precision
@@ -191,6 +196,19 @@ class Dmpc:
         if not self._ctx:
             raise DmpcError(self._L.dmpc_last_error(None).decode())
         self.device = device
+
+    DEVICE_ALL, DEVICE_CURRENT = -1, -2
+
+    @property
+    def n_devices(self):
+        """GPUs this context drives (1 unless created with DEVICE_ALL on a multi-GPU node)"""
+        return int(self._L.dmpc_group_size(self._ctx))
+
+    @staticmethod
+    def emulate_devices(n):
+        """tests: DEVICE_ALL contexts created from now on run n ranks that all sit on the current GPU (0: off)"""
+        if load().dmpc_debug_emulate_devices(int(n)):
+            raise DmpcError("emulate_devices: bad count")
 
     def close(self):
         if getattr(self, "_ctx", None):
@@ -291,8 +309,10 @@ class Dmpc:
     def step_sharded_device(self, S, N, lT, x_p, x_v, x_a, pf, p_out, v_out, a_out, lT_next, status, info, stream=0):
         self._chk(self._L.dmpc_step_sharded_device(self._ctx, S, N, lT, x_p, x_v, x_a, pf, p_out, v_out, a_out, lT_next, status, info, stream))
 
-    def transition_sharded(self, po, pf, K_T_max, error_tol=0.01, histories=True):
-        """dmpc_transition_sharded: po, pf [S,N,3] (the same on every rank); returns this rank's histories [S,count,K_T_max,3]."""
+    def transition_sharded(self, po, pf, K_T_max, error_tol=0.01, histories=True, gather=False):
+        """dmpc_transition_sharded: po, pf [S,N,3] (the same on every rank); returns this rank's histories [S,count,K_T_max,3].
+        gather=True (dmpc_transition_sharded_gather): the scene-wide histories are assembled on every rank's device afterwards, so that
+        postcheck(K_T_used, pf, KT_alloc=K_T_max) checks the whole transition."""
         po, pf = _f(po), _f(pf)
         S, N = po.shape[0], po.shape[1]
         lo, cnt, cmax = partition(N, getattr(self, "nranks", 1), getattr(self, "rank", 0))
@@ -303,8 +323,8 @@ class Dmpc:
         else:
             pk = vk = ak = None
             hp = (C.POINTER(C.c_double)(),) * 3
-        self._chk(self._L.dmpc_transition_sharded(self._ctx, S, N, _dp(po), _dp(pf), int(K_T_max), float(error_tol), hp[0], hp[1], hp[2],
-                                                  _ip(used), _ip(sst)))
+        fn = self._L.dmpc_transition_sharded_gather if gather else self._L.dmpc_transition_sharded
+        self._chk(fn(self._ctx, S, N, _dp(po), _dp(pf), int(K_T_max), float(error_tol), hp[0], hp[1], hp[2], _ip(used), _ip(sst)))
         return dict(pk=pk, vk=vk, ak=ak, K_T_used=used, scene_status=sst, lo=lo, count=cnt)
 
     def postcheck(self, K_T_used, pf, pk=None, vk=None, ak=None, KT_alloc=None, vmax=2.0, amax=1.0, Ts=0.01, interp=False,

@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
 #include <string>
 #include <thread>
 #include <vector>
@@ -44,6 +45,36 @@ struct DevBuf {
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
     template <class T> T *as() { return (T *)p; }
+};
+
+// One process, several GPUs (dmpc_create(prm, DMPC_DEVICE_ALL, ..)): what the sub-contexts of a group share -- a host barrier for
+// their threads, the pointers each rank publishes for the per-step exchange, and the events that order the peer copies.
+struct GroupShared {
+    int G = 1;
+    std::atomic<int> arrived{0};
+    std::atomic<int> phase{0};
+    std::atomic<int> abort{0};          // a rank failed: everybody leaves the barriers with an error instead of waiting forever
+    std::vector<double *> next_ptr;     // [G] table the rank reads in the NEXT step (peers write their chunks into it)
+    std::vector<int *> fall_ptr;        // [G] the rank's gathered scene verdicts
+    std::vector<int> dev;               // [G] HIP device of the rank
+    std::vector<hipEvent_t> ev;         // [G][2] "rank's copies of this step are enqueued", alternating
+    double *hist_dst[3] = {nullptr, nullptr, nullptr};   // rank 0's scene-wide history arrays (gather_histories)
+    // sense-reversing spin barrier of the G rank threads; false: the group was aborted
+    bool wait()
+    {
+        const int ph = phase.load(std::memory_order_acquire);
+        if (arrived.fetch_add(1, std::memory_order_acq_rel) == G - 1) {
+            arrived.store(0, std::memory_order_relaxed);
+            phase.store(ph + 1, std::memory_order_release);
+        } else {
+            int spins = 0;
+            while (phase.load(std::memory_order_acquire) == ph) {
+                if (abort.load(std::memory_order_relaxed)) return false;
+                if (++spins > 256) std::this_thread::yield();
+            }
+        }
+        return !abort.load(std::memory_order_relaxed);
+    }
 };
 
 struct dmpc_ctx {
@@ -88,7 +119,13 @@ struct dmpc_ctx {
     // multi-GPU (dmpc_multigpu.hip): RCCL communicator of this rank, exchange buffers
     void *comm = nullptr;
     int nranks = 1, rank = 0;
-    DevBuf sendbuf, mg_pf, mg_floc, mg_fall;
+    DevBuf sendbuf, sendbuf32, own64, mg_pf, mg_floc, mg_fall, full_p, full_v, full_a, gath;
+    // one process, several GPUs: this context is rank `rank` of the group `grp`; the context the caller holds (rank 0) owns
+    // the others (`peers`, ranks 1..G-1) and the shared block
+    GroupShared *grp = nullptr;
+    std::vector<dmpc_ctx *> peers;
+    long grp_steps = 0;      // exchanges of this rank so far (parity of the event pair)
+    int debug_rank = 0;      // dmpc_debug_set_rank: emulated rank without a transport (tests)
     DevBuf rb_A, rb_l, rb_sel, rb_out, rb_bin, rb_po, gen_out, hp_in, hp_out;                     // dense row builders (host-pointer entries)
     // profiling
     int profile = 0;
@@ -299,20 +336,18 @@ static int upload_tables(dmpc_ctx *ctx)
 
 extern "C" const char *dmpc_last_error(const dmpc_ctx *ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
 
-extern "C" dmpc_ctx *dmpc_create(const dmpc_params *prm, int device, int precision)
+static std::atomic<int> g_emulate_devices{0};
+// development / tests (not in the public header): DMPC_DEVICE_ALL then builds a group of n ranks that all sit on the calling thread's
+// current device -- the single-process multi-GPU path (threads, peer copies, events) on a box with ONE GPU.  n = 0: off.
+extern "C" int dmpc_debug_emulate_devices(int n)
 {
-    std::string why;
-    if (check_params(prm, why)) { g_err = "dmpc_create: " + why; return nullptr; }
-    if (precision != DMPC_PREC_F64 && precision != DMPC_PREC_MIXED) { g_err = "dmpc_create: precision must be DMPC_PREC_F64 or DMPC_PREC_MIXED"; return nullptr; }
-    int ndev = 0;
-    hipError_t e = hipGetDeviceCount(&ndev);
-    if (e != hipSuccess || ndev <= 0) {
-        g_err = std::string("dmpc_create: no HIP device available (") + hipGetErrorString(e) +
-                "); this library has no CPU fallback";
-        return nullptr;
-    }
-    if (device == -1 && hipGetDevice(&device) != hipSuccess) device = 0;   // -1: the calling thread's current HIP device
-    if (device < 0 || device >= ndev) { g_err = "dmpc_create: device index out of range"; return nullptr; }
+    if (n < 0 || n > 64) return -1;
+    g_emulate_devices.store(n);
+    return 0;
+}
+
+static dmpc_ctx *create_one(const dmpc_params *prm, int device, int precision)
+{
     if (hipSetDevice(device) != hipSuccess) { g_err = "dmpc_create: hipSetDevice failed"; return nullptr; }
     dmpc_ctx *ctx = new dmpc_ctx();
     ctx->device = device;
@@ -328,13 +363,79 @@ extern "C" dmpc_ctx *dmpc_create(const dmpc_params *prm, int device, int precisi
     return ctx;
 }
 
+extern "C" dmpc_ctx *dmpc_create(const dmpc_params *prm, int device, int precision)
+{
+    std::string why;
+    if (check_params(prm, why)) { g_err = "dmpc_create: " + why; return nullptr; }
+    if (precision != DMPC_PREC_F64 && precision != DMPC_PREC_MIXED) { g_err = "dmpc_create: precision must be DMPC_PREC_F64 or DMPC_PREC_MIXED"; return nullptr; }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        g_err = std::string("dmpc_create: no HIP device available (") + hipGetErrorString(e) +
+                "); this library has no CPU fallback";
+        return nullptr;
+    }
+    if (device == DMPC_DEVICE_CURRENT && hipGetDevice(&device) != hipSuccess) device = 0;
+    if (device == DMPC_DEVICE_ALL) {
+        // every visible GPU, one process: rank r of the group on device r (the reference's thread clusters, dmpc.cpp:1600-1625,
+        // one GPU each).  One visible GPU: a plain context.
+        std::vector<int> devs;
+        const int emu = g_emulate_devices.load();
+        if (emu > 0) {
+            int cur = 0;
+            if (hipGetDevice(&cur) != hipSuccess) cur = 0;
+            devs.assign((size_t)emu, cur);
+        } else
+            for (int d = 0; d < ndev; ++d) devs.push_back(d);
+        if (devs.size() == 1) return create_one(prm, devs[0], precision);
+        const int G = (int)devs.size();
+        GroupShared *sh = new GroupShared();
+        sh->G = G; sh->dev = devs;
+        sh->next_ptr.assign((size_t)G, nullptr); sh->fall_ptr.assign((size_t)G, nullptr);
+        sh->ev.assign((size_t)G * 2, nullptr);
+        dmpc_ctx *root = nullptr;
+        bool ok = true;
+        for (int r = 0; r < G && ok; ++r) {
+            dmpc_ctx *c = create_one(prm, devs[(size_t)r], precision);
+            if (!c) { ok = false; break; }
+            c->grp = sh; c->nranks = G; c->rank = r;
+            if (r == 0) root = c; else root->peers.push_back(c);
+            for (int u = 0; u < 2 && ok; ++u) ok = hipEventCreateWithFlags(&sh->ev[(size_t)r * 2 + u], hipEventDisableTiming) == hipSuccess;
+            // direct loads / stores and copies between the GPUs of the group over xGMI
+            for (int q = 0; q < G && ok; ++q)
+                if (devs[(size_t)q] != devs[(size_t)r]) {
+                    const hipError_t pe = hipDeviceEnablePeerAccess(devs[(size_t)q], 0);
+                    if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();   // copies still work (staged)
+                }
+        }
+        if (!ok) {
+            if (g_err.empty()) g_err = "dmpc_create: group initialisation failed";
+            if (root) dmpc_destroy(root); else delete sh;
+            return nullptr;
+        }
+        (void)hipSetDevice(devs[0]);
+        return root;
+    }
+    if (device < 0 || device >= ndev) { g_err = "dmpc_create: device index out of range"; return nullptr; }
+    return create_one(prm, device, precision);
+}
+
+extern "C" int dmpc_group_size(const dmpc_ctx *ctx) { return ctx ? (ctx->grp ? ctx->grp->G : 1) : 0; }
+
 extern "C" void dmpc_destroy(dmpc_ctx *ctx)
 {
     if (!ctx) return;
+    for (dmpc_ctx *pc : ctx->peers) dmpc_destroy(pc);
+    ctx->peers.clear();
     if (ctx->child) { dmpc_destroy(ctx->child); ctx->child = nullptr; }
     if (ctx->comm) (void)dmpc_comm_destroy(ctx);
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->grp && ctx->rank == 0) {   // the root goes last: the shared block with it
+        for (hipEvent_t ev : ctx->grp->ev) if (ev) (void)hipEventDestroy(ev);
+        delete ctx->grp;
+    }
+    ctx->grp = nullptr;
     for (auto &ev : ctx->events) { (void)hipEventDestroy(ev.t0); (void)hipEventDestroy(ev.t1); (void)hipEventDestroy(ev.t2); }
     if (ctx->dbg) (void)hipFree(ctx->dbg);
     if (ctx->d_tables) (void)hipFree(ctx->d_tables);
@@ -348,12 +449,20 @@ extern "C" int dmpc_set_params(dmpc_ctx *ctx, const dmpc_params *prm)
     if (!ctx) { g_err = "dmpc_set_params: ctx is NULL"; return -1; }
     std::string why;
     if (check_params(prm, why)) FAIL(ctx, "dmpc_set_params: " + why);
+    for (dmpc_ctx *pc : ctx->peers)
+        if (dmpc_set_params(pc, prm)) FAIL(ctx, pc->err);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     ctx->prm = *prm;
     return upload_tables(ctx);
 }
 
-extern "C" int64_t dmpc_solve_count(const dmpc_ctx *ctx) { return ctx ? ctx->solves + (ctx->child ? ctx->child->solves : 0) : 0; }
+extern "C" int64_t dmpc_solve_count(const dmpc_ctx *ctx)
+{
+    if (!ctx) return 0;
+    int64_t n = ctx->solves + (ctx->child ? ctx->child->solves : 0);
+    for (const dmpc_ctx *pc : ctx->peers) n += dmpc_solve_count(pc);
+    return n;
+}
 
 extern "C" int dmpc_profile(dmpc_ctx *ctx, int enable)
 {
@@ -420,7 +529,8 @@ static int tier1_qcap(const dmpc_ctx *ctx, int variant)
 static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_first, int c_count, const double *lT,
                        const double *x_p, const double *x_v, const double *x_a, const double *pf, double *p_out,
                        double *v_out, double *a_out, double *lT_next, int32_t *status, int32_t *info, hipStream_t st,
-                       const int *scene_done = nullptr, int short_from = 0, const float *lTf = nullptr, const PostStep *post = nullptr)
+                       const int *scene_done = nullptr, int short_from = 0, const float *lTf = nullptr, const PostStep *post = nullptr,
+                       const double *own_prev = nullptr /* mixed: fp64 predictions of chunk g_local [S][3K][C] when lT is not the full fp64 table */)
 {
     const dmpc_params &p = ctx->prm;
     const bool soft = variant_soft(p.variant);
@@ -439,7 +549,7 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     P.tables = ctx->d_tables;
     for (int i = 0; i < 3; ++i) P.hsum[i] = ctx->hsum[i];
     // mixed precision: the scan reads the fp32 copy lTf of the table; lT (fp64, chunk g_local) is the solve's fallback
-    P.lT = lTf ? (const double *)lTf : lT; P.own_prev = lTf ? lT + (size_t)g_local * S * N3 * C : nullptr; P.x_p = x_p; P.x_v = x_v; P.x_a = x_a; P.pf = pf;
+    P.lT = lTf ? (const double *)lTf : lT; P.own_prev = lTf ? (own_prev ? own_prev : lT + (size_t)g_local * S * N3 * C) : nullptr; P.x_p = x_p; P.x_v = x_v; P.x_a = x_a; P.pf = pf;
     P.p_out = p_out; P.v_out = v_out; P.a_out = a_out; P.lT_next = lT_next;
     P.status = status; P.info = info;
     {
@@ -699,6 +809,12 @@ extern "C" int dmpc_profile_read(dmpc_ctx *ctx, double *avg_ms, int64_t *n_launc
     return rc;
 }
 
+static int table_f32(dmpc_ctx *ctx, const double *src, DevBuf &dst, size_t n, hipStream_t st);
+static int group_transition(dmpc_ctx *root, int S, int N, const double *po, const double *pf, int K_T_max, double error_tol, double *pk,
+                            double *vk, double *ak, int32_t *K_T_used, int32_t *scene_status);
+static int group_step_batch(dmpc_ctx *root, int S, int N, const double *l, const double *x_p, const double *x_v, const double *x_a,
+                            const double *pf, double *p_out, double *v_out, double *a_out, int32_t *status, int32_t *info);
+
 extern "C" int dmpc_step_device(dmpc_ctx *ctx, int S, int G, int C, int g_local, const double *lT, const double *x_p,
                                 const double *x_v, const double *x_a, const double *pf, double *p_out, double *v_out,
                                 double *a_out, double *lT_next, int32_t *status, int32_t *info, void *stream)
@@ -706,10 +822,13 @@ extern "C" int dmpc_step_device(dmpc_ctx *ctx, int S, int G, int C, int g_local,
     if (!ctx) { g_err = "dmpc_step_device: ctx is NULL"; return -1; }
     if (S < 1 || G < 1 || C < 1 || g_local < 0 || g_local >= G) FAIL(ctx, "dmpc_step_device: bad S/G/C/g_local");
     if (!lT || !x_p || !x_v || !x_a || !pf || !p_out || !v_out || !a_out || !status) FAIL(ctx, "dmpc_step_device: NULL pointer");
-    if (ctx->precision != DMPC_PREC_F64) FAIL(ctx, "dmpc_step_device: device-layout entry points take fp64 tables (DMPC_PREC_F64 contexts only)");
+    if (ctx->grp) FAIL(ctx, "dmpc_step_device: device pointers belong to ONE GPU; a DMPC_DEVICE_ALL context drives several (use the host-pointer entry points)");
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    // mixed precision: the caller's table stays fp64; the scan reads an fp32 copy made here (half the bytes of the O(N) part)
+    const bool mixed = ctx->precision == DMPC_PREC_MIXED;
+    if (mixed && table_f32(ctx, lT, ctx->lTf, (size_t)G * S * N3 * C, (hipStream_t)stream)) return -1;
     return launch_step(ctx, S, G, C, g_local, 0, C, lT, x_p, x_v, x_a, pf, p_out, v_out, a_out, lT_next, status, info,
-                       (hipStream_t)stream);
+                       (hipStream_t)stream, nullptr, 0, mixed ? ctx->lTf.as<float>() : nullptr);
 }
 
 extern "C" int dmpc_table_from_rows_device(dmpc_ctx *ctx, int S, int G, int C, const double *rows, double *lT, void *stream)
@@ -774,6 +893,7 @@ extern "C" int dmpc_step_batch(dmpc_ctx *ctx, int S, int N, const double *l, con
     if (!ctx) { g_err = "dmpc_step_batch: ctx is NULL"; return -1; }
     if (S < 1 || N < 1) FAIL(ctx, "dmpc_step_batch: S and N must be >= 1");
     if (!l || !x_p || !x_v || !x_a || !pf || !p_out || !v_out || !a_out || !status) FAIL(ctx, "dmpc_step_batch: NULL pointer");
+    if (ctx->grp && N >= ctx->grp->G) return group_step_batch(ctx, S, N, l, x_p, x_v, x_a, pf, p_out, v_out, a_out, status, info);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const size_t A = (size_t)S * N;
     if (ensure_step_scratch(ctx, A, A)) return -1;
@@ -1020,6 +1140,10 @@ extern "C" int dmpc_transition(dmpc_ctx *ctx, int S, int N, const double *po, co
 {
     if (!ctx) { g_err = "dmpc_transition: ctx is NULL"; return -1; }
     ctx->split_S0 = 0;
+    if (ctx->grp) {   // every visible GPU: the agents of each scene sharded over them (dmpc_multigpu.hip)
+        if (S < 1 || N < 1 || K_T_max < 2 || !po || !pf || !K_T_used || !scene_status || ((pk || vk || ak) && !(pk && vk && ak))) FAIL(ctx, "dmpc_transition: bad arguments");
+        return group_transition(ctx, S, N, po, pf, K_T_max, error_tol, pk, vk, ak, K_T_used, scene_status);
+    }
     if (S < 32 || ctx->no_split || N < 1 || K_T_max < 2 || !po || !pf || !K_T_used || !scene_status)
         return transition_one(ctx, S, N, po, pf, K_T_max, error_tol, pk, vk, ak, K_T_used, scene_status);
     if (!ctx->child) {

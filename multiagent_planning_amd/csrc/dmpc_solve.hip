@@ -193,16 +193,28 @@ __device__ __forceinline__ void remove_slot2(double *B, int lane, int &q, int l,
         B[SL::XS + lane] = cc; B[SL::RR + lane] = ss;
         LSYNC();
     }
+    // the sweep, four columns per round: the twelve LDS reads of a round (columns and rotations) are in flight together, the
+    // dependent path is the two multiply-adds per column.  (Columns beyond q - 1 are read masked; their rotations are identities.)
     double carry = (lane <= l) ? T[tcol(l) + lane] : 0.0;
-    double right = (q - 1 > l && lane <= l + 1) ? T[tcol(l + 1) + lane] : 0.0;
-    for (int j = l; j < q - 1; ++j) {
-        const double next = (j + 2 < q && lane <= j + 2) ? T[tcol(j + 2) + lane] : 0.0;
-        const double cc = B[SL::XS + j], ss = B[SL::RR + j];
-        const double nl = cc * carry - ss * right;
-        const double nr_ = ss * carry + cc * right;
-        if (lane <= j + 1 && lane != l) T[tcol(j) + (lane < l ? lane : lane - 1)] = nl;
-        carry = nr_;
-        right = next;
+    const int row = lane < l ? lane : lane - 1;
+    for (int j0 = l; j0 < q - 1; j0 += 4) {
+        double rt[4], cj[4], sj[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + u;
+            const int jc = j + 1 < QCAP ? j + 1 : QCAP - 1;
+            rt[u] = (j + 1 < q && lane <= j + 1) ? T[tcol(jc) + lane] : 0.0;
+            cj[u] = B[SL::XS + (j & 63)]; sj[u] = B[SL::RR + (j & 63)];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + u;
+            if (j < q - 1) {
+                const double nl = cj[u] * carry - sj[u] * rt[u];
+                carry = sj[u] * carry + cj[u] * rt[u];
+                if (lane <= j + 1 && lane != l) T[tcol(j) + row] = nl;
+            }
+        }
     }
     // the column that dropped out: back to zero up to the end of its group (keeps "zero below the diagonal" for the next append)
     if (lane < ((q + 7) & ~7)) T[tcol(q - 1) + lane] = 0.0;
@@ -427,7 +439,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
     // development: cycles of the traced agent by phase (s_memtime): 0 pivot scan, 1 pivot descriptor + pin, 2 s / T's / T T's,
     // 3 residual + direction + delta, 4 ratio test + step + append, 5 drops, 6 verification / refinement, 7 ladder certificate +
     // ladder step, 8 set-up; counts: 10 verifications, 11 drops, 12 certificate calls
-    long long phv[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long phv[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // 13 s, 14 T's, 15 ratio test, 16 step + certificates, (4: append)
     long long ph_last = __builtin_amdgcn_s_memtime();
     const bool ph_on = P.dbg && gid == P.dbg_agent;
 #define PH(i_) do { const long long t__ = __builtin_amdgcn_s_memtime(); if (ph_on) phv[i_] += t__ - ph_last; ph_last = t__; } while (0)
@@ -847,8 +859,10 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                         }
                     }
                     B[SL::XS + lane] = sv; LSYNC();
+                    PH(13);
                     const double dvj = t_tmul2<QCAP, SL::T, SL::XS>(B, lane, q);
                     B[SL::RR + lane] = dvj; LSYNC();
+                    PH(14);
                     const double ri = t_mul2<QCAP, SL::T, SL::RR>(B, lane, q);
                     LSYNC();
                     PH(2);
@@ -909,6 +923,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                     const double imax = wave_max0(iratio);
                     const double t1 = 1.0 / imax;   // inf when no multiplier decreases
                     const double t = fmin(t1, t2);
+                    PH(15);
 #ifdef DMPC_DEV_TRACE
                     if (P.dbg && gid == P.dbg_agent && lane == 0 && iters <= P.dbg_cap) {
                         double *d = P.dbg + (size_t)(iters - 1) * 8;
@@ -940,6 +955,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                             if (p.si >= 0 && !p_row_has_slot && lane == 63) r_eps[p.si] -= t * 0.5 * p.ss;
                         }
                     }
+                    PH(16);
                     if (t2 <= t1) {
                         // full step: append p (new column of T = [-r/rho ; 1/rho], zero below the diagonal)
                         if (q >= QCAP) { rc = 2; break; }
@@ -1087,8 +1103,8 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
 #ifdef DMPC_DEV_TRACE
             if (ph_on && Q.dbg_cap >= 4) {
                 PH(9 > 8 ? 4 : 4);
-                double *d = Q.dbg + (size_t)(Q.dbg_cap - 2) * 8;
-                for (int u = 0; u < 13; ++u) d[u] = (double)phv[u];
+                double *d = Q.dbg + (size_t)(Q.dbg_cap - 3) * 8;
+                for (int u = 0; u < 20; ++u) d[u] = (double)phv[u];
             }
             if (Q.dbg_agent == -4) { inf[0] = dev_nfast; inf[1] = dev_rounds; inf[3] = dev_negdrops; }   // development: crash statistics in place of the branch record
 #endif

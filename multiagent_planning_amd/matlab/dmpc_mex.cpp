@@ -29,10 +29,19 @@
 
 #include "dmpc_hip.h"
 
-static dmpc_ctx *g_ctx = nullptr;
-static dmpc_params g_prm;
+// A few persistent contexts keyed by their parameters (most recently used first): scripts of the reference alternate helpers that
+// carry their own constants (initDMPC, CheckCollSoftDMPC, propStatedmpc ...) with the solver inside one loop -- one context re-tuned on
+// every call would rebuild and upload its tables twice per agent and MPC step.
+struct CtxSlot { dmpc_params prm; dmpc_ctx *ctx; };
+static CtxSlot g_slots[4] = {};
+static int g_nslots = 0;
+static bool g_registered = false;
 
-static void cleanup() { if (g_ctx) { dmpc_destroy(g_ctx); g_ctx = nullptr; } }
+static void cleanup()
+{
+    for (int i = 0; i < g_nslots; ++i) if (g_slots[i].ctx) dmpc_destroy(g_slots[i].ctx);
+    g_nslots = 0;
+}
 
 static double field(const mxArray *s, const char *name)
 {
@@ -44,7 +53,7 @@ static double field(const mxArray *s, const char *name)
 static dmpc_params read_params(const mxArray *s)
 {
     if (!mxIsStruct(s)) mexErrMsgIdAndTxt("dmpc:params", "params must be a struct");
-    dmpc_params p;
+    dmpc_params p{};   // value-initialised: the struct is compared bytewise (context cache)
     p.K = (int32_t)field(s, "K"); p.variant = (int32_t)field(s, "variant");
     p.order = (int32_t)field(s, "order"); p.max_tries = 0;
     p.h = field(s, "h"); p.rmin = field(s, "rmin"); p.c = field(s, "c"); p.alim = field(s, "alim");
@@ -59,17 +68,29 @@ static dmpc_params read_params(const mxArray *s)
 
 static dmpc_ctx *context(const dmpc_params &p)
 {
-    if (!g_ctx) {
-        g_ctx = dmpc_create(&p, 0, DMPC_PREC_F64);
-        if (!g_ctx) mexErrMsgIdAndTxt("dmpc:create", "%s", dmpc_last_error(nullptr));
-        g_prm = p;
-        mexAtExit(cleanup);
-        mexLock();
-    } else if (std::memcmp(&p, &g_prm, sizeof(p)) != 0) {
-        if (dmpc_set_params(g_ctx, &p)) mexErrMsgIdAndTxt("dmpc:params", "%s", dmpc_last_error(g_ctx));
-        g_prm = p;
+    for (int i = 0; i < g_nslots; ++i)
+        if (std::memcmp(&p, &g_slots[i].prm, sizeof(p)) == 0) {
+            const CtxSlot hit = g_slots[i];
+            for (int j = i; j > 0; --j) g_slots[j] = g_slots[j - 1];
+            g_slots[0] = hit;
+            return hit.ctx;
+        }
+    // every visible GPU (DMPC_DEVICE_ALL): on a multi-GPU node the agents of a scene are sharded over the GPUs inside the library,
+    // like the thread clusters of DMPC::solveParallelDMPCv2; with one GPU this is a plain context
+    dmpc_ctx *c = nullptr;
+    if (g_nslots == 4) {   // re-tune the least recently used context
+        c = g_slots[3].ctx;
+        if (dmpc_set_params(c, &p)) mexErrMsgIdAndTxt("dmpc:params", "%s", dmpc_last_error(c));
+        g_nslots = 3;
+    } else {
+        c = dmpc_create(&p, DMPC_DEVICE_ALL, DMPC_PREC_F64);
+        if (!c) mexErrMsgIdAndTxt("dmpc:create", "%s", dmpc_last_error(nullptr));
     }
-    return g_ctx;
+    for (int j = g_nslots; j > 0; --j) g_slots[j] = g_slots[j - 1];
+    g_slots[0].prm = p; g_slots[0].ctx = c;
+    g_nslots++;
+    if (!g_registered) { mexAtExit(cleanup); mexLock(); g_registered = true; }
+    return c;
 }
 
 static void need(bool ok, const char *what) { if (!ok) mexErrMsgIdAndTxt("dmpc:shape", "%s", what); }

@@ -25,7 +25,7 @@ def build():
     return EXE
 
 
-def call(cmd, prm, args=(), nlhs=1):
+def call(cmd, prm, args=(), nlhs=1, emulate_devices=0):
     """dmpc_mex(cmd, prm, args...) -> list of nlhs numpy arrays (column-major like MATLAB); raises RuntimeError with the
     MATLAB error text on mexErrMsgIdAndTxt.  prm: dict with K, variant, order, h, rmin, c, alim, Q1, S1, term, pmin, pmax."""
     exe = build()
@@ -42,7 +42,10 @@ def call(cmd, prm, args=(), nlhs=1):
     with tempfile.TemporaryDirectory() as td:
         rq, rp = os.path.join(td, "req.bin"), os.path.join(td, "rep.bin")
         open(rq, "wb").write(req)
-        subprocess.check_call([exe, rq, rp])
+        env = dict(os.environ)
+        if emulate_devices:
+            env["DMPC_TEST_EMULATE_DEVICES"] = str(int(emulate_devices))
+        subprocess.check_call([exe, rq, rp], env=env)
         buf = open(rp, "rb").read()
     rc, = struct.unpack_from("<i", buf, 0)
     off = 4

@@ -14,6 +14,8 @@
 
 #include "mex.h"
 
+extern "C" int dmpc_debug_emulate_devices(int n);   // libdmpc_hip.so (development entry, not in the public header)
+
 static void rd(FILE *f, void *p, size_t n) { if (fread(p, 1, n, f) != n) { fprintf(stderr, "short request\n"); exit(2); } }
 
 int main(int argc, char **argv)
@@ -51,6 +53,9 @@ int main(int argc, char **argv)
     FILE *o = fopen(argv[2], "wb");
     if (!o) { perror("reply"); return 2; }
     int32_t rc = 0;
+    // tests of the single-process multi-GPU path on a box with ONE GPU: the gateway's DMPC_DEVICE_ALL context runs this many ranks on
+    // the current device (development hook of the library, set by the test harness -- the gateway itself knows nothing of it)
+    if (const char *emu = getenv("DMPC_TEST_EMULATE_DEVICES")) dmpc_debug_emulate_devices(atoi(emu));
     try {
         mexFunction(nlhs, plhs.data(), (int)prhs.size(), prhs.data());
     } catch (const std::runtime_error &e) {

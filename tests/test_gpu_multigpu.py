@@ -75,3 +75,87 @@ def test_sharded_step_ranks_in_turn_equal_the_unsharded_step(variant, N, G):
         ok = one["status"][:, sl] & 1 == 1
         want = np.where(ok[..., None], one["p"][:, sl], l[:, sl])              # unsolved agents keep their old prediction
         assert np.array_equal(nxt, want), (variant, r)
+
+
+# ---- one process, several GPUs (dmpc_create(prm, DMPC_DEVICE_ALL, ..)); the ranks emulated on this box's single GPU ----------------
+
+@pytest.fixture
+def emulated():
+    yield mp.Dmpc.emulate_devices
+    mp.Dmpc.emulate_devices(0)
+
+
+@pytest.mark.parametrize("G,variant,N,precision", [(2, "bound", 20, "f64"), (3, "bound", 20, "f64"), (4, "bound2", 37, "f64"), (8, "bound", 100, "f64"),
+                                                   (3, "bound", 20, "mixed")])
+def test_group_context_transition_equals_single_gpu(emulated, G, variant, N, precision):
+    """DMPC_DEVICE_ALL: threads + peer copies + events between the MPC steps; the same histories, step counts and verdicts as the
+    single-GPU transition, bit for bit (f64; unequal clusters for G = 3, 8 | 20, 100; mixed precision: against the mixed single-GPU run --
+    the exchanged table is fp32 there) -- and the post-checks run on the histories the group left resident on its first GPU"""
+    cfg, kw, po, pf = _scenes(N, 4, wl.SEED0 + 41)
+    ref_d = mp.Dmpc(variant, precision=precision, **kw)
+    ref = ref_d.transition(po, pf, 100, cfg["error_tol"])
+    emulated(G)
+    d = mp.Dmpc(variant, device=mp.Dmpc.DEVICE_ALL, precision=precision, **kw)
+    assert d.n_devices == G
+    out = d.transition(po, pf, 100, cfg["error_tol"])
+    assert np.array_equal(out["K_T_used"], ref["K_T_used"]) and np.array_equal(out["scene_status"], ref["scene_status"])
+    for k in ("pk", "vk", "ak"):
+        assert np.array_equal(out[k], ref[k]), k
+    assert (ref["scene_status"] & mp.ST_REACHED).any()
+    ok = (ref["scene_status"] & mp.ST_REACHED) != 0
+    pc = d.postcheck(out["K_T_used"], pf, KT_alloc=100, mask=ok.astype(np.int32))          # resident, gathered on rank 0
+    pc_ref = ref_d.postcheck(ref["K_T_used"], pf, KT_alloc=100, mask=ok.astype(np.int32))
+    for k in pc:
+        assert np.array_equal(pc[k], pc_ref[k], equal_nan=True), k
+    # a second call on the same context (buffers, events and barrier state are reused)
+    out2 = d.transition(po, pf, 100, cfg["error_tol"], histories=False)
+    assert np.array_equal(out2["K_T_used"], ref["K_T_used"])
+
+
+@pytest.mark.parametrize("G,variant,N", [(2, "hard", 100), (3, "softall", 37), (5, "bound", 301)])
+def test_group_context_step_batch_equals_single_gpu(emulated, G, variant, N):
+    cfg, kw, po, pf = _scenes(N, 3, wl.SEED0 + 43, "C2" if variant == "hard" else "C4")
+    d1 = mp.Dmpc(variant, **kw)
+    l, _, _ = d1.init_batch(po, pf)
+    z = np.zeros_like(po)
+    one = d1.step_batch(l, po, z, z, pf)
+    emulated(G)
+    d = mp.Dmpc(variant, device=mp.Dmpc.DEVICE_ALL, **kw)
+    out = d.step_batch(l, po, z, z, pf)
+    for k in ("status", "p", "v", "a"):
+        assert np.array_equal(out[k], one[k]), k
+    assert np.array_equal(out["info"][..., :4], one["info"][..., :4])
+    # the helper entry points run on the group's first GPU
+    l2, _, _ = d.init_batch(po, pf)
+    assert np.array_equal(l2, l)
+    r = d.solve_one(l[0], 3, po[0, 3], z[0, 3], z[0, 3], pf[0, 3])
+    assert r["status"] == one["status"][0, 3] and np.array_equal(r["p"], one["p"][0, 3])
+
+
+def test_device_pointer_entry_points_refuse_a_group_context(emulated):
+    import torch
+    cfg, kw, po, pf = _scenes(10, 1, wl.SEED0 + 44)
+    emulated(2)
+    d = mp.Dmpc("bound", device=mp.Dmpc.DEVICE_ALL, **kw)
+    t = torch.zeros(8, dtype=torch.float64, device="cuda")
+    with pytest.raises(_lib.DmpcError, match="ONE GPU"):
+        d.step_device(1, 1, 10, 0, *([t.data_ptr()] * 11))
+    with pytest.raises(_lib.DmpcError):
+        d.comm_init(b"\0" * 128, 2, 0)
+
+
+def test_sharded_transition_gather_feeds_the_postcheck():
+    """dmpc_transition_sharded_gather with a world of one RCCL rank: the all-gather of the padded history slabs and the re-packing
+    run for real; dmpc_postcheck then reads the assembled scene-wide histories (f-1 after a sharded transition)"""
+    cfg, kw, po, pf = _scenes(12, 3, wl.SEED0 + 45)
+    ref_d = mp.Dmpc("bound", **kw)
+    ref = ref_d.transition(po, pf, 80, cfg["error_tol"], histories=False)
+    pc_ref = ref_d.postcheck(ref["K_T_used"], pf, KT_alloc=80)
+    d = mp.Dmpc("bound", **kw)
+    d.comm_init(mp.Dmpc.comm_unique_id(), 1, 0)
+    out = d.transition_sharded(po, pf, 80, cfg["error_tol"], histories=False, gather=True)
+    assert np.array_equal(out["K_T_used"], ref["K_T_used"])
+    pc = d.postcheck(out["K_T_used"], pf, KT_alloc=80)
+    for k in pc:
+        assert np.array_equal(pc[k], pc_ref[k], equal_nan=True), k
+    d.comm_destroy()

@@ -64,11 +64,56 @@ def test_mixed_transition_reaches_the_goals():
     assert np.abs(b["K_T_used"].astype(int) - a["K_T_used"].astype(int)).max() <= 3
 
 
-def test_device_entry_points_refuse_mixed_contexts():
+def test_mixed_precision_through_the_device_and_sharded_entry_points():
+    """DMPC_PREC_MIXED on the device-pointer entry points and in the sharded transition (the fp32 table is what the ranks exchange
+    there: half the payload).  dmpc_step_device / dmpc_step_sharded_device on a mixed context == the mixed dmpc_step_batch bit for bit
+    (same kernels, the fp32 copy of the caller's fp64 table made inside); the mixed sharded transition (emulated ranks of one
+    process) == the mixed single-GPU transition bit for bit; and against fp64: status agreement >= 99 %, l_inf(p) <= 1e-4 m."""
     import torch
-    kw = wl.solver_kwargs(wl.CONFIGS["C4"], 20)
-    d = mp.Dmpc("bound", precision="mixed", **kw)
-    t = torch.zeros(64, dtype=torch.float64, device="cuda:0")
-    with pytest.raises(mp.DmpcError, match="fp64"):
-        d.step_device(1, 1, 1, 0, t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), t.data_ptr(), 0,
-                      t.data_ptr(), 0, 0)
+    cfg = wl.CONFIGS["C4"]
+    N, S = 60, 3
+    kw = wl.solver_kwargs(cfg, N)
+    po, pf = wl.make_scenes(cfg, S, N, wl.SEED0 + 9)
+    l = np.stack([init_table(po[s], pf[s]) for s in range(S)])
+    z = np.zeros_like(po)
+    dmx, d64 = mp.Dmpc("bound", precision="mixed", **kw), mp.Dmpc("bound", **kw)
+    ref = dmx.step_batch(l, po, z, z, pf)
+    a64 = d64.step_batch(l, po, z, z, pf)
+    dev = torch.device("cuda", 0)
+    t = lambda a, dt=torch.float64: torch.from_numpy(np.ascontiguousarray(a)).to(dev, dt)
+    rows, lT = t(l), torch.empty((1, S, 45, N), dtype=torch.float64, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    dmx.table_from_rows_device(S, 1, N, rows.data_ptr(), lT.data_ptr(), st)
+    xp, xv, xa, gf = t(po), t(z), t(z), t(pf)
+    p = torch.empty((S, N, 45), dtype=torch.float64, device=dev); v, a = torch.empty_like(p), torch.empty_like(p)
+    nxt = torch.zeros((1, S, 45, N), dtype=torch.float64, device=dev)
+    stt = torch.zeros((S, N), dtype=torch.int32, device=dev); inf = torch.zeros((S, N, 8), dtype=torch.int32, device=dev)
+    for entry in ("step_device", "step_sharded_device"):
+        p.zero_(); stt.zero_()
+        if entry == "step_device":
+            dmx.step_device(S, 1, N, 0, lT.data_ptr(), xp.data_ptr(), xv.data_ptr(), xa.data_ptr(), gf.data_ptr(), p.data_ptr(), v.data_ptr(), a.data_ptr(),
+                            nxt.data_ptr(), stt.data_ptr(), inf.data_ptr(), st)
+        else:
+            dmx.step_sharded_device(S, N, lT.data_ptr(), xp.data_ptr(), xv.data_ptr(), xa.data_ptr(), gf.data_ptr(), p.data_ptr(), v.data_ptr(), a.data_ptr(),
+                                    nxt.data_ptr(), stt.data_ptr(), inf.data_ptr(), st)
+        torch.cuda.synchronize()
+        assert np.array_equal(stt.cpu().numpy(), ref["status"]) and np.array_equal(p.cpu().numpy(), ref["p"]), entry
+    eq = ref["status"] == a64["status"]
+    ok = eq & ((ref["status"] & 1) == 1)
+    assert eq.mean() >= 0.99 and np.abs(ref["p"][ok] - a64["p"][ok]).max() <= 1e-4
+    # the sharded transition in mixed precision
+    N2 = 20
+    kw2 = wl.solver_kwargs(cfg, N2)
+    po2, pf2 = wl.make_scenes(cfg, 4, N2, wl.SEED0 + 21)
+    one = mp.Dmpc("bound", precision="mixed", **kw2).transition(po2, pf2, 100, cfg["error_tol"])
+    f64 = mp.Dmpc("bound", **kw2).transition(po2, pf2, 100, cfg["error_tol"])
+    try:
+        mp.Dmpc.emulate_devices(3)
+        grp = mp.Dmpc("bound", device=mp.Dmpc.DEVICE_ALL, precision="mixed", **kw2).transition(po2, pf2, 100, cfg["error_tol"])
+    finally:
+        mp.Dmpc.emulate_devices(0)
+    assert np.array_equal(grp["K_T_used"], one["K_T_used"]) and np.array_equal(grp["scene_status"], one["scene_status"])
+    assert np.array_equal(grp["pk"], one["pk"])
+    assert np.abs(one["K_T_used"].astype(int) - f64["K_T_used"].astype(int)).max() <= 3
+    same = one["K_T_used"] == f64["K_T_used"]
+    assert same.any() and np.abs(one["pk"][same] - f64["pk"][same]).max() <= 1e-3      # closed loops of ~70 steps amplify the 1e-5 per-step deviation

@@ -83,3 +83,34 @@ def test_gateway_commands_match_the_c_abi():
     rpo, rpf = mh.call("random_test", prm1, [20, kw1["pmin"], kw1["pmax"], 0.5, 1.5, 42], nlhs=2)
     qpo, qpf = mp.Dmpc("bound", **kw1).random_test(1, 20, kw1["pmin"], kw1["pmax"], 0.5, 1.5, 42)
     assert np.array_equal(rpo.T, qpo[0]) and np.array_equal(rpf.T, qpf[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("G", [2, 3])
+def test_gateway_transition_and_step_on_all_gpus_of_one_process(G):
+    """The gateway creates its context on EVERY visible GPU (DMPC_DEVICE_ALL): the agents of a scene are sharded over the GPUs inside
+    the library, one host thread per GPU and peer copies between MPC steps (the thread clusters of dmpc.cpp:1600-1625,1656-1686).  On
+    this one-GPU box the ranks are emulated on the same device: dmpc_mex('transition') and dmpc_mex('step_batch') must return what
+    the single-GPU context returns, bit for bit (G = 3: unequal clusters)."""
+    import multiagent_planning_amd as mp
+    from multiagent_planning_amd import workload as wl
+    cfg = wl.CONFIGS["C4"]
+    N = 10
+    kw = wl.solver_kwargs(cfg, N)
+    prm = mh.params("bound", kw)
+    po, pf = wl.make_scenes(cfg, 1, N, wl.SEED0 + 5)
+    pk, vk, ak, used, sst = mh.call("transition", prm, [po[0].T, pf[0].T, 60, cfg["error_tol"]], nlhs=5, emulate_devices=G)
+    ref = mp.Dmpc("bound", **kw).transition(po, pf, 60, cfg["error_tol"])
+    assert int(used.ravel()[0]) == int(ref["K_T_used"][0]) and int(sst.ravel()[0]) == int(ref["scene_status"][0])
+    assert int(sst.ravel()[0]) & mp.ST_REACHED
+    for got, want in ((pk, "pk"), (vk, "vk"), (ak, "ak")):
+        assert np.array_equal(got.transpose(2, 1, 0), ref[want][0]), want
+    g, kwg = load_golden("comp_kctr_3_bound2")
+    l, xp, xv, xa, pfg = step14_inputs(g)
+    Ng = l.shape[0]
+    lm = np.ascontiguousarray(l.reshape(Ng, 15, 3).transpose(2, 1, 0))
+    P, V, A, st, inf = mh.call("step_batch", mh.params("bound2", kwg), [lm, xp.T, xv.T, xa.T, pfg.T], nlhs=5, emulate_devices=G)
+    out = mp.Dmpc("bound2", **kwg).step_batch(l, xp, xv, xa, pfg)
+    assert np.array_equal(st.ravel(), out["status"])
+    assert np.array_equal(P.transpose(2, 1, 0).reshape(Ng, 45), out["p"]) and np.array_equal(A.transpose(2, 1, 0).reshape(Ng, 45), out["a"])
+    assert np.array_equal(V.transpose(2, 1, 0).reshape(Ng, 45), out["v"])

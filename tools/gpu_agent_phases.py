@@ -14,8 +14,8 @@ d = mp.Dmpc(variant, **kw)
 l, xp, xv, xa, pf, alive = bench.capture_state(d, cfg, S, N, 12, wl.SEED0 + 2)
 L = _lib.load()
 L.dmpc_debug_trace.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
-names = ["pivot scan", "descriptor", "matvecs", "resid+dir", "ratio/step/append", "drops", "verify", "ladder", "setup"]
-cap = 8
+names = ["pivot scan", "descriptor", "T T's", "resid+dir", "append/other", "drops", "verify", "ladder", "setup", "-", "-", "-", "-", "s", "T's", "ratio", "step+certs"]
+cap = 8   # (the phase block takes rows cap-2 .. : 20 doubles)
 for g in gids:
     sc, n = divmod(g, N)
     for rep in range(2):
@@ -23,10 +23,11 @@ for g in gids:
         out = d.step_batch(l[sc], xp[sc], xv[sc], xa[sc], pf[sc])
         buf = np.zeros((cap, 8))
         L.dmpc_debug_trace(d._ctx, n, cap, buf.ctypes.data_as(C.c_void_p))
-    ph = buf.ravel()[(cap - 2) * 8:(cap - 2) * 8 + 13]
+    ph = buf.ravel()[(cap - 3) * 8:(cap - 3) * 8 + 20]
     i = out["info"][n]
-    tot = ph[:9].sum()
+    use = [0, 1, 2, 3, 4, 5, 6, 7, 8, 13, 14, 15, 16]
+    tot = ph[use].sum()
     print(f"agent {g} status {out['status'][n]} rows {i[1]} tries {i[2]} iters {i[4]} maxq {i[7]}: total {tot/100:.0f} us (100 MHz ticks)" if False else
           f"agent {g} status {out['status'][n]} rows {i[1]} tries {i[2]} iters {i[4]} maxq {i[7]}: total {tot:.0f} ticks; verifications {ph[10]:.0f} drops {ph[11]:.0f} certs {ph[12]:.0f}")
-    print("   " + "  ".join(f"{nm} {v/tot*100:.0f}%" for nm, v in zip(names, ph[:9])))
-    print("   per iteration (ticks): " + "  ".join(f"{nm} {v/max(i[4],1):.0f}" for nm, v in zip(names, ph[:9])))
+    print("   " + "  ".join(f"{names[u]} {ph[u]/tot*100:.0f}%" for u in use))
+    print("   per iteration (ticks): " + "  ".join(f"{names[u]} {ph[u]/max(i[4],1):.0f}" for u in use))
