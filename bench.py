@@ -78,8 +78,23 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.emulate_gpus:
+        # launched as `python bench.py --gpus N`: start the N ranks ourselves, exactly as the driver's
+        # `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...` does (one process per GPU, RCCL).
+        # On a box with fewer GPUs than N this is only a functional check of the multi-rank path (all ranks share GPU 0, the exchange
+        # staged through gloo; the JSON line says so) and has to be asked for with DMPC_BENCH_SHARE_GPU=1.
+        import socket
+        ndev = torch.cuda.device_count()
+        if ndev < args.gpus and not os.environ.get("DMPC_BENCH_SHARE_GPU"):
+            sys.exit(f"bench.py --gpus {args.gpus}: {ndev} GPU(s) visible (DMPC_BENCH_SHARE_GPU=1 runs the ranks on one GPU as a functional check)")
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
+        if world == 1 and args.gpus > 1 and not args.emulate_gpus:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     G = world
     emu = args.emulate_gpus if (world == 1 and args.emulate_gpus > 1) else 0
@@ -208,6 +223,23 @@ def main():
                              v_out.data_ptr(), a_out.data_ptr(), lT_next.data_ptr(), status.data_ptr(), info.data_ptr(), stream)
             torch.cuda.synchronize()
         exchange_ok = bool(torch.equal(lT_gath[rank], lT_next)) and int(ck[0].item()) == -int(ck[1].item())
+        # ... and the sharded step must be the UNSHARDED step of the same scenes, per agent and bit for bit: the first scenes solved
+        # again as ONE chunk of all N agents on this GPU (table in the G = 1 layout), this rank's agents compared
+        Sv = min(S, 8)
+        rows1 = dev_t(l[:Sv]); lT1 = torch.empty((1, Sv, 45, N), dtype=torch.float64, device=dev)
+        dmpc.table_from_rows_device(Sv, 1, N, rows1.data_ptr(), lT1.data_ptr(), stream)
+        f1 = [dev_t(a_[:Sv]) for a_ in (xp, xv, xa, pf)]
+        p1 = torch.empty((Sv, N, 45), dtype=torch.float64, device=dev); v1, a1 = torch.empty_like(p1), torch.empty_like(p1)
+        st1 = torch.zeros((Sv, N), dtype=torch.int32, device=dev)
+        ds = mp.Dmpc(cfg["variant"], device=local_rank, **kw)
+        ds.step_device(Sv, 1, N, 0, lT1.data_ptr(), f1[0].data_ptr(), f1[1].data_ptr(), f1[2].data_ptr(), f1[3].data_ptr(), p1.data_ptr(), v1.data_ptr(),
+                       a1.data_ptr(), 0, st1.data_ptr(), 0, stream)
+        torch.cuda.synchronize()
+        same = bool(torch.equal(p1[:, lo:lo + C], p_out[:Sv])) and bool(torch.equal(st1[:, lo:lo + C], status[:Sv]))
+        okt = torch.tensor([1 if same else 0], dtype=torch.int32, device="cpu" if share else dev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        exchange_ok = exchange_ok and int(okt.item()) == 1
+        del ds
 
     solves_per_step = S * N if not emu else S * C
     value = solves_per_step * args.steps / elapsed

@@ -654,12 +654,13 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
         while (W > 1 && lds0 * W > 64 * 1024) W >>= 1;
         const dim3 sgrid((unsigned)((total + W - 1) / W)), sblock(64u * W);
         P.lds_per_wave = (int)lds0;
+        const bool fx = P.fast_exit != 0;
         if (lTf) {
-            if (soft) hipLaunchKernelGGL((dmpc_scan_kernel<true, float>), sgrid, sblock, lds0 * W, st, P);
-            else hipLaunchKernelGGL((dmpc_scan_kernel<false, float>), sgrid, sblock, lds0 * W, st, P);
+            if (soft) { if (fx) hipLaunchKernelGGL((dmpc_scan_kernel<true, float, true>), sgrid, sblock, lds0 * W, st, P); else hipLaunchKernelGGL((dmpc_scan_kernel<true, float, false>), sgrid, sblock, lds0 * W, st, P); }
+            else { if (fx) hipLaunchKernelGGL((dmpc_scan_kernel<false, float, true>), sgrid, sblock, lds0 * W, st, P); else hipLaunchKernelGGL((dmpc_scan_kernel<false, float, false>), sgrid, sblock, lds0 * W, st, P); }
         } else {
-            if (soft) hipLaunchKernelGGL((dmpc_scan_kernel<true, double>), sgrid, sblock, lds0 * W, st, P);
-            else hipLaunchKernelGGL((dmpc_scan_kernel<false, double>), sgrid, sblock, lds0 * W, st, P);
+            if (soft) { if (fx) hipLaunchKernelGGL((dmpc_scan_kernel<true, double, true>), sgrid, sblock, lds0 * W, st, P); else hipLaunchKernelGGL((dmpc_scan_kernel<true, double, false>), sgrid, sblock, lds0 * W, st, P); }
+            else { if (fx) hipLaunchKernelGGL((dmpc_scan_kernel<false, double, true>), sgrid, sblock, lds0 * W, st, P); else hipLaunchKernelGGL((dmpc_scan_kernel<false, double, false>), sgrid, sblock, lds0 * W, st, P); }
         }
     }
     // heaviest-first launch order for the solve phase (key left by the scan in hdr[7]).  Tiny launches do not need it.
@@ -989,8 +990,8 @@ extern "C" int dmpc_rows_one(dmpc_ctx *ctx, int N, int n, const double *l, const
     if (ctx->rowbuf.ensure(per * 8) || ctx->rowkc.ensure((size_t)P.nrmax * 4) || ctx->hdr.ensure(32)) FAIL(ctx, "device allocation failed");
     P.rowbuf = ctx->rowbuf.as<double>(); P.rowkc = ctx->rowkc.as<int>(); P.hdr = ctx->hdr.as<int>();
     P.lds_per_wave = (int)scan_lds_bytes();
-    if (soft) hipLaunchKernelGGL((dmpc_scan_kernel<true, double>), dim3(1), dim3(64), scan_lds_bytes(), st, P);
-    else hipLaunchKernelGGL((dmpc_scan_kernel<false, double>), dim3(1), dim3(64), scan_lds_bytes(), st, P);
+    if (soft) hipLaunchKernelGGL((dmpc_scan_kernel<true, double, false>), dim3(1), dim3(64), scan_lds_bytes(), st, P);
+    else hipLaunchKernelGGL((dmpc_scan_kernel<false, double, false>), dim3(1), dim3(64), scan_lds_bytes(), st, P);
     HIPCHK(ctx, hipGetLastError());
     int hdr[8];
     HIPCHK(ctx, hipMemcpyAsync(hdr, ctx->hdr.p, 32, hipMemcpyDeviceToHost, st));

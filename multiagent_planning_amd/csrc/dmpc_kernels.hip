@@ -291,7 +291,7 @@ return empty_any;
 // register and LDS footprint free of the scan's needs (more resident agents per CU) and lets the solver be re-launched
 // for the few agents that overflow the tier-1 working-set capacity.
 // `vb`: the agent's index in the launch (already renumbered XCD-aware by the kernel); `smem`: this wave's LDS.
-template <bool SOFT, typename TT>
+template <bool SOFT, typename TT, bool FAST>
 __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, const int vb, unsigned char *smem)
 {
     const int S = P.S, G = P.G, C = P.C, nrmax = P.nrmax;
@@ -746,7 +746,7 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
         // above), its header flagged (hdr[4] & 16) -- and never enters the solve queue: the scan runs at twice the solver's
         // occupancy and the agent's state is already in registers.  (43 % of the agents of the solveSoftDMPCbound replay of
         // bench.py, nearly all of them once the swarm has spread out.)
-        if (P.fast_exit && status == 0 && !__any(cert_infeasible) && nr <= 128) {
+        if (FAST && status == 0 && !__any(cert_infeasible) && nr <= 128) {   // (FAST: a template parameter -- launches without the exit do not carry its registers)
             const int ls = (int)wave_max((double)ladder_start);
             const int ccase = cost_case(var, A.po[0] - A.pf[0], A.po[1] - A.pf[1], A.po[2] - A.pf[2], rows_exist);
             const double qw = ccase == 0 ? P.Qfar : (ccase == 1 ? P.Qnear : P.Q1);
@@ -805,7 +805,7 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
                 if (lane == 0) {
                     P.status[gid] = st;
                     hdr[4] = (violation ? 1 : 0) | (coll_flag ? 4 : 0) | 16;
-                    hdr[7] = 0;
+                    hdr[7] = 256;   // (the order kernel reads this word only)
                     if (P.info) {
                         int *inf = P.info + (size_t)gid * 8;
                         inf[0] = viol_k; inf[1] = nrows_ref; inf[2] = 1; inf[3] = ccase;
@@ -827,7 +827,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char dmpc_smem[];
 // XCD-aware mapping: workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8, private L2 each), so they are
 // renumbered such that every XCD works on whole scenes: a scene's prediction table is then fetched into ONE L2 instead of
 // eight.  Pure performance remap (a bijection on [0, gridDim)).
-template <bool SOFT, typename TT>
+template <bool SOFT, typename TT, bool FAST>
 __global__ __launch_bounds__(64 * SCAN_WAVES_PER_WG, SCAN_WAVES_PER_SIMD) void dmpc_scan_kernel(StepParams P)
 {
     const int W = (int)(blockDim.x >> 6);
@@ -837,7 +837,7 @@ __global__ __launch_bounds__(64 * SCAN_WAVES_PER_WG, SCAN_WAVES_PER_SIMD) void d
     for (int xx = 0; xx < x; ++xx) off += (nb - xx + 7) >> 3;
     const int agent = (off + y) * W + wave, total = P.S * P.c_count;
     if (agent >= total) return;
-    scan_body<SOFT, TT>(P, lane, agent, dmpc_smem + (size_t)wave * P.lds_per_wave);
+    scan_body<SOFT, TT, FAST>(P, lane, agent, dmpc_smem + (size_t)wave * P.lds_per_wave);
 }
 // Solve phase, one agent per 64-thread workgroup (shallow launches: bound by their slowest agent)
 template <bool SOFT, int QCAP>
@@ -881,10 +881,11 @@ __global__ __launch_bounds__(512, 1) void dmpc_solve_persist_kernel(StepParams P
     const int T3 = (rest - T1) < QUEUE_T3 * nw ? (rest - T1) : QUEUE_T3 * nw;
     constexpr int CHUNK = QUEUE_CHUNK;
     const int mid = rest - T1 - T3, T2 = (mid + CHUNK - 1) / CHUNK;
-    // The loop is pipelined over agents.  While agent i is solved the wave already holds the AGENT behind queue position
-    // i+1 (order[pos] loaded during the solve of agent i-1... i: off the critical path) and has the ticket of position i+2
-    // in flight: per agent one memory round trip is exposed (its set-up loads, all issued together by solve_body) instead of
-    // ticket -> order -> header -> state -> rows.  A wave holds at most two claimed positions ahead of the one it works on.
+    // The next ticket is claimed right before the current agent is solved and read after it: the atomic's latency hides behind the
+    // solve.  (Claiming two positions ahead -- the agent behind the next ticket resolved through the order during the solve, so that
+    // only one memory round trip per agent is exposed -- was built and measured in round 3: 0.935 against 0.891 ms on the headline
+    // launch.  A claimed position waits behind its wave's current agent, and when that one is a 300-500 us infeasibility proof the
+    // light agents parked behind it end the launch late.)
     const bool dyn = P.counter != nullptr;
     auto resolve = [&](int ps) -> int { return (ps < total && P.order) ? P.order[ps] : ps; };   // queue position -> agent
     auto decode = [&](int t, int &left) -> int {   // ticket -> first position it stands for (+ `left` further ones)
@@ -897,43 +898,34 @@ __global__ __launch_bounds__(512, 1) void dmpc_solve_persist_kernel(StepParams P
         }
         return nw + T1 + mid + (t - T1 - T2);
     };
-    int pos = wave * (int)gridDim.x + (int)blockIdx.x;   // first round: static
-    if (pos >= total) return;
-    int agent = resolve(pos);
-    // position after the first: a ticket (or the static stride); its agent is loaded during the first solve
-    int left = 0, pos_n, tkv = 0;
-    if (dyn) {
-        if (lane == 0) tkv = atomicAdd(P.counter, 1);
-        pos_n = decode(__builtin_amdgcn_readfirstlane(tkv), left);
-    } else pos_n = pos + nw;
+    int pos = wave * (int)gridDim.x + (int)blockIdx.x, left = 0;
 #ifdef DMPC_DEV_TRACE
     // development: start / end time and agent count of every wave (dmpc_debug_trace with agent = -2)
     const long long t_begin = wall_clock64();
     int n_done = 0;
 #endif
     for (;;) {
+        if (pos >= total) break;
 #ifdef DMPC_DEV_TRACE
         n_done++;
         const long long t_a = wall_clock64();
 #endif
-        const int agent_n = resolve(pos_n);   // in flight during this solve
-        // opaque copy of the lane id: keeps the compiler from hoisting the solver's per-lane constants out of this
-        // loop (they would stay live across the whole body and push the kernel into scratch spills)
+        int tkv = 0;
+        if (dyn && left == 0 && lane == 0) tkv = atomicAdd(P.counter, 1);
         int ln = lane;
         asm volatile("" : "+v"(ln));
-        const bool need_ticket = dyn && left == 0 && pos_n < total;
-        solve_body<SOFT, QCAP, true>(P, ln, agent, total, mine, shtab, need_ticket ? P.counter : nullptr, tkv);
+        int unused = 0;
+        const int agent = resolve(pos);
+        solve_body<SOFT, QCAP, true>(P, ln, agent, total, mine, shtab, nullptr, unused);
         LSYNC();
 #ifdef DMPC_DEV_TRACE
-        // development: start time and duration of every queue position (dmpc_debug_trace with agent = -3)
+        // development: start time and duration of every queue position (dmpc_debug_trace with agent = -3) / of every agent (-5)
         if (P.dbg && P.dbg_agent == -3 && lane == 0) { P.dbg[(size_t)pos * 2] = (double)t_a; P.dbg[(size_t)pos * 2 + 1] = (double)(wall_clock64() - t_a); }
-        if (P.dbg && P.dbg_agent == -5 && lane == 0) { P.dbg[(size_t)agent * 2] = (double)t_a; P.dbg[(size_t)agent * 2 + 1] = (double)(wall_clock64() - t_a); }   // the same by AGENT
+        if (P.dbg && P.dbg_agent == -5 && lane == 0) { P.dbg[(size_t)agent * 2] = (double)t_a; P.dbg[(size_t)agent * 2 + 1] = (double)(wall_clock64() - t_a); }
 #endif
-        pos = pos_n; agent = agent_n;
-        if (pos >= total) break;
-        if (!dyn) pos_n = pos + nw;                      // static round-robin over the (sorted) queue (development)
-        else if (left > 0) { pos_n = pos + 1; left--; }
-        else pos_n = decode(__builtin_amdgcn_readfirstlane(tkv), left);
+        if (!dyn) { pos += nw; continue; }
+        if (left > 0) { pos++; left--; continue; }
+        pos = decode(__builtin_amdgcn_readfirstlane(tkv), left);
     }
 #ifdef DMPC_DEV_TRACE
     if (P.dbg && P.dbg_agent == -2 && lane == 0) {
@@ -1074,7 +1066,7 @@ __global__ __launch_bounds__(64) void nbr_kernel(int S, int G, int C, int g_loca
 // interleaved sequence is heaviest-first overall up to the differences between the slices.
 __global__ void order_kernel(int count, const int *__restrict__ hdr, int *__restrict__ order, int *__restrict__ live_bound)
 {
-    // (agents the scan already finished -- hdr[4] & 16 -- sort behind everything else: bucket 256.  Slice b puts its live agents at
+    // (agents the scan already finished -- hdr[7] & 256, as hdr[4] & 16 -- sort behind everything else: bucket 256.  Slice b puts its live agents at
     // positions b, b + nb, ...: every position from nb * max_b(live agents of slice b) on holds a finished agent, and that bound
     // is what the solve queue runs to.)
     __shared__ int hist[257];
@@ -1083,7 +1075,8 @@ __global__ void order_kernel(int count, const int *__restrict__ hdr, int *__rest
     for (int i = threadIdx.x; i < 257; i += blockDim.x) hist[i] = 0;
     __syncthreads();
     for (int i = b + nb * (int)threadIdx.x; i < count; i += nb * (int)blockDim.x) {
-        const int key = (hdr[(size_t)i * 8 + 4] & 16) ? 256 : 255 - (hdr[(size_t)i * 8 + 7] & 255);   // bucket: heaviest first
+        const int h7 = hdr[(size_t)i * 8 + 7];
+        const int key = (h7 & 256) ? 256 : 255 - (h7 & 255);   // bucket: heaviest first
         atomicAdd(&hist[key], 1);
     }
     __syncthreads();
@@ -1094,7 +1087,8 @@ __global__ void order_kernel(int count, const int *__restrict__ hdr, int *__rest
     }
     __syncthreads();
     for (int i = b + nb * (int)threadIdx.x; i < count; i += nb * (int)blockDim.x) {
-        const int key = (hdr[(size_t)i * 8 + 4] & 16) ? 256 : 255 - (hdr[(size_t)i * 8 + 7] & 255);
+        const int h7 = hdr[(size_t)i * 8 + 7];
+        const int key = (h7 & 256) ? 256 : 255 - (h7 & 255);
         order[(size_t)atomicAdd(&offs[key], 1) * nb + b] = i;
     }
 }

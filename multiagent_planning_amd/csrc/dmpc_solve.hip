@@ -95,13 +95,17 @@ __device__ __forceinline__ double wave_max0(double v)   // v >= 0 on every lane
     return readlane_d(v, 63);
 }
 
-// the kernel's StepParams argument as it lies in the kernel-argument segment (first and only argument of every solve kernel);
-// the empty asm keeps the compiler from recognising the pointer, so fields read through it are loaded where they are used
-__device__ __forceinline__ const StepParams *kernarg_params()
+// The kernel's StepParams argument as it lies in the kernel-argument segment (first and only argument of every solve kernel), through a
+// pointer in the CONSTANT address space: fields read through it are scalar loads (s_load, the scalar cache) issued where they are used.
+// The empty asm keeps the compiler from recognising the pointer and hoisting the loads -- values kept in SGPRs across the solver loop
+// were spilled to VGPR lanes.  (A generic pointer here made every field a flat VECTOR load with the pointer in VGPRs: two dependent
+// memory round trips per output array in the output stage of every agent.)
+typedef const StepParams __attribute__((address_space(4))) *KargPtr;
+__device__ __forceinline__ KargPtr kernarg_params()
 {
-    const void *p = (const void *)__builtin_amdgcn_kernarg_segment_ptr();
+    KargPtr p = (KargPtr)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(p));
-    return (const StepParams *)p;
+    return p;
 }
 
 // uniform description of one constraint
@@ -190,30 +194,26 @@ __device__ __forceinline__ void remove_slot2(double *B, int lane, int &q, int l,
         double cc = 1.0, ss = 0.0;
         if (Sj > 1e-300) { const double inv = rsqrt(Sj); cc = bj * inv; ss = aj * inv; }
         LSYNC();
-        B[SL::XS + lane] = cc; B[SL::RR + lane] = ss;
+        B[SL::RR + 2 * lane] = cc; B[SL::RR + 2 * lane + 1] = ss;   // (cosine, sine) pairs over RR | XS (128 doubles, contiguous): one 16-byte broadcast read each
         LSYNC();
     }
-    // the sweep, four columns per round: the twelve LDS reads of a round (columns and rotations) are in flight together, the
-    // dependent path is the two multiply-adds per column.  (Columns beyond q - 1 are read masked; their rotations are identities.)
+    // the sweep, two columns per round (their LDS reads in flight together); the dependent path is two multiply-adds per column
+    static_assert(SL::XS == SL::RR + 64, "rotation pairs span the two staging vectors");
+    const double2 *rot = (const double2 *)__builtin_assume_aligned(B + SL::RR, 16);
     double carry = (lane <= l) ? T[tcol(l) + lane] : 0.0;
     const int row = lane < l ? lane : lane - 1;
-    for (int j0 = l; j0 < q - 1; j0 += 4) {
-        double rt[4], cj[4], sj[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = j0 + u;
-            const int jc = j + 1 < QCAP ? j + 1 : QCAP - 1;
-            rt[u] = (j + 1 < q && lane <= j + 1) ? T[tcol(jc) + lane] : 0.0;
-            cj[u] = B[SL::XS + (j & 63)]; sj[u] = B[SL::RR + (j & 63)];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = j0 + u;
-            if (j < q - 1) {
-                const double nl = cj[u] * carry - sj[u] * rt[u];
-                carry = sj[u] * carry + cj[u] * rt[u];
-                if (lane <= j + 1 && lane != l) T[tcol(j) + row] = nl;
-            }
+    for (int j0 = l; j0 < q - 1; j0 += 2) {
+        const int j1 = j0 + 1 < q - 1 ? j0 + 1 : j0;   // (an odd tail repeats its column: harmless reads, the second update masked)
+        const double r0 = (lane <= j0 + 1) ? T[tcol(j0 + 1) + lane] : 0.0;
+        const double r1 = (lane <= j1 + 1) ? T[tcol(j1 + 1) + lane] : 0.0;
+        const double2 c0 = rot[j0], c1 = rot[j1];
+        const double n0 = c0.x * carry - c0.y * r0;
+        carry = c0.y * carry + c0.x * r0;
+        if (lane <= j0 + 1 && lane != l) T[tcol(j0) + row] = n0;
+        if (j0 + 1 < q - 1) {
+            const double n1 = c1.x * carry - c1.y * r1;
+            carry = c1.y * carry + c1.x * r1;
+            if (lane <= j1 + 1 && lane != l) T[tcol(j1) + row] = n1;
         }
     }
     // the column that dropped out: back to zero up to the end of its group (keeps "zero below the diagonal" for the next append)
@@ -239,33 +239,33 @@ __device__ __forceinline__ void remove_slot2(double *B, int lane, int &q, int l,
 // Closed loops, tiny launches: the work of post_step_kernel for one agent (dmpc_soft_bound.m:132-134, the history column,
 // ReachedGoal.m:3-11), done by the wave that produced the agent's step; p_out, v_out, a_out: lanes 0..2 hold the first horizon column.
 // The scene's maximum / OR / count are order-independent, so which wave finishes last changes nothing.
-__device__ __forceinline__ void post_step_part(const StepParams &Q, const int lane, const int gid, const int scene, const bool solved,
+__device__ __forceinline__ void post_step_part(const KargPtr Qp, const int lane, const int gid, const int scene, const bool solved,
                                                const int status, const double p_out, const double v_out, const double a_out)
 {
     {
         double xn = 0.0, vn = 0.0, an = 0.0, e2 = 0.0;
         if (lane < 3) {
             const size_t b = (size_t)gid * 3 + lane;
-            xn = solved ? p_out : Q.post_xp[b]; vn = solved ? v_out : Q.post_xv[b]; an = solved ? a_out : Q.post_xa[b];
-            if (solved) { Q.post_xp[b] = xn; Q.post_xv[b] = vn; Q.post_xa[b] = an; }
-            const size_t ho = ((size_t)gid * Q.post_KT + Q.post_k) * 3 + lane;
-            Q.post_pk[ho] = xn; Q.post_vk[ho] = vn; Q.post_ak[ho] = an;
-            const double dd = xn - Q.pf[b];
+            xn = solved ? p_out : Qp->post_xp[b]; vn = solved ? v_out : Qp->post_xv[b]; an = solved ? a_out : Qp->post_xa[b];
+            if (solved) { Qp->post_xp[b] = xn; Qp->post_xv[b] = vn; Qp->post_xa[b] = an; }
+            const size_t ho = ((size_t)gid * Qp->post_KT + Qp->post_k) * 3 + lane;
+            Qp->post_pk[ho] = xn; Qp->post_vk[ho] = vn; Qp->post_ak[ho] = an;
+            const double dd = xn - Qp->pf[b];
             e2 = dd * dd;
         }
         const double dx2 = readlane_d(e2, 0), dy2 = readlane_d(e2, 1), dz2 = readlane_d(e2, 2);
         if (lane == 0) {
             const double dist = sqrt(dx2 + dy2 + dz2);
-            atomicMax(Q.post_max + scene, (unsigned long long)__double_as_longlong(dist));
-            atomicOr(Q.post_or + scene, status);
+            atomicMax(Qp->post_max + scene, (unsigned long long)__double_as_longlong(dist));
+            atomicOr(Qp->post_or + scene, status);
             __threadfence();
-            if (atomicAdd(Q.post_cnt + scene, 1) == Q.c_count - 1) {   // the scene's last agent of this step
-                const unsigned long long mb = atomicExch(Q.post_max + scene, 0ull);
-                const int orv = atomicExch(Q.post_or + scene, 0);
-                Q.post_cnt[scene] = 0;
-                const int reached = __longlong_as_double((long long)mb) < Q.post_tol ? 1 : 0;
-                Q.post_flags[(size_t)scene * 2] = reached; Q.post_flags[(size_t)scene * 2 + 1] = orv;
-                if (Q.post_done && (reached || (orv & ~ST_SOLVED))) Q.post_done[scene] = 1;
+            if (atomicAdd(Qp->post_cnt + scene, 1) == Qp->c_count - 1) {   // the scene's last agent of this step
+                const unsigned long long mb = atomicExch(Qp->post_max + scene, 0ull);
+                const int orv = atomicExch(Qp->post_or + scene, 0);
+                Qp->post_cnt[scene] = 0;
+                const int reached = __longlong_as_double((long long)mb) < Qp->post_tol ? 1 : 0;
+                Qp->post_flags[(size_t)scene * 2] = reached; Qp->post_flags[(size_t)scene * 2 + 1] = orv;
+                if (Qp->post_done && (reached || (orv & ~ST_SOLVED))) Qp->post_done[scene] = 1;
             }
         }
     }
@@ -327,11 +327,11 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
     if (h1.x & 16) {   // finished by the scan (unconstrained exit): nothing to solve; a fused post-step still takes its outputs
         after_loads();
         if (P.post_on) {
-            const StepParams &Q = *kernarg_params();
-            const int st_done = Q.status[gid];
+            const KargPtr Qp = kernarg_params();
+            const int st_done = Qp->status[gid];
             double p1 = 0.0, v1 = 0.0, a1 = 0.0;
-            if (lane < 3) { p1 = Q.p_out[(size_t)gid * N3 + lane]; v1 = Q.v_out[(size_t)gid * N3 + lane]; a1 = Q.a_out[(size_t)gid * N3 + lane]; }
-            post_step_part(Q, lane, gid, scene, (st_done & ST_SOLVED) != 0, st_done, p1, v1, a1);
+            if (lane < 3) { p1 = Qp->p_out[(size_t)gid * N3 + lane]; v1 = Qp->v_out[(size_t)gid * N3 + lane]; a1 = Qp->a_out[(size_t)gid * N3 + lane]; }
+            post_step_part(Qp, lane, gid, scene, (st_done & ST_SOLVED) != 0, st_done, p1, v1, a1);
         }
         return;
     }
@@ -522,21 +522,23 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                     const double fp = (cslot & 0x40000u) ? -1.0 : ((cslot & 0x80000u) ? 1.0 : 0.0);
                     const double U = fma(fb, rb, pU);
                     double Y = fma(fp, rp, pY);
-                    // (four collision slots per round: the eight LDS reads of a round are in flight together; solveSoftDMPCbound puts all
-                    // rows on ONE horizon step, whose three lanes then walk every collision slot of the working set here)
+                    // (slack variants: four collision slots per round, the eight LDS reads of a round in flight together -- solveSoftDMPCbound
+                    // puts all rows on ONE horizon step, whose three lanes then walk every collision slot of the working set here; the
+                    // slack-free variants spread their rows over the steps, a lane meets one or two slots: one per round)
+                    constexpr int MW = SOFT ? 4 : 1;
                     unsigned long long m = cm;
                     while (__any(m != 0ull)) {
-                        int jj[4]; bool hv[4]; double rj[4], vj[4];
+                        int jj[MW]; bool hv[MW]; double rj[MW], vj[MW];
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
+                        for (int u = 0; u < MW; ++u) {
                             hv[u] = m != 0ull;
                             jj[u] = hv[u] ? (__ffsll((long long)m) - 1) : 0;
                             m &= m - 1ull;
                         }
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) { rj[u] = B[SL::RR + jj[u]]; vj[u] = B[SL::SVEC + 3 * jj[u] + ax_l]; }
+                        for (int u = 0; u < MW; ++u) { rj[u] = B[SL::RR + jj[u]]; vj[u] = B[SL::SVEC + 3 * jj[u] + ax_l]; }
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) Y = hv[u] ? fma(-rj[u], vj[u], Y) : Y;
+                        for (int u = 0; u < MW; ++u) Y = hv[u] ? fma(-rj[u], vj[u], Y) : Y;
                     }
                     B[SL::Y + lane] = Y;
                     LSYNC();
@@ -836,15 +838,6 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                 // ---- inner loop: partial steps until p can be added
                 for (;;) {
                     if (++iters > P.iter_cap) { rc = 3; break; }
-                    // An agent that has already taken many iterations is a long one, and the launch ends with the longest: its wave
-                    // gets issue priority over the wave it shares the SIMD with (which works through light agents and fills the slots
-                    // the long dependent chains of this one leave).  Scheduling only.
-                    {
-                        const int itall = iters_total + iters;
-                        if (itall == 6) __builtin_amdgcn_s_setprio(1);
-                        else if (itall == 20) __builtin_amdgcn_s_setprio(2);
-                        else if (itall == 40) __builtin_amdgcn_s_setprio(3);
-                    }
                     // s = N_W' H^-1 n_p on the slot lanes
                     double sv = 0.0;
                     int mymeta = 0;
@@ -1052,8 +1045,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
     // ---------------------------------------------------------------- a9/a10: propagate, outputs
     // The launch parameters the output stage needs are read again from the kernel-argument segment (scalar loads through an
     // opaque pointer) instead of staying live in SGPRs across the solver loop, where they were spilled to VGPR lanes.
-    __builtin_amdgcn_s_setprio(0);
-    const StepParams &Q = *kernarg_params();
+    const KargPtr Qp = kernarg_params();
     int nslack = 0;
     if (solved) {
         status |= ST_SOLVED;
@@ -1068,7 +1060,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
         // p = A_p a + A_initp [po;vo] ; v = A_v a + vo   (propStatedmpc.m:3-4); p0_l, vo_l: per-lane copies kept from the set-up
         // (the uniform state would cost a dozen SGPRs across the solver loop, a second read a memory round trip here)
         p_out = w + p0_l;
-        v_out = vel_out(B + SL::A, k_l, ax_l, Q.h, vo_l);
+        v_out = vel_out(B + SL::A, k_l, ax_l, Qp->h, vo_l);
         a_out = a;
     }
     if (solved) {
@@ -1077,36 +1069,37 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
         if (ob_check) {   // is_inbounds.m:2-5 on p(:,1)
             const double tolb = 50e-3;
             bool bad = false;
-            if (lane < 3) bad = !(p_out < sel3(Q.pmax, lane) + tolb) || !(p_out > sel3(Q.pmin, lane) - tolb);
+            const double hi3 = lane == 0 ? Qp->pmax[0] : (lane == 1 ? Qp->pmax[1] : Qp->pmax[2]), lo3 = lane == 0 ? Qp->pmin[0] : (lane == 1 ? Qp->pmin[1] : Qp->pmin[2]);
+            if (lane < 3) bad = !(p_out < hi3 + tolb) || !(p_out > lo3 - tolb);
             if (__any(bad)) status |= ST_OUTBOUND;
         }
     }
     if (comp) {
-        Q.p_out[(size_t)gid * N3 + lane] = p_out;
-        Q.v_out[(size_t)gid * N3 + lane] = v_out;
-        Q.a_out[(size_t)gid * N3 + lane] = a_out;
-        if (Q.lT_next) {
+        Qp->p_out[(size_t)gid * N3 + lane] = p_out;
+        Qp->v_out[(size_t)gid * N3 + lane] = v_out;
+        Qp->a_out[(size_t)gid * N3 + lane] = a_out;
+        if (Qp->lT_next) {
             // next table chunk [S][3K][C]: uniform 64-bit base, 32-bit per-lane offset; unsolved agents keep their old prediction
-            const int Cq = Q.C;
-            // (mixed precision: Q.lT is the fp32 table of the scan; the fp64 predictions of this chunk are in Q.own_prev)
-            const double *own = Q.own_prev ? Q.own_prev + (size_t)scene * N3 * Cq + cl : Q.lT + ((size_t)(Q.g_local * Q.S + scene) * N3) * Cq + cl;
-            Q.lT_next[(size_t)scene * N3 * Cq + cl + (size_t)(unsigned)(lane * Cq)] = solved ? p_out : own[(size_t)(unsigned)(lane * Cq)];
+            const int Cq = Qp->C;
+            // (mixed precision: Qp->lT is the fp32 table of the scan; the fp64 predictions of this chunk are in Qp->own_prev)
+            const double *own = Qp->own_prev ? Qp->own_prev + (size_t)scene * N3 * Cq + cl : Qp->lT + ((size_t)(Qp->g_local * Qp->S + scene) * N3) * Cq + cl;
+            Qp->lT_next[(size_t)scene * N3 * Cq + cl + (size_t)(unsigned)(lane * Cq)] = solved ? p_out : own[(size_t)(unsigned)(lane * Cq)];
         }
     }
-    if (Q.post_on) post_step_part(Q, lane, gid, scene, solved, status, p_out, v_out, a_out);
+    if (Qp->post_on) post_step_part(Qp, lane, gid, scene, solved, status, p_out, v_out, a_out);
     if (lane == 0) {
-        Q.status[gid] = status;
-        if (Q.info) {
-            int *inf = Q.info + (size_t)gid * 8;
+        Qp->status[gid] = status;
+        if (Qp->info) {
+            int *inf = Qp->info + (size_t)gid * 8;
             inf[0] = viol_k; inf[1] = nrows_built; inf[2] = tries; inf[3] = ccase;
             inf[4] = iters_total; inf[5] = nslack; inf[6] = solved ? q : 0; inf[7] = maxq;
 #ifdef DMPC_DEV_TRACE
-            if (ph_on && Q.dbg_cap >= 4) {
+            if (ph_on && Qp->dbg_cap >= 4) {
                 PH(9 > 8 ? 4 : 4);
-                double *d = Q.dbg + (size_t)(Q.dbg_cap - 3) * 8;
+                double *d = Qp->dbg + (size_t)(Qp->dbg_cap - 3) * 8;
                 for (int u = 0; u < 20; ++u) d[u] = (double)phv[u];
             }
-            if (Q.dbg_agent == -4) { inf[0] = dev_nfast; inf[1] = dev_rounds; inf[3] = dev_negdrops; }   // development: crash statistics in place of the branch record
+            if (Qp->dbg_agent == -4) { inf[0] = dev_nfast; inf[1] = dev_rounds; inf[3] = dev_negdrops; }   // development: crash statistics in place of the branch record
 #endif
         }
     }

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Condense the rocprofv3 passes of tools/gpu_profile_round.sh into one JSON (stdout): per kernel and launch the counter
 averages; for the solve kernel the HBM-side traffic per launch, the instruction mix per solve and the issue fractions the bench
-line reports next to the HBM roofline.  usage: profile_summary.py gpurun_out/profile_round [solves_per_launch]"""
+line reports next to the HBM roofline.  usage: profile_summary.py gpurun_out/profile_round [solves_per_launch] [kernel name substring]"""
 import collections
 import csv
 import json
@@ -10,12 +10,13 @@ import sys
 
 root = sys.argv[1]
 spl = int(sys.argv[2]) if len(sys.argv) > 2 else 51200
+kern_sub = sys.argv[3] if len(sys.argv) > 3 else "solve_persist"
 CLOCK_HZ = 2.4e9            # MI355X peak engine clock (/opt/skills/guides/MI355X_MICROARCH.md); the counters are in cycles
 N_SIMD = 256 * 4            # 256 CUs x 4 SIMDs
 
 
-def short(n):
-    return n.split("(")[0].replace("void ", "").split("<")[0].replace("dmpc::", "")
+def short(n):   # template arguments kept: the slack-free and the slack-carrying solve kernels are different kernels
+    return n.split("(")[0].replace("void ", "").replace("dmpc::", "").strip()
 
 
 def counters(path):
@@ -26,7 +27,7 @@ def counters(path):
 
 
 passes = {}
-for name in ("fetch", "write", "sq", "sq2"):
+for name in ("fetch", "write", "sq", "sq2", "sq3"):
     p = os.path.join(root, name, f"{name}_counter_collection.csv")
     if os.path.exists(p):
         passes[name] = counters(p)
@@ -37,7 +38,7 @@ stats = {}
 if os.path.exists(kt):
     for r in csv.DictReader(open(kt)):
         stats[short(r["Name"])] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3, "pct": float(r["Percentage"])}
-out["kernel_stats"] = {k: v for k, v in stats.items() if k.startswith("dmpc") or k in ("order_kernel", "bbox_kernel")}
+out["kernel_stats"] = {k: v for k, v in stats.items() if k.startswith("dmpc") or k.split("<")[0] in ("order_kernel", "bbox_kernel", "nbr_kernel", "table_nbrmajor_kernel")}
 KIB = 1024.0
 traffic = {}
 for k in set(passes.get("fetch", {})) | set(passes.get("write", {})):
@@ -45,10 +46,10 @@ for k in set(passes.get("fetch", {})) | set(passes.get("write", {})):
     w = passes.get("write", {}).get(k, {}).get("WRITE_SIZE")
     if f is not None or w is not None:
         traffic[k] = {"fetch_kib": f, "write_kib": w, "bytes": ((f or 0) + (w or 0)) * KIB}
-out["traffic_per_launch"] = {k: v for k, v in traffic.items() if k.startswith("dmpc") or k == "order_kernel"}
-sk = next((k for k in traffic if "solve_persist" in k), None)
+out["traffic_per_launch"] = {k: v for k, v in traffic.items() if k.startswith("dmpc") or k.split("<")[0] in ("order_kernel", "nbr_kernel", "bbox_kernel", "table_nbrmajor_kernel")}
+sk = max((k for k in traffic if kern_sub in k), key=lambda k: stats.get(k, {}).get("pct", 0), default=None)
 if sk:
-    step_kernels = [k for k in traffic if k.startswith("dmpc_s") or k == "order_kernel"]
+    step_kernels = [k for k in traffic if k.startswith("dmpc_s") or k.split("<")[0] in ("order_kernel", "nbr_kernel", "bbox_kernel", "table_nbrmajor_kernel")]
     out["solve_kernel"] = sk
     out["hbm_bytes_per_launch"] = traffic[sk]["bytes"]
     out["whole_step_bytes_per_launch"] = sum(traffic[k]["bytes"] for k in step_kernels)
@@ -67,6 +68,19 @@ if sk:
                         "lds_frac": sq.get("SQ_INSTS_LDS", 0) / slots,
                         "note": f"slots = {N_SIMD} SIMDs x kernel time x {CLOCK_HZ / 1e9:.1f} GHz / 4 (a wave64 instruction occupies a SIMD for 4 cycles); "
                                 "the clock under load is lower than the peak used here, so the fractions are lower bounds"}
+    sq3 = passes.get("sq3", {}).get(sk, {})
+    if sq3 and sq and dur_s:
+        f64 = {c: sq3.get("SQ_INSTS_VALU_" + c, 0.0) for c in ("FMA_F64", "ADD_F64", "MUL_F64", "TRANS_F64")}
+        arith = sum(f64.values())
+        valu = sq.get("SQ_INSTS_VALU", 0) or 1.0
+        # lanes: SQ_THREAD_CYCLES_VALU counts active lanes x cycles; a full wave64 VALU instruction is 64 lanes x 4 cycles
+        lane_util = sq3.get("SQ_THREAD_CYCLES_VALU", 0.0) / (valu * 64.0 * 4.0) if sq3.get("SQ_THREAD_CYCLES_VALU") else None
+        flops = (2.0 * f64["FMA_F64"] + f64["ADD_F64"] + f64["MUL_F64"]) * 64.0 * (lane_util or 1.0)
+        out["fp64"] = {"valu_insts_per_solve": {k.lower(): v / spl for k, v in f64.items()}, "int32_per_solve": sq3.get("SQ_INSTS_VALU_INT32", 0.0) / spl,
+                       "fp64_share_of_valu": arith / valu, "lane_utilisation": lane_util,
+                       "achieved_tflops": flops / dur_s / 1e12, "peak_tflops_vector_fp64": 78.6,
+                       "salu_cycles_per_solve": sq3.get("SQ_INST_CYCLES_SALU", 0.0) / spl, "lds_bank_conflict_cycles_per_solve": sq3.get("SQ_LDS_BANK_CONFLICT", 0.0) / spl,
+                       "note": "fp64 arithmetic = FMA + ADD + MUL + TRANS wave-instructions; flops = (2 FMA + ADD + MUL) x 64 lanes x lane utilisation"}
     if sq2:
         wc = sq2.get("SQ_WAVE_CYCLES", 0) or 1.0
         out["wave_time"] = {"active_any": sq2.get("SQ_ACTIVE_INST_ANY", 0) / wc, "active_valu": sq2.get("SQ_ACTIVE_INST_VALU", 0) / wc,
