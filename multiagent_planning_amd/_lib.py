@@ -115,6 +115,7 @@ def load():
     L.dmpc_transition_sharded_gather.argtypes = [vp, C.c_int, C.c_int, dp, dp, C.c_int, C.c_double, dp, dp, dp, ip, ip]
     L.dmpc_group_size.argtypes = [vp]
     L.dmpc_debug_emulate_devices.argtypes = [C.c_int]
+    L.dmpc_debug_option.argtypes = [vp, C.c_char_p, C.c_int]
     L.dmpc_solve_count.restype = C.c_int64
     L.dmpc_solve_count.argtypes = [vp]
     L.dmpc_profile.argtypes = [vp, C.c_int]
@@ -209,6 +210,12 @@ class Dmpc:
         """tests: DEVICE_ALL contexts created from now on run n ranks that all sit on the current GPU (0: off)"""
         if load().dmpc_debug_emulate_devices(int(n)):
             raise DmpcError("emulate_devices: bad count")
+
+    def debug_option(self, name, value):
+        """development / tests: launch forms and tiers of this context (dmpc_debug_option: no_cull, no_persist, force_persist, tier1_qcap,
+        crash_min, no_fast_exit, iter_cap, split_parts ...); never arithmetic"""
+        self._chk(self._L.dmpc_debug_option(self._ctx, name.encode(), int(value)))
+        return self
 
     def close(self):
         if getattr(self, "_ctx", None):

@@ -89,31 +89,29 @@ struct dmpc_ctx {
     int max_lds_set = 0;
     // scratch for the host-pointer entry points
     DevBuf post_acc; int post_acc_S = 0, post_fused = 0;
-    int no_fuse = getenv("DMPC_NO_FUSE") ? 1 : 0;   // tuning: always launch post_step_kernel
+    int no_fuse = 0;         // development option no_fuse: always launch post_step_kernel
     DevBuf rowbuf, rowkc, hdr, order, bbox, nbr_list, nbr_cnt, lrow, counter, flag_list, scene_done;
     int num_cu = 0;
-    int no_persist = getenv("DMPC_NO_PERSIST") ? 1 : 0;   // tuning: one-agent-per-workgroup solve launches
+    int no_persist = 0;      // development option no_persist: one-agent-per-workgroup solve launches
     int max_lds_persist = 0;
-    int force_persist = getenv("DMPC_FORCE_PERSIST") ? 1 : 0;   // tests: exercise the persistent kernel on small launches
-    // per-neighbour bounding-box culling in the scan of large scenes (DMPC_NO_CULL=1 disables it, for A/B runs)
-    int no_cull = getenv("DMPC_NO_CULL") ? 1 : 0;
-    int no_lpt = getenv("DMPC_NO_LPT") ? 1 : 0;   // tuning: disable the heaviest-first solve order
-    int crash_min = getenv("DMPC_CRASH_MIN") ? atoi(getenv("DMPC_CRASH_MIN")) : CRASH_MIN_DEFAULT;   // see StepParams::crash_min
-    // retry ladder: every level from scratch (default).  DMPC_LADDER_WARM=1 keeps working set, factor and multipliers across levels:
-    // faster (C4 ladder agents 100 -> 65 iterations) but NOT safe -- the randomized campaign found agent-steps of solveSoftDMPCall
-    // that end infeasible or off by 8e-4 on the factor an infeasible try leaves behind, even with a conditioning guard
-    int ladder_warm = getenv("DMPC_LADDER_WARM") ? 1 : 0;
-    int no_fast_exit = getenv("DMPC_NO_FAST_EXIT") ? 1 : 0;   // tests: every agent through the solve kernel (the unconstrained exit of the scan off)
-    int iter_cap = getenv("DMPC_ITER_CAP") ? atoi(getenv("DMPC_ITER_CAP")) : ITER_CAP;   // development: cap the active-set iterations (agents beyond it end DMPC_ST_ITERCAP)
-    int tier1_env = getenv("DMPC_TIER1_QCAP") ? atoi(getenv("DMPC_TIER1_QCAP")) : 0;   // tuning / tests: 32 = two tiers for the slack variants (any value: no shallow-launch shortcut)
+    int force_persist = 0;   // development option force_persist (tests): the persistent kernel on small launches
+    int no_cull = 0;         // development option no_cull: no neighbour lists in the scan of large scenes (A/B runs, tests)
+    int no_lpt = 0;          // development option no_lpt: no heaviest-first solve order
+    int crash_min = CRASH_MIN_DEFAULT;   // see StepParams::crash_min (development option crash_min; crash_any: also for the slack-free variants)
+    int crash_any = 0;
+    int no_fast_exit = 0;    // development option no_fast_exit (tests): every agent through the solve kernel (the unconstrained exit of the scan off)
+    int iter_cap = ITER_CAP; // development option iter_cap: cap of the active-set iterations (agents beyond it end DMPC_ST_ITERCAP)
+    int tier1_env = 0;       // development option tier1_qcap (tests): 32 = two tiers for the slack variants (any value: no shallow-launch shortcut)
     int single_tier = 0;         // 1: solve with the full working-set capacity in one launch
     DevBuf lTf, lTf2;            // mixed precision: fp32 copies of the tables the scan reads
     DevBuf rows, lT, lT2, xp, xv, xa, pf, po, pout, vout, aout, status, info, hist_p, hist_v, hist_a, flags;
     int hist_S = 0, hist_N = 0, hist_KT = 0;   // shape of the histories left resident by the last dmpc_transition
     int pc_fallback_scenes = 0;   // last dmpc_postcheck: scenes of a cell-grid search that were searched again by brute force
-    dmpc_ctx *child = nullptr;   // second context (own stream and buffers) for the other half of a split batch of transitions
-    int split_S0 = 0;            // > 0: the last dmpc_transition left scenes [0, split_S0) here and the rest in `child`
-    int no_split = getenv("DMPC_NO_SPLIT") ? 1 : 0;
+    std::vector<dmpc_ctx *> children;   // further contexts (own stream and buffers) for the other parts of a split batch of transitions
+    std::vector<int> split_at;          // non-empty: the last dmpc_transition left scenes [split_at[i], split_at[i+1]) in part i (0: here, i > 0: children[i-1])
+    int split_parts = 0;     // development option split_parts: number of parts (0: the built-in rule)
+    int no_split = 0;        // development option no_split
+    int static_queue = 0;    // development option static_queue: persistent waves take queue positions round-robin instead of by ticket
     DevBuf pc_p, pc_v, pc_a, pc_M, pc_w, pc_scene, pc_agent, pc_interp;   // post-check work buffers
     DevBuf pc_pts, pc_cell, pc_fill, pc_start, pc_sorted, pc_on;           // post-check, large scenes: cell grid of a batch of samples
     // multi-GPU (dmpc_multigpu.hip): RCCL communicator of this rank, exchange buffers
@@ -132,7 +130,7 @@ struct dmpc_ctx {
     double *dbg = nullptr; int dbg_agent = -1, dbg_cap = 0;   // development trace (dmpc_debug_trace)
     DevBuf forced_order; int forced_n = 0;                    // development aid (dmpc_debug_set_order)
     struct Ev { hipEvent_t t0, t1, t2; };   // step start | scan+order done | solve tiers done
-    std::vector<Ev> events;
+    std::vector<Ev> events, ev_pool;
     double prof_scan_ms_sum = 0.0;
     double prof_ms_sum = 0.0;
     int64_t prof_n = 0;
@@ -346,6 +344,43 @@ extern "C" int dmpc_debug_emulate_devices(int n)
     return 0;
 }
 
+// Development / test options of a context (not in the public header; nothing in the library reads the environment per call).  They select
+// launch forms and tiers, never arithmetic: every combination returns the same bits (tests/test_gpu_paths.py).  A process can preset them for
+// the contexts it creates with ONE environment variable, DMPC_DEBUG_OPTIONS="name=value,name=value" (the probes under tools/).
+extern "C" int dmpc_debug_option(dmpc_ctx *ctx, const char *name, int value)
+{
+    if (!ctx || !name) return -1;
+    struct { const char *n; int dmpc_ctx::*f; } tab[] = {
+        {"no_fuse", &dmpc_ctx::no_fuse}, {"no_persist", &dmpc_ctx::no_persist}, {"force_persist", &dmpc_ctx::force_persist}, {"no_cull", &dmpc_ctx::no_cull},
+        {"no_lpt", &dmpc_ctx::no_lpt}, {"crash_min", &dmpc_ctx::crash_min}, {"crash_any", &dmpc_ctx::crash_any}, {"no_fast_exit", &dmpc_ctx::no_fast_exit},
+        {"iter_cap", &dmpc_ctx::iter_cap}, {"tier1_qcap", &dmpc_ctx::tier1_env}, {"split_parts", &dmpc_ctx::split_parts}, {"no_split", &dmpc_ctx::no_split},
+        {"static_queue", &dmpc_ctx::static_queue}};
+    for (auto &t : tab)
+        if (!std::strcmp(t.n, name)) {
+            ctx->*(t.f) = value;
+            for (dmpc_ctx *pc : ctx->peers) pc->*(t.f) = value;
+            for (dmpc_ctx *ch : ctx->children) ch->*(t.f) = value;
+            return 0;
+        }
+    ctx->err = std::string("dmpc_debug_option: unknown option ") + name;
+    return -1;
+}
+static void options_from_env(dmpc_ctx *ctx)
+{
+    const char *e = getenv("DMPC_DEBUG_OPTIONS");
+    if (!e) return;
+    std::string all(e);
+    size_t pos = 0;
+    while (pos < all.size()) {
+        size_t end = all.find(',', pos);
+        if (end == std::string::npos) end = all.size();
+        const std::string item = all.substr(pos, end - pos);
+        const size_t eq = item.find('=');
+        if (eq != std::string::npos) (void)dmpc_debug_option(ctx, item.substr(0, eq).c_str(), atoi(item.c_str() + eq + 1));
+        pos = end + 1;
+    }
+}
+
 static dmpc_ctx *create_one(const dmpc_params *prm, int device, int precision)
 {
     if (hipSetDevice(device) != hipSuccess) { g_err = "dmpc_create: hipSetDevice failed"; return nullptr; }
@@ -360,6 +395,7 @@ static dmpc_ctx *create_one(const dmpc_params *prm, int device, int precision)
         return nullptr;
     }
     if (hipDeviceGetAttribute(&ctx->num_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) ctx->num_cu = 0;
+    options_from_env(ctx);
     return ctx;
 }
 
@@ -427,7 +463,8 @@ extern "C" void dmpc_destroy(dmpc_ctx *ctx)
     if (!ctx) return;
     for (dmpc_ctx *pc : ctx->peers) dmpc_destroy(pc);
     ctx->peers.clear();
-    if (ctx->child) { dmpc_destroy(ctx->child); ctx->child = nullptr; }
+    for (dmpc_ctx *ch : ctx->children) dmpc_destroy(ch);
+    ctx->children.clear();
     if (ctx->comm) (void)dmpc_comm_destroy(ctx);
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
@@ -437,6 +474,7 @@ extern "C" void dmpc_destroy(dmpc_ctx *ctx)
     }
     ctx->grp = nullptr;
     for (auto &ev : ctx->events) { (void)hipEventDestroy(ev.t0); (void)hipEventDestroy(ev.t1); (void)hipEventDestroy(ev.t2); }
+    for (auto &ev : ctx->ev_pool) { (void)hipEventDestroy(ev.t0); (void)hipEventDestroy(ev.t1); (void)hipEventDestroy(ev.t2); }
     if (ctx->dbg) (void)hipFree(ctx->dbg);
     if (ctx->d_tables) (void)hipFree(ctx->d_tables);
     hipStream_t st = ctx->stream;
@@ -459,7 +497,8 @@ extern "C" int dmpc_set_params(dmpc_ctx *ctx, const dmpc_params *prm)
 extern "C" int64_t dmpc_solve_count(const dmpc_ctx *ctx)
 {
     if (!ctx) return 0;
-    int64_t n = ctx->solves + (ctx->child ? ctx->child->solves : 0);
+    int64_t n = ctx->solves;
+    for (const dmpc_ctx *ch : ctx->children) n += ch->solves;
     for (const dmpc_ctx *pc : ctx->peers) n += dmpc_solve_count(pc);
     return n;
 }
@@ -468,6 +507,14 @@ extern "C" int dmpc_profile(dmpc_ctx *ctx, int enable)
 {
     if (!ctx) return -1;
     ctx->profile = enable;
+    if (enable && ctx->ev_pool.size() < 64) {   // a pool for the next steps, created outside any timed loop
+        HIPCHK(ctx, hipSetDevice(ctx->device));
+        while (ctx->ev_pool.size() < 64) {
+            dmpc_ctx::Ev ev{nullptr, nullptr, nullptr};
+            HIPCHK(ctx, hipEventCreate(&ev.t0)); HIPCHK(ctx, hipEventCreate(&ev.t1)); HIPCHK(ctx, hipEventCreate(&ev.t2));
+            ctx->ev_pool.push_back(ev);
+        }
+    }
     return 0;
 }
 
@@ -563,10 +610,9 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     P.iter_cap = ctx->iter_cap;
     // (not for solveHardDMPC: rows at every horizon step, 3 % of the agents would qualify and every scan would pay for the test)
     P.fast_exit = (ctx->no_fast_exit || p.variant == DMPC_VAR_HARD) ? 0 : 1;
-    P.ladder_warm = ctx->ladder_warm;
     // measured: the crash start pays for the slack-carrying variants (C4, N = 10^4: solve launch -16 %) and costs on solveHardDMPC
     // (C2: -16 % throughput: with rows at every horizon step the bounds violated at the unconstrained minimiser are a poor guess)
-    P.crash_min = (soft || getenv("DMPC_CRASH_MIN")) ? ctx->crash_min : 0;
+    P.crash_min = (soft || ctx->crash_any) ? ctx->crash_min : 0;
     // tiny launches (a scene or a few, every agent resident at once: bound by the latency of their slowest agent, LDS is no
     // constraint) solve with the full working-set capacity in one launch; larger ones use the first tier and re-solve the few
     // agents that outgrow it (the smaller footprint also puts 6 instead of 4 one-agent workgroups on a CU: 512 transitions
@@ -603,10 +649,13 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
         ctx->max_lds_set = (int)ldsmax;
     }
     dmpc_ctx::Ev ev{nullptr, nullptr, nullptr};
-    if (ctx->profile) {
-        HIPCHK(ctx, hipEventCreate(&ev.t0));
-        HIPCHK(ctx, hipEventCreate(&ev.t1));
-        HIPCHK(ctx, hipEventCreate(&ev.t2));
+    if (ctx->profile) {   // event triples are recycled (dmpc_profile_read2 returns them to the pool): no event is created inside a timed loop
+        if (!ctx->ev_pool.empty()) { ev = ctx->ev_pool.back(); ctx->ev_pool.pop_back(); }
+        else {
+            HIPCHK(ctx, hipEventCreate(&ev.t0));
+            HIPCHK(ctx, hipEventCreate(&ev.t1));
+            HIPCHK(ctx, hipEventCreate(&ev.t2));
+        }
         HIPCHK(ctx, hipEventRecord(ev.t0, st));
     }
     const dim3 grid((unsigned)(S * c_count)), block(64);
@@ -712,7 +761,7 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
             HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_persist_kernel<false, 48>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             ctx->max_lds_persist = (int)lds;
         }
-        P.counter = getenv("DMPC_STATIC_QUEUE") ? nullptr : ctx->counter.as<int>() + tier;
+        P.counter = ctx->static_queue ? nullptr : ctx->counter.as<int>() + tier;
         P.lds_per_wave = (int)per;
         int wgs = (total + pw - 1) / pw;
         if (wgs > ctx->num_cu) wgs = ctx->num_cu;
@@ -790,7 +839,7 @@ extern "C" int dmpc_profile_read2(dmpc_ctx *ctx, double *solve_avg_ms, double *s
         ctx->prof_scan_ms_sum += ms_scan;
         ctx->prof_ms_sum += ms_solve;
         ctx->prof_n += 1;
-        (void)hipEventDestroy(ev.t0); (void)hipEventDestroy(ev.t1); (void)hipEventDestroy(ev.t2);
+        ctx->ev_pool.push_back(ev);
     }
     ctx->events.clear();
     if (solve_avg_ms) *solve_avg_ms = ctx->prof_n ? ctx->prof_ms_sum / (double)ctx->prof_n : 0.0;
@@ -1140,32 +1189,47 @@ extern "C" int dmpc_transition(dmpc_ctx *ctx, int S, int N, const double *po, co
                                int32_t *scene_status)
 {
     if (!ctx) { g_err = "dmpc_transition: ctx is NULL"; return -1; }
-    ctx->split_S0 = 0;
+    ctx->split_at.clear();
     if (ctx->grp) {   // every visible GPU: the agents of each scene sharded over them (dmpc_multigpu.hip)
         if (S < 1 || N < 1 || K_T_max < 2 || !po || !pf || !K_T_used || !scene_status || ((pk || vk || ak) && !(pk && vk && ak))) FAIL(ctx, "dmpc_transition: bad arguments");
         return group_transition(ctx, S, N, po, pf, K_T_max, error_tol, pk, vk, ak, K_T_used, scene_status);
     }
-    if (S < 32 || ctx->no_split || N < 1 || K_T_max < 2 || !po || !pf || !K_T_used || !scene_status)
+    // parts: every part runs its own MPC loop on its own stream; launches of fewer than ~2000 agents are one-agent workgroups, which the
+    // hardware interleaves across streams freely (persistent launches hold a CU's whole LDS), so many small parts overlap best
+    int parts = ctx->split_parts > 0 ? ctx->split_parts : (S >= 128 ? 4 : (S >= 32 ? 2 : 1));
+    if (parts > S) parts = S;
+    if (parts < 2 || ctx->no_split || N < 1 || K_T_max < 2 || !po || !pf || !K_T_used || !scene_status)
         return transition_one(ctx, S, N, po, pf, K_T_max, error_tol, pk, vk, ak, K_T_used, scene_status);
-    if (!ctx->child) {
-        ctx->child = dmpc_create(&ctx->prm, ctx->device, ctx->precision);
-        if (!ctx->child) FAIL(ctx, "dmpc_transition: second context: " + g_err);
-        ctx->child->no_split = 1;
-    } else if (std::memcmp(&ctx->child->prm, &ctx->prm, sizeof(dmpc_params)) != 0 && dmpc_set_params(ctx->child, &ctx->prm)) {
-        FAIL(ctx, "dmpc_transition: second context: " + ctx->child->err);
+    while ((int)ctx->children.size() < parts - 1) {
+        dmpc_ctx *ch = dmpc_create(&ctx->prm, ctx->device, ctx->precision);
+        if (!ch) FAIL(ctx, "dmpc_transition: further context: " + g_err);
+        ch->no_fuse = ctx->no_fuse; ch->no_persist = ctx->no_persist; ch->force_persist = ctx->force_persist; ch->no_cull = ctx->no_cull;
+        ch->no_lpt = ctx->no_lpt; ch->crash_min = ctx->crash_min; ch->crash_any = ctx->crash_any; ch->no_fast_exit = ctx->no_fast_exit;
+        ch->iter_cap = ctx->iter_cap; ch->tier1_env = ctx->tier1_env; ch->static_queue = ctx->static_queue;
+        ch->no_split = 1;
+        ctx->children.push_back(ch);
     }
-    const int S0 = S / 2, S1 = S - S0;
-    const size_t a0 = (size_t)S0 * N, h0 = a0 * (size_t)K_T_max * 3;
-    int rc1 = 0;
-    std::thread other([&]() {
-        rc1 = transition_one(ctx->child, S1, N, po + a0 * 3, pf + a0 * 3, K_T_max, error_tol, pk ? pk + h0 : nullptr, vk ? vk + h0 : nullptr,
-                             ak ? ak + h0 : nullptr, K_T_used + S0, scene_status + S0);
-    });
-    const int rc0 = transition_one(ctx, S0, N, po, pf, K_T_max, error_tol, pk, vk, ak, K_T_used, scene_status);
-    other.join();
-    if (rc1) FAIL(ctx, ctx->child->err);
-    if (rc0) return -1;
-    ctx->split_S0 = S0;   // the resident histories are split over the two contexts (dmpc_postcheck knows)
+    for (int i = 0; i < parts - 1; ++i)
+        if (std::memcmp(&ctx->children[(size_t)i]->prm, &ctx->prm, sizeof(dmpc_params)) != 0 && dmpc_set_params(ctx->children[(size_t)i], &ctx->prm))
+            FAIL(ctx, "dmpc_transition: further context: " + ctx->children[(size_t)i]->err);
+    std::vector<int> at((size_t)parts + 1);
+    for (int i = 0; i <= parts; ++i) at[(size_t)i] = (int)((long)S * i / parts);
+    std::vector<int> rc((size_t)parts, 0);
+    auto run = [&](int i) {
+        dmpc_ctx *c = i ? ctx->children[(size_t)i - 1] : ctx;
+        const int s0 = at[(size_t)i], sn = at[(size_t)i + 1] - s0;
+        const size_t a0 = (size_t)s0 * N, h0 = a0 * (size_t)K_T_max * 3;
+        rc[(size_t)i] = transition_one(c, sn, N, po + a0 * 3, pf + a0 * 3, K_T_max, error_tol, pk ? pk + h0 : nullptr, vk ? vk + h0 : nullptr,
+                                       ak ? ak + h0 : nullptr, K_T_used + s0, scene_status + s0);
+    };
+    std::vector<std::thread> th;
+    for (int i = 1; i < parts; ++i) th.emplace_back(run, i);
+    run(0);
+    for (auto &t : th) t.join();
+    for (int i = 1; i < parts; ++i)
+        if (rc[(size_t)i]) FAIL(ctx, ctx->children[(size_t)i - 1]->err);
+    if (rc[0]) return -1;
+    ctx->split_at = at;   // the resident histories are split over the contexts (dmpc_postcheck knows)
     ctx->hist_S = S;
     return 0;
 }
@@ -1360,27 +1424,32 @@ extern "C" int dmpc_postcheck(dmpc_ctx *ctx, int S, int N, int KT_alloc, const i
                               int32_t *violation, double *totdist, double *traj_time, double *p_interp, int ns_alloc)
 {
     if (!ctx) { g_err = "dmpc_postcheck: ctx is NULL"; return -1; }
-    const int S0 = ctx->split_S0;
-    if (pk || S0 <= 0 || S0 >= S || ctx->hist_S != S || !ctx->child || !K_T_used || !pf)
+    const int parts = (int)ctx->split_at.size() - 1;
+    if (pk || parts < 2 || ctx->split_at.back() != S || ctx->hist_S != S || (int)ctx->children.size() < parts - 1 || !K_T_used || !pf)
         return postcheck_one(ctx, S, N, KT_alloc, K_T_used, scene_mask, pk, vk, ak, pf, vmax, amax, Ts, r_factor, h_scaled, n_samples,
                              min_dist, violation, totdist, traj_time, p_interp, ns_alloc);
-    // histories left resident by a split dmpc_transition: each half is checked where it lives, concurrently
+    // histories left resident by a split dmpc_transition: each part is checked where it lives, concurrently
     auto off = [&](auto *ptr, size_t o) { return ptr ? ptr + o : ptr; };
-    const size_t a0 = (size_t)S0 * N;
-    ctx->hist_S = S0;
-    int rc1 = 0;
-    std::thread other([&]() {
-        rc1 = postcheck_one(ctx->child, S - S0, N, KT_alloc, K_T_used + S0, off(scene_mask, (size_t)S0), nullptr, nullptr, nullptr, pf + a0 * 3,
-                            vmax, amax, Ts, off(r_factor, (size_t)S0), off(h_scaled, (size_t)S0), off(n_samples, (size_t)S0),
-                            off(min_dist, (size_t)S0), off(violation, (size_t)S0), off(totdist, (size_t)S0), off(traj_time, (size_t)S0),
-                            off(p_interp, a0 * (size_t)ns_alloc * 3), ns_alloc);
-    });
-    const int rc0 = postcheck_one(ctx, S0, N, KT_alloc, K_T_used, scene_mask, nullptr, nullptr, nullptr, pf, vmax, amax, Ts, r_factor, h_scaled,
-                                  n_samples, min_dist, violation, totdist, traj_time, p_interp, ns_alloc);
-    other.join();
-    ctx->hist_S = S;
-    if (rc1) FAIL(ctx, ctx->child->err);
-    return rc0;
+    std::vector<int> rc((size_t)parts, 0);
+    auto run = [&](int i) {
+        dmpc_ctx *c = i ? ctx->children[(size_t)i - 1] : ctx;
+        const int s0 = ctx->split_at[(size_t)i], sn = ctx->split_at[(size_t)i + 1] - s0;
+        const size_t a0 = (size_t)s0 * N;
+        const int keep = c->hist_S;
+        c->hist_S = sn;
+        rc[(size_t)i] = postcheck_one(c, sn, N, KT_alloc, K_T_used + s0, off(scene_mask, (size_t)s0), nullptr, nullptr, nullptr, pf + a0 * 3, vmax, amax, Ts,
+                                      off(r_factor, (size_t)s0), off(h_scaled, (size_t)s0), off(n_samples, (size_t)s0), off(min_dist, (size_t)s0),
+                                      off(violation, (size_t)s0), off(totdist, (size_t)s0), off(traj_time, (size_t)s0),
+                                      off(p_interp, a0 * (size_t)ns_alloc * 3), ns_alloc);
+        c->hist_S = keep;
+    };
+    std::vector<std::thread> th;
+    for (int i = 1; i < parts; ++i) th.emplace_back(run, i);
+    run(0);
+    for (auto &t : th) t.join();
+    for (int i = 1; i < parts; ++i)
+        if (rc[(size_t)i]) FAIL(ctx, ctx->children[(size_t)i - 1]->err);
+    return rc[0];
 }
 
 

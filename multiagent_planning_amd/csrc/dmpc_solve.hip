@@ -473,12 +473,11 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
         // a register of the owning lane (bit c = row lane + 64 c), the rest (and all flags of the soft variants) in LDS bytes
         unsigned rcfl = 0;
         int nlive = 0;
-        // retry ladder, warm: a ladder step changes only right-hand sides (the slack bounds) and the linear cost of the slacks,
-        // no constraint normal -- the factor T of the working set an infeasible try ends with stays valid for the next level.
-        // The next try keeps working set, factor and multipliers, solves the multipliers for the new level in one
-        // refinement pass, drops those that come out negative (the finish of the crash start) and continues from there.
-        bool warm = false;
-        double cond_min = 1.0;
+        // Every ladder level starts from scratch.  (A warm ladder -- the next level keeping working set, factor and multipliers of the
+        // failed one: a ladder step changes right-hand sides and the slacks' linear cost, no constraint normal -- was built in round 2 and
+        // is gone: an infeasible try often ends in a nearly degenerate working set, and the randomized campaign found 6 of 470 550
+        // agent-steps that ended infeasible or with a wrong retry count on the factor it leaves behind, even with a conditioning guard.)
+        constexpr bool warm = false;
         PH(8);
         while (tries < max_tries) {
             tries++;
@@ -505,7 +504,6 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
             bool crash_stop = warm;          // warm: straight to the finish (solve the multipliers of the kept working set)
             bool crash_box = !warm;          // every slot of the batch is an acceleration bound
             int crash_rounds = 0, nfast = 0, accept_drops = 0;
-            if (!warm) cond_min = 1.0;   // smallest delta / s_pp of a constraint appended to the current factor (1: empty factor)
             const double dual0 = dual;
             LSYNC();
 
@@ -863,7 +861,6 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                         const double dlt = spp - wave_sum0(dvj * dvj);
                         if (!(dlt > 1e-9 * spp)) { crash_stop = true; break; }   // (distinct bounds are independent; guard only)
                         const double irho = rsqrt(dlt);
-                        cond_min = fmin(cond_min, dlt / spp);
                         if (lane < ((q + 8) & ~7)) B[SL::T + tcol(q) + lane] = (lane < q) ? (-ri * irho) : ((lane == q) ? irho : 0.0);
                         write_slot(p, 0.0);
                         if (lane == p.idx) cslot = (cslot & ~0xffu) | (unsigned)q | (p.ty == TY_BOXHI ? 0x10000u : 0x20000u);
@@ -953,7 +950,6 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                         // full step: append p (new column of T = [-r/rho ; 1/rho], zero below the diagonal)
                         if (q >= QCAP) { rc = 2; break; }
                         const double irho = rsqrt(delta);
-                        cond_min = fmin(cond_min, delta / spp);
                         if (lane < ((q + 8) & ~7)) B[SL::T + tcol(q) + lane] = (lane < q) ? (-ri * irho) : ((lane == q) ? irho : 0.0);
                         write_slot(p, lam_p);
                         if (p.ty < TY_COLL) {
@@ -1023,13 +1019,6 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                 for (int i = lane; i < nr; i += 64) { r_slb[i] *= f; r_st[i] *= f; }
                 rcslb[0] *= f; rcslb[1] *= f;
                 scale_pow += ilogb(f);
-                // warm start of the next level: the slack lower bounds in the working set get their new right-hand side (d = -lb)
-                // ... but only a well-conditioned one: an infeasible try often ends in a nearly degenerate working set (a constraint
-                // appended with delta / s_pp of 1e-6 leaves a factor with 1e3-1e4 on its diagonal), and continuing on that factor
-                // loses the digits the next level needs (randomized campaign, solveSoftDMPCall: three nearly parallel rows per
-                // neighbour -- 6 of 28 796 agent-steps ended infeasible where a fresh factor finds the solution)
-                warm = P.ladder_warm && q > 0 && cond_min >= 1e-3;
-                if (warm && lane < q && ((s_meta[lane] >> 8) & 0xff) == TY_SLKL) B[SL::SD + lane] *= f;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 LSYNC();

@@ -144,12 +144,10 @@ def test_persistent_and_per_agent_solve_kernels_are_bitwise_identical(variant, m
     po, pf = wl.make_scenes(cfg, S, N, wl.SEED0 + 17)
     outs = []
     # third form: two capacity tiers for the slack variants (32 slots first, the agents that outgrow them re-solved with 64)
-    for env in ({"DMPC_NO_PERSIST": "1"}, {"DMPC_FORCE_PERSIST": "1"}, {"DMPC_FORCE_PERSIST": "1", "DMPC_TIER1_QCAP": "32"}):
-        for k_, v_ in env.items():
-            monkeypatch.setenv(k_, v_)
-        d = mp.Dmpc(variant, **kw)            # the switches are read when the context is created
-        for k_ in env:
-            monkeypatch.delenv(k_)
+    for opts in ({"no_persist": 1}, {"force_persist": 1}, {"force_persist": 1, "tier1_qcap": 32}):
+        d = mp.Dmpc(variant, **kw)
+        for k_, v_ in opts.items():
+            d.debug_option(k_, v_)            # development options of the context (dmpc_debug_option): launch forms, never arithmetic
         l, _, _ = d.init_batch(po, pf)
         z = np.zeros_like(po)
         outs.append(d.step_batch(l, po, z, z, pf))

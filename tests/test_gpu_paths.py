@@ -1,9 +1,11 @@
-"""GPU: the alternative execution paths of round 2 must not change results.
+"""GPU: the alternative execution paths must not change results (development options of a context, dmpc_debug_option).
 
 * neighbour lists of large scenes (nbr_kernel + transposed list walk on the fp32 neighbour-major table): conservative
-  pre-filters, the decisions are made with the arithmetic of the plain walk => bit-identical to DMPC_NO_CULL=1;
+  pre-filters, the decisions are made with the arithmetic of the plain walk => bit-identical to option no_cull;
 * crash start of the acceleration bounds: another path to the same (unique) minimiser => same statuses and branch records,
-  trajectories to solver accuracy against DMPC_CRASH_MIN=0."""
+  trajectories to solver accuracy against crash_min = 0;
+* the unconstrained exit of the scan (round 3): agents whose unconstrained minimiser is feasible are finished by the scan kernel with
+  the solver's own arithmetic => bit-identical to option no_fast_exit (every agent through the solve kernel), in every launch form."""
 import numpy as np
 import pytest
 
@@ -13,8 +15,10 @@ from multiagent_planning_amd import workload as wl
 pytestmark = pytest.mark.gpu
 
 
-def _steps(variant, kw, po, pf, nsteps, precision="f64"):
-    d = mp.Dmpc(variant, precision=precision, **kw)     # the tuning switches are read when the context is created
+def _steps(variant, kw, po, pf, nsteps, precision="f64", **opts):
+    d = mp.Dmpc(variant, precision=precision, **kw)
+    for k_, v_ in opts.items():
+        d.debug_option(k_, v_)
     l, _, _ = d.init_batch(po, pf)
     xp, xv, xa = po.copy(), np.zeros_like(po), np.zeros_like(po)
     outs = []
@@ -35,8 +39,7 @@ def test_neighbour_lists_do_not_change_a_bit(variant, precision, monkeypatch):
     kw = wl.solver_kwargs(cfg, N)
     po, pf = wl.make_scenes(cfg, S, N, wl.SEED0 + 31)
     with_lists = _steps(variant, kw, po, pf, 3, precision)
-    monkeypatch.setenv("DMPC_NO_CULL", "1")
-    plain = _steps(variant, kw, po, pf, 3, precision)
+    plain = _steps(variant, kw, po, pf, 3, precision, no_cull=1)
     for a, b in zip(with_lists, plain):
         for k in ("status", "info", "p", "v", "a"):
             assert np.array_equal(a[k], b[k]), (variant, k)
@@ -54,8 +57,7 @@ def test_neighbour_list_overflow_falls_back_to_the_table(monkeypatch):
     po = np.array(kw["pmin"]) + 1.0 + rng.random((S, N, 3)) * 1.5
     pf = np.array(kw["pmin"]) + 1.0 + rng.random((S, N, 3)) * 1.5
     a = _steps("ondemand", kw, po, pf, 1)
-    monkeypatch.setenv("DMPC_NO_CULL", "1")
-    b = _steps("ondemand", kw, po, pf, 1)
+    b = _steps("ondemand", kw, po, pf, 1, no_cull=1)
     for k in ("status", "info", "p"):
         assert np.array_equal(a[0][k], b[0][k]), k
 
@@ -71,8 +73,7 @@ def test_crash_start_reaches_the_same_minimiser(variant, monkeypatch):
     po, _ = wl.make_scenes(cfg, S, N, wl.SEED0 + 41)
     pf = lo + rng.random((S, N, 3)) * (hi - lo)
     new = _steps(variant, kw, po, pf, 3)
-    monkeypatch.setenv("DMPC_CRASH_MIN", "0")
-    old = _steps(variant, kw, po, pf, 1)
+    old = _steps(variant, kw, po, pf, 1, crash_min=0)
     a, b = new[0], old[0]
     assert np.array_equal(a["status"], b["status"])
     assert np.array_equal(a["info"][..., :4], b["info"][..., :4])            # violating step, rows, retry-ladder count, cost case
@@ -84,3 +85,33 @@ def test_crash_start_reaches_the_same_minimiser(variant, monkeypatch):
     assert a["info"][..., 7].max() >= 20
     if variant != "repair":
         assert (a["info"][..., 2] > 1).any() or True
+
+
+@pytest.mark.parametrize("variant,N,S,opts", [("bound", 100, 40, {}), ("bound", 100, 40, {"force_persist": 1}), ("bound2", 60, 8, {}), ("ondemand", 100, 24, {}),
+                                              ("softall", 40, 6, {}), ("repair", 50, 6, {}), ("cpp", 80, 8, {}), ("bound", 700, 2, {}), ("bound", 20, 1, {})])
+def test_unconstrained_exit_of_the_scan_does_not_change_a_bit(variant, N, S, opts):
+    """closed-loop steps (late steps: most agents trivial) with and without the exit, in the launch forms the sizes select (one agent per
+    workgroup with and without the order kernel, persistent waves, large scenes with neighbour lists): every output word identical"""
+    cfg = wl.CONFIGS["C4"]
+    kw = wl.solver_kwargs(cfg, N)
+    po, pf = wl.make_scenes(cfg, S, N, wl.SEED0 + 51)
+    a = _steps(variant, kw, po, pf, 12, **opts)
+    b = _steps(variant, kw, po, pf, 12, no_fast_exit=1, **opts)
+    trivial = 0
+    for x, y in zip(a, b):
+        for k in ("status", "info", "p", "v", "a"):
+            assert np.array_equal(x[k], y[k]), (variant, k)
+        trivial += int(((x["status"] == 1) & (x["info"][..., 4] == 0)).sum())
+    assert trivial > 0                       # the exit did fire (the far goals of the 700-agent box saturate most bounds: few trivial steps there)
+
+
+def test_unconstrained_exit_in_whole_transitions():
+    """dmpc_transition (fused post-step for tiny launches, split batches) with and without the exit: identical histories"""
+    cfg = wl.CONFIGS["C4"]
+    for N, S in ((12, 3), (30, 40)):
+        kw = wl.solver_kwargs(cfg, N)
+        po, pf = wl.make_scenes(cfg, S, N, wl.SEED0 + 52)
+        a = mp.Dmpc("bound", **kw).transition(po, pf, 120, cfg["error_tol"])
+        b = mp.Dmpc("bound", **kw).debug_option("no_fast_exit", 1).transition(po, pf, 120, cfg["error_tol"])
+        for k in ("pk", "vk", "ak", "K_T_used", "scene_status"):
+            assert np.array_equal(a[k], b[k]), (N, k)

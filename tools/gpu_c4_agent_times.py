@@ -1,4 +1,4 @@
-"""development (library built with `make DEV_TRACE=1`; run with DMPC_FORCE_PERSIST=1 DMPC_TIER1_QCAP=64): duration of every agent's solve
+"""development (library built with `make DEV_TRACE=1`; run with DMPC_DEBUG_OPTIONS=force_persist=1,tier1_qcap=64): duration of every agent's solve
 at C4 N = 10^4 (third MPC step): is the launch bound by the sum of the work or by its longest agents?"""
 import sys, os, ctypes as C
 import numpy as np

@@ -1,4 +1,4 @@
-for env in "X=1" "DMPC_NO_PERSIST=1" "DMPC_CRASH_MIN=0" "DMPC_TIER1_QCAP=64"; do
+for env in "X=1" "DMPC_DEBUG_OPTIONS=no_persist=1" "DMPC_DEBUG_OPTIONS=crash_min=0" "DMPC_DEBUG_OPTIONS=tier1_qcap=64"; do
   echo "== $env"
   env $env STEPS=5 timeout 300 python tools/gpu_c4_hist.py 2>&1 | sed 's/| with rows.*| tries/| tries/' | cut -c1-330
 done

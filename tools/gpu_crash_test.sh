@@ -1,6 +1,6 @@
 # development: crash start / ladder warm start on and off -- tests, C4 N = 10^4 statistics, headline, one-scene latency
 timeout 1200 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; tail -4 gpurun_out/pytest_gpu.log
-for env in "X=1" "DMPC_LADDER_WARM=1" "DMPC_CRASH_MIN=0"; do
+for env in "X=1" "DMPC_DEBUG_OPTIONS=crash_min=0"; do
   echo "== $env"
   env $env STEPS=5 timeout 300 python tools/gpu_c4_hist.py 2>&1 | sed 's/| with rows.*| tries/| tries/' | cut -c1-330
   env $env timeout 300 python tools/gpu_single_scene.py 2>&1 | tail -2

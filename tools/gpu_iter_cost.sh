@@ -1,6 +1,6 @@
 #!/bin/bash
 # Development: instruction cost of one active-set iteration of the solve kernel.  The SQ instruction counters of the bench
-# workload are collected with the iteration cap (DMPC_ITER_CAP) at 0, 4 and unlimited; the differences divided by the
+# workload are collected with the iteration cap (development option iter_cap) at 0, 4 and unlimited; the differences divided by the
 # differences of the mean iteration count give the per-iteration cost, the cap-0 run the fixed per-agent cost.
 set -u
 REPO=$(pwd)
@@ -9,7 +9,7 @@ rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $REPO/bench.py --no-cpu-baseline --no-secondary --steps 5 --warmup 1"
 for cap in 0 4 100000; do
-  DMPC_ITER_CAP=$cap timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_BRANCH SQ_WAVE_CYCLES SQ_BUSY_CYCLES \
+  DMPC_DEBUG_OPTIONS=iter_cap=$cap timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_BRANCH SQ_WAVE_CYCLES SQ_BUSY_CYCLES \
       --output-format csv -d "$OUT/cap$cap" -o sq -- $BENCH > "$OUT/cap$cap.log" 2>&1
 done
 cd "$REPO"

@@ -1,5 +1,5 @@
 # development: single 64-slot tier against the 32/64 two-tier launch for the slack variants (bench secondaries)
-for env in "DMPC_TIER1_QCAP=48" "DMPC_TIER1_QCAP=32"; do
+for env in "DMPC_DEBUG_OPTIONS=tier1_qcap=48" "DMPC_DEBUG_OPTIONS=tier1_qcap=32"; do
   echo "== $env"
   env $env timeout 600 python bench.py --no-cpu-baseline > gpurun_out/bench_t.json
   python - <<'PY'
