@@ -123,6 +123,7 @@ struct dmpc_ctx {
     GroupShared *grp = nullptr;
     std::vector<dmpc_ctx *> peers;
     long grp_steps = 0;      // exchanges of this rank so far (parity of the event pair)
+    int grp_emulated = 0;    // the group's ranks share one device (dmpc_debug_emulate_devices): a second group is built the same way
     int debug_rank = 0;      // dmpc_debug_set_rank: emulated rank without a transport (tests)
     DevBuf rb_A, rb_l, rb_sel, rb_out, rb_bin, rb_po, gen_out, hp_in, hp_out;                     // dense row builders (host-pointer entries)
     // profiling
@@ -358,8 +359,8 @@ extern "C" int dmpc_debug_option(dmpc_ctx *ctx, const char *name, int value)
     for (auto &t : tab)
         if (!std::strcmp(t.n, name)) {
             ctx->*(t.f) = value;
-            for (dmpc_ctx *pc : ctx->peers) pc->*(t.f) = value;
-            for (dmpc_ctx *ch : ctx->children) ch->*(t.f) = value;
+            for (dmpc_ctx *pc : ctx->peers) (void)dmpc_debug_option(pc, name, value);
+            for (dmpc_ctx *ch : ctx->children) (void)dmpc_debug_option(ch, name, value);
             return 0;
         }
     ctx->err = std::string("dmpc_debug_option: unknown option ") + name;
@@ -434,7 +435,7 @@ extern "C" dmpc_ctx *dmpc_create(const dmpc_params *prm, int device, int precisi
         for (int r = 0; r < G && ok; ++r) {
             dmpc_ctx *c = create_one(prm, devs[(size_t)r], precision);
             if (!c) { ok = false; break; }
-            c->grp = sh; c->nranks = G; c->rank = r;
+            c->grp = sh; c->nranks = G; c->rank = r; c->grp_emulated = emu > 0;
             if (r == 0) root = c; else root->peers.push_back(c);
             for (int u = 0; u < 2 && ok; ++u) ok = hipEventCreateWithFlags(&sh->ev[(size_t)r * 2 + u], hipEventDisableTiming) == hipSuccess;
             // direct loads / stores and copies between the GPUs of the group over xGMI
@@ -1192,7 +1193,37 @@ extern "C" int dmpc_transition(dmpc_ctx *ctx, int S, int N, const double *po, co
     ctx->split_at.clear();
     if (ctx->grp) {   // every visible GPU: the agents of each scene sharded over them (dmpc_multigpu.hip)
         if (S < 1 || N < 1 || K_T_max < 2 || !po || !pf || !K_T_used || !scene_status || ((pk || vk || ak) && !(pk && vk && ak))) FAIL(ctx, "dmpc_transition: bad arguments");
-        return group_transition(ctx, S, N, po, pf, K_T_max, error_tol, pk, vk, ak, K_T_used, scene_status);
+        // Batches of 64 or more scenes run as TWO groups side by side (a second set of rank contexts, threads and streams on the same
+        // GPUs): scenes are independent, so while one half's ranks exchange their predictions (peer copies, barrier, events) the
+        // other half's solve kernels keep the GPUs busy -- the per-step exchange is off the critical path.
+        const int gparts = ctx->no_split ? 1 : (ctx->split_parts > 0 ? (ctx->split_parts > 2 ? 2 : ctx->split_parts) : (S >= 64 ? 2 : 1));
+        if (gparts < 2) return group_transition(ctx, S, N, po, pf, K_T_max, error_tol, pk, vk, ak, K_T_used, scene_status);
+        if (ctx->children.empty()) {
+            const int keep = g_emulate_devices.load();
+            if (ctx->grp_emulated) g_emulate_devices.store(ctx->grp->G);
+            dmpc_ctx *other = dmpc_create(&ctx->prm, DMPC_DEVICE_ALL, ctx->precision);
+            g_emulate_devices.store(keep);
+            if (!other || !other->grp || other->grp->G != ctx->grp->G) { if (other) dmpc_destroy(other); FAIL(ctx, "dmpc_transition: second group: " + g_err); }
+            other->no_split = 1;
+            ctx->children.push_back(other);
+        }
+        dmpc_ctx *other = ctx->children[0];
+        if (std::memcmp(&other->prm, &ctx->prm, sizeof(dmpc_params)) != 0 && dmpc_set_params(other, &ctx->prm)) FAIL(ctx, "dmpc_transition: second group: " + other->err);
+        const int S0 = S / 2;
+        const size_t a0 = (size_t)S0 * N, h0 = a0 * (size_t)K_T_max * 3;
+        int rc1 = 0;
+        std::thread th([&]() {
+            rc1 = group_transition(other, S - S0, N, po + a0 * 3, pf + a0 * 3, K_T_max, error_tol, pk ? pk + h0 : nullptr, vk ? vk + h0 : nullptr,
+                                   ak ? ak + h0 : nullptr, K_T_used + S0, scene_status + S0);
+        });
+        const int rc0 = group_transition(ctx, S0, N, po, pf, K_T_max, error_tol, pk, vk, ak, K_T_used, scene_status);
+        th.join();
+        (void)hipSetDevice(ctx->device);
+        if (rc1) FAIL(ctx, other->err);
+        if (rc0) return -1;
+        ctx->split_at = {0, S0, S};
+        ctx->hist_S = S;
+        return 0;
     }
     // parts: every part runs its own MPC loop on its own stream; launches of fewer than ~2000 agents are one-agent workgroups, which the
     // hardware interleaves across streams freely (persistent launches hold a CU's whole LDS), so many small parts overlap best

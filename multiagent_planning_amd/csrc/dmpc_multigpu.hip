@@ -349,7 +349,7 @@ static int transition_sharded_impl(dmpc_ctx *ctx, int S, int N, const double *po
     if (ensure_step_scratch(ctx, A, Aown)) return -1;
     if (ctx->lT.ensure(tab * 8) || ctx->lT2.ensure(tab * 8) || ctx->po.ensure(A * 24) || ctx->mg_pf.ensure(A * 24) || ctx->sendbuf.ensure(chunk * 8) ||
         ctx->hist_p.ensure(hist) || ctx->hist_v.ensure(hist) || ctx->hist_a.ensure(hist) || ctx->flags.ensure((size_t)K_T_max * S * 8) ||
-        ctx->scene_done.ensure((size_t)S * 4) || ctx->mg_floc.ensure((size_t)S * 8) || ctx->mg_fall.ensure((size_t)G * S * 8) ||
+        ctx->scene_done.ensure((size_t)S * 4) || ctx->mg_floc.ensure((size_t)S * 8) || ctx->mg_fall.ensure((size_t)G * S * 16) ||
         (mixed && (ctx->lTf.ensure(tab * 4) || ctx->lTf2.ensure(tab * 4) || ctx->sendbuf32.ensure(chunk * 4) || ctx->own64.ensure(chunk * 8))))
         FAIL(ctx, "device allocation failed");
     hipStream_t st = ctx->stream;
@@ -362,7 +362,7 @@ static int transition_sharded_impl(dmpc_ctx *ctx, int S, int N, const double *po
     HIPCHK(ctx, hipMemsetAsync(ctx->hist_v.p, 0, hist, st));
     HIPCHK(ctx, hipMemsetAsync(ctx->hist_a.p, 0, hist, st));
     HIPCHK(ctx, hipMemsetAsync(ctx->sendbuf.p, 0, chunk * 8, st));
-    HIPCHK(ctx, hipMemsetAsync(ctx->mg_fall.p, 0, (size_t)G * S * 8, st));
+    HIPCHK(ctx, hipMemsetAsync(ctx->mg_fall.p, 0, (size_t)G * S * 16, st));
     // k = 1: initDMPC for ALL agents (every rank builds the same first table), own states = (po, 0, 0)
     hipLaunchKernelGGL(init_rows_kernel, dim3((unsigned)((A * N3 + 255) / 256)), dim3(256), 0, st, (int)A, ctx->prm.h, ctx->po.as<double>(),
                        ctx->mg_pf.as<double>(), ctx->rows.as<double>());
@@ -390,18 +390,23 @@ static int transition_sharded_impl(dmpc_ctx *ctx, int S, int N, const double *po
         curf = ctx->lTf.as<float>();
         HIPCHK(ctx, hipMemcpyAsync(own_cur, cur + (size_t)rank * chunk, chunk * 8, hipMemcpyDeviceToDevice, st));
     }
+    // The gathered verdicts are double-buffered like the table: in the group transport a peer PUSHES its flags of step k+1 into this rank's
+    // memory as soon as it has seen this rank's copies of step k -- possibly before this rank's combine kernel of step k has read the
+    // buffer (found by running two groups side by side: a scene then stopped one step early on one rank).
+    int *fall = ctx->mg_fall.as<int>();
     auto publish = [&](const int *floc) -> int {   // this step's predictions (ctx->sendbuf, fp64) into everybody's next table
-        if (!mixed) return exchange(ctx, ctx->sendbuf.p, nxt, chunk, 8, floc, ctx->mg_fall.as<int>(), S * 2, st);
+        fall = ctx->mg_fall.as<int>() + (ctx->grp ? (size_t)(ctx->grp_steps & 1) * G * S * 2 : 0);
+        if (!mixed) return exchange(ctx, ctx->sendbuf.p, nxt, chunk, 8, floc, fall, S * 2, st);
         const unsigned bl = (unsigned)((chunk + 255) / 256 > 4096 ? 4096 : (chunk + 255) / 256);
         hipLaunchKernelGGL(mg::chunk_to_f32_kernel, dim3(bl), dim3(256), 0, st, chunk, (const double *)ctx->sendbuf.as<double>(), ctx->sendbuf32.as<float>());
-        return exchange(ctx, ctx->sendbuf32.p, nxtf, chunk, 4, floc, ctx->mg_fall.as<int>(), S * 2, st);
+        return exchange(ctx, ctx->sendbuf32.p, nxtf, chunk, 4, floc, fall, S * 2, st);
     };
     // ReachedGoal on the initDMPC column (as dmpc_transition): own verdicts, exchanged with a throw-away table exchange
     HIPCHK(ctx, hipMemsetD32Async((hipDeviceptr_t)ctx->status.p, DMPC_ST_SOLVED, Aown, st));
     hipLaunchKernelGGL(scene_reduce_kernel, dim3((unsigned)S), dim3(256), 0, st, (int)cnt, error_tol, xp, own_pf, (const int *)ctx->status.as<int32_t>(),
                        ctx->mg_floc.as<int>(), (int *)nullptr);
     if (publish(ctx->mg_floc.as<int>())) return -1;
-    hipLaunchKernelGGL(mg::combine_flags_kernel, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, st, G, S, (const int *)ctx->mg_fall.as<int>(),
+    hipLaunchKernelGGL(mg::combine_flags_kernel, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, st, G, S, (const int *)fall,
                        ctx->flags.as<int>(), ctx->scene_done.as<int>());
     std::vector<int32_t> flags((size_t)K_T_max * S * 2, 0);
     std::vector<int> done(S, 0);
@@ -422,7 +427,7 @@ static int transition_sharded_impl(dmpc_ctx *ctx, int S, int N, const double *po
         HIPCHK(ctx, hipGetLastError());
         if (publish(ctx->mg_floc.as<int>())) return -1;
         if (mixed) HIPCHK(ctx, hipMemcpyAsync(own_cur, ctx->sendbuf.p, chunk * 8, hipMemcpyDeviceToDevice, st));   // own fp64 predictions of the new table
-        hipLaunchKernelGGL(mg::combine_flags_kernel, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, st, G, S, (const int *)ctx->mg_fall.as<int>(),
+        hipLaunchKernelGGL(mg::combine_flags_kernel, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, st, G, S, (const int *)fall,
                            ctx->flags.as<int>() + (size_t)k * S * 2, ctx->scene_done.as<int>());
         std::swap(cur, nxt);   // l = new_l (dmpc_soft_bound.m:146)
         std::swap(curf, nxtf);

@@ -159,3 +159,39 @@ def test_sharded_transition_gather_feeds_the_postcheck():
     for k in pc:
         assert np.array_equal(pc[k], pc_ref[k], equal_nan=True), k
     d.comm_destroy()
+
+
+def test_group_context_large_batch_runs_as_two_groups(emulated):
+    """64 scenes or more on a DMPC_DEVICE_ALL context: two groups of rank contexts side by side (the exchange of one half under the
+    solve of the other); histories, verdicts and the post-checks on the resident histories equal the single-GPU run"""
+    cfg, kw, po, pf = _scenes(16, 70, wl.SEED0 + 47)
+    ref_d = mp.Dmpc("bound", **kw)
+    ref = ref_d.transition(po, pf, 90, cfg["error_tol"])
+    emulated(3)
+    d = mp.Dmpc("bound", device=mp.Dmpc.DEVICE_ALL, **kw)
+    out = d.transition(po, pf, 90, cfg["error_tol"])
+    for k in ("pk", "vk", "ak", "K_T_used", "scene_status"):
+        assert np.array_equal(out[k], ref[k]), k
+    ok = ((ref["scene_status"] & mp.ST_REACHED) != 0).astype(np.int32)
+    pc, pc_ref = d.postcheck(out["K_T_used"], pf, KT_alloc=90, mask=ok), ref_d.postcheck(ref["K_T_used"], pf, KT_alloc=90, mask=ok)
+    for k in pc:
+        assert np.array_equal(pc[k], pc_ref[k], equal_nan=True), k
+    one = mp.Dmpc("bound", device=mp.Dmpc.DEVICE_ALL, **kw).debug_option("no_split", 1).transition(po, pf, 90, cfg["error_tol"], histories=False)
+    assert np.array_equal(one["K_T_used"], ref["K_T_used"])
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without torch.distributed.run: bench.py starts the two ranks itself.  On this one-GPU box they share the
+    GPU and the exchange is staged through gloo (a functional check of the multi-rank path, flagged as such in the JSON line); the
+    sharded step must equal the unsharded step of the same scenes per agent, bit for bit (config.exchange_verified)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DMPC_BENCH_SHARE_GPU="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--scenes", "16", "--no-secondary",
+                        "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["exchange_verified"] is True
+    assert line["config"]["agents_per_scene"] == 200 and "FUNCTIONAL CHECK" in line["data"]

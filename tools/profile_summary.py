@@ -73,8 +73,8 @@ if sk:
         f64 = {c: sq3.get("SQ_INSTS_VALU_" + c, 0.0) for c in ("FMA_F64", "ADD_F64", "MUL_F64", "TRANS_F64")}
         arith = sum(f64.values())
         valu = sq.get("SQ_INSTS_VALU", 0) or 1.0
-        # lanes: SQ_THREAD_CYCLES_VALU counts active lanes x cycles; a full wave64 VALU instruction is 64 lanes x 4 cycles
-        lane_util = sq3.get("SQ_THREAD_CYCLES_VALU", 0.0) / (valu * 64.0 * 4.0) if sq3.get("SQ_THREAD_CYCLES_VALU") else None
+        # lanes: SQ_THREAD_CYCLES_VALU accumulates the active lanes of every VALU instruction (64 for a full wave)
+        lane_util = sq3.get("SQ_THREAD_CYCLES_VALU", 0.0) / (valu * 64.0) if sq3.get("SQ_THREAD_CYCLES_VALU") else None
         flops = (2.0 * f64["FMA_F64"] + f64["ADD_F64"] + f64["MUL_F64"]) * 64.0 * (lane_util or 1.0)
         out["fp64"] = {"valu_insts_per_solve": {k.lower(): v / spl for k, v in f64.items()}, "int32_per_solve": sq3.get("SQ_INSTS_VALU_INT32", 0.0) / spl,
                        "fp64_share_of_valu": arith / valu, "lane_utilisation": lane_util,
