@@ -365,6 +365,35 @@ def main():
                           "ms_per_mpc_step": float(np.mean(sc4[1:]) + np.mean(so4[1:])), "first_step_ms": sc4[0] + so4[0],
                           "value": N4 / ((np.mean(sc4[1:]) + np.mean(so4[1:])) * 1e-3), "unit": "solves/s"})
         del d4
+        # the same scene in mixed precision (fp32 table, scan and rows; fp64 QP): the O(N) part of the step at half the bytes
+        d4m = mp.Dmpc("bound", device=local_rank, precision="mixed", **kw4)
+        l4, _, _ = d4m.init_batch(po4, pf4)
+        x4p, x4v, x4a = po4.copy(), np.zeros_like(po4), np.zeros_like(po4)
+        scm, som = [], []
+        for k4 in range(9):
+            d4m.profile(True)
+            o4 = d4m.step_batch(l4, x4p, x4v, x4a, pf4)
+            sms, cms, _ = d4m.profile_read2()
+            scm.append(cms); som.append(sms)
+            okm = (o4["status"] == 1)
+            l4 = np.where(okm[..., None], o4["p"], l4); x4p = np.where(okm[..., None], o4["p"][..., :3], x4p)
+            x4v = np.where(okm[..., None], o4["v"][..., :3], x4v); x4a = np.where(okm[..., None], o4["a"][..., :3], x4a)
+        secondary.append({"workload": f"C4 as above in mixed precision (DMPC_PREC_MIXED)", "scan_ms": [round(x, 3) for x in scm], "solve_ms": [round(x, 3) for x in som],
+                          "ms_per_mpc_step": float(np.mean(scm[1:]) + np.mean(som[1:])), "value": N4 / ((np.mean(scm[1:]) + np.mean(som[1:])) * 1e-3), "unit": "solves/s"})
+        del d4m
+        # one process, every visible GPU (dmpc_create(.., DMPC_DEVICE_ALL, ..): threads + peer copies inside the library) -- the path a MEX /
+        # C++ caller gets; only when this process sees more than one GPU
+        if torch.cuda.device_count() > 1:
+            try:
+                dg = mp.Dmpc("bound", device=mp.Dmpc.DEVICE_ALL, **kwT)
+                dg.transition(poT[:8], pfT[:8], 10, cfgT["error_tol"], histories=False)
+                tt = time.perf_counter(); rg = dg.transition(poT, pfT, cfgT["K_T"], cfgT["error_tol"], histories=False); dtg = time.perf_counter() - tt
+                secondary.append({"workload": f"512 whole transitions, 100 agents, solveSoftDMPCbound, ONE process on {dg.n_devices} GPUs (DMPC_DEVICE_ALL: agents of "
+                                              "every scene sharded over the GPUs, peer copies between MPC steps)", "n_gpus": dg.n_devices, "wall_ms": dtg * 1e3,
+                                  "completed": int(((rg["scene_status"] & 256) != 0).sum()), "value": float(((rg["K_T_used"] - 1) * 100).sum() / dtg), "unit": "solves/s"})
+                del dg
+            except Exception as e:   # noqa: BLE001
+                secondary.append({"workload": "one process on all GPUs (DMPC_DEVICE_ALL)", "error": str(e)[:200]})
         # restore the headline workload's last outputs for the statistics below
         one_step()
         torch.cuda.synchronize()
@@ -431,10 +460,10 @@ def main():
         # GPU (360 B per agent of the scene), state+goal 96 B, p/v/a horizons 1080 B, status 20 B
         b_alg = 360.0 * N / C + 1196.0
         achieved = (S * C) * b_alg / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-        # PMC counters cannot be read inside the timed run: traffic and issue fractions come from the committed rocprofv3 passes of
-        # this same workload (profiles/r02_pmc_summary.json, made by tools/gpu_profile_round.sh + tools/profile_summary.py)
+        # PMC counters cannot be read inside the timed run: traffic, issue fractions and the fp64 instruction classes come from the committed
+        # rocprofv3 passes of this same workload (profiles/r03_pmc_summary.json, made by tools/gpu_profile_round.sh + tools/profile_summary.py)
         traffic, pmc = None, None
-        tj = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
+        tj = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")
         if os.path.exists(tj) and G == 1:
             try:
                 jt = json.load(open(tj))
@@ -463,10 +492,13 @@ def main():
                          "other_kernels_ms_avg": {"dmpc_scan_kernel+order_kernel": scan_ms},
                          "alg_bytes_per_solve": b_alg, "solves_per_launch": S * C,
                          "secondary": (dict(pmc.get("issue", {}), instructions_per_solve=pmc.get("instructions_per_solve"),
-                                            whole_step_traffic=pmc.get("whole_step_bytes_per_launch"),
-                                            source="profiles/r02_pmc_summary.json (rocprofv3 passes of this workload)") if pmc else None),
+                                            whole_step_traffic=pmc.get("whole_step_bytes_per_launch"), fp64=pmc.get("fp64"),
+                                            source="profiles/r03_pmc_summary.json (rocprofv3 passes of this workload, committed; not re-measured in this run)") if pmc else None),
                          "note": "on-chip, instruction-issue bound (profiles/README.md): compulsory HBM traffic is ~1.5 KB/solve against "
                                  "thousands of wave instructions, so the HBM fraction is small by construction; the issue fractions are in `secondary`"},
+            # `value` counts every agent-step launched (one call of the reference's per-agent solver each); of those, the share that ended
+            # with a solution / with a proof of infeasibility (agents the scan certifies infeasible never enter the solver):
+            "value_solved_only": value * float((st & 1).mean()),
             "workload_stats": {"solved_frac": float((st & 1).mean()), "infeasible_frac": float(((st & 8) != 0).mean()),
                                "invalid": int(((st & 48) != 0).sum()), "mean_iters": float(inf[..., 4].mean()),
                                "max_iters": int(inf[..., 4].max()), "mean_rows": float(inf[..., 1].mean()),

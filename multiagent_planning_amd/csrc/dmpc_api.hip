@@ -90,7 +90,7 @@ struct dmpc_ctx {
     // scratch for the host-pointer entry points
     DevBuf post_acc; int post_acc_S = 0, post_fused = 0;
     int no_fuse = 0;         // development option no_fuse: always launch post_step_kernel
-    DevBuf rowbuf, rowkc, hdr, order, bbox, nbr_list, nbr_cnt, lrow, counter, flag_list, scene_done;
+    DevBuf rowbuf, rowkc, hdr, order, bbox, bbox_nm, nbr_list, nbr_cnt, lrow, counter, flag_list, scene_done;
     int num_cu = 0;
     int no_persist = 0;      // development option no_persist: one-agent-per-workgroup solve launches
     int max_lds_persist = 0;
@@ -555,7 +555,7 @@ static int row_capacity(int variant, int N)
 // serialized launch cost more than anything else in the step.  Measured (bench secondaries, 51 200 agents of
 // solveSoftDMPCbound): 32/64 tiers 1.38 ms per step, one 64-slot tier (5 agents per CU) 1.07 ms, 48/64 tiers 1.02 ms;
 // 512 whole transitions 110 / 107 / 100 ms.  DMPC_TIER1_QCAP = 32 | 64 selects the other forms (tests cover the 32/64 hand-off).
-static int tier1_qcap(const dmpc_ctx *ctx, int variant);
+static int tier1_qcap(const dmpc_ctx *ctx, int variant, int scene_agents);
 // hard: 45 variables => at most 45 independent active rows; 48 leaves room for a numerically near-dependent addition
 static int full_qcap(int variant) { return variant_soft(variant) ? QMAX : 48; }
 
@@ -568,10 +568,16 @@ struct PostStep {
     int *flags, *done;
 };
 
-static int tier1_qcap(const dmpc_ctx *ctx, int variant)
+static int tier1_qcap(const dmpc_ctx *ctx, int variant, int scene_agents)
 {
     if (!variant_soft(variant)) return 48;
-    return (ctx->tier1_env == 32 || ctx->tier1_env == 64) ? ctx->tier1_env : 48;
+    if (ctx->tier1_env == 32 || ctx->tier1_env == 48 || ctx->tier1_env == 56 || ctx->tier1_env == 64) return ctx->tier1_env;
+    // Large scenes: 56 slots first.  Far from its goal an agent saturates most of its 45 acceleration bounds (the crash start appends up
+    // to 44 of them), and with a handful of rows and their pins the working set peaks at 48-50 slots: at N = 10^4 (C4) 50-75 agents per
+    // step outgrew a 48-slot tier, none needs more than 50 -- and the few that overflow are re-solved from scratch in a second,
+    // serialized launch that lasts as long as its slowest agent (0.56 ms of a 2.7 ms step).  56 slots cost 3.6 KB of LDS per agent
+    // (5 instead of 6 one-agent workgroups per CU) and take them all: solve 1.81 -> 1.44 ms per step.
+    return scene_agents >= 1024 ? 56 : 48;
 }
 
 static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_first, int c_count, const double *lT,
@@ -621,7 +627,7 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     const long ncu = ctx->num_cu > 0 ? ctx->num_cu : 256;
     const bool tiny = (long)S * c_count < 8L * ncu && !ctx->force_persist && !ctx->tier1_env;
     const bool shallow = (long)S * c_count < 16L * ncu * 8 && !ctx->force_persist && !ctx->tier1_env;
-    const int q1 = (ctx->single_tier || tiny) ? full_qcap(p.variant) : tier1_qcap(ctx, p.variant), q2 = full_qcap(p.variant);
+    const int q1 = (ctx->single_tier || tiny) ? full_qcap(p.variant) : tier1_qcap(ctx, p.variant, G * C), q2 = full_qcap(p.variant);
     const bool two_tier = q1 < q2;
     ctx->post_fused = 0;
     if (post && tiny && !two_tier && g_local == 0 && G == 1 && !ctx->no_fuse) {
@@ -645,6 +651,7 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     if ((int)ldsmax > ctx->max_lds_set) {
         HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_kernel<true, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsmax));
         HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_kernel<true, 48>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsmax));
+        HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_kernel<true, 56>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsmax));
         HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_kernel<true, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsmax));
         HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_kernel<false, 48>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsmax));
         ctx->max_lds_set = (int)ldsmax;
@@ -668,9 +675,9 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
                                p.variant == DMPC_VAR_CPP2;
     if (G * C >= 256 && !ctx->no_cull && finite_radius) {
         const int total = G * S * C;
-        if (ctx->bbox.ensure((size_t)total * 6 * NSEG * 4)) FAIL(ctx, "device allocation failed (bbox)");
-        if (lTf) hipLaunchKernelGGL(bbox_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, C, lTf, ctx->bbox.as<float>());
-        else hipLaunchKernelGGL(bbox_kernel<double>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, C, lT, ctx->bbox.as<float>());
+        if (ctx->bbox.ensure((size_t)total * 6 * NSEG * 4) || ctx->bbox_nm.ensure((size_t)total * NBOX_NM * 4)) FAIL(ctx, "device allocation failed (bbox)");
+        if (lTf) hipLaunchKernelGGL(bbox_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, C, lTf, ctx->bbox.as<float>(), ctx->bbox_nm.as<float>());
+        else hipLaunchKernelGGL(bbox_kernel<double>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, C, lT, ctx->bbox.as<float>(), ctx->bbox_nm.as<float>());
         if (C >= (1 << 20) || G > 2047)   // a list entry packs (chunk << 20) | column into an int
             FAIL(ctx, "neighbour lists: at most 2047 chunks of fewer than 2^20 agents");
         // neighbour lists from the boxes (nbr_kernel): up to 4096 entries per agent, within 1 GB of scratch
@@ -680,9 +687,9 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
         while (cap > 256 && agents * (size_t)cap * 4 > ((size_t)1 << 30)) cap >>= 1;
         if (ctx->nbr_list.ensure(agents * (size_t)cap * 4) || ctx->nbr_cnt.ensure(agents * 4 * NBR_PARTS)) FAIL(ctx, "device allocation failed (neighbour lists)");
         const double R = ((p.variant == DMPC_VAR_HARD) ? 1.0 : 3.0 * p.rmin) * 1.0001 + 1e-4;   // a little more than the scan's radius: conservative in fp32 too
-        const int nblk = (c_count + NBR_BLOCK - 1) / NBR_BLOCK;
+        const int nblk = (c_count + 63) / 64;
         hipLaunchKernelGGL(nbr_kernel, dim3((unsigned)(S * nblk * NBR_PARTS)), dim3(64), 0, st, S, G, C, g_local, c_first, c_count, short_from, (float)R, (float)(R * p.c),
-                           (const float *)ctx->bbox.as<float>(), (int)cap, ctx->nbr_list.as<int>(), ctx->nbr_cnt.as<int>());
+                           (const float *)ctx->bbox.as<float>(), (const float *)ctx->bbox_nm.as<float>(), (int)cap, ctx->nbr_list.as<int>(), ctx->nbr_cnt.as<int>());
         P.nbr_cap = (int)cap; P.nbr_list = ctx->nbr_list.as<int>(); P.nbr_cnt = ctx->nbr_cnt.as<int>();
         if (p.variant != DMPC_VAR_HARD) {   // the list walk of the per-step distance scan reads a neighbour-major copy of the table
             const size_t tot = (size_t)total * 64;
@@ -737,12 +744,14 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     auto launch_plain = [&](int qcap, size_t lds) {
         if (soft && qcap == 32) hipLaunchKernelGGL((dmpc_solve_kernel<true, 32>), grid, block, lds, st, P);
         else if (soft && qcap == 48) hipLaunchKernelGGL((dmpc_solve_kernel<true, 48>), grid, block, lds, st, P);
+        else if (soft && qcap == 56) hipLaunchKernelGGL((dmpc_solve_kernel<true, 56>), grid, block, lds, st, P);
         else if (soft) hipLaunchKernelGGL((dmpc_solve_kernel<true, 64>), grid, block, lds, st, P);
         else hipLaunchKernelGGL((dmpc_solve_kernel<false, 48>), grid, block, lds, st, P);
     };
     auto launch_persist = [&](int qcap, dim3 g, dim3 b, size_t lds) {
         if (soft && qcap == 32) hipLaunchKernelGGL((dmpc_solve_persist_kernel<true, 32>), g, b, lds, st, P);
         else if (soft && qcap == 48) hipLaunchKernelGGL((dmpc_solve_persist_kernel<true, 48>), g, b, lds, st, P);
+        else if (soft && qcap == 56) hipLaunchKernelGGL((dmpc_solve_persist_kernel<true, 56>), g, b, lds, st, P);
         else if (soft) hipLaunchKernelGGL((dmpc_solve_persist_kernel<true, 64>), g, b, lds, st, P);
         else hipLaunchKernelGGL((dmpc_solve_persist_kernel<false, 48>), g, b, lds, st, P);
     };
@@ -758,6 +767,7 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
         if ((int)lds > ctx->max_lds_persist) {
             HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_persist_kernel<true, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_persist_kernel<true, 48>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_persist_kernel<true, 56>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_persist_kernel<true, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_persist_kernel<false, 48>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             ctx->max_lds_persist = (int)lds;

@@ -18,8 +18,8 @@ __host__ __device__ constexpr int tcol(int j) { return 8 * (j >> 3) * (4 * (j >>
 __host__ __device__ constexpr int t_doubles(int qcap) { return tcol((qcap + 7) & ~7); }
 constexpr int ITER_CAP = 4000;
 constexpr int CRASH_MIN_DEFAULT = 4;
-constexpr int NBR_BLOCK = 8;    // nbr_kernel: agents per wave
-constexpr int NBR_PARTS = 4;    // nbr_kernel: the tiles of a scene are split over this many waves per agent block (N / NBR_BLOCK waves alone do not fill the chip)
+constexpr int NBR_PARTS = 16;   // nbr_kernel: the neighbours of a scene are split over this many waves per block of 64 agents (N / 64 waves alone do not fill the chip)
+constexpr int NBOX_NM = 20;     // floats per neighbour in the neighbour-major copy of the segment boxes (18 used; five 16-byte scalar loads)
 
 enum { VAR_BOUND = 0, VAR_BOUND2 = 1, VAR_ALL3 = 2, VAR_HARD = 3, VAR_ONDEMAND = 4, VAR_ELLIP = 5, VAR_SOFTALL = 6, VAR_REPAIR = 7,
        VAR_CPP = 8, VAR_CPP2 = 9 /* dmpc/cpp solveQPv2 with _k_factor 0 / -1 */ };

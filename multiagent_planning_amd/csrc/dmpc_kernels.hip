@@ -946,7 +946,7 @@ __global__ __launch_bounds__(512, 1) void dmpc_solve_persist_kernel(StepParams P
 constexpr int NSEG = 3, SEG_STEPS = K / NSEG;
 static_assert(NSEG * SEG_STEPS == K, "horizon segments");
 template <typename TT>
-__global__ void bbox_kernel(int total, int C, const TT *__restrict__ lT, float *__restrict__ bbox)
+__global__ void bbox_kernel(int total, int C, const TT *__restrict__ lT, float *__restrict__ bbox, float *__restrict__ bbox_nm /* [total][NBOX_NM]: the same boxes, one neighbour's 18 numbers contiguous (scalar loads of nbr_kernel) */)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;   // enumerates (g*S + s)*C + c
     if (i >= total) return;
@@ -963,7 +963,11 @@ __global__ void bbox_kernel(int total, int C, const TT *__restrict__ lT, float *
                 lo[a] = fmin(lo[a], v); hi[a] = fmax(hi[a], v);
             }
 #pragma unroll
-        for (int a = 0; a < 3; ++a) { dst[(size_t)(6 * sg + 2 * a) * C] = __double2float_rd(lo[a]); dst[(size_t)(6 * sg + 2 * a + 1) * C] = __double2float_ru(hi[a]); }
+        for (int a = 0; a < 3; ++a) {
+            const float flo = __double2float_rd(lo[a]), fhi = __double2float_ru(hi[a]);
+            dst[(size_t)(6 * sg + 2 * a) * C] = flo; dst[(size_t)(6 * sg + 2 * a + 1) * C] = fhi;
+            bbox_nm[(size_t)i * NBOX_NM + 6 * sg + 2 * a] = flo; bbox_nm[(size_t)i * NBOX_NM + 6 * sg + 2 * a + 1] = fhi;
+        }
     }
 }
 
@@ -979,83 +983,75 @@ __global__ void table_nbrmajor_kernel(size_t total, int C, const TT *__restrict_
     out[t] = (a4 < 3 && k4 < K) ? (float)lT[(gs * N3 + 3 * k4 + a4) * C + c] : 0.f;
 }
 
-// Neighbour lists of large scenes.  One wave takes NBR_BLOCK agents of a scene and streams the segment boxes of the whole
-// scene past them ONCE: a tile of 64 neighbours per round (lane = neighbour, 18 coalesced loads, the next tile's loads issued
-// before this one is tested), tested against the inflated boxes of the NBR_BLOCK agents (LDS broadcast); a neighbour whose
-// box overlaps in any segment is appended to the agent's list, in increasing neighbour order (ballot + prefix popcount).
-// The test used to sit in the scan kernel, one wave per agent: at N = 10^4 every one of the 10^4 waves streamed the boxes
-// through L2 (4.8 GB per step); here the stream is read N / NBR_BLOCK times, in fp32 (the pre-pass is bound by exactly that
-// stream: 18 values per neighbour and tile).
-// code = (chunk << 20) | column, as the scan decodes it.  cnt = -1: more survivors than `cap` (the scan walks the table).
-// Part q writes its survivors to the q-th quarter of every agent's list (cap / NBR_PARTS entries) and their number to
-// cnt_out[agent][q] (-1: did not fit); the scan kernel closes the gaps (the quarters are in increasing neighbour order).
+// Neighbour lists of large scenes: the all-pairs test of the segment boxes.  LANES = 64 AGENTS of a scene (their inflated boxes in
+// registers), the neighbours are walked one by one with the neighbour's 18 box numbers in SGPRs (five 16-byte scalar loads from the
+// neighbour-major copy of the boxes): 18 compares per neighbour test 64 agent-neighbour pairs, nothing goes through LDS.  A neighbour
+// whose box overlaps an agent's in any segment is appended to that agent's list -- per-lane counters, so every list is in increasing
+// neighbour order.  (Round 2 had the roles the other way round -- a tile of 64 neighbours in the lanes, 8 agents' boxes broadcast from
+// LDS, 144 LDS reads per tile and wave: at N = 10^4 that is 2.8e7 LDS instructions through ONE LDS pipe per CU, 0.2-0.37 ms whatever
+// the VALU did.)
+// code = (chunk << 20) | column, as the scan decodes it.  The neighbours of a scene are split over NBR_PARTS waves per agent block
+// (N / 64 waves alone do not fill the chip); part q writes its survivors to the q-th piece of every agent's list (cap / NBR_PARTS
+// entries) and their number to cnt_out[agent][q] (-1: did not fit: the scan walks the whole table); the scan kernel closes the gaps.
+typedef float f4_t __attribute__((ext_vector_type(4)));
+typedef const f4_t __attribute__((address_space(4))) *ConstF4;
 __global__ __launch_bounds__(64) void nbr_kernel(int S, int G, int C, int g_local, int c_first, int c_count, int short_from, float R, float Rz,
-                                                 const float *__restrict__ bbox, int cap, int *__restrict__ list, int *__restrict__ cnt_out)
+                                                 const float *__restrict__ bbox, const float *__restrict__ bbox_nm, int cap, int *__restrict__ list,
+                                                 int *__restrict__ cnt_out)
 {
     constexpr int NB = 6 * NSEG;
-    __shared__ float ob[NBR_BLOCK][NB];
-    const int nblk = (c_count + NBR_BLOCK - 1) / NBR_BLOCK;
+    const int nblk = (c_count + 63) >> 6;
     const int part = blockIdx.x % NBR_PARTS, sb = blockIdx.x / NBR_PARTS;
     const int scene = sb / nblk, b = sb - scene * nblk;
     const int lane = threadIdx.x;
-    const int ci0 = b * NBR_BLOCK, na = (c_count - ci0) < NBR_BLOCK ? (c_count - ci0) : NBR_BLOCK;
-    for (int i = lane; i < NB * NBR_BLOCK; i += 64) {
-        const int a = i / NB, x = i - NB * a;
-        const int cl = c_first + ci0 + (a < na ? a : 0);
+    const int ci = b * 64 + lane;
+    const bool mine = ci < c_count;
+    const int cl = c_first + (mine ? ci : 0);
+    // own boxes, inflated: even entries lower bound - R, odd entries upper bound + R (R carries a 1e-4 margin: far above the fp32
+    // rounding of these sums); z by Rz (the metric's z scale)
+    float ob[NB];
+#pragma unroll
+    for (int x = 0; x < NB; ++x) {
         const float v = bbox[((size_t)(g_local * S + scene) * NB + x) * C + cl];
         const float infl = (x % 6 < 4) ? R : Rz;
-        ob[a][x] = (x & 1) ? v + infl : v - infl;   // even: lower bound - R, odd: upper bound + R (R carries a 1e-4 margin: far above the fp32 rounding of these sums)
+        ob[x] = (x & 1) ? v + infl : v - infl;
     }
-    __syncthreads();
-    int cnt[NBR_BLOCK];
-    bool over[NBR_BLOCK];
-#pragma unroll
-    for (int a = 0; a < NBR_BLOCK; ++a) { cnt[a] = 0; over[a] = false; }
-    const size_t gid0 = (size_t)scene * c_count + ci0;
     const int pcap = cap / NBR_PARTS;
-    const int tiles_per_chunk = (C + 63) >> 6, ntiles = G * tiles_per_chunk;
-    const int t_lo = (int)((long)ntiles * part / NBR_PARTS), t_hi = (int)((long)ntiles * (part + 1) / NBR_PARTS);
-    float cur[NB], nxt[NB];
-    auto load_tile = [&](int t, float *dst) {
-        const int r = t / tiles_per_chunk, j0 = (t - r * tiles_per_chunk) << 6;
-        const int jj = j0 + lane, jc = jj < C ? jj : C - 1;
-        const float *bb = bbox + ((size_t)(r * S + scene) * NB) * C + jc;
+    const size_t gid = (size_t)scene * c_count + (mine ? ci : 0);
+    int *mylist = list + gid * (size_t)cap + (size_t)part * pcap;
+    const long E = (long)G * C;
+    const int e_lo = (int)(E * part / NBR_PARTS), e_hi = (int)(E * (part + 1) / NBR_PARTS);
+    int cnt = 0;
+    // the overlap test in arithmetic form: two boxes overlap on an axis iff max(n_lo - o_hi, o_lo - n_hi) <= 0; a segment overlaps iff the
+    // maximum over its six differences is <= 0, a neighbour is listed iff the minimum over the three segments is.  6 subtractions + 3
+    // three-operand maxima per segment with the neighbour's numbers as scalar operands: no mask logic on the scalar unit.  (A difference
+    // that rounds or flushes to zero reads as "touching": the list only ever grows by that, it is a superset by design.)
+    for (int e = e_lo; e < e_hi;) {
+        const int r = e / C, j_lo = e - r * C;
+        const int j_hi = (e_hi - e) < (C - j_lo) ? j_lo + (e_hi - e) : C;                      // this part's columns of chunk r
+        const int j_end = j_hi < C - ((short_from && r >= short_from) ? 1 : 0) ? j_hi : C - ((short_from && r >= short_from) ? 1 : 0);   // (padding column of a short chunk)
+        const float *base = bbox_nm + ((size_t)(r * S + scene) * C) * NBOX_NM;
+        const int self = (r == g_local) ? cl : -1;
+        for (int jc = j_lo; jc < j_end; ++jc) {
+            const ConstF4 nb = (ConstF4)(unsigned long long)(base + (size_t)jc * NBOX_NM);
+            const f4_t n0 = nb[0], n1 = nb[1], n2 = nb[2], n3 = nb[3], n4 = nb[4];
+            const float nv[20] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, n3.x, n3.y, n3.z, n3.w, n4.x, n4.y, n4.z, n4.w};
+            float sgm[NSEG];
 #pragma unroll
-        for (int x = 0; x < NB; ++x) dst[x] = bb[(size_t)x * C];
-    };
-    if (t_lo < t_hi) load_tile(t_lo, cur);
-    for (int t = t_lo; t < t_hi; ++t) {
-        if (t + 1 < t_hi) load_tile(t + 1, nxt);
-        const int r = t / tiles_per_chunk, j0 = (t - r * tiles_per_chunk) << 6;
-        const int jj = j0 + lane, jc = jj < C ? jj : C - 1;
-        const bool valid = jj < C - ((short_from && r >= short_from) ? 1 : 0);   // unequal clusters: the last column of a short chunk is padding
-        const int code = (r << 20) | jc;
-#pragma unroll
-        for (int a = 0; a < NBR_BLOCK; ++a) {
-            if (a < na) {
-                bool hit = false;
-#pragma unroll
-                for (int sg = 0; sg < NSEG; ++sg)
-                    hit = hit || (cur[6 * sg] <= ob[a][6 * sg + 1] && cur[6 * sg + 1] >= ob[a][6 * sg] && cur[6 * sg + 2] <= ob[a][6 * sg + 3] &&
-                                  cur[6 * sg + 3] >= ob[a][6 * sg + 2] && cur[6 * sg + 4] <= ob[a][6 * sg + 5] && cur[6 * sg + 5] >= ob[a][6 * sg + 4]);
-                hit = hit && valid && !((r == g_local) && (jj == c_first + ci0 + a));
-                const unsigned long long hm = __ballot(hit);
-                if (hm != 0ull && !over[a]) {
-                    const int n = __popcll(hm);
-                    if (cnt[a] + n > pcap) over[a] = true;
-                    else {
-                        if (hit) list[(gid0 + a) * (size_t)cap + (size_t)part * pcap + cnt[a] + lanes_below(hm, lane)] = code;
-                        cnt[a] += n;
-                    }
-                }
+            for (int sg = 0; sg < NSEG; ++sg) {
+                const float a0 = nv[6 * sg] - ob[6 * sg + 1], a1 = ob[6 * sg] - nv[6 * sg + 1], a2 = nv[6 * sg + 2] - ob[6 * sg + 3];
+                const float a3 = ob[6 * sg + 2] - nv[6 * sg + 3], a4 = nv[6 * sg + 4] - ob[6 * sg + 5], a5 = ob[6 * sg + 4] - nv[6 * sg + 5];
+                sgm[sg] = fmaxf(__builtin_fmaxf(__builtin_fmaxf(a0, a1), a2), __builtin_fmaxf(__builtin_fmaxf(a3, a4), a5));
+            }
+            const float worst = __builtin_fminf(__builtin_fminf(sgm[0], sgm[1]), sgm[2]);
+            if (worst <= 0.f && mine && jc != self) {
+                if (cnt < pcap) mylist[cnt] = (r << 20) | jc;
+                cnt++;
             }
         }
-#pragma unroll
-        for (int x = 0; x < NB; ++x) cur[x] = nxt[x];
+        e += j_hi - j_lo;
     }
-#pragma unroll
-    for (int a = 0; a < NBR_BLOCK; ++a)
-        if (a < na && lane == 0) cnt_out[(gid0 + a) * NBR_PARTS + part] = over[a] ? -1 : cnt[a];
+    if (mine) cnt_out[gid * NBR_PARTS + part] = cnt > pcap ? -1 : cnt;
 }
 
 // Longest-processing-time-first launch order for the solve phase: agents are bucketed by the key the scan left in

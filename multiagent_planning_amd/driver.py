@@ -178,6 +178,11 @@ class GpuLocalStep:
 
     def __call__(self, lT_full, x_p, x_v, x_a, pf, g_local):
         import torch
+        # dmpc_step_device knows equal clusters only (no short_from): a padded table of unequal clusters would be read with the padding
+        # columns as real neighbours at the origin -- refuse instead of computing on a wrong layout (unequal clusters: dmpc_step_sharded_device)
+        if tuple(lT_full.shape) != (self.G, self.S, K3, self.C) or tuple(x_p.shape[:2]) != (self.S, self.C):
+            raise ValueError(f"GpuLocalStep: table {tuple(lT_full.shape)} / state {tuple(x_p.shape)} do not match G={self.G}, S={self.S}, C={self.C} "
+                             "(equal clusters N = G*C only; unequal clusters go through Dmpc.step_sharded_device)")
         st = torch.cuda.current_stream().cuda_stream
         self.d.step_device(self.S, self.G, self.C, g_local, lT_full.data_ptr(), x_p.data_ptr(), x_v.data_ptr(), x_a.data_ptr(),
                            pf.data_ptr(), self.p.data_ptr(), self.v.data_ptr(), self.a.data_ptr(), 0, self.status.data_ptr(),
