@@ -308,6 +308,7 @@ def main():
         dT = mp.Dmpc("bound", device=local_rank, **kwT)
         poT, pfT = wl.make_scenes(cfgT, 512, 100, wl.SEED0 + 100)
         dT.transition(poT[:1], pfT[:1], 10, cfgT["error_tol"])   # warm-up
+        dT.transition(poT[:128], pfT[:128], 4, cfgT["error_tol"])   # ... and of the batch parts (their contexts are created on first use)
         for St in (1, 8, 512):
             tt = time.perf_counter()
             resT = dT.transition(poT[:St], pfT[:St], cfgT["K_T"], cfgT["error_tol"])
@@ -336,6 +337,7 @@ def main():
         for prec in ("f64", "mixed"):
             dm = mp.Dmpc("bound", device=local_rank, precision=prec, **kwT)
             dm.transition(poT[:8], pfT[:8], 10, cfgT["error_tol"], histories=False)
+            dm.transition(poT[:128], pfT[:128], 4, cfgT["error_tol"], histories=False)   # (creates the contexts of the batch parts)
             tt = time.perf_counter(); rm = dm.transition(poT, pfT, cfgT["K_T"], cfgT["error_tol"], histories=False); dtm = time.perf_counter() - tt
             secondary.append({"workload": f"512 whole transitions, 100 agents, solveSoftDMPCbound, precision {prec}, histories left on the device",
                               "wall_ms": dtm * 1e3, "completed": int(((rm["scene_status"] & 256) != 0).sum()),
