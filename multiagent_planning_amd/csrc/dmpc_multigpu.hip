@@ -25,6 +25,7 @@ struct Api {
     int (*GetUniqueId)(UniqueId *) = nullptr;
     int (*CommInitRank)(Comm *, int, UniqueId, int) = nullptr;
     int (*CommDestroy)(Comm) = nullptr;
+    int (*CommAbort)(Comm) = nullptr;
     int (*AllGather)(const void *, void *, size_t, int, Comm, hipStream_t) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
@@ -49,6 +50,7 @@ static void api_load(Api &a)
     a.GetUniqueId = (int (*)(UniqueId *))sym("ncclGetUniqueId");
     a.CommInitRank = (int (*)(Comm *, int, UniqueId, int))sym("ncclCommInitRank");
     a.CommDestroy = (int (*)(Comm))sym("ncclCommDestroy");
+    a.CommAbort = (int (*)(Comm))dlsym(a.h, "ncclCommAbort");   // (optional: a failing rank releases its peers)
     a.AllGather = (int (*)(const void *, void *, size_t, int, Comm, hipStream_t))sym("ncclAllGather");
     a.GroupStart = (int (*)())sym("ncclGroupStart");
     a.GroupEnd = (int (*)())sym("ncclGroupEnd");
@@ -416,8 +418,13 @@ static int transition_sharded_impl(dmpc_ctx *ctx, int S, int N, const double *po
     for (int k = 1; k < K_T_max && ndone < S; ++k) {
         if (launch_step(ctx, S, G, cmax, rank, 0, cnt, cur, xp, xv, xa, own_pf, ctx->pout.as<double>(), ctx->vout.as<double>(),
                         ctx->aout.as<double>(), ctx->sendbuf.as<double>(), ctx->status.as<int32_t>(), nullptr, st, ctx->scene_done.as<int>(), rem,
-                        mixed ? curf : nullptr, nullptr, mixed ? own_cur : nullptr))
-            { if (ctx->grp) ctx->grp->abort.store(1); return -1; }
+                        mixed ? curf : nullptr, nullptr, mixed ? own_cur : nullptr)) {
+            // a rank that cannot take its step must not leave the others waiting in the exchange: the group's barriers are released by
+            // the abort flag, an RCCL communicator is aborted (the peers' collectives then return an error instead of hanging)
+            if (ctx->grp) ctx->grp->abort.store(1);
+            if (ctx->comm && mg::api()->CommAbort) { (void)mg::api()->CommAbort((mg::Comm)ctx->comm); ctx->comm = nullptr; ctx->nranks = 1; ctx->rank = 0; }
+            return -1;
+        }
         // state advance + history column + this rank's verdict per scene (all own agents at their goals / OR of their status
         // bits) in one launch, then the exchange: predictions into the next table, verdicts of all ranks next to them
         hipLaunchKernelGGL(post_step_kernel, dim3((unsigned)S), dim3(cnt >= 256 ? 256 : 128), 0, st, (int)cnt, K_T_max, k, error_tol,

@@ -195,3 +195,21 @@ def test_bench_launches_its_own_ranks():
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["exchange_verified"] is True
     assert line["config"]["agents_per_scene"] == 200 and "FUNCTIONAL CHECK" in line["data"]
+
+
+def test_two_real_ranks_over_rccl():
+    """The wire itself: two processes, two GPUs, the library's RCCL all-gather between them (tests/rccl_two_ranks.py under
+    torch.distributed.run): sharded transition (fp64 and mixed: the fp32 exchange), unequal clusters, the history gather and the post-checks
+    on every rank, against the single-GPU run bit for bit.  Skipped on a box with one GPU (the emulated-rank tests above cover everything
+    but the transport there)."""
+    import os, subprocess, sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29541",
+                        os.path.join(root, "tests", "rccl_two_ranks.py")], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0 and "RCCL_TWO_RANKS_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
