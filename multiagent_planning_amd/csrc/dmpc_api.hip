@@ -106,6 +106,8 @@ struct dmpc_ctx {
     DevBuf lTf, lTf2;            // mixed precision: fp32 copies of the tables the scan reads
     DevBuf rows, lT, lT2, xp, xv, xa, pf, po, pout, vout, aout, status, info, hist_p, hist_v, hist_a, flags;
     int hist_S = 0, hist_N = 0, hist_KT = 0;   // shape of the histories left resident by the last dmpc_transition
+    int32_t *flags_host = nullptr; size_t flags_host_cap = 0;   // pinned: per-step verdicts of dmpc_transition
+    hipEvent_t flag_ev[2] = {nullptr, nullptr};
     int pc_fallback_scenes = 0;   // last dmpc_postcheck: scenes of a cell-grid search that were searched again by brute force
     std::vector<dmpc_ctx *> children;   // further contexts (own stream and buffers) for the other parts of a split batch of transitions
     std::vector<int> split_at;          // non-empty: the last dmpc_transition left scenes [split_at[i], split_at[i+1]) in part i (0: here, i > 0: children[i-1])
@@ -476,6 +478,8 @@ extern "C" void dmpc_destroy(dmpc_ctx *ctx)
     ctx->grp = nullptr;
     for (auto &ev : ctx->events) { (void)hipEventDestroy(ev.t0); (void)hipEventDestroy(ev.t1); (void)hipEventDestroy(ev.t2); }
     for (auto &ev : ctx->ev_pool) { (void)hipEventDestroy(ev.t0); (void)hipEventDestroy(ev.t1); (void)hipEventDestroy(ev.t2); }
+    for (int u = 0; u < 2; ++u) if (ctx->flag_ev[u]) (void)hipEventDestroy(ctx->flag_ev[u]);
+    if (ctx->flags_host) (void)hipHostFree(ctx->flags_host);
     if (ctx->dbg) (void)hipFree(ctx->dbg);
     if (ctx->d_tables) (void)hipFree(ctx->d_tables);
     hipStream_t st = ctx->stream;
@@ -1143,11 +1147,42 @@ static int transition_one(dmpc_ctx *ctx, int S, int N, const double *po, const d
     double *cur = ctx->lT.as<double>(), *nxt = ctx->lT2.as<double>();
     ctx->post_acc_S = 0;   // the scene accumulators of the fused post-step start from zero in every transition
     const bool mixed = ctx->precision == DMPC_PREC_MIXED;   // the scan of every step reads an fp32 copy of the current table
-    std::vector<int32_t> flags((size_t)K_T_max * S * 2, 0);
+    // The host looks at the per-step verdicts every `chunk` MPC steps -- one window BEHIND the steps it enqueues: the verdicts of window c
+    // are copied to pinned host memory behind an event, the steps of window c+1 are enqueued, and only then the host waits for the event
+    // of window c.  The device never idles while the host reads flags (a stream synchronisation per window cost 40-45 us of idle GPU per
+    // 8 steps: 8 % of a single-scene transition); the steps enqueued past the end of a trial are skipped on the device (scene_done), so
+    // what a scene records and reports does not change.
+    const size_t flag_ints = (size_t)K_T_max * S * 2;
+    if (ctx->flags_host_cap < flag_ints) {
+        if (ctx->flags_host) (void)hipHostFree(ctx->flags_host);
+        ctx->flags_host = nullptr; ctx->flags_host_cap = 0;
+        HIPCHK(ctx, hipHostMalloc((void **)&ctx->flags_host, flag_ints * 4, hipHostMallocDefault));
+        ctx->flags_host_cap = flag_ints;
+    }
+    int32_t *flags = ctx->flags_host;
+    for (int u = 0; u < 2; ++u)
+        if (!ctx->flag_ev[u]) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->flag_ev[u], hipEventDisableTiming));
     std::vector<int> done(S, 0);
     for (int s = 0; s < S; ++s) { K_T_used[s] = K_T_max; scene_status[s] = DMPC_ST_SOLVED; }
     int ndone = 0;
-    const int chunk = 8;   // host looks at the per-step flags every `chunk` MPC steps
+    const int chunk = 8;
+    int pend_k0 = -1, pend_k1 = -1, pend_ev = 0, nwin = 0;   // the window whose verdicts are in flight to the host
+    auto digest = [&]() -> int {   // wait for the pending window and fold its verdicts into done / K_T_used / scene_status
+        if (pend_k0 < 0) return 0;
+        HIPCHK(ctx, hipEventSynchronize(ctx->flag_ev[pend_ev]));
+        for (int kk = pend_k0; kk <= pend_k1; ++kk)
+            for (int s = 0; s < S; ++s) {
+                if (done[s]) continue;
+                const int32_t reached = flags[((size_t)kk * S + s) * 2], stbits = flags[((size_t)kk * S + s) * 2 + 1];
+                if (stbits & ~DMPC_ST_SOLVED) {   // some agent failed: the reference aborts the trial
+                    done[s] = 1; ndone++; K_T_used[s] = kk + 1; scene_status[s] = stbits;
+                } else if (reached) {             // ReachedGoal.m (failure_rate.m:125)
+                    done[s] = 1; ndone++; K_T_used[s] = kk + 1; scene_status[s] = DMPC_ST_SOLVED | DMPC_ST_REACHED;
+                }
+            }
+        pend_k0 = -1;
+        return 0;
+    };
     for (int k = 1; k < K_T_max && ndone < S; ++k) {
         if (mixed && table_f32(ctx, cur, ctx->lTf, A * N3, st)) return -1;
         const PostStep post{K_T_max, k, error_tol, xp, xv, xa, ctx->hist_p.as<double>(), ctx->hist_v.as<double>(), ctx->hist_a.as<double>(),
@@ -1166,22 +1201,16 @@ static int transition_one(dmpc_ctx *ctx, int S, int N, const double *po, const d
         HIPCHK(ctx, hipGetLastError());
         std::swap(cur, nxt);   // l = new_l (dmpc_soft_bound.m:146)
         if (k % chunk == 0 || k == K_T_max - 1) {
+            if (digest()) return -1;                                         // the window before this one (its steps ran while this one was enqueued)
             const int k0 = k <= chunk ? 0 : ((k - 1) / chunk) * chunk + 1;   // (the first window includes the initDMPC column)
             HIPCHK(ctx, hipMemcpyAsync(&flags[(size_t)k0 * S * 2], ctx->flags.as<int>() + (size_t)k0 * S * 2,
                                        (size_t)(k - k0 + 1) * S * 8, hipMemcpyDeviceToHost, st));
-            HIPCHK(ctx, hipStreamSynchronize(st));
-            for (int kk = k0; kk <= k; ++kk)
-                for (int s = 0; s < S; ++s) {
-                    if (done[s]) continue;
-                    const int32_t reached = flags[((size_t)kk * S + s) * 2], stbits = flags[((size_t)kk * S + s) * 2 + 1];
-                    if (stbits & ~DMPC_ST_SOLVED) {   // some agent failed: the reference aborts the trial
-                        done[s] = 1; ndone++; K_T_used[s] = kk + 1; scene_status[s] = stbits;
-                    } else if (reached) {             // ReachedGoal.m (failure_rate.m:125)
-                        done[s] = 1; ndone++; K_T_used[s] = kk + 1; scene_status[s] = DMPC_ST_SOLVED | DMPC_ST_REACHED;
-                    }
-                }
+            pend_ev = nwin++ & 1;
+            HIPCHK(ctx, hipEventRecord(ctx->flag_ev[pend_ev], st));
+            pend_k0 = k0; pend_k1 = k;
         }
     }
+    if (digest()) return -1;
     if (pk) {   // the histories stay resident for dmpc_postcheck either way; the download is optional
         HIPCHK(ctx, hipMemcpyAsync(pk, ctx->hist_p.p, hist, hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipMemcpyAsync(vk, ctx->hist_v.p, hist, hipMemcpyDeviceToHost, st));
