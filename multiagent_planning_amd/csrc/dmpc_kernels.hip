@@ -843,8 +843,7 @@ __global__ __launch_bounds__(64 * SCAN_WAVES_PER_WG, SCAN_WAVES_PER_SIMD) void d
 template <bool SOFT, int QCAP>
 __global__ __launch_bounds__(64, SOLVE_WAVES_PER_SIMD) void dmpc_solve_kernel(StepParams P)
 {
-    int no_ticket = 0;
-    solve_body<SOFT, QCAP, false>(P, threadIdx.x, blockIdx.x, gridDim.x, dmpc_smem, nullptr, nullptr, no_ticket);
+    solve_body<SOFT, QCAP, false>(P, threadIdx.x, blockIdx.x, gridDim.x, dmpc_smem, nullptr);
 }
 
 // Persistent form of the solve phase: one workgroup of up to 8 independent waves per CU (two per SIMD).  The Gram tables of the three
@@ -914,9 +913,8 @@ __global__ __launch_bounds__(512, 1) void dmpc_solve_persist_kernel(StepParams P
         if (dyn && left == 0 && lane == 0) tkv = atomicAdd(P.counter, 1);
         int ln = lane;
         asm volatile("" : "+v"(ln));
-        int unused = 0;
         const int agent = resolve(pos);
-        solve_body<SOFT, QCAP, true>(P, ln, agent, total, mine, shtab, nullptr, unused);
+        solve_body<SOFT, QCAP, true>(P, ln, agent, total, mine, shtab);
         LSYNC();
 #ifdef DMPC_DEV_TRACE
         // development: start time and duration of every queue position (dmpc_debug_trace with agent = -3) / of every agent (-5)

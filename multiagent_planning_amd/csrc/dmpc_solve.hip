@@ -73,6 +73,33 @@ __device__ __forceinline__ double wave_sum0(double v)
     v += dpp0_d<0x142>(v); v += dpp0_d<0x143>(v);
     return readlane_d(v, 63);
 }
+// Reciprocal, quotient and reciprocal square root of NORMAL positive doubles in a handful of instructions: the hardware estimate
+// (v_rcp_f64 / v_rsq_f64, ~26 bits) and two Newton steps (to the last bit or two), the quotient with one correction step on top.
+// The IEEE forms the compiler emits for `/`, `sqrt`, `rsqrt` carry 30-35 instructions each (scaling for denormals, the special
+// values, exact rounding): an eighth of an active-set iteration went into three quotients and one root.  The callers keep 0 and inf out
+// (explicit selects); nothing here reaches a result directly -- step lengths, the ratio test, the new factor column; the iterate the
+// solver returns is re-derived from the multipliers and refined.
+__device__ __forceinline__ double fast_rcp(double d)
+{
+    double x = __builtin_amdgcn_rcp(d);
+    double e = fma(-d, x, 1.0);
+    x = fma(x, e, x);
+    e = fma(-d, x, 1.0);
+    return fma(x, e, x);
+}
+__device__ __forceinline__ double fast_div(double a, double b)
+{
+    const double x = fast_rcp(b), q = a * x;
+    return fma(fma(-b, q, a), x, q);
+}
+__device__ __forceinline__ double fast_rsq(double d)
+{
+    double y = __builtin_amdgcn_rsq(d);
+    double e = fma(-d * y, y, 1.0);
+    y = fma(0.5 * y, e, y);
+    e = fma(-d * y, y, 1.0);
+    return fma(0.5 * y, e, y);
+}
 // inclusive prefix sum over the lanes (lane j: v_0 + ... + v_j), the gfx9 DPP scan: row_shr 1/2/4/8 inside the 16-lane rows, then
 // the two row broadcasts (rows 1 and 3 take row 0's / row 2's total, rows 2 and 3 the total of the lower half).  Fixed order.
 __device__ __forceinline__ double wave_scan_sum(double v)
@@ -190,9 +217,10 @@ __device__ __forceinline__ void remove_slot2(double *B, int lane, int &q, int l,
         B[SL::XS + lane] = Sj;
         LSYNC();
         // a_l is the diagonal entry as it stands (earlier rotations may have left it negative); every later a_j is a norm
-        const double aj = (lane == l) ? al : sqrt(B[SL::XS + (lane > 0 ? lane - 1 : 0)]);
+        const double Sp = B[SL::XS + (lane > 0 ? lane - 1 : 0)];
+        const double aj = (lane == l) ? al : ((Sp > 1e-300) ? Sp * fast_rsq(Sp) : 0.0);
         double cc = 1.0, ss = 0.0;
-        if (Sj > 1e-300) { const double inv = rsqrt(Sj); cc = bj * inv; ss = aj * inv; }
+        if (Sj > 1e-300) { const double inv = fast_rsq(Sj); cc = bj * inv; ss = aj * inv; }
         LSYNC();
         B[SL::RR + 2 * lane] = cc; B[SL::RR + 2 * lane + 1] = ss;   // (cosine, sine) pairs over RR | XS (128 doubles, contiguous): one 16-byte broadcast read each
         LSYNC();
@@ -272,16 +300,13 @@ __device__ __forceinline__ void post_step_part(const KargPtr Qp, const int lane,
 }
 
 // `bidx`: the workgroup's index (one-agent-per-workgroup launches, renumbered XCD-aware and sent through the launch order
-// here) or -- persistent form -- the AGENT the wave is about to solve (the queue position already resolved through the order:
-// the persistent loop loads it one agent ahead); `smem`: this wave's LDS; `shtab`: the workgroup-shared tables (persistent
-// form); `claim`: queue head the persistent loop wants its next ticket from (or null) -- claimed into `ticket` once every global
-// load of the agent's set-up has been consumed (loads and returning atomics come back in issue order on this part: an atomic
-// issued ahead of the set-up loads would be waited for with the first of them).
+// here) or -- persistent form -- the AGENT the wave is about to solve (the queue position already resolved through the order
+// by the persistent loop); `smem`: this wave's LDS; `shtab`: the workgroup-shared tables (persistent
+// form).
 template <bool SOFT, int QCAP, bool PERSIST>
 __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, const int bidx, const int nblocks,
-                                           unsigned char *smem, const double *shtab, int *claim, int &ticket)
+                                           unsigned char *smem, const double *shtab)
 {
-#define after_loads() do { if (PERSIST && claim && lane == 0) ticket = atomicAdd(claim, 1); } while (0)
     using SL = SolveLds<SOFT, QCAP, PERSIST>;
     constexpr bool soft = SOFT;
     const int nrmax = P.nrmax, var = P.variant;
@@ -322,10 +347,9 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
         po[d] = P.x_p[3 * gid + d]; vo[d] = P.x_v[3 * gid + d];
         ao[d] = P.x_a[3 * gid + d]; pf[d] = P.pf[3 * gid + d];
     }
-    if (P.only_flagged && !(stq & ST_QOVER)) { after_loads(); return; }   // tier 2: only agents that overflowed tier 1
-    if (h1.x & 8) { after_loads(); return; }                              // agent of a scene that already stopped
+    if (P.only_flagged && !(stq & ST_QOVER)) return;   // tier 2: only agents that overflowed tier 1
+    if (h1.x & 8) return;                              // agent of a scene that already stopped
     if (h1.x & 16) {   // finished by the scan (unconstrained exit): nothing to solve; a fused post-step still takes its outputs
-        after_loads();
         if (P.post_on) {
             const KargPtr Qp = kernarg_params();
             const int st_done = Qp->status[gid];
@@ -414,14 +438,13 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
         wlo_l = sel3(P.pmin, ax_l) - sel3(po, ax_l) - sh;
         // pivot weights: the entering constraint is the one farthest from feasibility in the metric of the problem,
         // violation / |n|_{H^-1} (compared in fp32: the choice only orders the pivots)
-        wbox_f = (float)rsqrt(G[k_l * 31]); wpos_f = (float)rsqrt(G[(15 + k_l) * 31]);
+        wbox_f = __builtin_amdgcn_rsqf((float)G[k_l * 31]); wpos_f = __builtin_amdgcn_rsqf((float)G[(15 + k_l) * 31]);   // (pivot weights: fp32)
     }
     auto row_weight = [&](double x0, double x1, double x2, int kc, double sd) -> float {
-        return (float)rsqrt(G[(15 + kc) * 31] * (x0 * x0 + x1 * x1 + x2 * x2) + (soft ? 0.5 * sd * sd : 0.0));
+        return __builtin_amdgcn_rsqf((float)(G[(15 + kc) * 31] * (x0 * x0 + x1 * x1 + x2 * x2) + (soft ? 0.5 * sd * sd : 0.0)));
     };
 #pragma unroll
     for (int c = 0; c < RC; ++c) rcw[c] = row_weight(rcx0[c], rcx1[c], rcx2[c], rckc[c], rcsd[c]);
-    after_loads();
 
     // ---------------------------------------------------------------- a7: dual active-set solve
     const bool ladder = soft && (var == VAR_BOUND || var == VAR_BOUND2 || var == VAR_ALL3 || cppv);
@@ -860,7 +883,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                     if (crash) {   // append without a step: column [-r/rho; 1/rho] with rho^2 = s_pp - |T's|^2, lambda_p = 0 until the batch is solved
                         const double dlt = spp - wave_sum0(dvj * dvj);
                         if (!(dlt > 1e-9 * spp)) { crash_stop = true; break; }   // (distinct bounds are independent; guard only)
-                        const double irho = rsqrt(dlt);
+                        const double irho = fast_rsq(dlt);
                         if (lane < ((q + 8) & ~7)) B[SL::T + tcol(q) + lane] = (lane < q) ? (-ri * irho) : ((lane == q) ? irho : 0.0);
                         write_slot(p, 0.0);
                         if (lane == p.idx) cslot = (cslot & ~0xffu) | (unsigned)q | (p.ty == TY_BOXHI ? 0x10000u : 0x20000u);
@@ -906,12 +929,13 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                     // more active constraints than variables is impossible: whatever round-off says, a constraint picked when
                     // the working set already spans all 45 + nlive variables is dependent
                     const bool dependent = !(delta > 1e-13 * spp) || q >= N3 + nlive;
-                    const double t2 = dependent ? INFINITY : vp / delta;
+                    const double t2 = dependent ? INFINITY : fast_div(vp, delta);
                     // ratio test on the multipliers: the blocking slot maximises r_j / lambda_j (identity 0: one bound_ctrl
                     // DPP maximum instead of a minimum with an infinity identity); t1 = 1 / max
-                    const double iratio = (lane < q && ri > 0.0) ? (ri / B[SL::SLAM + lane]) : 0.0;
+                    const double lam_l = B[SL::SLAM + lane];
+                    const double iratio = (lane < q && ri > 0.0) ? (lam_l > 1e-300 ? fast_div(ri, lam_l) : INFINITY) : 0.0;
                     const double imax = wave_max0(iratio);
-                    const double t1 = 1.0 / imax;   // inf when no multiplier decreases
+                    const double t1 = imax > 0.0 ? (imax < INFINITY ? fast_rcp(imax) : 0.0) : INFINITY;   // inf when no multiplier decreases
                     const double t = fmin(t1, t2);
                     PH(15);
 #ifdef DMPC_DEV_TRACE
@@ -949,7 +973,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                     if (t2 <= t1) {
                         // full step: append p (new column of T = [-r/rho ; 1/rho], zero below the diagonal)
                         if (q >= QCAP) { rc = 2; break; }
-                        const double irho = rsqrt(delta);
+                        const double irho = fast_rsq(delta);
                         if (lane < ((q + 8) & ~7)) B[SL::T + tcol(q) + lane] = (lane < q) ? (-ri * irho) : ((lane == q) ? irho : 0.0);
                         write_slot(p, lam_p);
                         if (p.ty < TY_COLL) {
@@ -1093,4 +1117,3 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
         }
     }
 }
-#undef after_loads
