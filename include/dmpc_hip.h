@@ -102,8 +102,9 @@ enum {
     DMPC_PREC_F64 = 0,   /* everything fp64 (the reference is MATLAB double)                                          */
     DMPC_PREC_MIXED = 1  /* the prediction table is kept in fp32 and the scan + collision rows (a5/a6) are computed in
                           * fp32; the QP itself (cost, factor, multipliers, propagation) and all inputs / outputs stay
-                          * fp64.  Host-pointer entry points (dmpc_step_batch, dmpc_solve_one, dmpc_transition); the
-                          * device-layout and multi-GPU entry points take fp64 tables only.  BASELINE configs[4].    */
+                          * fp64.  Every entry point takes such a context: the host-pointer ones, the device-pointer steps (they
+                          * make the fp32 copy of the caller's fp64 table themselves) and the sharded transitions, where the table
+                          * the ranks exchange per step is the fp32 one (half the payload).  BASELINE configs[4].               */
 };
 
 /* Create a solver context.  Replaces the constants/precompute preamble of dmpc/matlab/dmpc_soft_bound.m:80-108 and the DMPC ctor
@@ -213,9 +214,10 @@ int dmpc_advance_device(dmpc_ctx *ctx, int count, const double *p_out, const dou
  * K_T_used[S]: number of MPC steps taken per scene; scene_status[S]: OR of agent status bits at
  * the step where the scene stopped; DMPC_ST_SOLVED | DMPC_ST_REACHED = every agent within error_tol of its goal
  * (ReachedGoal.m), DMPC_ST_SOLVED alone = ran to K_T_max without reaching (failed_goal, failure_rate.m:131-134).
- * Batches of 32 or more scenes are run as two halves on two internal contexts (two HIP streams, one helper host thread
- * for the duration of the call) so that the slow tail of one half overlaps the other; scenes are independent, results
- * do not depend on the split (DMPC_NO_SPLIT=1 in the environment disables it). */
+ * Batches of 32 or more scenes are run in parts (2; 4 from 128 scenes on) on internal contexts of their own (a HIP stream and a
+ * helper host thread each for the duration of the call) so that the slow tail of one part overlaps the others; scenes are independent,
+ * results do not depend on the split.  On a DMPC_DEVICE_ALL context the agents of every scene are sharded over the GPUs instead
+ * (see dmpc_create), and batches of 64 or more scenes run as two such groups side by side. */
 int dmpc_transition(dmpc_ctx *ctx, int S, int N, const double *po, const double *pf, int K_T_max,
                     double error_tol, double *pk, double *vk, double *ak, int32_t *K_T_used,
                     int32_t *scene_status);
@@ -273,7 +275,11 @@ int dmpc_transition_sharded_gather(dmpc_ctx *ctx, int S, int N, const double *po
  * scene_mask (optional, [S]): 0 skips a scene (the reference only post-checks trials that stayed feasible and
  * reached their goals, failure_rate.m:136); skipped scenes report NaN / 0.  A checked scene whose histories are
  * all zero is an error (MATLAB: h_scaled = 0 makes tk empty and spline() fails).
- * p_interp (optional): [S][N][ns_alloc][3] interpolated positions (samples >= n_samples[s] are zero). */
+ * p_interp (optional): [S][N][ns_alloc][3] interpolated positions (samples >= n_samples[s] are zero).
+ * Any number of agents per scene: up to 256 the pairwise check is the literal all-pairs search; larger scenes bin the agents of every
+ * sample into a uniform cell grid (cell = 2 rmin in the metric of the check), test the 27-neighbourhood with the same fp64 expression and
+ * fall back to a tiled all-pairs pass for scenes without any pair that close -- min_dist and violation are exact either way.
+ * After dmpc_transition on a DMPC_DEVICE_ALL context, or dmpc_transition_sharded_gather, the resident histories are the scene-wide ones. */
 int dmpc_postcheck(dmpc_ctx *ctx, int S, int N, int KT_alloc, const int32_t *K_T_used, const int32_t *scene_mask,
                    const double *pk, const double *vk, const double *ak, const double *pf, double vmax, double amax, double Ts,
                    double *r_factor, double *h_scaled, int32_t *n_samples, double *min_dist, int32_t *violation,
