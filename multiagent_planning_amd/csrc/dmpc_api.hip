@@ -742,7 +742,8 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
 #ifdef DMPC_DEV_PW   // development builds: fewer persistent waves per CU (how much does a long agent lose to the wave it shares a SIMD with?)
         if (pw > DMPC_DEV_PW) pw = DMPC_DEV_PW;
 #endif
-        return pw > 8 ? 8 : pw;
+        const int cap = soft ? 8 : 9;   // waves per workgroup the kernels are compiled for (launch bounds)
+        return pw > cap ? cap : pw;
     };
     // the working-set capacity is a template parameter of the solve kernels
     auto launch_plain = [&](int qcap, size_t lds) {

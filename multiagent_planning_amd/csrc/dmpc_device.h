@@ -86,10 +86,10 @@ inline size_t scan_lds_bytes() { return (96 * 8 + (size_t)SCAN_CAND_CAP * 4 + 15
 // bytes of LDS of one solve wave (layout: SolveLds in dmpc_solve.hip; `persist`: the tables are shared by the workgroup)
 inline size_t solve_lds_bytes(int nrmax, bool soft, int qcap, bool persist)
 {
-    size_t dbl = (size_t)t_doubles(qcap) + 2 * 48 + 2 * 64 + (soft ? 2 * 48 : 0) + 5 * (size_t)qcap + (soft ? (size_t)qcap : 0) + (size_t)qcap / 2;
+    size_t dbl = (size_t)t_doubles(qcap) + 2 * 48 + 2 * 64 + (soft ? 2 * 48 : 48) + 5 * (size_t)qcap + (soft ? (size_t)qcap : 0) + (size_t)qcap / 2;
     if (!persist) dbl += TAB_CASE_DOUBLES + TAB_L_DOUBLES + 1;
     if (soft) dbl += (size_t)nrmax;                 // r_eps
-    const size_t bytes = dbl * 8 + (size_t)nrmax;   // + row flags (bytes)
+    const size_t bytes = dbl * 8 + (soft ? (size_t)nrmax : (((size_t)nrmax + 31) / 32) * 4);   // + row flags (soft: a byte per row; slack-free: a bit)
     return (bytes + 15) & ~(size_t)15;
 }
 // persistent solve kernel: the tables at the front of the workgroup's LDS

@@ -851,8 +851,10 @@ __global__ __launch_bounds__(64, SOLVE_WAVES_PER_SIMD) void dmpc_solve_kernel(St
 // claims agents from a global queue (heaviest first when order_kernel ran) until it is empty, so a wave that finishes a
 // light agent immediately starts the next one and the launch ends when the LAST agent ends, not when the slowest
 // workgroup slot drains.  No workgroup barrier after the table load: the waves never synchronise.
+// (slack-free variants: 9 waves per workgroup -- with the row flags as bits a ninth wave fits next to the tables in the CU's 160 KB,
+// and 168 registers per lane hold the kernel without spills; the slack variants need 17 KB of LDS and 230 registers per wave: 8)
 template <bool SOFT, int QCAP>
-__global__ __launch_bounds__(512, 1) void dmpc_solve_persist_kernel(StepParams P)
+__global__ __launch_bounds__(SOFT ? 512 : 576, 1) void dmpc_solve_persist_kernel(StepParams P)
 {
     // tier 2 works through the list of agents tier 1 flagged (P.order points at it); usually it is empty
     int total = P.only_flagged ? *P.flag_count : P.S * P.c_count;

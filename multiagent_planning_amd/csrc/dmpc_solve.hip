@@ -38,7 +38,8 @@ struct SolveLds {   // offsets in doubles from the wave's LDS base
     static constexpr int SLAM = SD + QCAP;
     static constexpr int SSS = SLAM + QCAP;
     static constexpr int META = SSS + (SOFT ? QCAP : 0);   // QCAP ints
-    static constexpr int TAB = META + QCAP / 2;             // one-agent-per-workgroup form: own copy of G (900) + Lt (225)
+    static constexpr int WU = META + QCAP / 2;              // slack-free variants: w_unc (48 doubles; two registers less across the solver loop)
+    static constexpr int TAB = WU + (SOFT ? 0 : 48);        // one-agent-per-workgroup form: own copy of G (900) + Lt (225)
     static constexpr int VAR = TAB + (PERSIST ? 0 : TAB_CASE_DOUBLES + TAB_L_DOUBLES + 1);   // r_eps (soft: nrmax doubles), r_fl (nrmax bytes)
 };
 
@@ -324,7 +325,8 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
 
     double *B = (double *)__builtin_assume_aligned(smem, 16);
     double *r_eps = B + SL::VAR;                                                   // soft variants: nrmax doubles
-    unsigned char *r_fl = (unsigned char *)(B + SL::VAR + (soft ? nrmax : 0));     // nrmax bytes
+    unsigned char *r_fl = (unsigned char *)(B + SL::VAR + (soft ? nrmax : 0));     // soft variants: nrmax bytes of flags; slack-free: nrmax BITS
+    unsigned *r_bits = (unsigned *)r_fl;   // (their only flag is RF_COLL; 80 instead of 640 bytes per wave: a ninth persistent wave fits the CU's LDS)
     int *s_meta = (int *)(B + SL::META);
     // collision rows: per-agent slice of the global scratch written by the scan kernel (lane = row: coalesced)
     const size_t per = (size_t)nrmax * (soft ? 7 : 4);
@@ -401,13 +403,14 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
     const bool comp = lane < N3;
     // unconstrained minimiser per axis: a_unc = -H1^-1 f,  f = -2(q L_K'(pf - A0_K x0) + s [ao;0..])
     //   => a_unc(k) = 2 q g (H1^-1 L')[k][K-1] + 2 s ao H1^-1[k][0],  g = pf - (po + K h vo)      (:88/:93)
-    double a_unc = 0.0, w_unc = 0.0;
+    double a_unc = 0.0, w_unc = 0.0;   // (w_unc: a register of the slack variants; the slack-free ones keep it in LDS, B[SL::WU])
     const double gax = comp ? goal_gap(sel3(pf, ax_l), sel3(po, ax_l), sel3(vo, ax_l), P.h) : 0.0;
     const double ao_l = comp ? sel3(ao, ax_l) : 0.0;
     if (comp) {
         a_unc = unc_entry(qw, sw, gax, ao_l, G[k_l * 30 + 15 + (K - 1)], G[k_l * 30]);
         // w_unc = Lambda a_unc from the same table
         w_unc = unc_entry(qw, sw, gax, ao_l, G[(15 + k_l) * 30 + 15 + (K - 1)], G[(15 + k_l) * 30]);
+        if (!SOFT) B[SL::WU + lane] = w_unc;
     }
 
     // Dual-bound certificate (slack-free variants): the iterate of the dual method minimises the cost over its working
@@ -428,12 +431,10 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
     }
 
     // per-lane constants of component (k_l, ax_l)
-    double whi_l = 0.0, wlo_l = 0.0, p0_l = 0.0, vo_l = 0.0;
+    double whi_l = 0.0, wlo_l = 0.0;
     float wbox_f = 0.f, wpos_f = 0.f;
     if (comp) {
         const double sh = (double)(k_l + 1) * P.h * sel3(vo, ax_l);   // A_initp(k,:) [po;vo] - po
-        vo_l = sel3(vo, ax_l);
-        p0_l = init_pos(k_l, P.h, vo_l, sel3(po, ax_l));               // A_initp(k,:) [po;vo]
         whi_l = sel3(P.pmax, ax_l) - sel3(po, ax_l) - sh;        // pmax - A0 x0  (:72)
         wlo_l = sel3(P.pmin, ax_l) - sel3(po, ax_l) - sh;
         // pivot weights: the entering constraint is the one farthest from feasibility in the metric of the problem,
@@ -508,8 +509,9 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
             int iters = 0;
             if (!warm) {
                 q = 0; cslot = 0x0000ffffu; cm = 0ull; rcfl = 0; nlive = 0;
-                for (int i = lane + (soft ? 0 : 64 * RC); i < nr; i += 64) r_fl[i] = 0;
-                a = a_unc; w = w_unc;
+                if (soft) { for (int i = lane; i < nr; i += 64) r_fl[i] = 0; }
+                else { for (int i = lane; i < ((nr + 31) >> 5); i += 64) r_bits[i] = 0u; }
+                a = a_unc; w = SOFT ? w_unc : (comp ? B[SL::WU + lane] : 0.0);
                 if (comp) { B[SL::A + lane] = a; B[SL::W + lane] = w; }
                 if (soft) for (int i = lane; i < nr; i += 64) r_eps[i] = 0.0;
             }
@@ -610,7 +612,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                 double za, zw;
                 direction(za, zw);
                 if (comp) {
-                    a = a_unc + za; w = w_unc + zw;
+                    a = a_unc + za; w = (SOFT ? w_unc : B[SL::WU + lane]) + zw;
                     B[SL::A + lane] = a; B[SL::W + lane] = w;
                 }
                 if (soft) {
@@ -665,7 +667,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                     if (!soft && didx < 64 * RC) { if (lane == (didx & 63)) rcfl &= ~(1u << (didx >> 6)); }
                     else if (lane == 0) {
                         const int bit = (dty == TY_COLL) ? RF_COLL : (dty == TY_SLKU ? RF_SLKU : RF_SLKL);
-                        r_fl[didx] &= ~bit;
+                        if (soft) r_fl[didx] &= ~bit; else r_bits[didx >> 5] &= ~(1u << (didx & 31));
                     }
                 }
                 remove_slot2<SOFT, QCAP, PERSIST>(B, lane, q, l, cslot, cm);
@@ -725,7 +727,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                     }
                 }
                 for (int i = lane + 64 * RC; i < nr; i += 64) {   // the rest streams from the global scratch
-                    const int fl = r_fl[i], kc = r_kc[i];
+                    const int fl = soft ? (int)r_fl[i] : (int)((r_bits[i >> 5] >> (i & 31)) & 1u), kc = r_kc[i];
                     const double x0 = r_xi[3 * i], x1 = r_xi[3 * i + 1], x2 = r_xi[3 * i + 2];
                     double v = -(x0 * B[SL::W + 3 * kc] + x1 * B[SL::W + 3 * kc + 1] + x2 * B[SL::W + 3 * kc + 2]) - r_b[i];
                     if (soft && (fl & RF_LIVE)) {
@@ -985,7 +987,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                             if (!soft && p.idx < 64 * RC) { if (lane == (p.idx & 63)) rcfl |= 1u << (p.idx >> 6); }
                             else if (lane == 0) {
                                 const int bit = (p.ty == TY_COLL) ? RF_COLL : (p.ty == TY_SLKU ? RF_SLKU : RF_SLKL);
-                                r_fl[p.idx] |= bit;
+                                if (soft) r_fl[p.idx] |= bit; else r_bits[p.idx >> 5] |= 1u << (p.idx & 31);
                             }
                             if (p.ty == TY_COLL && comp && k_l == p.gi - 15) cm |= 1ull << q;
                         }
@@ -1070,8 +1072,13 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
     }
     double p_out = 0.0, v_out = 0.0, a_out = 0.0;
     if (solved && comp) {
-        // p = A_p a + A_initp [po;vo] ; v = A_v a + vo   (propStatedmpc.m:3-4); p0_l, vo_l: per-lane copies kept from the set-up
-        // (the uniform state would cost a dozen SGPRs across the solver loop, a second read a memory round trip here)
+        // p = A_p a + A_initp [po;vo] ; v = A_v a + vo   (propStatedmpc.m:3-4).  The agent's state is read again here -- six SCALAR loads
+        // through constant-address-space pointers (the values are wave-uniform) -- instead of living in registers across the solver loop
+        typedef const double __attribute__((address_space(4))) *ConstD;
+        const ConstD sp = (ConstD)(unsigned long long)(Qp->x_p + 3 * (size_t)gid), sv_ = (ConstD)(unsigned long long)(Qp->x_v + 3 * (size_t)gid);
+        const double po0 = sp[0], po1 = sp[1], po2 = sp[2], vo0 = sv_[0], vo1 = sv_[1], vo2 = sv_[2];
+        const double vo_l = ax_l == 0 ? vo0 : (ax_l == 1 ? vo1 : vo2);
+        const double p0_l = init_pos(k_l, Qp->h, vo_l, ax_l == 0 ? po0 : (ax_l == 1 ? po1 : po2));   // A_initp(k,:) [po;vo]
         p_out = w + p0_l;
         v_out = vel_out(B + SL::A, k_l, ax_l, Qp->h, vo_l);
         a_out = a;
