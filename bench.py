@@ -456,6 +456,32 @@ def main():
     else:
         strong_hung = False
 
+    # --emulate-gpus G: the single-process multi-GPU path (DMPC_DEVICE_ALL) with its G ranks emulated on this GPU -- whole transitions as ONE
+    # group and as two groups side by side (the exchange of one half under the solve of the other).  The ranks share the device here, so this
+    # shows the host-side cost of the exchange protocol (threads, barriers, events, same-device copies), not xGMI; never a headline number.
+    group_overlap = None
+    if emu and rank == 0:
+        try:
+            cfgE = dict(wl.CONFIGS["C4"]); NE, SE = 100 * emu, 128
+            kwE = wl.solver_kwargs(cfgE, NE)
+            poE, pfE = wl.make_scenes(cfgE, SE, NE, wl.SEED0 + 60)
+            group_overlap = {"workload": f"{SE} scenes x {NE} agents, solveSoftDMPCbound, 40 MPC steps, ONE process, {emu} ranks emulated on one GPU"}
+            for label, opts in (("one_group_ms_per_step", {"no_split": 1}), ("two_groups_ms_per_step", {})):
+                mp.Dmpc.emulate_devices(emu)
+                dg = mp.Dmpc("bound", device=mp.Dmpc.DEVICE_ALL, **kwE)
+                for k_, v_ in opts.items():
+                    dg.debug_option(k_, v_)
+                dg.transition(poE[:8], pfE[:8], 6, cfgE["error_tol"], histories=False)
+                best = 1e9
+                for _ in range(3):
+                    tt = time.perf_counter(); rg = dg.transition(poE, pfE, 40, cfgE["error_tol"], histories=False); best = min(best, time.perf_counter() - tt)
+                group_overlap[label] = best * 1e3 / max(int((rg["K_T_used"] - 1).max()), 1)
+                del dg
+        except Exception as e:   # noqa: BLE001
+            group_overlap = {"error": str(e)[:200]}
+        finally:
+            mp.Dmpc.emulate_devices(0)
+
     st = status.cpu().numpy()
     inf = info.cpu().numpy()
 
@@ -513,6 +539,8 @@ def main():
             line["secondary"] = secondary
         if strong is not None:
             line["strong_scaling"] = strong
+        if group_overlap is not None:
+            line["single_process_group_emulated"] = group_overlap
         if not args.no_cpu_baseline and G == 1:
             # CPU baseline: the oracle (the literal dense QP of the .m files + dense Goldfarb-Idnani, oracle/dmpc_oracle.c) on
             # the same captured step, timed on this box's host cores.  The scenes of the batch are independent problems, so
