@@ -127,13 +127,13 @@ __device__ __forceinline__ double sel3(const double *v, int ax) { return ax == 0
 #define SCAN_WAVES_PER_WG 4
 #endif
 #ifndef QUEUE_CHUNK
-#define QUEUE_CHUNK 2   // measured on the headline workload (M solves/s): 1: 45.8, 2: 47.7, 3: 46.6, 4: 46.5
+#define QUEUE_CHUNK 2   // measured on the headline workload (M solves/s), tickets claimed at the end of a solve (round 3): 1: 48.9, 2: 52.0, 3: 51.4, 4: 50.5
 #endif
 #ifndef QUEUE_T1
 #define QUEUE_T1 1
 #endif
 #ifndef QUEUE_T3
-#define QUEUE_T3 1
+#define QUEUE_T3 2   // single-position tickets for the last 2 x #waves positions (1: 52.0, 2: 52.3, 4: 50.9, 8: 49.3 M solves/s)
 #endif
 #ifndef SOLVE_WAVES_PER_SIMD
 #define SOLVE_WAVES_PER_SIMD 2
@@ -843,7 +843,8 @@ __global__ __launch_bounds__(64 * SCAN_WAVES_PER_WG, SCAN_WAVES_PER_SIMD) void d
 template <bool SOFT, int QCAP>
 __global__ __launch_bounds__(64, SOLVE_WAVES_PER_SIMD) void dmpc_solve_kernel(StepParams P)
 {
-    solve_body<SOFT, QCAP, false>(P, threadIdx.x, blockIdx.x, gridDim.x, dmpc_smem, nullptr);
+    int tk_unused = 0; bool cl_unused = false;
+    solve_body<SOFT, QCAP, false>(P, threadIdx.x, blockIdx.x, gridDim.x, dmpc_smem, nullptr, false, tk_unused, cl_unused);
 }
 
 // Persistent form of the solve phase: one workgroup of up to 8 independent waves per CU (two per SIMD).  The Gram tables of the three
@@ -875,15 +876,16 @@ __global__ __launch_bounds__(SOFT ? 512 : 576, 1) void dmpc_solve_persist_kernel
     //     where the launch ends (the last #waves positions: a fine-grained tail), and for QUEUE_CHUNK adjacent positions in
     //     between (the light bulk): fewer atomics, at most one light chunk of imbalance -- and a pre-claimed chunk waits behind
     //     its wave's current agent, which is why the chunk is short;
-    //   * the next ticket is claimed BEFORE the current agent is solved and read after it: its latency hides behind the solve.
+    //   * the next ticket is claimed when the current agent is as good as solved (solve_body: CLAIM_NEXT) and read after its output
+    //     stage: most of the latency hides there, and no position waits behind a solve that turns out long.
     const int nw = (int)(gridDim.x * (blockDim.x >> 6));
     const int rest = total > nw ? total - nw : 0;
     const int T1 = rest < QUEUE_T1 * nw ? rest : QUEUE_T1 * nw;
     const int T3 = (rest - T1) < QUEUE_T3 * nw ? (rest - T1) : QUEUE_T3 * nw;
     constexpr int CHUNK = QUEUE_CHUNK;
     const int mid = rest - T1 - T3, T2 = (mid + CHUNK - 1) / CHUNK;
-    // The next ticket is claimed right before the current agent is solved and read after it: the atomic's latency hides behind the
-    // solve.  (Claiming two positions ahead -- the agent behind the next ticket resolved through the order during the solve, so that
+    // (Rounds 2-3 claimed the next ticket right BEFORE the current agent was solved -- the atomic's latency hides completely -- and the
+    // positions parked behind long solves ended the launch late: waves ending 779-878 us.  Claiming two positions ahead -- the agent behind the next ticket resolved through the order during the solve, so that
     // only one memory round trip per agent is exposed -- was built and measured in round 3: 0.935 against 0.891 ms on the headline
     // launch.  A claimed position waits behind its wave's current agent, and when that one is a 300-500 us infeasibility proof the
     // light agents parked behind it end the launch late.)
@@ -912,11 +914,13 @@ __global__ __launch_bounds__(SOFT ? 512 : 576, 1) void dmpc_solve_persist_kernel
         const long long t_a = wall_clock64();
 #endif
         int tkv = 0;
-        if (dyn && left == 0 && lane == 0) tkv = atomicAdd(P.counter, 1);
+        bool claimed = false;
+        const bool want = dyn && left == 0;
         int ln = lane;
         asm volatile("" : "+v"(ln));
         const int agent = resolve(pos);
-        solve_body<SOFT, QCAP, true>(P, ln, agent, total, mine, shtab);
+        solve_body<SOFT, QCAP, true>(P, ln, agent, total, mine, shtab, want, tkv, claimed);
+        if (want && !claimed && lane == 0) tkv = atomicAdd(P.counter, 1);   // (the quick ways out of the solver: stopped scene, agent finished by the scan)
         LSYNC();
 #ifdef DMPC_DEV_TRACE
         // development: start time and duration of every queue position (dmpc_debug_trace with agent = -3) / of every agent (-5)

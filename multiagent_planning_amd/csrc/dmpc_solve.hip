@@ -306,8 +306,14 @@ __device__ __forceinline__ void post_step_part(const KargPtr Qp, const int lane,
 // form).
 template <bool SOFT, int QCAP, bool PERSIST>
 __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, const int bidx, const int nblocks,
-                                           unsigned char *smem, const double *shtab)
+                                           unsigned char *smem, const double *shtab, const bool want_ticket, int &ticket, bool &claimed)
 {
+    // Persistent form: the wave's NEXT queue ticket is claimed (lane 0, result left in flight in `ticket`) when the agent is as good as done
+    // -- the first violation scan that finds nothing, or the start of the output stage -- so that the atomic's latency hides behind the
+    // output stage and nothing is claimed ahead of a solve: a position claimed before a 300-500 us infeasibility proof waited behind
+    // it, and such parked agents were the last to end the launch (round 3: the waves ended 779-878 us, busy fraction 0.90).
+#define CLAIM_NEXT() do { if (PERSIST && want_ticket && !claimed) { claimed = true; \
+        if (lane == 0) ticket = atomicAdd(kernarg_params()->counter, 1); } } while (0)
     using SL = SolveLds<SOFT, QCAP, PERSIST>;
     constexpr bool soft = SOFT;
     const int nrmax = P.nrmax, var = P.variant;
@@ -746,6 +752,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                 PH(0);
                 if (wm == 0ull) {
                     PHC(10);
+                    CLAIM_NEXT();
                     if (!crash && (q == 0 || fresh)) break;   // optimal
                     if (!crash && !soft) {
                         // (slack-free variants; the slack variants carry multipliers of 1e5-1e6 and always take the full verification)
@@ -1061,6 +1068,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
     // The launch parameters the output stage needs are read again from the kernel-argument segment (scalar loads through an
     // opaque pointer) instead of staying live in SGPRs across the solver loop, where they were spilled to VGPR lanes.
     const KargPtr Qp = kernarg_params();
+    CLAIM_NEXT();
     int nslack = 0;
     if (solved) {
         status |= ST_SOLVED;
