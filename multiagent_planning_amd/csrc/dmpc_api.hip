@@ -307,7 +307,7 @@ static void build_case_tables(double h, double q, double s, double *out /*675*/,
 // (H1^-1 L')(i,j), G[W i][W j] = L H1^-1 L' -- then Lt[k][kk] = Lambda(kk,k)
 static int upload_tables(dmpc_ctx *ctx)
 {
-    std::vector<double> t(TAB_DOUBLES, 0.0);
+    std::vector<double> t(TAB_ALL_DOUBLES, 0.0);
     const dmpc_params &p = ctx->prm;
     const double sfree = p.Sfree > 0 ? p.Sfree : 10.0;
     const double qs[3] = {p.Qfar > 0 ? p.Qfar : 1000.0, p.Qnear > 0 ? p.Qnear : 10000.0, p.Q1};   // far (:44-47), near (:49-52), coll (:54-57)
@@ -323,6 +323,31 @@ static int upload_tables(dmpc_ctx *ctx)
                 G[(15 + j) * 30 + i] = hmp[225 + i * K + j];
                 G[(15 + i) * 30 + 15 + j] = hmp[450 + i * K + j];
             }
+        // Tp = C^-T with H1^-1 = C C' (the ROUNDED table above: the numbers the solver's Schur complement is made of).  The leading
+        // m x m block of Tp is the inverse factor of the leading block of H1^-1: S^-1 = Tp Tp' for the bounds of steps 0..m-1 of one axis.
+        {
+            long double C[K][K], Ci[K][K];
+            memset(C, 0, sizeof(C)); memset(Ci, 0, sizeof(Ci));
+            for (int j = 0; j < K; ++j) {
+                long double d = hmp[j * K + j];
+                for (int k = 0; k < j; ++k) d -= C[j][k] * C[j][k];
+                C[j][j] = sqrtl(d);
+                for (int i = j + 1; i < K; ++i) {
+                    long double v = hmp[i * K + j];
+                    for (int k = 0; k < j; ++k) v -= C[i][k] * C[j][k];
+                    C[i][j] = v / C[j][j];
+                }
+            }
+            for (int c2 = 0; c2 < K; ++c2)   // C^-1 column by column (forward substitution)
+                for (int i = c2; i < K; ++i) {
+                    long double v = (i == c2) ? 1.0L : 0.0L;
+                    for (int k = c2; k < i; ++k) v -= C[i][k] * Ci[k][c2];
+                    Ci[i][c2] = v / C[i][i];
+                }
+            double *Tp = &t[(size_t)TAB_DOUBLES + (size_t)c * TAB_TP_CASE];
+            for (int i = 0; i < K; ++i)
+                for (int j = i; j < K; ++j) Tp[i * (31 - i) / 2 + j - i] = (double)Ci[j][i];
+        }
     }
     for (int k = 0; k < K; ++k)
         for (int kk = k; kk < K; ++kk) t[3 * TAB_CASE_DOUBLES + k * K + kk] = p.h * p.h / 2 + (double)(kk - k) * p.h * p.h;
@@ -392,7 +417,7 @@ static dmpc_ctx *create_one(const dmpc_params *prm, int device, int precision)
     ctx->precision = precision;
     ctx->prm = *prm;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipMalloc((void **)&ctx->d_tables, sizeof(double) * TAB_DOUBLES) != hipSuccess || upload_tables(ctx) != 0) {
+        hipMalloc((void **)&ctx->d_tables, sizeof(double) * TAB_ALL_DOUBLES) != hipSuccess || upload_tables(ctx) != 0) {
         g_err = "dmpc_create: device initialisation failed: " + ctx->err;
         dmpc_destroy(ctx);
         return nullptr;

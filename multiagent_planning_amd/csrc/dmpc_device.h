@@ -79,6 +79,12 @@ constexpr int SCAN_CAND_CAP = 1024;   // (neighbour, step) candidates buffered p
 constexpr int TAB_CASE_DOUBLES = 900;
 constexpr int TAB_L_DOUBLES = 225;
 constexpr int TAB_DOUBLES = 3 * TAB_CASE_DOUBLES + TAB_L_DOUBLES;   // 2925
+// behind them in the same device buffer (global memory only, never staged in LDS): per cost case the upper-triangular inverse Cholesky
+// factor Tp of H1^-1 (H1^-1 = C C', Tp = C^-T; its upper triangle packed row by row: entry (i, j >= i) at i (31 - i) / 2 + j - i) -- the
+// factor columns of a working set of acceleration bounds that is a prefix of the horizon (crash start of the slack variants, dmpc_solve.hip)
+constexpr int TAB_TP_CASE = 120;
+constexpr int TAB_TP_DOUBLES = 3 * TAB_TP_CASE;
+constexpr int TAB_ALL_DOUBLES = TAB_DOUBLES + TAB_TP_DOUBLES;
 
 // bytes of dynamic LDS of one scan wave: own prediction, unconstrained minimiser + candidate list of the all-k (hard) scan +
 // neighbour list

@@ -265,6 +265,163 @@ __device__ __forceinline__ void remove_slot2(double *B, int lane, int &q, int l,
     LSYNC();
 }
 
+// Crash start of the slack variants: append violated acceleration bounds |a| <= alim to the working set WITHOUT a step (lambda = 0; the
+// multipliers of the batch are solved afterwards by the refinement pass of the solver).  Two ways, one per call:
+//  * from the table.  While the working set holds nothing but bounds appended here and those of an axis are the steps 0 .. m-1 (far
+//    from its goal an agent saturates a prefix of the horizon: |a_unc(k)| falls with k), the inverse factor of S = N'H^-1 N is KNOWN:
+//    per axis the leading block of Tp = C^-T (H1^-1 = C C', one packed table per cost case, built on the host), signs sigma_i sigma_j
+//    on top, exact zeros between the axes -- H, and with it H^-1, is block diagonal in the three axes (every model matrix is
+//    kron(., I3)).  Every violated bound that extends its axis' prefix is appended in ONE pass, its column copied from the table.
+//  * by products, one bound PER AXIS and call: the axes are exactly orthogonal in the H^-1 metric, so one pair of triangular products
+//    serves three pivots at once (s stacked by the slots' axes; (T's)_j and (T T's)_i only see their own axis) and the factor is bit
+//    for bit the one of appending the three one after the other.
+// (C4, 10^4 agents: 27 of an agent's 38 "iterations" are such appends -- 17 now come from the table, 10 by products; one bound per
+// round they were the largest single piece of the solve launch.)
+// Returns the new slot count, the calling lane's updated slot record and flags: bit 0 the factor is still the table's, bit 1 stop the
+// crash (dependent pivot: guard only), bit 2 this call used the table, bits 8.. bounds appended (0: nothing was violated).
+typedef __attribute__((address_space(3))) double LdsD;
+struct CrashRes { int q; unsigned cslot; int flags; };
+template <bool SOFT, int QCAP, bool PERSIST>
+__device__ __attribute__((noinline)) CrashRes crash_append(LdsD *Bl, const LdsD *Gl, const double *tpg, const int lane, const int q, unsigned cslot,
+                                                           const double a, const double alim, const double tol, const bool tbl_ok)
+{
+    using SL = SolveLds<SOFT, QCAP, PERSIST>;
+    double *B = (double *)Bl;
+    const double *G = (const double *)Gl;
+    int *s_meta = (int *)(B + SL::META);
+    const bool comp = lane < N3;
+    const int k_l = comp ? lane / 3 : 0, ax_l = comp ? lane - 3 * k_l : 0;
+    constexpr int CAP = QCAP - 4 < 44 ? QCAP - 4 : 44;
+    constexpr unsigned long long AX0 = 0x0000249249249249ull;   // lanes 0, 3, ..., 42: the components of axis 0
+    CrashRes res; res.q = q; res.cslot = cslot; res.flags = tbl_ok ? 1 : 0;
+    const unsigned long long vm = __ballot(comp && !(cslot & 0x30000u) && fabs(a) - alim > tol);
+    if (vm == 0ull) return res;
+    const unsigned long long hm = __ballot(a > 0.0);
+    if (tbl_ok) {
+        const unsigned long long mem = __ballot(comp && (cslot & 0x30000u) != 0u);
+        int m0[3], nn[3];
+        bool pre_ok = true;
+        int room = CAP - q;
+#pragma unroll
+        for (int x = 0; x < 3; ++x) {
+            const unsigned long long axm = AX0 << x, Mx = mem & axm, Vx = vm & axm;
+            const int m = __popcll(Mx);
+            if (Mx != (axm & ((1ull << (3 * m)) - 1ull))) pre_ok = false;
+            const unsigned long long nz = axm & ~(Mx | Vx);
+            const int e = nz ? ((__ffsll((long long)nz) - 1 - x) / 3) : K;
+            int n = e > m ? e - m : 0;
+            n = n < room ? n : room;
+            room -= n;
+            m0[x] = m; nn[x] = n;
+        }
+        const int nb = nn[0] + nn[1] + nn[2];
+        if (pre_ok && nb > 0) {
+            const int qn = q + nb;
+            // (axis, step, sign) of the slot in this lane: old slots from their record, new ones from the runs
+            int iax = 0, ik = 0; double isg = 0.0;
+            if (lane < q) {
+                const int mj = s_meta[lane], cj = mj >> 16;
+                ik = cj / 3; iax = cj - 3 * ik;
+                isg = (((mj >> 8) & 0xff) == TY_BOXHI) ? 1.0 : -1.0;
+            } else if (lane < qn) {
+                const int t = lane - q;
+                iax = t < nn[0] ? 0 : (t < nn[0] + nn[1] ? 1 : 2);
+                ik = (iax == 0 ? m0[0] + t : (iax == 1 ? m0[1] + t - nn[0] : m0[2] + t - nn[0] - nn[1]));
+                isg = ((hm >> (3 * ik + iax)) & 1ull) ? 1.0 : -1.0;
+            }
+            // the case's packed table through the two staging vectors (120 of their 128 doubles): two loads per lane, once
+            {
+                const double t0 = tpg[lane], t1 = tpg[lane + 64 < TAB_TP_CASE ? lane + 64 : 0];
+                B[SL::RR + lane] = t0;
+                if (lane + 64 < TAB_TP_CASE) B[SL::RR + 64 + lane] = t1;
+                LSYNC();
+            }
+            const double *tp = B + SL::RR + ik * (31 - ik) / 2 - ik;   // tp[kj] = Tp(ik, kj), kj >= ik
+            int j = q;
+#pragma unroll
+            for (int x = 0; x < 3; ++x) {
+                for (int u = 0; u < nn[x]; ++u, ++j) {
+                    const int kj = m0[x] + u;
+                    const double sgj = ((hm >> (3 * kj + x)) & 1ull) ? 1.0 : -1.0;
+                    if (lane < ((j + 8) & ~7)) {
+                        const bool nzr = lane <= j && lane < qn && iax == x;   // (rows of the axis: their steps are <= kj)
+                        B[SL::T + tcol(j) + lane] = nzr ? (isg * sgj) * tp[kj] : 0.0;
+                    }
+                }
+            }
+            if (lane >= q && lane < qn) {
+                B[SL::SVEC + 3 * lane] = iax == 0 ? isg : 0.0; B[SL::SVEC + 3 * lane + 1] = iax == 1 ? isg : 0.0; B[SL::SVEC + 3 * lane + 2] = iax == 2 ? isg : 0.0;
+                B[SL::SD + lane] = alim; B[SL::SLAM + lane] = 0.0; B[SL::SSS + lane] = 0.0;
+                s_meta[lane] = ik | ((isg > 0.0 ? TY_BOXHI : TY_BOXLO) << 8) | ((3 * ik + iax) << 16);
+            }
+            if (comp) {   // the component's own slot index
+                const int mx = ax_l == 0 ? m0[0] : (ax_l == 1 ? m0[1] : m0[2]), nx = ax_l == 0 ? nn[0] : (ax_l == 1 ? nn[1] : nn[2]);
+                const int off = ax_l == 0 ? 0 : (ax_l == 1 ? nn[0] : nn[0] + nn[1]);
+                if (k_l >= mx && k_l < mx + nx)
+                    cslot = (cslot & ~0xffu) | (unsigned)(q + off + k_l - mx) | (a > 0.0 ? 0x10000u : 0x20000u);
+            }
+            LSYNC();
+            res.q = qn; res.cslot = cslot; res.flags = 1 | 4 | (nb << 8);
+            return res;
+        }
+    }
+    // by products: the lowest violated component of every axis
+    int pc[3], pk[3]; double psg[3], spa[3];
+#pragma unroll
+    for (int x = 0; x < 3; ++x) {
+        const unsigned long long mx = vm & (AX0 << x);
+        pc[x] = mx ? (__ffsll((long long)mx) - 1) : -1;
+        pk[x] = pc[x] >= 0 ? pc[x] / 3 : 0;
+        psg[x] = (pc[x] >= 0 && ((hm >> pc[x]) & 1ull)) ? 1.0 : -1.0;
+        spa[x] = G[pk[x] * 31];
+    }
+    // s = N_W' H^-1 [n_x n_y n_z] stacked: slot j takes the entry of its own axis' pivot
+    int jax = 0; double sv = 0.0;
+    if (lane < q) {
+        const int mj = s_meta[lane];
+        const int cj = mj >> 16, gj = mj & 0xff;
+        jax = cj - 3 * (cj / 3);
+        const double sgj = (((mj >> 8) & 0xff) == TY_BOXHI) ? 1.0 : -1.0;
+        const int pkj = jax == 0 ? pk[0] : (jax == 1 ? pk[1] : pk[2]);
+        const bool has = (jax == 0 ? pc[0] : (jax == 1 ? pc[1] : pc[2])) >= 0;
+        const double sgp = jax == 0 ? psg[0] : (jax == 1 ? psg[1] : psg[2]);
+        sv = has ? G[gj * 30 + pkj] * (sgj * sgp) : 0.0;
+    }
+    B[SL::XS + lane] = sv; LSYNC();
+    const double dvj = t_tmul2<QCAP, SL::T, SL::XS>(B, lane, q);
+    B[SL::RR + lane] = dvj; LSYNC();
+    const double ri = t_mul2<QCAP, SL::T, SL::RR>(B, lane, q);
+    LSYNC();
+    const double d2 = (lane < q) ? dvj * dvj : 0.0;
+    double irho[3]; bool okx[3];
+    bool stop = false;
+#pragma unroll
+    for (int x = 0; x < 3; ++x) {
+        const double dlt = spa[x] - wave_sum0(jax == x ? d2 : 0.0);
+        okx[x] = pc[x] >= 0 && dlt > 1e-9 * spa[x];        // (distinct bounds are independent; guard only)
+        if (pc[x] >= 0 && !okx[x]) stop = true;
+        irho[x] = okx[x] ? fast_rsq(dlt) : 0.0;
+    }
+    // the new columns [-r/rho ; 1/rho] (own axis; exact zeros elsewhere), slots, per-component slot index
+    int qn = q;
+#pragma unroll
+    for (int x = 0; x < 3; ++x) {
+        if (!okx[x]) continue;
+        if (lane < ((qn + 8) & ~7))
+            B[SL::T + tcol(qn) + lane] = (lane < q) ? ((jax == x) ? (-ri * irho[x]) : 0.0) : ((lane == qn) ? irho[x] : 0.0);
+        if (lane == 0) {
+            B[SL::SVEC + 3 * qn] = x == 0 ? psg[x] : 0.0; B[SL::SVEC + 3 * qn + 1] = x == 1 ? psg[x] : 0.0; B[SL::SVEC + 3 * qn + 2] = x == 2 ? psg[x] : 0.0;
+            B[SL::SD + qn] = alim; B[SL::SLAM + qn] = 0.0; B[SL::SSS + qn] = 0.0;
+            s_meta[qn] = pk[x] | ((psg[x] > 0.0 ? TY_BOXHI : TY_BOXLO) << 8) | (pc[x] << 16);
+        }
+        if (lane == pc[x]) cslot = (cslot & ~0xffu) | (unsigned)qn | (psg[x] > 0.0 ? 0x10000u : 0x20000u);
+        ++qn;
+    }
+    LSYNC();
+    res.q = qn; res.cslot = cslot; res.flags = (stop ? 2 : 0) | ((qn - q) << 8);   // (the slots of an axis are no prefix in step order any more)
+    return res;
+}
+
 // Closed loops, tiny launches: the work of post_step_kernel for one agent (dmpc_soft_bound.m:132-134, the history column,
 // ReachedGoal.m:3-11), done by the wave that produced the agent's step; p_out, v_out, a_out: lanes 0..2 hold the first horizon column.
 // The scene's maximum / OR / count are order-independent, so which wave finishes last changes nothing.
@@ -455,7 +612,10 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
 
     // ---------------------------------------------------------------- a7: dual active-set solve
     const bool ladder = soft && (var == VAR_BOUND || var == VAR_BOUND2 || var == VAR_ALL3 || cppv);
-    constexpr int LADDER_CERT_AFTER = 16;
+#ifndef DMPC_LADDER_CERT_AFTER
+#define DMPC_LADDER_CERT_AFTER 8    // (bound replay, 512 scenes: 16: 0.994 ms per step, 12: 0.980, 8: 0.965, 4: 0.959 -- the certificate runs for every agent that gets this far)
+#endif
+    constexpr int LADDER_CERT_AFTER = DMPC_LADDER_CERT_AFTER;
     constexpr int FARKAS_AFTER = 8;
     const int max_tries = P.max_tries > 0 ? P.max_tries : (cppv ? 21 : 30);
     // hdr[6] = retry-ladder levels the scan certified infeasible (the ladder starts behind them, the skipped tries counted).
@@ -465,7 +625,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
     int tries = h1.z, iters_total = 0, maxq = 0, q = 0;
     int scale_pow = 0;   // the rows' slack bound and penalty currently carry the factor 2^scale_pow
 #ifdef DMPC_DEV_TRACE
-    int dev_nfast = 0, dev_rounds = 0, dev_negdrops = 0;
+    int dev_nfast = 0, dev_rounds = 0, dev_negdrops = 0, dev_tbl = 0, dev_gen = 0;
     // development: cycles of the traced agent by phase (s_memtime): 0 pivot scan, 1 pivot descriptor + pin, 2 s / T's / T T's,
     // 3 residual + direction + delta, 4 ratio test + step + append, 5 drops, 6 verification / refinement, 7 ladder certificate +
     // ladder step, 8 set-up; counts: 10 verifications, 11 drops, 12 certificate calls
@@ -691,7 +851,30 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                 }
             };
 
-            bool fresh = !warm;             // primal == x(lambda) with refined lambda
+            // Crash start, first batch: every acceleration bound violated at the unconstrained minimiser is appended BEFORE the iteration
+            // starts (crash_append: from the table while the sets are prefixes of the horizon, else one bound per axis and call).  Out of
+            // line and outside the loop: inside it the call cost the iteration 3-4 % (registers live across the call site).  Bounds that
+            // only show after the multipliers of this batch are solved go through the one-at-a-time appends of the iteration.
+            if (SOFT && crash) {
+                bool tbl_ok = true;
+                while (q < (QCAP - 4 < 44 ? QCAP - 4 : 44)) {
+                    const CrashRes cr = crash_append<SOFT, QCAP, PERSIST>((LdsD *)B, (const LdsD *)G, P.tables + TAB_DOUBLES + (size_t)ccase * TAB_TP_CASE,
+                                                                          lane, q, cslot, a, P.alim, tol, tbl_ok);
+                    const int nb = cr.flags >> 8;
+                    if (cr.flags & 2) crash_stop = true;
+                    if (nb == 0) break;
+                    iters += nb; nfast += nb;
+#ifdef DMPC_DEV_TRACE
+                    if (cr.flags & 4) dev_tbl += nb; else dev_gen += nb;
+#endif
+                    q = cr.q; cslot = cr.cslot;
+                    tbl_ok = (cr.flags & 1) != 0;
+                    if (crash_stop) break;
+                }
+                if (q > maxq) maxq = q;
+                LSYNC();
+            }
+            bool fresh = !warm && nfast == 0;   // primal == x(lambda) with refined lambda
             int since_sync = 0;
             bool cert_done = false;
             for (;;) {
@@ -1127,7 +1310,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                 double *d = Qp->dbg + (size_t)(Qp->dbg_cap - 3) * 8;
                 for (int u = 0; u < 20; ++u) d[u] = (double)phv[u];
             }
-            if (Qp->dbg_agent == -4) { inf[0] = dev_nfast; inf[1] = dev_rounds; inf[3] = dev_negdrops; }   // development: crash statistics in place of the branch record
+            if (Qp->dbg_agent == -4) { inf[0] = dev_nfast; inf[1] = dev_rounds; inf[3] = dev_negdrops; inf[5] = dev_tbl; inf[6] = dev_gen; }   // development: crash statistics in place of the branch record
 #endif
         }
     }

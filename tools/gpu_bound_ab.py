@@ -1,0 +1,20 @@
+"""development: solve / scan kernel times of the bench's `solveSoftDMPCbound` replay launch (python tools/with_lib.py <lib> tools/gpu_bound_ab.py for another build)"""
+import sys, os
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import multiagent_planning_amd as mp
+from multiagent_planning_amd import workload as wl
+import bench
+variant = sys.argv[1] if len(sys.argv) > 1 else "bound"
+cfg, N, S = dict(wl.CONFIGS["C2"], variant=variant), 100, 512
+kw = wl.solver_kwargs(cfg, N)
+d = mp.Dmpc(variant, **kw)
+l, xp, xv, xa, pf, alive = bench.capture_state(d, cfg, S, N, 12, wl.SEED0 + 2)
+for rep in range(3):
+    for _ in range(3): out = d.step_batch(l, xp, xv, xa, pf)
+    d.profile(True)
+    for _ in range(10): out = d.step_batch(l, xp, xv, xa, pf)
+    sms, cms, _ = d.profile_read2()
+    d.profile(False)
+    inf = out["info"].reshape(-1, 8)
+    print(f"{variant}: solve {sms*1e3:7.1f} us  scan+order {cms*1e3:6.1f} us  | iterations mean {inf[:,4].mean():.2f} max {inf[:,4].max()}  tries max {inf[:,2].max()}")

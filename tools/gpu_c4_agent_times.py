@@ -36,4 +36,4 @@ for k in range(3):
 assert L.dmpc_debug_trace(d._ctx, -4, 8, None) == 0
 out = d.step_batch(l, xp, xv, xa, pf)
 inf = out["info"][0]
-print(f"crash: appended mean {inf[:,0].mean():.1f} of {inf[:,4].mean():.1f} iterations; rounds mean {inf[:,1].mean():.2f}; agents with a negative-multiplier drop {(inf[:,3]>0).mean():.3f}; final active {inf[:,6].mean():.1f}")
+print(f"crash: appended mean {inf[:,0].mean():.1f} of {inf[:,4].mean():.1f} iterations (from the table {inf[:,5].mean():.1f}, by products {inf[:,6].mean():.1f}); rounds mean {inf[:,1].mean():.2f}; agents with a negative-multiplier drop {(inf[:,3]>0).mean():.3f}")
