@@ -73,14 +73,17 @@ def test_crash_start_reaches_the_same_minimiser(variant, monkeypatch):
     po, _ = wl.make_scenes(cfg, S, N, wl.SEED0 + 41)
     pf = lo + rng.random((S, N, 3)) * (hi - lo)
     new = _steps(variant, kw, po, pf, 3)
-    old = _steps(variant, kw, po, pf, 1, crash_min=0)
-    a, b = new[0], old[0]
-    assert np.array_equal(a["status"], b["status"])
-    assert np.array_equal(a["info"][..., :4], b["info"][..., :4])            # violating step, rows, retry-ladder count, cost case
-    solved = (a["status"] & 1) == 1
-    assert solved.mean() > 0.5
-    for k in ("p", "v", "a"):
-        assert np.abs(a[k] - b[k])[solved].max() <= 1e-9, k
+    old = _steps(variant, kw, po, pf, 3, crash_min=0)
+    # step 1 starts at rest (the violated bounds are prefixes of the horizon: the factor comes from the table); steps 2-3 start with
+    # velocity and a previous acceleration (gaps, runs of the opposite sign at the end of the horizon: product rounds as well)
+    for st, (a, b) in enumerate(zip(new, old)):
+        assert np.array_equal(a["status"], b["status"]), st
+        assert np.array_equal(a["info"][..., :4], b["info"][..., :4]), st    # violating step, rows, retry-ladder count, cost case
+        solved = (a["status"] & 1) == 1
+        assert solved.mean() > 0.5
+        for k in ("p", "v", "a"):
+            assert np.abs(a[k] - b[k])[solved].max() <= (1e-9 if st == 0 else 1e-8), (st, k)   # (closed loop: step t starts from step t-1's output)
+    a = new[0]
     # the crash start did run: fewer full iterations are impossible to see from outside, but the working sets are large
     assert a["info"][..., 7].max() >= 20
     if variant != "repair":
