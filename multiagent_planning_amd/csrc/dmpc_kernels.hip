@@ -611,6 +611,7 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
             // rounding of a workspace-sized coordinate); the decision dist < rmin is made on the table itself, with the
             // arithmetic of the other walk, for the few (step, neighbour) pairs that pass.
             const float *rt = (const float *)P.lrow;
+            const float *rt1 = rt + (size_t)scene * C * 64;
             constexpr int TW = 8;
             const int k4 = lane >> 2, a4 = lane & 3;
             const bool act = a4 < 3 && k4 < K;
@@ -629,7 +630,10 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
                     for (int u = 0; u < TW; ++u) {
                         const int uu = (u0 + u < m) ? u0 + u : m - 1;   // (a repeated neighbour changes nothing: OR and min)
                         cu[u] = readlane_i(codes, uu);
-                        nv[u] = rt[((size_t)((cu[u] >> 20) * S + scene) * C + (cu[u] & 0xfffff)) * 64 + lane];
+                        // (one chunk -- a scene on one GPU: the code IS the column; the general form costs eight more scalar instructions per
+                        // listed neighbour, and the walk of the 100-700 neighbours of an agent of a 10^4-agent scene is scalar-bound)
+                        nv[u] = (G == 1) ? rt1[(size_t)(unsigned)cu[u] * 64 + lane]
+                                         : rt[((size_t)((cu[u] >> 20) * S + scene) * C + (cu[u] & 0xfffff)) * 64 + lane];
                     }
 #pragma unroll
                     for (int u = 0; u < TW; ++u) {
