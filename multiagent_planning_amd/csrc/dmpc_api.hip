@@ -325,15 +325,17 @@ static int upload_tables(dmpc_ctx *ctx)
             }
         // Tp = C^-T with H1^-1 = C C' (the ROUNDED table above: the numbers the solver's Schur complement is made of).  The leading
         // m x m block of Tp is the inverse factor of the leading block of H1^-1: S^-1 = Tp Tp' for the bounds of steps 0..m-1 of one axis.
-        {
+        // Second table: the same for the steps in FALLING order (14, 13, ..): H1^-1 with rows and columns reversed.
+        for (int rev = 0; rev < 2; ++rev) {
             long double C[K][K], Ci[K][K];
             memset(C, 0, sizeof(C)); memset(Ci, 0, sizeof(Ci));
+            auto hi = [&](int i, int j) -> long double { return rev ? hmp[(K - 1 - i) * K + (K - 1 - j)] : hmp[i * K + j]; };
             for (int j = 0; j < K; ++j) {
-                long double d = hmp[j * K + j];
+                long double d = hi(j, j);
                 for (int k = 0; k < j; ++k) d -= C[j][k] * C[j][k];
                 C[j][j] = sqrtl(d);
                 for (int i = j + 1; i < K; ++i) {
-                    long double v = hmp[i * K + j];
+                    long double v = hi(i, j);
                     for (int k = 0; k < j; ++k) v -= C[i][k] * C[j][k];
                     C[i][j] = v / C[j][j];
                 }
@@ -344,7 +346,7 @@ static int upload_tables(dmpc_ctx *ctx)
                     for (int k = c2; k < i; ++k) v -= C[i][k] * Ci[k][c2];
                     Ci[i][c2] = v / C[i][i];
                 }
-            double *Tp = &t[(size_t)TAB_DOUBLES + (size_t)c * TAB_TP_CASE];
+            double *Tp = &t[(size_t)TAB_DOUBLES + (size_t)(2 * c + rev) * TAB_TP_CASE];
             for (int i = 0; i < K; ++i)
                 for (int j = i; j < K; ++j) Tp[i * (31 - i) / 2 + j - i] = (double)Ci[j][i];
         }

@@ -82,8 +82,10 @@ constexpr int TAB_DOUBLES = 3 * TAB_CASE_DOUBLES + TAB_L_DOUBLES;   // 2925
 // behind them in the same device buffer (global memory only, never staged in LDS): per cost case the upper-triangular inverse Cholesky
 // factor Tp of H1^-1 (H1^-1 = C C', Tp = C^-T; its upper triangle packed row by row: entry (i, j >= i) at i (31 - i) / 2 + j - i) -- the
 // factor columns of a working set of acceleration bounds that is a prefix of the horizon (crash start of the slack variants, dmpc_solve.hip)
+// Two tables per case: for the steps in rising order (a prefix 0 .. m-1 of the horizon) and in falling order (the END of the horizon,
+// steps 14, 13, ..: the factor of J H1^-1 J, J the order-reversing permutation).
 constexpr int TAB_TP_CASE = 120;
-constexpr int TAB_TP_DOUBLES = 3 * TAB_TP_CASE;
+constexpr int TAB_TP_DOUBLES = 3 * 2 * TAB_TP_CASE;
 constexpr int TAB_ALL_DOUBLES = TAB_DOUBLES + TAB_TP_DOUBLES;
 
 // bytes of dynamic LDS of one scan wave: own prediction, unconstrained minimiser + candidate list of the all-k (hard) scan +

@@ -269,8 +269,8 @@ __device__ __forceinline__ void remove_slot2(double *B, int lane, int &q, int l,
 // multipliers of the batch are solved afterwards by the refinement pass of the solver).  Two ways, one per call:
 //  * from the table.  While the working set holds nothing but bounds appended here and those of an axis are the steps 0 .. m-1 (far
 //    from its goal an agent saturates a prefix of the horizon: |a_unc(k)| falls with k), the inverse factor of S = N'H^-1 N is KNOWN:
-//    per axis the leading block of Tp = C^-T (H1^-1 = C C', one packed table per cost case, built on the host), signs sigma_i sigma_j
-//    on top, exact zeros between the axes -- H, and with it H^-1, is block diagonal in the three axes (every model matrix is
+//    per axis the leading block of Tp = C^-T (H1^-1 = C C', one packed table per cost case, built on the host; a second one for the
+//    END of the horizon -- steps 14, 13, .. in falling order, the other common shape), signs sigma_i sigma_j on top, exact zeros between the axes -- H, and with it H^-1, is block diagonal in the three axes (every model matrix is
 //    kron(., I3)).  Every violated bound that extends its axis' prefix is appended in ONE pass, its column copied from the table.
 //  * by products, one bound PER AXIS and call: the axes are exactly orthogonal in the H^-1 metric, so one pair of triangular products
 //    serves three pivots at once (s stacked by the slots' axes; (T's)_j and (T T's)_i only see their own axis) and the factor is bit
@@ -292,32 +292,42 @@ __device__ __attribute__((noinline)) CrashRes crash_append(LdsD *Bl, const LdsD 
     const bool comp = lane < N3;
     const int k_l = comp ? lane / 3 : 0, ax_l = comp ? lane - 3 * k_l : 0;
     constexpr int CAP = QCAP - 4 < 44 ? QCAP - 4 : 44;
-    constexpr unsigned long long AX0 = 0x0000249249249249ull;   // lanes 0, 3, ..., 42: the components of axis 0
+    constexpr unsigned long long AX0 = 0x0000049249249249ull;   // lanes 0, 3, ..., 42: the 15 components of axis 0
     CrashRes res; res.q = q; res.cslot = cslot; res.flags = tbl_ok ? 1 : 0;
     const unsigned long long vm = __ballot(comp && !(cslot & 0x30000u) && fabs(a) - alim > tol);
     if (vm == 0ull) return res;
     const unsigned long long hm = __ballot(a > 0.0);
     if (tbl_ok) {
         const unsigned long long mem = __ballot(comp && (cslot & 0x30000u) != 0u);
-        int m0[3], nn[3];
+        // per axis: the members are the first m steps of the horizon (dir = 0: table of the rising order) or its LAST m steps (dir = 1:
+        // table of the falling order); the run of violated bounds that continues them
+        int m0[3], nn[3], dr[3];
         bool pre_ok = true;
         int room = CAP - q;
 #pragma unroll
         for (int x = 0; x < 3; ++x) {
             const unsigned long long axm = AX0 << x, Mx = mem & axm, Vx = vm & axm;
             const int m = __popcll(Mx);
-            if (Mx != (axm & ((1ull << (3 * m)) - 1ull))) pre_ok = false;
+            const bool is_pre = Mx == (axm & ((1ull << (3 * m)) - 1ull));
+            const bool is_suf = Mx == (axm & ~((1ull << (3 * (K - m))) - 1ull));
+            if (!is_pre && !is_suf) pre_ok = false;
+            // rising: first step not in (members | violated); falling: last such step
             const unsigned long long nz = axm & ~(Mx | Vx);
-            const int e = nz ? ((__ffsll((long long)nz) - 1 - x) / 3) : K;
-            int n = e > m ? e - m : 0;
+            const int e_up = nz ? ((__ffsll((long long)nz) - 1 - x) / 3) : K;                    // steps 0 .. e_up-1 are members or violated
+            const int e_dn = nz ? ((63 - __clzll((long long)nz) - x) / 3) : -1;                  // steps e_dn+1 .. K-1 are members or violated
+            const int n_up = is_pre && e_up > m ? e_up - m : 0;
+            const int n_dn = is_suf && (K - 1 - e_dn) > m ? (K - 1 - e_dn) - m : 0;
+            const int d = (m > 0) ? (is_pre ? 0 : 1) : (n_up > 0 ? 0 : 1);                       // (m == 0: whichever end is violated, the start first)
+            int n = d ? n_dn : n_up;
             n = n < room ? n : room;
             room -= n;
-            m0[x] = m; nn[x] = n;
+            m0[x] = m; nn[x] = n; dr[x] = d;
         }
         const int nb = nn[0] + nn[1] + nn[2];
         if (pre_ok && nb > 0) {
             const int qn = q + nb;
-            // (axis, step, sign) of the slot in this lane: old slots from their record, new ones from the runs
+            // (axis, step, sign) of the slot in this lane: old slots from their record, new ones from the runs; ip = position of the
+            // step in its axis' order (k rising, K-1-k falling)
             int iax = 0, ik = 0; double isg = 0.0;
             if (lane < q) {
                 const int mj = s_meta[lane], cj = mj >> 16;
@@ -326,26 +336,38 @@ __device__ __attribute__((noinline)) CrashRes crash_append(LdsD *Bl, const LdsD 
             } else if (lane < qn) {
                 const int t = lane - q;
                 iax = t < nn[0] ? 0 : (t < nn[0] + nn[1] ? 1 : 2);
-                ik = (iax == 0 ? m0[0] + t : (iax == 1 ? m0[1] + t - nn[0] : m0[2] + t - nn[0] - nn[1]));
+                const int ta = iax == 0 ? t : (iax == 1 ? t - nn[0] : t - nn[0] - nn[1]);
+                const int ma = iax == 0 ? m0[0] : (iax == 1 ? m0[1] : m0[2]);
+                const int da = iax == 0 ? dr[0] : (iax == 1 ? dr[1] : dr[2]);
+                ik = da ? K - 1 - (ma + ta) : ma + ta;
                 isg = ((hm >> (3 * ik + iax)) & 1ull) ? 1.0 : -1.0;
             }
-            // the case's packed table through the two staging vectors (120 of their 128 doubles): two loads per lane, once
-            {
-                const double t0 = tpg[lane], t1 = tpg[lane + 64 < TAB_TP_CASE ? lane + 64 : 0];
-                B[SL::RR + lane] = t0;
-                if (lane + 64 < TAB_TP_CASE) B[SL::RR + 64 + lane] = t1;
-                LSYNC();
-            }
-            const double *tp = B + SL::RR + ik * (31 - ik) / 2 - ik;   // tp[kj] = Tp(ik, kj), kj >= ik
-            int j = q;
+            const int idr = iax == 0 ? dr[0] : (iax == 1 ? dr[1] : dr[2]);
+            const int ip = idr ? K - 1 - ik : ik;
+            const double *tp = B + SL::RR + ip * (31 - ip) / 2 - ip;   // tp[pj] = Tp(ip, pj), pj >= ip
+            // the case's packed tables through the two staging vectors (120 of their 128 doubles), one order at a time
+#pragma unroll 1
+            for (int pass = 0; pass < 2; ++pass) {
+                if (!((nn[0] && dr[0] == pass) || (nn[1] && dr[1] == pass) || (nn[2] && dr[2] == pass))) continue;
+                {
+                    const double *tg = tpg + pass * TAB_TP_CASE;
+                    const double t0 = tg[lane], t1 = tg[lane + 64 < TAB_TP_CASE ? lane + 64 : 0];
+                    LSYNC();
+                    B[SL::RR + lane] = t0;
+                    if (lane + 64 < TAB_TP_CASE) B[SL::RR + 64 + lane] = t1;
+                    LSYNC();
+                }
+                int j = q;
 #pragma unroll
-            for (int x = 0; x < 3; ++x) {
-                for (int u = 0; u < nn[x]; ++u, ++j) {
-                    const int kj = m0[x] + u;
-                    const double sgj = ((hm >> (3 * kj + x)) & 1ull) ? 1.0 : -1.0;
-                    if (lane < ((j + 8) & ~7)) {
-                        const bool nzr = lane <= j && lane < qn && iax == x;   // (rows of the axis: their steps are <= kj)
-                        B[SL::T + tcol(j) + lane] = nzr ? (isg * sgj) * tp[kj] : 0.0;
+                for (int x = 0; x < 3; ++x) {
+                    if (dr[x] != pass) { j += nn[x]; continue; }
+                    for (int u = 0; u < nn[x]; ++u, ++j) {
+                        const int pj = m0[x] + u, kj = dr[x] ? K - 1 - pj : pj;
+                        const double sgj = ((hm >> (3 * kj + x)) & 1ull) ? 1.0 : -1.0;
+                        if (lane < ((j + 8) & ~7)) {
+                            const bool nzr = lane <= j && lane < qn && iax == x;   // (rows of the axis: their positions are <= pj)
+                            B[SL::T + tcol(j) + lane] = nzr ? (isg * sgj) * tp[pj] : 0.0;
+                        }
                     }
                 }
             }
@@ -356,9 +378,11 @@ __device__ __attribute__((noinline)) CrashRes crash_append(LdsD *Bl, const LdsD 
             }
             if (comp) {   // the component's own slot index
                 const int mx = ax_l == 0 ? m0[0] : (ax_l == 1 ? m0[1] : m0[2]), nx = ax_l == 0 ? nn[0] : (ax_l == 1 ? nn[1] : nn[2]);
+                const int dx = ax_l == 0 ? dr[0] : (ax_l == 1 ? dr[1] : dr[2]);
                 const int off = ax_l == 0 ? 0 : (ax_l == 1 ? nn[0] : nn[0] + nn[1]);
-                if (k_l >= mx && k_l < mx + nx)
-                    cslot = (cslot & ~0xffu) | (unsigned)(q + off + k_l - mx) | (a > 0.0 ? 0x10000u : 0x20000u);
+                const int pl = dx ? K - 1 - k_l : k_l;
+                if (pl >= mx && pl < mx + nx)
+                    cslot = (cslot & ~0xffu) | (unsigned)(q + off + pl - mx) | (a > 0.0 ? 0x10000u : 0x20000u);
             }
             LSYNC();
             res.q = qn; res.cslot = cslot; res.flags = 1 | 4 | (nb << 8);
@@ -858,7 +882,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
             if (SOFT && crash) {
                 bool tbl_ok = true;
                 while (q < (QCAP - 4 < 44 ? QCAP - 4 : 44)) {
-                    const CrashRes cr = crash_append<SOFT, QCAP, PERSIST>((LdsD *)B, (const LdsD *)G, P.tables + TAB_DOUBLES + (size_t)ccase * TAB_TP_CASE,
+                    const CrashRes cr = crash_append<SOFT, QCAP, PERSIST>((LdsD *)B, (const LdsD *)G, P.tables + TAB_DOUBLES + (size_t)ccase * 2 * TAB_TP_CASE,
                                                                           lane, q, cslot, a, P.alim, tol, tbl_ok);
                     const int nb = cr.flags >> 8;
                     if (cr.flags & 2) crash_stop = true;
