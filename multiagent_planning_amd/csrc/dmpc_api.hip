@@ -855,6 +855,18 @@ extern "C" int dmpc_debug_trace(dmpc_ctx *ctx, int agent, int cap, double *host_
     return 0;
 }
 
+// development aid (not part of the public header): the scan's hand-off headers of the last step (8 ints per agent: rows, reference row count,
+// violating step, status, flags, rows exist, ladder start, launch-order key)
+extern "C" int dmpc_debug_read_hdr(dmpc_ctx *ctx, int *host_out, int n_agents)
+{
+    if (!ctx || !host_out) return -1;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if ((size_t)n_agents * 32 > ctx->hdr.cap) { ctx->err = "dmpc_debug_read_hdr: more agents than the last step had"; return -1; }
+    HIPCHK(ctx, hipMemcpy(host_out, ctx->hdr.p, (size_t)n_agents * 32, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 // development aid (not part of the public header): force the solve launch order (a permutation of the S*c_count agents
 // of the next launches; n = 0 returns to the built-in policy).  Used to measure what an ideal order would give.
 extern "C" int dmpc_debug_set_order(dmpc_ctx *ctx, const int *host_order, int n)
