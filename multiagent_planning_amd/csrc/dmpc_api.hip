@@ -95,6 +95,7 @@ struct dmpc_ctx {
     int no_persist = 0;      // development option no_persist: one-agent-per-workgroup solve launches
     int max_lds_persist = 0;
     int force_persist = 0;   // development option force_persist (tests): the persistent kernel on small launches
+    int cull_min = 256;      // development option cull_min: neighbour lists from this many agents per scene on
     int no_cull = 0;         // development option no_cull: no neighbour lists in the scan of large scenes (A/B runs, tests)
     int no_lpt = 0;          // development option no_lpt: no heaviest-first solve order
     int crash_min = CRASH_MIN_DEFAULT;   // see StepParams::crash_min (development option crash_min; crash_any: also for the slack-free variants)
@@ -381,7 +382,7 @@ extern "C" int dmpc_debug_option(dmpc_ctx *ctx, const char *name, int value)
 {
     if (!ctx || !name) return -1;
     struct { const char *n; int dmpc_ctx::*f; } tab[] = {
-        {"no_fuse", &dmpc_ctx::no_fuse}, {"no_persist", &dmpc_ctx::no_persist}, {"force_persist", &dmpc_ctx::force_persist}, {"no_cull", &dmpc_ctx::no_cull},
+        {"no_fuse", &dmpc_ctx::no_fuse}, {"no_persist", &dmpc_ctx::no_persist}, {"force_persist", &dmpc_ctx::force_persist}, {"no_cull", &dmpc_ctx::no_cull}, {"cull_min", &dmpc_ctx::cull_min},
         {"no_lpt", &dmpc_ctx::no_lpt}, {"crash_min", &dmpc_ctx::crash_min}, {"crash_any", &dmpc_ctx::crash_any}, {"no_fast_exit", &dmpc_ctx::no_fast_exit},
         {"iter_cap", &dmpc_ctx::iter_cap}, {"tier1_qcap", &dmpc_ctx::tier1_env}, {"split_parts", &dmpc_ctx::split_parts}, {"no_split", &dmpc_ctx::no_split},
         {"static_queue", &dmpc_ctx::static_queue}};
@@ -704,7 +705,7 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     const bool finite_radius = p.variant == DMPC_VAR_HARD || p.variant == DMPC_VAR_BOUND || p.variant == DMPC_VAR_BOUND2 ||
                                p.variant == DMPC_VAR_ALL3 || p.variant == DMPC_VAR_ONDEMAND || p.variant == DMPC_VAR_CPP ||
                                p.variant == DMPC_VAR_CPP2;
-    if (G * C >= 256 && !ctx->no_cull && finite_radius) {
+    if (G * C >= ctx->cull_min && !ctx->no_cull && finite_radius) {
         const int total = G * S * C;
         if (ctx->bbox.ensure((size_t)total * 6 * NSEG * 4) || ctx->bbox_nm.ensure((size_t)total * NBOX_NM * 4)) FAIL(ctx, "device allocation failed (bbox)");
         if (lTf) hipLaunchKernelGGL(bbox_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, C, lTf, ctx->bbox.as<float>(), ctx->bbox_nm.as<float>());
@@ -1313,7 +1314,7 @@ extern "C" int dmpc_transition(dmpc_ctx *ctx, int S, int N, const double *po, co
     while ((int)ctx->children.size() < parts - 1) {
         dmpc_ctx *ch = dmpc_create(&ctx->prm, ctx->device, ctx->precision);
         if (!ch) FAIL(ctx, "dmpc_transition: further context: " + g_err);
-        ch->no_fuse = ctx->no_fuse; ch->no_persist = ctx->no_persist; ch->force_persist = ctx->force_persist; ch->no_cull = ctx->no_cull;
+        ch->no_fuse = ctx->no_fuse; ch->no_persist = ctx->no_persist; ch->force_persist = ctx->force_persist; ch->no_cull = ctx->no_cull; ch->cull_min = ctx->cull_min;
         ch->no_lpt = ctx->no_lpt; ch->crash_min = ctx->crash_min; ch->crash_any = ctx->crash_any; ch->no_fast_exit = ctx->no_fast_exit;
         ch->iter_cap = ctx->iter_cap; ch->tier1_env = ctx->tier1_env; ch->static_queue = ctx->static_queue;
         ch->no_split = 1;

@@ -184,6 +184,19 @@ __device__ __forceinline__ double vel_out(const double *a_s, int k_l, int ax_l, 
     return fma(h, sv, vo);
 }
 
+// The kernel's StepParams argument as it lies in the kernel-argument segment (first and only argument of every solve kernel), through a
+// pointer in the CONSTANT address space: fields read through it are scalar loads (s_load, the scalar cache) issued where they are used.
+// The empty asm keeps the compiler from recognising the pointer and hoisting the loads -- values kept in SGPRs across the solver loop
+// were spilled to VGPR lanes.  (A generic pointer here made every field a flat VECTOR load with the pointer in VGPRs: two dependent
+// memory round trips per output array in the output stage of every agent.)
+typedef const StepParams __attribute__((address_space(4))) *KargPtr;
+__device__ __forceinline__ KargPtr kernarg_params()
+{
+    KargPtr p = (KargPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
 // Retry-ladder certificate (bounded-slack variants).  The rows of one horizon step k constrain only w_k = (Lambda a)_k,
 // and with |a| <= alim the reachable set of w_k is EXACTLY the box |w_k| <= alim ((k+1) h)^2 / 2 per axis (cut by the
 // workspace bounds of that step).  With every slack at its lower bound slb*f the rows are the half-spaces
@@ -683,6 +696,9 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
                         // wave can pass the distance test: d2 is first compared against a slightly inflated squared
                         // threshold (a superset), the exact `norm(...) < r` decision is then made on sqrt(d2) itself.
                         if (__any(valid && d2 < rmin2_hi)) {
+                            // (the empty asm keeps this a BRANCH: the compiler turned the wave-uniform test into selects and ran the 25
+                            // instructions of the IEEE root for every step of every neighbour -- 800 of the 3 000 instructions of an agent's scan)
+                            asm volatile("");
                             const real dist = sqrt(d2);
                             if (valid && dist < rmin) anyb |= (1u << k);       // CheckCollSoftDMPC.m:11
                         }
@@ -752,25 +768,37 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
         // bench.py, nearly all of them once the swarm has spread out.)
         if (FAST && status == 0 && !__any(cert_infeasible) && nr <= 128) {   // (FAST: a template parameter -- launches without the exit do not carry its registers)
             const int ls = (int)wave_max((double)ladder_start);
-            const int ccase = cost_case(var, A.po[0] - A.pf[0], A.po[1] - A.pf[1], A.po[2] - A.pf[2], rows_exist);
-            const double qw = ccase == 0 ? P.Qfar : (ccase == 1 ? P.Qnear : P.Q1);
-            const double sw = ccase == 2 ? ((var == VAR_ALL3) ? 10.0 : P.S1) : P.Sfree;
+            // The launch parameters and the agent's state are read AGAIN here -- scalar loads through constant-address-space pointers --
+            // instead of staying live in SGPRs across the neighbour walk and the row builder: the slack variants' scan spilled 190
+            // scalar registers to VGPR lanes (a fifth of its instructions were v_readlane / v_writelane and the s_nop around them).
+            const KargPtr Qp = kernarg_params();
+            typedef const double __attribute__((address_space(4))) *ConstD;
+            Agent B_;
+            {
+                const ConstD sp = (ConstD)(unsigned long long)(Qp->x_p + 3 * (size_t)gid), sv = (ConstD)(unsigned long long)(Qp->x_v + 3 * (size_t)gid);
+                const ConstD sa = (ConstD)(unsigned long long)(Qp->x_a + 3 * (size_t)gid), sf = (ConstD)(unsigned long long)(Qp->pf + 3 * (size_t)gid);
+#pragma unroll
+                for (int d = 0; d < 3; ++d) { B_.po[d] = sp[d]; B_.vo[d] = sv[d]; B_.ao[d] = sa[d]; B_.pf[d] = sf[d]; }
+            }
+            const int ccase = cost_case(var, B_.po[0] - B_.pf[0], B_.po[1] - B_.pf[1], B_.po[2] - B_.pf[2], rows_exist);
+            const double qw = ccase == 0 ? Qp->Qfar : (ccase == 1 ? Qp->Qnear : Qp->Q1);
+            const double sw = ccase == 2 ? ((var == VAR_ALL3) ? 10.0 : Qp->S1) : Qp->Sfree;
             const bool comp = lane < N3;
             const int k_l = comp ? lane / 3 : 0, ax_l = comp ? lane - 3 * k_l : 0;
-            const double *tb = P.tables + (size_t)ccase * TAB_CASE_DOUBLES;
+            const double *tb = Qp->tables + (size_t)ccase * TAB_CASE_DOUBLES;
             double a_unc = 0.0, w_unc = 0.0, p0_l = 0.0, vo_l = 0.0;
             bool viol = false;
             const double tol = 1e-10;
             if (comp) {
-                const double gax = goal_gap(sel3(A.pf, ax_l), sel3(A.po, ax_l), sel3(A.vo, ax_l), P.h);
-                const double ao_l = sel3(A.ao, ax_l);
+                const double gax = goal_gap(sel3(B_.pf, ax_l), sel3(B_.po, ax_l), sel3(B_.vo, ax_l), Qp->h);
+                const double ao_l = sel3(B_.ao, ax_l);
                 a_unc = unc_entry(qw, sw, gax, ao_l, tb[k_l * 30 + 15 + (K - 1)], tb[k_l * 30]);
                 w_unc = unc_entry(qw, sw, gax, ao_l, tb[(15 + k_l) * 30 + 15 + (K - 1)], tb[(15 + k_l) * 30]);
-                vo_l = sel3(A.vo, ax_l);
-                const double sh = (double)(k_l + 1) * P.h * vo_l;
-                const double whi = sel3(P.pmax, ax_l) - sel3(A.po, ax_l) - sh, wlo = sel3(P.pmin, ax_l) - sel3(A.po, ax_l) - sh;
-                p0_l = init_pos(k_l, P.h, vo_l, sel3(A.po, ax_l));
-                viol = (fabs(a_unc) - P.alim > tol) || (fmax(w_unc - whi, wlo - w_unc) > tol);
+                vo_l = sel3(B_.vo, ax_l);
+                const double sh = (double)(k_l + 1) * Qp->h * vo_l;
+                const double whi = (ax_l == 0 ? Qp->pmax[0] : (ax_l == 1 ? Qp->pmax[1] : Qp->pmax[2])) - sel3(B_.po, ax_l) - sh, wlo = (ax_l == 0 ? Qp->pmin[0] : (ax_l == 1 ? Qp->pmin[1] : Qp->pmin[2])) - sel3(B_.po, ax_l) - sh;
+                p0_l = init_pos(k_l, Qp->h, vo_l, sel3(B_.po, ax_l));
+                viol = (fabs(a_unc) - Qp->alim > tol) || (fmax(w_unc - whi, wlo - w_unc) > tol);
             }
             bool trivial = ls == 0 && !__any(viol);
             double *a_s = (double *)smem, *wu_s = a_s + 48;   // (own prediction and key vector are dead by now)
@@ -792,26 +820,26 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
                 int st = ST_SOLVED | (coll_flag ? ST_COLL : 0);
                 const double p_out = w_unc + p0_l;
                 double v_out = 0.0;
-                if (comp) v_out = vel_out(a_s, k_l, ax_l, P.h, vo_l);
+                if (comp) v_out = vel_out(a_s, k_l, ax_l, Qp->h, vo_l);
                 const bool ob_check = !(var == VAR_ELLIP || var == VAR_SOFTALL || cppv);   // (as the solver's output stage)
                 if (ob_check) {
                     const double tolb = 50e-3;
                     bool bad = false;
-                    if (lane < 3) bad = !(p_out < sel3(P.pmax, lane) + tolb) || !(p_out > sel3(P.pmin, lane) - tolb);
+                    if (lane < 3) bad = !(p_out < (lane == 0 ? Qp->pmax[0] : (lane == 1 ? Qp->pmax[1] : Qp->pmax[2])) + tolb) || !(p_out > (lane == 0 ? Qp->pmin[0] : (lane == 1 ? Qp->pmin[1] : Qp->pmin[2])) - tolb);
                     if (__any(bad)) st |= ST_OUTBOUND;
                 }
                 if (comp) {
-                    P.p_out[(size_t)gid * N3 + lane] = p_out;
-                    P.v_out[(size_t)gid * N3 + lane] = v_out;
-                    P.a_out[(size_t)gid * N3 + lane] = a_unc;
-                    if (P.lT_next) P.lT_next[(size_t)scene * N3 * C + cl + (size_t)(unsigned)(lane * C)] = p_out;
+                    Qp->p_out[(size_t)gid * N3 + lane] = p_out;
+                    Qp->v_out[(size_t)gid * N3 + lane] = v_out;
+                    Qp->a_out[(size_t)gid * N3 + lane] = a_unc;
+                    if (Qp->lT_next) Qp->lT_next[(size_t)scene * N3 * C + cl + (size_t)(unsigned)(lane * C)] = p_out;
                 }
                 if (lane == 0) {
-                    P.status[gid] = st;
+                    Qp->status[gid] = st;
                     hdr[4] = (violation ? 1 : 0) | (coll_flag ? 4 : 0) | 16;
                     hdr[7] = 256;   // (the order kernel reads this word only)
-                    if (P.info) {
-                        int *inf = P.info + (size_t)gid * 8;
+                    if (Qp->info) {
+                        int *inf = Qp->info + (size_t)gid * 8;
                         inf[0] = viol_k; inf[1] = nrows_ref; inf[2] = 1; inf[3] = ccase;
                         inf[4] = 0; inf[5] = 0; inf[6] = 0; inf[7] = 0;
                     }

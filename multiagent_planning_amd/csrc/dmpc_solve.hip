@@ -123,19 +123,6 @@ __device__ __forceinline__ double wave_max0(double v)   // v >= 0 on every lane
     return readlane_d(v, 63);
 }
 
-// The kernel's StepParams argument as it lies in the kernel-argument segment (first and only argument of every solve kernel), through a
-// pointer in the CONSTANT address space: fields read through it are scalar loads (s_load, the scalar cache) issued where they are used.
-// The empty asm keeps the compiler from recognising the pointer and hoisting the loads -- values kept in SGPRs across the solver loop
-// were spilled to VGPR lanes.  (A generic pointer here made every field a flat VECTOR load with the pointer in VGPRs: two dependent
-// memory round trips per output array in the output stage of every agent.)
-typedef const StepParams __attribute__((address_space(4))) *KargPtr;
-__device__ __forceinline__ KargPtr kernarg_params()
-{
-    KargPtr p = (KargPtr)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(p));
-    return p;
-}
-
 // uniform description of one constraint
 struct Cd {
     int ty, idx, gi, si;     // type, index (component or row), Gram index (space, step), slack row (-1: none)

@@ -6,10 +6,12 @@ import multiagent_planning_amd as mp
 from multiagent_planning_amd import workload as wl
 import bench
 variant = sys.argv[1] if len(sys.argv) > 1 else "bound"
+precision = sys.argv[2] if len(sys.argv) > 2 else "f64"
+k_cap = int(sys.argv[3]) if len(sys.argv) > 3 else 12
 cfg, N, S = dict(wl.CONFIGS["C2"], variant=variant), 100, 512
 kw = wl.solver_kwargs(cfg, N)
-d = mp.Dmpc(variant, **kw)
-l, xp, xv, xa, pf, alive = bench.capture_state(d, cfg, S, N, 12, wl.SEED0 + 2)
+d = mp.Dmpc(variant, precision=precision, **kw)
+l, xp, xv, xa, pf, alive = bench.capture_state(d, cfg, S, N, k_cap, wl.SEED0 + 2)
 for rep in range(3):
     for _ in range(3): out = d.step_batch(l, xp, xv, xa, pf)
     d.profile(True)
@@ -17,4 +19,4 @@ for rep in range(3):
     sms, cms, _ = d.profile_read2()
     d.profile(False)
     inf = out["info"].reshape(-1, 8)
-    print(f"{variant}: solve {sms*1e3:7.1f} us  scan+order {cms*1e3:6.1f} us  | iterations mean {inf[:,4].mean():.2f} max {inf[:,4].max()}  tries max {inf[:,2].max()}")
+    print(f"{variant} {precision} step {k_cap}: solve {sms*1e3:7.1f} us  scan+order {cms*1e3:6.1f} us  | iterations mean {inf[:,4].mean():.2f} max {inf[:,4].max()}  tries max {inf[:,2].max()}")
