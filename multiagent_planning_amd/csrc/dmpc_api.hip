@@ -96,6 +96,7 @@ struct dmpc_ctx {
     int max_lds_persist = 0;
     int force_persist = 0;   // development option force_persist (tests): the persistent kernel on small launches
     int cull_min = 256;      // development option cull_min: neighbour lists from this many agents per scene on
+    int order_slices = 0;    // development option order_slices: workgroups of the order kernel (0: by launch size)
     int no_cull = 0;         // development option no_cull: no neighbour lists in the scan of large scenes (A/B runs, tests)
     int no_lpt = 0;          // development option no_lpt: no heaviest-first solve order
     int crash_min = CRASH_MIN_DEFAULT;   // see StepParams::crash_min (development option crash_min; crash_any: also for the slack-free variants)
@@ -382,7 +383,7 @@ extern "C" int dmpc_debug_option(dmpc_ctx *ctx, const char *name, int value)
 {
     if (!ctx || !name) return -1;
     struct { const char *n; int dmpc_ctx::*f; } tab[] = {
-        {"no_fuse", &dmpc_ctx::no_fuse}, {"no_persist", &dmpc_ctx::no_persist}, {"force_persist", &dmpc_ctx::force_persist}, {"no_cull", &dmpc_ctx::no_cull}, {"cull_min", &dmpc_ctx::cull_min},
+        {"no_fuse", &dmpc_ctx::no_fuse}, {"no_persist", &dmpc_ctx::no_persist}, {"force_persist", &dmpc_ctx::force_persist}, {"no_cull", &dmpc_ctx::no_cull}, {"order_slices", &dmpc_ctx::order_slices}, {"cull_min", &dmpc_ctx::cull_min},
         {"no_lpt", &dmpc_ctx::no_lpt}, {"crash_min", &dmpc_ctx::crash_min}, {"crash_any", &dmpc_ctx::crash_any}, {"no_fast_exit", &dmpc_ctx::no_fast_exit},
         {"iter_cap", &dmpc_ctx::iter_cap}, {"tier1_qcap", &dmpc_ctx::tier1_env}, {"split_parts", &dmpc_ctx::split_parts}, {"no_split", &dmpc_ctx::no_split},
         {"static_queue", &dmpc_ctx::static_queue}};
@@ -755,7 +756,9 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     // heaviest-first launch order for the solve phase (key left by the scan in hdr[7]).  Tiny launches do not need it.
     if (ctx->forced_n == S * c_count) P.order = ctx->forced_order.as<int>();   // development aid: externally supplied launch order
     else if (run_order) {
-        const int total = S * c_count, nb = total >= 16384 ? 8 : 1;
+        // (slices: the kernel is a chain of dependent memory round trips per thread -- 8 workgroups of 1024 threads took 20 us for 51 200
+        // agents, six agents per thread one after the other; with one agent per thread 7 us: headline 52.3 -> 53.2 M solves/s)
+        const int total = S * c_count, nb = ctx->order_slices > 0 ? ctx->order_slices : (total >= 65536 ? 64 : (total >= 1024 ? total / 1024 : 1));
         hipLaunchKernelGGL(order_kernel, dim3((unsigned)nb), dim3(1024), 0, st, total, (const int *)P.hdr, ctx->order.as<int>(), ctx->counter.as<int>() + 3);
         P.order = ctx->order.as<int>();
         P.live_bound = ctx->counter.as<int>() + 3;
@@ -1314,7 +1317,7 @@ extern "C" int dmpc_transition(dmpc_ctx *ctx, int S, int N, const double *po, co
     while ((int)ctx->children.size() < parts - 1) {
         dmpc_ctx *ch = dmpc_create(&ctx->prm, ctx->device, ctx->precision);
         if (!ch) FAIL(ctx, "dmpc_transition: further context: " + g_err);
-        ch->no_fuse = ctx->no_fuse; ch->no_persist = ctx->no_persist; ch->force_persist = ctx->force_persist; ch->no_cull = ctx->no_cull; ch->cull_min = ctx->cull_min;
+        ch->no_fuse = ctx->no_fuse; ch->no_persist = ctx->no_persist; ch->force_persist = ctx->force_persist; ch->no_cull = ctx->no_cull; ch->order_slices = ctx->order_slices; ch->cull_min = ctx->cull_min;
         ch->no_lpt = ctx->no_lpt; ch->crash_min = ctx->crash_min; ch->crash_any = ctx->crash_any; ch->no_fast_exit = ctx->no_fast_exit;
         ch->iter_cap = ctx->iter_cap; ch->tier1_env = ctx->tier1_env; ch->static_queue = ctx->static_queue;
         ch->no_split = 1;
