@@ -59,6 +59,7 @@ struct StepParams {
     int *post_or, *post_cnt;        // [S] OR of the status words, number of agents accounted for
     const int *scene_done;  // [S] or null: scenes of a transition that already stopped (reached their goals / failed): skipped
     int *counter;           // persistent solve kernel: queue head (zeroed before the launch)
+    int *zero4;             // scan kernel: four ints its first workgroup sets to zero (the queue heads / tier-2 count / live bound of this step: no memset launch), or null
     int lds_per_wave;       // persistent solve kernel: bytes of LDS per wave (after the shared tables)
     int *flag_count, *flag_list;   // tier 1 -> tier 2: number / ids of the agents whose working set overflowed (or null)
     double *dbg;            // optional per-iteration trace of agent dbg_agent (development aid)

@@ -868,6 +868,7 @@ __global__ __launch_bounds__(64 * SCAN_WAVES_PER_WG, SCAN_WAVES_PER_SIMD) void d
     int off = 0;
     for (int xx = 0; xx < x; ++xx) off += (nb - xx + 7) >> 3;
     const int agent = (off + y) * W + wave, total = P.S * P.c_count;
+    if (P.zero4 && blockIdx.x == 0 && threadIdx.x < 4) P.zero4[threadIdx.x] = 0;   // (nothing reads them before the order / solve kernels of this step)
     if (agent >= total) return;
     scan_body<SOFT, TT, FAST>(P, lane, agent, dmpc_smem + (size_t)wave * P.lds_per_wave);
 }
