@@ -633,6 +633,11 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
             const float sc = act ? (a4 == 2 ? (float)e1z : 1.f) : 0.f;
             const float thr = (float)(rmin * rmin) * 1.001f;
             const int k3 = head ? 3 * k4 : 0;
+            // (two copies of the loop: one chunk -- a scene on one GPU, the code IS the column -- and the general form, which costs eight more
+            // scalar instructions per listed neighbour; a test per neighbour cost branches instead.  The walk of the 100-700 neighbours of an
+            // agent of a 10^4-agent scene is scalar-bound.)
+            auto walk = [&](auto one_tag) {
+            constexpr bool one = decltype(one_tag)::value;
             for (int e0 = 0; e0 < nnbr; e0 += 64) {
                 const int codes = (e0 + lane < nnbr) ? scan_nbr[e0 + lane] : 0;
                 const int m = (nnbr - e0) < 64 ? (nnbr - e0) : 64;
@@ -643,10 +648,8 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
                     for (int u = 0; u < TW; ++u) {
                         const int uu = (u0 + u < m) ? u0 + u : m - 1;   // (a repeated neighbour changes nothing: OR and min)
                         cu[u] = readlane_i(codes, uu);
-                        // (one chunk -- a scene on one GPU: the code IS the column; the general form costs eight more scalar instructions per
-                        // listed neighbour, and the walk of the 100-700 neighbours of an agent of a 10^4-agent scene is scalar-bound)
-                        nv[u] = (G == 1) ? rt1[(size_t)(unsigned)cu[u] * 64 + lane]
-                                         : rt[((size_t)((cu[u] >> 20) * S + scene) * C + (cu[u] & 0xfffff)) * 64 + lane];
+                        nv[u] = one ? rt1[(size_t)(unsigned)cu[u] * 64 + lane]
+                                    : rt[((size_t)((cu[u] >> 20) * S + scene) * C + (cu[u] & 0xfffff)) * 64 + lane];
                     }
 #pragma unroll
                     for (int u = 0; u < TW; ++u) {
@@ -668,6 +671,8 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
                     }
                 }
             }
+            };
+            if (G == 1) walk(std::true_type{}); else walk(std::false_type{});
         } else {
             for (int e0 = 0; e0 < n_entries; e0 += 64) {
                 int r, jc;
