@@ -611,12 +611,27 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
         const double sh = (double)(k_l + 1) * P.h * sel3(vo, ax_l);   // A_initp(k,:) [po;vo] - po
         whi_l = sel3(P.pmax, ax_l) - sel3(po, ax_l) - sh;        // pmax - A0 x0  (:72)
         wlo_l = sel3(P.pmin, ax_l) - sel3(po, ax_l) - sh;
-        // pivot weights: the entering constraint is the one farthest from feasibility in the metric of the problem,
-        // violation / |n|_{H^-1} (compared in fp32: the choice only orders the pivots)
-        wbox_f = __builtin_amdgcn_rsqf((float)G[k_l * 31]); wpos_f = __builtin_amdgcn_rsqf((float)G[(15 + k_l) * 31]);   // (pivot weights: fp32)
+        // Pivot weights (fp32: the choice only orders the pivots; the minimiser does not depend on it).  Slack-free variants: the entering
+        // constraint is the one farthest from feasibility in the metric of the problem, violation / |n|_{H^-1} -- with the collision rows
+        // of solveHardDMPC EIGHT times as heavy (below).  Slack variants: plain violation for the acceleration bounds and the workspace
+        // walls, 4 violation / |xi| for the collision rows.  Both say "rows first": a bound that is violated now is often not at the
+        // optimum once the rows have moved the iterate, and every such detour costs an append and a drop.  Measured in round 3 (the
+        // rule had been violation / |n|_{H^-1} for everything): solveSoftDMPCbound replay mean 1.10 -> 1.01 iterations, longest agent
+        // 115 -> 67, solve launch 0.76 -> 0.48 ms; the 10^4-agent scene 1.16 -> 0.95-1.0 ms; solveHardDMPC 7.01 -> 6.52 iterations.
+        // (A slack row brings its pin along -- two slots -- so "rows first" passes through larger working sets: where that runs out of the
+        // 64 slots of the last tier the level is solved again with the metric rule, `alt_rule`, which adds the rows as sparingly as the
+        // bounds: three agent-steps of solveSoftDMPCall in the recorded scenes of the randomized campaign.)
+        if (SOFT) { wbox_f = 1.f; wpos_f = 1.f; }
+        else { wbox_f = __builtin_amdgcn_rsqf((float)G[k_l * 31]); wpos_f = __builtin_amdgcn_rsqf((float)G[(15 + k_l) * 31]); }
     }
+    const float rowmul = (var == VAR_HARD) ? 8.f : 1.f;   // (solveHardDMPCOnDemand, solveEllipDMPC: measured neutral to slightly worse with heavier rows)
+    bool alt_rule = false;   // slack variants: the metric rule for everything (second attempt of a level that ran out of slots)
     auto row_weight = [&](double x0, double x1, double x2, int kc, double sd) -> float {
-        return __builtin_amdgcn_rsqf((float)(G[(15 + kc) * 31] * (x0 * x0 + x1 * x1 + x2 * x2) + (soft ? 0.5 * sd * sd : 0.0)));
+        if (SOFT) {
+            if (alt_rule) return __builtin_amdgcn_rsqf((float)(G[(15 + kc) * 31] * (x0 * x0 + x1 * x1 + x2 * x2) + 0.5 * sd * sd));
+            return 4.f * __builtin_amdgcn_rsqf((float)(x0 * x0 + x1 * x1 + x2 * x2));
+        }
+        return rowmul * __builtin_amdgcn_rsqf((float)(G[(15 + kc) * 31] * (x0 * x0 + x1 * x1 + x2 * x2)));
     };
 #pragma unroll
     for (int c = 0; c < RC; ++c) rcw[c] = row_weight(rcx0[c], rcx1[c], rcx2[c], rckc[c], rcsd[c]);
@@ -1225,6 +1240,14 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
             dev_nfast += nfast; dev_rounds += crash_rounds;
 #endif
             if (rc == 0) { solved = true; break; }
+            if (SOFT && rc == 2 && P.qover_bit == ST_CAPACITY && !alt_rule) {   // last tier out of slots: the level once more, rows as sparingly as bounds
+                alt_rule = true;
+                if (comp) { wbox_f = __builtin_amdgcn_rsqf((float)G[k_l * 31]); wpos_f = __builtin_amdgcn_rsqf((float)G[(15 + k_l) * 31]); }
+#pragma unroll
+                for (int c = 0; c < RC; ++c) rcw[c] = row_weight(rcx0[c], rcx1[c], rcx2[c], rckc[c], rcsd[c]);
+                tries--;
+                continue;
+            }
             if (rc == 2) {   // first tier: flag for the second-tier launch, rows back to what the scan wrote (exact: powers of two); last tier: capacity error
                 status |= P.qover_bit;
                 if (soft && scale_pow && P.qover_bit == ST_QOVER) {
