@@ -101,6 +101,7 @@ struct dmpc_ctx {
     int no_lpt = 0;          // development option no_lpt: no heaviest-first solve order
     int crash_min = CRASH_MIN_DEFAULT;   // see StepParams::crash_min (development option crash_min; crash_any: also for the slack-free variants)
     int crash_any = 0;
+    int pivot_explore = 0;   // development option pivot_explore (DMPC_PIVOT_EXPLORE builds)
     int no_fast_exit = 0;    // development option no_fast_exit (tests): every agent through the solve kernel (the unconstrained exit of the scan off)
     int iter_cap = ITER_CAP; // development option iter_cap: cap of the active-set iterations (agents beyond it end DMPC_ST_ITERCAP)
     int tier1_env = 0;       // development option tier1_qcap (tests): 32 = two tiers for the slack variants (any value: no shallow-launch shortcut)
@@ -384,7 +385,7 @@ extern "C" int dmpc_debug_option(dmpc_ctx *ctx, const char *name, int value)
     if (!ctx || !name) return -1;
     struct { const char *n; int dmpc_ctx::*f; } tab[] = {
         {"no_fuse", &dmpc_ctx::no_fuse}, {"no_persist", &dmpc_ctx::no_persist}, {"force_persist", &dmpc_ctx::force_persist}, {"no_cull", &dmpc_ctx::no_cull}, {"order_slices", &dmpc_ctx::order_slices}, {"cull_min", &dmpc_ctx::cull_min},
-        {"no_lpt", &dmpc_ctx::no_lpt}, {"crash_min", &dmpc_ctx::crash_min}, {"crash_any", &dmpc_ctx::crash_any}, {"no_fast_exit", &dmpc_ctx::no_fast_exit},
+        {"no_lpt", &dmpc_ctx::no_lpt}, {"crash_min", &dmpc_ctx::crash_min}, {"crash_any", &dmpc_ctx::crash_any}, {"no_fast_exit", &dmpc_ctx::no_fast_exit}, {"pivot_explore", &dmpc_ctx::pivot_explore},
         {"iter_cap", &dmpc_ctx::iter_cap}, {"tier1_qcap", &dmpc_ctx::tier1_env}, {"split_parts", &dmpc_ctx::split_parts}, {"no_split", &dmpc_ctx::no_split},
         {"static_queue", &dmpc_ctx::static_queue}};
     for (auto &t : tab)
@@ -653,6 +654,7 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     // measured: the crash start pays for the slack-carrying variants (C4, N = 10^4: solve launch -16 %) and costs on solveHardDMPC
     // (C2: -16 % throughput: with rows at every horizon step the bounds violated at the unconstrained minimiser are a poor guess)
     P.crash_min = (soft || ctx->crash_any) ? ctx->crash_min : 0;
+    P.pivot_explore = ctx->pivot_explore;
     // tiny launches (a scene or a few, every agent resident at once: bound by the latency of their slowest agent, LDS is no
     // constraint) solve with the full working-set capacity in one launch; larger ones use the first tier and re-solve the few
     // agents that outgrow it (the smaller footprint also puts 6 instead of 4 one-agent workgroups on a CU: 512 transitions
@@ -1318,7 +1320,7 @@ extern "C" int dmpc_transition(dmpc_ctx *ctx, int S, int N, const double *po, co
         dmpc_ctx *ch = dmpc_create(&ctx->prm, ctx->device, ctx->precision);
         if (!ch) FAIL(ctx, "dmpc_transition: further context: " + g_err);
         ch->no_fuse = ctx->no_fuse; ch->no_persist = ctx->no_persist; ch->force_persist = ctx->force_persist; ch->no_cull = ctx->no_cull; ch->order_slices = ctx->order_slices; ch->cull_min = ctx->cull_min;
-        ch->no_lpt = ctx->no_lpt; ch->crash_min = ctx->crash_min; ch->crash_any = ctx->crash_any; ch->no_fast_exit = ctx->no_fast_exit;
+        ch->no_lpt = ctx->no_lpt; ch->crash_min = ctx->crash_min; ch->crash_any = ctx->crash_any; ch->no_fast_exit = ctx->no_fast_exit; ch->pivot_explore = ctx->pivot_explore;
         ch->iter_cap = ctx->iter_cap; ch->tier1_env = ctx->tier1_env; ch->static_queue = ctx->static_queue;
         ch->no_split = 1;
         ctx->children.push_back(ch);

@@ -66,6 +66,7 @@ struct StepParams {
     int dbg_agent, dbg_cap;
     int short_from;         // unequal clusters: chunks r >= short_from hold C-1 agents (last column = padding); 0: all chunks hold C
     int crash_min;          // crash start of the acceleration bounds when at least this many are violated at the unconstrained minimiser (0: never)
+    int pivot_explore;      // development builds (DMPC_PIVOT_EXPLORE): extra pivot-weight multipliers, see dmpc_solve.hip
     int fast_exit;          // scan: finish the agents whose unconstrained minimiser is feasible (they never enter the solve queue)
     const int *live_bound;  // persistent solve kernel: queue positions from *live_bound on hold agents the scan finished (order_kernel), or null
     int iter_cap;           // active-set iteration cap per try (ITER_CAP; development runs lower it to measure the per-iteration cost)

@@ -626,15 +626,28 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
     }
     const float rowmul = (var == VAR_HARD) ? 8.f : 1.f;   // (solveHardDMPCOnDemand, solveEllipDMPC: measured neutral to slightly worse with heavier rows)
     bool alt_rule = false;   // slack variants: the metric rule for everything (second attempt of a level that ran out of slots)
+#ifdef DMPC_PIVOT_EXPLORE
+    const float explore_row = ((P.pivot_explore & 15) ? ldexpf(1.f, (P.pivot_explore & 15) - 8) : 1.f);
+#else
+    constexpr float explore_row = 1.f;
+#endif
     auto row_weight = [&](double x0, double x1, double x2, int kc, double sd) -> float {
         if (SOFT) {
             if (alt_rule) return __builtin_amdgcn_rsqf((float)(G[(15 + kc) * 31] * (x0 * x0 + x1 * x1 + x2 * x2) + 0.5 * sd * sd));
-            return 4.f * __builtin_amdgcn_rsqf((float)(x0 * x0 + x1 * x1 + x2 * x2));
+            return explore_row * 4.f * __builtin_amdgcn_rsqf((float)(x0 * x0 + x1 * x1 + x2 * x2));
         }
-        return rowmul * __builtin_amdgcn_rsqf((float)(G[(15 + kc) * 31] * (x0 * x0 + x1 * x1 + x2 * x2)));
+        return explore_row * rowmul * __builtin_amdgcn_rsqf((float)(G[(15 + kc) * 31] * (x0 * x0 + x1 * x1 + x2 * x2)));
     };
 #pragma unroll
     for (int c = 0; c < RC; ++c) rcw[c] = row_weight(rcx0[c], rcx1[c], rcx2[c], rckc[c], rcsd[c]);
+    float wslk_u = 1.4142135f, wslk_l = 1.4142135f;   // the slack bounds' weights (|n|^2 = 1/2)
+#ifdef DMPC_PIVOT_EXPLORE   // development build: extra multipliers 2^(field - 8) packed into P.pivot_explore (0 = 1): bits 0-3 rows, 4-7 eps <= 0, 8-11 eps >= slb, 12-15 walls, 16-19 bounds
+    {
+        const int pe = P.pivot_explore;
+        auto mul = [&](int sh) -> float { const int f = (pe >> sh) & 15; return f ? ldexpf(1.f, f - 8) : 1.f; };
+        wslk_u *= mul(4); wslk_l *= mul(8); wpos_f *= mul(12); wbox_f *= mul(16);
+    }
+#endif
 
     // ---------------------------------------------------------------- a7: dual active-set solve
     const bool ladder = soft && (var == VAR_BOUND || var == VAR_BOUND2 || var == VAR_ALL3 || cppv);
@@ -934,9 +947,9 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                         if (soft && (fl & RF_LIVE)) {
                             const double e = r_eps[i];
                             v += rcsd[c] * e;
-                            if (!(fl & RF_SLKU)) CAND(e, 1.4142135f, (TY_SLKU << 16) | i);   // |n|^2 = 1/2
+                            if (!(fl & RF_SLKU)) CAND(e, wslk_u, (TY_SLKU << 16) | i);
                             const double lo = rcslb[c] - e;   // -eps <= -slb
-                            if (!(fl & RF_SLKL)) CAND(lo, 1.4142135f, (TY_SLKL << 16) | i);
+                            if (!(fl & RF_SLKL)) CAND(lo, wslk_l, (TY_SLKL << 16) | i);
                         }
                         if (!(fl & RF_COLL)) CAND(v, rcw[c], (TY_COLL << 16) | i);
                     }
@@ -948,9 +961,9 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                     if (soft && (fl & RF_LIVE)) {
                         const double e = r_eps[i];
                         v += r_sd[i] * e;
-                        if (!(fl & RF_SLKU)) CAND(e, 1.4142135f, (TY_SLKU << 16) | i);
+                        if (!(fl & RF_SLKU)) CAND(e, wslk_u, (TY_SLKU << 16) | i);
                         const double lo = r_slb[i] - e;
-                        if (!(fl & RF_SLKL)) CAND(lo, 1.4142135f, (TY_SLKL << 16) | i);
+                        if (!(fl & RF_SLKL)) CAND(lo, wslk_l, (TY_SLKL << 16) | i);
                     }
                     if (!(fl & RF_COLL) && v > tol) CAND(v, row_weight(x0, x1, x2, kc, soft ? r_sd[i] : 0.0), (TY_COLL << 16) | i);
                 }
