@@ -655,7 +655,10 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
 #define DMPC_LADDER_CERT_AFTER 8    // (bound replay, 512 scenes: 16: 0.994 ms per step, 12: 0.980, 8: 0.965, 4: 0.959 -- the certificate runs for every agent that gets this far)
 #endif
     constexpr int LADDER_CERT_AFTER = DMPC_LADDER_CERT_AFTER;
-    constexpr int FARKAS_AFTER = 8;
+#ifndef DMPC_FARKAS_AFTER
+#define DMPC_FARKAS_AFTER 8
+#endif
+    constexpr int FARKAS_AFTER = DMPC_FARKAS_AFTER;
     const int max_tries = P.max_tries > 0 ? P.max_tries : (cppv ? 21 : 30);
     // hdr[6] = retry-ladder levels the scan certified infeasible (the ladder starts behind them, the skipped tries counted).
     // A first-tier launch that runs out of working-set slots hands the agent over UNTOUCHED (its row scalings undone, nothing
