@@ -710,6 +710,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
         // is gone: an infeasible try often ends in a nearly degenerate working set, and the randomized campaign found 6 of 470 550
         // agent-steps that ended infeasible or with a wrong retry count on the factor it leaves behind, even with a conditioning guard.)
         constexpr bool warm = false;
+        bool cert_known = false;   // the level about to start has passed the ladder certificate (it is not certainly infeasible)
         PH(8);
         while (tries < max_tries) {
             tries++;
@@ -918,7 +919,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
             }
             bool fresh = !warm && nfast == 0;   // primal == x(lambda) with refined lambda
             int since_sync = 0;
-            bool cert_done = false;
+            bool cert_done = cert_known;   // (a level the ladder step below already put through the certificate is not tested again: 44 us a call for 26 rows)
             for (;;) {
                 if (soft && ladder && violation && !cert_done && iters - nfast >= LADDER_CERT_AFTER) {
                     cert_done = true;
@@ -1280,8 +1281,11 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
             if (soft && ladder && violation) {
                 PH(4);
                 double f = 2.0;
-                while (tries < max_tries - 1 &&
-                       ladder_level_infeasible(r_xi, r_b, r_sd, r_slb, r_kc, nr, B + SL::RR, P.h, P.alim, f, whi_l, wlo_l, lane)) { f *= 2.0; ++tries; }
+                cert_known = false;
+                while (tries < max_tries - 1) {
+                    if (!ladder_level_infeasible(r_xi, r_b, r_sd, r_slb, r_kc, nr, B + SL::RR, P.h, P.alim, f, whi_l, wlo_l, lane)) { cert_known = true; break; }
+                    f *= 2.0; ++tries;
+                }
                 for (int i = lane; i < nr; i += 64) { r_slb[i] *= f; r_st[i] *= f; }
                 rcslb[0] *= f; rcslb[1] *= f;
                 scale_pow += ilogb(f);
