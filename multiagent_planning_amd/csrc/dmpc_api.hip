@@ -116,6 +116,8 @@ struct dmpc_ctx {
     std::vector<int> split_at;          // non-empty: the last dmpc_transition left scenes [split_at[i], split_at[i+1]) in part i (0: here, i > 0: children[i-1])
     int split_parts = 0;     // development option split_parts: number of parts (0: the built-in rule)
     int no_split = 0;        // development option no_split
+    int no_split_t = 0;      // development option no_split_t: slack-free persistent solve with the whole inverse factor in every wave's block (nine waves per CU; A/B runs, tests)
+    int ext_cap = 0;         // development option ext_cap (tests): at most this many T extensions per workgroup (1: every agent that needs one waits for the same slot)
     int static_queue = 0;    // development option static_queue: persistent waves take queue positions round-robin instead of by ticket
     DevBuf pc_p, pc_v, pc_a, pc_M, pc_w, pc_scene, pc_agent, pc_interp;   // post-check work buffers
     DevBuf pc_pts, pc_cell, pc_fill, pc_start, pc_sorted, pc_on;           // post-check, large scenes: cell grid of a batch of samples
@@ -387,7 +389,7 @@ extern "C" int dmpc_debug_option(dmpc_ctx *ctx, const char *name, int value)
         {"no_fuse", &dmpc_ctx::no_fuse}, {"no_persist", &dmpc_ctx::no_persist}, {"force_persist", &dmpc_ctx::force_persist}, {"no_cull", &dmpc_ctx::no_cull}, {"order_slices", &dmpc_ctx::order_slices}, {"cull_min", &dmpc_ctx::cull_min},
         {"no_lpt", &dmpc_ctx::no_lpt}, {"crash_min", &dmpc_ctx::crash_min}, {"crash_any", &dmpc_ctx::crash_any}, {"no_fast_exit", &dmpc_ctx::no_fast_exit}, {"pivot_explore", &dmpc_ctx::pivot_explore},
         {"iter_cap", &dmpc_ctx::iter_cap}, {"tier1_qcap", &dmpc_ctx::tier1_env}, {"split_parts", &dmpc_ctx::split_parts}, {"no_split", &dmpc_ctx::no_split},
-        {"static_queue", &dmpc_ctx::static_queue}};
+        {"static_queue", &dmpc_ctx::static_queue}, {"no_split_t", &dmpc_ctx::no_split_t}, {"ext_cap", &dmpc_ctx::ext_cap}};
     for (auto &t : tab)
         if (!std::strcmp(t.n, name)) {
             ctx->*(t.f) = value;
@@ -769,14 +771,29 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     // phase 1: persistent waves (one workgroup per CU, shared tables, agents claimed from a queue) when at least two
     // waves fit next to the shared tables; otherwise one agent per workgroup
     const size_t LDS_CU = 160 * 1024;
+    // Slack-free variants (round 4): split T -- HARD_TS columns of the inverse factor in every wave's block, the rest of the 48 in
+    // extensions that the waves of a workgroup take from a pool when an agent's working set outgrows them (dmpc_solve.hip) -- so that
+    // twelve waves (three per SIMD: what 168 registers per lane allow) share a CU's LDS instead of nine.
+    const int tsplit = (!soft && !ctx->no_split_t) ? HARD_TS : 0;
+    int n_ext = 0;
     auto persist_waves = [&](int qcap, size_t &per) -> int {
-        per = solve_lds_bytes(P.nrmax, soft, qcap, true);
+        per = solve_lds_bytes(P.nrmax, soft, qcap, true, tsplit);
         int pw = (int)((LDS_CU - PERSIST_TABLE_BYTES) / per);
 #ifdef DMPC_DEV_PW   // development builds: fewer persistent waves per CU (how much does a long agent lose to the wave it shares a SIMD with?)
         if (pw > DMPC_DEV_PW) pw = DMPC_DEV_PW;
 #endif
-        const int cap = soft ? 8 : 9;   // waves per workgroup the kernels are compiled for (launch bounds)
-        return pw > cap ? cap : pw;
+        const int cap = soft ? 8 : (tsplit ? 12 : 9);   // waves per workgroup the kernels are compiled for (launch bounds)
+        pw = pw > cap ? cap : pw;
+        if (tsplit) {   // the extensions need room too: at least a third as many as waves (3 % of the headline launch's agents need one, for 15 % of its iterations)
+            const size_t eb = (size_t)ext_doubles(qcap, tsplit) * 8;
+            for (;; --pw) {
+                n_ext = (int)((LDS_CU - PERSIST_TABLE_BYTES - EXT_PAD_BYTES - (size_t)pw * per) / eb);
+                if (n_ext > 31) n_ext = 31;
+                if (pw < 2 || 3 * n_ext >= pw) break;
+            }
+            if (ctx->ext_cap > 0 && n_ext > ctx->ext_cap) n_ext = ctx->ext_cap;
+        }
+        return pw;
     };
     // the working-set capacity is a template parameter of the solve kernels
     auto launch_plain = [&](int qcap, size_t lds) {
@@ -791,6 +808,7 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
         else if (soft && qcap == 48) hipLaunchKernelGGL((dmpc_solve_persist_kernel<true, 48>), g, b, lds, st, P);
         else if (soft && qcap == 56) hipLaunchKernelGGL((dmpc_solve_persist_kernel<true, 56>), g, b, lds, st, P);
         else if (soft) hipLaunchKernelGGL((dmpc_solve_persist_kernel<true, 64>), g, b, lds, st, P);
+        else if (tsplit) hipLaunchKernelGGL((dmpc_solve_persist_kernel<false, 48, HARD_TS>), g, b, lds, st, P);
         else hipLaunchKernelGGL((dmpc_solve_persist_kernel<false, 48>), g, b, lds, st, P);
     };
     auto solve_launch = [&](int qcap, size_t lds_plain, int tier, bool want_persist) -> int {
@@ -801,13 +819,15 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
             launch_plain(qcap, lds_plain);
             return 0;
         }
-        const size_t lds = PERSIST_TABLE_BYTES + (size_t)pw * per;
+        const size_t lds = PERSIST_TABLE_BYTES + (size_t)pw * per + (tsplit ? (size_t)n_ext * ext_doubles(qcap, tsplit) * 8 + EXT_PAD_BYTES : 0);
+        P.n_ext = tsplit ? n_ext : 0;
         if ((int)lds > ctx->max_lds_persist) {
             HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_persist_kernel<true, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_persist_kernel<true, 48>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_persist_kernel<true, 56>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_persist_kernel<true, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_persist_kernel<false, 48>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_persist_kernel<false, 48, HARD_TS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             ctx->max_lds_persist = (int)lds;
         }
         P.counter = ctx->static_queue ? nullptr : ctx->counter.as<int>() + tier;
@@ -1321,7 +1341,7 @@ extern "C" int dmpc_transition(dmpc_ctx *ctx, int S, int N, const double *po, co
         if (!ch) FAIL(ctx, "dmpc_transition: further context: " + g_err);
         ch->no_fuse = ctx->no_fuse; ch->no_persist = ctx->no_persist; ch->force_persist = ctx->force_persist; ch->no_cull = ctx->no_cull; ch->order_slices = ctx->order_slices; ch->cull_min = ctx->cull_min;
         ch->no_lpt = ctx->no_lpt; ch->crash_min = ctx->crash_min; ch->crash_any = ctx->crash_any; ch->no_fast_exit = ctx->no_fast_exit; ch->pivot_explore = ctx->pivot_explore;
-        ch->iter_cap = ctx->iter_cap; ch->tier1_env = ctx->tier1_env; ch->static_queue = ctx->static_queue;
+        ch->iter_cap = ctx->iter_cap; ch->tier1_env = ctx->tier1_env; ch->static_queue = ctx->static_queue; ch->no_split_t = ctx->no_split_t; ch->ext_cap = ctx->ext_cap;
         ch->no_split = 1;
         ctx->children.push_back(ch);
     }

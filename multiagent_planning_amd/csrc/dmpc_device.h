@@ -16,6 +16,10 @@ __host__ __device__ constexpr int tcol(int j) { return 8 * (j >> 3) * (4 * (j >>
 // past the last column by up to 63 doubles; their values are masked, and the vectors that follow T in the per-agent LDS
 // block (>= 4 x 48 doubles) are what they touch.
 __host__ __device__ constexpr int t_doubles(int qcap) { return tcol((qcap + 7) & ~7); }
+#ifndef DMPC_HARD_TS
+#define DMPC_HARD_TS 16
+#endif
+constexpr int HARD_TS = DMPC_HARD_TS;   // slack-free persistent solve: columns of T in a wave's own LDS block (split T, dmpc_solve.hip); the other 48 - HARD_TS come from the workgroup's pool
 constexpr int ITER_CAP = 4000;
 constexpr int CRASH_MIN_DEFAULT = 4;
 constexpr int NBR_PARTS = 16;   // nbr_kernel: the neighbours of a scene are split over this many waves per block of 64 agents (N / 64 waves alone do not fill the chip)
@@ -69,6 +73,7 @@ struct StepParams {
     int pivot_explore;      // development builds (DMPC_PIVOT_EXPLORE): extra pivot-weight multipliers, see dmpc_solve.hip
     int fast_exit;          // scan: finish the agents whose unconstrained minimiser is feasible (they never enter the solve queue)
     const int *live_bound;  // persistent solve kernel: queue positions from *live_bound on hold agents the scan finished (order_kernel), or null
+    int n_ext;              // persistent solve kernel with a split T: extensions in the workgroup's pool (behind the waves' blocks)
     int iter_cap;           // active-set iteration cap per try (ITER_CAP; development runs lower it to measure the per-iteration cost)
 };
 
@@ -94,15 +99,19 @@ constexpr int TAB_ALL_DOUBLES = TAB_DOUBLES + TAB_TP_DOUBLES;
 // neighbour list
 inline size_t scan_lds_bytes() { return (96 * 8 + (size_t)SCAN_CAND_CAP * 4 + 15) & ~(size_t)15; }
 // bytes of LDS of one solve wave (layout: SolveLds in dmpc_solve.hip; `persist`: the tables are shared by the workgroup)
-inline size_t solve_lds_bytes(int nrmax, bool soft, int qcap, bool persist)
+// `tsplit` (persistent slack-free kernels, round 4): the wave's own block holds the first tsplit columns of T only; an agent whose
+// working set outgrows them takes one of the workgroup's EXTENSIONS (columns tsplit .. qcap-1, ext_doubles) from a small pool
+inline size_t solve_lds_bytes(int nrmax, bool soft, int qcap, bool persist, int tsplit = 0)
 {
-    size_t dbl = (size_t)t_doubles(qcap) + 2 * 48 + 2 * 64 + (soft ? 2 * 48 : 48) + 5 * (size_t)qcap + (soft ? (size_t)qcap : 0) + (size_t)qcap / 2;
+    size_t dbl = (size_t)t_doubles(tsplit > 0 ? tsplit : qcap) + 2 * 48 + 2 * 64 + (soft ? 2 * 48 : 48) + 5 * (size_t)qcap + (soft ? (size_t)qcap : 0) + (size_t)qcap / 2;
     if (!persist) dbl += TAB_CASE_DOUBLES + TAB_L_DOUBLES + 1;
     if (soft) dbl += (size_t)nrmax;                 // r_eps
     const size_t bytes = dbl * 8 + (soft ? (size_t)nrmax : (((size_t)nrmax + 31) / 32) * 4);   // + row flags (soft: a byte per row; slack-free: a bit)
     return (bytes + 15) & ~(size_t)15;
 }
-// persistent solve kernel: the tables at the front of the workgroup's LDS
-constexpr size_t PERSIST_TABLE_BYTES = ((size_t)TAB_DOUBLES * 8 + 15) & ~(size_t)15;
+// persistent solve kernel: the tables at the front of the workgroup's LDS, then 16 bytes of pool header (bit mask of the free T extensions)
+constexpr size_t PERSIST_TABLE_BYTES = (((size_t)TAB_DOUBLES * 8 + 15) & ~(size_t)15) + 16;
+__host__ __device__ constexpr int ext_doubles(int qcap, int tsplit) { return t_doubles(qcap) - t_doubles(tsplit); }
+constexpr size_t EXT_PAD_BYTES = 512;   // behind the last extension: unconditional wave reads run past a column's end (values masked)
 
 }  // namespace dmpc

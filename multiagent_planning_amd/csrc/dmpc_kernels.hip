@@ -892,8 +892,10 @@ __global__ __launch_bounds__(64, SOLVE_WAVES_PER_SIMD) void dmpc_solve_kernel(St
 // workgroup slot drains.  No workgroup barrier after the table load: the waves never synchronise.
 // (slack-free variants: 9 waves per workgroup -- with the row flags as bits a ninth wave fits next to the tables in the CU's 160 KB,
 // and 168 registers per lane hold the kernel without spills; the slack variants need 17 KB of LDS and 230 registers per wave: 8)
-template <bool SOFT, int QCAP>
-__global__ __launch_bounds__(SOFT ? 512 : 576, 1) void dmpc_solve_persist_kernel(StepParams P)
+// (round 4, slack-free variants: TWELVE waves per workgroup -- three per SIMD, what 168 registers per lane allow -- with the split T of
+// dmpc_solve.hip: TS columns of the factor per wave and a pool of P.n_ext extensions behind the waves' blocks)
+template <bool SOFT, int QCAP, int TS = QCAP>
+__global__ __launch_bounds__(SOFT ? 512 : 768, 1) void dmpc_solve_persist_kernel(StepParams P)
 {
     // tier 2 works through the list of agents tier 1 flagged (P.order points at it); usually it is empty
     int total = P.only_flagged ? *P.flag_count : P.S * P.c_count;
@@ -901,6 +903,11 @@ __global__ __launch_bounds__(SOFT ? 512 : 576, 1) void dmpc_solve_persist_kernel
     if (total == 0) return;
     double *shtab = (double *)dmpc_smem;
     for (int i = threadIdx.x; i < TAB_DOUBLES; i += blockDim.x) shtab[i] = P.tables[i];
+    if (TS < QCAP) {   // the pool of T extensions: all free, all zero
+        double *ex = (double *)(dmpc_smem + PERSIST_TABLE_BYTES + (size_t)(blockDim.x >> 6) * P.lds_per_wave);
+        for (int i = threadIdx.x; i < P.n_ext * ext_doubles(QCAP, TS) + (int)(EXT_PAD_BYTES / 8); i += blockDim.x) ex[i] = 0.0;
+        if (threadIdx.x == 0) *(unsigned *)(dmpc_smem + PERSIST_TABLE_BYTES - 16) = (1u << P.n_ext) - 1u;
+    }
     __syncthreads();
     // readfirstlane: tells the compiler the wave index (and with it every LDS base address and every value read
     // through one) is wave-uniform -- otherwise the solver's uniform branches are compiled as divergent ones
@@ -957,7 +964,8 @@ __global__ __launch_bounds__(SOFT ? 512 : 576, 1) void dmpc_solve_persist_kernel
         int ln = lane;
         asm volatile("" : "+v"(ln));
         const int agent = resolve(pos);
-        solve_body<SOFT, QCAP, true>(P, ln, agent, total, mine, shtab, want, tkv, claimed);
+        solve_body<SOFT, QCAP, true, TS>(P, ln, agent, total, mine, shtab, want, tkv, claimed,
+                                         (int)(((blockDim.x >> 6) - wave) * (P.lds_per_wave >> 3)));
         if (want && !claimed && lane == 0) tkv = atomicAdd(P.counter, 1);   // (the quick ways out of the solver: stopped scene, agent finished by the scan)
         LSYNC();
 #ifdef DMPC_DEV_TRACE

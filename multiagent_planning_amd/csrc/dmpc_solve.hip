@@ -22,10 +22,15 @@
 //     violation, the step lengths and every quantity that reaches the result stay fp64.
 // All arithmetic that reaches an output is fp64; no atomics; fixed-order reductions => bit-reproducible.
 
-template <bool SOFT, int QCAP, bool PERSIST>
+// TS < QCAP ("split T", persistent slack-free kernels, round 4): the wave's block holds columns 0 .. TS-1 of T only.  The fp64 inverse
+// factor was 10.9 of the 15.1 KB of LDS per wave and capped the launch at nine waves per CU, while 97 % of the agents of the headline
+// launch never hold more than 16 constraints.  An agent that outgrows TS columns takes an EXTENSION (columns TS .. QCAP-1 in the same
+// padded layout) from a pool the workgroup shares, at the wave-uniform offset `xo` doubles from the wave's base (0: none held): the same
+// values at other addresses -- results are bit for bit those of the unsplit layout.
+template <bool SOFT, int QCAP, bool PERSIST, int TS = QCAP>
 struct SolveLds {   // offsets in doubles from the wave's LDS base
     static constexpr int T = 0;
-    static constexpr int A = t_doubles(QCAP);
+    static constexpr int A = t_doubles(TS);
     static constexpr int W = A + 48;
     static constexpr int RR = W + 48;
     static constexpr int XS = RR + 64;
@@ -131,11 +136,13 @@ struct Cd {
 
 // y = T' x  (lane j gets y_j; 0 for j >= q).  x is the LDS vector at offset XOFF (zero beyond q).  Groups of 8 with one
 // lane mask per group; two FMA chains per group (half the dependent latency).
-template <int QCAP, int TOFF, int XOFF>
-__device__ __forceinline__ double t_tmul2(const double *B, int lane, int q)
+template <int QCAP, int TOFF, int XOFF, int TS = QCAP>
+__device__ __forceinline__ double t_tmul2(const double *B, int lane, int q, const int xo = 0)
 {
     double acc = 0.0;
-    const double *col = B + TOFF + tcol(lane < QCAP ? lane : QCAP - 1);
+    const int qlim = (TS < QCAP && xo == 0) ? TS : QCAP;   // (no extension held: q <= TS, the lanes beyond read column TS-1, masked)
+    const int jc = lane < qlim ? lane : qlim - 1;
+    const double *col = B + TOFF + tcol(jc) + ((TS < QCAP && jc >= TS) ? xo : 0);
     const double *xs = B + XOFF;
     for (int i0 = 0; i0 < q; i0 += 8) {
         double t[8], x[8];
@@ -150,13 +157,14 @@ __device__ __forceinline__ double t_tmul2(const double *B, int lane, int q)
 }
 // y = T x  (lane i gets y_i; 0 for i >= q).  The 8 columns of group g hold rows 0 .. 8(g+1)-1 (zeros below the diagonal),
 // so a lane either owns the whole group or skips it; columns >= q only meet x_j = 0.
-template <int QCAP, int TOFF, int XOFF>
-__device__ __forceinline__ double t_mul2(const double *B, int lane, int q)
+template <int QCAP, int TOFF, int XOFF, int TS = QCAP>
+__device__ __forceinline__ double t_mul2(const double *B, int lane, int q, const int xo = 0)
 {
     double acc = 0.0;
     const double *row = B + TOFF + lane;
     const double *xs = B + XOFF;
-    for (int j0 = 0; j0 < q; j0 += 8) {
+    const int q0 = (TS < QCAP && q > TS) ? TS : q;
+    for (int j0 = 0; j0 < q0; j0 += 8) {
         double t[8], x[8];
         const int c0 = tcol(j0), len = j0 + 9;
 #pragma unroll
@@ -166,16 +174,30 @@ __device__ __forceinline__ double t_mul2(const double *B, int lane, int q)
         for (int u = 2; u < 8; u += 2) { s0 = fma(t[u], x[u], s0); s1 = fma(t[u + 1], x[u + 1], s1); }
         acc += (lane < j0 + 8) ? (s0 + s1) : 0.0;
     }
+    if (TS < QCAP) {   // the column groups of the extension (the same sums in the same order)
+        const double *rowx = row + xo;
+        for (int j0 = TS; j0 < q; j0 += 8) {
+            double t[8], x[8];
+            const int c0 = tcol(j0), len = j0 + 9;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { t[u] = rowx[c0 + u * len]; x[u] = xs[j0 + u]; }
+            double s0 = t[0] * x[0], s1 = t[1] * x[1];
+#pragma unroll
+            for (int u = 2; u < 8; u += 2) { s0 = fma(t[u], x[u], s0); s1 = fma(t[u + 1], x[u + 1], s1); }
+            acc += (lane < j0 + 8) ? (s0 + s1) : 0.0;
+        }
+    }
     return (lane < q) ? acc : 0.0;
 }
 
 // delete slot l: Givens rotations on adjacent columns zero row l of T left-to-right; row l and the last column drop out.
 // Fused with the row deletion (each lane carries its row of the "current right column" in a register).
-template <bool SOFT, int QCAP, bool PERSIST>
-__device__ __forceinline__ void remove_slot2(double *B, int lane, int &q, int l, unsigned &cslot, unsigned long long &cm)
+template <bool SOFT, int QCAP, bool PERSIST, int TS = QCAP>
+__device__ __forceinline__ void remove_slot2(double *B, int lane, int &q, int l, unsigned &cslot, unsigned long long &cm, const int xo = 0)
 {
-    using SL = SolveLds<SOFT, QCAP, PERSIST>;
+    using SL = SolveLds<SOFT, QCAP, PERSIST, TS>;
     double *T = B + SL::T;
+    auto tc = [&](int j) -> int { return tcol(j) + ((TS < QCAP && j >= TS) ? xo : 0); };   // start of column j (split T: the extension's columns at +xo)
     int *s_meta = (int *)(B + SL::META);
     // per-component slot indices (2 bytes: box slot, position slot; 0xff = none) and the per-step collision-slot mask:
     // the removed slot disappears, higher slots move down by one
@@ -197,8 +219,8 @@ __device__ __forceinline__ void remove_slot2(double *B, int lane, int &q, int l,
     // long solve).
     {
         const bool act = lane >= l && lane <= q - 2;
-        const double bj = act ? T[tcol(lane + 1) + l] : 0.0;
-        const double al = T[tcol(l) + l];
+        const double bj = act ? T[tc(lane + 1) + l] : 0.0;
+        const double al = T[tc(l) + l];
         double val = bj * bj;
         if (lane == l) val = fma(al, al, val);
         const double Sj = wave_scan_sum(val);   // lane j: a_l^2 + b_l^2 + ... + b_j^2
@@ -216,24 +238,24 @@ __device__ __forceinline__ void remove_slot2(double *B, int lane, int &q, int l,
     // the sweep, two columns per round (their LDS reads in flight together); the dependent path is two multiply-adds per column
     static_assert(SL::XS == SL::RR + 64, "rotation pairs span the two staging vectors");
     const double2 *rot = (const double2 *)__builtin_assume_aligned(B + SL::RR, 16);
-    double carry = (lane <= l) ? T[tcol(l) + lane] : 0.0;
+    double carry = (lane <= l) ? T[tc(l) + lane] : 0.0;
     const int row = lane < l ? lane : lane - 1;
     for (int j0 = l; j0 < q - 1; j0 += 2) {
         const int j1 = j0 + 1 < q - 1 ? j0 + 1 : j0;   // (an odd tail repeats its column: harmless reads, the second update masked)
-        const double r0 = (lane <= j0 + 1) ? T[tcol(j0 + 1) + lane] : 0.0;
-        const double r1 = (lane <= j1 + 1) ? T[tcol(j1 + 1) + lane] : 0.0;
+        const double r0 = (lane <= j0 + 1) ? T[tc(j0 + 1) + lane] : 0.0;
+        const double r1 = (lane <= j1 + 1) ? T[tc(j1 + 1) + lane] : 0.0;
         const double2 c0 = rot[j0], c1 = rot[j1];
         const double n0 = c0.x * carry - c0.y * r0;
         carry = c0.y * carry + c0.x * r0;
-        if (lane <= j0 + 1 && lane != l) T[tcol(j0) + row] = n0;
+        if (lane <= j0 + 1 && lane != l) T[tc(j0) + row] = n0;
         if (j0 + 1 < q - 1) {
             const double n1 = c1.x * carry - c1.y * r1;
             carry = c1.y * carry + c1.x * r1;
-            if (lane <= j1 + 1 && lane != l) T[tcol(j1) + row] = n1;
+            if (lane <= j1 + 1 && lane != l) T[tc(j1) + row] = n1;
         }
     }
     // the column that dropped out: back to zero up to the end of its group (keeps "zero below the diagonal" for the next append)
-    if (lane < ((q + 7) & ~7)) T[tcol(q - 1) + lane] = 0.0;
+    if (lane < ((q + 7) & ~7)) T[tc(q - 1) + lane] = 0.0;
     const bool mv = lane > l && lane < q;
     double v0 = 0, v1 = 0, v2 = 0, ss = 0, d = 0, lam = 0; int meta = 0;
     if (mv) {
@@ -472,9 +494,10 @@ __device__ __forceinline__ void post_step_part(const KargPtr Qp, const int lane,
 // here) or -- persistent form -- the AGENT the wave is about to solve (the queue position already resolved through the order
 // by the persistent loop); `smem`: this wave's LDS; `shtab`: the workgroup-shared tables (persistent
 // form).
-template <bool SOFT, int QCAP, bool PERSIST>
+template <bool SOFT, int QCAP, bool PERSIST, int TS = QCAP>
 __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, const int bidx, const int nblocks,
-                                           unsigned char *smem, const double *shtab, const bool want_ticket, int &ticket, bool &claimed)
+                                           unsigned char *smem, const double *shtab, const bool want_ticket, int &ticket, bool &claimed,
+                                           const int ext0 = 0 /* split T: doubles from this wave's block to extension 0 of the workgroup's pool */)
 {
     // Persistent form: the wave's NEXT queue ticket is claimed (lane 0, result left in flight in `ticket`) when the agent is as good as done
     // -- the first violation scan that finds nothing, or the start of the output stage -- so that the atomic's latency hides behind the
@@ -482,9 +505,27 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
     // it, and such parked agents were the last to end the launch (round 3: the waves ended 779-878 us, busy fraction 0.90).
 #define CLAIM_NEXT() do { if (PERSIST && want_ticket && !claimed) { claimed = true; \
         if (lane == 0) ticket = atomicAdd(kernarg_params()->counter, 1); } } while (0)
-    using SL = SolveLds<SOFT, QCAP, PERSIST>;
+    using SL = SolveLds<SOFT, QCAP, PERSIST, TS>;
     constexpr bool soft = SOFT;
+    static_assert(TS == QCAP || (PERSIST && !SOFT && TS % 8 == 0 && TS < QCAP), "split T: persistent slack-free kernels");
     const int nrmax = P.nrmax, var = P.variant;
+    // split T: offset (doubles from the wave's base) that puts column j >= TS of the factor at tcol(j) + xo; 0: no extension held.
+    // The pool: a bit mask of the free extensions behind the workgroup's tables; lane 0 takes the lowest free one (LDS atomic), waits
+    // if there is none (the holders never wait for anything: they finish), and the agent gives it back -- zeroed -- when it is done.
+    int xo = 0;
+#define ENSURE_EXT(qn_) do { if (TS < QCAP && (qn_) >= TS && xo == 0) { \
+        unsigned *pool__ = (unsigned *)(shtab) + (PERSIST_TABLE_BYTES - 16) / 4; \
+        int sl__ = -1; \
+        if (lane == 0) { \
+            for (;;) { \
+                const unsigned m__ = __atomic_load_n(pool__, __ATOMIC_RELAXED); \
+                if (m__) { const int b__ = __ffs((int)m__) - 1; if ((atomicAnd(pool__, ~(1u << b__)) >> b__) & 1u) { sl__ = b__; break; } } \
+                else __builtin_amdgcn_s_sleep(16); \
+            } \
+        } \
+        sl__ = __builtin_amdgcn_readfirstlane(sl__); \
+        xo = ext0 + sl__ * ext_doubles(QCAP, TS) - tcol(TS); \
+    } } while (0)
     int vb = bidx;
     if (!PERSIST) {   // XCD-aware renumbering (see step_body)
         const int nb = nblocks, x = bidx & 7, y = bidx >> 3;
@@ -879,7 +920,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                         if (soft) r_fl[didx] &= ~bit; else r_bits[didx >> 5] &= ~(1u << (didx & 31));
                     }
                 }
-                remove_slot2<SOFT, QCAP, PERSIST>(B, lane, q, l, cslot, cm);
+                remove_slot2<SOFT, QCAP, PERSIST, TS>(B, lane, q, l, cslot, cm, xo);
                 if (soft && dty == TY_COLL && didx != keep_row) {
                     const int fl = r_fl[didx];
                     if ((fl & RF_LIVE) && (fl & RF_SLKU) && !(fl & RF_SLKL)) {
@@ -888,7 +929,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                         const int ul = __ffsll((long long)um) - 1;
                         LSYNC();
                         if (lane == 0) { r_fl[didx] = 0; r_eps[didx] = 0.0; }
-                        remove_slot2<SOFT, QCAP, PERSIST>(B, lane, q, ul, cslot, cm);
+                        remove_slot2<SOFT, QCAP, PERSIST, TS>(B, lane, q, ul, cslot, cm, xo);
                         nlive--;
                     }
                 }
@@ -1000,9 +1041,9 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                         const double mx = wave_max0(fabs(rho));
                         if (!(mx > 1e-13)) break;
                         B[SL::XS + lane] = rho; LSYNC();
-                        const double dvj = t_tmul2<QCAP, SL::T, SL::XS>(B, lane, q);
+                        const double dvj = t_tmul2<QCAP, SL::T, SL::XS, TS>(B, lane, q, xo);
                         B[SL::RR + lane] = dvj; LSYNC();
-                        const double ri = t_mul2<QCAP, SL::T, SL::RR>(B, lane, q);
+                        const double ri = t_mul2<QCAP, SL::T, SL::RR, TS>(B, lane, q, xo);
                         if (lane < q) B[SL::SLAM + lane] += ri;
                         LSYNC();
                         primal_fast();
@@ -1025,7 +1066,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                                 while (neg != 0ull) {
                                     const int l = 63 - __clzll((long long)neg);
                                     neg &= ~(1ull << l);
-                                    remove_slot2<SOFT, QCAP, PERSIST>(B, lane, q, l, cslot, cm);
+                                    remove_slot2<SOFT, QCAP, PERSIST, TS>(B, lane, q, l, cslot, cm, xo);
                                 }
                             } else drop_slot(63 - __clzll((long long)neg), -1);   // any kind of slot (and maybe its pin): one per pass
 #ifdef DMPC_DEV_TRACE
@@ -1109,10 +1150,10 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                     }
                     B[SL::XS + lane] = sv; LSYNC();
                     PH(13);
-                    const double dvj = t_tmul2<QCAP, SL::T, SL::XS>(B, lane, q);
+                    const double dvj = t_tmul2<QCAP, SL::T, SL::XS, TS>(B, lane, q, xo);
                     B[SL::RR + lane] = dvj; LSYNC();
                     PH(14);
-                    const double ri = t_mul2<QCAP, SL::T, SL::RR>(B, lane, q);
+                    const double ri = t_mul2<QCAP, SL::T, SL::RR, TS>(B, lane, q, xo);
                     LSYNC();
                     PH(2);
                     if (crash) {   // append without a step: column [-r/rho; 1/rho] with rho^2 = s_pp - |T's|^2, lambda_p = 0 until the batch is solved
@@ -1209,7 +1250,8 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                         // full step: append p (new column of T = [-r/rho ; 1/rho], zero below the diagonal)
                         if (q >= QCAP) { rc = 2; break; }
                         const double irho = fast_rsq(delta);
-                        if (lane < ((q + 8) & ~7)) B[SL::T + tcol(q) + lane] = (lane < q) ? (-ri * irho) : ((lane == q) ? irho : 0.0);
+                        ENSURE_EXT(q);
+                        if (lane < ((q + 8) & ~7)) B[SL::T + tcol(q) + ((TS < QCAP && q >= TS) ? xo : 0) + lane] = (lane < q) ? (-ri * irho) : ((lane == q) ? irho : 0.0);
                         write_slot(p, lam_p);
                         if (p.ty < TY_COLL) {
                             if (lane == p.idx) {
@@ -1246,7 +1288,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                     const int ul = __ffsll((long long)um) - 1;
                     LSYNC();
                     if (lane == 0) { r_fl[p.idx] = 0; r_eps[p.idx] = 0.0; }
-                    remove_slot2<SOFT, QCAP, PERSIST>(B, lane, q, ul, cslot, cm);
+                    remove_slot2<SOFT, QCAP, PERSIST, TS>(B, lane, q, ul, cslot, cm, xo);
                     nlive--;
                 }
                 if (((++since_sync) & 31) == 0) primal_fast();   // periodic re-sync with x(lambda)
@@ -1306,6 +1348,12 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
     // opaque pointer) instead of staying live in SGPRs across the solver loop, where they were spilled to VGPR lanes.
     const KargPtr Qp = kernarg_params();
     CLAIM_NEXT();
+    if (TS < QCAP && xo != 0) {   // the extension goes back to the pool, zeroed (every LDS value a wave can read stays finite)
+        double *ex = B + xo + tcol(TS);
+        for (int i = lane; i < ext_doubles(QCAP, TS); i += 64) ex[i] = 0.0;
+        LSYNC();
+        if (lane == 0) atomicOr((unsigned *)(shtab) + (PERSIST_TABLE_BYTES - 16) / 4, 1u << ((xo + tcol(TS) - ext0) / ext_doubles(QCAP, TS)));
+    }
     int nslack = 0;
     if (solved) {
         status |= ST_SOLVED;

@@ -118,3 +118,20 @@ def test_unconstrained_exit_in_whole_transitions():
         b = mp.Dmpc("bound", **kw).debug_option("no_fast_exit", 1).transition(po, pf, 120, cfg["error_tol"])
         for k in ("pk", "vk", "ak", "K_T_used", "scene_status"):
             assert np.array_equal(a[k], b[k]), (N, k)
+
+
+@pytest.mark.parametrize("variant,N,S,opts", [("hard", 100, 48, {}), ("ondemand", 100, 48, {}), ("ellip", 60, 64, {}), ("hard", 100, 48, {"ext_cap": 1})])
+def test_split_inverse_factor_does_not_change_a_bit(variant, N, S, opts):
+    """round 4, slack-free persistent solve: the first columns of the inverse factor in the wave's own LDS block, the rest in an extension
+    taken from the workgroup's pool when the working set outgrows them (twelve waves per CU instead of nine).  Same values at other
+    addresses: every output word equals the unsplit layout's (option no_split_t), including the agents that hold an extension -- also
+    with ONE extension per workgroup (option ext_cap), where the waves that want it at the same time wait for each other."""
+    cfg = wl.CONFIGS["C2"]
+    kw = wl.solver_kwargs(cfg, N)
+    po, pf = wl.make_scenes(cfg, S, N, wl.SEED0 + 61)
+    a = _steps(variant, kw, po, pf, 2, force_persist=1, **opts)
+    b = _steps(variant, kw, po, pf, 2, force_persist=1, no_split_t=1)
+    for x, y in zip(a, b):
+        for k in ("status", "info", "p", "v", "a"):
+            assert np.array_equal(x[k], y[k]), (variant, k)
+    assert max(int(x["info"][..., 7].max()) for x in a) > 16      # some agent did take an extension
