@@ -117,6 +117,8 @@ struct dmpc_ctx {
     int split_parts = 0;     // development option split_parts: number of parts (0: the built-in rule)
     int no_split = 0;        // development option no_split
     int no_split_t = 0;      // development option no_split_t: slack-free persistent solve with the whole inverse factor in every wave's block (nine waves per CU; A/B runs, tests)
+    int nbr_grid = 1;        // development option nbr_grid: 0 = neighbour lists of large scenes from the all-pairs box test of round 3 (nbr_kernel) instead of the cell grid + distance filter
+    DevBuf grid;             // cell grid of the neighbour lists (counts, starts, entries)
     int ext_cap = 0;         // development option ext_cap (tests): at most this many T extensions per workgroup (1: every agent that needs one waits for the same slot)
     int static_queue = 0;    // development option static_queue: persistent waves take queue positions round-robin instead of by ticket
     DevBuf pc_p, pc_v, pc_a, pc_M, pc_w, pc_scene, pc_agent, pc_interp;   // post-check work buffers
@@ -389,7 +391,7 @@ extern "C" int dmpc_debug_option(dmpc_ctx *ctx, const char *name, int value)
         {"no_fuse", &dmpc_ctx::no_fuse}, {"no_persist", &dmpc_ctx::no_persist}, {"force_persist", &dmpc_ctx::force_persist}, {"no_cull", &dmpc_ctx::no_cull}, {"order_slices", &dmpc_ctx::order_slices}, {"cull_min", &dmpc_ctx::cull_min},
         {"no_lpt", &dmpc_ctx::no_lpt}, {"crash_min", &dmpc_ctx::crash_min}, {"crash_any", &dmpc_ctx::crash_any}, {"no_fast_exit", &dmpc_ctx::no_fast_exit}, {"pivot_explore", &dmpc_ctx::pivot_explore},
         {"iter_cap", &dmpc_ctx::iter_cap}, {"tier1_qcap", &dmpc_ctx::tier1_env}, {"split_parts", &dmpc_ctx::split_parts}, {"no_split", &dmpc_ctx::no_split},
-        {"static_queue", &dmpc_ctx::static_queue}, {"no_split_t", &dmpc_ctx::no_split_t}, {"ext_cap", &dmpc_ctx::ext_cap}};
+        {"static_queue", &dmpc_ctx::static_queue}, {"no_split_t", &dmpc_ctx::no_split_t}, {"ext_cap", &dmpc_ctx::ext_cap}, {"nbr_grid", &dmpc_ctx::nbr_grid}};
     for (auto &t : tab)
         if (!std::strcmp(t.n, name)) {
             ctx->*(t.f) = value;
@@ -723,18 +725,53 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
         if (cap > 4096) cap = 4096;
         while (cap > 256 && agents * (size_t)cap * 4 > ((size_t)1 << 30)) cap >>= 1;
         if (ctx->nbr_list.ensure(agents * (size_t)cap * 4) || ctx->nbr_cnt.ensure(agents * 4 * NBR_PARTS)) FAIL(ctx, "device allocation failed (neighbour lists)");
-        const double R = ((p.variant == DMPC_VAR_HARD) ? 1.0 : 3.0 * p.rmin) * 1.0001 + 1e-4;   // a little more than the scan's radius: conservative in fp32 too
-        const int nblk = (c_count + 63) / 64;
-        hipLaunchKernelGGL(nbr_kernel, dim3((unsigned)(S * nblk * NBR_PARTS)), dim3(64), 0, st, S, G, C, g_local, c_first, c_count, short_from, (float)R, (float)(R * p.c),
-                           (const float *)ctx->bbox.as<float>(), (const float *)ctx->bbox_nm.as<float>(), (int)cap, ctx->nbr_list.as<int>(), ctx->nbr_cnt.as<int>());
-        P.nbr_cap = (int)cap; P.nbr_list = ctx->nbr_list.as<int>(); P.nbr_cnt = ctx->nbr_cnt.as<int>();
-        if (p.variant != DMPC_VAR_HARD) {   // the list walk of the per-step distance scan reads a neighbour-major copy of the table
+        const double Rsel = (p.variant == DMPC_VAR_HARD) ? 1.0 : 3.0 * p.rmin;
+        const double R = Rsel * 1.0001 + 1e-4;   // a little more than the scan's radius: conservative in fp32 too
+        // round 4: lists from a cell grid, filtered by the fp32 distance test (grid_query_kernel); the all-pairs box test of round 3 stays
+        // behind option nbr_grid = 0 (A/B runs, tests) and for scenes whose bitmap would not fit a wave's LDS
+        const size_t gq_lds = grid_query_lds_per_wave(G * C);
+        const bool use_grid = ctx->nbr_grid && gq_lds * GQ_WAVES <= 64 * 1024;
+        if (p.variant != DMPC_VAR_HARD || use_grid) {   // neighbour-major fp32 copy of the table: the list walk of the per-step distance scan, the distance test of the grid query
             const size_t tot = (size_t)total * 64;
             if (ctx->lrow.ensure(tot * 4)) FAIL(ctx, "device allocation failed (neighbour-major table)");
             if (lTf) hipLaunchKernelGGL(table_nbrmajor_kernel<float>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, tot, C, lTf, ctx->lrow.as<float>());
             else hipLaunchKernelGGL(table_nbrmajor_kernel<double>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, tot, C, lT, ctx->lrow.as<float>());
-            P.lrow = ctx->lrow.p;
+            if (p.variant != DMPC_VAR_HARD) P.lrow = ctx->lrow.p;
         }
+        if (use_grid) {
+            // cells: R along x (the cells of a run along x are contiguous in the entry array: their granularity is free), 1.5 R along y
+            // and 1.5 R c along z (the metric's z scale), at most 32 per axis
+            GridGeom gg;
+            const double cell[3] = {R, 1.5 * R, 1.5 * R * p.c};
+            int ncell = 1;
+            for (int a = 0; a < 3; ++a) {
+                const double span = p.pmax[a] - p.pmin[a];
+                int n = (int)(span / cell[a]);
+                n = n < 1 ? 1 : (n > 32 ? 32 : n);
+                gg.n[a] = n; gg.org[a] = (float)p.pmin[a]; gg.inv[a] = (float)(n / (span > 0 ? span : 1.0));
+                ncell *= n;
+            }
+            // one grid per third of the horizon (keyed by the centre of that segment's box: a third of the extent of the whole horizon's).  One
+            // buffer: [S][3][ncell] counts, [S][3][3] largest half extents (zeroed together), [S][3][ncell + 1] starts, [3][G S C] cells, [S][3][G C] entries
+            const size_t n_cnt = (size_t)S * NSEG * ncell, n_mh = (size_t)S * NSEG * 3, n_st = (size_t)S * NSEG * (ncell + 1);
+            const size_t n_hd = (n_cnt + n_mh + n_st + (size_t)NSEG * total + 7) & ~(size_t)7;   // (the entry records behind it are 32-byte aligned)
+            if (ctx->grid.ensure((n_hd + 8 * (size_t)NSEG * total) * 4)) FAIL(ctx, "device allocation failed (neighbour grid)");
+            int *g_cnt = ctx->grid.as<int>(), *g_mh = g_cnt + n_cnt, *g_st = g_mh + n_mh, *g_cell = g_st + n_st;
+            f4_t *g_ent = (f4_t *)(g_cnt + n_hd);
+            HIPCHK(ctx, hipMemsetAsync(g_cnt, 0, (n_cnt + n_mh) * 4, st));
+            hipLaunchKernelGGL(grid_bin_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, S, C, short_from, gg, (const float *)ctx->bbox_nm.as<float>(), g_cell, g_cnt, g_mh);
+            hipLaunchKernelGGL(grid_scan_kernel, dim3((unsigned)(S * NSEG)), dim3(256), 0, st, ncell, g_cnt, g_st);
+            hipLaunchKernelGGL(grid_fill_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, S, C, ncell, (const int *)g_cell, g_cnt, (const int *)g_st, (const float *)ctx->bbox_nm.as<float>(), g_ent);
+            const int nq = S * c_count;
+            hipLaunchKernelGGL(grid_query_kernel, dim3((unsigned)((nq + GQ_WAVES - 1) / GQ_WAVES)), dim3(64 * GQ_WAVES), gq_lds * GQ_WAVES, st, S, G, C, g_local, c_first, c_count, gg,
+                               (float)R, (float)(R * p.c), (float)(1.0 / p.c), (float)(Rsel * Rsel * 1.002), (const float *)ctx->bbox_nm.as<float>(), (const float *)ctx->lrow.as<float>(),
+                               (const int *)g_st, (const f4_t *)g_ent, (const int *)g_mh, (int)cap, (int)gq_lds, ctx->nbr_list.as<int>(), ctx->nbr_cnt.as<int>());
+        } else {
+            const int nblk = (c_count + 63) / 64;
+            hipLaunchKernelGGL(nbr_kernel, dim3((unsigned)(S * nblk * NBR_PARTS)), dim3(64), 0, st, S, G, C, g_local, c_first, c_count, short_from, (float)R, (float)(R * p.c),
+                               (const float *)ctx->bbox.as<float>(), (const float *)ctx->bbox_nm.as<float>(), (int)cap, ctx->nbr_list.as<int>(), ctx->nbr_cnt.as<int>());
+        }
+        P.nbr_cap = (int)cap; P.nbr_list = ctx->nbr_list.as<int>(); P.nbr_cnt = ctx->nbr_cnt.as<int>();
     }
     const bool run_order = ctx->forced_n != S * c_count && S * c_count >= 512 && !ctx->no_lpt;
     P.zero4 = (!tiny || run_order) ? ctx->counter.as<int>() : nullptr;   // queue heads of the persistent solve launches, tier-2 count, live bound: zeroed by the scan kernel (a memset is a launch of its own, 5 us)
@@ -782,7 +819,7 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
 #ifdef DMPC_DEV_PW   // development builds: fewer persistent waves per CU (how much does a long agent lose to the wave it shares a SIMD with?)
         if (pw > DMPC_DEV_PW) pw = DMPC_DEV_PW;
 #endif
-        const int cap = soft ? 8 : (tsplit ? 12 : 9);   // waves per workgroup the kernels are compiled for (launch bounds)
+        const int cap = soft ? 8 : (tsplit ? HARD_PW : 9);   // waves per workgroup the kernels are compiled for (launch bounds)
         pw = pw > cap ? cap : pw;
         if (tsplit) {   // the extensions need room too: at least a third as many as waves (3 % of the headline launch's agents need one, for 15 % of its iterations)
             const size_t eb = (size_t)ext_doubles(qcap, tsplit) * 8;
@@ -1341,7 +1378,7 @@ extern "C" int dmpc_transition(dmpc_ctx *ctx, int S, int N, const double *po, co
         if (!ch) FAIL(ctx, "dmpc_transition: further context: " + g_err);
         ch->no_fuse = ctx->no_fuse; ch->no_persist = ctx->no_persist; ch->force_persist = ctx->force_persist; ch->no_cull = ctx->no_cull; ch->order_slices = ctx->order_slices; ch->cull_min = ctx->cull_min;
         ch->no_lpt = ctx->no_lpt; ch->crash_min = ctx->crash_min; ch->crash_any = ctx->crash_any; ch->no_fast_exit = ctx->no_fast_exit; ch->pivot_explore = ctx->pivot_explore;
-        ch->iter_cap = ctx->iter_cap; ch->tier1_env = ctx->tier1_env; ch->static_queue = ctx->static_queue; ch->no_split_t = ctx->no_split_t; ch->ext_cap = ctx->ext_cap;
+        ch->iter_cap = ctx->iter_cap; ch->tier1_env = ctx->tier1_env; ch->static_queue = ctx->static_queue; ch->no_split_t = ctx->no_split_t; ch->ext_cap = ctx->ext_cap; ch->nbr_grid = ctx->nbr_grid;
         ch->no_split = 1;
         ctx->children.push_back(ch);
     }

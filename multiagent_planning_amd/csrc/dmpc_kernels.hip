@@ -895,7 +895,7 @@ __global__ __launch_bounds__(64, SOLVE_WAVES_PER_SIMD) void dmpc_solve_kernel(St
 // (round 4, slack-free variants: TWELVE waves per workgroup -- three per SIMD, what 168 registers per lane allow -- with the split T of
 // dmpc_solve.hip: TS columns of the factor per wave and a pool of P.n_ext extensions behind the waves' blocks)
 template <bool SOFT, int QCAP, int TS = QCAP>
-__global__ __launch_bounds__(SOFT ? 512 : 768, 1) void dmpc_solve_persist_kernel(StepParams P)
+__global__ __launch_bounds__(SOFT ? 512 : DMPC_HARD_PW * 64, 1) void dmpc_solve_persist_kernel(StepParams P)
 {
     // tier 2 works through the list of agents tier 1 flagged (P.order points at it); usually it is empty
     int total = P.only_flagged ? *P.flag_count : P.S * P.c_count;
@@ -1102,6 +1102,271 @@ __global__ __launch_bounds__(64) void nbr_kernel(int S, int G, int C, int g_loca
         e += j_hi - j_lo;
     }
     if (mine) cnt_out[gid * NBR_PARTS + part] = cnt > pcap ? -1 : cnt;
+}
+
+// --------------------------------------------------------------------------------------------
+// Neighbour lists of large scenes, round 4: a cell grid instead of the all-pairs box test, and the fp32 DISTANCE test of the scan's list
+// walk moved in here.  (C4, 10^4 agents, round 3: nbr_kernel is an O(N^2) box test -- 222 us -- whose lists hold the 100-700 neighbours
+// whose horizon boxes come close; every lane appended to its own list at a 16 KB stride, 137 MB of written cache lines for 12 MB of
+// entries; the scan then walked those lists once per agent with a whole horizon of distances per entry, 327 us.)
+//   grid_bin / grid_scan / grid_fill: the agents of a scene binned by the CENTRE of their whole-horizon box (counting sort: count,
+//     exclusive scan per scene, scatter; the order inside a cell is whatever the atomics give -- nothing below depends on it);
+//   grid_query: one wave per agent.  Candidates = the cells within own half extent + R + the scene's LARGEST half extent of the own
+//     centre (a running maximum from grid_bin), lanes = candidates: the segment-box test of nbr_kernel (18 numbers per candidate),
+//     survivors compacted into an LDS staging list; full waves of survivors then take the distance test itself -- the candidate's
+//     whole horizon from the fp32 neighbour-major table (15 x 16 bytes per lane) against the own horizon (LDS broadcasts), pass = some
+//     horizon step closer than the selection radius (3 rmin; 1 for the hard rows), widened by 1e-3 as in the scan -- and set their bit in
+//     a per-wave BITMAP over the scene's agents; the list is the bitmap read in order: increasing neighbour index whatever order the
+//     candidates came in (the scan builds rows in list order = the reference's row order), duplicates impossible, written as one
+//     contiguous run.  Lists of 10-40 entries instead of 100-700: a superset of every pair the scan can select at any step, so results
+//     are unchanged bit for bit (tests/test_gpu_paths.py against option no_cull).
+// --------------------------------------------------------------------------------------------
+struct GridGeom {
+    float org[3], inv[3];   // cell index along axis a = clamp(floor((x - org[a]) * inv[a]), 0, n[a] - 1)
+    int n[3];
+};
+__device__ __forceinline__ int grid_coord(const GridGeom &g, int a, float x)
+{
+    const float t = (x - g.org[a]) * g.inv[a];
+    const int c = (int)floorf(t);
+    return c < 0 ? 0 : (c >= g.n[a] ? g.n[a] - 1 : c);   // clamping is monotone: points within d of each other stay within ceil(d / cell) cells
+}
+// thread per table column (chunk, scene, column): per horizon segment the cell of the segment box's centre, cell counts, the scene's
+// largest half extents (one atomic per wave and quantity when the wave's columns belong to one scene -- 10^4 same-address atomics are
+// 0.1 ms of serialised service each)
+__global__ void grid_bin_kernel(int total, int S, int C, int short_from, GridGeom gg, const float *__restrict__ bbox_nm, int *__restrict__ cellof,
+                                int *__restrict__ cnt, int *__restrict__ maxhalf)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // (r * S + scene) * C + c
+    const bool in = i < total;
+    const int ii = in ? i : total - 1;
+    const int c = ii % C, rs = ii / C, scene = rs % S, r = rs / S;
+    const bool valid = in && !(short_from && r >= short_from && c == C - 1);   // (padding column of a short chunk)
+    const float *b = bbox_nm + (size_t)ii * NBOX_NM;
+    const int ncell = gg.n[0] * gg.n[1] * gg.n[2];
+    const int sc0 = __builtin_amdgcn_readfirstlane(scene);
+    const bool uni = __all(scene == sc0);
+#pragma unroll
+    for (int sg = 0; sg < NSEG; ++sg) {
+        int cc[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float lo = b[6 * sg + 2 * a], hi = b[6 * sg + 2 * a + 1];
+            const float half = 0.5f * (hi - lo) * 1.0001f + 1e-5f;   // (rounded up: the query's reach must cover it)
+            cc[a] = grid_coord(gg, a, 0.5f * (lo + hi));
+            int hb = valid ? __float_as_int(half) : 0;   // non-negative floats order like integers
+            int *dst = maxhalf + ((size_t)scene * NSEG + sg) * 3 + a;
+            if (uni) {
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(hb, off); hb = o > hb ? o : hb; }
+                if ((threadIdx.x & 63) == 0 && hb > *(volatile int *)dst) atomicMax(dst, hb);
+            } else if (valid && hb > *(volatile int *)dst) atomicMax(dst, hb);
+        }
+        const int cell = (cc[2] * gg.n[1] + cc[1]) * gg.n[0] + cc[0];
+        if (in) cellof[(size_t)sg * total + i] = valid ? cell : -1;
+        if (valid) atomicAdd(cnt + ((size_t)scene * NSEG + sg) * ncell + cell, 1);
+    }
+}
+// block per (scene, segment): start[..][0 .. ncell] = exclusive prefix of the cell counts; the counts are zeroed (grid_fill counts them up again)
+__global__ void grid_scan_kernel(int ncell, int *__restrict__ cnt, int *__restrict__ start)
+{
+    __shared__ int part[256];
+    __shared__ int carry;
+    const int scene = blockIdx.x, t = threadIdx.x;
+    int *c = cnt + (size_t)scene * ncell, *st = start + (size_t)scene * (ncell + 1);
+    if (t == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < ncell; base += 256) {
+        const int v = base + t < ncell ? c[base + t] : 0;
+        part[t] = v;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            const int add = t >= off ? part[t - off] : 0;
+            __syncthreads();
+            part[t] += add;
+            __syncthreads();
+        }
+        if (base + t < ncell) { st[base + t] = carry + part[t] - v; c[base + t] = 0; }
+        __syncthreads();
+        if (t == 0) carry += part[255];
+        __syncthreads();
+    }
+    if (t == 0) st[ncell] = carry;
+}
+// entry = 32-byte record {code, segment box lo/hi x, y, z, 0}: the query's box test then streams its candidates COALESCED (a gather of the
+// candidates' boxes -- 64 cache lines per wave load, three loads per candidate -- kept the address units busy for the whole kernel)
+__global__ void grid_fill_kernel(int total, int S, int C, int ncell, const int *__restrict__ cellof, int *__restrict__ cnt, const int *__restrict__ start,
+                                 const float *__restrict__ bbox_nm, f4_t *__restrict__ ent)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = i % C, rs = i / C, scene = rs % S, r = rs / S;
+    const size_t nag = (size_t)total / S;
+#pragma unroll
+    for (int sg = 0; sg < NSEG; ++sg) {
+        const int cell = cellof[(size_t)sg * total + i];
+        if (cell < 0) return;
+        const size_t ss = (size_t)scene * NSEG + sg;
+        const int pos = atomicAdd(cnt + ss * ncell + cell, 1);
+        const float *b = bbox_nm + (size_t)i * NBOX_NM + 6 * sg;
+        f4_t *rec = ent + 2 * (ss * nag + start[ss * (ncell + 1) + cell] + pos);
+        f4_t r0, r1;
+        r0.x = __int_as_float((r << 20) | c); r0.y = b[0]; r0.z = b[1]; r0.w = b[2];
+        r1.x = b[3]; r1.y = b[4]; r1.z = b[5]; r1.w = 0.f;
+        rec[0] = r0; rec[1] = r1;
+    }
+}
+constexpr int GQ_WAVES = 4;        // waves (agents) per workgroup of grid_query_kernel
+constexpr int GQ_STAGE = 128;      // staging list of box-test survivors per wave (a full wave is taken off it as soon as there is one)
+inline size_t grid_query_lds_per_wave(int nagents) { return (size_t)(((nagents + 31) / 32) * 4 + GQ_STAGE * 4 + 64 * 16 + 15) & ~(size_t)15; }
+typedef float f2_t __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(64 * GQ_WAVES) void grid_query_kernel(int S, int G, int C, int g_local, int c_first, int c_count, GridGeom gg, float R, float Rz, float e1z, float thr2,
+                                                                   const float *__restrict__ bbox_nm, const float *__restrict__ lrow, const int *__restrict__ start,
+                                                                   const f4_t *__restrict__ ent, const int *__restrict__ maxhalf, int cap, int lds_per_wave,
+                                                                   int *__restrict__ list, int *__restrict__ cnt_out)
+{
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63);
+    const int gid = __builtin_amdgcn_readfirstlane((int)blockIdx.x * GQ_WAVES + wave);
+    if (gid >= S * c_count) return;
+    const int scene = gid / c_count, ci = gid - scene * c_count, cl = c_first + ci;
+    const int nag = G * C, nwords = (nag + 31) >> 5, ncell = gg.n[0] * gg.n[1] * gg.n[2];
+    unsigned char *mine = dmpc_smem + (size_t)wave * lds_per_wave;
+    unsigned *bits = (unsigned *)mine;
+    int *stage = (int *)(mine + (size_t)nwords * 4);
+    f4_t *ownrow = (f4_t *)(mine + (((size_t)nwords * 4 + GQ_STAGE * 4 + 15) & ~(size_t)15));
+    for (int i = lane; i < nwords; i += 64) bits[i] = 0u;
+    const size_t self_i = (size_t)(g_local * S + scene) * C + cl;
+    if (lane < 16) ownrow[lane] = ((const f4_t *)lrow)[self_i * 16 + lane];   // the own horizon: 15 x (x, y, z, 0) + 4 zeros
+    // own boxes (wave-uniform: scalar loads)
+    const ConstF4 ob4 = (ConstF4)(unsigned long long)(bbox_nm + self_i * NBOX_NM);
+    const f4_t o0 = ob4[0], o1 = ob4[1], o2 = ob4[2], o3 = ob4[3], o4 = ob4[4];
+    const float obx[18] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w, o2.x, o2.y, o2.z, o2.w, o3.x, o3.y, o3.z, o3.w, o4.x, o4.y};
+    LSYNC();
+    const int self_code = (g_local << 20) | cl;
+#pragma unroll 1
+    for (int sg = 0; sg < NSEG; ++sg) {
+        // this segment's own box, inflated by the selection radius; the cells its neighbours' centres can lie in
+        float ob[6];
+        int c_lo[3], c_hi[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float lo = sg == 0 ? obx[2 * a] : (sg == 1 ? obx[6 + 2 * a] : obx[12 + 2 * a]);
+            const float hi = sg == 0 ? obx[2 * a + 1] : (sg == 1 ? obx[6 + 2 * a + 1] : obx[12 + 2 * a + 1]);
+            const float infl = a < 2 ? R : Rz;
+            const float reach = infl + __int_as_float(maxhalf[((size_t)scene * NSEG + sg) * 3 + a]);   // a neighbour's centre is at most its half extent from its box
+            c_lo[a] = grid_coord(gg, a, lo - reach); c_hi[a] = grid_coord(gg, a, hi + reach);
+            ob[2 * a] = lo - infl; ob[2 * a + 1] = hi + infl;
+        }
+        const size_t ss = (size_t)scene * NSEG + sg;
+        const int *st = start + ss * (ncell + 1);
+        const f4_t *en = ent + 2 * ss * nag;
+        int nst = 0;
+        // the distance test over this segment's horizon steps on a full wave (or the rest) of staged survivors
+        auto traj_test = [&](int n) {
+            const bool have = lane < n;
+            const int code = stage[have ? lane : 0];
+            const int r = code >> 20, jc = code & 0xfffff;
+            const f4_t *row = (const f4_t *)lrow + ((size_t)(r * S + scene) * C + jc) * 16 + SEG_STEPS * sg;
+            f4_t v[SEG_STEPS];
+#pragma unroll
+            for (int u = 0; u < SEG_STEPS; ++u) v[u] = row[u];
+            bool pass = false;
+#pragma unroll
+            for (int u = 0; u < SEG_STEPS; ++u) {
+                const f4_t o = ownrow[SEG_STEPS * sg + u];
+                const float dx = o.x - v[u].x, dy = o.y - v[u].y, dz = (o.z - v[u].z) * e1z;
+                pass = pass || (dx * dx + dy * dy + dz * dz < thr2);
+            }
+            if (have && pass) {
+                const int idx = r * C + jc;
+                atomicOr(bits + (idx >> 5), 1u << (idx & 31));
+            }
+        };
+        // The candidates: per (y, z) cell row one RUN of entries (the cells of a run along x are contiguous), ~50 entries each at N = 10^4.
+        // The walk is a chain of dependent memory round trips -- run bounds, entries, the entries' boxes -- and was bound by their latency
+        // (246 us at N = 10^4): the bounds of up to 64 runs are fetched at once (lanes = runs), and the rounds of 64 candidates are software
+        // pipelined -- entries two rounds ahead, boxes one round ahead of the test.
+        const int ny = c_hi[1] - c_lo[1] + 1, nruns_all = ny * (c_hi[2] - c_lo[2] + 1);
+        const UDiv div_ny((unsigned)ny);
+        for (int run0 = 0; run0 < nruns_all; run0 += 64) {
+            const int nruns = nruns_all - run0 < 64 ? nruns_all - run0 : 64;
+            int rb = 0, re = 0;
+            if (lane < nruns) {
+                int qz, qy;
+                div_ny.divmod((unsigned)(run0 + lane), qz, qy);
+                const int row0 = ((c_lo[2] + qz) * gg.n[1] + c_lo[1] + qy) * gg.n[0];
+                rb = st[row0 + c_lo[0]]; re = st[row0 + c_hi[0] + 1];
+            }
+            int ft = 0, fj = 0;   // fetch cursor: run, round within the run (wave-uniform)
+            struct Rec { f4_t a, b; bool hv; };
+            auto fetch_next = [&](Rec &rc) -> bool {
+                int b = 0, e = 0;
+                while (ft < nruns) {
+                    b = __builtin_amdgcn_readlane(rb, ft) + 64 * fj; e = __builtin_amdgcn_readlane(re, ft);
+                    if (b < e) break;
+                    ++ft; fj = 0;
+                }
+                if (ft >= nruns) return false;
+                rc.hv = b + lane < e;
+                const f4_t *p = en + 2 * (size_t)(rc.hv ? b + lane : b);
+                rc.a = p[0]; rc.b = p[1];
+                ++fj;
+                return true;
+            };
+            Rec r0, r1;
+            r0.hv = r1.hv = false; r0.a = r0.b = r1.a = r1.b = f4_t{0.f, 0.f, 0.f, 0.f};
+            bool v0 = fetch_next(r0), v1 = false;
+            while (v0) {
+                v1 = fetch_next(r1);   // (the next round's records in flight during this round's test)
+                // overlap in arithmetic form (nbr_kernel): the maximum of the six differences is <= 0
+                const float m6 = fmaxf(__builtin_fmaxf(__builtin_fmaxf(r0.a.y - ob[1], ob[0] - r0.a.z), r0.a.w - ob[3]),
+                                       __builtin_fmaxf(__builtin_fmaxf(ob[2] - r0.b.x, r0.b.y - ob[5]), ob[4] - r0.b.z));
+                const int c0 = __float_as_int(r0.a.x);
+                const bool surv = r0.hv && c0 != self_code && m6 <= 0.f;
+                const unsigned long long m = __ballot(surv);
+                if (m) {
+                    if (surv) stage[nst + lanes_below(m, lane)] = c0;
+                    nst += __popcll(m);
+                    LSYNC();
+                    if (nst >= 64) {
+                        traj_test(64);
+                        LSYNC();
+                        const int keep = lane < nst - 64 ? stage[64 + lane] : 0;
+                        LSYNC();
+                        if (lane < nst - 64) stage[lane] = keep;
+                        nst -= 64;
+                        LSYNC();
+                    }
+                }
+                r0 = r1; v0 = v1;
+            }
+        }
+        if (nst > 0) traj_test(nst);
+        LSYNC();
+    }
+    // the list = the bitmap in order (increasing neighbour index), one contiguous run per agent
+    int *out = list + (size_t)gid * cap;
+    int total = 0;
+    const UDiv div_c((unsigned)C);
+    for (int w0 = 0; w0 < nwords; w0 += 64) {
+        unsigned word = w0 + lane < nwords ? bits[w0 + lane] : 0u;
+        const int mycnt = __popc(word);
+        int pre = mycnt;   // inclusive prefix of the lanes' counts
+        for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(pre, off); if (lane >= off) pre += o; }
+        const int wave_total = __builtin_amdgcn_readlane(pre, 63);
+        int pos = total + pre - mycnt;
+        while (word) {
+            const int b = __ffs((int)word) - 1;
+            word &= word - 1u;
+            const int idx = ((w0 + lane) << 5) + b;
+            int r = 0, jc = idx;
+            if (G > 1) div_c.divmod((unsigned)idx, r, jc);
+            if (pos < cap) out[pos] = (r << 20) | jc;
+            ++pos;
+        }
+        total += wave_total;
+    }
+    if (lane < NBR_PARTS) cnt_out[(size_t)gid * NBR_PARTS + lane] = lane == 0 ? (total > cap ? -1 : total) : 0;
 }
 
 // Longest-processing-time-first launch order for the solve phase: agents are bucketed by the key the scan left in

@@ -582,7 +582,10 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
     const int nrows_built = h0.y, viol_k = h0.z;
     const bool violation = (h1.x & 1) != 0, rows_exist = h1.y != 0;
     const bool cppv = (var == VAR_CPP || var == VAR_CPP2);
-    constexpr int RC = soft ? 1 : 2;   // register cache of the first collision rows (RC per lane; the rest is streamed from the L2-resident scratch)
+#ifndef DMPC_HARD_RC
+#define DMPC_HARD_RC 2
+#endif
+    constexpr int RC = soft ? 1 : DMPC_HARD_RC;   // register cache of the first collision rows (RC per lane; the rest is streamed from the L2-resident scratch)
     double rcx0[2], rcx1[2], rcx2[2], rcb[2], rcsd[2], rcslb[2];
     float rcw[2];
     int rckc[2];

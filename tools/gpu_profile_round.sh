@@ -15,7 +15,7 @@ OUT=$REPO/gpurun_out/$LABEL
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 case $WL in
-  headline) BENCH="python $REPO/bench.py --no-cpu-baseline --no-secondary"; SPL=51200; KERN="solve_persist_kernel<false, 48>";;
+  headline) BENCH="python $REPO/bench.py --no-cpu-baseline --no-secondary"; SPL=51200; KERN="solve_persist_kernel<false, 48";;
   bound)    BENCH="python $REPO/tools/replay_workload.py bound"; SPL=51200; KERN="solve_persist_kernel<true, 48>";;
   c4)       BENCH="python $REPO/tools/replay_workload.py c4"; SPL=10000; KERN="dmpc_solve_";;
 esac

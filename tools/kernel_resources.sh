@@ -1,7 +1,7 @@
 #!/bin/bash
 # development: register / scratch / occupancy of every kernel of the library as the compiler reports them (no GPU needed)
 cd "$(dirname "$0")/../multiagent_planning_amd/csrc" && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function \
-  -mllvm -amdgpu-atomic-optimizer-strategy=None -S --cuda-device-only -Rpass-analysis=kernel-resource-usage -o /dev/null dmpc_api.hip 2>&1 |
+  -mllvm -amdgpu-atomic-optimizer-strategy=None -S --cuda-device-only -Rpass-analysis=kernel-resource-usage $KRES_DEFS -o /dev/null dmpc_api.hip 2>&1 |
 python3 -c "
 import sys,re
 cur=None;rows=[]
