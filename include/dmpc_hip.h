@@ -47,7 +47,14 @@ enum {
      * (dmpc.h:191-205): pass h, rmin, c, alim as (double)(float) values and term = -1e6, Q1 = 1000, S1 = 100 (:846,942-945)
      * to reproduce its arithmetic. */
     DMPC_VAR_CPP = 8,
-    DMPC_VAR_CPP2 = 9
+    DMPC_VAR_CPP2 = 9,
+    /* the FIRST C++ version, DMPC::solveQP (dmpc/cpp/dmpc.cpp:554-801; callers solveDMPC :1367, cluster_solve :1776): at the first
+     * horizon step k (0-based) where check_collisions (:378-396) finds a neighbour inside rmin, rows for ALL N-1 neighbours
+     * (build_collconstraint :450-498) on step k-1, each with its own slack: [A I; 0 I] x <= [b; 0] (:629-633), linear slack cost -1e6
+     * (:715), quadratic slack weight 1 (:719); cost cases by `violation` (:640-661); ONE QuadProgDense solve, no retry, no in-bounds
+     * test, no first-step collision test.  A violation at k = 0 makes the reference index row -3 of A0 (undefined behaviour): reported
+     * as DMPC_ST_COLL without a solve.  Float members as for DMPC_VAR_CPP. */
+    DMPC_VAR_CPP1 = 10
 };
 
 /* per-agent status bits (the reference's feasible/success, outbound, coll flags) */
@@ -110,7 +117,7 @@ enum {
 /* Create a solver context.  Replaces the constants/precompute preamble of dmpc/matlab/dmpc_soft_bound.m:80-108 and the DMPC ctor
  * dmpc/cpp/dmpc.cpp:19-75.  precision: DMPC_PREC_*.
  *   device >= 0           one HIP device.
- *   DMPC_DEVICE_ALL  (-1) EVERY visible GPU, from this one process: the agents of each scene are sharded over the GPUs in the
+ *   DMPC_DEVICE_ALL (-100) EVERY visible GPU, from this one process: the agents of each scene are sharded over the GPUs in the
  *                         reference's contiguous thread clusters (DMPC::solveParallelDMPCv2, dmpc/cpp/dmpc.cpp:1600-1625: N/G each,
  *                         the first N mod G one more), one internal host thread + stream + sub-context per GPU, and the join of
  *                         every MPC step (`prev_obs = obs`, :1671-1681; `l = new_l`, dmpc_soft_bound.m:146) is a set of direct
@@ -120,10 +127,11 @@ enum {
  *                         dmpc_postcheck on the resident histories -- work unchanged on such a context; the per-agent and helper
  *                         entry points run on its first GPU; the device-pointer entry points (one device's memory) refuse it.
  *                         With one visible GPU this is a plain context.  Results do not depend on the number of GPUs, bit for bit.
- *   DMPC_DEVICE_CURRENT (-2) the calling thread's current HIP device (one process per GPU: "this rank's GPU").
+ *   DMPC_DEVICE_CURRENT (-1) the calling thread's current HIP device (one process per GPU: "this rank's GPU").
+ *   Any other negative value is refused.
  * Returns NULL on failure (no device, bad parameters); dmpc_last_error(NULL) has the text. */
-#define DMPC_DEVICE_ALL (-1)
-#define DMPC_DEVICE_CURRENT (-2)
+#define DMPC_DEVICE_CURRENT (-1)   /* (the value "current device" has had since the first version of this header) */
+#define DMPC_DEVICE_ALL (-100)
 dmpc_ctx *dmpc_create(const dmpc_params *prm, int device, int precision);
 /* number of GPUs the context drives (1 unless created with DMPC_DEVICE_ALL on a multi-GPU node) */
 int dmpc_group_size(const dmpc_ctx *ctx);

@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdmpc_hip.so")
 
-VARIANTS = dict(bound=0, bound2=1, all3=2, hard=3, ondemand=4, ellip=5, softall=6, repair=7, cpp=8, cpp2=9)
+VARIANTS = dict(bound=0, bound2=1, all3=2, hard=3, ondemand=4, ellip=5, softall=6, repair=7, cpp=8, cpp2=9, cpp1=10)
 ST_SOLVED, ST_OUTBOUND, ST_COLL, ST_INFEAS, ST_CAPACITY, ST_ITERCAP = 1, 2, 4, 8, 16, 32
 PRECISIONS = dict(f64=0, mixed=1)
 ST_REACHED = 256   # scene_status of transition(): every agent reached its goal
@@ -188,8 +188,8 @@ class Dmpc:
 
     def __init__(self, variant="bound", device=0, precision="f64", **kw):
         """precision: "f64" (DMPC_PREC_F64) or "mixed" (DMPC_PREC_MIXED: fp32 table / scan / rows, fp64 QP);
-        device: a HIP device index, DEVICE_ALL (-1: every visible GPU from this process, agents sharded over them) or
-        DEVICE_CURRENT (-2: the calling thread's current device)"""
+        device: a HIP device index, DEVICE_ALL (-100: every visible GPU from this process, agents sharded over them) or
+        DEVICE_CURRENT (-1: the calling thread's current device)"""
         self._L = load()
         self.prm = make_params(variant, **kw)
         self.precision = precision
@@ -198,7 +198,7 @@ class Dmpc:
             raise DmpcError(self._L.dmpc_last_error(None).decode())
         self.device = device
 
-    DEVICE_ALL, DEVICE_CURRENT = -1, -2
+    DEVICE_ALL, DEVICE_CURRENT = -100, -1
 
     @property
     def n_devices(self):

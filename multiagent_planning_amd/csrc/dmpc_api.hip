@@ -168,7 +168,7 @@ static int check_params(const dmpc_params *p, std::string &why)
     if (!p) { why = "params is NULL"; return -1; }
     if (p->K != K) { why = "only K = k_hor = 15 is supported (the value every reference script uses)"; return -1; }
     if (p->order != 2) { why = "only ellipsoid order 2 is supported (the value every reference script uses)"; return -1; }
-    if (p->variant < 0 || p->variant > DMPC_VAR_CPP2) { why = "unknown variant"; return -1; }
+    if (p->variant < 0 || p->variant > DMPC_VAR_CPP1) { why = "unknown variant"; return -1; }
     if (!(p->h > 0) || !(p->rmin > 0) || !(p->c > 0) || !(p->alim > 0)) { why = "h, rmin, c, alim must be positive"; return -1; }
     for (int d = 0; d < 3; ++d)
         if (!(p->pmax[d] > p->pmin[d])) { why = "pmax must exceed pmin"; return -1; }
@@ -449,6 +449,7 @@ extern "C" dmpc_ctx *dmpc_create(const dmpc_params *prm, int device, int precisi
         return nullptr;
     }
     if (device == DMPC_DEVICE_CURRENT && hipGetDevice(&device) != hipSuccess) device = 0;
+    if (device < 0 && device != DMPC_DEVICE_ALL) { g_err = "dmpc_create: device must be a HIP device index, DMPC_DEVICE_CURRENT or DMPC_DEVICE_ALL"; return nullptr; }
     if (device == DMPC_DEVICE_ALL) {
         // every visible GPU, one process: rank r of the group on device r (the reference's thread clusters, dmpc.cpp:1600-1625,
         // one GPU each).  One visible GPU: a plain context.
@@ -564,7 +565,7 @@ extern "C" int dmpc_profile(dmpc_ctx *ctx, int enable)
 static bool variant_soft(int v)
 {
     return v == DMPC_VAR_BOUND || v == DMPC_VAR_BOUND2 || v == DMPC_VAR_ALL3 || v == DMPC_VAR_SOFTALL || v == DMPC_VAR_REPAIR ||
-           v == DMPC_VAR_CPP || v == DMPC_VAR_CPP2;
+           v == DMPC_VAR_CPP || v == DMPC_VAR_CPP2 || v == DMPC_VAR_CPP1;
 }
 
 // row capacity per agent.  Rows live in global scratch (40-64 B each); LDS only holds 4-12 B per row
@@ -592,7 +593,7 @@ static int row_capacity(int variant, int N)
 // that outgrow 32 are exactly the long ones (several retry-ladder levels, many active rows) and re-solving them in a second,
 // serialized launch cost more than anything else in the step.  Measured (bench secondaries, 51 200 agents of
 // solveSoftDMPCbound): 32/64 tiers 1.38 ms per step, one 64-slot tier (5 agents per CU) 1.07 ms, 48/64 tiers 1.02 ms;
-// 512 whole transitions 110 / 107 / 100 ms.  DMPC_TIER1_QCAP = 32 | 64 selects the other forms (tests cover the 32/64 hand-off).
+// 512 whole transitions 110 / 107 / 100 ms.  development option tier1_qcap = 32 | 64 selects the other forms (tests cover the 32/64 hand-off).
 static int tier1_qcap(const dmpc_ctx *ctx, int variant, int scene_agents);
 // hard: 45 variables => at most 45 independent active rows; 48 leaves room for a numerically near-dependent addition
 static int full_qcap(int variant) { return variant_soft(variant) ? QMAX : 48; }
@@ -915,6 +916,25 @@ extern "C" int dmpc_debug_trace(dmpc_ctx *ctx, int agent, int cap, double *host_
         HIPCHK(ctx, hipMalloc((void **)&ctx->dbg, sizeof(double) * 8 * cap));
         HIPCHK(ctx, hipMemset(ctx->dbg, 0, sizeof(double) * 8 * cap));
     }
+    return 0;
+}
+
+// development aid (not part of the public header): a coalesced streaming read of `bytes` bytes at lane_bytes (8 | 16) per lane, `reps`
+// launches -- the known byte count the FETCH_SIZE counter is calibrated on (tools/gpu_fetch_calib.py under rocprofv3 --pmc FETCH_SIZE)
+extern "C" int dmpc_debug_read_probe(dmpc_ctx *ctx, size_t bytes, int lane_bytes, int reps)
+{
+    if (!ctx || (lane_bytes != 8 && lane_bytes != 16) || bytes < 4096) return -1;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    void *buf = nullptr; double *sink = nullptr;
+    HIPCHK(ctx, hipMalloc(&buf, bytes));
+    HIPCHK(ctx, hipMalloc((void **)&sink, 64));
+    HIPCHK(ctx, hipMemsetAsync(buf, 0, bytes, ctx->stream));
+    for (int r = 0; r < reps; ++r) {
+        if (lane_bytes == 8) hipLaunchKernelGGL(read_probe_kernel<double>, dim3(256 * 16), dim3(256), 0, ctx->stream, bytes / 8, (const double *)buf, sink);
+        else hipLaunchKernelGGL(read_probe_kernel<double2>, dim3(256 * 16), dim3(256), 0, ctx->stream, bytes / 16, (const double2 *)buf, sink);
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(buf); (void)hipFree(sink);
     return 0;
 }
 
@@ -1324,6 +1344,17 @@ static int transition_one(dmpc_ctx *ctx, int S, int N, const double *po, const d
     return 0;
 }
 
+// development options of a context handed to a context it creates for itself (further parts of a split batch, the second group)
+static void copy_debug_options(dmpc_ctx *dst, const dmpc_ctx *src)
+{
+    static const char *names[] = {"no_fuse", "no_persist", "force_persist", "no_cull", "order_slices", "cull_min", "no_lpt", "crash_min", "crash_any", "no_fast_exit",
+                                  "pivot_explore", "iter_cap", "tier1_qcap", "static_queue", "no_split_t", "ext_cap", "nbr_grid"};
+    int dmpc_ctx::*fields[] = {&dmpc_ctx::no_fuse, &dmpc_ctx::no_persist, &dmpc_ctx::force_persist, &dmpc_ctx::no_cull, &dmpc_ctx::order_slices, &dmpc_ctx::cull_min,
+                               &dmpc_ctx::no_lpt, &dmpc_ctx::crash_min, &dmpc_ctx::crash_any, &dmpc_ctx::no_fast_exit, &dmpc_ctx::pivot_explore, &dmpc_ctx::iter_cap,
+                               &dmpc_ctx::tier1_env, &dmpc_ctx::static_queue, &dmpc_ctx::no_split_t, &dmpc_ctx::ext_cap, &dmpc_ctx::nbr_grid};
+    for (size_t i = 0; i < sizeof(names) / sizeof(names[0]); ++i) (void)dmpc_debug_option(dst, names[i], src->*(fields[i]));
+}
+
 // Batched transitions are bound, MPC step by MPC step, by the slowest agent of the whole batch while most of the GPU
 // idles.  Scenes are independent, so a large batch is run as two halves on two contexts (= two HIP streams, two host
 // threads): the tail of one half overlaps the bulk of the other (512 transitions of 100 agents: 103 -> 60 ms).
@@ -1339,6 +1370,9 @@ extern "C" int dmpc_transition(dmpc_ctx *ctx, int S, int N, const double *po, co
         // GPUs): scenes are independent, so while one half's ranks exchange their predictions (peer copies, barrier, events) the
         // other half's solve kernels keep the GPUs busy -- the per-step exchange is off the critical path.
         const int gparts = ctx->no_split ? 1 : (ctx->split_parts > 0 ? (ctx->split_parts > 2 ? 2 : ctx->split_parts) : (S >= 64 ? 2 : 1));
+        // fewer agents than twice the GPUs (the reference's small swarms on an 8-GPU node): the first GPU alone, as dmpc_step_batch does --
+        // sharding N = 4 agents over 8 GPUs is impossible and over 2-3 of them nothing but barriers and peer copies
+        if (N < 2 * ctx->grp->G) return transition_one(ctx, S, N, po, pf, K_T_max, error_tol, pk, vk, ak, K_T_used, scene_status);
         if (gparts < 2) return group_transition(ctx, S, N, po, pf, K_T_max, error_tol, pk, vk, ak, K_T_used, scene_status);
         if (ctx->children.empty()) {
             const int keep = g_emulate_devices.load();
@@ -1346,6 +1380,7 @@ extern "C" int dmpc_transition(dmpc_ctx *ctx, int S, int N, const double *po, co
             dmpc_ctx *other = dmpc_create(&ctx->prm, DMPC_DEVICE_ALL, ctx->precision);
             g_emulate_devices.store(keep);
             if (!other || !other->grp || other->grp->G != ctx->grp->G) { if (other) dmpc_destroy(other); FAIL(ctx, "dmpc_transition: second group: " + g_err); }
+            copy_debug_options(other, ctx);   // (and, through dmpc_debug_option, to its rank contexts)
             other->no_split = 1;
             ctx->children.push_back(other);
         }
@@ -1376,9 +1411,7 @@ extern "C" int dmpc_transition(dmpc_ctx *ctx, int S, int N, const double *po, co
     while ((int)ctx->children.size() < parts - 1) {
         dmpc_ctx *ch = dmpc_create(&ctx->prm, ctx->device, ctx->precision);
         if (!ch) FAIL(ctx, "dmpc_transition: further context: " + g_err);
-        ch->no_fuse = ctx->no_fuse; ch->no_persist = ctx->no_persist; ch->force_persist = ctx->force_persist; ch->no_cull = ctx->no_cull; ch->order_slices = ctx->order_slices; ch->cull_min = ctx->cull_min;
-        ch->no_lpt = ctx->no_lpt; ch->crash_min = ctx->crash_min; ch->crash_any = ctx->crash_any; ch->no_fast_exit = ctx->no_fast_exit; ch->pivot_explore = ctx->pivot_explore;
-        ch->iter_cap = ctx->iter_cap; ch->tier1_env = ctx->tier1_env; ch->static_queue = ctx->static_queue; ch->no_split_t = ctx->no_split_t; ch->ext_cap = ctx->ext_cap; ch->nbr_grid = ctx->nbr_grid;
+        copy_debug_options(ch, ctx);
         ch->no_split = 1;
         ctx->children.push_back(ch);
     }

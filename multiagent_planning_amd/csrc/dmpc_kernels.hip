@@ -491,6 +491,7 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
                     if (var == VAR_BOUND2 || var == VAR_ALL3) slb = -0.01;           // bound2:77, all:92
                     else if (cppv) slb = -(real)0.01f;                              // dmpc.cpp:907-914,1079: -eps <= lim, float lim = 0.01
                     else if (var == VAR_SOFTALL) { sd = 1.0; st = -1e5; slb = -INFINITY; }  // solveSoftDMPC.m:21,65
+                    else if (var == VAR_CPP1) { sd = 1.0; st = -1e6; slb = -INFINITY; }     // dmpc.cpp:629-633,715: [A I] x <= b, eps <= 0, f_w = -10^6
                     else if (var == VAR_REPAIR) { st = P.term / dist; slb = -INFINITY; }    // repair:77,81
                     L.r_sd[pos] = sd; L.r_st[pos] = st; L.r_slb[pos] = slb;
                 }
@@ -726,13 +727,15 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
                     // cpp: `dist < _rmin - _collision_tol` (floats) raises execution_ended, the build goes on (dmpc.cpp:419-424)
                     if (cppv && mind0 < (real)((float)rmin - 0.05f)) coll_flag = true;
                 }
+                // DMPC::solveQP (dmpc.cpp:626-637): rows on step k-1 (`3*(k-1)`, :480-485); k = 0 indexes row -3 there (undefined): `coll`, no QP
+                if (var == VAR_CPP1 && k == 0) { status = ST_COLL; viol_k = 1; break; }
                 if (skip_k1 && k == 0) continue;          // solveSoftDMPCbound2.m:29-31
                 viol_k = k + 1; violation = true; rows_exist = true;
                 if (var == VAR_ALL3) {                     // solveSoftDMPCall.m:34-48: steps k-1,k,k+1
                     const int k0 = (k == 1) ? k : k - 1, k1 = (k == K - 1) ? k : k + 1;
                     for (int kk = k0; kk <= k1; ++kk) build_rows(k, kk, kk, 3.0 * rmin, false);
                 } else {
-                    const int kc = (var == VAR_BOUND2 || var == VAR_CPP2) ? k - 1 : k;   // CollConstrSoftDMPC2.m:8; dmpc.cpp:516
+                    const int kc = (var == VAR_BOUND2 || var == VAR_CPP2 || var == VAR_CPP1) ? k - 1 : k;   // CollConstrSoftDMPC2.m:8; dmpc.cpp:516; :480-485
                     // neighbour radius: 3 rmin (CheckCollSoftDMPC.m:12); cpp: _rmin*(1+(float)k/_k_hor) in float arithmetic
                     // (dmpc.cpp:418) -- __f*_rn keep the three float operations unfused
                     const real near_r = cppv ? (real)__fmul_rn((float)rmin, __fadd_rn(1.0f, __fdiv_rn((float)k, (float)K))) : 3.0 * rmin;
@@ -826,7 +829,7 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
                 const double p_out = w_unc + p0_l;
                 double v_out = 0.0;
                 if (comp) v_out = vel_out(a_s, k_l, ax_l, Qp->h, vo_l);
-                const bool ob_check = !(var == VAR_ELLIP || var == VAR_SOFTALL || cppv);   // (as the solver's output stage)
+                const bool ob_check = !(var == VAR_ELLIP || var == VAR_SOFTALL || var == VAR_CPP1 || cppv);   // (as the solver's output stage)
                 if (ob_check) {
                     const double tolb = 50e-3;
                     bool bad = false;
@@ -1367,6 +1370,19 @@ __global__ __launch_bounds__(64 * GQ_WAVES) void grid_query_kernel(int S, int G,
         total += wave_total;
     }
     if (lane < NBR_PARTS) cnt_out[(size_t)gid * NBR_PARTS + lane] = lane == 0 ? (total > cap ? -1 : total) : 0;
+}
+
+// calibration of the HBM-side counters (profiles/: FETCH_SIZE is documented for 16-byte-per-lane streams only): a streaming read of a known
+// number of bytes at 8 or 16 bytes per lane, coalesced, as this library's kernels read their tables and rows
+template <typename T>
+__global__ void read_probe_kernel(size_t n, const T *__restrict__ src, double *__restrict__ sink)
+{
+    double acc = 0.0;
+    for (size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x; t < n; t += (size_t)gridDim.x * blockDim.x) {
+        const T v = src[t];
+        acc += ((const double *)&v)[0];
+    }
+    if (acc == 1.2345e300) sink[0] = acc;   // (keeps the loads alive; never true for a zeroed buffer)
 }
 
 // Longest-processing-time-first launch order for the solve phase: agents are bucketed by the key the scan left in

@@ -365,6 +365,9 @@ static int transition_sharded_impl(dmpc_ctx *ctx, int S, int N, const double *po
     HIPCHK(ctx, hipMemsetAsync(ctx->hist_a.p, 0, hist, st));
     HIPCHK(ctx, hipMemsetAsync(ctx->sendbuf.p, 0, chunk * 8, st));
     HIPCHK(ctx, hipMemsetAsync(ctx->mg_fall.p, 0, (size_t)G * S * 16, st));
+    // group transport: the peers PUSH their verdict flags into this rank's mg_fall right after the first barrier, on their own streams --
+    // the memset above must have run by then
+    if (ctx->grp) HIPCHK(ctx, hipStreamSynchronize(st));
     // k = 1: initDMPC for ALL agents (every rank builds the same first table), own states = (po, 0, 0)
     hipLaunchKernelGGL(init_rows_kernel, dim3((unsigned)((A * N3 + 255) / 256)), dim3(256), 0, st, (int)A, ctx->prm.h, ctx->po.as<double>(),
                        ctx->mg_pf.as<double>(), ctx->rows.as<double>());
@@ -490,6 +493,10 @@ static int group_run(dmpc_ctx *root, F &&body)
     GroupShared *sh = root->grp;
     const int G = sh->G;
     sh->abort.store(0); sh->arrived.store(0);
+    // the parity of the event pairs and of the double-buffered verdict flags starts afresh: a call that failed half-way through an exchange
+    // may have left the ranks' counters apart
+    root->grp_steps = 0;
+    for (dmpc_ctx *pc : root->peers) pc->grp_steps = 0;
     std::vector<int> rc((size_t)G, 0);
     std::vector<std::thread> th;
     for (int r = 1; r < G; ++r)

@@ -1380,7 +1380,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
         a_out = a;
     }
     if (solved) {
-        const bool ob_check = !(var == VAR_ELLIP || var == VAR_SOFTALL || cppv);   // solveQPv2 has no in-bounds test
+        const bool ob_check = !(var == VAR_ELLIP || var == VAR_SOFTALL || var == VAR_CPP1 || cppv);   // solveQPv2 / solveQP have no in-bounds test
         if (h1.x & 4) status |= ST_COLL;   // cpp: collision noticed at the first step, solution still returned
         if (ob_check) {   // is_inbounds.m:2-5 on p(:,1)
             const double tolb = 50e-3;
@@ -1407,7 +1407,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
         Qp->status[gid] = status;
         if (Qp->info) {
             int *inf = Qp->info + (size_t)gid * 8;
-            inf[0] = viol_k; inf[1] = nrows_built; inf[2] = tries; inf[3] = ccase;
+            inf[0] = viol_k; inf[1] = nrows_built; inf[2] = tries; inf[3] = (!solved && (status & ST_COLL)) ? 0 : ccase;   // (`coll` return: no QP, no cost case)
             inf[4] = iters_total; inf[5] = nslack; inf[6] = solved ? q : 0; inf[7] = maxq;
 #ifdef DMPC_DEV_TRACE
             if (ph_on && Qp->dbg_cap >= 4) {

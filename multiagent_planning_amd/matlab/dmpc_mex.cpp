@@ -17,6 +17,8 @@
 //   [xi,rhs,dist,kc,viol_k,coll] = dmpc_mex('rows_one', params, l, n, po, vo)           CheckCollSoftDMPC + CollConstr*DMPC rows
 //   Ain            = dmpc_mex('rows_dense', params, xi, kc, A)                          -diff_mat*A of structured rows
 //   [pk,vk,ak,K_T_used,scene_status] = dmpc_mex('transition', params, po, pf, K_T_max, error_tol)   the whole k-loop on the GPU
+//   inbounds       = dmpc_mex('is_inbounds', params, p, pmin, pmax)                    is_inbounds.m
+//   pass           = dmpc_mex('reached_goal', params, p, pf, error_tol)                ReachedGoal.m
 //   [po,pf]        = dmpc_mex('random_test', params, N, pmin, pmax, rmin, c, seed)      randomTest.m
 //   [po,pf]        = dmpc_mex('random_exchange', params, N, pmin, pmax, rmin, seed)     randomExchange.m
 // `params` is a struct with the fields of dmpc_params (variant as the DMPC_VAR_* integer).
@@ -252,6 +254,22 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
                             with_init ? nullptr : po, with_init ? vo : nullptr, mxGetPr(prhs[7]), mxGetPr(plhs[0]), mxGetPr(v)))
             mexErrMsgIdAndTxt("dmpc:prop_state", "%s", dmpc_last_error(ctx));
         if (nlhs > 1) plhs[1] = v;
+        return;
+    }
+    if (!std::strcmp(cmd, "is_inbounds")) {   // is_inbounds.m:1-6: p is 3 x n (column-major = [n][3] points)
+        need(nrhs == 5 && mxGetM(prhs[2]) == 3 && mxGetNumberOfElements(prhs[3]) == 3 && mxGetNumberOfElements(prhs[4]) == 3, "is_inbounds: (cmd, params, p(3 x n), pmin, pmax)");
+        int32_t ok = 0;
+        if (dmpc_is_inbounds(ctx, (int)mxGetN(prhs[2]), mxGetPr(prhs[2]), mxGetPr(prhs[3]), mxGetPr(prhs[4]), &ok))
+            mexErrMsgIdAndTxt("dmpc:is_inbounds", "%s", dmpc_last_error(ctx));
+        plhs[0] = mxCreateDoubleScalar(ok ? 1.0 : 0.0);   // (a double 0/1: `if (...)` and `&&` in the scripts take it like the logical of the .m file)
+        return;
+    }
+    if (!std::strcmp(cmd, "reached_goal")) {   // ReachedGoal.m:1-11 on the positions of ONE time index: p, pf are 3 x N
+        need(nrhs == 5 && mxGetM(prhs[2]) == 3 && mxGetNumberOfElements(prhs[3]) == mxGetNumberOfElements(prhs[2]), "reached_goal: (cmd, params, p(3 x N), pf(3 x N), error_tol)");
+        int32_t ok = 0;
+        if (dmpc_reached_goal(ctx, (int)mxGetN(prhs[2]), mxGetPr(prhs[2]), mxGetPr(prhs[3]), mxGetScalar(prhs[4]), &ok))
+            mexErrMsgIdAndTxt("dmpc:reached_goal", "%s", dmpc_last_error(ctx));
+        plhs[0] = mxCreateDoubleScalar(ok ? 1.0 : 0.0);   // (a double 0/1: `if (...)` and `&&` in the scripts take it like the logical of the .m file)
         return;
     }
     if (!std::strcmp(cmd, "rows_one")) {   // CheckCollSoftDMPC.m + CollConstr*DMPC.m of the context's variant, structured rows

@@ -500,6 +500,11 @@ static scan_t scan_and_rows(const ctx_t *c, const orc_params *prm, int N, int n,
     const int soft_near = (var == ORC_BOUND || var == ORC_BOUND2 || var == ORC_ALL3 || var == ORC_ONDEMAND || cpp);
     const int coll_check = (var == ORC_BOUND || var == ORC_BOUND2 || var == ORC_ALL3 || var == ORC_REPAIR);
     const int skip_k1 = (var == ORC_BOUND2 || var == ORC_ALL3 || var == ORC_REPAIR || var == ORC_CPP2);
+    /* DMPC::solveQP (dmpc.cpp:626-637): the first k (0-based) with check_collisions (:378-396: any neighbour with dist < _rmin) gets
+     * rows for EVERY neighbour (build_collconstraint :450-498) on horizon step k-1 (`_A0.middleRows(3*(k-1),3)`, diff_row at 3*(k-1)).
+     * k = 0 would index row -3 there: the reference's behaviour is undefined (Eigen assertion / out-of-bounds read); restated as the
+     * `coll` outcome, no QP.  No first-step tolerance test, no near-neighbour selection. */
+    const int cpp1 = (var == ORC_CPP1);
     unsigned char *sel = (unsigned char *)malloc((size_t)N);
     for (int k = 1; k <= K; ++k) {
         int any = 0, cnt = 0;
@@ -525,6 +530,7 @@ static scan_t scan_and_rows(const ctx_t *c, const orc_params *prm, int N, int n,
             free(sel);
             return sc;
         }
+        if (cpp1 && k == 1) { sc.status = ORC_ST_COLL; sc.viol_k = 1; free(sel); return sc; }
         if (skip_k1 && k == 1) continue; /* solveSoftDMPCbound2.m:29-31 */
         sc.viol_k = k;
         sc.nv = cnt;
@@ -541,7 +547,7 @@ static scan_t scan_and_rows(const ctx_t *c, const orc_params *prm, int N, int n,
                     if (sel[j]) build_row(c, prm, l, n, j, ks[t], ks[t], x0, R);
         } else {
             sc.nblocks = 1;
-            int kc = (var == ORC_BOUND2 || var == ORC_CPP2) ? k - 1 : k; /* CollConstrSoftDMPC2.m:8; dmpc.cpp:516 k_ctr = k + _k_factor */
+            int kc = (var == ORC_BOUND2 || var == ORC_CPP2 || cpp1) ? k - 1 : k; /* CollConstrSoftDMPC2.m:8; dmpc.cpp:516 k_ctr = k + _k_factor; solveQP: 3*(k-1), dmpc.cpp:480-485 */
             for (int j = 0; j < N; ++j)
                 if (sel[j]) build_row(c, prm, l, n, j, k, kc, x0, R);
         }
@@ -575,6 +581,8 @@ static slackcfg_t slack_cfg(const orc_params *prm)
     case ORC_SOFTALL: s.has_slack = 1; s.coef_is_dist = 0; s.lb = -INFINITY; s.lin = -1e5; s.ub_as_row = 1; break; /* solveSoftDMPC.m:21,65 */
     case ORC_CPP: case ORC_CPP2: /* dmpc.cpp:907-914: eps <= 0, -eps <= lim with float lim = 0.01 (:1079); term = -1e6 via params */
         s.has_slack = 1; s.coef_is_dist = 1; s.lb = -(double)0.01f; s.lin = prm->term; break;
+    case ORC_CPP1: /* dmpc.cpp:629-633 [A_coll I; 0 I] x <= [b; 0]: coefficient 1, eps <= 0, no lower bound; f_w = -10^6 (:715), W = I (:719) */
+        s.has_slack = 1; s.coef_is_dist = 0; s.lb = -INFINITY; s.lin = -1e6; s.ub_as_row = 1; break;
     case ORC_REPAIR: s.has_slack = 1; s.coef_is_dist = 1; s.lb = -INFINITY; s.lin = prm->term; s.lin_over_dist = 1; break; /* repair:33,77,81 */
     default: break;
     }
@@ -747,7 +755,7 @@ static int solve_ctx(ctx_t *c, const orc_params *prm, int N, int n, const double
             info[ORC_I_NSLACK] = nsl;
             info[ORC_I_NACTIVE] = nact;
             status = ORC_ST_SOLVED;
-            const int ob_check = !(prm->variant == ORC_ELLIP || prm->variant == ORC_SOFTALL || cppv); /* solveQPv2 has no in-bounds test */
+            const int ob_check = !(prm->variant == ORC_ELLIP || prm->variant == ORC_SOFTALL || cppv || prm->variant == ORC_CPP1); /* solveQPv2 / solveQP have no in-bounds test */
             if (sc.coll_flag) status |= ORC_ST_COLL;
             if (ob_check && !in_bounds(p, prm->pmin, prm->pmax)) status |= ORC_ST_OUTBOUND; /* :125-128 */
             free(x); free(lam); qp_free(&qp);

@@ -34,7 +34,8 @@ enum {
     ORC_SOFTALL = 6,    /* solveSoftDMPC.m             */
     ORC_REPAIR = 7,     /* solveSoftDMPCrepair.m       */
     ORC_CPP = 8,        /* dmpc/cpp DMPC::solveQPv2, _k_factor = 0  (dmpc.cpp:803-1287) */
-    ORC_CPP2 = 9        /* dmpc/cpp DMPC::solveQPv2, _k_factor = -1                      */
+    ORC_CPP2 = 9,       /* dmpc/cpp DMPC::solveQPv2, _k_factor = -1                      */
+    ORC_CPP1 = 10       /* dmpc/cpp DMPC::solveQP (the first version: dmpc.cpp:554-801; rows for ALL N-1 neighbours, check_collisions :378-396, build_collconstraint :450-498) */
 };
 
 /* status bits returned per agent */

@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "libdmpc_oracle.so")
 
-VARIANTS = dict(bound=0, bound2=1, all3=2, hard=3, ondemand=4, ellip=5, softall=6, repair=7, cpp=8, cpp2=9)
+VARIANTS = dict(bound=0, bound2=1, all3=2, hard=3, ondemand=4, ellip=5, softall=6, repair=7, cpp=8, cpp2=9, cpp1=10)
 ST_SOLVED, ST_OUTBOUND, ST_COLL, ST_INFEAS = 1, 2, 4, 8
 INFO_LEN = 8
 I_VIOLK, I_NV, I_TRIES, I_CASE, I_ITERS, I_NSLACK, I_NACTIVE, I_NROWS = range(8)

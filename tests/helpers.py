@@ -6,7 +6,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden")
 
-ALL_VARIANTS = ["bound", "bound2", "all3", "hard", "ondemand", "ellip", "softall", "repair", "cpp", "cpp2"]
+ALL_VARIANTS = ["bound", "bound2", "all3", "hard", "ondemand", "ellip", "softall", "repair", "cpp", "cpp2", "cpp1"]
 
 
 def load_golden(name):

@@ -103,7 +103,7 @@ def test_c3_softall_sample_certified():
     _report("C3 softall N=1000 (sample)", ns, ni, w)
 
 
-@pytest.mark.parametrize("variant", ["ondemand", "ellip", "all3", "softall", "repair", "hard"])
+@pytest.mark.parametrize("variant", ["ondemand", "ellip", "all3", "softall", "repair", "hard", "cpp1"])
 @pytest.mark.parametrize("name", ["failure_rate2_bound", "comp_kctr_3_bound2"])
 def test_recorded_congested_scenes_certified(name, variant):
     g, kw = load_golden(name)
@@ -134,7 +134,7 @@ def test_campaign_slice():
         for variant in ALL_VARIANTS:
             d = mp.Dmpc(variant, **kw); prm = orc.make_params(variant, **kw)
             l = init_table(po, pf); xp, xv, xa = po.copy(), np.zeros_like(po), np.zeros_like(po)
-            tol = 5e-8 if variant in ("softall", "repair") else 1e-9 * max(1.0, abs(kw["term"]) / 5e4)
+            tol = 5e-8 if variant in ("softall", "repair", "cpp1") else 1e-9 * max(1.0, abs(kw["term"]) / 5e4)
             for k in range(int(rng.integers(2, 5))):
                 out = d.step_batch(l, xp, xv, xa, pf); ref = orc.step(prm, l, xp, xv, xa, pf, nthreads=8)
                 total += N
@@ -221,7 +221,7 @@ def test_randomized_campaign_time_boxed():
         for variant in ALL_VARIANTS:
             d = mp.Dmpc(variant, **kw); prm = orc.make_params(variant, **kw)
             l = init_table(po, pf); xp, xv, xa = po.copy(), np.zeros_like(po), np.zeros_like(po)
-            tol = 5e-8 if variant in ("softall", "repair") else 1e-9 * max(1.0, abs(kw["term"]) / 5e4)
+            tol = 5e-8 if variant in ("softall", "repair", "cpp1") else 1e-9 * max(1.0, abs(kw["term"]) / 5e4)
             for k in range(int(rng.integers(2, 7))):
                 out = d.step_batch(l, xp, xv, xa, pf); ref = orc.step(prm, l, xp, xv, xa, pf, nthreads=8)
                 total += N

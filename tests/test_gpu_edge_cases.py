@@ -75,7 +75,7 @@ def test_random_config_scenes_teacher_forced(cfg_name, N, steps):
     prm = orc.make_params(cfg["variant"], **kw)
     l = init_table(po, pf)
     xp, xv, xa = po.copy(), np.zeros_like(po), np.zeros_like(po)
-    tol = 2e-8 if cfg["variant"] in ("softall", "repair") else 1e-9
+    tol = 2e-8 if cfg["variant"] in ("softall", "repair", "cpp1") else 1e-9
     for k in range(steps):
         out = d.step_batch(l, xp, xv, xa, pf)
         ref = orc.step(prm, l, xp, xv, xa, pf)
@@ -137,4 +137,44 @@ def test_cpp_flavour_semantics():
     pf = np.array([[0.0, 0.0, 1.0], [0.0, 1.0, 1.0]])
     xv = np.array([[0.3, 0.0, 0.0], [0.0, 0.0, 0.0]])
     out = mp.Dmpc("cpp", **kwc).step_batch(init_table(po, pf), po, xv, z[:2], pf)
+    assert not (out["status"] & mp.ST_OUTBOUND).any()
+
+
+def test_cpp_first_version_semantics():
+    """DMPC::solveQP, the FIRST C++ version (dmpc/cpp/dmpc.cpp:554-801; callers solveDMPC :1367, cluster_solve :1776): rows for ALL N-1
+    neighbours at the first violating step k, on step k-1 (:480-485), every row with its own unbounded slack (:629-633), one solve,
+    no in-bounds flag.  A violation at k = 0 makes the reference index row -3 (undefined there): `coll`, no solve.  No output of this
+    code path is recorded in the reference (parity unpinned at the solver boundary): the checkers are the oracle's literal restatement
+    and, in tests/test_gpu_certificates.py, the KKT certificate."""
+    f32 = lambda x: float(np.float32(x))
+    kwc = dict(KW, h=f32(0.2), rmin=f32(0.35), c=f32(2.0), alim=f32(1.0), term=-1e6)
+    rm = kwc["rmin"]
+    z = np.zeros((3, 3))
+    # everybody predicted to stay put; agent 1 comes inside rmin of agent 0 from horizon step 3 (1-based) on, agent 2 stays 1.5 rmin away
+    po = np.array([[0.0, 0.0, 1.0], [0.9 * rm, 0.0, 1.0], [0.0, 1.5 * rm, 1.0]])
+    pf = po.copy()
+    l3 = np.tile(po[:, None, :], (1, 15, 1)); l3[1, :2, 0] = 1.2 * rm
+    l = l3.reshape(3, 45)
+    rows = mp.Dmpc("cpp1", **kwc).rows_one(l, 0, po[0], z[0])
+    ref = orc.rows_one(orc.make_params("cpp1", **kwc), l, 0, po[0], z[0])
+    assert rows["viol_k"] == 3 and len(rows["kc"]) == 2 == ref["nrows"]          # BOTH neighbours (solveQPv2 would take one)
+    assert (np.asarray(rows["kc"]) == 2).all()                                    # on horizon step k - 1 = 2 (1-based, as viol_k)
+    assert np.abs(np.asarray(ref["b"]) - np.asarray(rows["rhs"])).max() < 1e-12
+    out = mp.Dmpc("cpp1", **kwc).step_batch(l, po, z, z, pf)
+    refs = orc.step(orc.make_params("cpp1", **kwc), l, po, z, z, pf)
+    compare_to_oracle(out, refs, 2e-8, "cpp1")
+    assert (out["status"] == 1).all() and (out["info"][:, 2] == 1).all()           # one solve each
+    # violation at the very first horizon step: undefined in the reference (row -3 of A0) -> coll, no outputs
+    po = np.array([[0.0, 0.0, 1.0], [0.2, 0.0, 1.0], [2.0, 2.0, 1.0]])
+    pf = np.array([[1.0, 0.0, 1.0], [-1.0, 0.0, 1.0], [0.0, 0.0, 1.0]])
+    l = init_table(po, pf)
+    out = mp.Dmpc("cpp1", **kwc).step_batch(l, po, z, z, pf)
+    refs = orc.step(orc.make_params("cpp1", **kwc), l, po, z, z, pf)
+    compare_to_oracle(out, refs, 2e-8, "cpp1 first-step")
+    assert out["status"][0] == mp.ST_COLL and out["status"][1] == mp.ST_COLL and out["status"][2] == 1
+    # never outbound
+    po = np.array([[2.49, 0.0, 1.0], [-2.0, 0.0, 1.0]])
+    pf = np.array([[0.0, 0.0, 1.0], [0.0, 1.0, 1.0]])
+    xv = np.array([[0.3, 0.0, 0.0], [0.0, 0.0, 0.0]])
+    out = mp.Dmpc("cpp1", **kwc).step_batch(init_table(po, pf), po, xv, z[:2], pf)
     assert not (out["status"] & mp.ST_OUTBOUND).any()

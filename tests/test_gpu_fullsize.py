@@ -147,6 +147,37 @@ def test_c4_bound_10000_agents_sharded_in_8_chunks():
     _sample_vs_oracle("bound", kw, l[0], po[0], z[0], z[0], pf[0], o1, idx, 1e-9, "C4")
 
 
+def test_c4_closed_loop_steps_3_6_10_sampled_against_the_oracle():
+    """BASELINE configs[3] in the state the bench TIMES: the closed loop of the 10^4-agent scene at MPC steps 3, 6 and 10, where the
+    agents move (neighbour lists from the cell grid at full density, crash start of the acceleration bounds from the factor
+    tables, retry ladder, 56-slot first tier).  Every step: size-independent properties on all agents and, at steps 3, 6, 10, a sample of
+    48 agents against the oracle -- the agents with the most iterations, with ladder retries, with the most rows, and random ones --
+    on identical inputs (teacher forcing on the GPU's own states), 1e-9."""
+    cfg, N = wl.CONFIGS["C4"], 10000
+    kw = wl.solver_kwargs(cfg, N)
+    po, pf = wl.make_scenes(cfg, 1, N, wl.SEED0 + 4)
+    d = mp.Dmpc("bound", **kw)
+    l, _, _ = d.init_batch(po, pf)
+    xp, xv, xa = po.copy(), np.zeros_like(po), np.zeros_like(po)
+    rng = np.random.default_rng(13)
+    for step in range(2, 11):
+        out = d.step_batch(l, xp, xv, xa, pf)
+        _properties(out, l, xp, xv, kw, "bound", f"C4 step {step}")
+        if step in (3, 6, 10):
+            inf, st = out["info"][0], out["status"][0]
+            heavy = np.argsort(inf[:, 4])[-12:]
+            ladder = np.where(inf[:, 2] > 1)[0][:12]
+            rows = np.argsort(inf[:, 1])[-12:]
+            idx = np.unique(np.concatenate([heavy, ladder, rows, rng.integers(0, N, 12)]))
+            assert idx.size >= 30
+            o1 = {k: v[0] for k, v in out.items()}
+            _sample_vs_oracle("bound", kw, l[0], xp[0], xv[0], xa[0], pf[0], o1, idx, 1e-9, f"C4 step {step}")
+            assert (inf[:, 7] >= 40).any() and (inf[:, 2] > 1).any()            # the heavy paths did run
+        ok = (out["status"] == 1)[..., None]
+        l = np.where(ok, out["p"], l); xp = np.where(ok, out["p"][..., :3], xp)
+        xv = np.where(ok, out["v"][..., :3], xv); xa = np.where(ok, out["a"][..., :3], xa)
+
+
 @pytest.mark.parametrize("N,G", [(120, 3), (320, 4)])
 def test_hard_rows_in_chunked_layouts(N, G):
     """solveHardDMPC on the multi-rank layout lT[G][S][45][C]: the flat (step, neighbour) scan pass without a neighbour

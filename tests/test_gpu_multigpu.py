@@ -112,6 +112,23 @@ def test_group_context_transition_equals_single_gpu(emulated, G, variant, N, pre
     assert np.array_equal(out2["K_T_used"], ref["K_T_used"])
 
 
+@pytest.mark.parametrize("G,N", [(8, 4), (8, 7), (4, 6)])
+def test_group_context_with_fewer_agents_than_gpus(emulated, G, N):
+    """the reference's small swarms (N = 4 .. 7) on a multi-GPU node: a DMPC_DEVICE_ALL context -- what the MEX gateway creates -- must
+    run them (on its first GPU) instead of refusing to shard 4 agents over 8 GPUs; transition and single step alike"""
+    cfg, kw, po, pf = _scenes(N, 3, wl.SEED0 + 45)
+    ref = mp.Dmpc("bound", **kw).transition(po, pf, 100, cfg["error_tol"])
+    emulated(G)
+    d = mp.Dmpc("bound", device=mp.Dmpc.DEVICE_ALL, **kw)
+    assert d.n_devices == G
+    out = d.transition(po, pf, 100, cfg["error_tol"])
+    for k in ("pk", "vk", "ak", "K_T_used", "scene_status"):
+        assert np.array_equal(out[k], ref[k]), k
+    l, _, _ = d.init_batch(po, pf)
+    z = np.zeros_like(po)
+    assert np.array_equal(d.step_batch(l, po, z, z, pf)["p"], mp.Dmpc("bound", **kw).step_batch(l, po, z, z, pf)["p"])
+
+
 @pytest.mark.parametrize("G,variant,N", [(2, "hard", 100), (3, "softall", 37), (5, "bound", 301)])
 def test_group_context_step_batch_equals_single_gpu(emulated, G, variant, N):
     cfg, kw, po, pf = _scenes(N, 3, wl.SEED0 + 43, "C2" if variant == "hard" else "C4")

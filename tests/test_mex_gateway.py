@@ -70,6 +70,16 @@ def test_gateway_commands_match_the_c_abi():
     ok = int(np.where(out["status"] == 1)[0][0])
     pp, vv = mh.call("prop_state", prm, [Lam, Av, A0, xp[ok], xv[ok], out["a"][ok]], nlhs=2)
     assert np.abs(pp.ravel() - out["p"][ok]).max() < 1e-12 and np.abs(vv.ravel() - out["v"][ok]).max() < 1e-12
+    # is_inbounds.m / ReachedGoal.m (what the .m shims of the same names call)
+    pts = out["p"][ok].reshape(15, 3)
+    ib, = mh.call("is_inbounds", prm, [pts.T, np.array(kw["pmin"]), np.array(kw["pmax"])])
+    assert bool(ib.ravel()[0]) == bool(d.is_inbounds(pts, kw["pmin"], kw["pmax"]))
+    ib2, = mh.call("is_inbounds", prm, [(pts + 100.0).T, np.array(kw["pmin"]), np.array(kw["pmax"])])
+    assert not bool(ib2.ravel()[0])
+    rg, = mh.call("reached_goal", prm, [xp.T, pf.T, 0.05])
+    assert bool(rg.ravel()[0]) == bool(d.reached_goal(xp, pf, 0.05))
+    rg2, = mh.call("reached_goal", prm, [pf.T, pf.T, 0.05])
+    assert bool(rg2.ravel()[0])
     # generators and a whole transition (C1: the 4-agent swap of dmpc_soft_bound.m)
     from multiagent_planning_amd import workload as wl
     c1 = wl.CONFIGS["C1"]

@@ -18,5 +18,17 @@ for p in ("fetch", "write", "sq", "sq2", "sq3"):
     rows = list(csv.DictReader(open(fn)))
     with open(f"{dst}/{prefix}_pmc_{p}_counter_collection.csv", "w", newline="") as f:
         w = csv.DictWriter(f, fieldnames=rows[0].keys()); w.writeheader(); w.writerows(r for r in rows if keep(r["Kernel_Name"]))
-shutil.copy(f"{src}/summary.json", f"{dst}/{prefix}_pmc_summary.json")
+import json, subprocess
+summ = json.load(open(f"{src}/summary.json"))
+try:   # the commit the passes were taken at (this script runs where the repository is; the GPU box has no .git)
+    summ["git_commit"] = subprocess.run(["git", "rev-parse", "HEAD"], capture_output=True, text=True, cwd=dst).stdout.strip()
+    summ["git_dirty"] = bool(subprocess.run(["git", "status", "--porcelain", "--", "multiagent_planning_amd/csrc"], capture_output=True, text=True, cwd=os.path.dirname(dst)).stdout.strip())
+except Exception:
+    pass
+json.dump(summ, open(f"{dst}/{prefix}_pmc_summary.json", "w"), indent=1)
+fn = f"{src}/calib/calib_counter_collection.csv"
+if os.path.exists(fn):
+    rows = list(csv.DictReader(open(fn)))
+    with open(f"{dst}/{prefix}_pmc_calib_counter_collection.csv", "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=rows[0].keys()); w.writeheader(); w.writerows(r for r in rows if "read_probe" in r["Kernel_Name"])
 print("collected", src, "->", prefix)

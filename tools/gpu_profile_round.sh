@@ -15,9 +15,9 @@ OUT=$REPO/gpurun_out/$LABEL
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 case $WL in
-  headline) BENCH="python $REPO/bench.py --no-cpu-baseline --no-secondary"; SPL=51200; KERN="solve_persist_kernel<false, 48";;
-  bound)    BENCH="python $REPO/tools/replay_workload.py bound"; SPL=51200; KERN="solve_persist_kernel<true, 48>";;
-  c4)       BENCH="python $REPO/tools/replay_workload.py c4"; SPL=10000; KERN="dmpc_solve_";;
+  headline) BENCH="python $REPO/bench.py --no-cpu-baseline --no-secondary"; SPL=51200; KERN="solve_persist_kernel<false, 48"; WPS=3;;
+  bound)    BENCH="python $REPO/tools/replay_workload.py bound"; SPL=51200; KERN="solve_persist_kernel<true, 48"; WPS=2;;
+  c4)       BENCH="python $REPO/tools/replay_workload.py c4"; SPL=10000; KERN="dmpc_solve_"; WPS=1.25;;
 esac
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o kt -- $BENCH --steps 30 --warmup 3 > "$OUT/kt.log" 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o fetch -- $BENCH --steps 5 --warmup 1 > "$OUT/fetch.log" 2>&1
@@ -28,13 +28,14 @@ timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_
     --output-format csv -d "$OUT/sq2" -o sq2 -- $BENCH --steps 5 --warmup 1 > "$OUT/sq2.log" 2>&1
 timeout 300 rocprofv3 --pmc SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_SALU SQ_LDS_BANK_CONFLICT \
     --output-format csv -d "$OUT/sq3" -o sq3 -- $BENCH --steps 5 --warmup 1 > "$OUT/sq3.log" 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/calib" -o calib -- python $REPO/tools/gpu_fetch_calib.py > "$OUT/calib.log" 2>&1
 cd "$REPO"
 find "$OUT" -name "*.db" -delete   # keep the csv summaries only (size)
-python3 tools/profile_summary.py "$OUT" $SPL "$KERN" > "$OUT/summary.json"
+python3 tools/profile_summary.py "$OUT" $SPL "$KERN" $WPS > "$OUT/summary.json"
 tail -1 "$OUT/kt.log" | cut -c1-300
 python3 - <<PY
 import json
 d = json.load(open("$OUT/summary.json"))
-print({k: d.get(k) for k in ("solve_kernel", "instructions_per_solve", "fp64", "issue")})
+print({k: d.get(k) for k in ("solve_kernel", "source_hash", "instructions_per_solve", "fp64", "wave_time", "traffic_calibration")})
 print(d.get("kernel_stats"))
 PY
