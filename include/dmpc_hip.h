@@ -107,11 +107,17 @@ typedef struct dmpc_ctx dmpc_ctx;
 /* arithmetic of a context */
 enum {
     DMPC_PREC_F64 = 0,   /* everything fp64 (the reference is MATLAB double)                                          */
-    DMPC_PREC_MIXED = 1  /* the prediction table is kept in fp32 and the scan + collision rows (a5/a6) are computed in
+    DMPC_PREC_MIXED = 1, /* the prediction table is kept in fp32 and the scan + collision rows (a5/a6) are computed in
                           * fp32; the QP itself (cost, factor, multipliers, propagation) and all inputs / outputs stay
                           * fp64.  Every entry point takes such a context: the host-pointer ones, the device-pointer steps (they
                           * make the fp32 copy of the caller's fp64 table themselves) and the sharded transitions, where the table
                           * the ranks exchange per step is the fp32 one (half the payload).  BASELINE configs[4].               */
+    DMPC_PREC_F32FACTOR = 2, /* the QP below fp64 (BASELINE configs[4], "fp32 vs fp64 tolerance sweep"): the inverse factor of the
+                          * active-set solver -- its largest object, what every iteration multiplies with -- is STORED in fp32; cost,
+                          * multipliers, residuals and the refinement of the result stay fp64 (lambda += T T' rho until the active-set
+                          * residual is at 1e-13 or stops contracting).  Scan and rows fp64.  Not bit-compatible with DMPC_PREC_F64:
+                          * the sweep (tests/test_gpu_precision.py) reports status agreement and l_inf per variant. */
+    DMPC_PREC_LOW = 3    /* DMPC_PREC_MIXED | DMPC_PREC_F32FACTOR: fp32 table / scan / rows AND fp32 factor                      */
 };
 
 /* Create a solver context.  Replaces the constants/precompute preamble of dmpc/matlab/dmpc_soft_bound.m:80-108 and the DMPC ctor

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libdmpc_hip.so")
 
 VARIANTS = dict(bound=0, bound2=1, all3=2, hard=3, ondemand=4, ellip=5, softall=6, repair=7, cpp=8, cpp2=9, cpp1=10)
 ST_SOLVED, ST_OUTBOUND, ST_COLL, ST_INFEAS, ST_CAPACITY, ST_ITERCAP = 1, 2, 4, 8, 16, 32
-PRECISIONS = dict(f64=0, mixed=1)
+PRECISIONS = dict(f64=0, mixed=1, f32factor=2, low=3)
 ST_REACHED = 256   # scene_status of transition(): every agent reached its goal
 INFO_LEN = 8
 I_VIOLK, I_NROWS, I_TRIES, I_CASE, I_ITERS, I_NSLACK, I_NACTIVE, I_MAXQ = range(8)
@@ -187,7 +187,8 @@ class Dmpc:
     """One solver context on one HIP device (wraps dmpc_create/dmpc_destroy)."""
 
     def __init__(self, variant="bound", device=0, precision="f64", **kw):
-        """precision: "f64" (DMPC_PREC_F64) or "mixed" (DMPC_PREC_MIXED: fp32 table / scan / rows, fp64 QP);
+        """precision: "f64" (DMPC_PREC_F64), "mixed" (DMPC_PREC_MIXED: fp32 table / scan / rows, fp64 QP), "f32factor" (DMPC_PREC_F32FACTOR: the solver's
+        inverse factor stored in fp32, refined against fp64 residuals) or "low" (both);
         device: a HIP device index, DEVICE_ALL (-100: every visible GPU from this process, agents sharded over them) or
         DEVICE_CURRENT (-1: the calling thread's current device)"""
         self._L = load()

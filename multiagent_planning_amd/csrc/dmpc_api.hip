@@ -119,6 +119,7 @@ struct dmpc_ctx {
     int no_split_t = 0;      // development option no_split_t: slack-free persistent solve with the whole inverse factor in every wave's block (nine waves per CU; A/B runs, tests)
     int nbr_grid = 1;        // development option nbr_grid: 0 = neighbour lists of large scenes from the all-pairs box test of round 3 (nbr_kernel) instead of the cell grid + distance filter
     DevBuf grid;             // cell grid of the neighbour lists (counts, starts, entries)
+    int f32_dep_exp = 8;     // development option f32_dep_exp: fp32-factor kernels treat a pivot as dependent below delta / s_pp = 10^-n
     int ext_cap = 0;         // development option ext_cap (tests): at most this many T extensions per workgroup (1: every agent that needs one waits for the same slot)
     int static_queue = 0;    // development option static_queue: persistent waves take queue positions round-robin instead of by ticket
     DevBuf pc_p, pc_v, pc_a, pc_M, pc_w, pc_scene, pc_agent, pc_interp;   // post-check work buffers
@@ -391,7 +392,7 @@ extern "C" int dmpc_debug_option(dmpc_ctx *ctx, const char *name, int value)
         {"no_fuse", &dmpc_ctx::no_fuse}, {"no_persist", &dmpc_ctx::no_persist}, {"force_persist", &dmpc_ctx::force_persist}, {"no_cull", &dmpc_ctx::no_cull}, {"order_slices", &dmpc_ctx::order_slices}, {"cull_min", &dmpc_ctx::cull_min},
         {"no_lpt", &dmpc_ctx::no_lpt}, {"crash_min", &dmpc_ctx::crash_min}, {"crash_any", &dmpc_ctx::crash_any}, {"no_fast_exit", &dmpc_ctx::no_fast_exit}, {"pivot_explore", &dmpc_ctx::pivot_explore},
         {"iter_cap", &dmpc_ctx::iter_cap}, {"tier1_qcap", &dmpc_ctx::tier1_env}, {"split_parts", &dmpc_ctx::split_parts}, {"no_split", &dmpc_ctx::no_split},
-        {"static_queue", &dmpc_ctx::static_queue}, {"no_split_t", &dmpc_ctx::no_split_t}, {"ext_cap", &dmpc_ctx::ext_cap}, {"nbr_grid", &dmpc_ctx::nbr_grid}};
+        {"static_queue", &dmpc_ctx::static_queue}, {"no_split_t", &dmpc_ctx::no_split_t}, {"ext_cap", &dmpc_ctx::ext_cap}, {"nbr_grid", &dmpc_ctx::nbr_grid}, {"f32_dep_exp", &dmpc_ctx::f32_dep_exp}};
     for (auto &t : tab)
         if (!std::strcmp(t.n, name)) {
             ctx->*(t.f) = value;
@@ -440,7 +441,7 @@ extern "C" dmpc_ctx *dmpc_create(const dmpc_params *prm, int device, int precisi
 {
     std::string why;
     if (check_params(prm, why)) { g_err = "dmpc_create: " + why; return nullptr; }
-    if (precision != DMPC_PREC_F64 && precision != DMPC_PREC_MIXED) { g_err = "dmpc_create: precision must be DMPC_PREC_F64 or DMPC_PREC_MIXED"; return nullptr; }
+    if (precision < DMPC_PREC_F64 || precision > DMPC_PREC_LOW) { g_err = "dmpc_create: precision must be DMPC_PREC_F64, _MIXED, _F32FACTOR or _LOW"; return nullptr; }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0) {
@@ -654,6 +655,7 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     }
     P.dbg = ctx->dbg; P.dbg_agent = ctx->dbg_agent; P.dbg_cap = ctx->dbg_cap;
     P.iter_cap = ctx->iter_cap;
+    P.dep_tol_f32 = std::pow(10.0, -(double)ctx->f32_dep_exp);
     // (not for solveHardDMPC: rows at every horizon step, 3 % of the agents would qualify and every scan would pay for the test)
     P.fast_exit = (ctx->no_fast_exit || p.variant == DMPC_VAR_HARD) ? 0 : 1;
     // measured: the crash start pays for the slack-carrying variants (C4, N = 10^4: solve launch -16 %) and costs on solveHardDMPC
@@ -667,7 +669,8 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     const long ncu = ctx->num_cu > 0 ? ctx->num_cu : 256;
     const bool tiny = (long)S * c_count < 8L * ncu && !ctx->force_persist && !ctx->tier1_env;
     const bool shallow = (long)S * c_count < 16L * ncu * 8 && !ctx->force_persist && !ctx->tier1_env;
-    const int q1 = (ctx->single_tier || tiny) ? full_qcap(p.variant) : tier1_qcap(ctx, p.variant, G * C), q2 = full_qcap(p.variant);
+    const bool f32t = (ctx->precision & DMPC_PREC_F32FACTOR) != 0;   // fp32 inverse factor: one tier with the full capacity, no split T
+    const int q1 = (ctx->single_tier || tiny || f32t) ? full_qcap(p.variant) : tier1_qcap(ctx, p.variant, G * C), q2 = full_qcap(p.variant);
     const bool two_tier = q1 < q2;
     ctx->post_fused = 0;
     if (post && tiny && !two_tier && g_local == 0 && G == 1 && !ctx->no_fuse) {
@@ -686,7 +689,7 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     P.scene_done = scene_done;
     P.short_from = short_from;   // unequal clusters: chunks from here on hold C-1 agents (dmpc_multigpu.hip)
     const size_t lds0 = scan_lds_bytes();
-    const size_t lds1 = solve_lds_bytes(P.nrmax, soft, q1, false), lds2 = solve_lds_bytes(P.nrmax, soft, q2, false);
+    const size_t lds1 = solve_lds_bytes(P.nrmax, soft, q1, false, 0, f32t), lds2 = solve_lds_bytes(P.nrmax, soft, q2, false, 0, f32t);
     const size_t ldsmax = lds2 > lds1 ? lds2 : lds1;
     if ((int)ldsmax > ctx->max_lds_set) {
         HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_kernel<true, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsmax));
@@ -694,6 +697,8 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
         HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_kernel<true, 56>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsmax));
         HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_kernel<true, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsmax));
         HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_kernel<false, 48>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsmax));
+        HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_kernel<true, 64, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsmax));
+        HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_kernel<false, 48, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsmax));
         ctx->max_lds_set = (int)ldsmax;
     }
     dmpc_ctx::Ev ev{nullptr, nullptr, nullptr};
@@ -812,15 +817,15 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     // Slack-free variants (round 4): split T -- HARD_TS columns of the inverse factor in every wave's block, the rest of the 48 in
     // extensions that the waves of a workgroup take from a pool when an agent's working set outgrows them (dmpc_solve.hip) -- so that
     // twelve waves (three per SIMD: what 168 registers per lane allow) share a CU's LDS instead of nine.
-    const int tsplit = (!soft && !ctx->no_split_t) ? HARD_TS : 0;
+    const int tsplit = (!soft && !ctx->no_split_t && !f32t) ? HARD_TS : 0;
     int n_ext = 0;
     auto persist_waves = [&](int qcap, size_t &per) -> int {
-        per = solve_lds_bytes(P.nrmax, soft, qcap, true, tsplit);
+        per = solve_lds_bytes(P.nrmax, soft, qcap, true, tsplit, f32t);
         int pw = (int)((LDS_CU - PERSIST_TABLE_BYTES) / per);
 #ifdef DMPC_DEV_PW   // development builds: fewer persistent waves per CU (how much does a long agent lose to the wave it shares a SIMD with?)
         if (pw > DMPC_DEV_PW) pw = DMPC_DEV_PW;
 #endif
-        const int cap = soft ? 8 : (tsplit ? HARD_PW : 9);   // waves per workgroup the kernels are compiled for (launch bounds)
+        const int cap = soft ? 8 : ((tsplit || f32t) ? HARD_PW : 9);   // waves per workgroup the kernels are compiled for (launch bounds)
         pw = pw > cap ? cap : pw;
         if (tsplit) {   // the extensions need room too: at least a third as many as waves (3 % of the headline launch's agents need one, for 15 % of its iterations)
             const size_t eb = (size_t)ext_doubles(qcap, tsplit) * 8;
@@ -835,14 +840,16 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     };
     // the working-set capacity is a template parameter of the solve kernels
     auto launch_plain = [&](int qcap, size_t lds) {
-        if (soft && qcap == 32) hipLaunchKernelGGL((dmpc_solve_kernel<true, 32>), grid, block, lds, st, P);
+        if (f32t) { if (soft) hipLaunchKernelGGL((dmpc_solve_kernel<true, 64, float>), grid, block, lds, st, P); else hipLaunchKernelGGL((dmpc_solve_kernel<false, 48, float>), grid, block, lds, st, P); }
+        else if (soft && qcap == 32) hipLaunchKernelGGL((dmpc_solve_kernel<true, 32>), grid, block, lds, st, P);
         else if (soft && qcap == 48) hipLaunchKernelGGL((dmpc_solve_kernel<true, 48>), grid, block, lds, st, P);
         else if (soft && qcap == 56) hipLaunchKernelGGL((dmpc_solve_kernel<true, 56>), grid, block, lds, st, P);
         else if (soft) hipLaunchKernelGGL((dmpc_solve_kernel<true, 64>), grid, block, lds, st, P);
         else hipLaunchKernelGGL((dmpc_solve_kernel<false, 48>), grid, block, lds, st, P);
     };
     auto launch_persist = [&](int qcap, dim3 g, dim3 b, size_t lds) {
-        if (soft && qcap == 32) hipLaunchKernelGGL((dmpc_solve_persist_kernel<true, 32>), g, b, lds, st, P);
+        if (f32t) { if (soft) hipLaunchKernelGGL((dmpc_solve_persist_kernel<true, 64, 64, float>), g, b, lds, st, P); else hipLaunchKernelGGL((dmpc_solve_persist_kernel<false, 48, 48, float>), g, b, lds, st, P); }
+        else if (soft && qcap == 32) hipLaunchKernelGGL((dmpc_solve_persist_kernel<true, 32>), g, b, lds, st, P);
         else if (soft && qcap == 48) hipLaunchKernelGGL((dmpc_solve_persist_kernel<true, 48>), g, b, lds, st, P);
         else if (soft && qcap == 56) hipLaunchKernelGGL((dmpc_solve_persist_kernel<true, 56>), g, b, lds, st, P);
         else if (soft) hipLaunchKernelGGL((dmpc_solve_persist_kernel<true, 64>), g, b, lds, st, P);
@@ -866,6 +873,8 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
             HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_persist_kernel<true, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_persist_kernel<false, 48>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_persist_kernel<false, 48, HARD_TS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_persist_kernel<true, 64, 64, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_persist_kernel<false, 48, 48, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             ctx->max_lds_persist = (int)lds;
         }
         P.counter = ctx->static_queue ? nullptr : ctx->counter.as<int>() + tier;
@@ -1013,7 +1022,7 @@ extern "C" int dmpc_step_device(dmpc_ctx *ctx, int S, int G, int C, int g_local,
     if (ctx->grp) FAIL(ctx, "dmpc_step_device: device pointers belong to ONE GPU; a DMPC_DEVICE_ALL context drives several (use the host-pointer entry points)");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     // mixed precision: the caller's table stays fp64; the scan reads an fp32 copy made here (half the bytes of the O(N) part)
-    const bool mixed = ctx->precision == DMPC_PREC_MIXED;
+    const bool mixed = (ctx->precision & DMPC_PREC_MIXED) != 0;
     if (mixed && table_f32(ctx, lT, ctx->lTf, (size_t)G * S * N3 * C, (hipStream_t)stream)) return -1;
     return launch_step(ctx, S, G, C, g_local, 0, C, lT, x_p, x_v, x_a, pf, p_out, v_out, a_out, lT_next, status, info,
                        (hipStream_t)stream, nullptr, 0, mixed ? ctx->lTf.as<float>() : nullptr);
@@ -1092,7 +1101,7 @@ extern "C" int dmpc_step_batch(dmpc_ctx *ctx, int S, int N, const double *l, con
     HIPCHK(ctx, hipMemcpyAsync(ctx->xa.p, x_a, A * 24, hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipMemcpyAsync(ctx->pf.p, pf, A * 24, hipMemcpyHostToDevice, st));
     if (dmpc_table_from_rows_device(ctx, S, 1, N, ctx->rows.as<double>(), ctx->lT.as<double>(), st)) return -1;
-    const bool mixed = ctx->precision == DMPC_PREC_MIXED;
+    const bool mixed = (ctx->precision & DMPC_PREC_MIXED) != 0;
     if (mixed && table_f32(ctx, ctx->lT.as<double>(), ctx->lTf, A * N3, st)) return -1;
     if (launch_step(ctx, S, 1, N, 0, 0, N, ctx->lT.as<double>(), ctx->xp.as<double>(), ctx->xv.as<double>(),
                     ctx->xa.as<double>(), ctx->pf.as<double>(), ctx->pout.as<double>(), ctx->vout.as<double>(),
@@ -1124,7 +1133,7 @@ extern "C" int dmpc_solve_one(dmpc_ctx *ctx, int N, int n, const double *l, cons
     HIPCHK(ctx, hipMemcpyAsync(ctx->xa.p, ao, 24, hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipMemcpyAsync(ctx->pf.p, pf, 24, hipMemcpyHostToDevice, st));
     if (dmpc_table_from_rows_device(ctx, 1, 1, N, ctx->rows.as<double>(), ctx->lT.as<double>(), st)) return -1;
-    const bool mixed = ctx->precision == DMPC_PREC_MIXED;
+    const bool mixed = (ctx->precision & DMPC_PREC_MIXED) != 0;
     if (mixed && table_f32(ctx, ctx->lT.as<double>(), ctx->lTf, (size_t)N * N3, st)) return -1;
     if (launch_step(ctx, 1, 1, N, 0, n, 1, ctx->lT.as<double>(), ctx->xp.as<double>(), ctx->xv.as<double>(),
                     ctx->xa.as<double>(), ctx->pf.as<double>(), ctx->pout.as<double>(), ctx->vout.as<double>(),
@@ -1269,7 +1278,7 @@ static int transition_one(dmpc_ctx *ctx, int S, int N, const double *po, const d
                        (const int *)ctx->status.as<int32_t>(), ctx->flags.as<int>(), ctx->scene_done.as<int>());
     double *cur = ctx->lT.as<double>(), *nxt = ctx->lT2.as<double>();
     ctx->post_acc_S = 0;   // the scene accumulators of the fused post-step start from zero in every transition
-    const bool mixed = ctx->precision == DMPC_PREC_MIXED;   // the scan of every step reads an fp32 copy of the current table
+    const bool mixed = (ctx->precision & DMPC_PREC_MIXED) != 0;   // the scan of every step reads an fp32 copy of the current table
     // The host looks at the per-step verdicts every `chunk` MPC steps -- one window BEHIND the steps it enqueues: the verdicts of window c
     // are copied to pinned host memory behind an event, the steps of window c+1 are enqueued, and only then the host waits for the event
     // of window c.  The device never idles while the host reads flags (a stream synchronisation per window cost 40-45 us of idle GPU per
@@ -1348,10 +1357,10 @@ static int transition_one(dmpc_ctx *ctx, int S, int N, const double *po, const d
 static void copy_debug_options(dmpc_ctx *dst, const dmpc_ctx *src)
 {
     static const char *names[] = {"no_fuse", "no_persist", "force_persist", "no_cull", "order_slices", "cull_min", "no_lpt", "crash_min", "crash_any", "no_fast_exit",
-                                  "pivot_explore", "iter_cap", "tier1_qcap", "static_queue", "no_split_t", "ext_cap", "nbr_grid"};
+                                  "pivot_explore", "iter_cap", "tier1_qcap", "static_queue", "no_split_t", "ext_cap", "nbr_grid", "f32_dep_exp"};
     int dmpc_ctx::*fields[] = {&dmpc_ctx::no_fuse, &dmpc_ctx::no_persist, &dmpc_ctx::force_persist, &dmpc_ctx::no_cull, &dmpc_ctx::order_slices, &dmpc_ctx::cull_min,
                                &dmpc_ctx::no_lpt, &dmpc_ctx::crash_min, &dmpc_ctx::crash_any, &dmpc_ctx::no_fast_exit, &dmpc_ctx::pivot_explore, &dmpc_ctx::iter_cap,
-                               &dmpc_ctx::tier1_env, &dmpc_ctx::static_queue, &dmpc_ctx::no_split_t, &dmpc_ctx::ext_cap, &dmpc_ctx::nbr_grid};
+                               &dmpc_ctx::tier1_env, &dmpc_ctx::static_queue, &dmpc_ctx::no_split_t, &dmpc_ctx::ext_cap, &dmpc_ctx::nbr_grid, &dmpc_ctx::f32_dep_exp};
     for (size_t i = 0; i < sizeof(names) / sizeof(names[0]); ++i) (void)dmpc_debug_option(dst, names[i], src->*(fields[i]));
 }
 

@@ -77,6 +77,7 @@ struct StepParams {
     int pivot_explore;      // development builds (DMPC_PIVOT_EXPLORE): extra pivot-weight multipliers, see dmpc_solve.hip
     int fast_exit;          // scan: finish the agents whose unconstrained minimiser is feasible (they never enter the solve queue)
     const int *live_bound;  // persistent solve kernel: queue positions from *live_bound on hold agents the scan finished (order_kernel), or null
+    double dep_tol_f32;     // fp32-factor kernels: dependence threshold on delta / s_pp (development option f32_dep_exp: 10^-n)
     int n_ext;              // persistent solve kernel with a split T: extensions in the workgroup's pool (behind the waves' blocks)
     int iter_cap;           // active-set iteration cap per try (ITER_CAP; development runs lower it to measure the per-iteration cost)
 };
@@ -105,9 +106,9 @@ inline size_t scan_lds_bytes() { return (96 * 8 + (size_t)SCAN_CAND_CAP * 4 + 15
 // bytes of LDS of one solve wave (layout: SolveLds in dmpc_solve.hip; `persist`: the tables are shared by the workgroup)
 // `tsplit` (persistent slack-free kernels, round 4): the wave's own block holds the first tsplit columns of T only; an agent whose
 // working set outgrows them takes one of the workgroup's EXTENSIONS (columns tsplit .. qcap-1, ext_doubles) from a small pool
-inline size_t solve_lds_bytes(int nrmax, bool soft, int qcap, bool persist, int tsplit = 0)
+inline size_t solve_lds_bytes(int nrmax, bool soft, int qcap, bool persist, int tsplit = 0, bool f32_factor = false)
 {
-    size_t dbl = (size_t)t_doubles(tsplit > 0 ? tsplit : qcap) + 2 * 48 + 2 * 64 + (soft ? 2 * 48 : 48) + 5 * (size_t)qcap + (soft ? (size_t)qcap : 0) + (size_t)qcap / 2;
+    size_t dbl = (f32_factor ? ((size_t)t_doubles(qcap) + 1) / 2 : (size_t)t_doubles(tsplit > 0 ? tsplit : qcap)) + 2 * 48 + 2 * 64 + (soft ? 2 * 48 : 48) + 5 * (size_t)qcap + (soft ? (size_t)qcap : 0) + (size_t)qcap / 2;
     if (!persist) dbl += TAB_CASE_DOUBLES + TAB_L_DOUBLES + 1;
     if (soft) dbl += (size_t)nrmax;                 // r_eps
     const size_t bytes = dbl * 8 + (soft ? (size_t)nrmax : (((size_t)nrmax + 31) / 32) * 4);   // + row flags (soft: a byte per row; slack-free: a bit)

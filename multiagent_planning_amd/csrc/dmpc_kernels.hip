@@ -881,11 +881,11 @@ __global__ __launch_bounds__(64 * SCAN_WAVES_PER_WG, SCAN_WAVES_PER_SIMD) void d
     scan_body<SOFT, TT, FAST>(P, lane, agent, dmpc_smem + (size_t)wave * P.lds_per_wave);
 }
 // Solve phase, one agent per 64-thread workgroup (shallow launches: bound by their slowest agent)
-template <bool SOFT, int QCAP>
+template <bool SOFT, int QCAP, typename TF = double>
 __global__ __launch_bounds__(64, SOLVE_WAVES_PER_SIMD) void dmpc_solve_kernel(StepParams P)
 {
     int tk_unused = 0; bool cl_unused = false;
-    solve_body<SOFT, QCAP, false>(P, threadIdx.x, blockIdx.x, gridDim.x, dmpc_smem, nullptr, false, tk_unused, cl_unused);
+    solve_body<SOFT, QCAP, false, QCAP, TF>(P, threadIdx.x, blockIdx.x, gridDim.x, dmpc_smem, nullptr, false, tk_unused, cl_unused);
 }
 
 // Persistent form of the solve phase: one workgroup of up to 8 independent waves per CU (two per SIMD).  The Gram tables of the three
@@ -897,7 +897,7 @@ __global__ __launch_bounds__(64, SOLVE_WAVES_PER_SIMD) void dmpc_solve_kernel(St
 // and 168 registers per lane hold the kernel without spills; the slack variants need 17 KB of LDS and 230 registers per wave: 8)
 // (round 4, slack-free variants: TWELVE waves per workgroup -- three per SIMD, what 168 registers per lane allow -- with the split T of
 // dmpc_solve.hip: TS columns of the factor per wave and a pool of P.n_ext extensions behind the waves' blocks)
-template <bool SOFT, int QCAP, int TS = QCAP>
+template <bool SOFT, int QCAP, int TS = QCAP, typename TF = double>
 __global__ __launch_bounds__(SOFT ? 512 : DMPC_HARD_PW * 64, 1) void dmpc_solve_persist_kernel(StepParams P)
 {
     // tier 2 works through the list of agents tier 1 flagged (P.order points at it); usually it is empty
@@ -967,7 +967,7 @@ __global__ __launch_bounds__(SOFT ? 512 : DMPC_HARD_PW * 64, 1) void dmpc_solve_
         int ln = lane;
         asm volatile("" : "+v"(ln));
         const int agent = resolve(pos);
-        solve_body<SOFT, QCAP, true, TS>(P, ln, agent, total, mine, shtab, want, tkv, claimed,
+        solve_body<SOFT, QCAP, true, TS, TF>(P, ln, agent, total, mine, shtab, want, tkv, claimed,
                                          (int)(((blockDim.x >> 6) - wave) * (P.lds_per_wave >> 3)));
         if (want && !claimed && lane == 0) tkv = atomicAdd(P.counter, 1);   // (the quick ways out of the solver: stopped scene, agent finished by the scan)
         LSYNC();

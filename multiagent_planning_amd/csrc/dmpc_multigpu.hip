@@ -254,7 +254,7 @@ extern "C" int dmpc_step_sharded_device(dmpc_ctx *ctx, int S, int N, const doubl
     if (ctx->sendbuf.ensure(chunk * 8)) FAIL(ctx, "device allocation failed (exchange buffer)");
     const int rem = N % G;
     // mixed precision: the caller's tables are fp64 (and so is the payload of this entry point); the scan reads an fp32 copy
-    const bool mixed = ctx->precision == DMPC_PREC_MIXED;
+    const bool mixed = (ctx->precision & DMPC_PREC_MIXED) != 0;
     if (mixed && table_f32(ctx, lT, ctx->lTf, (size_t)G * chunk, st)) return -1;
     if (launch_step(ctx, S, G, cmax, rank, 0, cnt, lT, x_p, x_v, x_a, pf, p_out, v_out, a_out, ctx->sendbuf.as<double>(), status, info, st,
                     nullptr, rem ? rem : 0, mixed ? ctx->lTf.as<float>() : nullptr))
@@ -345,7 +345,7 @@ static int transition_sharded_impl(dmpc_ctx *ctx, int S, int N, const double *po
         FAIL(ctx, "dmpc_transition_sharded: bad arguments");
     if (G > 1 && !ctx->comm && !ctx->grp && !ctx->debug_rank) FAIL(ctx, "dmpc_transition_sharded: no communicator");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    const bool mixed = ctx->precision == DMPC_PREC_MIXED;
+    const bool mixed = (ctx->precision & DMPC_PREC_MIXED) != 0;
     const size_t A = (size_t)S * N, Aown = (size_t)S * cnt, tab = (size_t)G * S * N3 * cmax, chunk = (size_t)S * N3 * cmax;
     const size_t hist = Aown * (size_t)K_T_max * 24;
     if (ensure_step_scratch(ctx, A, Aown)) return -1;
@@ -555,7 +555,7 @@ static int group_step_batch(dmpc_ctx *root, int S, int N, const double *l, const
         double *dst[4] = {c->xp.as<double>(), c->xv.as<double>(), c->xa.as<double>(), c->pf.as<double>()};
         for (int u = 0; u < 4; ++u)
             HIPCHK(c, hipMemcpy2DAsync(dst[u], (size_t)cnt * 24, src[u] + (size_t)lo * 3, (size_t)N * 24, (size_t)cnt * 24, (size_t)S, hipMemcpyHostToDevice, st));
-        const bool mixed = c->precision == DMPC_PREC_MIXED;
+        const bool mixed = (c->precision & DMPC_PREC_MIXED) != 0;
         if (mixed && table_f32(c, c->lT.as<double>(), c->lTf, tab, st)) return -1;
         if (launch_step(c, S, G, cmax, r, 0, cnt, c->lT.as<double>(), dst[0], dst[1], dst[2], dst[3], c->pout.as<double>(), c->vout.as<double>(),
                         c->aout.as<double>(), nullptr, c->status.as<int32_t>(), c->info.as<int32_t>(), st, nullptr, rem, mixed ? c->lTf.as<float>() : nullptr))

@@ -27,10 +27,13 @@
 // launch never hold more than 16 constraints.  An agent that outgrows TS columns takes an EXTENSION (columns TS .. QCAP-1 in the same
 // padded layout) from a pool the workgroup shares, at the wave-uniform offset `xo` doubles from the wave's base (0: none held): the same
 // values at other addresses -- results are bit for bit those of the unsplit layout.
-template <bool SOFT, int QCAP, bool PERSIST, int TS = QCAP>
+// TF = float (DMPC_PREC_F32FACTOR, round 4: the "QP below fp64" of BASELINE configs[4]): the inverse factor is STORED in fp32 -- half the
+// LDS of the solver's largest object; products, rotations and every other quantity stay fp64, and the refinement pass (lambda += T T' rho
+// against fp64 residuals) runs until the active-set residual is back at 1e-13 or stops contracting.
+template <bool SOFT, int QCAP, bool PERSIST, int TS = QCAP, typename TF = double>
 struct SolveLds {   // offsets in doubles from the wave's LDS base
     static constexpr int T = 0;
-    static constexpr int A = t_doubles(TS);
+    static constexpr int A = (t_doubles(TS) * (int)sizeof(TF) + 7) / 8;
     static constexpr int W = A + 48;
     static constexpr int RR = W + 48;
     static constexpr int XS = RR + 64;
@@ -136,18 +139,18 @@ struct Cd {
 
 // y = T' x  (lane j gets y_j; 0 for j >= q).  x is the LDS vector at offset XOFF (zero beyond q).  Groups of 8 with one
 // lane mask per group; two FMA chains per group (half the dependent latency).
-template <int QCAP, int TOFF, int XOFF, int TS = QCAP>
+template <int QCAP, int TOFF, int XOFF, int TS = QCAP, typename TF = double>
 __device__ __forceinline__ double t_tmul2(const double *B, int lane, int q, const int xo = 0)
 {
     double acc = 0.0;
     const int qlim = (TS < QCAP && xo == 0) ? TS : QCAP;   // (no extension held: q <= TS, the lanes beyond read column TS-1, masked)
     const int jc = lane < qlim ? lane : qlim - 1;
-    const double *col = B + TOFF + tcol(jc) + ((TS < QCAP && jc >= TS) ? xo : 0);
+    const TF *col = (const TF *)(B + TOFF) + tcol(jc) + ((TS < QCAP && jc >= TS) ? xo : 0);
     const double *xs = B + XOFF;
     for (int i0 = 0; i0 < q; i0 += 8) {
         double t[8], x[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { t[u] = col[i0 + u]; x[u] = xs[i0 + u]; }
+        for (int u = 0; u < 8; ++u) { t[u] = (double)col[i0 + u]; x[u] = xs[i0 + u]; }
         double s0 = t[0] * x[0], s1 = t[1] * x[1];
 #pragma unroll
         for (int u = 2; u < 8; u += 2) { s0 = fma(t[u], x[u], s0); s1 = fma(t[u + 1], x[u + 1], s1); }
@@ -157,30 +160,30 @@ __device__ __forceinline__ double t_tmul2(const double *B, int lane, int q, cons
 }
 // y = T x  (lane i gets y_i; 0 for i >= q).  The 8 columns of group g hold rows 0 .. 8(g+1)-1 (zeros below the diagonal),
 // so a lane either owns the whole group or skips it; columns >= q only meet x_j = 0.
-template <int QCAP, int TOFF, int XOFF, int TS = QCAP>
+template <int QCAP, int TOFF, int XOFF, int TS = QCAP, typename TF = double>
 __device__ __forceinline__ double t_mul2(const double *B, int lane, int q, const int xo = 0)
 {
     double acc = 0.0;
-    const double *row = B + TOFF + lane;
+    const TF *row = (const TF *)(B + TOFF) + lane;
     const double *xs = B + XOFF;
     const int q0 = (TS < QCAP && q > TS) ? TS : q;
     for (int j0 = 0; j0 < q0; j0 += 8) {
         double t[8], x[8];
         const int c0 = tcol(j0), len = j0 + 9;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { t[u] = row[c0 + u * len]; x[u] = xs[j0 + u]; }
+        for (int u = 0; u < 8; ++u) { t[u] = (double)row[c0 + u * len]; x[u] = xs[j0 + u]; }
         double s0 = t[0] * x[0], s1 = t[1] * x[1];
 #pragma unroll
         for (int u = 2; u < 8; u += 2) { s0 = fma(t[u], x[u], s0); s1 = fma(t[u + 1], x[u + 1], s1); }
         acc += (lane < j0 + 8) ? (s0 + s1) : 0.0;
     }
     if (TS < QCAP) {   // the column groups of the extension (the same sums in the same order)
-        const double *rowx = row + xo;
+        const TF *rowx = row + xo;
         for (int j0 = TS; j0 < q; j0 += 8) {
             double t[8], x[8];
             const int c0 = tcol(j0), len = j0 + 9;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { t[u] = rowx[c0 + u * len]; x[u] = xs[j0 + u]; }
+            for (int u = 0; u < 8; ++u) { t[u] = (double)rowx[c0 + u * len]; x[u] = xs[j0 + u]; }
             double s0 = t[0] * x[0], s1 = t[1] * x[1];
 #pragma unroll
             for (int u = 2; u < 8; u += 2) { s0 = fma(t[u], x[u], s0); s1 = fma(t[u + 1], x[u + 1], s1); }
@@ -192,11 +195,11 @@ __device__ __forceinline__ double t_mul2(const double *B, int lane, int q, const
 
 // delete slot l: Givens rotations on adjacent columns zero row l of T left-to-right; row l and the last column drop out.
 // Fused with the row deletion (each lane carries its row of the "current right column" in a register).
-template <bool SOFT, int QCAP, bool PERSIST, int TS = QCAP>
+template <bool SOFT, int QCAP, bool PERSIST, int TS = QCAP, typename TF = double>
 __device__ __forceinline__ void remove_slot2(double *B, int lane, int &q, int l, unsigned &cslot, unsigned long long &cm, const int xo = 0)
 {
-    using SL = SolveLds<SOFT, QCAP, PERSIST, TS>;
-    double *T = B + SL::T;
+    using SL = SolveLds<SOFT, QCAP, PERSIST, TS, TF>;
+    TF *T = (TF *)(B + SL::T);
     auto tc = [&](int j) -> int { return tcol(j) + ((TS < QCAP && j >= TS) ? xo : 0); };   // start of column j (split T: the extension's columns at +xo)
     int *s_meta = (int *)(B + SL::META);
     // per-component slot indices (2 bytes: box slot, position slot; 0xff = none) and the per-step collision-slot mask:
@@ -219,8 +222,8 @@ __device__ __forceinline__ void remove_slot2(double *B, int lane, int &q, int l,
     // long solve).
     {
         const bool act = lane >= l && lane <= q - 2;
-        const double bj = act ? T[tc(lane + 1) + l] : 0.0;
-        const double al = T[tc(l) + l];
+        const double bj = act ? (double)T[tc(lane + 1) + l] : 0.0;
+        const double al = (double)T[tc(l) + l];
         double val = bj * bj;
         if (lane == l) val = fma(al, al, val);
         const double Sj = wave_scan_sum(val);   // lane j: a_l^2 + b_l^2 + ... + b_j^2
@@ -238,24 +241,24 @@ __device__ __forceinline__ void remove_slot2(double *B, int lane, int &q, int l,
     // the sweep, two columns per round (their LDS reads in flight together); the dependent path is two multiply-adds per column
     static_assert(SL::XS == SL::RR + 64, "rotation pairs span the two staging vectors");
     const double2 *rot = (const double2 *)__builtin_assume_aligned(B + SL::RR, 16);
-    double carry = (lane <= l) ? T[tc(l) + lane] : 0.0;
+    double carry = (lane <= l) ? (double)T[tc(l) + lane] : 0.0;
     const int row = lane < l ? lane : lane - 1;
     for (int j0 = l; j0 < q - 1; j0 += 2) {
         const int j1 = j0 + 1 < q - 1 ? j0 + 1 : j0;   // (an odd tail repeats its column: harmless reads, the second update masked)
-        const double r0 = (lane <= j0 + 1) ? T[tc(j0 + 1) + lane] : 0.0;
-        const double r1 = (lane <= j1 + 1) ? T[tc(j1 + 1) + lane] : 0.0;
+        const double r0 = (lane <= j0 + 1) ? (double)T[tc(j0 + 1) + lane] : 0.0;
+        const double r1 = (lane <= j1 + 1) ? (double)T[tc(j1 + 1) + lane] : 0.0;
         const double2 c0 = rot[j0], c1 = rot[j1];
         const double n0 = c0.x * carry - c0.y * r0;
         carry = c0.y * carry + c0.x * r0;
-        if (lane <= j0 + 1 && lane != l) T[tc(j0) + row] = n0;
+        if (lane <= j0 + 1 && lane != l) T[tc(j0) + row] = (TF)n0;
         if (j0 + 1 < q - 1) {
             const double n1 = c1.x * carry - c1.y * r1;
             carry = c1.y * carry + c1.x * r1;
-            if (lane <= j1 + 1 && lane != l) T[tc(j1) + row] = n1;
+            if (lane <= j1 + 1 && lane != l) T[tc(j1) + row] = (TF)n1;
         }
     }
     // the column that dropped out: back to zero up to the end of its group (keeps "zero below the diagonal" for the next append)
-    if (lane < ((q + 7) & ~7)) T[tc(q - 1) + lane] = 0.0;
+    if (lane < ((q + 7) & ~7)) T[tc(q - 1) + lane] = (TF)0.0;
     const bool mv = lane > l && lane < q;
     double v0 = 0, v1 = 0, v2 = 0, ss = 0, d = 0, lam = 0; int meta = 0;
     if (mv) {
@@ -290,12 +293,13 @@ __device__ __forceinline__ void remove_slot2(double *B, int lane, int &q, int l,
 // crash (dependent pivot: guard only), bit 2 this call used the table, bits 8.. bounds appended (0: nothing was violated).
 typedef __attribute__((address_space(3))) double LdsD;
 struct CrashRes { int q; unsigned cslot; int flags; };
-template <bool SOFT, int QCAP, bool PERSIST>
+template <bool SOFT, int QCAP, bool PERSIST, typename TF = double>
 __device__ __attribute__((noinline)) CrashRes crash_append(LdsD *Bl, const LdsD *Gl, const double *tpg, const int lane, const int q, unsigned cslot,
                                                            const double a, const double alim, const double tol, const bool tbl_ok)
 {
-    using SL = SolveLds<SOFT, QCAP, PERSIST>;
+    using SL = SolveLds<SOFT, QCAP, PERSIST, QCAP, TF>;
     double *B = (double *)Bl;
+    TF *Tf = (TF *)(B + SL::T);
     const double *G = (const double *)Gl;
     int *s_meta = (int *)(B + SL::META);
     const bool comp = lane < N3;
@@ -375,7 +379,7 @@ __device__ __attribute__((noinline)) CrashRes crash_append(LdsD *Bl, const LdsD 
                         const double sgj = ((hm >> (3 * kj + x)) & 1ull) ? 1.0 : -1.0;
                         if (lane < ((j + 8) & ~7)) {
                             const bool nzr = lane <= j && lane < qn && iax == x;   // (rows of the axis: their positions are <= pj)
-                            B[SL::T + tcol(j) + lane] = nzr ? (isg * sgj) * tp[pj] : 0.0;
+                            Tf[tcol(j) + lane] = (TF)(nzr ? (isg * sgj) * tp[pj] : 0.0);
                         }
                     }
                 }
@@ -421,9 +425,9 @@ __device__ __attribute__((noinline)) CrashRes crash_append(LdsD *Bl, const LdsD 
         sv = has ? G[gj * 30 + pkj] * (sgj * sgp) : 0.0;
     }
     B[SL::XS + lane] = sv; LSYNC();
-    const double dvj = t_tmul2<QCAP, SL::T, SL::XS>(B, lane, q);
+    const double dvj = t_tmul2<QCAP, SL::T, SL::XS, QCAP, TF>(B, lane, q);
     B[SL::RR + lane] = dvj; LSYNC();
-    const double ri = t_mul2<QCAP, SL::T, SL::RR>(B, lane, q);
+    const double ri = t_mul2<QCAP, SL::T, SL::RR, QCAP, TF>(B, lane, q);
     LSYNC();
     const double d2 = (lane < q) ? dvj * dvj : 0.0;
     double irho[3]; bool okx[3];
@@ -441,7 +445,7 @@ __device__ __attribute__((noinline)) CrashRes crash_append(LdsD *Bl, const LdsD 
     for (int x = 0; x < 3; ++x) {
         if (!okx[x]) continue;
         if (lane < ((qn + 8) & ~7))
-            B[SL::T + tcol(qn) + lane] = (lane < q) ? ((jax == x) ? (-ri * irho[x]) : 0.0) : ((lane == qn) ? irho[x] : 0.0);
+            Tf[tcol(qn) + lane] = (TF)((lane < q) ? ((jax == x) ? (-ri * irho[x]) : 0.0) : ((lane == qn) ? irho[x] : 0.0));
         if (lane == 0) {
             B[SL::SVEC + 3 * qn] = x == 0 ? psg[x] : 0.0; B[SL::SVEC + 3 * qn + 1] = x == 1 ? psg[x] : 0.0; B[SL::SVEC + 3 * qn + 2] = x == 2 ? psg[x] : 0.0;
             B[SL::SD + qn] = alim; B[SL::SLAM + qn] = 0.0; B[SL::SSS + qn] = 0.0;
@@ -494,7 +498,7 @@ __device__ __forceinline__ void post_step_part(const KargPtr Qp, const int lane,
 // here) or -- persistent form -- the AGENT the wave is about to solve (the queue position already resolved through the order
 // by the persistent loop); `smem`: this wave's LDS; `shtab`: the workgroup-shared tables (persistent
 // form).
-template <bool SOFT, int QCAP, bool PERSIST, int TS = QCAP>
+template <bool SOFT, int QCAP, bool PERSIST, int TS = QCAP, typename TF = double>
 __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, const int bidx, const int nblocks,
                                            unsigned char *smem, const double *shtab, const bool want_ticket, int &ticket, bool &claimed,
                                            const int ext0 = 0 /* split T: doubles from this wave's block to extension 0 of the workgroup's pool */)
@@ -505,8 +509,14 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
     // it, and such parked agents were the last to end the launch (round 3: the waves ended 779-878 us, busy fraction 0.90).
 #define CLAIM_NEXT() do { if (PERSIST && want_ticket && !claimed) { claimed = true; \
         if (lane == 0) ticket = atomicAdd(kernarg_params()->counter, 1); } } while (0)
-    using SL = SolveLds<SOFT, QCAP, PERSIST, TS>;
+    using SL = SolveLds<SOFT, QCAP, PERSIST, TS, TF>;
     constexpr bool soft = SOFT;
+    constexpr bool F32T = sizeof(TF) == 4;
+    static_assert(!F32T || TS == QCAP, "the fp32 factor is not split");
+    // fp32 factor: r = T T's carries ~1e-7 relative, so a DEPENDENT pivot shows a residual nu'H^-1 nu of ~1e-13 s_pp instead of ~1e-30:
+    // the dependence threshold moves up, and the refinement gets more passes (it contracts by ~1e-7 cond(S) per pass instead of at once)
+    const double DEP_TOL = F32T ? P.dep_tol_f32 : 1e-13;
+    constexpr int REFINE_PASSES = F32T ? 10 : 3;
     static_assert(TS == QCAP || (PERSIST && !SOFT && TS % 8 == 0 && TS < QCAP), "split T: persistent slack-free kernels");
     const int nrmax = P.nrmax, var = P.variant;
     // split T: offset (doubles from the wave's base) that puts column j >= TS of the factor at tcol(j) + xo; 0: no extension held.
@@ -923,7 +933,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                         if (soft) r_fl[didx] &= ~bit; else r_bits[didx >> 5] &= ~(1u << (didx & 31));
                     }
                 }
-                remove_slot2<SOFT, QCAP, PERSIST, TS>(B, lane, q, l, cslot, cm, xo);
+                remove_slot2<SOFT, QCAP, PERSIST, TS, TF>(B, lane, q, l, cslot, cm, xo);
                 if (soft && dty == TY_COLL && didx != keep_row) {
                     const int fl = r_fl[didx];
                     if ((fl & RF_LIVE) && (fl & RF_SLKU) && !(fl & RF_SLKL)) {
@@ -932,7 +942,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                         const int ul = __ffsll((long long)um) - 1;
                         LSYNC();
                         if (lane == 0) { r_fl[didx] = 0; r_eps[didx] = 0.0; }
-                        remove_slot2<SOFT, QCAP, PERSIST, TS>(B, lane, q, ul, cslot, cm, xo);
+                        remove_slot2<SOFT, QCAP, PERSIST, TS, TF>(B, lane, q, ul, cslot, cm, xo);
                         nlive--;
                     }
                 }
@@ -945,7 +955,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
             if (SOFT && crash) {
                 bool tbl_ok = true;
                 while (q < (QCAP - 4 < 44 ? QCAP - 4 : 44)) {
-                    const CrashRes cr = crash_append<SOFT, QCAP, PERSIST>((LdsD *)B, (const LdsD *)G, P.tables + TAB_DOUBLES + (size_t)ccase * 2 * TAB_TP_CASE,
+                    const CrashRes cr = crash_append<SOFT, QCAP, PERSIST, TF>((LdsD *)B, (const LdsD *)G, P.tables + TAB_DOUBLES + (size_t)ccase * 2 * TAB_TP_CASE,
                                                                           lane, q, cslot, a, P.alim, tol, tbl_ok);
                     const int nb = cr.flags >> 8;
                     if (cr.flags & 2) crash_stop = true;
@@ -1024,7 +1034,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                     PHC(10);
                     CLAIM_NEXT();
                     if (!crash && (q == 0 || fresh)) break;   // optimal
-                    if (!crash && !soft) {
+                    if (!crash && !soft && !F32T) {   // (fp32 factor: the incrementally updated iterate drifts by ~1e-7 per step -- always the full verification)
                         // (slack-free variants; the slack variants carry multipliers of 1e5-1e6 and always take the full verification)
                         // No constraint is violated at the (incrementally updated) iterate.  Round-off of the factor reaches the iterate
                         // only through N_W: an error dr of r = T T's moves x by t H^-1 N_W dr, which shows in the values of the
@@ -1039,20 +1049,23 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                     // (crash: the appended slots carry lambda = 0 and their violation at the stale iterate -- the same pass solves them)
                     if (!fresh) {
                     primal_fast();
-                    for (int pass = 0; pass < 3; ++pass) {
+                    double mx_prev = INFINITY;
+                    for (int pass = 0; pass < REFINE_PASSES; ++pass) {
                         const double rho = (lane < q) ? slot_value(lane) : 0.0;
                         const double mx = wave_max0(fabs(rho));
                         if (!(mx > 1e-13)) break;
+                        if (F32T && !(mx < 0.5 * mx_prev)) break;   // (fp32 factor: the refinement has stopped contracting)
+                        mx_prev = mx;
                         B[SL::XS + lane] = rho; LSYNC();
-                        const double dvj = t_tmul2<QCAP, SL::T, SL::XS, TS>(B, lane, q, xo);
+                        const double dvj = t_tmul2<QCAP, SL::T, SL::XS, TS, TF>(B, lane, q, xo);
                         B[SL::RR + lane] = dvj; LSYNC();
-                        const double ri = t_mul2<QCAP, SL::T, SL::RR, TS>(B, lane, q, xo);
+                        const double ri = t_mul2<QCAP, SL::T, SL::RR, TS, TF>(B, lane, q, xo);
                         if (lane < q) B[SL::SLAM + lane] += ri;
                         LSYNC();
                         primal_fast();
                     }
                     }
-                    if (SOFT && !crash && !was_fresh && accept_drops < 4) {   // (slack variants: the slack-free kernels keep `crash` a compile-time false)
+                    if ((SOFT || F32T) && !crash && !was_fresh && accept_drops < 4) {   // (slack variants, and every variant with the fp32 factor; the fp64 slack-free kernels keep `crash` a compile-time false)
                         // acceptance: the refined multipliers must be non-negative.  At a degenerate vertex the incrementally updated
                         // multipliers can drift and the refinement then uncovers a negative one: the point is feasible but not the
                         // minimiser (randomized campaign, seed 2: one solveSoftDMPCall agent-step of 454 611, objective off by 2e-5).
@@ -1069,7 +1082,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                                 while (neg != 0ull) {
                                     const int l = 63 - __clzll((long long)neg);
                                     neg &= ~(1ull << l);
-                                    remove_slot2<SOFT, QCAP, PERSIST, TS>(B, lane, q, l, cslot, cm, xo);
+                                    remove_slot2<SOFT, QCAP, PERSIST, TS, TF>(B, lane, q, l, cslot, cm, xo);
                                 }
                             } else drop_slot(63 - __clzll((long long)neg), -1);   // any kind of slot (and maybe its pin): one per pass
 #ifdef DMPC_DEV_TRACE
@@ -1123,7 +1136,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                 if (soft && p.ty == TY_COLL && !(r_fl[p.idx] & RF_LIVE)) {
                     if (q >= QCAP - 1) { rc = 2; break; }
                     const Cd u = slack_desc(TY_SLKU, p.idx);
-                    if (lane < ((q + 8) & ~7)) B[SL::T + tcol(q) + lane] = (lane == q) ? 1.4142135623730951 : 0.0;
+                    if (lane < ((q + 8) & ~7)) ((TF *)(B + SL::T))[tcol(q) + lane] = (TF)((lane == q) ? 1.4142135623730951 : 0.0);
                     if (lane == 0) r_fl[p.idx] |= (RF_LIVE | RF_SLKU);
                     nlive++;
                     write_slot(u, -r_st[p.idx]);
@@ -1153,17 +1166,17 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                     }
                     B[SL::XS + lane] = sv; LSYNC();
                     PH(13);
-                    const double dvj = t_tmul2<QCAP, SL::T, SL::XS, TS>(B, lane, q, xo);
+                    const double dvj = t_tmul2<QCAP, SL::T, SL::XS, TS, TF>(B, lane, q, xo);
                     B[SL::RR + lane] = dvj; LSYNC();
                     PH(14);
-                    const double ri = t_mul2<QCAP, SL::T, SL::RR, TS>(B, lane, q, xo);
+                    const double ri = t_mul2<QCAP, SL::T, SL::RR, TS, TF>(B, lane, q, xo);
                     LSYNC();
                     PH(2);
                     if (crash) {   // append without a step: column [-r/rho; 1/rho] with rho^2 = s_pp - |T's|^2, lambda_p = 0 until the batch is solved
                         const double dlt = spp - wave_sum0(dvj * dvj);
                         if (!(dlt > 1e-9 * spp)) { crash_stop = true; break; }   // (distinct bounds are independent; guard only)
                         const double irho = fast_rsq(dlt);
-                        if (lane < ((q + 8) & ~7)) B[SL::T + tcol(q) + lane] = (lane < q) ? (-ri * irho) : ((lane == q) ? irho : 0.0);
+                        if (lane < ((q + 8) & ~7)) ((TF *)(B + SL::T))[tcol(q) + lane] = (TF)((lane < q) ? (-ri * irho) : ((lane == q) ? irho : 0.0));
                         write_slot(p, 0.0);
                         if (lane == p.idx) cslot = (cslot & ~0xffu) | (unsigned)q | (p.ty == TY_BOXHI ? 0x10000u : 0x20000u);
                         q++; nfast++;
@@ -1207,7 +1220,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                     PH(3);
                     // more active constraints than variables is impossible: whatever round-off says, a constraint picked when
                     // the working set already spans all 45 + nlive variables is dependent
-                    const bool dependent = !(delta > 1e-13 * spp) || q >= N3 + nlive;
+                    const bool dependent = !(delta > DEP_TOL * spp) || q >= N3 + nlive;
                     const double t2 = dependent ? INFINITY : fast_div(vp, delta);
                     // ratio test on the multipliers: the blocking slot maximises r_j / lambda_j (identity 0: one bound_ctrl
                     // DPP maximum instead of a minimum with an infinity identity); t1 = 1 / max
@@ -1254,7 +1267,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                         if (q >= QCAP) { rc = 2; break; }
                         const double irho = fast_rsq(delta);
                         ENSURE_EXT(q);
-                        if (lane < ((q + 8) & ~7)) B[SL::T + tcol(q) + ((TS < QCAP && q >= TS) ? xo : 0) + lane] = (lane < q) ? (-ri * irho) : ((lane == q) ? irho : 0.0);
+                        if (lane < ((q + 8) & ~7)) ((TF *)(B + SL::T))[tcol(q) + ((TS < QCAP && q >= TS) ? xo : 0) + lane] = (TF)((lane < q) ? (-ri * irho) : ((lane == q) ? irho : 0.0));
                         write_slot(p, lam_p);
                         if (p.ty < TY_COLL) {
                             if (lane == p.idx) {
@@ -1291,7 +1304,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                     const int ul = __ffsll((long long)um) - 1;
                     LSYNC();
                     if (lane == 0) { r_fl[p.idx] = 0; r_eps[p.idx] = 0.0; }
-                    remove_slot2<SOFT, QCAP, PERSIST, TS>(B, lane, q, ul, cslot, cm, xo);
+                    remove_slot2<SOFT, QCAP, PERSIST, TS, TF>(B, lane, q, ul, cslot, cm, xo);
                     nlive--;
                 }
                 if (((++since_sync) & 31) == 0) primal_fast();   // periodic re-sync with x(lambda)

@@ -18,30 +18,34 @@ SWEEP = [("C2", "hard", 100, {}), ("C4", "bound", 100, {}), ("C5", "repair", 200
          ("C3", "softall", 200, {}), ("C2", "ondemand", 100, {}), ("C4", "bound2", 100, {})]
 
 
-def run_sweep(cfgname, variant, N, over, steps=6, S=4, seed=5):
+def run_sweep(cfgname, variant, N, over, steps=6, S=4, seed=5, precision="mixed"):
     cfg = wl.CONFIGS[cfgname]
     kw = dict(wl.solver_kwargs(cfg, N), **over)
     po, pf = wl.make_scenes(cfg, S, N, wl.SEED0 + seed)
-    d64, dmx = mp.Dmpc(variant, **kw), mp.Dmpc(variant, precision="mixed", **kw)
+    d64, dmx = mp.Dmpc(variant, **kw), mp.Dmpc(variant, precision=precision, **kw)
     l = np.stack([init_table(po[s], pf[s]) for s in range(S)])
     xp, xv, xa = po.copy(), np.zeros_like(po), np.zeros_like(po)
     tot = same = both = 0
     worst = 0.0
+    ntries = ninvalid = 0
     for k in range(steps):
         a = d64.step_batch(l, xp, xv, xa, pf)
         b = dmx.step_batch(l, xp, xv, xa, pf)
         tot += a["status"].size
         eq = a["status"] == b["status"]
         same += int(eq.sum())
-        ok = eq & ((a["status"] & 1) == 1)
+        te = eq & (a["info"][..., 2] == b["info"][..., 2])             # same status word AND same retry-ladder level: the same QP was solved
+        ntries += int((eq & ~te).sum())
+        ok = (te if precision in ("f32factor", "low") else eq) & ((a["status"] & 1) == 1)
         both += int(ok.sum())
         if ok.any():
             worst = max(worst, float(np.abs(a["p"][ok] - b["p"][ok]).max()))
-        assert not (b["status"] & (mp.ST_CAPACITY | mp.ST_ITERCAP)).any()
+        ninvalid += int(((b["status"] & (mp.ST_CAPACITY | mp.ST_ITERCAP)) != 0).sum())
+        assert precision not in ("f64", "mixed") or ninvalid == 0
         upd = (a["status"] & 1) == 1
         l = np.where(upd[..., None], a["p"], l); xp = np.where(upd[..., None], a["p"][..., :3], xp)
         xv = np.where(upd[..., None], a["v"][..., :3], xv); xa = np.where(upd[..., None], a["a"][..., :3], xa)
-    return dict(agent_steps=tot, status_agreement=same / tot, compared=both, linf_p=worst)
+    return dict(agent_steps=tot, status_agreement=same / tot, compared=both, linf_p=worst, other_retry_count=ntries, invalid=ninvalid)
 
 
 @pytest.mark.parametrize("cfgname,variant,N,over", SWEEP)
@@ -52,6 +56,39 @@ def test_mixed_precision_against_fp64(cfgname, variant, N, over):
     assert r["status_agreement"] >= 0.99
     assert r["linf_p"] <= 1e-4
     assert r["compared"] > 0.5 * r["agent_steps"] or variant == "hard"
+
+
+# The QP below fp64 (DMPC_PREC_F32FACTOR: the solver's inverse factor stored in fp32, refined against fp64 residuals; DMPC_PREC_LOW: + the
+# fp32 table / scan / rows of DMPC_PREC_MIXED) -- the other half of the configs[4] sweep (DESIGN.md section 6 has the table, tools/gpu_f32factor_sweep.py
+# the sweep over the dependence threshold).  What the fp32 factor changes is WHICH decisions the active-set method takes near a degenerate
+# working set -- never the accuracy of an accepted result (the refinement brings the active-set residual back to 1e-13 against fp64 Gram
+# entries, multipliers are checked for sign) -- so an agent whose status word and retry-ladder level agree has solved the same QP and must
+# agree to 1e-9; the disagreements are counted.  Measured: none for hard / ondemand / ellip / bound / softall / cpp1 (l_inf 3e-13 .. 2e-12,
+# multipliers up to 1e5), 0.05 % status words for repair (|term| / d up to 1e7), 0.1-0.2 % ladder levels for bound2 / cpp, and solveSoftDMPCall
+# -- three nearly parallel rows per neighbour -- is the one variant the fp32 factor is not fit for (1 % of the agent-steps on another
+# ladder level, 0.1 % out of slots or iterations).
+F32_SWEEP = [("C2", "hard", 100, {}, 1.0, 0), ("C4", "bound", 100, {}, 0.999, 2), ("C5", "repair", 200, {"term": -1e6}, 0.998, 0), ("C5", "repair", 200, {"term": -1e7}, 0.998, 0),
+             ("C3", "softall", 200, {}, 0.999, 0), ("C2", "ondemand", 100, {}, 1.0, 0), ("C2", "ellip", 100, {}, 1.0, 0), ("C4", "bound2", 100, {}, 0.998, 24),
+             ("C4", "cpp1", 100, {}, 1.0, 0), ("C4", "all3", 100, {}, 0.98, 200)]
+
+
+@pytest.mark.parametrize("cfgname,variant,N,over,min_status,max_other_level", F32_SWEEP)
+def test_fp32_factor_against_fp64(cfgname, variant, N, over, min_status, max_other_level):
+    r = run_sweep(cfgname, variant, N, over, precision="f32factor")
+    print(f"fp32-FACTOR-vs-fp64 sweep [{cfgname} {variant} N={N} {over}]: {r['agent_steps']} agent-steps, status agreement {r['status_agreement']:.4f}, "
+          f"same status on another retry-ladder level {r['other_retry_count']}, out of slots / iterations {r['invalid']}, "
+          f"l_inf(p) over the {r['compared']} agents that solved the same QP on both sides = {r['linf_p']:.2e} m")
+    assert r["status_agreement"] >= min_status
+    assert r["other_retry_count"] <= max_other_level
+    assert r["linf_p"] <= (1e-9 if variant != "all3" else 1e-3)
+    assert r["invalid"] == 0 or variant == "all3"
+
+
+@pytest.mark.parametrize("cfgname,variant,N,over", [SWEEP[0], SWEEP[1], SWEEP[2]])
+def test_low_precision_everywhere_against_fp64(cfgname, variant, N, over):
+    r = run_sweep(cfgname, variant, N, over, precision="low")
+    print(f"LOW (fp32 scan + rows + factor)-vs-fp64 sweep [{cfgname} {variant} N={N} {over}]: status agreement {r['status_agreement']:.4f}, l_inf(p) = {r['linf_p']:.2e} m")
+    assert r["status_agreement"] >= 0.99 and r["linf_p"] <= 1e-4
 
 
 def test_mixed_transition_reaches_the_goals():
