@@ -26,6 +26,10 @@
 
 #include <stdint.h>
 
+/* the library is built with hidden visibility: the entry points declared here (and the development interface of
+ * dmpc_hip_dev.h) are all it exports */
+#define DMPC_API __attribute__((visibility("default")))
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -138,26 +142,26 @@ enum {
  * Returns NULL on failure (no device, bad parameters); dmpc_last_error(NULL) has the text. */
 #define DMPC_DEVICE_CURRENT (-1)   /* (the value "current device" has had since the first version of this header) */
 #define DMPC_DEVICE_ALL (-100)
-dmpc_ctx *dmpc_create(const dmpc_params *prm, int device, int precision);
+DMPC_API dmpc_ctx *dmpc_create(const dmpc_params *prm, int device, int precision);
 /* number of GPUs the context drives (1 unless created with DMPC_DEVICE_ALL on a multi-GPU node) */
-int dmpc_group_size(const dmpc_ctx *ctx);
-void dmpc_destroy(dmpc_ctx *ctx);
-const char *dmpc_last_error(const dmpc_ctx *ctx);
+DMPC_API int dmpc_group_size(const dmpc_ctx *ctx);
+DMPC_API void dmpc_destroy(dmpc_ctx *ctx);
+DMPC_API const char *dmpc_last_error(const dmpc_ctx *ctx);
 
 /* Change parameters (variant, weights, bounds ...) of an existing context. */
-int dmpc_set_params(dmpc_ctx *ctx, const dmpc_params *prm);
+DMPC_API int dmpc_set_params(dmpc_ctx *ctx, const dmpc_params *prm);
 
 /* a1-a3: getPosMat.m:1 (Lambda = A = A_p), A_v / A_initp loop dmpc_soft_bound.m:92-108,
  * getDeltaMat.m:1.  Host computation, row-major; any pointer may be NULL.
  * Lambda, Av, Delta: 3K x 3K; A0: 3K x 6. */
-int dmpc_model_matrices(const dmpc_params *prm, double *Lambda, double *Av, double *A0, double *Delta);
+DMPC_API int dmpc_model_matrices(const dmpc_params *prm, double *Lambda, double *Av, double *A0, double *Delta);
 
 /* getPosVelMat.m:1 (dec-iSCP/cup-SCP helper kept for signature parity): Aaug (12 x 3K). */
-int dmpc_posvel_matrix(double h, int K, double *Aaug);
+DMPC_API int dmpc_posvel_matrix(double h, int K, double *Aaug);
 
 /* a4: initDMPC.m:1 for S*N agents (MPC step k = 1).  Host pointers.
  * po, pf: [S][N][3]; l_out, v_out, a_out: [S][N][3K]. */
-int dmpc_init_batch(dmpc_ctx *ctx, int S, int N, const double *po, const double *pf, double *l_out,
+DMPC_API int dmpc_init_batch(dmpc_ctx *ctx, int S, int N, const double *po, const double *pf, double *l_out,
                     double *v_out, double *a_out);
 
 /* a11: ONE MPC step for all agents of S scenes == the body of `for n = 1:N`
@@ -166,14 +170,14 @@ int dmpc_init_batch(dmpc_ctx *ctx, int S, int N, const double *po, const double 
  * l: [S][N][3K]; x_p,x_v,x_a (= pk,vk,ak(:,k-1,n)), pf: [S][N][3];
  * p_out,v_out,a_out: [S][N][3K] (rows of agents without DMPC_ST_SOLVED are zero);
  * status: [S][N]; info: [S][N][8] (may be NULL). */
-int dmpc_step_batch(dmpc_ctx *ctx, int S, int N, const double *l, const double *x_p, const double *x_v,
+DMPC_API int dmpc_step_batch(dmpc_ctx *ctx, int S, int N, const double *l, const double *x_p, const double *x_v,
                     const double *x_a, const double *pf, double *p_out, double *v_out, double *a_out,
                     int32_t *status, int32_t *info);
 
 /* a7/a8: one agent (0-based n) of one scene: the per-call entry the signature-preserving MATLAB
  * wrappers use ([p,v,a,feasible,outbound,coll] = solveSoftDMPCbound(...), solveSoftDMPCbound.m:1).
  * Host pointers.  l: [N][3K]; po,vo,ao,pf: [3]; p,v,a: [3K]; info: [8] or NULL. */
-int dmpc_solve_one(dmpc_ctx *ctx, int N, int n, const double *l, const double *po, const double *vo,
+DMPC_API int dmpc_solve_one(dmpc_ctx *ctx, int N, int n, const double *l, const double *po, const double *vo,
                    const double *ao, const double *pf, double *p, double *v, double *a, int32_t *status,
                    int32_t *info);
 
@@ -185,7 +189,7 @@ int dmpc_solve_one(dmpc_ctx *ctx, int N, int n, const double *l, const double *p
  *   xi: [max_rows][3] = E2*(p - p_j); kc: 1-based constrained horizon step; rhs = bin; slack_coef = prev_dist
  *   (1 for solveSoftDMPC, 0 for the hard variants); nrows = number of rows built (may exceed max_rows);
  *   viol_k = 1-based first violating horizon step (0 none); status = DMPC_ST_COLL or 0. */
-int dmpc_rows_one(dmpc_ctx *ctx, int N, int n, const double *l, const double *po, const double *vo, int max_rows,
+DMPC_API int dmpc_rows_one(dmpc_ctx *ctx, int N, int n, const double *l, const double *po, const double *vo, int max_rows,
                   double *xi, double *rhs, double *slack_coef, int32_t *kc, int32_t *nrows, int32_t *viol_k,
                   int32_t *status);
 
@@ -198,17 +202,17 @@ int dmpc_rows_one(dmpc_ctx *ctx, int N, int n, const double *l, const double *po
  * other work on that stream (e.g. the RCCL all-gather of lT_next); asynchronous: returns after enqueueing.
  *   x_p,x_v,x_a,pf : [S][C][3]          p_out,v_out,a_out : [S][C][3K]
  *   lT_next        : [S][3K][C] (this chunk, may be NULL)   status [S][C], info [S][C][8] */
-int dmpc_step_device(dmpc_ctx *ctx, int S, int G, int C, int g_local, const double *lT, const double *x_p,
+DMPC_API int dmpc_step_device(dmpc_ctx *ctx, int S, int G, int C, int g_local, const double *lT, const double *x_p,
                      const double *x_v, const double *x_a, const double *pf, double *p_out, double *v_out,
                      double *a_out, double *lT_next, int32_t *status, int32_t *info, void *stream);
 
 /* layout helpers (device pointers, asynchronous on `stream`):
  * rows [S][N][3K] -> lT [G][S][3K][C] with N = G*C, and first columns x_next = out(:,1). */
-int dmpc_table_from_rows_device(dmpc_ctx *ctx, int S, int G, int C, const double *rows, double *lT, void *stream);
+DMPC_API int dmpc_table_from_rows_device(dmpc_ctx *ctx, int S, int G, int C, const double *rows, double *lT, void *stream);
 
 /* Fused state advance on device: x_p,x_v,x_a <- first horizon column of p_out,v_out,a_out for
  * SOLVED agents (dmpc_soft_bound.m:132-134).  [S][C] agents. */
-int dmpc_advance_device(dmpc_ctx *ctx, int count, const double *p_out, const double *v_out, const double *a_out,
+DMPC_API int dmpc_advance_device(dmpc_ctx *ctx, int count, const double *p_out, const double *v_out, const double *a_out,
                         const int32_t *status, double *x_p, double *x_v, double *x_a, void *stream);
 
 /* Whole transition on one device: the `for k = 1:K_T` loop of dmpc_soft_bound.m:115-148 /
@@ -232,7 +236,7 @@ int dmpc_advance_device(dmpc_ctx *ctx, int count, const double *p_out, const dou
  * helper host thread each for the duration of the call) so that the slow tail of one part overlaps the others; scenes are independent,
  * results do not depend on the split.  On a DMPC_DEVICE_ALL context the agents of every scene are sharded over the GPUs instead
  * (see dmpc_create), and batches of 64 or more scenes run as two such groups side by side. */
-int dmpc_transition(dmpc_ctx *ctx, int S, int N, const double *po, const double *pf, int K_T_max,
+DMPC_API int dmpc_transition(dmpc_ctx *ctx, int S, int N, const double *po, const double *pf, int K_T_max,
                     double error_tol, double *pk, double *vk, double *ak, int32_t *K_T_used,
                     int32_t *scene_status);
 
@@ -248,16 +252,18 @@ int dmpc_transition(dmpc_ctx *ctx, int S, int N, const double *po, const double 
  * A context without a communicator behaves as rank 0 of 1 (the exchange is a device copy).
  * Table layout for N agents on G ranks: lT[G][S][3K][Cmax], Cmax = ceil(N/G); the last column of the chunks of the short
  * ranks is padding that is never read. */
-int dmpc_partition(int N, int G, int rank, int32_t *lo, int32_t *count, int32_t *cmax);
-int dmpc_comm_unique_id(char *id128);
-int dmpc_comm_init(dmpc_ctx *ctx, const char *id128, int nranks, int rank);
-int dmpc_comm_destroy(dmpc_ctx *ctx);
+DMPC_API int dmpc_partition(int N, int G, int rank, int32_t *lo, int32_t *count, int32_t *cmax);
+DMPC_API int dmpc_comm_unique_id(char *id128);
+DMPC_API int dmpc_comm_init(dmpc_ctx *ctx, const char *id128, int nranks, int rank);
+DMPC_API int dmpc_comm_destroy(dmpc_ctx *ctx);
+/* ranks of the context's communicator as RCCL itself counts them (ncclCommCount); the group size of a DMPC_DEVICE_ALL context; 1 otherwise */
+DMPC_API int dmpc_comm_size(const dmpc_ctx *ctx);
 
 /* One MPC step of this rank's agents + the exchange (cluster_solvev2 + the join, dmpc.cpp:1656-1686,1792-1841).  Device
  * pointers, asynchronous on `stream`: x_p, x_v, x_a, pf: [S][count][3] and p_out, v_out, a_out: [S][count][3K] of this
  * rank's `count` agents (dmpc_partition); lT, lT_next: the whole table [G][S][3K][Cmax] before / after the step -- every
  * rank's new predictions arrive in its slot of lT_next by the all-gather.  status [S][count], info [S][count][8] or NULL. */
-int dmpc_step_sharded_device(dmpc_ctx *ctx, int S, int N, const double *lT, const double *x_p, const double *x_v,
+DMPC_API int dmpc_step_sharded_device(dmpc_ctx *ctx, int S, int N, const double *lT, const double *x_p, const double *x_v,
                              const double *x_a, const double *pf, double *p_out, double *v_out, double *a_out,
                              double *lT_next, int32_t *status, int32_t *info, void *stream);
 
@@ -265,14 +271,14 @@ int dmpc_step_sharded_device(dmpc_ctx *ctx, int S, int N, const double *lT, cons
  * the histories pk, vk, ak [S][count][K_T_max][3] of ITS agents (or NULL), and the same K_T_used[S] / scene_status[S] as the
  * other ranks (a scene stops on every rank at the step where any agent of any rank fails or all agents reached their
  * goals: the rule of dmpc_transition).  Results do not depend on the number of ranks (bit for bit). */
-int dmpc_transition_sharded(dmpc_ctx *ctx, int S, int N, const double *po, const double *pf, int K_T_max, double error_tol,
+DMPC_API int dmpc_transition_sharded(dmpc_ctx *ctx, int S, int N, const double *po, const double *pf, int K_T_max, double error_tol,
                             double *pk, double *vk, double *ak, int32_t *K_T_used, int32_t *scene_status);
 
 /* The same, followed by ONE all-gather per history array: every rank then also holds the scene-wide histories [S][N][K_T_max][3]
  * on its device, which is what dmpc_postcheck(.., pk = NULL, ..) checks -- the post-checks of test/failure_rate.m:136-195 after a
  * sharded transition, on any rank (pk, vk, ak still return the rank's own agents).  A DMPC_DEVICE_ALL context does this inside
  * dmpc_transition. */
-int dmpc_transition_sharded_gather(dmpc_ctx *ctx, int S, int N, const double *po, const double *pf, int K_T_max, double error_tol,
+DMPC_API int dmpc_transition_sharded_gather(dmpc_ctx *ctx, int S, int N, const double *po, const double *pf, int K_T_max, double error_tol,
                                    double *pk, double *vk, double *ak, int32_t *K_T_used, int32_t *scene_status);
 
 /* f-1: the post-checks the reference runs after every transition -- test/failure_rate.m:136-195 (identical
@@ -294,7 +300,7 @@ int dmpc_transition_sharded_gather(dmpc_ctx *ctx, int S, int N, const double *po
  * sample into a uniform cell grid (cell = 2 rmin in the metric of the check), test the 27-neighbourhood with the same fp64 expression and
  * fall back to a tiled all-pairs pass for scenes without any pair that close -- min_dist and violation are exact either way.
  * After dmpc_transition on a DMPC_DEVICE_ALL context, or dmpc_transition_sharded_gather, the resident histories are the scene-wide ones. */
-int dmpc_postcheck(dmpc_ctx *ctx, int S, int N, int KT_alloc, const int32_t *K_T_used, const int32_t *scene_mask,
+DMPC_API int dmpc_postcheck(dmpc_ctx *ctx, int S, int N, int KT_alloc, const int32_t *K_T_used, const int32_t *scene_mask,
                    const double *pk, const double *vk, const double *ak, const double *pf, double vmax, double amax, double Ts,
                    double *r_factor, double *h_scaled, int32_t *n_samples, double *min_dist, int32_t *violation,
                    double *totdist, double *traj_time, double *p_interp, int ns_alloc);
@@ -312,27 +318,27 @@ int dmpc_postcheck(dmpc_ctx *ctx, int S, int N, int KT_alloc, const int32_t *K_T
  * order; k_cmp / k_blk: 0-based horizon column compared / 3-row block of A used; A: a_rows x ncols with element
  * (i,j) at A[i*a_rs + j*a_cs] (MATLAB column-major: a_rs = 1, a_cs = a_rows); Ain: n_sel x ncols with strides
  * o_rs / o_cs; bin, dist (optional): [n_sel].  The *_device form takes device pointers and a HIP stream. */
-int dmpc_coll_rows(dmpc_ctx *ctx, int K, int N_obs, int n_sel, const int32_t *sel, const double *l, int k_cmp, int k_blk,
+DMPC_API int dmpc_coll_rows(dmpc_ctx *ctx, int K, int N_obs, int n_sel, const int32_t *sel, const double *l, int k_cmp, int k_blk,
                    const double *p, const double *a0, double rmin, double c, const double *A, int a_rows, int ncols,
                    int64_t a_rs, int64_t a_cs, double *Ain, int64_t o_rs, int64_t o_cs, double *bin, double *dist);
-int dmpc_coll_rows_device(dmpc_ctx *ctx, int K, int n_sel, const int32_t *d_sel, const double *d_l, int k_cmp, int k_blk,
+DMPC_API int dmpc_coll_rows_device(dmpc_ctx *ctx, int K, int n_sel, const int32_t *d_sel, const double *d_l, int k_cmp, int k_blk,
                           const double *p, const double *a0, double rmin, double c, const double *d_A, int64_t a_rs,
                           int64_t a_cs, int ncols, double *d_Ain, int64_t o_rs, int64_t o_cs, double *d_bin, double *d_dist,
                           void *stream);
 
 /* dense form of structured rows as dmpc_rows_one returns them: Ain(r,:) = -(xi_r . A(3 kc_r - 2 .. 3 kc_r, :)), kc 1-based
  * (`Ain_total(idx,:) = -diff_mat*Ain`, CollConstrSoftDMPC.m:24-27).  xi [nr][3], kc [nr]; A / Ain strided as above. */
-int dmpc_rows_dense(dmpc_ctx *ctx, int nr, const double *xi, const int32_t *kc, const double *A, int a_rows, int ncols,
+DMPC_API int dmpc_rows_dense(dmpc_ctx *ctx, int nr, const double *xi, const int32_t *kc, const double *A, int a_rows, int ncols,
                     int64_t a_rs, int64_t a_cs, double *Ain, int64_t o_rs, int64_t o_cs);
 
 /* cup-SCP/AddCollConstr.m:1-31: the K N(N-1)/2 pairwise rows (pairs i<j in order, k fastest) of the coupled QP
  *     r = dist (rmin - dist) + diff.(p_i,k - p_j,k) - diff.(po_i - po_j)
  *     Ain(row,:) = -(diff . A(blk(i,k),:) - diff . A(blk(j,k),:)),  blk(i,k) = rows 3K(i-1)+3(k-1)+1..3;  bin = -r
  * p: [N][K][3] (== MATLAB p(3,K,N)); po: [N][3]; A: 3KN x ncols (strided as above); Ain: K N(N-1)/2 x ncols. */
-int dmpc_add_coll_constr(dmpc_ctx *ctx, int K, int N, const double *p, const double *po, double rmin, double c,
+DMPC_API int dmpc_add_coll_constr(dmpc_ctx *ctx, int K, int N, const double *p, const double *po, double rmin, double c,
                          const double *A, int ncols, int64_t a_rs, int64_t a_cs, double *Ain, int64_t o_rs, int64_t o_cs,
                          double *bin);
-int dmpc_add_coll_constr_device(dmpc_ctx *ctx, int K, int N, const double *d_p, const double *d_po, double rmin, double c,
+DMPC_API int dmpc_add_coll_constr_device(dmpc_ctx *ctx, int K, int N, const double *d_p, const double *d_po, double rmin, double c,
                                 const double *d_A, int64_t a_rs, int64_t a_cs, int ncols, double *d_Ain, int64_t o_rs,
                                 int64_t o_cs, double *d_bin, void *stream);
 
@@ -342,13 +348,13 @@ int dmpc_add_coll_constr_device(dmpc_ctx *ctx, int K, int N, const double *d_p, 
  * then the 3 x T position block of every trajectory, then the velocity blocks, then the acceleration blocks -- each
  * matrix in Eigen's default stream format (6 significant digits, columns aligned per matrix), byte for byte.
  * po [N][3], pf [N_cmd][3], pos/vel/acc [N_cmd][T][3] (== MATLAB pk(3,T,N_cmd)). */
-int dmpc_trajectories2file(const char *path, int N, int N_cmd, int T, double h_scaled, const double *pmin,
+DMPC_API int dmpc_trajectories2file(const char *path, int N, int N_cmd, int T, double h_scaled, const double *pmin,
                            const double *pmax, const double *po, const double *pf, const double *pos,
                            const double *vel, const double *acc);
 /* test2file (dmpc/cpp/cluster_test.cpp:9-33; read by dmpc/cpp_results/cluster_test.m): header
  * `n_cluster n_vehicles n_trials`, the cluster sizes and vehicle counts, then one n_vehicles x n_trials block of
  * wall times per cluster size.  times [n_cluster][n_vehicles][n_trials]. */
-int dmpc_test2file(const char *path, int n_cluster, int n_vehicles, int n_trials, const double *cluster_size,
+DMPC_API int dmpc_test2file(const char *path, int n_cluster, int n_vehicles, int n_trials, const double *cluster_size,
                    const double *num_vehicles, const double *times);
 
 /* f-2: the reference's start/goal generators for S scenes at once.
@@ -360,11 +366,11 @@ int dmpc_test2file(const char *path, int n_cluster, int n_vehicles, int n_trials
  * po, pf: [S][N][3].  MATLAB's global rand stream cannot be reproduced: draws come from a counter-based stream
  * (splitmix64 of seed, scene, set, draw index), so a (seed, S, N, box, rmin) tuple always gives the same scenes.
  * The _device form writes [2][S][N][3] (starts, then goals) to device memory on the caller's stream. */
-int dmpc_random_test(dmpc_ctx *ctx, int S, int N, const double *pmin, const double *pmax, double rmin, double c,
+DMPC_API int dmpc_random_test(dmpc_ctx *ctx, int S, int N, const double *pmin, const double *pmax, double rmin, double c,
                      uint64_t seed, double *po, double *pf);
-int dmpc_random_exchange(dmpc_ctx *ctx, int S, int N, const double *pmin, const double *pmax, double rmin, uint64_t seed,
+DMPC_API int dmpc_random_exchange(dmpc_ctx *ctx, int S, int N, const double *pmin, const double *pmax, double rmin, uint64_t seed,
                          double *po, double *pf);
-int dmpc_random_sets_device(dmpc_ctx *ctx, int S, int N, const double *pmin, const double *pmax, double rmin, double c,
+DMPC_API int dmpc_random_sets_device(dmpc_ctx *ctx, int S, int N, const double *pmin, const double *pmax, double rmin, double c,
                             uint64_t seed, int exchange, double *d_po_pf, void *stream);
 
 /* Standalone forms of the path's small helpers (fused into the step kernels inside the solvers), for callers that
@@ -375,24 +381,24 @@ int dmpc_random_sets_device(dmpc_ctx *ctx, int S, int N, const double *pmin, con
  *                     over the rows (or NULL).
  *   dmpc_is_inbounds  is_inbounds.m:1-6 on npts points [npts][3] (5 cm tolerance)
  *   dmpc_reached_goal ReachedGoal.m:1-11: max_i |p_i - pf_i| < error_tol, p, pf [N][3] */
-int dmpc_prop_state(dmpc_ctx *ctx, int n_rows, int n_cols, const double *A_p, const double *A_v, const double *A_initp,
+DMPC_API int dmpc_prop_state(dmpc_ctx *ctx, int n_rows, int n_cols, const double *A_p, const double *A_v, const double *A_initp,
                     const double *po, const double *vo, const double *off_p, const double *off_v, const double *a,
                     double *p, double *v);
-int dmpc_is_inbounds(dmpc_ctx *ctx, int npts, const double *p, const double *pmin, const double *pmax, int32_t *inbounds);
-int dmpc_reached_goal(dmpc_ctx *ctx, int N, const double *p, const double *pf, double error_tol, int32_t *reached);
+DMPC_API int dmpc_is_inbounds(dmpc_ctx *ctx, int npts, const double *p, const double *pmin, const double *pmax, int32_t *inbounds);
+DMPC_API int dmpc_reached_goal(dmpc_ctx *ctx, int N, const double *p, const double *pf, double error_tol, int32_t *reached);
 
 /* Agent-steps LAUNCHED by this context so far (incl. the half of a split dmpc_transition batch that runs on the internal
  * second context).  An upper bound of the QPs actually solved: agents of scenes that already stopped are skipped on the
  * device, and agents the scan certifies infeasible never enter the solver; per-agent outcomes are in status[]. */
-int64_t dmpc_solve_count(const dmpc_ctx *ctx);
+DMPC_API int64_t dmpc_solve_count(const dmpc_ctx *ctx);
 
 /* Roofline instrumentation: with dmpc_profile(ctx,1) every step-kernel launch is bracketed by HIP
  * events on the stream it is launched on; dmpc_profile_read drains them and returns the average
  * duration (ms) of the step's kernels and the step count since the previous read. */
-int dmpc_profile(dmpc_ctx *ctx, int enable);
-int dmpc_profile_read(dmpc_ctx *ctx, double *avg_ms, int64_t *n_launches);
+DMPC_API int dmpc_profile(dmpc_ctx *ctx, int enable);
+DMPC_API int dmpc_profile_read(dmpc_ctx *ctx, double *avg_ms, int64_t *n_launches);
 /* same, split into the solve kernel(s) (dmpc_solve_kernel, the dominant kernel) and scan + ordering */
-int dmpc_profile_read2(dmpc_ctx *ctx, double *solve_avg_ms, double *scan_avg_ms, int64_t *n_steps);
+DMPC_API int dmpc_profile_read2(dmpc_ctx *ctx, double *solve_avg_ms, double *scan_avg_ms, int64_t *n_steps);
 
 #ifdef __cplusplus
 }

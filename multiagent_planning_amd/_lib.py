@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "dmpc_trajectories2file", "dmpc_test2file", "dmpc_random_test", "dmpc_random_exchange", "dmpc_random_sets_device",
     "dmpc_prop_state", "dmpc_is_inbounds", "dmpc_reached_goal", "dmpc_rows_dense",
     "dmpc_partition", "dmpc_comm_unique_id", "dmpc_comm_init", "dmpc_comm_destroy", "dmpc_step_sharded_device",
-    "dmpc_transition_sharded", "dmpc_transition_sharded_gather", "dmpc_group_size",
+    "dmpc_transition_sharded", "dmpc_transition_sharded_gather", "dmpc_group_size", "dmpc_comm_size",
 ]
 
 
@@ -110,6 +110,7 @@ def load():
     L.dmpc_comm_unique_id.argtypes = [C.c_char_p]
     L.dmpc_comm_init.argtypes = [vp, C.c_char_p, C.c_int, C.c_int]
     L.dmpc_comm_destroy.argtypes = [vp]
+    L.dmpc_comm_size.argtypes = [vp]
     L.dmpc_step_sharded_device.argtypes = [vp, C.c_int, C.c_int] + [vp] * 12
     L.dmpc_transition_sharded.argtypes = [vp, C.c_int, C.c_int, dp, dp, C.c_int, C.c_double, dp, dp, dp, ip, ip]
     L.dmpc_transition_sharded_gather.argtypes = [vp, C.c_int, C.c_int, dp, dp, C.c_int, C.c_double, dp, dp, dp, ip, ip]
@@ -309,6 +310,10 @@ class Dmpc:
     def comm_init(self, id128, nranks, rank):
         self._chk(self._L.dmpc_comm_init(self._ctx, bytes(id128), int(nranks), int(rank)))
         self.nranks, self.rank = int(nranks), int(rank)
+
+    def comm_size(self):
+        """ranks of this context's communicator as RCCL counts them (ncclCommCount)"""
+        return int(self._L.dmpc_comm_size(self._ctx))
 
     def comm_destroy(self):
         self._L.dmpc_comm_destroy(self._ctx)

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../../include/dmpc_hip.h"
+#include "../../include/dmpc_hip_dev.h"
 #include "dmpc_device.h"
 
 #include "dmpc_kernels.hip"

@@ -26,6 +26,7 @@ struct Api {
     int (*CommInitRank)(Comm *, int, UniqueId, int) = nullptr;
     int (*CommDestroy)(Comm) = nullptr;
     int (*CommAbort)(Comm) = nullptr;
+    int (*CommCount)(Comm, int *) = nullptr;
     int (*AllGather)(const void *, void *, size_t, int, Comm, hipStream_t) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
@@ -51,6 +52,7 @@ static void api_load(Api &a)
     a.CommInitRank = (int (*)(Comm *, int, UniqueId, int))sym("ncclCommInitRank");
     a.CommDestroy = (int (*)(Comm))sym("ncclCommDestroy");
     a.CommAbort = (int (*)(Comm))dlsym(a.h, "ncclCommAbort");   // (optional: a failing rank releases its peers)
+    a.CommCount = (int (*)(Comm, int *))dlsym(a.h, "ncclCommCount");   // (optional: dmpc_comm_size reports what the communicator itself says)
     a.AllGather = (int (*)(const void *, void *, size_t, int, Comm, hipStream_t))sym("ncclAllGather");
     a.GroupStart = (int (*)())sym("ncclGroupStart");
     a.GroupEnd = (int (*)())sym("ncclGroupEnd");
@@ -165,6 +167,15 @@ extern "C" int dmpc_debug_set_rank(dmpc_ctx *ctx, int nranks, int rank)
     if (!ctx || ctx->comm || ctx->grp || nranks < 1 || rank < 0 || rank >= nranks) return -1;
     ctx->nranks = nranks; ctx->rank = rank; ctx->debug_rank = nranks > 1;
     return 0;
+}
+
+// ranks of the context's communicator as RCCL counts them (ncclCommCount); without a communicator: the ranks of the group (DMPC_DEVICE_ALL)
+// or 1.  What a launcher prints next to a scaling figure: the number of ranks that really took part.
+extern "C" int dmpc_comm_size(const dmpc_ctx *ctx)
+{
+    if (!ctx) return 0;
+    if (ctx->comm && mg::api()->CommCount) { int n = 0; if (mg::api()->CommCount((mg::Comm)ctx->comm, &n) == 0) return n; }
+    return ctx->grp ? ctx->grp->G : ctx->nranks;
 }
 
 extern "C" int dmpc_comm_destroy(dmpc_ctx *ctx)

@@ -27,6 +27,17 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib.ABI_SYMBOLS) == syms
 
 
+def test_library_exports_nothing_else():
+    """hidden visibility: the dynamic symbol table holds the boundary (include/dmpc_hip.h) and the development interface
+    (include/dmpc_hip_dev.h), no kernel stubs and no helper"""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted(ln.split()[-1] for ln in out.splitlines() if " T " in ln)
+    dev = open(os.path.join(ROOT, "include", "dmpc_hip_dev.h")).read()
+    dev = sorted(set(re.findall(r"\b(dmpc_debug_[a-z_0-9]+)\s*\(", re.sub(r"/\*.*?\*/", "", dev, flags=re.S))))
+    assert exported == sorted(_header_symbols() + dev), set(exported) ^ set(_header_symbols() + dev)
+
+
 def test_model_matrices_match_goldens_bitwise():
     g, kw = load_golden("failure_rate2_bound")
     Lam, Av, A0, Dl = mp.model_matrices(kw["h"])
