@@ -118,6 +118,7 @@ struct dmpc_ctx {
     int split_parts = 0;     // development option split_parts: number of parts (0: the built-in rule)
     int no_split = 0;        // development option no_split
     int no_split_t = 0;      // development option no_split_t: slack-free persistent solve with the whole inverse factor in every wave's block (nine waves per CU; A/B runs, tests)
+    int grid_min = 2048;     // development option grid_min: cell-grid neighbour lists from this many agents per scene on (below: nbr_kernel)
     int nbr_grid = 1;        // development option nbr_grid: 0 = neighbour lists of large scenes from the all-pairs box test of round 3 (nbr_kernel) instead of the cell grid + distance filter
     DevBuf grid;             // cell grid of the neighbour lists (counts, starts, entries)
     int f32_dep_exp = 8;     // development option f32_dep_exp: fp32-factor kernels treat a pivot as dependent below delta / s_pp = 10^-n
@@ -393,7 +394,7 @@ extern "C" int dmpc_debug_option(dmpc_ctx *ctx, const char *name, int value)
         {"no_fuse", &dmpc_ctx::no_fuse}, {"no_persist", &dmpc_ctx::no_persist}, {"force_persist", &dmpc_ctx::force_persist}, {"no_cull", &dmpc_ctx::no_cull}, {"order_slices", &dmpc_ctx::order_slices}, {"cull_min", &dmpc_ctx::cull_min},
         {"no_lpt", &dmpc_ctx::no_lpt}, {"crash_min", &dmpc_ctx::crash_min}, {"crash_any", &dmpc_ctx::crash_any}, {"no_fast_exit", &dmpc_ctx::no_fast_exit}, {"pivot_explore", &dmpc_ctx::pivot_explore},
         {"iter_cap", &dmpc_ctx::iter_cap}, {"tier1_qcap", &dmpc_ctx::tier1_env}, {"split_parts", &dmpc_ctx::split_parts}, {"no_split", &dmpc_ctx::no_split},
-        {"static_queue", &dmpc_ctx::static_queue}, {"no_split_t", &dmpc_ctx::no_split_t}, {"ext_cap", &dmpc_ctx::ext_cap}, {"nbr_grid", &dmpc_ctx::nbr_grid}, {"f32_dep_exp", &dmpc_ctx::f32_dep_exp}};
+        {"static_queue", &dmpc_ctx::static_queue}, {"no_split_t", &dmpc_ctx::no_split_t}, {"ext_cap", &dmpc_ctx::ext_cap}, {"nbr_grid", &dmpc_ctx::nbr_grid}, {"f32_dep_exp", &dmpc_ctx::f32_dep_exp}, {"grid_min", &dmpc_ctx::grid_min}};
     for (auto &t : tab)
         if (!std::strcmp(t.n, name)) {
             ctx->*(t.f) = value;
@@ -737,7 +738,10 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
         // round 4: lists from a cell grid, filtered by the fp32 distance test (grid_query_kernel); the all-pairs box test of round 3 stays
         // behind option nbr_grid = 0 (A/B runs, tests) and for scenes whose bitmap would not fit a wave's LDS
         const size_t gq_lds = grid_query_lds_per_wave(G * C);
-        const bool use_grid = ctx->nbr_grid && gq_lds * GQ_WAVES <= 64 * 1024;
+        // (from grid_min agents per scene on: in a scene of a few hundred agents the reach of a query covers most of the workspace and the
+        // all-pairs test with the neighbours' boxes as scalar operands is the cheaper pass -- 512 scenes of 800 agents, hard rows: scan side
+        // 0.65 ms with nbr_kernel, 0.90 ms with the grid; one scene of 10^4 agents: 0.58 against 0.32 ms)
+        const bool use_grid = ctx->nbr_grid && G * C >= ctx->grid_min && gq_lds * GQ_WAVES <= 64 * 1024;
         if (p.variant != DMPC_VAR_HARD || use_grid) {   // neighbour-major fp32 copy of the table: the list walk of the per-step distance scan, the distance test of the grid query
             const size_t tot = (size_t)total * 64;
             if (ctx->lrow.ensure(tot * 4)) FAIL(ctx, "device allocation failed (neighbour-major table)");
@@ -1358,10 +1362,10 @@ static int transition_one(dmpc_ctx *ctx, int S, int N, const double *po, const d
 static void copy_debug_options(dmpc_ctx *dst, const dmpc_ctx *src)
 {
     static const char *names[] = {"no_fuse", "no_persist", "force_persist", "no_cull", "order_slices", "cull_min", "no_lpt", "crash_min", "crash_any", "no_fast_exit",
-                                  "pivot_explore", "iter_cap", "tier1_qcap", "static_queue", "no_split_t", "ext_cap", "nbr_grid", "f32_dep_exp"};
+                                  "pivot_explore", "iter_cap", "tier1_qcap", "static_queue", "no_split_t", "ext_cap", "nbr_grid", "f32_dep_exp", "grid_min"};
     int dmpc_ctx::*fields[] = {&dmpc_ctx::no_fuse, &dmpc_ctx::no_persist, &dmpc_ctx::force_persist, &dmpc_ctx::no_cull, &dmpc_ctx::order_slices, &dmpc_ctx::cull_min,
                                &dmpc_ctx::no_lpt, &dmpc_ctx::crash_min, &dmpc_ctx::crash_any, &dmpc_ctx::no_fast_exit, &dmpc_ctx::pivot_explore, &dmpc_ctx::iter_cap,
-                               &dmpc_ctx::tier1_env, &dmpc_ctx::static_queue, &dmpc_ctx::no_split_t, &dmpc_ctx::ext_cap, &dmpc_ctx::nbr_grid, &dmpc_ctx::f32_dep_exp};
+                               &dmpc_ctx::tier1_env, &dmpc_ctx::static_queue, &dmpc_ctx::no_split_t, &dmpc_ctx::ext_cap, &dmpc_ctx::nbr_grid, &dmpc_ctx::f32_dep_exp, &dmpc_ctx::grid_min};
     for (size_t i = 0; i < sizeof(names) / sizeof(names[0]); ++i) (void)dmpc_debug_option(dst, names[i], src->*(fields[i]));
 }
 

@@ -38,11 +38,13 @@ def test_neighbour_lists_do_not_change_a_bit(variant, precision, monkeypatch):
     N, S = 700, 2                      # >= 256 agents per scene: lists on; 700 is not a multiple of 64 (ragged last tile)
     kw = wl.solver_kwargs(cfg, N)
     po, pf = wl.make_scenes(cfg, S, N, wl.SEED0 + 31)
-    with_lists = _steps(variant, kw, po, pf, 3, precision)
+    with_lists = _steps(variant, kw, po, pf, 3, precision)                      # (700 agents: the all-pairs box test, nbr_kernel)
+    with_grid = _steps(variant, kw, po, pf, 3, precision, grid_min=256)         # the cell grid + distance filter of scenes >= 2048 agents, forced
     plain = _steps(variant, kw, po, pf, 3, precision, no_cull=1)
-    for a, b in zip(with_lists, plain):
+    for a, g, b in zip(with_lists, with_grid, plain):
         for k in ("status", "info", "p", "v", "a"):
             assert np.array_equal(a[k], b[k]), (variant, k)
+            assert np.array_equal(g[k], b[k]), (variant, k, "grid")
     assert (with_lists[-1]["info"][..., 1] > 0).any()      # some agents did build collision rows
 
 
@@ -57,9 +59,27 @@ def test_neighbour_list_overflow_falls_back_to_the_table(monkeypatch):
     po = np.array(kw["pmin"]) + 1.0 + rng.random((S, N, 3)) * 1.5
     pf = np.array(kw["pmin"]) + 1.0 + rng.random((S, N, 3)) * 1.5
     a = _steps("ondemand", kw, po, pf, 1)
+    g = _steps("ondemand", kw, po, pf, 1, grid_min=256)
     b = _steps("ondemand", kw, po, pf, 1, no_cull=1)
     for k in ("status", "info", "p"):
         assert np.array_equal(a[0][k], b[0][k]), k
+        assert np.array_equal(g[0][k], b[0][k]), (k, "grid")
+
+
+def test_cell_grid_lists_at_full_size_do_not_change_a_bit():
+    """one scene of 3 000 agents (>= 2 048: the cell grid is the default), three closed-loop steps, bound and hard rows: identical to
+    the whole-table walk (no_cull) and to the all-pairs lists (nbr_grid = 0); sharded layouts of the same scene are in tests/test_gpu_fullsize.py"""
+    cfg = wl.CONFIGS["C4"]
+    N, S = 3000, 1
+    kw = wl.solver_kwargs(cfg, N)
+    po, pf = wl.make_scenes_device(mp.Dmpc("bound", **kw), cfg, S, N, wl.SEED0 + 33)
+    for variant in ("bound", "hard"):
+        a = _steps(variant, kw, po, pf, 3)
+        b = _steps(variant, kw, po, pf, 3, no_cull=1)
+        c = _steps(variant, kw, po, pf, 3, nbr_grid=0)
+        for x, y, z in zip(a, b, c):
+            for k in ("status", "info", "p", "v", "a"):
+                assert np.array_equal(x[k], y[k]) and np.array_equal(x[k], z[k]), (variant, k)
 
 
 @pytest.mark.parametrize("variant", ["bound", "bound2", "repair"])
