@@ -50,7 +50,8 @@ stats = {}
 if os.path.exists(kt):
     for r in csv.DictReader(open(kt)):
         stats[short(r["Name"])] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3, "pct": float(r["Percentage"])}
-out["kernel_stats"] = {k: v for k, v in stats.items() if k.startswith("dmpc") or k.split("<")[0] in ("order_kernel", "bbox_kernel", "nbr_kernel", "table_nbrmajor_kernel")}
+STEP_KERNELS = ("order_kernel", "bbox_kernel", "nbr_kernel", "table_nbrmajor_kernel", "grid_bin_kernel", "grid_scan_kernel", "grid_fill_kernel", "grid_query_kernel")
+out["kernel_stats"] = {k: v for k, v in stats.items() if k.startswith("dmpc") or k.split("<")[0] in STEP_KERNELS}
 KIB = 1024.0
 # FETCH_SIZE calibration on this library's access pattern (tools/gpu_fetch_calib.py: 3 launches of a 512 MiB coalesced streaming read at 8 and
 # at 16 bytes per lane): factor = known bytes / (counter x 1 KiB); applied to every FETCH_SIZE below (the kernels read 8 bytes per lane)
@@ -73,10 +74,10 @@ for k in set(passes.get("fetch", {})) | set(passes.get("write", {})):
     w = passes.get("write", {}).get(k, {}).get("WRITE_SIZE")
     if f is not None or w is not None:
         traffic[k] = {"fetch_kib": f, "write_kib": w, "bytes": ((f or 0) * fetch_factor + (w or 0)) * KIB}
-out["traffic_per_launch"] = {k: v for k, v in traffic.items() if k.startswith("dmpc") or k.split("<")[0] in ("order_kernel", "nbr_kernel", "bbox_kernel", "table_nbrmajor_kernel")}
+out["traffic_per_launch"] = {k: v for k, v in traffic.items() if k.startswith("dmpc") or k.split("<")[0] in STEP_KERNELS}
 sk = max((k for k in traffic if kern_sub in k), key=lambda k: stats.get(k, {}).get("pct", 0), default=None)
 if sk:
-    step_kernels = [k for k in traffic if k.startswith("dmpc_s") or k.split("<")[0] in ("order_kernel", "nbr_kernel", "bbox_kernel", "table_nbrmajor_kernel")]
+    step_kernels = [k for k in traffic if k.startswith("dmpc_s") or k.split("<")[0] in STEP_KERNELS]
     out["solve_kernel"] = sk
     out["hbm_bytes_per_launch"] = traffic[sk]["bytes"]
     out["whole_step_bytes_per_launch"] = sum(traffic[k]["bytes"] for k in step_kernels)
@@ -114,5 +115,5 @@ if sk:
                             "valu_pipe_busy": sq2.get("SQ_ACTIVE_INST_VALU", 0) / wc * waves_per_simd,
                             "note": "fractions of a wave's resident cycles (SQ_ACTIVE_INST_VALU / _SCA / _LDS, SQ_WAIT_ANY = parked on s_waitcnt, SQ_WAIT_INST_ANY = ready but "
                                     "not issued) ; valu_pipe_busy = active_valu x resident waves per SIMD"}
-out["counters"] = {p: {k: v for k, v in d.items() if k.startswith("dmpc") or k == "order_kernel"} for p, d in passes.items()}
+out["counters"] = {p: {k: v for k, v in d.items() if k.startswith("dmpc") or k.split("<")[0] in STEP_KERNELS} for p, d in passes.items()}
 print(json.dumps(out, indent=1))
