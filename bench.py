@@ -551,6 +551,21 @@ def main():
                     traffic = jt.get("hbm_bytes_per_launch")
             except Exception as e:   # noqa: BLE001
                 pmc, pmc_note = None, f"profiles/{PMC_SUMMARY}: {e}"
+        # the box's practical HBM ceiling next to the 8 TB/s of the data sheet ("also measure a device-copy ceiling"): a 1 GiB
+        # device-to-device copy, read + written bytes over HIP-event time, best of 5
+        copy_gbs = None
+        try:
+            src_c = torch.empty(1 << 28, dtype=torch.float32, device=dev); dst_c = torch.empty_like(src_c)
+            dst_c.copy_(src_c); torch.cuda.synchronize()
+            best_c = 1e9
+            for _ in range(5):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); dst_c.copy_(src_c); e1.record(); torch.cuda.synchronize()
+                best_c = min(best_c, e0.elapsed_time(e1))
+            copy_gbs = 2.0 * src_c.numel() * 4 / (best_c * 1e-3) / 1e9
+            del src_c, dst_c
+        except Exception:   # noqa: BLE001
+            copy_gbs = None
         ncu = torch.cuda.get_device_properties(dev).multi_processor_count
         kname = "dmpc_solve_persist_kernel" if S * C >= 16 * ncu * 8 else "dmpc_solve_kernel"
         line = {
@@ -567,6 +582,7 @@ def main():
                        "exchange": exchange, "exchange_verified": exchange_ok, "n_ranks_seen": (dmpc.comm_size() if in_lib else (G if use_dist else 1))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "measured_copy_ceiling_GBps": copy_gbs, "frac_of_copy_ceiling": (achieved / copy_gbs if copy_gbs else None),
                          "kernel": kname, "kernel_ms_avg": kern_ms, "launches": n_launch,
                          "other_kernels_ms_avg": {"dmpc_scan_kernel+order_kernel": scan_ms},
                          "alg_bytes_per_solve": b_alg, "solves_per_launch": S * C,
@@ -585,6 +601,7 @@ def main():
             "workload_stats": {"solved_frac": float((st & 1).mean()), "infeasible_frac": float(((st & 8) != 0).mean()),
                                "invalid": int(((st & 48) != 0).sum()), "mean_iters": float(inf[..., 4].mean()),
                                "max_iters": int(inf[..., 4].max()), "mean_rows": float(inf[..., 1].mean()),
+                               "tries_histogram": {str(int(t)): int(c) for t, c in zip(*np.unique(inf[..., 2], return_counts=True))},
                                "max_rows": int(inf[..., 1].max()), "max_working_set": int(inf[..., 7].max()),
                                "scenes_alive_at_capture": int(alive.sum())},
         }

@@ -121,6 +121,7 @@ struct dmpc_ctx {
     int grid_min = 2048;     // development option grid_min: cell-grid neighbour lists from this many agents per scene on (below: nbr_kernel)
     int nbr_grid = 1;        // development option nbr_grid: 0 = neighbour lists of large scenes from the all-pairs box test of round 3 (nbr_kernel) instead of the cell grid + distance filter
     DevBuf grid;             // cell grid of the neighbour lists (counts, starts, entries)
+    int no_level_check = 0;  // development option no_level_check (see StepParams)
     int f32_dep_exp = 8;     // development option f32_dep_exp: fp32-factor kernels treat a pivot as dependent below delta / s_pp = 10^-n
     int ext_cap = 0;         // development option ext_cap (tests): at most this many T extensions per workgroup (1: every agent that needs one waits for the same slot)
     int static_queue = 0;    // development option static_queue: persistent waves take queue positions round-robin instead of by ticket
@@ -394,7 +395,7 @@ extern "C" int dmpc_debug_option(dmpc_ctx *ctx, const char *name, int value)
         {"no_fuse", &dmpc_ctx::no_fuse}, {"no_persist", &dmpc_ctx::no_persist}, {"force_persist", &dmpc_ctx::force_persist}, {"no_cull", &dmpc_ctx::no_cull}, {"order_slices", &dmpc_ctx::order_slices}, {"cull_min", &dmpc_ctx::cull_min},
         {"no_lpt", &dmpc_ctx::no_lpt}, {"crash_min", &dmpc_ctx::crash_min}, {"crash_any", &dmpc_ctx::crash_any}, {"no_fast_exit", &dmpc_ctx::no_fast_exit}, {"pivot_explore", &dmpc_ctx::pivot_explore},
         {"iter_cap", &dmpc_ctx::iter_cap}, {"tier1_qcap", &dmpc_ctx::tier1_env}, {"split_parts", &dmpc_ctx::split_parts}, {"no_split", &dmpc_ctx::no_split},
-        {"static_queue", &dmpc_ctx::static_queue}, {"no_split_t", &dmpc_ctx::no_split_t}, {"ext_cap", &dmpc_ctx::ext_cap}, {"nbr_grid", &dmpc_ctx::nbr_grid}, {"f32_dep_exp", &dmpc_ctx::f32_dep_exp}, {"grid_min", &dmpc_ctx::grid_min}};
+        {"static_queue", &dmpc_ctx::static_queue}, {"no_split_t", &dmpc_ctx::no_split_t}, {"ext_cap", &dmpc_ctx::ext_cap}, {"nbr_grid", &dmpc_ctx::nbr_grid}, {"f32_dep_exp", &dmpc_ctx::f32_dep_exp}, {"grid_min", &dmpc_ctx::grid_min}, {"no_level_check", &dmpc_ctx::no_level_check}};
     for (auto &t : tab)
         if (!std::strcmp(t.n, name)) {
             ctx->*(t.f) = value;
@@ -658,6 +659,7 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     P.dbg = ctx->dbg; P.dbg_agent = ctx->dbg_agent; P.dbg_cap = ctx->dbg_cap;
     P.iter_cap = ctx->iter_cap;
     P.dep_tol_f32 = std::pow(10.0, -(double)ctx->f32_dep_exp);
+    P.no_level_check = ctx->no_level_check;
     // (not for solveHardDMPC: rows at every horizon step, 3 % of the agents would qualify and every scan would pay for the test)
     P.fast_exit = (ctx->no_fast_exit || p.variant == DMPC_VAR_HARD) ? 0 : 1;
     // measured: the crash start pays for the slack-carrying variants (C4, N = 10^4: solve launch -16 %) and costs on solveHardDMPC
@@ -1362,10 +1364,10 @@ static int transition_one(dmpc_ctx *ctx, int S, int N, const double *po, const d
 static void copy_debug_options(dmpc_ctx *dst, const dmpc_ctx *src)
 {
     static const char *names[] = {"no_fuse", "no_persist", "force_persist", "no_cull", "order_slices", "cull_min", "no_lpt", "crash_min", "crash_any", "no_fast_exit",
-                                  "pivot_explore", "iter_cap", "tier1_qcap", "static_queue", "no_split_t", "ext_cap", "nbr_grid", "f32_dep_exp", "grid_min"};
+                                  "pivot_explore", "iter_cap", "tier1_qcap", "static_queue", "no_split_t", "ext_cap", "nbr_grid", "f32_dep_exp", "grid_min", "no_level_check"};
     int dmpc_ctx::*fields[] = {&dmpc_ctx::no_fuse, &dmpc_ctx::no_persist, &dmpc_ctx::force_persist, &dmpc_ctx::no_cull, &dmpc_ctx::order_slices, &dmpc_ctx::cull_min,
                                &dmpc_ctx::no_lpt, &dmpc_ctx::crash_min, &dmpc_ctx::crash_any, &dmpc_ctx::no_fast_exit, &dmpc_ctx::pivot_explore, &dmpc_ctx::iter_cap,
-                               &dmpc_ctx::tier1_env, &dmpc_ctx::static_queue, &dmpc_ctx::no_split_t, &dmpc_ctx::ext_cap, &dmpc_ctx::nbr_grid, &dmpc_ctx::f32_dep_exp, &dmpc_ctx::grid_min};
+                               &dmpc_ctx::tier1_env, &dmpc_ctx::static_queue, &dmpc_ctx::no_split_t, &dmpc_ctx::ext_cap, &dmpc_ctx::nbr_grid, &dmpc_ctx::f32_dep_exp, &dmpc_ctx::grid_min, &dmpc_ctx::no_level_check};
     for (size_t i = 0; i < sizeof(names) / sizeof(names[0]); ++i) (void)dmpc_debug_option(dst, names[i], src->*(fields[i]));
 }
 

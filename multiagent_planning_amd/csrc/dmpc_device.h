@@ -77,6 +77,7 @@ struct StepParams {
     int pivot_explore;      // development builds (DMPC_PIVOT_EXPLORE): extra pivot-weight multipliers, see dmpc_solve.hip
     int fast_exit;          // scan: finish the agents whose unconstrained minimiser is feasible (they never enter the solve queue)
     const int *live_bound;  // persistent solve kernel: queue positions from *live_bound on hold agents the scan finished (order_kernel), or null
+    int no_level_check;     // development option no_level_check: solveSoftDMPCall without the slack-free feasibility pass per ladder level (A/B runs, tests)
     double dep_tol_f32;     // fp32-factor kernels: dependence threshold on delta / s_pp (development option f32_dep_exp: 10^-n)
     int n_ext;              // persistent solve kernel with a split T: extensions in the workgroup's pool (behind the waves' blocks)
     int iter_cap;           // active-set iteration cap per try (ITER_CAP; development runs lower it to measure the per-iteration cost)

@@ -773,7 +773,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
         // replay took more than 100 iterations, up to 1 247 over 4-5 levels: 12.8 ms per step against 0.45-0.7 ms for every other variant).
         // `hp`: this pass of the loop is that check -- rows as hard constraints with right-hand side b - d slb, nothing recorded; an
         // infeasible verdict takes the ladder step exactly as a failed try would, a feasible one is followed by the real solve of the level.
-        const bool hp_variant = SOFT && var == VAR_ALL3 && violation;
+        const bool hp_variant = SOFT && var == VAR_ALL3 && violation && !P.no_level_check;
         bool hp = false, level_checked = false;
         while (tries < max_tries) {
             tries++;
@@ -983,6 +983,15 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
             }
             bool fresh = !warm && nfast == 0;   // primal == x(lambda) with refined lambda
             int since_sync = 0;
+            // Round 4 (found by the randomized campaign: one solveSoftDMPCall agent-step of 135 000 ended one ladder level late, on a level an
+            // LP shows feasible with room to spare).  An acceleration bound violated by 1.4e-9 -- drift of the incrementally updated iterate,
+            // the bound is exactly active at the vertex -- was picked as pivot, found dependent on the working set, and the ratio test then
+            // took entries of r that are pure round-off of the factor (1e-19) as blocking constraints: partial steps of 1e19, the
+            // multipliers destroyed, "infeasible".  Two guards: on a DEPENDENT pivot only entries of r above 1e-9 of its largest can block,
+            // and an infeasibility verdict reached without a step on an iterate that has not been re-derived from the multipliers since
+            // the last primal step is not believed: the iterate is re-derived and refined (`resync`), and the violations are looked at again.
+            bool x_synced = fresh, resync = false;
+            int resyncs = 0;
             bool cert_done = cert_known;   // (a level the ladder step below already put through the certificate is not tested again: 44 us a call for 26 rows)
             for (;;) {
                 if (soft && ladder && violation && !cert_done && iters - nfast >= LADDER_CERT_AFTER) {
@@ -1040,13 +1049,15 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                 }
 #undef CAND
                 const float smax = wave_max_f(bests);
-                const unsigned long long wm = __ballot(bestc >= 0 && bests == smax);
+                const bool forced = SOFT && resync;   // (re-derive the iterate first: the scan above ran on the stale one)
+                resync = false;
+                const unsigned long long wm = forced ? 0ull : __ballot(bestc >= 0 && bests == smax);
                 PH(0);
                 if (wm == 0ull) {
                     PHC(10);
-                    CLAIM_NEXT();
-                    if (!crash && (q == 0 || fresh)) break;   // optimal
-                    if (!crash && !soft && !F32T) {   // (fp32 factor: the incrementally updated iterate drifts by ~1e-7 per step -- always the full verification)
+                    if (!forced) CLAIM_NEXT();
+                    if (!crash && !forced && (q == 0 || fresh)) break;   // optimal
+                    if (!crash && !soft && !F32T && !forced) {   // (fp32 factor: the incrementally updated iterate drifts by ~1e-7 per step -- always the full verification)
                         // (slack-free variants; the slack variants carry multipliers of 1e5-1e6 and always take the full verification)
                         // No constraint is violated at the (incrementally updated) iterate.  Round-off of the factor reaches the iterate
                         // only through N_W: an error dr of r = T T's moves x by t H^-1 N_W dr, which shows in the values of the
@@ -1109,7 +1120,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                             if (!soft) dual = dual0 + 0.5 * wave_sum0(g_l * (a - a_unc));   // cost at x(lambda): f(x_unc) + 1/2 nu' H^-1 nu
                         }
                     }
-                    fresh = true;
+                    fresh = true; x_synced = true;
                     PH(6);
                     continue;
                 }
@@ -1239,7 +1250,10 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                     // ratio test on the multipliers: the blocking slot maximises r_j / lambda_j (identity 0: one bound_ctrl
                     // DPP maximum instead of a minimum with an infinity identity); t1 = 1 / max
                     const double lam_l = B[SL::SLAM + lane];
-                    const double iratio = (lane < q && ri > 0.0) ? (lam_l > 1e-300 ? fast_div(ri, lam_l) : INFINITY) : 0.0;
+                    // (slack variants only: the slack-free kernels sit at their register limit -- both guards cost the headline 8 % -- and four rounds of
+                    // campaigns have not shown the failure there: their rows are not nearly parallel triples)
+                    const double rcut = (SOFT && dependent) ? 1e-9 * wave_max0((lane < q) ? fabs(ri) : 0.0) : 0.0;   // (dependent pivot: round-off of the factor does not block)
+                    const double iratio = (lane < q && ri > rcut) ? (lam_l > 1e-300 ? fast_div(ri, lam_l) : INFINITY) : 0.0;
                     const double imax = wave_max0(iratio);
                     const double t1 = imax > 0.0 ? (imax < INFINITY ? fast_rcp(imax) : 0.0) : INFINITY;   // inf when no multiplier decreases
                     const double t = fmin(t1, t2);
@@ -1250,7 +1264,10 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                         d[0] = (double)pcode; d[1] = (double)q; d[2] = delta; d[3] = spp; d[4] = t1; d[5] = t2; d[6] = vp; d[7] = lam_p;
                     }
 #endif
-                    if (!(t < INFINITY)) { rc = 1; break; }
+                    if (!(t < INFINITY)) {
+                        if (SOFT && lam_p == 0.0 && !x_synced && resyncs < 3) { ++resyncs; resync = true; break; }   // not believed on a stale iterate
+                        rc = 1; break;
+                    }
                     if (lane < q) B[SL::SLAM + lane] -= t * ri;
                     lam_p += t;
                     if (!dependent) {
@@ -1269,6 +1286,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                         }
                         vp -= t * delta;
                         a -= t * za; w -= t * zw;
+                        if (SOFT) x_synced = false;
                         if (comp) { B[SL::A + lane] = a; B[SL::W + lane] = w; }
                         if (soft) {
                             if (owner) r_eps[mymeta >> 16] -= t * 0.5 * nue;
@@ -1304,13 +1322,14 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                     }
                     PH(4); PHC(11);
                     // partial step: drop the blocking constraint
-                    const unsigned long long bm = __ballot(lane < q && ri > 0.0 && iratio == imax);
+                    const unsigned long long bm = __ballot(lane < q && ri > rcut && iratio == imax);
                     const int l = __ffsll((long long)bm) - 1;
                     drop_slot(l, (p.ty == TY_COLL) ? p.idx : -1);
                     LSYNC();
                     PH(5);
                 }
                 if (rc) break;
+                if (SOFT && resync) continue;
                 // pin added while its collision row is not active: decoupled again -> drop both
                 if (soft && p.ty == TY_SLKU && !(r_fl[p.idx] & (RF_COLL | RF_SLKL))) {
                     const int mm = (lane < q) ? s_meta[lane] : 0;

@@ -6,7 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import multiagent_planning_amd as mp
 from multiagent_planning_amd import workload as wl, _lib
 N = 10000
-gids = [int(x) for x in sys.argv[1:]] or [17, 1234, 5000, 7777, 9001]
+gids = [int(x) for x in sys.argv[1:] if x != "top"] or [17, 1234, 5000, 7777, 9001]
+pick_top = "top" in sys.argv[1:]
 cfg = wl.CONFIGS["C4"]; kw = wl.solver_kwargs(cfg, N)
 po, pf = wl.make_scenes(cfg, 1, N, wl.SEED0 + 4)
 d = mp.Dmpc(cfg["variant"], **kw)
@@ -17,6 +18,9 @@ for k in range(2):
     ok = out["status"] == 1
     l = np.where(ok[..., None], out["p"], l); xp = np.where(ok[..., None], out["p"][..., :3], xp)
     xv = np.where(ok[..., None], out["v"][..., :3], xv); xa = np.where(ok[..., None], out["a"][..., :3], xa)
+if pick_top:   # (round 4) the agents with the most iterations of this step
+    o_ = d.step_batch(l, xp, xv, xa, pf)
+    gids = [int(g) for g in np.argsort(o_["info"][0, :, 4])[-5:][::-1]]
 L = _lib.load()
 L.dmpc_debug_trace.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
 names = ["pivot scan", "descriptor", "T T's / crash round", "resid+dir", "append/other", "drops", "verify", "ladder", "setup", "-", "-", "-", "-", "s", "T's", "ratio", "step+certs"]
