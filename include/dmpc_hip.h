@@ -90,7 +90,8 @@ enum {
 typedef struct {
     int32_t K;         /* horizon length k_hor; must be 15                                   */
     int32_t variant;   /* DMPC_VAR_*                                                         */
-    int32_t order;     /* ellipsoid order; must be 2 (the only value the reference uses)     */
+    int32_t order;     /* ellipsoid order: 2; or 4 (super-ellipsoid of test/comp_test_ellipconstr.m:158-187: dist = |E1 d|_4, E2 = E^-4) with
+                        * the all-neighbour variants DMPC_VAR_SOFTALL / _ELLIP / _REPAIR / _CPP1; refused otherwise */
     int32_t max_tries; /* <=0: reference default (30)                                        */
     double h;          /* time step                                                          */
     double rmin;       /* collision radius                                                   */

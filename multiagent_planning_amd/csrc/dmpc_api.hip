@@ -171,7 +171,9 @@ static int check_params(const dmpc_params *p, std::string &why)
 {
     if (!p) { why = "params is NULL"; return -1; }
     if (p->K != K) { why = "only K = k_hor = 15 is supported (the value every reference script uses)"; return -1; }
-    if (p->order != 2) { why = "only ellipsoid order 2 is supported (the value every reference script uses)"; return -1; }
+    if (p->order != 2 && !(p->order == 4 && (p->variant == DMPC_VAR_SOFTALL || p->variant == DMPC_VAR_ELLIP || p->variant == DMPC_VAR_REPAIR || p->variant == DMPC_VAR_CPP1))) {
+        why = "ellipsoid order must be 2, or 4 with solveSoftDMPC / solveEllipDMPC / solveSoftDMPCrepair / DMPC::solveQP (test/comp_test_ellipconstr.m:158)"; return -1;
+    }
     if (p->variant < 0 || p->variant > DMPC_VAR_CPP1) { why = "unknown variant"; return -1; }
     if (!(p->h > 0) || !(p->rmin > 0) || !(p->c > 0) || !(p->alim > 0)) { why = "h, rmin, c, alim must be positive"; return -1; }
     for (int d = 0; d < 3; ++d)
@@ -639,7 +641,8 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     if (p.variant == DMPC_VAR_HARD && (G > 256 || C >= (1 << 20)))   // packing of the scan's candidate list
         FAIL(ctx, "solveHardDMPC scan: at most 256 chunks of fewer than 2^20 agents");
     P.max_tries = p.max_tries;
-    P.h = p.h; P.rmin = p.rmin; P.e1z = 1.0 / p.c; P.e2z = 1.0 / (p.c * p.c);
+    P.ell_order = p.order;
+    P.h = p.h; P.rmin = p.rmin; P.e1z = 1.0 / p.c; P.e2z = p.order == 4 ? 1.0 / (p.c * p.c * p.c * p.c) : 1.0 / (p.c * p.c);   // E1 = E^-1, E2 = E^-order
     P.alim = p.alim; P.Q1 = p.Q1; P.S1 = p.S1; P.term = p.term;
     P.Qfar = p.Qfar > 0 ? p.Qfar : 1000.0; P.Qnear = p.Qnear > 0 ? p.Qnear : 10000.0; P.Sfree = p.Sfree > 0 ? p.Sfree : 10.0;
     for (int d = 0; d < 3; ++d) { P.pmin[d] = p.pmin[d]; P.pmax[d] = p.pmax[d]; }
@@ -661,7 +664,7 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     P.dep_tol_f32 = std::pow(10.0, -(double)ctx->f32_dep_exp);
     P.no_level_check = ctx->no_level_check;
     // (not for solveHardDMPC: rows at every horizon step, 3 % of the agents would qualify and every scan would pay for the test)
-    P.fast_exit = (ctx->no_fast_exit || p.variant == DMPC_VAR_HARD) ? 0 : 1;
+    P.fast_exit = (ctx->no_fast_exit || p.variant == DMPC_VAR_HARD || p.order == 4) ? 0 : 1;
     // measured: the crash start pays for the slack-carrying variants (C4, N = 10^4: solve launch -16 %) and costs on solveHardDMPC
     // (C2: -16 % throughput: with rows at every horizon step the bounds violated at the unconstrained minimiser are a poor guess)
     P.crash_min = (soft || ctx->crash_any) ? ctx->crash_min : 0;
@@ -799,7 +802,10 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
         const dim3 sgrid((unsigned)((total + W - 1) / W)), sblock(64u * W);
         P.lds_per_wave = (int)lds0;
         const bool fx = P.fast_exit != 0;
-        if (lTf) {
+        if (p.order == 4) {   // super-ellipsoid of order 4 (all-neighbour variants): its own scan kernels, without the unconstrained exit
+            if (lTf) { if (soft) hipLaunchKernelGGL((dmpc_scan_kernel<true, float, false, true>), sgrid, sblock, lds0 * W, st, P); else hipLaunchKernelGGL((dmpc_scan_kernel<false, float, false, true>), sgrid, sblock, lds0 * W, st, P); }
+            else { if (soft) hipLaunchKernelGGL((dmpc_scan_kernel<true, double, false, true>), sgrid, sblock, lds0 * W, st, P); else hipLaunchKernelGGL((dmpc_scan_kernel<false, double, false, true>), sgrid, sblock, lds0 * W, st, P); }
+        } else if (lTf) {
             if (soft) { if (fx) hipLaunchKernelGGL((dmpc_scan_kernel<true, float, true>), sgrid, sblock, lds0 * W, st, P); else hipLaunchKernelGGL((dmpc_scan_kernel<true, float, false>), sgrid, sblock, lds0 * W, st, P); }
             else { if (fx) hipLaunchKernelGGL((dmpc_scan_kernel<false, float, true>), sgrid, sblock, lds0 * W, st, P); else hipLaunchKernelGGL((dmpc_scan_kernel<false, float, false>), sgrid, sblock, lds0 * W, st, P); }
         } else {
@@ -1182,7 +1188,8 @@ extern "C" int dmpc_rows_one(dmpc_ctx *ctx, int N, int n, const double *l, const
     P.variant = p.variant; P.S = 1; P.G = 1; P.C = N; P.g_local = 0; P.c_first = n; P.c_count = 1;
     const long want = (p.variant == DMPC_VAR_HARD ? (long)K : (p.variant == DMPC_VAR_ALL3 ? 3L : 1L)) * (N > 1 ? N - 1 : 1);
     P.nrmax = (int)((want + 1) & ~1L);   // the exact worst case: nothing is pruned or truncated here
-    P.h = p.h; P.rmin = p.rmin; P.e1z = 1.0 / p.c; P.e2z = 1.0 / (p.c * p.c);
+    P.ell_order = p.order;
+    P.h = p.h; P.rmin = p.rmin; P.e1z = 1.0 / p.c; P.e2z = p.order == 4 ? 1.0 / (p.c * p.c * p.c * p.c) : 1.0 / (p.c * p.c);   // E1 = E^-1, E2 = E^-order
     P.alim = p.alim; P.Q1 = p.Q1; P.S1 = p.S1; P.term = p.term;
     for (int d = 0; d < 3; ++d) { P.pmin[d] = p.pmin[d]; P.pmax[d] = p.pmax[d]; }
     P.tables = ctx->d_tables; P.lT = ctx->lT.as<double>();

@@ -36,6 +36,7 @@ enum { ST_SOLVED = 1, ST_OUTBOUND = 2, ST_COLL = 4, ST_INFEAS = 8, ST_CAPACITY =
 
 struct StepParams {
     int variant, S, G, C, g_local, nrmax, max_tries, c_first, c_count, qcap;
+    int ell_order;          // super-ellipsoid order: 2, or 4 for the all-neighbour variants (softall, ellip, repair, cpp1)
     double h, rmin, e1z, e2z, alim, Q1, S1, term;
     double Qfar, Qnear, Sfree;   // weights of the collision-free cost cases (HEAD: 1000, 10000, 10)
     double pmin[3], pmax[3];

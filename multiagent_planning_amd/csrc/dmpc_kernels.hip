@@ -304,7 +304,7 @@ return empty_any;
 // register and LDS footprint free of the scan's needs (more resident agents per CU) and lets the solver be re-launched
 // for the few agents that overflow the tier-1 working-set capacity.
 // `vb`: the agent's index in the launch (already renumbered XCD-aware by the kernel); `smem`: this wave's LDS.
-template <bool SOFT, typename TT, bool FAST>
+template <bool SOFT, typename TT, bool FAST, bool ORD4 = false>
 __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, const int vb, unsigned char *smem)
 {
     const int S = P.S, G = P.G, C = P.C, nrmax = P.nrmax;
@@ -370,6 +370,11 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
     int ladder_start = 0;   // first retry-ladder level that is not certainly infeasible (soft ladder variants)
     bool rows_exist = false, violation = false;
     const bool cppv = (var == VAR_CPP || var == VAR_CPP2);   // dmpc/cpp solveQPv2 flavour (dmpc.cpp:803-1287)
+    // Super-ellipsoid of ORDER 4 (round 4; CheckCollEllipDMPC.m:7, CollConstrEllipDMPC.m:13-19 with order = 4, E1 = E^-1, E2 = E^-4 as
+    // test/comp_test_ellipconstr.m:158-187 sets them for solveSoftDMPC): dist = |E1 d|_4, xi = E2 d.^3, prev_dist = dist^3,
+    // r = dist^3 (rmin - dist) + xi.p - xi.A0 x0.  Only the variants whose scan is "any neighbour inside rmin, rows for every neighbour"
+    // (softall, ellip, repair, cpp1: the generic walk below + build_rows) take it; the API refuses the others.
+    constexpr bool ord4 = ORD4;   // (a template parameter: the order-2 kernels carry none of it)
     const bool near_sel = (var == VAR_BOUND || var == VAR_BOUND2 || var == VAR_ALL3 || var == VAR_ONDEMAND || cppv);
     const bool coll_check = (var == VAR_BOUND || var == VAR_BOUND2 || var == VAR_ALL3 || var == VAR_REPAIR);
     const bool skip_k1 = (var == VAR_BOUND2 || var == VAR_ALL3 || var == VAR_REPAIR || var == VAR_CPP2);
@@ -437,7 +442,9 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
         auto emit_row = [&](bool sel, int kc, real dx, real dy, real dz, real dist, real px, real py, real pz) {
             const real sh = (real)(kc + 1) * h_;
             const real a0x = po_[0] + sh * vo_[0], a0y = po_[1] + sh * vo_[1], a0z = po_[2] + sh * vo_[2];
-            const real x0 = dx, x1 = dy, x2 = dz * e2z;   // diff = E2*(p - pj)
+            // diff = E2*(p - pj).^(order-1); pd = prev_dist = dist^(order-1) (P.e2z = c^-order)
+            const real x0 = ord4 ? dx * dx * dx : dx, x1 = ord4 ? dy * dy * dy : dy, x2 = (ord4 ? dz * dz * dz : dz) * e2z;
+            const real pd = ord4 ? dist * dist * dist : dist;
             {
                 const unsigned long long m0 = __ballot(sel);
                 if (m0 == 0ull) return;                         // no neighbour of this chunk is close at this step
@@ -452,20 +459,20 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
                 if (!soft && sel) {
                     // the row reads  xi.w_kc >= rr  for the position offset w = Lambda a;  |w_kc| <= hw per axis
                     // (the right-hand side of the row without the reference's division: dist (xi.p / dist) = xi.p)
-                    const real rr = dist * (rmin - dist) + (x0 * px + x1 * py + x2 * pz) - (x0 * a0x + x1 * a0y + x2 * a0z);
+                    const real rr = pd * (rmin - dist) + (x0 * px + x1 * py + x2 * pz) - (x0 * a0x + x1 * a0y + x2 * a0z);
                     const real rng = (fabs(x0) + fabs(x1) + fabs(x2)) * hw;
                     if (rr - (x0 * w_s[3 * kc] + x1 * w_s[3 * kc + 1] + x2 * w_s[3 * kc + 2]) > (real)0.1 * MARG) key_steps |= 1u << kc;
                     key_tight |= (rr > 0.8 * rng) ? 8u : ((rr > 0.5 * rng) ? 4u : ((rr > 0.0) ? 2u : 1u));
                 }
                 const real lin_min = x0 * (a0x - (px - dx)) + x1 * (a0y - (py - dy)) + x2 * (a0z - (pz - dz)) - (fabs(x0) + fabs(x1) + fabs(x2)) * hw;
-                if (lin_min >= dist * rmin + MARG && !P.no_prune) sel = false;
+                if (lin_min >= pd * rmin + MARG && !P.no_prune) sel = false;
                 // Exact infeasibility certificate for rows without slack: if even the BEST point of the
                 // reachable box violates the row (max of the linearised distance < dist*rmin), no acceleration
                 // within |a| <= alim satisfies it -> the QP is infeasible; the long active-set proof is skipped.
                 if (sel) {
                     const real lin_max = lin_min + 2.0 * (fabs(x0) + fabs(x1) + fabs(x2)) * hw;
                     if (!soft) {
-                        if (lin_max < dist * rmin - MARG) cert_infeasible = true;
+                        if (lin_max < pd * rmin - MARG) cert_infeasible = true;
                     } else if (var == VAR_BOUND || var == VAR_BOUND2 || var == VAR_ALL3 || cppv) {
                         // Soft rows with a bounded slack (coefficient dist): the row needs
                         //   lin >= dist*(rmin + eps),  eps >= slb * 2^t at ladder level t (solveSoftDMPCbound.m:147-153),
@@ -482,17 +489,17 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
             const int pos = nr + lanes_below(m, lane);
             if (sel && pos < nrmax) {
                 // r = dist*(rmin - dist + diff*p/dist) - diff*A_initp(kc)*[po;vo]   (:21)
-                const real rr = dist * (rmin - dist + (x0 * px + x1 * py + x2 * pz) / dist) - (x0 * a0x + x1 * a0y + x2 * a0z);
+                const real rr = pd * (rmin - dist + (x0 * px + x1 * py + x2 * pz) / pd) - (x0 * a0x + x1 * a0y + x2 * a0z);
                 L.r_xi[3 * pos] = x0; L.r_xi[3 * pos + 1] = x1; L.r_xi[3 * pos + 2] = x2;
                 L.r_b[pos] = -rr;
                 L.r_kc[pos] = kc;
                     if (soft) {
-                    real sd = dist, st = P.term, slb = -0.05;
+                    real sd = pd, st = P.term, slb = -0.05;
                     if (var == VAR_BOUND2 || var == VAR_ALL3) slb = -0.01;           // bound2:77, all:92
                     else if (cppv) slb = -(real)0.01f;                              // dmpc.cpp:907-914,1079: -eps <= lim, float lim = 0.01
                     else if (var == VAR_SOFTALL) { sd = 1.0; st = -1e5; slb = -INFINITY; }  // solveSoftDMPC.m:21,65
                     else if (var == VAR_CPP1) { sd = 1.0; st = -1e6; slb = -INFINITY; }     // dmpc.cpp:629-633,715: [A I] x <= b, eps <= 0, f_w = -10^6
-                    else if (var == VAR_REPAIR) { st = P.term / dist; slb = -INFINITY; }    // repair:77,81
+                    else if (var == VAR_REPAIR) { st = P.term / pd; slb = -INFINITY; }      // repair:77,81 (term ./ prev_dist)
                     L.r_sd[pos] = sd; L.r_st[pos] = st; L.r_slb[pos] = slb;
                 }
             }
@@ -512,7 +519,7 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
                 const real *base = nbp + (size_t)(3 * ke) * C, *bsel = nbp + (size_t)(3 * ksel) * C;
                 const real dx = px - base[0], dy = py - base[(size_t)C], dz = pz - base[2 * (size_t)C];
                 const real ez = dz * e1z;
-                const real dist = sqrt(dx * dx + dy * dy + ez * ez);
+                const real dist = ord4 ? sqrt(sqrt(dx * dx * dx * dx + dy * dy * dy * dy + ez * ez * ez * ez)) : sqrt(dx * dx + dy * dy + ez * ez);
                 real dsel = dist;
                 if (ksel != ke && !sel_all) {
                     const real sx = qx - bsel[0], sy = qy - bsel[(size_t)C];
@@ -546,7 +553,7 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
         };
         unsigned anyb = 0;
         real mind0 = INFINITY;
-        const real rmin2_hi = rmin * rmin * ((real)1.0 + (real)4.0 * MARG);
+        const real rmin2_hi = (ord4 ? rmin * rmin * rmin * rmin : rmin * rmin) * ((real)1.0 + (real)4.0 * MARG);
         if (var == VAR_HARD) {
             // solveHardDMPC.m:18-22 + CollConstrHardDMPC.m:19: every k, neighbours with dist < 1.  Two passes.  The first
             // only tests the 15 N distances and compacts the (step, neighbour) candidates -- about one in ten -- into an
@@ -697,7 +704,8 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
                         const real px = own_s[3 * k], py = own_s[3 * k + 1], pz = own_s[3 * k + 2];
                         const real dx = px - nx[u], dy = py - ny[u], dz = pz - nz[u];
                         const real ez = dz * e1z;
-                        const real d2 = dx * dx + dy * dy + ez * ez;
+                        // (order 4: the sum of fourth powers against rmin^4; the root of the root decides)
+                        const real d2 = ord4 ? dx * dx * dx * dx + dy * dy * dy * dy + ez * ez * ez * ez : dx * dx + dy * dy + ez * ez;
                         // The IEEE square root (a dozen instructions in fp64) is taken only when some lane of the
                         // wave can pass the distance test: d2 is first compared against a slightly inflated squared
                         // threshold (a superset), the exact `norm(...) < r` decision is then made on sqrt(d2) itself.
@@ -705,7 +713,7 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
                             // (the empty asm keeps this a BRANCH: the compiler turned the wave-uniform test into selects and ran the 25
                             // instructions of the IEEE root for every step of every neighbour -- 800 of the 3 000 instructions of an agent's scan)
                             asm volatile("");
-                            const real dist = sqrt(d2);
+                            const real dist = ord4 ? sqrt(sqrt(d2)) : sqrt(d2);
                             if (valid && dist < rmin) anyb |= (1u << k);       // CheckCollSoftDMPC.m:11
                         }
                         if (k == 0 && valid) mind0 = fmin(mind0, d2);           // squared; the root is taken once below
@@ -723,6 +731,7 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
                 if (var == VAR_ALL3) violation = true;   // solveSoftDMPCall.m:22 (some_violation)
                 if ((coll_check || cppv) && k == 0) {
                     mind0 = sqrt((real)wave_min((double)mind0));   // min of the roots == root of the min (sqrt is monotone)
+                    if (ord4) mind0 = sqrt(mind0);                // (order 4: the walk accumulated sums of fourth powers)
                     if (coll_check && mind0 < rmin - 0.05) { status = ST_COLL; viol_k = 1; break; }   // :25-31
                     // cpp: `dist < _rmin - _collision_tol` (floats) raises execution_ended, the build goes on (dmpc.cpp:419-424)
                     if (cppv && mind0 < (real)((float)rmin - 0.05f)) coll_flag = true;
@@ -867,7 +876,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char dmpc_smem[];
 // XCD-aware mapping: workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8, private L2 each), so they are
 // renumbered such that every XCD works on whole scenes: a scene's prediction table is then fetched into ONE L2 instead of
 // eight.  Pure performance remap (a bijection on [0, gridDim)).
-template <bool SOFT, typename TT, bool FAST>
+template <bool SOFT, typename TT, bool FAST, bool ORD4 = false>
 __global__ __launch_bounds__(64 * SCAN_WAVES_PER_WG, SCAN_WAVES_PER_SIMD) void dmpc_scan_kernel(StepParams P)
 {
     const int W = (int)(blockDim.x >> 6);
@@ -878,7 +887,7 @@ __global__ __launch_bounds__(64 * SCAN_WAVES_PER_WG, SCAN_WAVES_PER_SIMD) void d
     const int agent = (off + y) * W + wave, total = P.S * P.c_count;
     if (P.zero4 && blockIdx.x == 0 && threadIdx.x < 4) P.zero4[threadIdx.x] = 0;   // (nothing reads them before the order / solve kernels of this step)
     if (agent >= total) return;
-    scan_body<SOFT, TT, FAST>(P, lane, agent, dmpc_smem + (size_t)wave * P.lds_per_wave);
+    scan_body<SOFT, TT, FAST, ORD4>(P, lane, agent, dmpc_smem + (size_t)wave * P.lds_per_wave);
 }
 // Solve phase, one agent per 64-thread workgroup (shallow launches: bound by their slowest agent)
 template <bool SOFT, int QCAP, typename TF = double>

@@ -401,6 +401,20 @@ static double edist(const double *p, const double *pj, double c)
     double dx = p[0] - pj[0], dy = p[1] - pj[1], dz = (p[2] - pj[2]) / c;
     return sqrt(dx * dx + dy * dy + dz * dz);
 }
+/* norm(E1*(p - pj), order) for the super-ellipsoid of order 4 (CheckCollEllipDMPC.m:7, test/comp_test_ellipconstr.m:158-163) */
+static double edist_o(const double *p, const double *pj, double c, int order)
+{
+    if (order == 2) return edist(p, pj, c);
+    double dx = p[0] - pj[0], dy = p[1] - pj[1], dz = (p[2] - pj[2]) / c;
+    return sqrt(sqrt(dx * dx * dx * dx + dy * dy * dy * dy + dz * dz * dz * dz));
+}
+/* order 4 exists for the variants whose scan is CheckCollEllipDMPC + rows for every neighbour (the one script of the reference that sets
+ * order = 4, test/comp_test_ellipconstr.m:158-187, calls solveSoftDMPC) */
+static int order_ok(const orc_params *prm)
+{
+    if (prm->order == 2) return 1;
+    return prm->order == 4 && (prm->variant == ORC_SOFTALL || prm->variant == ORC_ELLIP || prm->variant == ORC_REPAIR || prm->variant == ORC_CPP1);
+}
 
 typedef struct {
     int nrows;      /* number of collision rows */
@@ -433,6 +447,33 @@ static void build_row(const ctx_t *c, const orc_params *prm, const double *l, in
     const double *p = &l[(size_t)n * n3 + 3 * (ke - 1)];
     const double *pj = &l[(size_t)j * n3 + 3 * (ke - 1)];
     const double cc = prm->c;
+    if (prm->order == 4) {
+        /* CollConstrEllipDMPC.m:13-19 with order = 4, E1 = E^-1, E2 = E^-4 (comp_test_ellipconstr.m:160-163):
+         *   dist = norm(E1*(p-pj),4); diff = (E2*(p-pj).^3)'; prev_dist = dist^3;
+         *   r = dist^3*(rmin - dist + diff*p/dist^3) - diff*A_initp(3(kc-1)+1:3kc,:)*[po';vo'] */
+        const double dist4 = edist_o(p, pj, cc, 4), pd = dist4 * dist4 * dist4, c4 = cc * cc * cc * cc;
+        const double d0 = p[0] - pj[0], d1 = p[1] - pj[1], d2 = p[2] - pj[2];
+        const double df[3] = {d0 * d0 * d0, d1 * d1 * d1, d2 * d2 * d2 / c4};
+        const double dp4 = df[0] * p[0] + df[1] * p[1] + df[2] * p[2];
+        double da4 = 0.0;
+        for (int t = 0; t < 3; ++t) {
+            const double *a0 = &c->A0[(size_t)(3 * (kc - 1) + t) * 6];
+            double s = 0.0;
+            for (int u = 0; u < 6; ++u) s += a0[u] * x0[u];
+            da4 += df[t] * s;
+        }
+        const double r4 = pd * (prm->rmin - dist4 + dp4 / pd) - da4;
+        rows_push(R, n3);
+        double *g4 = &R->G[(size_t)(R->nrows - 1) * n3];
+        for (int jj = 0; jj < n3; ++jj) {
+            double s = 0.0;
+            for (int t = 0; t < 3; ++t) s += df[t] * c->Lam[(size_t)(3 * (kc - 1) + t) * n3 + jj];
+            g4[jj] = -s;
+        }
+        R->b[R->nrows - 1] = -r4;
+        R->dist[R->nrows - 1] = pd;   /* prev_dist = dist^(order-1) */
+        return;
+    }
     double dist = edist(p, pj, cc);
     double diff[3] = {(p[0] - pj[0]), (p[1] - pj[1]), (p[2] - pj[2]) / (cc * cc)};
     double dp = diff[0] * p[0] + diff[1] * p[1] + diff[2] * p[2];
@@ -512,7 +553,7 @@ static scan_t scan_and_rows(const ctx_t *c, const orc_params *prm, int N, int n,
         for (int j = 0; j < N; ++j) {
             sel[j] = 0;
             if (j == n) continue;
-            double d = edist(&own[3 * (k - 1)], &l[(size_t)j * n3 + 3 * (k - 1)], prm->c);
+            double d = edist_o(&own[3 * (k - 1)], &l[(size_t)j * n3 + 3 * (k - 1)], prm->c, prm->order);
             if (d < rmin) any = 1;               /* CheckCollSoftDMPC.m:11 */
             if (d < mind) mind = d;
             /* CheckCollSoftDMPC.m:12; cpp: viol_constr = dist < _rmin*(1+(float)k/_k_hor), float arithmetic, k 0-based
@@ -783,7 +824,7 @@ int orc_solve_one(const orc_params *prm, int N, int n, const double *l, const do
                   const double vo[3], const double ao[3], const double pf[3], double *p, double *v,
                   double *a, int *info, double *obj)
 {
-    if (prm->order != 2 || prm->K < 1 || prm->K > MAXK) return -1;
+    if (!order_ok(prm) || prm->K < 1 || prm->K > MAXK) return -1;
     ctx_t *c = ctx_new(prm->h, prm->K);
     int st = solve_ctx(c, prm, N, n, l, po, vo, ao, pf, p, v, a, info, obj);
     ctx_free(c);
@@ -815,7 +856,7 @@ int orc_step(const orc_params *prm, int N, const double *l, const double *x_p, c
              const double *x_a, const double *pf, double *p, double *v, double *a, int *status,
              int *info, double *obj, int nthreads)
 {
-    if (prm->order != 2 || prm->K < 1 || prm->K > MAXK) return -1;
+    if (!order_ok(prm) || prm->K < 1 || prm->K > MAXK) return -1;
     if (nthreads < 1) nthreads = 1;
     if (nthreads > N) nthreads = N > 0 ? N : 1;
     ctx_t *c = ctx_new(prm->h, prm->K);
@@ -843,7 +884,7 @@ int orc_eval_one(const orc_params *prm, int N, int n, const double *l, const dou
                  const double vo[3], const double ao[3], const double pf[3], const double *acc,
                  double *obj, double *maxviol)
 {
-    if (prm->order != 2 || prm->K < 1 || prm->K > MAXK) return -1;
+    if (!order_ok(prm) || prm->K < 1 || prm->K > MAXK) return -1;
     ctx_t *c = ctx_new(prm->h, prm->K);
     const int n3 = c->n3;
     double x0[6] = {po[0], po[1], po[2], vo[0], vo[1], vo[2]};
@@ -897,7 +938,7 @@ out:
 int orc_rows_one(const orc_params *prm, int N, int n, const double *l, const double po[3], const double vo[3],
                  int max_rows, double *G, double *b, double *dist, int *nrows, int *viol_k, int *status)
 {
-    if (prm->order != 2 || prm->K < 1 || prm->K > MAXK) return -1;
+    if (!order_ok(prm) || prm->K < 1 || prm->K > MAXK) return -1;
     ctx_t *c = ctx_new(prm->h, prm->K);
     double x0[6] = {po[0], po[1], po[2], vo[0], vo[1], vo[2]};
     rows_t R;
@@ -924,7 +965,7 @@ int orc_assemble_one(const orc_params *prm, int N, int n, const double *l, const
                      const double ao[3], const double pf[3], int level, int *n_out, int *m_out, int *ncoll_out,
                      double *H, double *f, double *C, double *d)
 {
-    if (prm->order != 2 || prm->K < 1 || prm->K > MAXK) return -1;
+    if (!order_ok(prm) || prm->K < 1 || prm->K > MAXK) return -1;
     ctx_t *c = ctx_new(prm->h, prm->K);
     const int n3 = c->n3;
     double x0[6] = {po[0], po[1], po[2], vo[0], vo[1], vo[2]};
@@ -991,7 +1032,7 @@ static void *scene_worker(void *arg)
 int orc_step_scenes(const orc_params *prm, int S, int N, const double *l, const double *x_p, const double *x_v, const double *x_a,
                     const double *pf, double *p, double *v, double *a, int *status, int *info, int nthreads)
 {
-    if (prm->order != 2 || prm->K < 1 || prm->K > MAXK || S < 1) return -1;
+    if (!order_ok(prm) || prm->K < 1 || prm->K > MAXK || S < 1) return -1;
     if (nthreads < 1) nthreads = 1;
     if (nthreads > S) nthreads = S;
     /* the dense QP of every solve is allocated and freed (as the reference's scripts do): keep those blocks in the per-thread

@@ -49,7 +49,7 @@ enum {
 typedef struct {
     int K;          /* horizon length k_hor (15)                         */
     int variant;    /* ORC_*                                             */
-    int order;      /* ellipsoid order; only 2 is supported              */
+    int order;      /* ellipsoid order: 2; 4 for the all-neighbour variants (softall, ellip, repair, cpp1) */
     int max_tries;  /* <=0: reference default (30; repair: 10; cpp: 21)  */
     double h;       /* time step                                         */
     double rmin;    /* collision radius                                  */

@@ -78,9 +78,9 @@ def _f(a):
 
 
 def make_params(variant, K=15, h=0.2, rmin=0.35, c=2.0, alim=1.0, Q1=1000.0, S1=100.0, term=-5e4,
-                pmin=(-2.5, -2.5, 0.2), pmax=(2.5, 2.5, 2.2), max_tries=0, Qfar=0.0, Qnear=0.0, Sfree=0.0):
+                pmin=(-2.5, -2.5, 0.2), pmax=(2.5, 2.5, 2.2), max_tries=0, Qfar=0.0, Qnear=0.0, Sfree=0.0, order=2):
     p = Params()
-    p.K, p.variant, p.order, p.max_tries = K, VARIANTS[variant] if isinstance(variant, str) else variant, 2, max_tries
+    p.K, p.variant, p.order, p.max_tries = K, VARIANTS[variant] if isinstance(variant, str) else variant, int(order), max_tries
     p.h, p.rmin, p.c, p.alim, p.Q1, p.S1, p.term = h, rmin, c, alim, Q1, S1, term
     p.Qfar, p.Qnear, p.Sfree = Qfar, Qnear, Sfree
     for i in range(3):

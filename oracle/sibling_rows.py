@@ -17,6 +17,31 @@ def _geom(p, pj, E1, E2):
     return dist, diff
 
 
+def CollConstrEllipDMPC_order(p, po, vo, n, k, l, rmin, Ain, A_initp, E1, E2, order):
+    """CollConstrEllipDMPC.m:1-30 literally, for ANY order (2 or 4: test/comp_test_ellipconstr.m:158-163 sets order = 4, E2 = E^-4):
+    dist = norm(E1*(p-pj(:,k)),order); diff = (E2*(p-pj(:,k)).^(order-1))'; prev_dist = dist^(order-1);
+    r = dist^(order-1)*(rmin - dist + diff*p/(dist^(order-1))) - diff*A_initp(3*(k-1)+1:3*k,:)*[po';vo']"""
+    p, po, vo = (np.ravel(x).astype(float) for x in (p, po, vo))
+    l = np.asarray(l, float)
+    N_obs, K = l.shape[2], l.shape[1]
+    Ain_total = np.zeros((N_obs - 1, 3 * K)); bin_total = np.zeros((N_obs - 1, 1)); prev_dist = np.zeros((N_obs - 1, 1))
+    idx = 0
+    for i in range(1, N_obs + 1):
+        if i != n:
+            pj = l[:, :, i - 1]
+            d = p - pj[:, k - 1]
+            dist = np.linalg.norm(E1 @ d, order)
+            diff = E2 @ (d ** (order - 1))
+            pd = dist ** (order - 1)
+            r = pd * (rmin - dist + diff @ p / pd) - diff @ A_initp[3 * (k - 1):3 * k, :] @ np.r_[po, vo]
+            diff_mat = np.r_[np.zeros(3 * (k - 1)), diff, np.zeros(3 * (K - k))]
+            Ain_total[idx] = -diff_mat @ Ain
+            bin_total[idx] = -r
+            prev_dist[idx] = pd
+            idx += 1
+    return Ain_total, bin_total, prev_dist
+
+
 def CollConstr(p, po, k, l, Ain, rmin, E1, E2, order=2):
     assert order == 2
     p, po = np.ravel(p).astype(float), np.ravel(po).astype(float)

@@ -178,3 +178,33 @@ def test_cpp_first_version_semantics():
     xv = np.array([[0.3, 0.0, 0.0], [0.0, 0.0, 0.0]])
     out = mp.Dmpc("cpp1", **kwc).step_batch(init_table(po, pf), po, xv, z[:2], pf)
     assert not (out["status"] & mp.ST_OUTBOUND).any()
+
+
+@pytest.mark.parametrize("variant", ["softall", "ellip", "repair", "cpp1"])
+def test_super_ellipsoid_of_order_4(variant):
+    """order = 4 (test/comp_test_ellipconstr.m:158-187 runs solveSoftDMPC with E1 = E^-1, E2 = E^-4): dist = |E1 d|_4, xi = E2 d.^3,
+    prev_dist = dist^3 in scan and rows of the all-neighbour variants.  GPU against the oracle (whose order-4 rows are checked against a
+    literal numpy restatement of CollConstrEllipDMPC.m in tests/test_oracle_golden.py) on a congested recorded scene and on random C3 / C5
+    scenes, several teacher-forced steps; the other variants refuse order 4."""
+    from helpers import load_golden, step14_inputs
+    g, kw = load_golden("comp_kctr_3_bound2")
+    l, xp, xv, xa, pf = step14_inputs(g)
+    tol = {"ellip": 1e-9, "cpp1": 5e-7}.get(variant, 2e-8)   # (slack penalties of 1e5 / 1e6: the allowance scales with them, DESIGN.md section 2)
+    out = mp.Dmpc(variant, order=4, **kw).step_batch(l, xp, xv, xa, pf)
+    ref = orc.step(orc.make_params(variant, order=4, **kw), l, xp, xv, xa, pf, nthreads=8)
+    compare_to_oracle(out, ref, tol, f"{variant} order 4 (recorded scene)")
+    o2 = mp.Dmpc(variant, **kw).step_batch(l, xp, xv, xa, pf)
+    assert (out["info"][:, 1] > 0).any() and not np.array_equal(out["p"], o2["p"])          # rows were built, and they are not the order-2 rows
+    cfg = wl.CONFIGS["C5"]; N = 60
+    kw5 = wl.solver_kwargs(cfg, N)
+    po, pf5 = wl.make_scenes(cfg, 1, N, wl.SEED0 + 77); po, pf5 = po[0], pf5[0]
+    d, prm = mp.Dmpc(variant, order=4, **kw5), orc.make_params(variant, order=4, **kw5)
+    l5 = init_table(po, pf5); xp5, xv5, xa5 = po.copy(), np.zeros_like(po), np.zeros_like(po)
+    for k in range(4):
+        o = d.step_batch(l5, xp5, xv5, xa5, pf5); r = orc.step(prm, l5, xp5, xv5, xa5, pf5)
+        compare_to_oracle(o, r, tol, f"{variant} order 4 C5 step {k + 2}")
+        ok = o["status"] == 1
+        l5 = np.where(ok[:, None], o["p"], l5); xp5 = np.where(ok[:, None], o["p"][:, :3], xp5)
+        xv5 = np.where(ok[:, None], o["v"][:, :3], xv5); xa5 = np.where(ok[:, None], o["a"][:, :3], xa5)
+    with pytest.raises(Exception, match="order"):
+        mp.Dmpc("bound", order=4, **kw)

@@ -209,3 +209,29 @@ def test_postcheck_tree_search_equals_literal_pair_loop():
         r2 = PC.postcheck(p, v, a, p[:, -1], 0.2, 0.35, 2.0, pairs="tree")
         assert abs(r1["min_dist"] - r2["min_dist"]) < 1e-13 and r1["violation"] == r2["violation"]
         assert np.array_equal(r1["p"], r2["p"])
+
+
+def test_order_4_rows_of_the_oracle_follow_CollConstrEllipDMPC_literally():
+    """the oracle's order-4 branch (super-ellipsoid of test/comp_test_ellipconstr.m:158-163) against a literal numpy restatement of
+    CollConstrEllipDMPC.m:1-30 for any order (oracle/sibling_rows.py); order 2 through the same restatement as a control.  Parity
+    unpinned: the reference holds no record of an order-4 run."""
+    from oracle import sibling_rows as sr
+    g, kw = load_golden("comp_kctr_3_bound2")
+    l, xp, xv = g["l"], g["pk"][:, 12], g["vk"][:, 12]
+    N = l.shape[0]
+    Lam, Av, A0, Dl = orc.model_matrices(kw["h"], 15)
+    lm = l.reshape(N, 15, 3).transpose(2, 1, 0)
+    for order in (2, 4):
+        prm = orc.make_params("ellip", order=order, **kw)
+        E1 = np.diag([1, 1, 1 / kw["c"]]); E2 = np.linalg.matrix_power(E1, order)
+        checked = 0
+        for n in range(0, N, 3):
+            r = orc.rows_one(prm, l, n, xp[n], xv[n])
+            if r["nrows"] == 0:
+                continue
+            k = r["viol_k"]
+            A, b, pd = sr.CollConstrEllipDMPC_order(lm[:, k - 1, n], xp[n], xv[n], n + 1, k, lm, kw["rmin"], Lam, A0, E1, E2, order)
+            assert np.abs(np.asarray(r["b"]) - b[:, 0]).max() < 1e-11 and np.abs(np.asarray(r["dist"]) - pd[:, 0]).max() < 1e-12
+            assert np.abs(np.asarray(r["G"]).reshape(-1, 45) - A).max() < 1e-11
+            checked += 1
+        assert checked > 10

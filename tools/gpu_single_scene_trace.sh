@@ -1,9 +1,9 @@
 #!/bin/bash
 # development: kernel trace of ONE 100-agent scene in closed loop (where do the microseconds of a step go)
 REPO=$(pwd); OUT=$REPO/gpurun_out/single_trace; rm -rf "$OUT"; mkdir -p "$OUT"
-cd /tmp && export TMPDIR=/tmp
+export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o ss -- python $REPO/tools/gpu_single_scene.py > "$OUT/log.txt" 2>&1
-cd $REPO
+cd "$REPO"
 tail -3 "$OUT/log.txt"
 head -12 "$OUT/ss_kernel_stats.csv" | cut -c1-200
 python3 - <<'PY'
