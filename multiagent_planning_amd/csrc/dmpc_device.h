@@ -110,10 +110,10 @@ inline size_t scan_lds_bytes() { return (96 * 8 + (size_t)SCAN_CAND_CAP * 4 + 15
 // working set outgrows them takes one of the workgroup's EXTENSIONS (columns tsplit .. qcap-1, ext_doubles) from a small pool
 inline size_t solve_lds_bytes(int nrmax, bool soft, int qcap, bool persist, int tsplit = 0, bool f32_factor = false)
 {
-    size_t dbl = (f32_factor ? ((size_t)t_doubles(qcap) + 1) / 2 : (size_t)t_doubles(tsplit > 0 ? tsplit : qcap)) + 2 * 48 + 2 * 64 + (soft ? 2 * 48 : 48) + 5 * (size_t)qcap + (soft ? (size_t)qcap : 0) + (size_t)qcap / 2;
+    size_t dbl = (f32_factor ? ((size_t)t_doubles(qcap) + 1) / 2 : (size_t)t_doubles(tsplit > 0 ? tsplit : qcap)) + 2 * 48 + 2 * 64 + 48 + 5 * (size_t)qcap + (soft ? (size_t)qcap : 0) + (size_t)qcap / 2;
     if (!persist) dbl += TAB_CASE_DOUBLES + TAB_L_DOUBLES + 1;
     if (soft) dbl += (size_t)nrmax;                 // r_eps
-    const size_t bytes = dbl * 8 + (soft ? (size_t)nrmax : (((size_t)nrmax + 31) / 32) * 4);   // + row flags (soft: a byte per row; slack-free: a bit)
+    const size_t bytes = dbl * 8 + (soft ? 4 * (size_t)nrmax : (((size_t)nrmax + 31) / 32) * 4);   // + row flags (soft: a byte per row + three bytes of slot map; slack-free: a bit)
     return (bytes + 15) & ~(size_t)15;
 }
 // persistent solve kernel: the tables at the front of the workgroup's LDS, then 16 bytes of pool header (bit mask of the free T extensions)

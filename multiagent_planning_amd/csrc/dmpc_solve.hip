@@ -39,8 +39,10 @@ struct SolveLds {   // offsets in doubles from the wave's LDS base
     static constexpr int XS = RR + 64;
     // slack-free variants: Y lives where x (the input of T'x) was, nu where r was -- both are dead by then; the slack
     // bookkeeping of the soft variants still reads r after nu is written, so they keep separate vectors
-    static constexpr int Y = SOFT ? XS + 64 : XS;
-    static constexpr int NU = SOFT ? Y + 48 : RR;
+    // (round 4: Y over x for the slack variants too -- what their bookkeeping still reads after nu is written is r, not x; the 48 doubles pay
+    // for the rows' slot maps, so that eight slack waves still fit a CU next to the tables)
+    static constexpr int Y = XS;
+    static constexpr int NU = SOFT ? XS + 64 : RR;
     static constexpr int SVEC = SOFT ? NU + 48 : XS + 64;
     static constexpr int SD = SVEC + 3 * QCAP;
     static constexpr int SLAM = SD + QCAP;
@@ -196,7 +198,8 @@ __device__ __forceinline__ double t_mul2(const double *B, int lane, int q, const
 // delete slot l: Givens rotations on adjacent columns zero row l of T left-to-right; row l and the last column drop out.
 // Fused with the row deletion (each lane carries its row of the "current right column" in a register).
 template <bool SOFT, int QCAP, bool PERSIST, int TS = QCAP, typename TF = double>
-__device__ __forceinline__ void remove_slot2(double *B, int lane, int &q, int l, unsigned &cslot, unsigned long long &cm, const int xo = 0)
+__device__ __forceinline__ void remove_slot2(double *B, int lane, int &q, int l, unsigned &cslot, unsigned long long &cm, const int xo = 0,
+                                             unsigned char *rmap = nullptr /* slack kernels: the rows' slot maps [3][nrm] (collision / eps <= 0 / eps >= slb) */, const int nrm = 0)
 {
     using SL = SolveLds<SOFT, QCAP, PERSIST, TS, TF>;
     TF *T = (TF *)(B + SL::T);
@@ -261,6 +264,10 @@ __device__ __forceinline__ void remove_slot2(double *B, int lane, int &q, int l,
     if (lane < ((q + 7) & ~7)) T[tc(q - 1) + lane] = (TF)0.0;
     const bool mv = lane > l && lane < q;
     double v0 = 0, v1 = 0, v2 = 0, ss = 0, d = 0, lam = 0; int meta = 0;
+    if (SOFT && lane == l && B[SL::SSS + l] != 0.0) {   // the removed slot leaves its row's map
+        const int ml = s_meta[l], tl = (ml >> 8) & 0xff;
+        if (tl >= TY_COLL) rmap[(size_t)(tl - TY_COLL) * nrm + (ml >> 16)] = 0xff;
+    }
     if (mv) {
         v0 = B[SL::SVEC + 3 * lane]; v1 = B[SL::SVEC + 3 * lane + 1]; v2 = B[SL::SVEC + 3 * lane + 2];
         d = B[SL::SD + lane]; lam = B[SL::SLAM + lane]; meta = s_meta[lane];
@@ -271,7 +278,11 @@ __device__ __forceinline__ void remove_slot2(double *B, int lane, int &q, int l,
         const int t = lane - 1;
         B[SL::SVEC + 3 * t] = v0; B[SL::SVEC + 3 * t + 1] = v1; B[SL::SVEC + 3 * t + 2] = v2;
         B[SL::SD + t] = d; B[SL::SLAM + t] = lam; s_meta[t] = meta;
-        if (SOFT) B[SL::SSS + t] = ss;
+        if (SOFT) {
+            B[SL::SSS + t] = ss;
+            const int tm = (meta >> 8) & 0xff;
+            if (ss != 0.0 && tm >= TY_COLL) rmap[(size_t)(tm - TY_COLL) * nrm + (meta >> 16)] = (unsigned char)t;   // (it moved down by one)
+        }
     }
     q -= 1;
     LSYNC();
@@ -552,6 +563,16 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
     double *r_eps = B + SL::VAR;                                                   // soft variants: nrmax doubles
     unsigned char *r_fl = (unsigned char *)(B + SL::VAR + (soft ? nrmax : 0));     // soft variants: nrmax bytes of flags; slack-free: nrmax BITS
     unsigned *r_bits = (unsigned *)r_fl;   // (their only flag is RF_COLL; 80 instead of 640 bytes per wave: a ninth persistent wave fits the CU's LDS)
+    // Slack kernels, round 4: per row the working-set slot of its collision constraint, of its pin eps <= 0 and of its bound eps >= slb
+    // (0xff: none; only slots with a slack coefficient are entered).  The slack part of the residual used to be found by every lane
+    // walking ALL slack-carrying slots of the working set one after the other (20-30 dependent LDS round trips per iteration for an
+    // agent of the 10^4-agent scene: a quarter of its iteration); with the maps a slot's lane reads the up to three slots of its own row.
+    unsigned char *m_row = r_fl + nrmax;   // [3][nrmax]
+    auto row_slots = [&](int row, int &s0, int &s1, int &s2) {   // ascending (the order of the sums they replace), 0xff last
+        const int a = m_row[row], b = m_row[nrmax + row], c = m_row[2 * nrmax + row];
+        const int lo = a < b ? a : b, hi = a < b ? b : a;
+        s0 = lo < c ? lo : c; s2 = hi > c ? hi : c; s1 = lo > c ? lo : (hi < c ? hi : c);
+    };
     int *s_meta = (int *)(B + SL::META);
     // collision rows: per-agent slice of the global scratch written by the scan kernel (lane = row: coalesced)
     const size_t per = (size_t)nrmax * (soft ? 7 : 4);
@@ -782,7 +803,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
             int iters = 0;
             if (!warm) {
                 q = 0; cslot = 0x0000ffffu; cm = 0ull; rcfl = 0; nlive = 0;
-                if (soft) { for (int i = lane; i < nr; i += 64) r_fl[i] = 0; }
+                if (soft) { for (int i = lane; i < nr; i += 64) { r_fl[i] = 0; m_row[i] = 0xff; m_row[nrmax + i] = 0xff; m_row[2 * nrmax + i] = 0xff; } }
                 else { for (int i = lane; i < ((nr + 31) >> 5); i += 64) r_bits[i] = 0u; }
                 a = a_unc; w = SOFT ? w_unc : (comp ? B[SL::WU + lane] : 0.0);
                 if (comp) { B[SL::A + lane] = a; B[SL::W + lane] = w; }
@@ -896,11 +917,15 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                     }
                     const bool mine = (smk >> lane) & 1ull;
                     const int myrow = mine ? (s_meta[lane] >> 16) : -1;
-                    bool owner = mine;
+                    bool owner = false;
                     double acc = 0.0;
-                    for (unsigned long long m = smk; m; m &= m - 1) {
-                        const int j = __ffsll((long long)m) - 1;
-                        if ((s_meta[j] >> 16) == myrow) { acc += B[SL::RR + j] * B[SL::SSS + j]; if (j < lane) owner = false; }
+                    if (mine) {
+                        int s0, s1, s2;
+                        row_slots(myrow, s0, s1, s2);
+                        acc += B[SL::RR + s0] * B[SL::SSS + s0];
+                        if (s1 != 0xff) acc += B[SL::RR + s1] * B[SL::SSS + s1];
+                        if (s2 != 0xff) acc += B[SL::RR + s2] * B[SL::SSS + s2];
+                        owner = lane == s0;
                     }
                     if (owner) r_eps[myrow] = -0.5 * (r_st[myrow] + acc);
                 }
@@ -943,7 +968,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                         if (soft) r_fl[didx] &= ~bit; else r_bits[didx >> 5] &= ~(1u << (didx & 31));
                     }
                 }
-                remove_slot2<SOFT, QCAP, PERSIST, TS, TF>(B, lane, q, l, cslot, cm, xo);
+                remove_slot2<SOFT, QCAP, PERSIST, TS, TF>(B, lane, q, l, cslot, cm, xo, m_row, nrmax);
                 if (soft && dty == TY_COLL && didx != keep_row) {
                     const int fl = r_fl[didx];
                     if ((fl & RF_LIVE) && (fl & RF_SLKU) && !(fl & RF_SLKL)) {
@@ -952,7 +977,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                         const int ul = __ffsll((long long)um) - 1;
                         LSYNC();
                         if (lane == 0) { r_fl[didx] = 0; r_eps[didx] = 0.0; }
-                        remove_slot2<SOFT, QCAP, PERSIST, TS, TF>(B, lane, q, ul, cslot, cm, xo);
+                        remove_slot2<SOFT, QCAP, PERSIST, TS, TF>(B, lane, q, ul, cslot, cm, xo, m_row, nrmax);
                         nlive--;
                     }
                 }
@@ -1105,7 +1130,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                                 while (neg != 0ull) {
                                     const int l = 63 - __clzll((long long)neg);
                                     neg &= ~(1ull << l);
-                                    remove_slot2<SOFT, QCAP, PERSIST, TS, TF>(B, lane, q, l, cslot, cm, xo);
+                                    remove_slot2<SOFT, QCAP, PERSIST, TS, TF>(B, lane, q, l, cslot, cm, xo, m_row, nrmax);
                                 }
                             } else drop_slot(63 - __clzll((long long)neg), -1);   // any kind of slot (and maybe its pin): one per pass
 #ifdef DMPC_DEV_TRACE
@@ -1162,7 +1187,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                     if (q >= QCAP - 1) { rc = 2; break; }
                     const Cd u = slack_desc(TY_SLKU, p.idx);
                     if (lane < ((q + 8) & ~7)) ((TF *)(B + SL::T))[tcol(q) + lane] = (TF)((lane == q) ? 1.4142135623730951 : 0.0);
-                    if (lane == 0) r_fl[p.idx] |= (RF_LIVE | RF_SLKU);
+                    if (lane == 0) { r_fl[p.idx] |= (RF_LIVE | RF_SLKU); m_row[nrmax + p.idx] = (unsigned char)q; }
                     nlive++;
                     write_slot(u, -r_st[p.idx]);
                     q++;
@@ -1230,14 +1255,16 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                     if (soft) {
                         const bool mine = (smk >> lane) & 1ull;
                         const int myrow = mine ? (mymeta >> 16) : -1;
-                        owner = mine;
-                        if (mine && p.si == myrow) nue += p.ss;
-                        for (unsigned long long m = smk; m; m &= m - 1) {
-                            const int j = __ffsll((long long)m) - 1;
-                            const int rj = s_meta[j] >> 16;
-                            if (rj == myrow) { nue -= B[SL::RR + j] * B[SL::SSS + j]; if (j < lane) owner = false; }
-                            if (rj == p.si) p_row_has_slot = true;
+                        if (mine) {
+                            int s0, s1, s2;
+                            row_slots(myrow, s0, s1, s2);
+                            if (p.si == myrow) nue += p.ss;
+                            nue -= B[SL::RR + s0] * B[SL::SSS + s0];
+                            if (s1 != 0xff) nue -= B[SL::RR + s1] * B[SL::SSS + s1];
+                            if (s2 != 0xff) nue -= B[SL::RR + s2] * B[SL::SSS + s2];
+                            owner = lane == s0;
                         }
+                        if (p.si >= 0) p_row_has_slot = (m_row[p.si] & m_row[nrmax + p.si] & m_row[2 * nrmax + p.si]) != 0xff;
                         if (owner) part += 0.5 * nue * nue;
                         if (p.si >= 0 && !p_row_has_slot && lane == 63) part += 0.5 * p.ss * p.ss;
                     }
@@ -1310,7 +1337,8 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                             if (!soft && p.idx < 64 * RC) { if (lane == (p.idx & 63)) rcfl |= 1u << (p.idx >> 6); }
                             else if (lane == 0) {
                                 const int bit = (p.ty == TY_COLL) ? RF_COLL : (p.ty == TY_SLKU ? RF_SLKU : RF_SLKL);
-                                if (soft) r_fl[p.idx] |= bit; else r_bits[p.idx >> 5] |= 1u << (p.idx & 31);
+                                if (soft) { r_fl[p.idx] |= bit; if (p.ss != 0.0) m_row[(size_t)(p.ty - TY_COLL) * nrmax + p.idx] = (unsigned char)q; }
+                                else r_bits[p.idx >> 5] |= 1u << (p.idx & 31);
                             }
                             if (p.ty == TY_COLL && comp && k_l == p.gi - 15) cm |= 1ull << q;
                         }
@@ -1337,7 +1365,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                     const int ul = __ffsll((long long)um) - 1;
                     LSYNC();
                     if (lane == 0) { r_fl[p.idx] = 0; r_eps[p.idx] = 0.0; }
-                    remove_slot2<SOFT, QCAP, PERSIST, TS, TF>(B, lane, q, ul, cslot, cm, xo);
+                    remove_slot2<SOFT, QCAP, PERSIST, TS, TF>(B, lane, q, ul, cslot, cm, xo, m_row, nrmax);
                     nlive--;
                 }
                 if (((++since_sync) & 31) == 0) primal_fast();   // periodic re-sync with x(lambda)
