@@ -82,6 +82,8 @@ def main():
                     help="tuning aid: on ONE GPU run rank 0's share of a G-GPU job (table of 100*G agents per scene, "
                          "no collective) to see the per-rank step time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--debug-option", action="append", default=[], metavar="NAME=VALUE",
+                    help="development: a dmpc_debug_option of the headline context (A/B runs, e.g. grid_min=1073741824); recorded in the line")
     args = ap.parse_args()
 
     import torch
@@ -138,6 +140,8 @@ def main():
     S = args.scenes
     kw = wl.solver_kwargs(cfg, N)
     dmpc = mp.Dmpc(cfg["variant"], device=local_rank, **kw)
+    for kv in args.debug_option:
+        dmpc.debug_option(kv.split("=")[0], int(kv.split("=")[1]))
     # the per-step exchange runs INSIDE the library (dmpc_step_sharded_device: solve + ncclAllGather on one stream); the RCCL id
     # of the library's communicator travels through torch.distributed.  If the library cannot set its communicator up, the
     # exchange falls back to torch.distributed's all-gather (and the JSON line says so).
@@ -579,7 +583,8 @@ def main():
                                    f"{int(alive.sum())}/{S} scenes still alive there)",
                        "agents_per_scene": N, "scenes": S, "solves_per_step": solves_per_step,
                        "parallelism": f"agents sharded x{G}, all-gather per step" if G > 1 else "single GPU",
-                       "exchange": exchange, "exchange_verified": exchange_ok, "n_ranks_seen": (dmpc.comm_size() if in_lib else (G if use_dist else 1))},
+                       "exchange": exchange, "exchange_verified": exchange_ok, "n_ranks_seen": (dmpc.comm_size() if in_lib else (G if use_dist else 1)),
+                       **({"debug_options": args.debug_option} if args.debug_option else {})},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "measured_copy_ceiling_GBps": copy_gbs, "frac_of_copy_ceiling": (achieved / copy_gbs if copy_gbs else None),

@@ -118,7 +118,8 @@ struct dmpc_ctx {
     int split_parts = 0;     // development option split_parts: number of parts (0: the built-in rule)
     int no_split = 0;        // development option no_split
     int no_split_t = 0;      // development option no_split_t: slack-free persistent solve with the whole inverse factor in every wave's block (nine waves per CU; A/B runs, tests)
-    int grid_min = 2048;     // development option grid_min: cell-grid neighbour lists from this many agents per scene on (below: nbr_kernel)
+    int grid_min = 768;      // development option grid_min: cell-grid neighbour lists from this many agents per scene on (below: nbr_kernel) ...
+    int grid_min_part = 2048; // ... and when the query covers only a PART of the scene's agents (a rank's chunk: the grid is still built over all of them)
     int nbr_grid = 1;        // development option nbr_grid: 0 = neighbour lists of large scenes from the all-pairs box test of round 3 (nbr_kernel) instead of the cell grid + distance filter
     DevBuf grid;             // cell grid of the neighbour lists (counts, starts, entries)
     int no_level_check = 0;  // development option no_level_check (see StepParams)
@@ -401,6 +402,7 @@ extern "C" int dmpc_debug_option(dmpc_ctx *ctx, const char *name, int value)
     for (auto &t : tab)
         if (!std::strcmp(t.n, name)) {
             ctx->*(t.f) = value;
+            if (t.f == &dmpc_ctx::grid_min) ctx->grid_min_part = value;   // (the option forces the grid for every query from that size on)
             for (dmpc_ctx *pc : ctx->peers) (void)dmpc_debug_option(pc, name, value);
             for (dmpc_ctx *ch : ctx->children) (void)dmpc_debug_option(ch, name, value);
             return 0;
@@ -742,11 +744,14 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
         const double R = Rsel * 1.0001 + 1e-4;   // a little more than the scan's radius: conservative in fp32 too
         // round 4: lists from a cell grid, filtered by the fp32 distance test (grid_query_kernel); the all-pairs box test of round 3 stays
         // behind option nbr_grid = 0 (A/B runs, tests) and for scenes whose bitmap would not fit a wave's LDS
-        const size_t gq_lds = grid_query_lds_per_wave(G * C);
+        const size_t gq_lds = grid_query_lds(G * C);
         // (from grid_min agents per scene on: in a scene of a few hundred agents the reach of a query covers most of the workspace and the
-        // all-pairs test with the neighbours' boxes as scalar operands is the cheaper pass -- 512 scenes of 800 agents, hard rows: scan side
-        // 0.65 ms with nbr_kernel, 0.90 ms with the grid; one scene of 10^4 agents: 0.58 against 0.32 ms)
-        const bool use_grid = ctx->nbr_grid && G * C >= ctx->grid_min && gq_lds * GQ_WAVES <= 64 * 1024;
+        // all-pairs test with the neighbours' boxes as scalar operands is the cheaper pass -- tools/gpu_grid_min_ab.py, 102 400 agents, scan
+        // side all-pairs / grid: hard rows 400 agents per scene 0.81 / 0.81 ms, 800: 1.07 / 0.91, 1 600: 1.42 / 1.06, 3 200: 1.92 / 1.24;
+        // solveSoftDMPCbound 400: 0.62 / 0.66, 800: 0.71 / 0.69, 1 600: 0.84 / 0.73, 3 200: 1.04 / 0.81.  A rank that queries ONE chunk of
+        // 8 x 100 agents per scene still bins all 800: 0.87 against 0.64 ms, `bench.py --emulate-gpus 8 --debug-option grid_min=512`)
+        const int grid_from = (c_count == G * C) ? ctx->grid_min : ctx->grid_min_part;
+        const bool use_grid = ctx->nbr_grid && G * C >= grid_from && gq_lds <= 64 * 1024;
         if (p.variant != DMPC_VAR_HARD || use_grid) {   // neighbour-major fp32 copy of the table: the list walk of the per-step distance scan, the distance test of the grid query
             const size_t tot = (size_t)total * 64;
             if (ctx->lrow.ensure(tot * 4)) FAIL(ctx, "device allocation failed (neighbour-major table)");
@@ -777,11 +782,12 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
             HIPCHK(ctx, hipMemsetAsync(g_cnt, 0, (n_cnt + n_mh) * 4, st));
             hipLaunchKernelGGL(grid_bin_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, S, C, short_from, gg, (const float *)ctx->bbox_nm.as<float>(), g_cell, g_cnt, g_mh);
             hipLaunchKernelGGL(grid_scan_kernel, dim3((unsigned)(S * NSEG)), dim3(256), 0, st, ncell, g_cnt, g_st);
-            hipLaunchKernelGGL(grid_fill_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, S, C, ncell, (const int *)g_cell, g_cnt, (const int *)g_st, (const float *)ctx->bbox_nm.as<float>(), g_ent);
+            hipLaunchKernelGGL(grid_fill_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, S, C, ncell, (float)(1.0 / p.c), (const int *)g_cell, g_cnt, (const int *)g_st, (const float *)ctx->lrow.as<float>(), g_ent);
             const int nq = S * c_count;
-            hipLaunchKernelGGL(grid_query_kernel, dim3((unsigned)((nq + GQ_WAVES - 1) / GQ_WAVES)), dim3(64 * GQ_WAVES), gq_lds * GQ_WAVES, st, S, G, C, g_local, c_first, c_count, gg,
+            hipLaunchKernelGGL(grid_query_kernel, dim3((unsigned)nq), dim3(64 * GQ_WAVES), gq_lds, st, S, G, C, g_local, c_first, c_count, gg,
                                (float)R, (float)(R * p.c), (float)(1.0 / p.c), (float)(Rsel * Rsel * 1.002), (const float *)ctx->bbox_nm.as<float>(), (const float *)ctx->lrow.as<float>(),
-                               (const int *)g_st, (const f4_t *)g_ent, (const int *)g_mh, (int)cap, (int)gq_lds, ctx->nbr_list.as<int>(), ctx->nbr_cnt.as<int>());
+                               (const int *)g_st, (const f4_t *)g_ent, (const int *)g_mh, (int)cap, (G == 1 && c_first == 0 && c_count == C && !short_from) ? 1 : 0,
+                               ctx->nbr_list.as<int>(), ctx->nbr_cnt.as<int>());
         } else {
             const int nblk = (c_count + 63) / 64;
             hipLaunchKernelGGL(nbr_kernel, dim3((unsigned)(S * nblk * NBR_PARTS)), dim3(64), 0, st, S, G, C, g_local, c_first, c_count, short_from, (float)R, (float)(R * p.c),

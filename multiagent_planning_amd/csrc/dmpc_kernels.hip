@@ -1123,15 +1123,22 @@ __global__ __launch_bounds__(64) void nbr_kernel(int S, int G, int C, int g_loca
 // entries; the scan then walked those lists once per agent with a whole horizon of distances per entry, 327 us.)
 //   grid_bin / grid_scan / grid_fill: the agents of a scene binned by the CENTRE of their whole-horizon box (counting sort: count,
 //     exclusive scan per scene, scatter; the order inside a cell is whatever the atomics give -- nothing below depends on it);
-//   grid_query: one wave per agent.  Candidates = the cells within own half extent + R + the scene's LARGEST half extent of the own
-//     centre (a running maximum from grid_bin), lanes = candidates: the segment-box test of nbr_kernel (18 numbers per candidate),
-//     survivors compacted into an LDS staging list; full waves of survivors then take the distance test itself -- the candidate's
-//     whole horizon from the fp32 neighbour-major table (15 x 16 bytes per lane) against the own horizon (LDS broadcasts), pass = some
-//     horizon step closer than the selection radius (3 rmin; 1 for the hard rows), widened by 1e-3 as in the scan -- and set their bit in
-//     a per-wave BITMAP over the scene's agents; the list is the bitmap read in order: increasing neighbour index whatever order the
-//     candidates came in (the scan builds rows in list order = the reference's row order), duplicates impossible, written as one
-//     contiguous run.  Lists of 10-40 entries instead of 100-700: a superset of every pair the scan can select at any step, so results
-//     are unchanged bit for bit (tests/test_gpu_paths.py against option no_cull).
+//   grid_query: one workgroup per agent, one wave per horizon segment.  Candidates = the entries of the cells within own half extent + R +
+//     the scene's LARGEST half extent of the own box centre (a running maximum from grid_bin), streamed as two coalesced 16-byte halves
+//     per candidate, lanes = candidates; pre-test = closest approach of the two segment CHORDS at equal time against R + both deviations
+//     from the chord (grid_fill_kernel; the segment-box test of nbr_kernel passed 609 candidates per agent at N = 10^4, this one 157);
+//     survivors compacted into an LDS staging list; full waves of survivors then take the distance test itself -- the candidate's segment
+//     from the fp32 neighbour-major table (5 x 16 bytes per lane) against the own one (LDS broadcasts), pass = some horizon step closer
+//     than the selection radius (3 rmin; 1 for the hard rows), widened by 1e-3 as in the scan -- and set their bit in the workgroup's
+//     BITMAP over the scene's agents; the list is the bitmap read in order: increasing neighbour index whatever order the candidates came
+//     in (the scan builds rows in list order = the reference's row order), duplicates impossible, written as one contiguous run.  Lists of
+//     10-40 entries (100 at N = 10^4) instead of 100-700: a superset of every pair the scan can select at any step, so results are
+//     unchanged bit for bit (tests/test_gpu_paths.py against option no_cull).
+//     N = 10^4, one scene: 171 us with the box pre-test and 32-byte records -> 106 (chord pre-test) -> 94 (records as two arrays: a wave's
+//     load is whole cache lines) -> 91 (agents taken in cell order) -> 88 us (a wave per segment).  What is left is the candidate stream,
+//     2 046 records per agent = 655 MB per step out of the L2s, at ~80 instructions per round of 64: without any survivor the kernel took
+//     90 of 106 us, without the stream 18 (both compiled out); its loads were NOT in flight during the previous round's test until the
+//     instruction stream was read (see the loop), and putting them in flight changed nothing -- throughput, not latency.
 // --------------------------------------------------------------------------------------------
 struct GridGeom {
     float org[3], inv[3];   // cell index along axis a = clamp(floor((x - org[a]) * inv[a]), 0, n[a] - 1)
@@ -1205,10 +1212,13 @@ __global__ void grid_scan_kernel(int ncell, int *__restrict__ cnt, int *__restri
     }
     if (t == 0) st[ncell] = carry;
 }
-// entry = 32-byte record {code, segment box lo/hi x, y, z, 0}: the query's box test then streams its candidates COALESCED (a gather of the
-// candidates' boxes -- 64 cache lines per wave load, three loads per candidate -- kept the address units busy for the whole kernel)
-__global__ void grid_fill_kernel(int total, int S, int C, int ncell, const int *__restrict__ cellof, int *__restrict__ cnt, const int *__restrict__ start,
-                                 const float *__restrict__ bbox_nm, f4_t *__restrict__ ent)
+// entry = 32-byte record: the query streams its candidates COALESCED (a gather of the candidates' data -- 64 cache lines per wave load --
+// kept the address units busy for the whole kernel).  What a record holds is the segment's CHORD: {code, first step x, y, z/c, last - first step
+// x, y, z/c, largest distance of the segment's steps from the chord at their own time} -- the query's pre-test is the closest approach of
+// two chords AT EQUAL TIME (two agents whose segment boxes overlap are usually at the overlap at different times: the box test let 609
+// candidates per agent through to the distance test at N = 10^4, the chord test 157; 100 are listed)
+__global__ void grid_fill_kernel(int total, int S, int C, int ncell, float e1z, const int *__restrict__ cellof, int *__restrict__ cnt, const int *__restrict__ start,
+                                 const float *__restrict__ lrow, f4_t *__restrict__ ent)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
@@ -1220,45 +1230,63 @@ __global__ void grid_fill_kernel(int total, int S, int C, int ncell, const int *
         if (cell < 0) return;
         const size_t ss = (size_t)scene * NSEG + sg;
         const int pos = atomicAdd(cnt + ss * ncell + cell, 1);
-        const float *b = bbox_nm + (size_t)i * NBOX_NM + 6 * sg;
-        f4_t *rec = ent + 2 * (ss * nag + start[ss * (ncell + 1) + cell] + pos);
+        const f4_t *row = (const f4_t *)lrow + (size_t)i * 16 + SEG_STEPS * sg;
+        f4_t v[SEG_STEPS];
+#pragma unroll
+        for (int u = 0; u < SEG_STEPS; ++u) { v[u] = row[u]; v[u].z *= e1z; }
+        const f4_t a0 = v[0], a1 = v[SEG_STEPS - 1];
+        float dev2 = 0.f;
+#pragma unroll
+        for (int u = 1; u < SEG_STEPS - 1; ++u) {
+            const float t = (float)u / (float)(SEG_STEPS - 1);
+            const float dx = v[u].x - (a0.x + t * (a1.x - a0.x)), dy = v[u].y - (a0.y + t * (a1.y - a0.y)), dz = v[u].z - (a0.z + t * (a1.z - a0.z));
+            dev2 = fmaxf(dev2, dx * dx + dy * dy + dz * dz);
+        }
+        const size_t ei = ss * nag + start[ss * (ncell + 1) + cell] + pos;
         f4_t r0, r1;
-        r0.x = __int_as_float((r << 20) | c); r0.y = b[0]; r0.z = b[1]; r0.w = b[2];
-        r1.x = b[3]; r1.y = b[4]; r1.z = b[5]; r1.w = 0.f;
-        rec[0] = r0; rec[1] = r1;
+        r0.x = __int_as_float((r << 20) | c); r0.y = a0.x; r0.z = a0.y; r0.w = a0.z;
+        r1.x = a1.x - a0.x; r1.y = a1.y - a0.y; r1.z = a1.z - a0.z; r1.w = sqrtf(dev2) * 1.0001f + 1e-5f;   // (rounded up)
+        ent[ei] = r0; ent[(size_t)S * NSEG * nag + ei] = r1;   // two arrays of 16-byte halves: a wave's load of either is whole cache lines
     }
 }
-constexpr int GQ_WAVES = 4;        // waves (agents) per workgroup of grid_query_kernel
+// A workgroup = ONE agent, a wave per horizon segment (the segments are independent up to the bitmap, which the three waves share): three
+// times as many, shorter waves -- the launch is a little more than one round of resident waves deep (39 agents per CU at N = 10^4 against
+// 28 wave slots), and ends with the last agents' whole chains otherwise.
+constexpr int GQ_WAVES = NSEG;
 constexpr int GQ_STAGE = 128;      // staging list of box-test survivors per wave (a full wave is taken off it as soon as there is one)
-inline size_t grid_query_lds_per_wave(int nagents) { return (size_t)(((nagents + 31) / 32) * 4 + GQ_STAGE * 4 + 64 * 16 + 15) & ~(size_t)15; }
+inline size_t grid_query_lds(int nagents) { return (((size_t)((nagents + 31) / 32) * 4 + GQ_WAVES * GQ_STAGE * 4 + 15) & ~(size_t)15) + 16 * 16; }
 typedef float f2_t __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(64 * GQ_WAVES) void grid_query_kernel(int S, int G, int C, int g_local, int c_first, int c_count, GridGeom gg, float R, float Rz, float e1z, float thr2,
                                                                    const float *__restrict__ bbox_nm, const float *__restrict__ lrow, const int *__restrict__ start,
-                                                                   const f4_t *__restrict__ ent, const int *__restrict__ maxhalf, int cap, int lds_per_wave,
+                                                                   const f4_t *__restrict__ ent, const int *__restrict__ maxhalf, int cap, int cell_order,
                                                                    int *__restrict__ list, int *__restrict__ cnt_out)
 {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = (int)(threadIdx.x & 63);
-    const int gid = __builtin_amdgcn_readfirstlane((int)blockIdx.x * GQ_WAVES + wave);
-    if (gid >= S * c_count) return;
-    const int scene = gid / c_count, ci = gid - scene * c_count, cl = c_first + ci;
+    const int gid = (int)blockIdx.x;
     const int nag = G * C, nwords = (nag + 31) >> 5, ncell = gg.n[0] * gg.n[1] * gg.n[2];
-    unsigned char *mine = dmpc_smem + (size_t)wave * lds_per_wave;
-    unsigned *bits = (unsigned *)mine;
-    int *stage = (int *)(mine + (size_t)nwords * 4);
-    f4_t *ownrow = (f4_t *)(mine + (((size_t)nwords * 4 + GQ_STAGE * 4 + 15) & ~(size_t)15));
-    for (int i = lane; i < nwords; i += 64) bits[i] = 0u;
+    const int scene = gid / c_count;
+    int ci = gid - scene * c_count;
+    // cell_order (a query over whole scenes): wave number -> agent through the first segment's entry array, which IS the scene's agents sorted
+    // by cell -- the waves of a workgroup, and of a CU, then stream the same cells' candidates (one trip to the L2 for the lot; in agent
+    // order every wave fetched its 65 KB of candidates on its own: 655 MB per step at N = 10^4, 11 TB/s out of the L2s)
+    if (cell_order) ci = __builtin_amdgcn_readfirstlane(__float_as_int(ent[(size_t)scene * NSEG * nag + ci].x) & 0xfffff);
+    const int cl = c_first + ci;
+    const int oid = scene * c_count + ci;   // where this agent's list goes
+    unsigned *bits = (unsigned *)dmpc_smem;
+    int *stage = (int *)(dmpc_smem + (size_t)nwords * 4) + wave * GQ_STAGE;
+    f4_t *ownrow = (f4_t *)(dmpc_smem + (((size_t)nwords * 4 + GQ_WAVES * GQ_STAGE * 4 + 15) & ~(size_t)15));
+    for (int i = (int)threadIdx.x; i < nwords; i += 64 * GQ_WAVES) bits[i] = 0u;
     const size_t self_i = (size_t)(g_local * S + scene) * C + cl;
-    if (lane < 16) ownrow[lane] = ((const f4_t *)lrow)[self_i * 16 + lane];   // the own horizon: 15 x (x, y, z, 0) + 4 zeros
+    if (threadIdx.x < 16) ownrow[lane] = ((const f4_t *)lrow)[self_i * 16 + lane];   // the own horizon: 15 x (x, y, z, 0) + 4 zeros
     // own boxes (wave-uniform: scalar loads)
     const ConstF4 ob4 = (ConstF4)(unsigned long long)(bbox_nm + self_i * NBOX_NM);
     const f4_t o0 = ob4[0], o1 = ob4[1], o2 = ob4[2], o3 = ob4[3], o4 = ob4[4];
     const float obx[18] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w, o2.x, o2.y, o2.z, o2.w, o3.x, o3.y, o3.z, o3.w, o4.x, o4.y};
-    LSYNC();
+    __syncthreads();
     const int self_code = (g_local << 20) | cl;
-#pragma unroll 1
-    for (int sg = 0; sg < NSEG; ++sg) {
+    {
+        const int sg = wave;
         // this segment's own box, inflated by the selection radius; the cells its neighbours' centres can lie in
-        float ob[6];
         int c_lo[3], c_hi[3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
@@ -1267,11 +1295,23 @@ __global__ __launch_bounds__(64 * GQ_WAVES) void grid_query_kernel(int S, int G,
             const float infl = a < 2 ? R : Rz;
             const float reach = infl + __int_as_float(maxhalf[((size_t)scene * NSEG + sg) * 3 + a]);   // a neighbour's centre is at most its half extent from its box
             c_lo[a] = grid_coord(gg, a, lo - reach); c_hi[a] = grid_coord(gg, a, hi + reach);
-            ob[2 * a] = lo - infl; ob[2 * a + 1] = hi + infl;
         }
+        // the own chord of this segment (z in the metric's scale) and the steps' largest distance from it, as grid_fill computes them
+        f4_t oa0 = ownrow[SEG_STEPS * sg], oa1 = ownrow[SEG_STEPS * sg + SEG_STEPS - 1];
+        oa0.z *= e1z; oa1.z *= e1z;
+        const float odx = oa1.x - oa0.x, ody = oa1.y - oa0.y, odz = oa1.z - oa0.z;
+        float odev2 = 0.f;
+#pragma unroll
+        for (int u = 1; u < SEG_STEPS - 1; ++u) {
+            const f4_t o = ownrow[SEG_STEPS * sg + u];
+            const float t = (float)u / (float)(SEG_STEPS - 1);
+            const float dx = o.x - (oa0.x + t * odx), dy = o.y - (oa0.y + t * ody), dz = o.z * e1z - (oa0.z + t * odz);
+            odev2 = fmaxf(odev2, dx * dx + dy * dy + dz * dz);
+        }
+        const float lim0 = sqrtf(thr2) + sqrtf(odev2) * 1.0001f + 2e-4f;   // selection radius + own deviation (+ slack for the fp32 arithmetic of the test)
         const size_t ss = (size_t)scene * NSEG + sg;
         const int *st = start + ss * (ncell + 1);
-        const f4_t *en = ent + 2 * ss * nag;
+        const f4_t *en = ent + ss * nag, *en2 = ent + (size_t)S * NSEG * nag + ss * nag;
         int nst = 0;
         // the distance test over this segment's horizon steps on a full wave (or the rest) of staged survivors
         auto traj_test = [&](int n) {
@@ -1295,9 +1335,7 @@ __global__ __launch_bounds__(64 * GQ_WAVES) void grid_query_kernel(int S, int G,
             }
         };
         // The candidates: per (y, z) cell row one RUN of entries (the cells of a run along x are contiguous), ~50 entries each at N = 10^4.
-        // The walk is a chain of dependent memory round trips -- run bounds, entries, the entries' boxes -- and was bound by their latency
-        // (246 us at N = 10^4): the bounds of up to 64 runs are fetched at once (lanes = runs), and the rounds of 64 candidates are software
-        // pipelined -- entries two rounds ahead, boxes one round ahead of the test.
+        // The bounds of up to 64 runs are fetched at once (lanes = runs); the records of the next round are in flight during a round's test.
         const int ny = c_hi[1] - c_lo[1] + 1, nruns_all = ny * (c_hi[2] - c_lo[2] + 1);
         const UDiv div_ny((unsigned)ny);
         for (int run0 = 0; run0 < nruns_all; run0 += 64) {
@@ -1309,32 +1347,40 @@ __global__ __launch_bounds__(64 * GQ_WAVES) void grid_query_kernel(int S, int G,
                 const int row0 = ((c_lo[2] + qz) * gg.n[1] + c_lo[1] + qy) * gg.n[0];
                 rb = st[row0 + c_lo[0]]; re = st[row0 + c_hi[0] + 1];
             }
-            int ft = 0, fj = 0;   // fetch cursor: run, round within the run (wave-uniform)
+            // The runs of this batch as ONE sequence of entries (a run holds ~50 entries at N = 10^4: a round of 64 lanes per run left a third of
+            // the lanes idle and, worse, made every run a memory round trip of its own): lanes = the next 64 entries of the concatenation, each
+            // lane finds its run in the prefix sums of the run lengths (six shuffles) -- half the rounds.
+            const int len = re - rb;
+            int pre = len;   // inclusive prefix of the run lengths
+            for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(pre, off); if (lane >= off) pre += o; }
+            const int tot = __builtin_amdgcn_readlane(pre, 63);
+            const int basev = rb - (pre - len);   // entry index of sequence position v in run j: basev_j + v
+            const int nround = (tot + 63) >> 6;
             struct Rec { f4_t a, b; bool hv; };
-            auto fetch_next = [&](Rec &rc) -> bool {
-                int b = 0, e = 0;
-                while (ft < nruns) {
-                    b = __builtin_amdgcn_readlane(rb, ft) + 64 * fj; e = __builtin_amdgcn_readlane(re, ft);
-                    if (b < e) break;
-                    ++ft; fj = 0;
-                }
-                if (ft >= nruns) return false;
-                rc.hv = b + lane < e;
-                const f4_t *p = en + 2 * (size_t)(rc.hv ? b + lane : b);
-                rc.a = p[0]; rc.b = p[1];
-                ++fj;
-                return true;
+            // (the loads of a round are issued UNCONDITIONALLY, into registers of their own -- two record sets, the loop unrolled by two: a
+            // fetch behind a branch, or a copy of the loaded registers at the loop's end, makes the compiler wait for the loads it has just
+            // issued (s_waitcnt vmcnt(0)) and the prefetch is gone: that was the state of this loop until the instruction stream was read)
+            auto fetch = [&](int k, Rec &rc) {
+                const int vi = 64 * k + lane;
+                rc.hv = vi < tot;
+                const int vq = rc.hv ? vi : tot - 1;
+                int j = 0;   // the first run whose inclusive prefix exceeds vq
+#pragma unroll
+                for (int step = 32; step > 0; step >>= 1) { const int pm = __shfl(pre, j + step - 1); if (pm <= vq) j += step; }
+                const size_t ei = (size_t)(__shfl(basev, j) + vq);
+                rc.a = en[ei]; rc.b = en2[ei];
             };
-            Rec r0, r1;
-            r0.hv = r1.hv = false; r0.a = r0.b = r1.a = r1.b = f4_t{0.f, 0.f, 0.f, 0.f};
-            bool v0 = fetch_next(r0), v1 = false;
-            while (v0) {
-                v1 = fetch_next(r1);   // (the next round's records in flight during this round's test)
-                // overlap in arithmetic form (nbr_kernel): the maximum of the six differences is <= 0
-                const float m6 = fmaxf(__builtin_fmaxf(__builtin_fmaxf(r0.a.y - ob[1], ob[0] - r0.a.z), r0.a.w - ob[3]),
-                                       __builtin_fmaxf(__builtin_fmaxf(ob[2] - r0.b.x, r0.b.y - ob[5]), ob[4] - r0.b.z));
-                const int c0 = __float_as_int(r0.a.x);
-                const bool surv = r0.hv && c0 != self_code && m6 <= 0.f;
+            auto test = [&](const Rec &rc) {
+                // closest approach of the two chords at equal time: r(t) = q + t e on [0, 1], against radius + both deviations.  (Any t gives
+                // an upper bound of the minimum; the rounded t* is off by parts in 10^6 and |r(t)|^2 is flat there to second order.)
+                const float qx = rc.a.y - oa0.x, qy = rc.a.z - oa0.y, qz = rc.a.w - oa0.z;
+                const float ex = rc.b.x - odx, ey = rc.b.y - ody, ez = rc.b.z - odz;
+                const float ee = ex * ex + ey * ey + ez * ez, qe = qx * ex + qy * ey + qz * ez, qq = qx * qx + qy * qy + qz * qz;
+                const float tt = __builtin_fminf(__builtin_fmaxf(-qe * __builtin_amdgcn_rcpf(__builtin_fmaxf(ee, 1e-20f)), 0.f), 1.f);
+                const float d2 = qq + tt * (qe + qe + tt * ee);   // |q + t e|^2 (rounding: parts in 10^7 of qq <= 60: the slack in lim0 covers it)
+                const float lim = lim0 + rc.b.w;
+                const int c0 = __float_as_int(rc.a.x);
+                const bool surv = rc.hv && c0 != self_code && d2 <= lim * lim;
                 const unsigned long long m = __ballot(surv);
                 if (m) {
                     if (surv) stage[nst + lanes_below(m, lane)] = c0;
@@ -1350,14 +1396,25 @@ __global__ __launch_bounds__(64 * GQ_WAVES) void grid_query_kernel(int S, int G,
                         LSYNC();
                     }
                 }
-                r0 = r1; v0 = v1;
+            };
+            if (nround > 0) {
+                Rec ra, rb2;
+                fetch(0, ra);
+                for (int k = 0; k < nround; k += 2) {
+                    fetch(k + 1 < nround ? k + 1 : nround - 1, rb2);   // (past the end: the last round once more, never tested)
+                    test(ra);
+                    if (k + 1 >= nround) break;
+                    fetch(k + 2 < nround ? k + 2 : nround - 1, ra);
+                    test(rb2);
+                }
             }
         }
         if (nst > 0) traj_test(nst);
-        LSYNC();
     }
+    __syncthreads();
+    if (wave != 0) return;
     // the list = the bitmap in order (increasing neighbour index), one contiguous run per agent
-    int *out = list + (size_t)gid * cap;
+    int *out = list + (size_t)oid * cap;
     int total = 0;
     const UDiv div_c((unsigned)C);
     for (int w0 = 0; w0 < nwords; w0 += 64) {
@@ -1378,7 +1435,7 @@ __global__ __launch_bounds__(64 * GQ_WAVES) void grid_query_kernel(int S, int G,
         }
         total += wave_total;
     }
-    if (lane < NBR_PARTS) cnt_out[(size_t)gid * NBR_PARTS + lane] = lane == 0 ? (total > cap ? -1 : total) : 0;
+    if (lane < NBR_PARTS) cnt_out[(size_t)oid * NBR_PARTS + lane] = lane == 0 ? (total > cap ? -1 : total) : 0;
 }
 
 // calibration of the HBM-side counters (profiles/: FETCH_SIZE is documented for 16-byte-per-lane streams only): a streaming read of a known

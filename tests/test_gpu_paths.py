@@ -39,7 +39,7 @@ def test_neighbour_lists_do_not_change_a_bit(variant, precision, monkeypatch):
     kw = wl.solver_kwargs(cfg, N)
     po, pf = wl.make_scenes(cfg, S, N, wl.SEED0 + 31)
     with_lists = _steps(variant, kw, po, pf, 3, precision)                      # (700 agents: the all-pairs box test, nbr_kernel)
-    with_grid = _steps(variant, kw, po, pf, 3, precision, grid_min=256)         # the cell grid + distance filter of scenes >= 2048 agents, forced
+    with_grid = _steps(variant, kw, po, pf, 3, precision, grid_min=256)         # the cell grid + distance filter of scenes >= 1024 agents, forced
     plain = _steps(variant, kw, po, pf, 3, precision, no_cull=1)
     for a, g, b in zip(with_lists, with_grid, plain):
         for k in ("status", "info", "p", "v", "a"):
