@@ -100,6 +100,10 @@ struct dmpc_ctx {
     int order_slices = 0;    // development option order_slices: workgroups of the order kernel (0: by launch size)
     int no_cull = 0;         // development option no_cull: no neighbour lists in the scan of large scenes (A/B runs, tests)
     int no_lpt = 0;          // development option no_lpt: no heaviest-first solve order
+    int order_hint = 0;      // option order_hint = 1: the launch order also uses the agents' work estimates of the context's previous step (measured: no gain in
+                             // closed loops -- the heavy agents of a step are not the heavy agents of the step before -- so off; a replay of ONE step would flatter it)
+    DevBuf prev_cost;        // [S * c_count] work estimates of the previous step (solve kernel -> order kernel)
+    long prev_cost_shape = -1;
     int crash_min = CRASH_MIN_DEFAULT;   // see StepParams::crash_min (development option crash_min; crash_any: also for the slack-free variants)
     int crash_any = 0;
     int pivot_explore = 0;   // development option pivot_explore (DMPC_PIVOT_EXPLORE builds)
@@ -396,7 +400,7 @@ extern "C" int dmpc_debug_option(dmpc_ctx *ctx, const char *name, int value)
     if (!ctx || !name) return -1;
     struct { const char *n; int dmpc_ctx::*f; } tab[] = {
         {"no_fuse", &dmpc_ctx::no_fuse}, {"no_persist", &dmpc_ctx::no_persist}, {"force_persist", &dmpc_ctx::force_persist}, {"no_cull", &dmpc_ctx::no_cull}, {"order_slices", &dmpc_ctx::order_slices}, {"cull_min", &dmpc_ctx::cull_min},
-        {"no_lpt", &dmpc_ctx::no_lpt}, {"crash_min", &dmpc_ctx::crash_min}, {"crash_any", &dmpc_ctx::crash_any}, {"no_fast_exit", &dmpc_ctx::no_fast_exit}, {"pivot_explore", &dmpc_ctx::pivot_explore},
+        {"no_lpt", &dmpc_ctx::no_lpt}, {"order_hint", &dmpc_ctx::order_hint}, {"crash_min", &dmpc_ctx::crash_min}, {"crash_any", &dmpc_ctx::crash_any}, {"no_fast_exit", &dmpc_ctx::no_fast_exit}, {"pivot_explore", &dmpc_ctx::pivot_explore},
         {"iter_cap", &dmpc_ctx::iter_cap}, {"tier1_qcap", &dmpc_ctx::tier1_env}, {"split_parts", &dmpc_ctx::split_parts}, {"no_split", &dmpc_ctx::no_split},
         {"static_queue", &dmpc_ctx::static_queue}, {"no_split_t", &dmpc_ctx::no_split_t}, {"ext_cap", &dmpc_ctx::ext_cap}, {"nbr_grid", &dmpc_ctx::nbr_grid}, {"f32_dep_exp", &dmpc_ctx::f32_dep_exp}, {"grid_min", &dmpc_ctx::grid_min}, {"no_level_check", &dmpc_ctx::no_level_check}};
     for (auto &t : tab)
@@ -825,7 +829,16 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
         // (slices: the kernel is a chain of dependent memory round trips per thread -- 8 workgroups of 1024 threads took 20 us for 51 200
         // agents, six agents per thread one after the other; with one agent per thread 7 us: headline 52.3 -> 53.2 M solves/s)
         const int total = S * c_count, nb = ctx->order_slices > 0 ? ctx->order_slices : (total >= 65536 ? 64 : (total >= 1024 ? total / 1024 : 1));
-        hipLaunchKernelGGL(order_kernel, dim3((unsigned)nb), dim3(1024), 0, st, total, (const int *)P.hdr, ctx->order.as<int>(), ctx->counter.as<int>() + 3);
+        int *hint = nullptr;
+        if (ctx->order_hint) {   // the previous step's work estimates: valid while the batch keeps its shape
+            if (ctx->prev_cost.ensure((size_t)total * 4)) FAIL(ctx, "device allocation failed (order hint)");
+            const long shape = ((long)S << 32) ^ ((long)c_count << 8) ^ (long)p.variant;
+            if (shape != ctx->prev_cost_shape) { HIPCHK(ctx, hipMemsetAsync(ctx->prev_cost.p, 0, (size_t)total * 4, st)); ctx->prev_cost_shape = shape; }
+            hint = ctx->prev_cost.as<int>();
+            P.cost_out = hint;
+        }
+        hipLaunchKernelGGL(order_kernel, dim3((unsigned)nb), dim3(1024), (size_t)((total + nb - 1) / nb) * 2, st, total, (const int *)P.hdr, ctx->order.as<int>(), ctx->counter.as<int>() + 3,
+                           hint, ctx->order_hint);
         P.order = ctx->order.as<int>();
         P.live_bound = ctx->counter.as<int>() + 3;
     }
@@ -1377,10 +1390,10 @@ static int transition_one(dmpc_ctx *ctx, int S, int N, const double *po, const d
 static void copy_debug_options(dmpc_ctx *dst, const dmpc_ctx *src)
 {
     static const char *names[] = {"no_fuse", "no_persist", "force_persist", "no_cull", "order_slices", "cull_min", "no_lpt", "crash_min", "crash_any", "no_fast_exit",
-                                  "pivot_explore", "iter_cap", "tier1_qcap", "static_queue", "no_split_t", "ext_cap", "nbr_grid", "f32_dep_exp", "grid_min", "no_level_check"};
+                                  "pivot_explore", "iter_cap", "tier1_qcap", "static_queue", "no_split_t", "ext_cap", "nbr_grid", "f32_dep_exp", "grid_min", "no_level_check", "order_hint"};
     int dmpc_ctx::*fields[] = {&dmpc_ctx::no_fuse, &dmpc_ctx::no_persist, &dmpc_ctx::force_persist, &dmpc_ctx::no_cull, &dmpc_ctx::order_slices, &dmpc_ctx::cull_min,
                                &dmpc_ctx::no_lpt, &dmpc_ctx::crash_min, &dmpc_ctx::crash_any, &dmpc_ctx::no_fast_exit, &dmpc_ctx::pivot_explore, &dmpc_ctx::iter_cap,
-                               &dmpc_ctx::tier1_env, &dmpc_ctx::static_queue, &dmpc_ctx::no_split_t, &dmpc_ctx::ext_cap, &dmpc_ctx::nbr_grid, &dmpc_ctx::f32_dep_exp, &dmpc_ctx::grid_min, &dmpc_ctx::no_level_check};
+                               &dmpc_ctx::tier1_env, &dmpc_ctx::static_queue, &dmpc_ctx::no_split_t, &dmpc_ctx::ext_cap, &dmpc_ctx::nbr_grid, &dmpc_ctx::f32_dep_exp, &dmpc_ctx::grid_min, &dmpc_ctx::no_level_check, &dmpc_ctx::order_hint};
     for (size_t i = 0; i < sizeof(names) / sizeof(names[0]); ++i) (void)dmpc_debug_option(dst, names[i], src->*(fields[i]));
 }
 

@@ -81,6 +81,8 @@ struct StepParams {
     int no_level_check;     // development option no_level_check: solveSoftDMPCall without the slack-free feasibility pass per ladder level (A/B runs, tests)
     double dep_tol_f32;     // fp32-factor kernels: dependence threshold on delta / s_pp (development option f32_dep_exp: 10^-n)
     int n_ext;              // persistent solve kernel with a split T: extensions in the workgroup's pool (behind the waves' blocks)
+    int *cost_out;          // [S*c_count] or null: work estimate of this agent's solve (quarter microseconds: iterations weighted by the working-set size,
+                            // certificate calls) -- the NEXT step's launch order is built from it (order_kernel; dmpc_api.hip: order hint)
     int iter_cap;           // active-set iteration cap per try (ITER_CAP; development runs lower it to measure the per-iteration cost)
 };
 

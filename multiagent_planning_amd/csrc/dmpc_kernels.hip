@@ -423,6 +423,8 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
     // Launch-order key of the slack-free variants (see order_kernel): which horizon steps have a row that is violated
     // at the unconstrained minimiser, and how tight the tightest row is against the reachable box.
     unsigned key_steps = 0, key_tight = 0;
+    float key_soft = 0.f;    // slack variants: the launch-order key before the terms of the unconstrained-exit block
+    float key_share = 1.f;   // slack ladder variants: the smallest share of the reachable box a row leaves feasible at ladder level 0
     if (!soft) {
         // w_unc = Lambda a_unc of the collision cost case (rows exist): 2 q g P1[k][K-1] + 2 s ao M1[0][k]  (Gram table
         // of case 2: G[W k][W K-1] and G[W k][A 0])
@@ -479,6 +481,10 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
                         // so every level with lin_max < dist*(rmin + slb 2^t) is certainly infeasible and the
                         // retry ladder can start at the first level that passes this necessary test.
                         real slb_t = (var == VAR_BOUND) ? -0.05 : (cppv ? -(real)0.01f : -0.01);
+                        {   // launch-order key: the feasible share of the reachable box at ladder level 0 (as the slack-free variants' tightness class)
+                            const real share = (lin_max - dist * (rmin + slb_t)) / (lin_max - lin_min + (real)1e-30);
+                            key_share = fminf(key_share, (float)share);
+                        }
                         int t = 0;
                         while (t < 40 && lin_max < dist * (rmin + slb_t) - MARG) { slb_t *= 2.0; ++t; }
                         if (t > ladder_start) ladder_start = t;
@@ -760,10 +766,8 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
             hdr[0] = nr; hdr[1] = nrows_ref; hdr[2] = viol_k; hdr[3] = status;
             hdr[4] = (violation ? 1 : 0) | (coll_flag ? 4 : 0); hdr[5] = rows_exist ? 1 : 0; hdr[6] = 0;
         }
-        {
-            const int ls = (int)wave_max((double)ladder_start);
-            if (lane == 0) hdr[6] = ls;
-        }
+        const int ls_key = (int)wave_max((double)ladder_start);
+        if (lane == 0) hdr[6] = ls_key;
         {
             // launch-order key (order_kernel, heaviest first).  Slack-carrying variants: the row count.  Slack-free
             // variants: 4 x (horizon steps with a row violated at the unconstrained minimiser) + tightness class of the
@@ -771,6 +775,18 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
             // the hardware (tools/gpu_order_probe.py, 51 200 C2 agents): natural 1240 us, by row count 1137, by the true
             // iteration counts 1096, by this key 1064.
             int key = nr >> 2;
+            if (soft) {
+                // Slack variants (round 4): rows / 4 said little about the work -- at N = 10^4 the solve launch took 1.6 times its work per wave
+                // slot and ended with agents of 100-450 us from the END of the queue.  Ingredients fitted on that scene's closed loop
+                // (tools/gpu_key_features.py + tools/key_fit.py: list scheduling of the agents' measured work in the order a candidate key gives):
+                // the smallest feasible share of the reachable box a row leaves at ladder level 0, the ladder levels the scan certified
+                // infeasible, and -- added in the unconstrained-exit block below, where the unconstrained minimiser is known -- the acceleration
+                // bounds and the rows it violates.  (An agent's own previous solve predicts the bulk, rank correlation 0.8, but not the heavy
+                // agents: a retry ladder is a one-step event.  The perfect order would be worth 0.97 -> 0.72 ms; this key 0.97 -> 0.8x.)
+                const float smin = -(float)wave_max((double)-key_share);
+                key_soft = 0.7f * (float)nr + 56.f * (1.f - fminf(fmaxf(smin, 0.f), 1.f)) + 52.f * (float)ls_key;
+                key = (int)key_soft;
+            }
             if (!soft) {
                 const unsigned ks = wave_or(key_steps), kt = wave_or(key_tight);
                 key = 4 * __popc(ks) + (kt ? 31 - __clz((int)kt) : 0);
@@ -819,7 +835,32 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
             }
             bool trivial = ls == 0 && !__any(viol);
             double *a_s = (double *)smem, *wu_s = a_s + 48;   // (own prediction and key vector are dead by now)
-            if (trivial) {
+            if (soft) {   // launch-order key, second part: acceleration bounds and rows violated at the unconstrained minimiser
+                const int nsat = __popcll(__ballot(comp && fabs(a_unc) - Qp->alim > tol));
+                LSYNC();
+                if (comp) { a_s[lane] = a_unc; wu_s[lane] = w_unc; }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the rows this wave wrote are read back
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                LSYNC();
+                int nrv = 0;   // (wave-uniform: whole rounds)
+                for (int i0 = 0; i0 < nr; i0 += 64) {
+                    const bool in = i0 + lane < nr;
+                    const int i = in ? i0 + lane : 0;
+                    const int kc = L.r_kc[i];
+                    const double v = -(L.r_xi[3 * i] * wu_s[3 * kc] + L.r_xi[3 * i + 1] * wu_s[3 * kc + 1] + L.r_xi[3 * i + 2] * wu_s[3 * kc + 2]) - L.r_b[i];
+                    nrv += __popcll(__ballot(in && v > tol));
+                }
+                trivial = trivial && nrv == 0;
+                const int key2 = (int)(key_soft + 1.5f * (float)nsat + 5.6f * (float)nrv);
+#ifdef DMPC_DEV_TRACE   // development: the raw ingredients in the upper bits of the word (tools/gpu_key_features.py; order_kernel reads bits 0-8 only)
+                const float smin = -(float)wave_max((double)-key_share);
+                const int qs = smin >= 1.f ? 31 : (smin <= 0.f ? 0 : (int)(smin * 31.f));
+                if (lane == 0) hdr[7] = (key2 > 255 ? 255 : key2) | (qs << 9) | ((nsat > 63 ? 63 : nsat) << 14) | ((nrv > 63 ? 63 : nrv) << 20) | ((ls > 7 ? 7 : ls) << 26);
+#else
+                if (lane == 0) hdr[7] = key2 > 255 ? 255 : key2;
+#endif
+            }
+            if (trivial && !soft) {
                 LSYNC();
                 if (comp) { a_s[lane] = a_unc; wu_s[lane] = w_unc; }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the rows this wave wrote are read back
@@ -1457,19 +1498,33 @@ __global__ void read_probe_kernel(size_t n, const T *__restrict__ src, double *_
 // results do not depend on the order.  gridDim.x workgroups: workgroup b sorts the agents i = b (mod gridDim.x)
 // (statistically identical slices) and writes its r-th heaviest agent to position r * gridDim.x + b, so the
 // interleaved sequence is heaviest-first overall up to the differences between the slices.
-__global__ void order_kernel(int count, const int *__restrict__ hdr, int *__restrict__ order, int *__restrict__ live_bound)
+// Order hint (round 4): when the context solved the same batch shape in its previous step, `prev_cost` holds every agent's work estimate of
+// THAT solve (quarter microseconds, written by the solve kernel; 0: finished by the scan) -- in a closed loop the best predictor there is of
+// this step's solve (an agent in a conflict stays in it for several steps), where the scan's key (row count) says little about the retry
+// ladder or the size of the final working set: at N = 10^4 the launch took 1.6 times its work per wave slot and ended with agents of
+// 100-450 us that the row count had put at the END of the queue.  key = max(previous cost / 4 us, scan key); the entry is reset to 0 for
+// agents the scan finishes this step.
+__global__ void order_kernel(int count, const int *__restrict__ hdr, int *__restrict__ order, int *__restrict__ live_bound, int *__restrict__ prev_cost, int use_hint)
 {
     // (agents the scan already finished -- hdr[7] & 256, as hdr[4] & 16 -- sort behind everything else: bucket 256.  Slice b puts its live agents at
     // positions b, b + nb, ...: every position from nb * max_b(live agents of slice b) on holds a finished agent, and that bound
     // is what the solve queue runs to.)
     __shared__ int hist[257];
     __shared__ int offs[257];
+    short *keys = (short *)dmpc_smem;   // dynamic LDS: the slice's keys, first pass -> second pass (ceil(count / gridDim.x) entries)
     const int nb = gridDim.x, b = blockIdx.x;
     for (int i = threadIdx.x; i < 257; i += blockDim.x) hist[i] = 0;
     __syncthreads();
     for (int i = b + nb * (int)threadIdx.x; i < count; i += nb * (int)blockDim.x) {
         const int h7 = hdr[(size_t)i * 8 + 7];
-        const int key = (h7 & 256) ? 256 : 255 - (h7 & 255);   // bucket: heaviest first
+        int heavy = h7 & 255;
+        if (prev_cost) {
+            const int pc = prev_cost[i] >> 4;
+            if (use_hint && pc > heavy) heavy = pc > 255 ? 255 : pc;
+            if (h7 & 256) prev_cost[i] = 0;
+        }
+        const int key = (h7 & 256) ? 256 : 255 - heavy;   // bucket: heaviest first
+        keys[(i - b) / nb] = (short)key;
         atomicAdd(&hist[key], 1);
     }
     __syncthreads();
@@ -1480,8 +1535,7 @@ __global__ void order_kernel(int count, const int *__restrict__ hdr, int *__rest
     }
     __syncthreads();
     for (int i = b + nb * (int)threadIdx.x; i < count; i += nb * (int)blockDim.x) {
-        const int h7 = hdr[(size_t)i * 8 + 7];
-        const int key = (h7 & 256) ? 256 : 255 - (h7 & 255);
+        const int key = keys[(i - b) / nb];
         order[(size_t)atomicAdd(&offs[key], 1) * nb + b] = i;
     }
 }

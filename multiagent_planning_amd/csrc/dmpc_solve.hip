@@ -740,6 +740,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
     // recorded): the second tier repeats the whole solve, on the path an uninterrupted solve takes -- the result of an agent
     // must not depend on how deep the launch was that it ran in.
     int tries = h1.z, iters_total = 0, maxq = 0, q = 0;
+    int cost = 0;   // work estimate in quarter microseconds (wave-uniform, scalar registers): the next step's launch-order key (P.cost_out)
     int scale_pow = 0;   // the rows' slack bound and penalty currently carry the factor 2^scale_pow
 #ifdef DMPC_DEV_TRACE
     int dev_nfast = 0, dev_rounds = 0, dev_negdrops = 0, dev_tbl = 0, dev_gen = 0;
@@ -1022,6 +1023,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                 if (soft && ladder && violation && !cert_done && iters - nfast >= LADDER_CERT_AFTER) {
                     cert_done = true;
                     PH(4); PHC(12);
+                    cost += 176;   // (44 us a call)
                     const bool cert_inf = ladder_level_infeasible(r_xi, r_b, r_sd, r_slb, r_kc, nr, B + SL::RR, P.h, P.alim, 1.0, whi_l, wlo_l, lane);
                     PH(7);
                     if (cert_inf) { rc = 1; break; }
@@ -1201,6 +1203,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                 // ---- inner loop: partial steps until p can be added
                 for (;;) {
                     if (++iters > P.iter_cap) { rc = 3; break; }
+                    cost += crash ? 3 + (q >> 3) : 8 + (q >> 2);   // (a lone wave: 2 us per iteration + 0.06 us per slot; an append without a step: a third)
                     // s = N_W' H^-1 n_p on the slot lanes
                     double sv = 0.0;
                     int mymeta = 0;
@@ -1485,6 +1488,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
     if (Qp->post_on) post_step_part(Qp, lane, gid, scene, solved, status, p_out, v_out, a_out);
     if (lane == 0) {
         Qp->status[gid] = status;
+        if (Qp->cost_out) Qp->cost_out[gid] = cost;
         if (Qp->info) {
             int *inf = Qp->info + (size_t)gid * 8;
             inf[0] = viol_k; inf[1] = nrows_built; inf[2] = tries; inf[3] = (!solved && (status & ST_COLL)) ? 0 : ccase;   // (`coll` return: no QP, no cost case)
@@ -1495,6 +1499,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                 double *d = Qp->dbg + (size_t)(Qp->dbg_cap - 3) * 8;
                 for (int u = 0; u < 20; ++u) d[u] = (double)phv[u];
             }
+            if (Qp->dbg_agent == -6) { inf[5] = h1.w; inf[0] = cost; }   // development: the scan's key word (with the feature bits of the DEV_TRACE scan) and the work estimate
             if (Qp->dbg_agent == -4) { inf[0] = dev_nfast; inf[1] = dev_rounds; inf[3] = dev_negdrops; inf[5] = dev_tbl; inf[6] = dev_gen; }   // development: crash statistics in place of the branch record
 #endif
         }

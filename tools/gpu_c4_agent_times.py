@@ -14,7 +14,7 @@ xp, xv, xa = po.copy(), np.zeros_like(po), np.zeros_like(po)
 L = _lib.load()
 L.dmpc_debug_trace.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
 cap = N * 2 // 8 + 8
-for k in range(3):
+for k in range(int(sys.argv[1]) if len(sys.argv) > 1 else 3):
     assert L.dmpc_debug_trace(d._ctx, -3, cap, None) == 0
     d.profile(True)
     out = d.step_batch(l, xp, xv, xa, pf)

@@ -10,7 +10,7 @@ import torch
 import multiagent_planning_amd as mp
 from multiagent_planning_amd import workload as wl
 import bench
-ap = argparse.ArgumentParser(); ap.add_argument("what"); ap.add_argument("--steps", type=int, default=20); ap.add_argument("--warmup", type=int, default=3)
+ap = argparse.ArgumentParser(); ap.add_argument("what"); ap.add_argument("--steps", type=int, default=20); ap.add_argument("--warmup", type=int, default=3); ap.add_argument("--one-state", type=int, default=-1, help="c4: replay this one state only (development: the order hint with a perfect prediction)")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 t = lambda x, dt=torch.float64: torch.from_numpy(np.ascontiguousarray(x)).to(dev, dt)
@@ -36,6 +36,7 @@ else:
         l = np.where(ok[..., None], o["p"], l); xp = np.where(ok[..., None], o["p"][..., :3], xp)
         xv = np.where(ok[..., None], o["v"][..., :3], xv); xa = np.where(ok[..., None], o["a"][..., :3], xa)
     states = states[1:]          # MPC steps 3-10 (the first solve from the initDMPC table is the outlier)
+    if a.one_state >= 0: states = [states[a.one_state]]
 bufs = []
 for (l_, xp_, xv_, xa_) in states:
     rows = t(l_); lT = torch.empty((1, S, 45, N), dtype=torch.float64, device=dev)
