@@ -1499,7 +1499,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                 double *d = Qp->dbg + (size_t)(Qp->dbg_cap - 3) * 8;
                 for (int u = 0; u < 20; ++u) d[u] = (double)phv[u];
             }
-            if (Qp->dbg_agent == -6) { inf[5] = h1.w; inf[0] = cost; }   // development: the scan's key word (with the feature bits of the DEV_TRACE scan) and the work estimate
+            if (Qp->dbg_agent == -6) { inf[5] = h1.w; inf[3] = cost; }   // development: the scan's key word (with the feature bits of the DEV_TRACE scan) and the work estimate
             if (Qp->dbg_agent == -4) { inf[0] = dev_nfast; inf[1] = dev_rounds; inf[3] = dev_negdrops; inf[5] = dev_tbl; inf[6] = dev_gen; }   // development: crash statistics in place of the branch record
 #endif
         }

@@ -25,4 +25,4 @@ for k in range(9):
 os.makedirs("gpurun_out", exist_ok=True)
 np.savez_compressed("gpurun_out/key_features.npz", info=np.array(infos))
 i = infos[3]
-print("step 5: cost mean", i[:, 0].mean(), "iters mean", i[:, 4].mean(), "key word sample", [hex(x) for x in i[:5, 5]])
+print("step 5: cost mean", i[:, 3].mean(), "iters mean", i[:, 4].mean(), "key word sample", [hex(x) for x in i[:5, 5]])

@@ -13,7 +13,7 @@ def feats(inf):
     w = inf[:, 5]
     key = w & 255; fin = (w >> 8) & 1
     qs = ((w >> 9) & 31) / 31.0; nsat = (w >> 14) & 63; nrv = (w >> 20) & 63; ls = (w >> 26) & 7
-    return dict(key=key, fin=fin, cut=nsat.astype(float), smin=qs, ntight=nrv, ls=ls, nsat=nsat, nrv=nrv, rows=inf[:, 1], cost=inf[:, 0] * 0.25 * 1.73, iters=inf[:, 4], tries=inf[:, 2], maxq=inf[:, 7])
+    return dict(key=key, fin=fin, cut=nsat.astype(float), smin=qs, ntight=nrv, ls=ls, nsat=nsat, nrv=nrv, rows=inf[:, 1], violk=inf[:, 0], cost=inf[:, 3] * 0.25 * 1.73, iters=inf[:, 4], tries=inf[:, 2], maxq=inf[:, 7])
 S = [feats(d[k]) for k in range(d.shape[0])]
 def evaluate(fn, label):
     ms = []
