@@ -7,7 +7,7 @@ import multiagent_planning_amd as mp
 from multiagent_planning_amd import workload as wl, _lib
 import bench
 variant = sys.argv[1]
-gids = [int(x) for x in sys.argv[2:]]
+gids = [x for x in sys.argv[2:]]   # agent ids, or `max`: the agent with the most iterations of the replayed step
 cfg, N, S = dict(wl.CONFIGS["C2"], variant=variant), 100, 512
 kw = wl.solver_kwargs(cfg, N)
 d = mp.Dmpc(variant, **kw)
@@ -16,6 +16,11 @@ L = _lib.load()
 L.dmpc_debug_trace.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
 names = ["pivot scan", "descriptor", "T T's", "resid+dir", "append/other", "drops", "verify", "ladder", "setup", "-", "-", "-", "-", "s", "T's", "ratio", "step+certs"]
 cap = 8   # (the phase block takes rows cap-2 .. : 20 doubles)
+if "max" in gids:
+    o_all = d.step_batch(l, xp, xv, xa, pf)
+    it_all = o_all["info"][..., 4].reshape(-1)
+    gids = [int(i) for i in np.argsort(it_all)[-gids.count("max"):][::-1]] + [int(x) for x in gids if x != "max"]
+gids = [int(x) for x in gids]
 for g in gids:
     sc, n = divmod(g, N)
     for rep in range(2):

@@ -37,9 +37,9 @@ evaluate(lambda f, p: f["nrv"].astype(float), "rows violated at the unconstraine
 evaluate(lambda f, p: f["ls"] * 100.0 + f["cut"], "ladder start, cut sum")
 print("work per slot:", [round(S[k]["cost"].sum() / M) for k in range(1, len(S))], " longest:", [round(S[k]["cost"].max()) for k in range(1, len(S))])
 # who are the heavy ones?
-f = S[4]; top = np.argsort(f["cost"])[-200:]
+f = S[min(4, len(S) - 1)]; top = np.argsort(f["cost"])[-200:]
 for name in ("rows", "smin", "nsat", "nrv", "ls", "tries", "maxq", "iters"):
-    print(f"  heaviest 200 of step 6: {name:7s} median {np.median(f[name][top]):.2f} (all agents {np.median(f[name]):.2f})  10th pct {np.percentile(f[name][top], 10):.2f}  90th {np.percentile(f[name][top], 90):.2f}")
+    print(f"  heaviest 200 of one step: {name:7s} median {np.median(f[name][top]):.2f} (all agents {np.median(f[name]):.2f})  10th pct {np.percentile(f[name][top], 10):.2f}  90th {np.percentile(f[name][top], 90):.2f}")
 # a linear search over simple combinations
 best = None
 rng = np.random.default_rng(1)
