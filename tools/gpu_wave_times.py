@@ -13,7 +13,7 @@ l, _, _ = d.init_batch(po, pf)
 z = np.zeros_like(po)
 L = _lib.load()
 L.dmpc_debug_trace.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
-NW = 2304            # persistent waves of the launch: 256 CUs x 9 (slack-free kernels since round 3; 8 for the slack variants)
+NW = 3072            # persistent waves of the launch: 256 CUs x 12 (slack-free kernels since round 4; 9 in round 3; 8 for the slack variants)
 cap = NW * 3 // 8 + 8
 for rep in range(3):
     assert L.dmpc_debug_trace(d._ctx, -2, cap, None) == 0
@@ -29,3 +29,5 @@ print(f"waves {ok.sum()}  start spread {b.max():.1f} us  end: min {e.min():.1f} 
 print(f"agents per wave: min {n[ok].min():.0f} median {np.median(n[ok]):.0f} max {n[ok].max():.0f}; busy fraction {((e-b).sum()/(ok.sum()*e.max())):.3f}")
 last = np.argsort(e)[-5:]
 print("last waves end at", np.round(e[last], 1), "agents", n[ok][last])
+h, edges = np.histogram(e, bins=12)
+print("wave ends histogram (us):", [f"{edges[i]:.0f}-{edges[i+1]:.0f}: {h[i]}" for i in range(len(h))])
