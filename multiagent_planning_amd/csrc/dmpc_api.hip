@@ -681,7 +681,13 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     // in two halves of 25 600 agents 75 -> 63 ms); from `shallow` up the first tier runs as persistent waves
     const long ncu = ctx->num_cu > 0 ? ctx->num_cu : 256;
     const bool tiny = (long)S * c_count < 8L * ncu && !ctx->force_persist && !ctx->tier1_env;
-    const bool shallow = (long)S * c_count < 16L * ncu * 8 && !ctx->force_persist && !ctx->tier1_env;
+    // (round 4, with the fitted launch-order key: launches whose agents are HEAVY -- the all-neighbour variants in scenes of >= 200 agents, every
+    // violating agent carries a row per neighbour: C3 16 x 1 000 agents 37 iterations each, C5 64 x 200 agents 29 -- are throughput-bound from a
+    // quarter of that depth on: persistent waves 1.50 / 0.89 ms against 1.77 / 1.05.  Light launches of the same depth -- 128 scenes x 100 agents
+    // of solveSoftDMPC at MPC step 12, one iteration per agent -- stay with one agent per workgroup: 0.21 against 0.25 ms.)
+    const bool heavy_agents = (p.variant == DMPC_VAR_SOFTALL || p.variant == DMPC_VAR_REPAIR || p.variant == DMPC_VAR_ELLIP || p.variant == DMPC_VAR_CPP1) && G * C >= 200;
+    // (crossover, agents per launch: C3 4 000: 0.72 / 0.71 ms, 8 000: 1.06 / 0.96; C5 3 200: 0.37 / 0.47, 6 400: 0.59 / 0.61 -- one agent per workgroup / persistent)
+    const bool shallow = (long)S * c_count < (heavy_agents ? 28L : 128L) * ncu && !ctx->force_persist && !ctx->tier1_env;
     const bool f32t = (ctx->precision & DMPC_PREC_F32FACTOR) != 0;   // fp32 inverse factor: one tier with the full capacity, no split T
     const int q1 = (ctx->single_tier || tiny || f32t) ? full_qcap(p.variant) : tier1_qcap(ctx, p.variant, G * C), q2 = full_qcap(p.variant);
     const bool two_tier = q1 < q2;
@@ -921,7 +927,7 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     // bound by their single slowest agent, which runs ~4 % faster in the leaner one-agent-per-workgroup kernel.
     size_t per1 = 0, per2 = 0;
     const int pw1 = persist_waves(q1, per1), pw2 = persist_waves(q2, per2);
-    const bool deep = !shallow && (long)S * c_count >= 16L * ctx->num_cu * (pw1 > 0 ? pw1 : 1);
+    const bool deep = !shallow && (long)S * c_count >= (heavy_agents ? 28L : 16L * (pw1 > 0 ? pw1 : 1)) * ctx->num_cu;
     // tier 2 as persistent waves over the flagged list (nearly always empty: the launch then costs a few microseconds
     // instead of one workgroup per agent just to find out that there is nothing to do)
     const bool t2_list = two_tier && !tiny && !ctx->no_persist && pw2 >= 2 && ctx->num_cu >= 1;

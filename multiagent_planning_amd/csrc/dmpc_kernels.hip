@@ -1520,7 +1520,7 @@ __global__ void order_kernel(int count, const int *__restrict__ hdr, int *__rest
         int heavy = h7 & 255;
         if (prev_cost) {
             const int pc = prev_cost[i] >> 4;
-            if (use_hint && pc > heavy) heavy = pc > 255 ? 255 : pc;
+            if (use_hint == 2 ? pc > 0 : (use_hint && pc > heavy)) heavy = pc > 255 ? 255 : pc;   // (2: the previous work alone -- in a replay of ONE step the perfect order: tools/gpu_order_oracle.py)
             if (h7 & 256) prev_cost[i] = 0;
         }
         const int key = (h7 & 256) ? 256 : 255 - heavy;   // bucket: heaviest first

@@ -8,7 +8,7 @@ import bench
 variant = sys.argv[1] if len(sys.argv) > 1 else "bound"
 precision = sys.argv[2] if len(sys.argv) > 2 else "f64"
 k_cap = int(sys.argv[3]) if len(sys.argv) > 3 else 12
-cfg, N, S = dict(wl.CONFIGS["C2"], variant=variant), 100, 512
+cfg, N, S = dict(wl.CONFIGS["C2"], variant=variant), 100, (int(sys.argv[4]) if len(sys.argv) > 4 else 512)
 kw = wl.solver_kwargs(cfg, N)
 d = mp.Dmpc(variant, precision=precision, **kw)
 l, xp, xv, xa, pf, alive = bench.capture_state(d, cfg, S, N, k_cap, wl.SEED0 + 2)

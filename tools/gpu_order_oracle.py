@@ -1,5 +1,5 @@
 """development (round 4): how much is the launch ORDER worth on a workload?  One captured closed-loop state of a config is solved repeatedly, once with the
-scan's key alone and once with option order_hint = 1 -- in a replay of ONE state the hint is the same step's own work estimate, i.e. (nearly) the
+scan's key alone and once with option order_hint = 2 (the previous work estimate INSTEAD of the key) -- in a replay of ONE state that is the same step's own work, i.e. (nearly) the
 perfect order, which no closed loop would see.  usage: python tools/gpu_order_oracle.py C3|C4|C5 [scenes] [mpc_step]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,7 +13,7 @@ kstep = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 kw = wl.solver_kwargs(cfg, N)
 po, pf = wl.make_scenes(cfg, min(S, 4), N, wl.SEED0 + 9)
 po, pf = np.tile(po, (S // min(S, 4), 1, 1)), np.tile(pf, (S // min(S, 4), 1, 1))
-for hint in (0, 1):
+for hint in (0, 2):
     d = mp.Dmpc(cfg["variant"], **kw)
     d.debug_option("order_hint", hint)
     l, _, _ = d.init_batch(po, pf)
