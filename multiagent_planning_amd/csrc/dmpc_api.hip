@@ -790,7 +790,7 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
             int *g_cnt = ctx->grid.as<int>(), *g_mh = g_cnt + n_cnt, *g_st = g_mh + n_mh, *g_cell = g_st + n_st;
             f4_t *g_ent = (f4_t *)(g_cnt + n_hd);
             HIPCHK(ctx, hipMemsetAsync(g_cnt, 0, (n_cnt + n_mh) * 4, st));
-            hipLaunchKernelGGL(grid_bin_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, S, C, short_from, gg, (const float *)ctx->bbox_nm.as<float>(), g_cell, g_cnt, g_mh);
+            hipLaunchKernelGGL(grid_bin_kernel, dim3((unsigned)((total + 255) / 256), NSEG), dim3(256), 0, st, total, S, C, short_from, gg, (const float *)ctx->bbox_nm.as<float>(), g_cell, g_cnt, g_mh);
             hipLaunchKernelGGL(grid_scan_kernel, dim3((unsigned)(S * NSEG)), dim3(256), 0, st, ncell, g_cnt, g_st);
             hipLaunchKernelGGL(grid_fill_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, S, C, ncell, (float)(1.0 / p.c), (const int *)g_cell, g_cnt, (const int *)g_st, (const float *)ctx->lrow.as<float>(), g_ent);
             const int nq = S * c_count;

@@ -1206,8 +1206,10 @@ __global__ void grid_bin_kernel(int total, int S, int C, int short_from, GridGeo
     const int ncell = gg.n[0] * gg.n[1] * gg.n[2];
     const int sc0 = __builtin_amdgcn_readfirstlane(scene);
     const bool uni = __all(scene == sc0);
-#pragma unroll
-    for (int sg = 0; sg < NSEG; ++sg) {
+    // (blockIdx.y = segment: a thread's work is a chain of dependent round trips -- loads, wave maxima, atomics -- and 10^4 threads do not fill
+    // the chip: three times as many, a third as long)
+    {
+        const int sg = (int)blockIdx.y;
         int cc[3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
