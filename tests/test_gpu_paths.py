@@ -155,3 +155,33 @@ def test_split_inverse_factor_does_not_change_a_bit(variant, N, S, opts):
         for k in ("status", "info", "p", "v", "a"):
             assert np.array_equal(x[k], y[k]), (variant, k)
     assert max(int(x["info"][..., 7].max()) for x in a) > 16      # some agent did take an extension
+
+
+def test_order_hint_is_pure_scheduling():
+    """option order_hint (the launch order also uses, or -- 2 -- is, every agent's work estimate of the context's previous step): another ORDER of the
+    same solves, so three closed-loop steps are identical bit for bit to the default order and to no order at all"""
+    cfg = wl.CONFIGS["C2"]
+    N, S = 100, 64                      # 6 400 agents per launch: the order kernel runs (>= 512)
+    kw = wl.solver_kwargs(cfg, N)
+    po, pf = wl.make_scenes(cfg, S, N, wl.SEED0 + 41)
+    base = _steps("bound", kw, po, pf, 3)
+    for opts in (dict(order_hint=1), dict(order_hint=2), dict(no_lpt=1)):
+        other = _steps("bound", kw, po, pf, 3, **opts)
+        for a, b in zip(base, other):
+            for k in ("status", "info", "p", "v", "a"):
+                assert np.array_equal(a[k], b[k]), (opts, k)
+
+
+def test_heavy_launches_as_persistent_waves_do_not_change_a_bit():
+    """the all-neighbour variants in scenes of >= 200 agents take persistent waves from 7 000 agents per launch on (round 4): 40 scenes x 200 agents of
+    solveSoftDMPCrepair against the same launch with one agent per workgroup"""
+    cfg = wl.CONFIGS["C5"]
+    N, S = 200, 40
+    kw = wl.solver_kwargs(cfg, N)
+    po, pf = wl.make_scenes(cfg, 4, N, wl.SEED0 + 43)
+    po, pf = np.tile(po, (S // 4, 1, 1)), np.tile(pf, (S // 4, 1, 1))
+    a = _steps("repair", kw, po, pf, 2)
+    b = _steps("repair", kw, po, pf, 2, no_persist=1)
+    for x, y in zip(a, b):
+        for k in ("status", "info", "p", "v", "a"):
+            assert np.array_equal(x[k], y[k]), k
