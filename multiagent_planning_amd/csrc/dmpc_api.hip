@@ -762,19 +762,17 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
         // 8 x 100 agents per scene still bins all 800: 0.87 against 0.64 ms, `bench.py --emulate-gpus 8 --debug-option grid_min=512`)
         const int grid_from = (c_count == G * C) ? ctx->grid_min : ctx->grid_min_part;
         const bool use_grid = ctx->nbr_grid && G * C >= grid_from && gq_lds <= 64 * 1024;
-        if (p.variant != DMPC_VAR_HARD || use_grid) {   // neighbour-major fp32 copy of the table: the list walk of the per-step distance scan, the distance test of the grid query
-            const size_t tot = (size_t)total * 64;
-            if (ctx->lrow.ensure(tot * 4)) FAIL(ctx, "device allocation failed (neighbour-major table)");
-            if (lTf) hipLaunchKernelGGL(table_nbrmajor_kernel<float>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, tot, C, lTf, ctx->lrow.as<float>());
-            else hipLaunchKernelGGL(table_nbrmajor_kernel<double>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, tot, C, lT, ctx->lrow.as<float>());
-            if (p.variant != DMPC_VAR_HARD) P.lrow = ctx->lrow.p;
-        }
+        // (grid geometry and buffer first: the counters are zeroed by the neighbour-major copy kernel, which runs anyway -- a memset of an odd
+        // size is two fill launches, 9 us)
+        GridGeom gg{};
+        int ncell = 1;
+        int *g_cnt = nullptr, *g_mh = nullptr, *g_st = nullptr, *g_cell = nullptr;
+        f4_t *g_ent = nullptr;
+        size_t n_zero = 0;
         if (use_grid) {
             // cells: R along x (the cells of a run along x are contiguous in the entry array: their granularity is free), 1.5 R along y
             // and 1.5 R c along z (the metric's z scale), at most 32 per axis
-            GridGeom gg;
             const double cell[3] = {R, 1.5 * R, 1.5 * R * p.c};
-            int ncell = 1;
             for (int a = 0; a < 3; ++a) {
                 const double span = p.pmax[a] - p.pmin[a];
                 int n = (int)(span / cell[a]);
@@ -787,11 +785,20 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
             const size_t n_cnt = (size_t)S * NSEG * ncell, n_mh = (size_t)S * NSEG * 3, n_st = (size_t)S * NSEG * (ncell + 1);
             const size_t n_hd = (n_cnt + n_mh + n_st + (size_t)NSEG * total + 7) & ~(size_t)7;   // (the entry records behind it are 32-byte aligned)
             if (ctx->grid.ensure((n_hd + 8 * (size_t)NSEG * total) * 4)) FAIL(ctx, "device allocation failed (neighbour grid)");
-            int *g_cnt = ctx->grid.as<int>(), *g_mh = g_cnt + n_cnt, *g_st = g_mh + n_mh, *g_cell = g_st + n_st;
-            f4_t *g_ent = (f4_t *)(g_cnt + n_hd);
-            HIPCHK(ctx, hipMemsetAsync(g_cnt, 0, (n_cnt + n_mh) * 4, st));
+            g_cnt = ctx->grid.as<int>(); g_mh = g_cnt + n_cnt; g_st = g_mh + n_mh; g_cell = g_st + n_st;
+            g_ent = (f4_t *)(g_cnt + n_hd);
+            n_zero = n_cnt + n_mh;
+        }
+        if (p.variant != DMPC_VAR_HARD || use_grid) {   // neighbour-major fp32 copy of the table: the list walk of the per-step distance scan, the distance test of the grid query
+            const size_t tot = (size_t)total * 64;
+            if (ctx->lrow.ensure(tot * 4)) FAIL(ctx, "device allocation failed (neighbour-major table)");
+            if (lTf) hipLaunchKernelGGL(table_nbrmajor_kernel<float>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, tot, C, lTf, ctx->lrow.as<float>(), g_cnt, n_zero);
+            else hipLaunchKernelGGL(table_nbrmajor_kernel<double>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, tot, C, lT, ctx->lrow.as<float>(), g_cnt, n_zero);
+            if (p.variant != DMPC_VAR_HARD) P.lrow = ctx->lrow.p;
+        }
+        if (use_grid) {
             hipLaunchKernelGGL(grid_bin_kernel, dim3((unsigned)((total + 255) / 256), NSEG), dim3(256), 0, st, total, S, C, short_from, gg, (const float *)ctx->bbox_nm.as<float>(), g_cell, g_cnt, g_mh);
-            hipLaunchKernelGGL(grid_scan_kernel, dim3((unsigned)(S * NSEG)), dim3(256), 0, st, ncell, g_cnt, g_st);
+            hipLaunchKernelGGL(grid_scan_kernel, dim3((unsigned)(S * NSEG)), dim3(ncell > 512 ? 1024 : 256), 0, st, ncell, g_cnt, g_st);
             hipLaunchKernelGGL(grid_fill_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, S, C, ncell, (float)(1.0 / p.c), (const int *)g_cell, g_cnt, (const int *)g_st, (const float *)ctx->lrow.as<float>(), g_ent);
             const int nq = S * c_count;
             hipLaunchKernelGGL(grid_query_kernel, dim3((unsigned)nq), dim3(64 * GQ_WAVES), gq_lds, st, S, G, C, g_local, c_first, c_count, gg,

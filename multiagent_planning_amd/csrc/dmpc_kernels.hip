@@ -1077,9 +1077,10 @@ __global__ void bbox_kernel(int total, int C, const TT *__restrict__ lT, float *
 // Neighbour-major fp32 copy of the prediction table for the list walk of the scan: out[chunk][scene][column][64] with element
 // 4k + axis = component (k, axis) of that neighbour's horizon, 0 in the fourth slot of every step and in the last four.
 template <typename TT>
-__global__ void table_nbrmajor_kernel(size_t total, int C, const TT *__restrict__ lT, float *__restrict__ out)
+__global__ void table_nbrmajor_kernel(size_t total, int C, const TT *__restrict__ lT, float *__restrict__ out, int *__restrict__ zbuf /* or null: the cell-grid counters, zeroed here */, size_t nz)
 {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (size_t z = t; z < nz; z += (size_t)gridDim.x * blockDim.x) zbuf[z] = 0;
     if (t >= total) return;
     const int l = (int)(t & 63), k4 = l >> 2, a4 = l & 3;
     const size_t gc = t >> 6, gs = gc / (size_t)C, c = gc - gs * (size_t)C;
@@ -1232,17 +1233,17 @@ __global__ void grid_bin_kernel(int total, int S, int C, int short_from, GridGeo
 // block per (scene, segment): start[..][0 .. ncell] = exclusive prefix of the cell counts; the counts are zeroed (grid_fill counts them up again)
 __global__ void grid_scan_kernel(int ncell, int *__restrict__ cnt, int *__restrict__ start)
 {
-    __shared__ int part[256];
+    __shared__ int part[1024];   // (blockDim.x <= 1024 threads per chunk: 1 560 cells at N = 10^4 are two chunks)
     __shared__ int carry;
-    const int scene = blockIdx.x, t = threadIdx.x;
+    const int scene = blockIdx.x, t = threadIdx.x, nt = (int)blockDim.x;
     int *c = cnt + (size_t)scene * ncell, *st = start + (size_t)scene * (ncell + 1);
     if (t == 0) carry = 0;
     __syncthreads();
-    for (int base = 0; base < ncell; base += 256) {
+    for (int base = 0; base < ncell; base += nt) {
         const int v = base + t < ncell ? c[base + t] : 0;
         part[t] = v;
         __syncthreads();
-        for (int off = 1; off < 256; off <<= 1) {
+        for (int off = 1; off < nt; off <<= 1) {
             const int add = t >= off ? part[t - off] : 0;
             __syncthreads();
             part[t] += add;
@@ -1250,7 +1251,7 @@ __global__ void grid_scan_kernel(int ncell, int *__restrict__ cnt, int *__restri
         }
         if (base + t < ncell) { st[base + t] = carry + part[t] - v; c[base + t] = 0; }
         __syncthreads();
-        if (t == 0) carry += part[255];
+        if (t == 0) carry += part[nt - 1];
         __syncthreads();
     }
     if (t == 0) st[ncell] = carry;
