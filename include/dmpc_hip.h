@@ -123,6 +123,8 @@ enum {
                           * residual is at 1e-13 or stops contracting).  Scan and rows fp64.  Not bit-compatible with DMPC_PREC_F64:
                           * the sweep (tests/test_gpu_precision.py) reports status agreement and l_inf per variant. */
     DMPC_PREC_LOW = 3    /* DMPC_PREC_MIXED | DMPC_PREC_F32FACTOR: fp32 table / scan / rows AND fp32 factor                      */
+    /* DMPC_VAR_ALL3 keeps the fp64 factor whatever the context's precision says: its three nearly parallel rows per neighbour are the
+     * one case the sweep found the fp32 factor unfit for (1 % of its agent-steps on another retry-ladder level). */
 };
 
 /* Create a solver context.  Replaces the constants/precompute preamble of dmpc/matlab/dmpc_soft_bound.m:80-108 and the DMPC ctor
@@ -143,6 +145,11 @@ enum {
  * Returns NULL on failure (no device, bad parameters); dmpc_last_error(NULL) has the text. */
 #define DMPC_DEVICE_CURRENT (-1)   /* (the value "current device" has had since the first version of this header) */
 #define DMPC_DEVICE_ALL (-100)
+/* ABI revision of this header.  The special device values changed once (the round-3 header had DMPC_DEVICE_ALL = -1, DMPC_DEVICE_CURRENT = -2;
+ * since revision 4 they are the two values above and any other negative device is refused), so a binding compiled against another header
+ * should compare dmpc_abi_version() with the DMPC_ABI_VERSION it was built with before its first dmpc_create. */
+#define DMPC_ABI_VERSION 5
+DMPC_API int dmpc_abi_version(void);
 DMPC_API dmpc_ctx *dmpc_create(const dmpc_params *prm, int device, int precision);
 /* number of GPUs the context drives (1 unless created with DMPC_DEVICE_ALL on a multi-GPU node) */
 DMPC_API int dmpc_group_size(const dmpc_ctx *ctx);
@@ -387,6 +394,17 @@ DMPC_API int dmpc_prop_state(dmpc_ctx *ctx, int n_rows, int n_cols, const double
                     double *p, double *v);
 DMPC_API int dmpc_is_inbounds(dmpc_ctx *ctx, int npts, const double *p, const double *pmin, const double *pmax, int32_t *inbounds);
 DMPC_API int dmpc_reached_goal(dmpc_ctx *ctx, int N, const double *p, const double *pf, double error_tol, int32_t *reached);
+
+/* Warm start of closed loops.  The reference solves every (k, n) QP from scratch (quadprog, solveSoftDMPCbound.m:103); the minimiser of
+ * these strictly convex QPs is unique, so where an exact solver STARTS is free.  The slack-carrying variants can start an agent's solve
+ * from the working set its previous MPC step ended with, moved one horizon step earlier: the same minimiser (to round-off: <= 1e-9,
+ * identical statuses and retry counts -- tests/test_gpu_warm.py), a fraction of the iterations.
+ *   dmpc_transition / dmpc_transition_sharded*   closed loops by construction: warm starts are ON inside them.
+ *   dmpc_step_batch / dmpc_step_device / dmpc_step_sharded_device   every call starts COLD unless dmpc_warm_start(ctx, 1) was called:
+ *       the caller then promises that consecutive calls of the same batch shape are consecutive MPC steps of the same agents
+ *       (a call with another shape, dmpc_warm_start itself and every transition forget the kept sets).  mode 0 = cold again.
+ * Benchmarks that REPLAY one captured MPC step must leave this off: a replayed step would start solved. */
+DMPC_API int dmpc_warm_start(dmpc_ctx *ctx, int mode);
 
 /* Agent-steps LAUNCHED by this context so far (incl. the half of a split dmpc_transition batch that runs on the internal
  * second context).  An upper bound of the QPs actually solved: agents of scenes that already stopped are skipped on the

@@ -221,7 +221,9 @@ def collision_rows(variant, po, vo, n, h, l, K, rmin, pmin, pmax, alim, Q1, S1, 
 def _c_of(E1, E2, order):
     E1, E2 = np.asarray(E1, float), np.asarray(E2, float)
     if int(order) != 2:
-        raise NotImplementedError("only order = 2 ellipsoids are supported (the only value the reference's scripts use)")
+        # (order 4 -- test/comp_test_ellipconstr.m:158 -- exists inside the all-neighbour SOLVERS (solveSoftDMPC, solveEllipDMPC,
+        # solveSoftDMPCrepair, DMPC::solveQP) and dmpc_rows_one; the dense row builders behind these standalone helpers are order 2)
+        raise NotImplementedError("the standalone dense row builders take order = 2 ellipsoids only (order 4: the all-neighbour solvers and rows_one)")
     if not (np.allclose(E1, np.diag(np.diag(E1))) and abs(E1[0, 0] - 1) < 1e-15 and abs(E1[1, 1] - 1) < 1e-15
             and np.allclose(E2, E1 @ E1, rtol=0, atol=1e-15)):
         raise NotImplementedError("E1 must be diag(1,1,1/c) and E2 = E1^2")

@@ -345,7 +345,7 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
     int *hdr = P.hdr + (size_t)gid * 8;
     if (P.scene_done && P.scene_done[scene]) {
         // the scene's transition is over (dmpc_transition): nothing to solve, the state stays frozen (status 0 = no update)
-        if (lane == 0) { hdr[0] = 0; hdr[1] = 0; hdr[2] = 0; hdr[3] = 0; hdr[4] = 8; hdr[5] = 0; hdr[6] = 0; hdr[7] = 0; P.status[gid] = 0; }
+        if (lane == 0) { hdr[0] = 0; hdr[1] = 0; hdr[2] = 0; hdr[3] = 0; hdr[4] = 8; hdr[5] = 0; hdr[6] = 0; hdr[7] = 0; P.status[gid] = 0; if (P.ws_n) P.ws_n[gid] = 0; }
         return;
     }
 
@@ -441,11 +441,13 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
         // neighbour with dist < sel_r (or all), in increasing neighbour index (CollConstrSoftDMPC.m:11-31)
         // one collision row, CollConstrSoftDMPC.m:16-28: neighbour offset (dx,dy,dz) and ellipsoidal distance at
         // the evaluation step (own position px,py,pz), constraining horizon step kc; compacted by ballot
-        auto emit_row = [&](bool sel, int kc, real dx, real dy, real dz, real dist, real px, real py, real pz) {
+        auto emit_row = [&](bool sel, int kc, real dx, real dy, real dz, real dist, real px, real py, real pz, int nbcode /* (chunk << 20) | column of the neighbour */) {
             const real sh = (real)(kc + 1) * h_;
             const real a0x = po_[0] + sh * vo_[0], a0y = po_[1] + sh * vo_[1], a0z = po_[2] + sh * vo_[2];
             // diff = E2*(p - pj).^(order-1); pd = prev_dist = dist^(order-1) (P.e2z = c^-order)
-            const real x0 = ord4 ? dx * dx * dx : dx, x1 = ord4 ? dy * dy * dy : dy, x2 = (ord4 ? dz * dz * dz : dz) * e2z;
+            // (order 4, DMPC::solveQP: dmpc.cpp:47,478 scale before the power, (E2 d).^3 -- z component (c^-4 dz)^3; the MATLAB helpers E2 * d.^3)
+            const real dzs = dz * e2z;
+            const real x0 = ord4 ? dx * dx * dx : dx, x1 = ord4 ? dy * dy * dy : dy, x2 = ord4 ? (var == VAR_CPP1 ? dzs * dzs * dzs : dz * dz * dz * e2z) : dzs;
             const real pd = ord4 ? dist * dist * dist : dist;
             {
                 const unsigned long long m0 = __ballot(sel);
@@ -499,6 +501,7 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
                 L.r_xi[3 * pos] = x0; L.r_xi[3 * pos + 1] = x1; L.r_xi[3 * pos + 2] = x2;
                 L.r_b[pos] = -rr;
                 L.r_kc[pos] = kc;
+                if (P.rownb) P.rownb[(size_t)gid * nrmax + pos] = nbcode;   // warm start of closed loops: which neighbour the row belongs to
                     if (soft) {
                     real sd = pd, st = P.term, slb = -0.05;
                     if (var == VAR_BOUND2 || var == VAR_ALL3) slb = -0.01;           // bound2:77, all:92
@@ -532,7 +535,7 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
                     const real sz = (qz - bsel[2 * (size_t)C]) * e1z;
                     dsel = sqrt(sx * sx + sy * sy + sz * sz);
                 }
-                emit_row(valid && (sel_all || dsel < sel_r), kc, dx, dy, dz, dist, px, py, pz);
+                emit_row(valid && (sel_all || dsel < sel_r), kc, dx, dy, dz, dist, px, py, pz, (r << 20) | jc);
             }
         };
 
@@ -552,7 +555,7 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
                 const real dx = px - nb[0], dy = py - nb[(size_t)C], dz = pz - nb[2 * (size_t)C];
                 const real ez = dz * e1z;
                 const real dist = sqrt(dx * dx + dy * dy + ez * ez);
-                emit_row(have && dist < 1.0, kk, dx, dy, dz, dist, px, py, pz);
+                emit_row(have && dist < 1.0, kk, dx, dy, dz, dist, px, py, pz, code & 0x0fffffff);
             }
             ncand = 0;
             LSYNC();
@@ -894,6 +897,7 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
                 }
                 if (lane == 0) {
                     Qp->status[gid] = st;
+                    if (Qp->ws_n) Qp->ws_n[gid] = 0;   // (warm start: nothing was active)
                     hdr[4] = (violation ? 1 : 0) | (coll_flag ? 4 : 0) | 16;
                     hdr[7] = 256;   // (the order kernel reads this word only)
                     if (Qp->info) {

@@ -453,7 +453,10 @@ static void build_row(const ctx_t *c, const orc_params *prm, const double *l, in
          *   r = dist^3*(rmin - dist + diff*p/dist^3) - diff*A_initp(3(kc-1)+1:3kc,:)*[po';vo'] */
         const double dist4 = edist_o(p, pj, cc, 4), pd = dist4 * dist4 * dist4, c4 = cc * cc * cc * cc;
         const double d0 = p[0] - pj[0], d1 = p[1] - pj[1], d2 = p[2] - pj[2];
-        const double df[3] = {d0 * d0 * d0, d1 * d1 * d1, d2 * d2 * d2 / c4};
+        /* DMPC::solveQP's rows (dmpc/cpp/dmpc.cpp:47 _E2 = E1.^order, :478 diff = (_E2*(p - pj)).^(order-1)) scale BEFORE the power:
+         * z component (c^-4 dz)^3, where the MATLAB helpers (CollConstrEllipDMPC.m:13, `.^` binds tighter) give c^-4 dz^3 */
+        const double dzs = d2 / c4;
+        const double df[3] = {d0 * d0 * d0, d1 * d1 * d1, prm->variant == ORC_CPP1 ? dzs * dzs * dzs : d2 * d2 * d2 / c4};
         const double dp4 = df[0] * p[0] + df[1] * p[1] + df[2] * p[2];
         double da4 = 0.0;
         for (int t = 0; t < 3; ++t) {

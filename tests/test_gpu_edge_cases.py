@@ -208,3 +208,29 @@ def test_super_ellipsoid_of_order_4(variant):
         xv5 = np.where(ok[:, None], o["v"][:, :3], xv5); xa5 = np.where(ok[:, None], o["a"][:, :3], xa5)
     with pytest.raises(Exception, match="order"):
         mp.Dmpc("bound", order=4, **kw)
+
+
+@pytest.mark.parametrize("variant", ["softall", "ellip", "repair", "cpp1"])
+def test_rows_one_of_order_4_matches_the_oracle(variant):
+    """dmpc_rows_one (the standalone a5/a6 entry behind the CollConstr* / CheckColl* shims) on an order-4 context: it launched the order-2
+    scan kernel until round 5 (rows with dist = 2-norm and z scaled by c^-4: neither order).  GPU rows against the oracle's, whose order-4
+    branches are checked against literal restatements in tests/test_oracle_golden.py."""
+    from helpers import load_golden
+    g, kw = load_golden("comp_kctr_3_bound2")
+    l, xp, xv = g["l"], g["pk"][:, 12], g["vk"][:, 12]
+    d, prm = mp.Dmpc(variant, order=4, **kw), orc.make_params(variant, order=4, **kw)
+    Lam = orc.model_matrices(kw["h"], 15)[0]
+    checked = 0
+    for n in range(0, l.shape[0], 5):
+        r, o = d.rows_one(l, n, xp[n], xv[n]), orc.rows_one(prm, l, n, xp[n], xv[n])
+        assert r["nrows"] == o["nrows"] and r["viol_k"] == o["viol_k"], n
+        if r["nrows"] == 0:
+            continue
+        G = np.asarray(o["G"]).reshape(-1, 45)
+        for i in range(r["nrows"]):
+            kc = r["kc"][i]
+            dense = -(r["xi"][i] @ Lam[3 * (kc - 1):3 * kc])
+            assert np.abs(dense - G[i]).max() < 1e-12 * max(1.0, np.abs(G[i]).max()), (n, i)
+        assert np.abs(r["rhs"] - np.asarray(o["b"])).max() < 1e-11, n
+        checked += 1
+    assert checked > 3

@@ -235,3 +235,39 @@ def test_order_4_rows_of_the_oracle_follow_CollConstrEllipDMPC_literally():
             assert np.abs(np.asarray(r["G"]).reshape(-1, 45) - A).max() < 1e-11
             checked += 1
         assert checked > 10
+
+
+def test_order_4_rows_of_the_first_cpp_version_scale_before_the_power():
+    """DMPC::solveQP's rows for order 4 (dmpc/cpp/dmpc.cpp:47 `_E2 = _E1.array().pow(_order)`, :476-481
+    `diff = (_E2*(prev_p - pj)).array().pow(_order - 1)`, `r = pow(dist,_order-1)*(_rmin - dist) + diff'*prev_p - diff'*A0*x0`): the z
+    component is (c^-4 dz)^3, not the c^-4 dz^3 of the MATLAB helpers (`.^` binds tighter there).  The oracle's cpp1 branch against a
+    literal numpy restatement of those lines; rows on step k-1 (`3*(k-1)`, 0-based k)."""
+    g, kw = load_golden("comp_kctr_3_bound2")
+    l, xp, xv = g["l"], g["pk"][:, 12], g["vk"][:, 12]
+    N = l.shape[0]
+    Lam, Av, A0, Dl = orc.model_matrices(kw["h"], 15)
+    prm = orc.make_params("cpp1", order=4, **kw)
+    E1 = np.diag([1, 1, 1 / kw["c"]]); E2 = E1 ** 4
+    checked = 0
+    for n in range(0, N, 3):
+        r = orc.rows_one(prm, l, n, xp[n], xv[n])
+        if r["nrows"] == 0:
+            continue
+        k1 = r["viol_k"]                    # 1-based first violating step; the rows constrain step k1 - 1 (1-based)
+        kc = k1 - 1
+        own = l[n].reshape(15, 3)[k1 - 1]
+        x0 = np.r_[xp[n], xv[n]]
+        rows_G, rows_b = [], []
+        for j in range(N):
+            if j == n:
+                continue
+            pj = l[j].reshape(15, 3)[k1 - 1]
+            dist = (np.abs(E1 @ (own - pj)) ** 4).sum() ** 0.25
+            diff = (E2 @ (own - pj)) ** 3
+            rr = dist ** 3 * (kw["rmin"] - dist) + diff @ own - diff @ A0[3 * (kc - 1):3 * kc] @ x0
+            row = np.zeros(45); row[3 * (kc - 1):3 * kc] = diff
+            rows_G.append(-row @ Lam); rows_b.append(-rr)
+        assert np.abs(np.asarray(r["G"]).reshape(-1, 45) - np.array(rows_G)).max() < 1e-11
+        assert np.abs(np.asarray(r["b"]) - np.array(rows_b)).max() < 1e-11
+        checked += 1
+    assert checked > 5

@@ -1,0 +1,49 @@
+"""development (DEV_TRACE build: python tools/with_trace_lib.py tools/gpu_c4_iter_trace.py [mpc_step] [rank]): the pivot sequence of one heavy agent of
+the 10^4-agent scene (C4) -- which constraints enter, how often each, full steps against partial steps (drops)."""
+import sys, os, ctypes as C, collections
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import multiagent_planning_amd as mp
+from multiagent_planning_amd import workload as wl, _lib
+N = 10000
+kstep = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+rank = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+cfg = wl.CONFIGS["C4"]; kw = wl.solver_kwargs(cfg, N)
+po, pf = wl.make_scenes(cfg, 1, N, wl.SEED0 + 4)
+d = mp.Dmpc(cfg["variant"], **kw)
+l, _, _ = d.init_batch(po, pf)
+xp, xv, xa = po.copy(), np.zeros_like(po), np.zeros_like(po)
+for k in range(kstep - 2):
+    out = d.step_batch(l, xp, xv, xa, pf)
+    ok = out["status"] == 1
+    l = np.where(ok[..., None], out["p"], l); xp = np.where(ok[..., None], out["p"][..., :3], xp)
+    xv = np.where(ok[..., None], out["v"][..., :3], xv); xa = np.where(ok[..., None], out["a"][..., :3], xa)
+o_ = d.step_batch(l, xp, xv, xa, pf)
+g = int(np.argsort(o_["info"][0, :, 4])[::-1][rank])
+L = _lib.load()
+L.dmpc_debug_trace.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+cap = 400
+L.dmpc_debug_trace(d._ctx, g, cap, None)
+out = d.step_batch(l, xp, xv, xa, pf)
+buf = np.zeros((cap, 8))
+L.dmpc_debug_trace(d._ctx, g, cap, buf.ctypes.data_as(C.c_void_p))
+i = out["info"][0, g]
+print(f"agent {g} status {out['status'][0, g]} viol_k {i[0]} rows {i[1]} tries {i[2]} iters {i[4]} nslack {i[5]} active {i[6]} maxq {i[7]}")
+print("solves of this agent (ladder count after, iterations, of them appends without a step, verdict 0 ok / 1 infeasible / 2 slots / 3 cap, final slots, level check, 2^k scaling):")
+for r in buf[cap - 12:cap - 4]:
+    if r[1] > 0: print("   ", [int(x) for x in r[:7]])
+names = ["BH", "BL", "PH", "PL", "CO", "SU", "SL"]
+cnt = collections.Counter(); seq = []
+nfull = npart = 0
+for r in buf[:cap - 12]:
+    if r[3] == 0: continue
+    code = int(r[0]); ty, idx = code >> 16, code & 0xffff
+    nm = f"{names[ty]}{idx // 3}{'xyz'[idx % 3]}" if ty < 4 else f"{names[ty]}{idx}"
+    full = r[5] <= r[4]
+    dep = not (r[2] > 1e-13 * r[3])
+    seq.append(f"{nm}{'+' if full else '-'}{'!' if dep else ''}@{int(r[1])}")
+    if full: cnt[nm] += 1; nfull += 1
+    else: npart += 1
+print(f"recorded iterations (last try wins on shared indices): full steps {nfull}, partial steps (drops) {npart}")
+print(" ".join(seq))
+print("constraints added more than once:", {k: v for k, v in cnt.items() if v > 1})
