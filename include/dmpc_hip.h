@@ -395,17 +395,6 @@ DMPC_API int dmpc_prop_state(dmpc_ctx *ctx, int n_rows, int n_cols, const double
 DMPC_API int dmpc_is_inbounds(dmpc_ctx *ctx, int npts, const double *p, const double *pmin, const double *pmax, int32_t *inbounds);
 DMPC_API int dmpc_reached_goal(dmpc_ctx *ctx, int N, const double *p, const double *pf, double error_tol, int32_t *reached);
 
-/* Warm start of closed loops.  The reference solves every (k, n) QP from scratch (quadprog, solveSoftDMPCbound.m:103); the minimiser of
- * these strictly convex QPs is unique, so where an exact solver STARTS is free.  The slack-carrying variants can start an agent's solve
- * from the working set its previous MPC step ended with, moved one horizon step earlier: the same minimiser (to round-off: <= 1e-9,
- * identical statuses and retry counts -- tests/test_gpu_warm.py), a fraction of the iterations.
- *   dmpc_transition / dmpc_transition_sharded*   closed loops by construction: warm starts are ON inside them.
- *   dmpc_step_batch / dmpc_step_device / dmpc_step_sharded_device   every call starts COLD unless dmpc_warm_start(ctx, 1) was called:
- *       the caller then promises that consecutive calls of the same batch shape are consecutive MPC steps of the same agents
- *       (a call with another shape, dmpc_warm_start itself and every transition forget the kept sets).  mode 0 = cold again.
- * Benchmarks that REPLAY one captured MPC step must leave this off: a replayed step would start solved. */
-DMPC_API int dmpc_warm_start(dmpc_ctx *ctx, int mode);
-
 /* Agent-steps LAUNCHED by this context so far (incl. the half of a split dmpc_transition batch that runs on the internal
  * second context).  An upper bound of the QPs actually solved: agents of scenes that already stopped are skipped on the
  * device, and agents the scan certifies infeasible never enter the solver; per-agent outcomes are in status[]. */

@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "dmpc_trajectories2file", "dmpc_test2file", "dmpc_random_test", "dmpc_random_exchange", "dmpc_random_sets_device",
     "dmpc_prop_state", "dmpc_is_inbounds", "dmpc_reached_goal", "dmpc_rows_dense",
     "dmpc_partition", "dmpc_comm_unique_id", "dmpc_comm_init", "dmpc_comm_destroy", "dmpc_step_sharded_device",
-    "dmpc_transition_sharded", "dmpc_transition_sharded_gather", "dmpc_group_size", "dmpc_comm_size", "dmpc_warm_start", "dmpc_abi_version",
+    "dmpc_transition_sharded", "dmpc_transition_sharded_gather", "dmpc_group_size", "dmpc_comm_size", "dmpc_abi_version",
 ]
 
 
@@ -117,7 +117,6 @@ def load():
     L.dmpc_group_size.argtypes = [vp]
     L.dmpc_debug_emulate_devices.argtypes = [C.c_int]
     L.dmpc_debug_option.argtypes = [vp, C.c_char_p, C.c_int]
-    L.dmpc_warm_start.argtypes = [vp, C.c_int]
     L.dmpc_solve_count.restype = C.c_int64
     L.dmpc_solve_count.argtypes = [vp]
     L.dmpc_profile.argtypes = [vp, C.c_int]
@@ -464,12 +463,6 @@ class Dmpc:
 
     def advance_device(self, count, p_out, v_out, a_out, status, x_p, x_v, x_a, stream=0):
         self._chk(self._L.dmpc_advance_device(self._ctx, count, p_out, v_out, a_out, status, x_p, x_v, x_a, stream or None))
-
-    def warm_start(self, on=True):
-        """closed loops driven through step_batch / step_device: consecutive calls are consecutive MPC steps of the same agents, every solve
-        starts from the agent's previous working set (dmpc_warm_start); False: every solve starts cold (the default).  Either forgets the kept sets."""
-        self._chk(self._L.dmpc_warm_start(self._ctx, 1 if on else 0))
-        return self
 
     def profile(self, enable=True):
         self._chk(self._L.dmpc_profile(self._ctx, 1 if enable else 0))

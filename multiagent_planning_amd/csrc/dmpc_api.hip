@@ -102,13 +102,6 @@ struct dmpc_ctx {
     int no_lpt = 0;          // development option no_lpt: no heaviest-first solve order
     int order_hint = 0;      // option order_hint = 1: the launch order also uses the agents' work estimates of the context's previous step (measured: no gain in
                              // closed loops -- the heavy agents of a step are not the heavy agents of the step before -- so off; a replay of ONE step would flatter it)
-    // Warm start of closed loops (round 5; slack variants): every agent's final working set seeds its next MPC step (dmpc_solve.hip).  `warm`: the
-    // step entry points carry the sets from call to call (dmpc_warm_start: the caller promises consecutive MPC steps of the same agents);
-    // `warm_transition`: set by the transition loops for their duration (development option no_warm_start = 1: transitions start every solve cold).
-    int warm = 0, warm_transition = 0, no_warm_start = 0;
-    int bulk_rounds = 3;     // development option bulk_rounds: primal-dual active-set rounds of the slack kernels after the crash start's first batch (0: the round-4 iteration, bit for bit)
-    long ws_shape = -1;      // batch shape the kept sets belong to (-1: none; the next launch starts from empty sets)
-    DevBuf ws_set, ws_n, rownb;
     DevBuf prev_cost;        // [S * c_count] work estimates of the previous step (solve kernel -> order kernel)
     long prev_cost_shape = -1;
     int crash_min = CRASH_MIN_DEFAULT;   // see StepParams::crash_min (development option crash_min; crash_any: also for the slack-free variants)
@@ -410,7 +403,7 @@ extern "C" int dmpc_debug_option(dmpc_ctx *ctx, const char *name, int value)
         {"no_fuse", &dmpc_ctx::no_fuse}, {"no_persist", &dmpc_ctx::no_persist}, {"force_persist", &dmpc_ctx::force_persist}, {"no_cull", &dmpc_ctx::no_cull}, {"order_slices", &dmpc_ctx::order_slices}, {"cull_min", &dmpc_ctx::cull_min},
         {"no_lpt", &dmpc_ctx::no_lpt}, {"order_hint", &dmpc_ctx::order_hint}, {"crash_min", &dmpc_ctx::crash_min}, {"crash_any", &dmpc_ctx::crash_any}, {"no_fast_exit", &dmpc_ctx::no_fast_exit}, {"pivot_explore", &dmpc_ctx::pivot_explore},
         {"iter_cap", &dmpc_ctx::iter_cap}, {"tier1_qcap", &dmpc_ctx::tier1_env}, {"split_parts", &dmpc_ctx::split_parts}, {"no_split", &dmpc_ctx::no_split},
-        {"static_queue", &dmpc_ctx::static_queue}, {"no_split_t", &dmpc_ctx::no_split_t}, {"ext_cap", &dmpc_ctx::ext_cap}, {"nbr_grid", &dmpc_ctx::nbr_grid}, {"f32_dep_exp", &dmpc_ctx::f32_dep_exp}, {"grid_min", &dmpc_ctx::grid_min}, {"no_level_check", &dmpc_ctx::no_level_check}, {"no_warm_start", &dmpc_ctx::no_warm_start}, {"bulk_rounds", &dmpc_ctx::bulk_rounds}};
+        {"static_queue", &dmpc_ctx::static_queue}, {"no_split_t", &dmpc_ctx::no_split_t}, {"ext_cap", &dmpc_ctx::ext_cap}, {"nbr_grid", &dmpc_ctx::nbr_grid}, {"f32_dep_exp", &dmpc_ctx::f32_dep_exp}, {"grid_min", &dmpc_ctx::grid_min}, {"no_level_check", &dmpc_ctx::no_level_check}};
     for (auto &t : tab)
         if (!std::strcmp(t.n, name)) {
             ctx->*(t.f) = value;
@@ -554,18 +547,6 @@ extern "C" int dmpc_set_params(dmpc_ctx *ctx, const dmpc_params *prm)
     return upload_tables(ctx);
 }
 
-// Warm start of the step entry points (closed loops driven by the caller): mode 1 = every agent's solve starts from the working set its
-// previous call ended with (shifted by one horizon step); mode 0 = every solve starts cold (the default).  Either call forgets the kept sets.
-extern "C" int dmpc_warm_start(dmpc_ctx *ctx, int mode)
-{
-    if (!ctx) { g_err = "dmpc_warm_start: ctx is NULL"; return -1; }
-    if (mode != 0 && mode != 1) FAIL(ctx, "dmpc_warm_start: mode must be 0 or 1");
-    ctx->warm = mode; ctx->ws_shape = -1;
-    for (dmpc_ctx *pc : ctx->peers) (void)dmpc_warm_start(pc, mode);
-    for (dmpc_ctx *ch : ctx->children) (void)dmpc_warm_start(ch, mode);
-    return 0;
-}
-
 extern "C" int64_t dmpc_solve_count(const dmpc_ctx *ctx)
 {
     if (!ctx) return 0;
@@ -630,13 +611,6 @@ static int tier1_qcap(const dmpc_ctx *ctx, int variant, int scene_agents);
 // hard: 45 variables => at most 45 independent active rows; 48 leaves room for a numerically near-dependent addition
 static int full_qcap(int variant) { return variant_soft(variant) ? QMAX : 48; }
 
-// a transition loop: warm starts on for its duration, from empty sets (option no_warm_start: off)
-struct WarmScope {
-    dmpc_ctx *c;
-    explicit WarmScope(dmpc_ctx *ctx) : c(ctx) { c->warm_transition = c->no_warm_start ? 0 : 1; c->ws_shape = -1; }
-    ~WarmScope() { c->warm_transition = 0; c->ws_shape = -1; }
-};
-
 // what follows a solve in a closed loop (post_step_kernel); launch_step folds it into the solve kernel when the launch is tiny and
 // single-tier, and reports that in ctx->post_fused
 struct PostStep {
@@ -692,14 +666,6 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
             FAIL(ctx, "device allocation failed (row scratch)");
         P.rowbuf = ctx->rowbuf.as<double>(); P.rowkc = ctx->rowkc.as<int>(); P.hdr = ctx->hdr.as<int>();
     }
-    if (soft && (ctx->warm || ctx->warm_transition)) {   // warm start: the sets of the previous step of THIS batch shape (anything else starts from empty sets)
-        const size_t agents = (size_t)S * c_count;
-        if (ctx->ws_set.ensure(agents * QMAX * 8) || ctx->ws_n.ensure(agents * 4) || ctx->rownb.ensure(agents * P.nrmax * 4))
-            FAIL(ctx, "device allocation failed (warm-start sets)");
-        const long shape = ((long)S << 40) ^ ((long)G << 34) ^ ((long)g_local << 28) ^ ((long)c_first << 14) ^ ((long)c_count << 4) ^ (long)p.variant;
-        if (shape != ctx->ws_shape) { HIPCHK(ctx, hipMemsetAsync(ctx->ws_n.p, 0, agents * 4, st)); ctx->ws_shape = shape; }
-        P.ws_set = ctx->ws_set.as<int>(); P.ws_n = ctx->ws_n.as<int>(); P.rownb = ctx->rownb.as<int>();
-    }
     P.dbg = ctx->dbg; P.dbg_agent = ctx->dbg_agent; P.dbg_cap = ctx->dbg_cap;
     P.iter_cap = ctx->iter_cap;
     P.dep_tol_f32 = std::pow(10.0, -(double)ctx->f32_dep_exp);
@@ -710,7 +676,6 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     // (C2: -16 % throughput: with rows at every horizon step the bounds violated at the unconstrained minimiser are a poor guess)
     P.crash_min = (soft || ctx->crash_any) ? ctx->crash_min : 0;
     P.pivot_explore = ctx->pivot_explore;
-    P.bulk_rounds = soft ? ctx->bulk_rounds : 0;
     // tiny launches (a scene or a few, every agent resident at once: bound by the latency of their slowest agent, LDS is no
     // constraint) solve with the full working-set capacity in one launch; larger ones use the first tier and re-solve the few
     // agents that outgrow it (the smaller footprint also puts 6 instead of 4 one-agent workgroups on a CU: 512 transitions
@@ -1344,7 +1309,6 @@ static int transition_one(dmpc_ctx *ctx, int S, int N, const double *po, const d
         ctx->hist_a.ensure(hist) || ctx->flags.ensure((size_t)K_T_max * S * 8) || ctx->scene_done.ensure((size_t)S * 4))
         FAIL(ctx, "device allocation failed");
     hipStream_t st = ctx->stream;
-    WarmScope warm_scope(ctx);   // the loop below is a closed loop: every solve starts from the agent's previous working set
     double *xp = ctx->xp.as<double>(), *xv = ctx->xv.as<double>(), *xa = ctx->xa.as<double>();
     HIPCHK(ctx, hipMemcpyAsync(ctx->po.p, po, A * 24, hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipMemcpyAsync(ctx->pf.p, pf, A * 24, hipMemcpyHostToDevice, st));
@@ -1448,10 +1412,10 @@ static int transition_one(dmpc_ctx *ctx, int S, int N, const double *po, const d
 static void copy_debug_options(dmpc_ctx *dst, const dmpc_ctx *src)
 {
     static const char *names[] = {"no_fuse", "no_persist", "force_persist", "no_cull", "order_slices", "cull_min", "no_lpt", "crash_min", "crash_any", "no_fast_exit",
-                                  "pivot_explore", "iter_cap", "tier1_qcap", "static_queue", "no_split_t", "ext_cap", "nbr_grid", "f32_dep_exp", "grid_min", "no_level_check", "order_hint", "no_warm_start", "bulk_rounds"};
+                                  "pivot_explore", "iter_cap", "tier1_qcap", "static_queue", "no_split_t", "ext_cap", "nbr_grid", "f32_dep_exp", "grid_min", "no_level_check", "order_hint"};
     int dmpc_ctx::*fields[] = {&dmpc_ctx::no_fuse, &dmpc_ctx::no_persist, &dmpc_ctx::force_persist, &dmpc_ctx::no_cull, &dmpc_ctx::order_slices, &dmpc_ctx::cull_min,
                                &dmpc_ctx::no_lpt, &dmpc_ctx::crash_min, &dmpc_ctx::crash_any, &dmpc_ctx::no_fast_exit, &dmpc_ctx::pivot_explore, &dmpc_ctx::iter_cap,
-                               &dmpc_ctx::tier1_env, &dmpc_ctx::static_queue, &dmpc_ctx::no_split_t, &dmpc_ctx::ext_cap, &dmpc_ctx::nbr_grid, &dmpc_ctx::f32_dep_exp, &dmpc_ctx::grid_min, &dmpc_ctx::no_level_check, &dmpc_ctx::order_hint, &dmpc_ctx::no_warm_start, &dmpc_ctx::bulk_rounds};
+                               &dmpc_ctx::tier1_env, &dmpc_ctx::static_queue, &dmpc_ctx::no_split_t, &dmpc_ctx::ext_cap, &dmpc_ctx::nbr_grid, &dmpc_ctx::f32_dep_exp, &dmpc_ctx::grid_min, &dmpc_ctx::no_level_check, &dmpc_ctx::order_hint};
     for (size_t i = 0; i < sizeof(names) / sizeof(names[0]); ++i) (void)dmpc_debug_option(dst, names[i], src->*(fields[i]));
 }
 

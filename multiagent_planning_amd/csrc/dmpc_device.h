@@ -84,14 +84,6 @@ struct StepParams {
     int *cost_out;          // [S*c_count] or null: work estimate of this agent's solve (quarter microseconds: iterations weighted by the working-set size,
                             // certificate calls) -- the NEXT step's launch order is built from it (order_kernel; dmpc_api.hip: order hint)
     int iter_cap;           // active-set iteration cap per try (ITER_CAP; development runs lower it to measure the per-iteration cost)
-    // Warm start of closed loops (round 5; slack-carrying variants): the final working set of every agent's solve is kept -- ws_set[agent][QMAX]
-    // pairs {type | constrained step << 8, component or neighbour code}, ws_n[agent] slots (0: none) -- and seeds the agent's next MPC step,
-    // shifted by one horizon step (dmpc_solve.hip).  rownb[agent][nrmax]: the neighbour (chunk << 20 | column) behind every collision row
-    // of this step (written by the scan), the identity of a row from one step to the next.  All null: every solve starts cold.
-    int *rownb;
-    int *ws_set;
-    int *ws_n;
-    int bulk_rounds;        // slack variants: primal-dual active-set rounds after the crash start's first batch (dmpc_solve.hip; 0: none -- the round-4 path, bit for bit)
 };
 
 constexpr int SCAN_CAND_CAP = 1024;   // (neighbour, step) candidates buffered per flush of the hard-row scan

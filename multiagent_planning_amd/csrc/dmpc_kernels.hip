@@ -208,11 +208,17 @@ __device__ __forceinline__ KargPtr kernarg_params()
 // nearly exact and the ladder jumps straight to the first level that can work instead of proving 2-3 levels
 // infeasible with 100+ iterations each.  Only the first 128 rows are used.  Out of line: it runs for a handful
 // of agents per launch and must not cost the solver's hot loop any registers.
+// `pl_planes`: planes (4 doubles each) the scratch `pl` holds -- the rows of a step beyond pl_planes - 6 are left out.  Until round 5 that was
+// 26 rows everywhere (the two 64-double staging vectors), and the heaviest agents of the 10^4-agent scene are exactly those with 27-40 rows on
+// their step: the certificate passed levels that the rows it did not look at make infeasible, and the dual method then proved each of them
+// with 40-50 iterations at 4-5 us (tools/gpu_c4_iter_trace.py: 81 + 73 of an agent's 207 iterations).  The callers now hand over what is dead
+// at the time: the three staging vectors inside a solve (44 planes), the inverse factor's block between two solves (128 rows).
 __device__ __attribute__((noinline)) bool ladder_level_infeasible(const double *__restrict__ r_xi, const double *__restrict__ r_b,
                                                                   const double *__restrict__ r_sd, const double *__restrict__ r_slb,
                                                                   const int *__restrict__ r_kc, int nr, double *pl, double h,
-                                                                  double alim, double f, double whi_l, double wlo_l, int lane)
+                                                                  double alim, double f, double whi_l, double wlo_l, int lane, const int pl_planes = 32)
 {
+    const int mcap = pl_planes - 6;
     const int kc0 = lane < nr ? r_kc[lane] : -1, kc1 = lane + 64 < nr ? r_kc[lane + 64] : -1;
     bool empty_any = false;
     for (int k = 0; k < K && !empty_any; ++k) {
@@ -220,7 +226,7 @@ __device__ __attribute__((noinline)) bool ladder_level_infeasible(const double *
         const unsigned long long m0 = __ballot(s0), m1 = __ballot(s1);
         const int c0 = __popcll(m0), m = c0 + __popcll(m1);
         if (m == 0) continue;
-        const int M = m < 26 ? m : 26;
+        const int M = m < mcap ? m : mcap;
         const double sh = (double)(k + 1) * h, R = 0.5 * alim * sh * sh;
         LSYNC();
         {
@@ -229,7 +235,7 @@ __device__ __attribute__((noinline)) bool ladder_level_infeasible(const double *
             for (int c = 0; c < 2; ++c) {
                 const bool sel = c ? s1 : s0;
                 const int pp = c ? p1 : p0;
-                if (sel && pp < 26) {
+                if (sel && pp < mcap) {
                     const int i = lane + 64 * c;
                     const double x0 = r_xi[3 * i], x1 = r_xi[3 * i + 1], x2 = r_xi[3 * i + 2];
                     const double rhs = r_b[i] - r_sd[i] * r_slb[i] * f;
@@ -345,7 +351,7 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
     int *hdr = P.hdr + (size_t)gid * 8;
     if (P.scene_done && P.scene_done[scene]) {
         // the scene's transition is over (dmpc_transition): nothing to solve, the state stays frozen (status 0 = no update)
-        if (lane == 0) { hdr[0] = 0; hdr[1] = 0; hdr[2] = 0; hdr[3] = 0; hdr[4] = 8; hdr[5] = 0; hdr[6] = 0; hdr[7] = 0; P.status[gid] = 0; if (P.ws_n) P.ws_n[gid] = 0; }
+        if (lane == 0) { hdr[0] = 0; hdr[1] = 0; hdr[2] = 0; hdr[3] = 0; hdr[4] = 8; hdr[5] = 0; hdr[6] = 0; hdr[7] = 0; P.status[gid] = 0; }
         return;
     }
 
@@ -441,7 +447,7 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
         // neighbour with dist < sel_r (or all), in increasing neighbour index (CollConstrSoftDMPC.m:11-31)
         // one collision row, CollConstrSoftDMPC.m:16-28: neighbour offset (dx,dy,dz) and ellipsoidal distance at
         // the evaluation step (own position px,py,pz), constraining horizon step kc; compacted by ballot
-        auto emit_row = [&](bool sel, int kc, real dx, real dy, real dz, real dist, real px, real py, real pz, int nbcode /* (chunk << 20) | column of the neighbour */) {
+        auto emit_row = [&](bool sel, int kc, real dx, real dy, real dz, real dist, real px, real py, real pz) {
             const real sh = (real)(kc + 1) * h_;
             const real a0x = po_[0] + sh * vo_[0], a0y = po_[1] + sh * vo_[1], a0z = po_[2] + sh * vo_[2];
             // diff = E2*(p - pj).^(order-1); pd = prev_dist = dist^(order-1) (P.e2z = c^-order)
@@ -501,7 +507,6 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
                 L.r_xi[3 * pos] = x0; L.r_xi[3 * pos + 1] = x1; L.r_xi[3 * pos + 2] = x2;
                 L.r_b[pos] = -rr;
                 L.r_kc[pos] = kc;
-                if (P.rownb) P.rownb[(size_t)gid * nrmax + pos] = nbcode;   // warm start of closed loops: which neighbour the row belongs to
                     if (soft) {
                     real sd = pd, st = P.term, slb = -0.05;
                     if (var == VAR_BOUND2 || var == VAR_ALL3) slb = -0.01;           // bound2:77, all:92
@@ -535,7 +540,7 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
                     const real sz = (qz - bsel[2 * (size_t)C]) * e1z;
                     dsel = sqrt(sx * sx + sy * sy + sz * sz);
                 }
-                emit_row(valid && (sel_all || dsel < sel_r), kc, dx, dy, dz, dist, px, py, pz, (r << 20) | jc);
+                emit_row(valid && (sel_all || dsel < sel_r), kc, dx, dy, dz, dist, px, py, pz);
             }
         };
 
@@ -555,7 +560,7 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
                 const real dx = px - nb[0], dy = py - nb[(size_t)C], dz = pz - nb[2 * (size_t)C];
                 const real ez = dz * e1z;
                 const real dist = sqrt(dx * dx + dy * dy + ez * ez);
-                emit_row(have && dist < 1.0, kk, dx, dy, dz, dist, px, py, pz, code & 0x0fffffff);
+                emit_row(have && dist < 1.0, kk, dx, dy, dz, dist, px, py, pz);
             }
             ncand = 0;
             LSYNC();
@@ -897,7 +902,6 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
                 }
                 if (lane == 0) {
                     Qp->status[gid] = st;
-                    if (Qp->ws_n) Qp->ws_n[gid] = 0;   // (warm start: nothing was active)
                     hdr[4] = (violation ? 1 : 0) | (coll_flag ? 4 : 0) | 16;
                     hdr[7] = 256;   // (the order kernel reads this word only)
                     if (Qp->info) {

@@ -366,7 +366,6 @@ static int transition_sharded_impl(dmpc_ctx *ctx, int S, int N, const double *po
         (mixed && (ctx->lTf.ensure(tab * 4) || ctx->lTf2.ensure(tab * 4) || ctx->sendbuf32.ensure(chunk * 4) || ctx->own64.ensure(chunk * 8))))
         FAIL(ctx, "device allocation failed");
     hipStream_t st = ctx->stream;
-    WarmScope warm_scope(ctx);   // a closed loop: every solve starts from the agent's previous working set (dmpc_solve.hip)
     double *xp = ctx->xp.as<double>(), *xv = ctx->xv.as<double>(), *xa = ctx->xa.as<double>(), *own_pf = ctx->pf.as<double>();
     HIPCHK(ctx, hipMemcpyAsync(ctx->po.p, po, A * 24, hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipMemcpyAsync(ctx->mg_pf.p, pf, A * 24, hipMemcpyHostToDevice, st));

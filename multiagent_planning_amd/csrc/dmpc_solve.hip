@@ -306,9 +306,7 @@ typedef __attribute__((address_space(3))) double LdsD;
 struct CrashRes { int q; unsigned cslot; int flags; };
 template <bool SOFT, int QCAP, bool PERSIST, typename TF = double>
 __device__ __attribute__((noinline)) CrashRes crash_append(LdsD *Bl, const LdsD *Gl, const double *tpg, const int lane, const int q, unsigned cslot,
-                                                           const double a, const double alim, const double tol, const bool tbl_ok,
-                                                           const bool use_seed = false /* warm start: the bounds to append are GIVEN (components seed_vm, BOXHI where seed_hm) */,
-                                                           const unsigned long long seed_vm = 0ull, const unsigned long long seed_hm = 0ull)
+                                                           const double a, const double alim, const double tol, const bool tbl_ok)
 {
     using SL = SolveLds<SOFT, QCAP, PERSIST, QCAP, TF>;
     double *B = (double *)Bl;
@@ -320,11 +318,11 @@ __device__ __attribute__((noinline)) CrashRes crash_append(LdsD *Bl, const LdsD 
     constexpr int CAP = QCAP - 4 < 44 ? QCAP - 4 : 44;
     constexpr unsigned long long AX0 = 0x0000049249249249ull;   // lanes 0, 3, ..., 42: the 15 components of axis 0
     CrashRes res; res.q = q; res.cslot = cslot; res.flags = tbl_ok ? 1 : 0;
-    const unsigned long long mem = __ballot(comp && (cslot & 0x30000u) != 0u);
-    const unsigned long long vm = use_seed ? (seed_vm & ~mem) : __ballot(comp && !(cslot & 0x30000u) && fabs(a) - alim > tol);
+    const unsigned long long vm = __ballot(comp && !(cslot & 0x30000u) && fabs(a) - alim > tol);
     if (vm == 0ull) return res;
-    const unsigned long long hm = use_seed ? seed_hm : __ballot(a > 0.0);
+    const unsigned long long hm = __ballot(a > 0.0);
     if (tbl_ok) {
+        const unsigned long long mem = __ballot(comp && (cslot & 0x30000u) != 0u);
         // per axis: the members are the first m steps of the horizon (dir = 0: table of the rising order) or its LAST m steps (dir = 1:
         // table of the falling order); the run of violated bounds that continues them
         int m0[3], nn[3], dr[3];
@@ -408,7 +406,7 @@ __device__ __attribute__((noinline)) CrashRes crash_append(LdsD *Bl, const LdsD 
                 const int off = ax_l == 0 ? 0 : (ax_l == 1 ? nn[0] : nn[0] + nn[1]);
                 const int pl = dx ? K - 1 - k_l : k_l;
                 if (pl >= mx && pl < mx + nx)
-                    cslot = (cslot & ~0xffu) | (unsigned)(q + off + pl - mx) | (((hm >> lane) & 1ull) ? 0x10000u : 0x20000u);
+                    cslot = (cslot & ~0xffu) | (unsigned)(q + off + pl - mx) | (a > 0.0 ? 0x10000u : 0x20000u);
             }
             LSYNC();
             res.q = qn; res.cslot = cslot; res.flags = 1 | 4 | (nb << 8);
@@ -726,72 +724,6 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
     }
 #endif
 
-    // ---------------------------------------------------------------- warm start of closed loops (round 5; slack variants)
-    // The minimiser of the QP is unique (H > 0), so the working set the dual method STARTS from is free -- and in a closed loop the set an agent
-    // ended its previous MPC step with, moved one horizon step earlier, is nearly the one it will end this step with: the heavy agents of the
-    // 10^4-agent scene spent 100-250 iterations, half of them drops, on re-discovering it (profiles/README.md, round 5).  The seeds: lanes
-    // 0 .. nseed-1 hold the previous step's slots in slot order -- acceleration bounds as two component masks (appended by the crash start from
-    // its tables), walls / rows / slack bounds as (type, component or row of THIS step: the row of the same neighbour) for the appends without a
-    // step inside the loop.  After the last seed the multipliers of the whole set are solved at once, negative ones dropped: a valid state of the
-    // dual method (lambda >= 0, the iterate minimises over the set), which continues as always.  The result does not depend on the seeds beyond
-    // round-off (tests: <= 1e-9 against the oracle and against the cold start, identical statuses and ladder counts).
-    int nseed = 0, wsd_ty = -1, wsd_idx = 0;
-    unsigned long long seed_vm = 0ull, seed_hm = 0ull;
-    bool seeded = false;
-    if (SOFT && P.ws_n && !(status & (ST_COLL | ST_CAPACITY | ST_INFEAS))) {
-        const int n0 = __builtin_amdgcn_readfirstlane(P.ws_n[gid]);
-        if (n0 > 0) {
-            nseed = n0 < QMAX ? n0 : QMAX;
-            int sx = 0, sy = 0;
-            if (lane < nseed) { const int *wp = P.ws_set + ((size_t)gid * QMAX + lane) * 2; sx = wp[0]; sy = wp[1]; }
-            const int ty = lane < nseed ? (sx & 0xff) : -1, kco = (sx >> 8) & 0xff;
-            // bounds and walls: one horizon step earlier (step 0 has left the horizon)
-            unsigned vlo = 0u, vhi = 0u, hlo = 0u, hhi = 0u;
-            if (ty >= 0 && ty < TY_COLL && sy >= 3) {
-                const int c = sy - 3;
-                if (ty < TY_POSHI) {
-                    if (c < 32) { vlo = 1u << c; if (ty == TY_BOXHI) hlo = vlo; } else { vhi = 1u << (c - 32); if (ty == TY_BOXHI) hhi = vhi; }
-                } else { wsd_ty = ty; wsd_idx = c; }
-            }
-            seed_vm = (unsigned long long)wave_or(vlo) | ((unsigned long long)wave_or(vhi) << 32);
-            seed_hm = (unsigned long long)wave_or(hlo) | ((unsigned long long)wave_or(hhi) << 32);
-            // (the new last step of the horizon takes the seeds of the step before it: a run of saturated bounds at the END of the horizon stays one)
-            seed_vm |= (seed_vm & (7ull << (3 * (K - 2)))) << 3; seed_hm |= (seed_hm & (7ull << (3 * (K - 2)))) << 3;
-            // rows: the row of the same neighbour in this step's scratch (solveSoftDMPCall: on the same instant, i.e. one step earlier)
-            const bool rowseed = ty >= TY_COLL;
-            const unsigned long long rm = __ballot(rowseed);
-            int myrow = -1;
-            if (rm != 0ull && P.rownb) {
-                const int *r_nb = P.rownb + (size_t)gid * nrmax;
-                for (int i0 = 0; i0 < nr; i0 += 64) {
-                    const int i = i0 + lane;
-                    const int nbv = i < nr ? r_nb[i] : -1, kcv = i < nr ? r_kc[i] : -1;
-                    unsigned long long m = rm;
-                    while (m != 0ull) {
-                        const int sd = __ffsll((long long)m) - 1;
-                        m &= m - 1ull;
-                        const int key = readlane_i(sy, sd), kcs = readlane_i(kco, sd);
-                        const unsigned long long hit = __ballot(nbv == key && (var != VAR_ALL3 || kcv == kcs - 1));
-                        if (hit != 0ull && lane == sd && myrow < 0) myrow = i0 + __ffsll((long long)hit) - 1;
-                    }
-                }
-            }
-            if (rowseed && myrow >= 0) { wsd_ty = ty; wsd_idx = myrow; }
-            // a row that ended WITHOUT its pin eps <= 0 (slack strictly negative): its slack starts free (bit 8)
-            {
-                unsigned long long m = __ballot(wsd_ty == TY_SLKU);
-                bool has = false;
-                while (m != 0ull) {
-                    const int sd = __ffsll((long long)m) - 1;
-                    m &= m - 1ull;
-                    if (wsd_idx == readlane_i(wsd_idx, sd)) has = true;
-                }
-                if (wsd_ty == TY_COLL && !has) wsd_ty |= 0x100;
-            }
-            seeded = seed_vm != 0ull || __any(wsd_ty >= 0);
-        }
-    }
-
     // ---------------------------------------------------------------- a7: dual active-set solve
     const bool ladder = soft && (var == VAR_BOUND || var == VAR_BOUND2 || var == VAR_ALL3 || cppv);
 #ifndef DMPC_LADDER_CERT_AFTER
@@ -888,22 +820,9 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
             // minimiser is the iterate -- a valid state of the dual method, which continues from there with every constraint.
             // (slack-free variants: measured on solveHardDMPC, where rows sit on every horizon step, the guess is poor and the crash costs
             // 16 % -- compiled out there)
-            bool crash = SOFT && (warm || seeded || (P.crash_min > 0 && __popcll(__ballot(comp && fabs(a_unc) - P.alim > tol)) >= P.crash_min));
+            bool crash = SOFT && (warm || (P.crash_min > 0 && __popcll(__ballot(comp && fabs(a_unc) - P.alim > tol)) >= P.crash_min));
             bool crash_stop = warm;          // warm: straight to the finish (solve the multipliers of the kept working set)
-            bool crash_box = !warm && !seeded;   // every slot of the batch is an acceleration bound
-            int seed_i = 0;                  // warm start: next seed of the in-loop appends
-            // Bulk rounds (round 5).  The crash start appends the violated acceleration bounds without steps, solves the multipliers of the
-            // batch at once and drops the negative ones; from there on the method used to change ONE constraint per iteration -- and the heavy
-            // agents of the 10^4-agent scene spent 60-90 iterations of their last ladder level on exactly that: a row that enters against 30
-            // saturated bounds drops them one partial step at a time (8-15 drops per row), the bounds the rows then push over their limit come
-            // back one full iteration each (10-12 in a row), at 4-5 us per iteration with 40 slots.  With P.bulk_rounds > 0 the rounds go on
-            // after the first batch with EVERY kind of constraint: all constraints violated at the iterate are appended without a step (a third
-            // of an iteration each), the multipliers of the whole set solved by the refinement pass, every negative one dropped (a rotation
-            // sweep each, no products), and again from the new iterate -- a primal-dual active-set round.  Every round ends in a valid state of
-            // the dual method (lambda >= 0, the iterate minimises over the set); after P.bulk_rounds rounds, at a dependent candidate or short
-            // of the capacity the one-at-a-time iteration takes over, so termination and the infeasibility verdicts are the dual method's.
-            int bulk_left = SOFT ? P.bulk_rounds : 0, round_app = 0, cert_cnt = 0;
-            bool crash_all = false, redo = false;
+            bool crash_box = !warm;          // every slot of the batch is an acceleration bound
             int crash_rounds = 0, nfast = 0, accept_drops = 0;
             const double dual0 = dual;
             LSYNC();
@@ -1065,44 +984,29 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                 }
             };
 
-            // the pin eps <= 0 of a soft row whose slack becomes a variable: decoupled from everything else in the set (S(u,u) = 1/2), active
-            // with the multiplier -st of the slack's linear cost
-            auto pin_row = [&](int row) {
-                const Cd u = slack_desc(TY_SLKU, row);
-                if (lane < ((q + 8) & ~7)) ((TF *)(B + SL::T))[tcol(q) + lane] = (TF)((lane == q) ? 1.4142135623730951 : 0.0);
-                if (lane == 0) { r_fl[row] |= (RF_LIVE | RF_SLKU); m_row[nrmax + row] = (unsigned char)q; }
-                nlive++;
-                write_slot(u, -r_st[row]);
-                q++;
+            // Agents with more rows on their step than the in-loop certificate can look at (38): the level is certified BEFORE the solve, while
+            // the factor's block is free to hold the planes of all of them -- when it passes, the search ends at the first line of the first batch
+            // that meets the polytope (microseconds); when it fails, a whole solve that would have ended in the dual method's own proof is saved.
+            bool pre_inf = false;
+            if (SOFT && ladder && violation && !cert_known && !hp && nr > 38 && q == 0) {
+                constexpr int CP = (t_doubles(QCAP) * (int)sizeof(TF) / 8) / 4 < 134 ? (t_doubles(QCAP) * (int)sizeof(TF) / 8) / 4 : 134;
+                cost += 176;
+                pre_inf = ladder_level_infeasible(r_xi, r_b, r_sd, r_slb, r_kc, nr, B + SL::T, P.h, P.alim, 1.0, whi_l, wlo_l, lane, CP);
                 LSYNC();
-            };
-            // the bookkeeping of a constraint that enters the working set as slot q (before q is advanced)
-            auto book_append = [&](const Cd &p) {
-                if (p.ty < TY_COLL) {
-                    if (lane == p.idx) {
-                        if (p.ty < TY_POSHI) cslot = (cslot & ~0xffu) | (unsigned)q | (p.ty == TY_BOXHI ? 0x10000u : 0x20000u);
-                        else cslot = (cslot & ~0xff00u) | ((unsigned)q << 8) | (p.ty == TY_POSHI ? 0x40000u : 0x80000u);
-                    }
-                } else {
-                    if (!soft && p.idx < 64 * RC) { if (lane == (p.idx & 63)) rcfl |= 1u << (p.idx >> 6); }
-                    else if (lane == 0) {
-                        const int bit = (p.ty == TY_COLL) ? RF_COLL : (p.ty == TY_SLKU ? RF_SLKU : RF_SLKL);
-                        if (soft) { r_fl[p.idx] |= bit; if (p.ss != 0.0) m_row[(size_t)(p.ty - TY_COLL) * nrmax + p.idx] = (unsigned char)q; }
-                        else r_bits[p.idx >> 5] |= 1u << (p.idx & 31);
-                    }
-                    if (p.ty == TY_COLL && comp && k_l == p.gi - 15) cm |= 1ull << q;
-                }
-            };
-
+                for (int i = lane; i < 4 * ((nr < CP - 6 ? nr : CP - 6) + 6); i += 64) B[SL::T + i] = 0.0;
+                LSYNC();
+                cert_known = true;   // (this level is not tested again)
+                if (pre_inf) rc = 1;
+            }
             // Crash start, first batch: every acceleration bound violated at the unconstrained minimiser is appended BEFORE the iteration
             // starts (crash_append: from the table while the sets are prefixes of the horizon, else one bound per axis and call).  Out of
             // line and outside the loop: inside it the call cost the iteration 3-4 % (registers live across the call site).  Bounds that
             // only show after the multipliers of this batch are solved go through the one-at-a-time appends of the iteration.
-            if (SOFT && crash) {
+            if (SOFT && crash && !pre_inf) {
                 bool tbl_ok = true;
                 while (q < (QCAP - 4 < 44 ? QCAP - 4 : 44)) {
                     const CrashRes cr = crash_append<SOFT, QCAP, PERSIST, TF>((LdsD *)B, (const LdsD *)G, P.tables + TAB_DOUBLES + (size_t)ccase * 2 * TAB_TP_CASE,
-                                                                          lane, q, cslot, a, P.alim, tol, tbl_ok, seeded, seed_vm, seed_hm);
+                                                                          lane, q, cslot, a, P.alim, tol, tbl_ok);
                     const int nb = cr.flags >> 8;
                     if (cr.flags & 2) crash_stop = true;
                     if (nb == 0) break;
@@ -1129,70 +1033,30 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
             bool x_synced = fresh, resync = false;
             int resyncs = 0;
             bool cert_done = cert_known;   // (a level the ladder step below already put through the certificate is not tested again: 44 us a call for 26 rows)
-            for (;;) {
-                if (soft && ladder && violation && !cert_done && iters - nfast + cert_cnt >= LADDER_CERT_AFTER) {
+            for (; !pre_inf;) {
+                if (soft && ladder && violation && !cert_done && iters - nfast >= LADDER_CERT_AFTER) {
                     cert_done = true;
                     PH(4); PHC(12);
                     cost += 176;   // (44 us a call)
-                    const bool cert_inf = ladder_level_infeasible(r_xi, r_b, r_sd, r_slb, r_kc, nr, B + SL::RR, P.h, P.alim, 1.0, whi_l, wlo_l, lane);
+                    static_assert(!SOFT || (SL::XS == SL::RR + 64 && SL::NU == SL::XS + 64), "the three staging vectors are one block of 176 doubles");
+                    const bool cert_inf = ladder_level_infeasible(r_xi, r_b, r_sd, r_slb, r_kc, nr, B + SL::RR, P.h, P.alim, 1.0, whi_l, wlo_l, lane, 44);   // (RR | XS | NU are dead between two iterations: 38 rows of a step)
                     PH(7);
                     if (cert_inf) { rc = 1; break; }
-                }
-                // ---- warm start: the next seed is the pivot (appended without a step, below); after the last one the crash start's finish
-                int seed_code = -1;
-                bool seed_live = false;   // (this seed marked its row's slack free)
-                if (SOFT && seeded && crash && !crash_all && !crash_stop && !redo && q < (QCAP - 4 < 44 ? QCAP - 4 : 44)) {
-                    while (seed_i < nseed) {
-                        const int sty = readlane_i(wsd_ty, seed_i), sidx = readlane_i(wsd_idx, seed_i);
-                        ++seed_i;
-                        if (sty < 0) continue;
-                        const int ty = sty & 0xff;
-                        if (ty < TY_COLL) {   // workspace wall
-                            if (readlane_i((int)cslot, sidx) & 0xc0000) continue;
-                            seed_code = (ty << 16) | sidx;
-                            break;
-                        }
-                        if (hp && ty != TY_COLL) continue;   // (level check of solveSoftDMPCall: no slack variables)
-                        const int fl = r_fl[sidx];
-                        if (ty == TY_COLL) {
-                            if (fl & RF_COLL) continue;
-                            if (!hp && (sty & 0x100) && !(fl & RF_LIVE)) {   // the row ended without its pin: slack free from the start
-                                LSYNC();
-                                if (lane == 0) r_fl[sidx] = (unsigned char)(fl | RF_LIVE);
-                                nlive++; seed_live = true;
-                                LSYNC();
-                            }
-                            seed_code = (TY_COLL << 16) | sidx;
-                            break;
-                        }
-                        if (ty == TY_SLKU) {
-                            if (fl & RF_SLKU) continue;
-                            if (!(fl & RF_LIVE)) { pin_row(sidx); ++iters; ++nfast; if (q > maxq) maxq = q; if (q >= (QCAP - 4 < 44 ? QCAP - 4 : 44)) break; continue; }
-                            seed_code = (TY_SLKU << 16) | sidx;
-                            break;
-                        }
-                        if (!(fl & RF_LIVE) || (fl & RF_SLKL)) continue;   // eps >= slb: only for a live slack
-                        seed_code = (TY_SLKL << 16) | sidx;
-                        break;
-                    }
-                    if (seed_code < 0) crash_stop = true;
                 }
                 // ---- most violated constraint not in the working set (score = violation / |n|_{H^-1}, fp32)
                 double bestv = 0.0; float bests = 0.f; int bestc = -1;
 #define CAND(v_, w_, code_) do { const double v__ = (v_); const float s__ = (float)v__ * (w_); \
                                  if (v__ > tol && s__ > bests) { bests = s__; bestv = v__; bestc = (code_); } } while (0)
                 // the crash ends its batch when nothing is left to append, when a multiplier had to be dropped, or short of the capacity
-                const bool crash_finish = crash && (crash_stop || redo || q >= (QCAP - 4 < 44 ? QCAP - 4 : 44));   // (the same for the 48- and 64-slot kernels: the path of an agent must not depend on the tier)
-                if (SOFT && seed_code >= 0 && !crash_finish && lane == 0) { bestc = seed_code; bests = 1.f; }
-                const bool scan_all = !crash || (crash_all && !crash_finish);   // every kind of constraint is a candidate (bulk rounds: at the iterate of the last finish)
-                if (comp && !crash_finish && !(SOFT && seeded && crash && !crash_all)) {
+                const bool crash_finish = crash && (crash_stop || q >= (QCAP - 4 < 44 ? QCAP - 4 : 44));   // (the same for the 48- and 64-slot kernels: the path of an agent must not depend on the tier)
+                if (comp && !crash_finish) {
                     // a <= alim and -a <= alim are violated one at a time: one candidate for the pair (not while a member is active)
                     const bool hi = a > 0.0;
                     if (!(cslot & 0x30000u)) CAND(fabs(a) - P.alim, wbox_f, ((hi ? TY_BOXHI : TY_BOXLO) << 16) | lane);
                     const double c2 = w - whi_l, c3 = wlo_l - w;
-                    if (scan_all && !(cslot & 0xc0000u)) CAND(fmax(c2, c3), wpos_f, ((c2 > c3 ? TY_POSHI : TY_POSLO) << 16) | lane);
+                    if (!crash && !(cslot & 0xc0000u)) CAND(fmax(c2, c3), wpos_f, ((c2 > c3 ? TY_POSHI : TY_POSLO) << 16) | lane);
                 }
-                if (scan_all) {
+                if (!crash) {
 #pragma unroll
                 for (int c = 0; c < RC; ++c) {   // rows held in registers
                     const int i = lane + 64 * c;
@@ -1235,7 +1099,6 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                     PHC(10);
                     if (!forced) CLAIM_NEXT();
                     if (!crash && !forced && (q == 0 || fresh)) break;   // optimal
-                    if (SOFT && crash && crash_all && !crash_finish && fresh && !forced) break;   // (bulk round: every kind was looked at, at the iterate of the finish)
                     if (!crash && !soft && !F32T && !forced) {   // (fp32 factor: the incrementally updated iterate drifts by ~1e-7 per step -- always the full verification)
                         // (slack-free variants; the slack variants carry multipliers of 1e5-1e6 and always take the full verification)
                         // No constraint is violated at the (incrementally updated) iterate.  Round-off of the factor reaches the iterate
@@ -1286,24 +1149,15 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                                     neg &= ~(1ull << l);
                                     remove_slot2<SOFT, QCAP, PERSIST, TS, TF>(B, lane, q, l, cslot, cm, xo, m_row, nrmax);
                                 }
-                            } else if (seeded || bulk_left > 0 || crash_all) {   // warm start / bulk rounds: every negative multiplier goes, highest slot first (a row takes its pin along: look again after each)
-                                while (neg != 0ull) {
-                                    drop_slot(63 - __clzll((long long)neg), -1);
-                                    neg = __ballot(lane < q && B[SL::SLAM + (lane < q ? lane : 0)] < 0.0);
-                                }
                             } else drop_slot(63 - __clzll((long long)neg), -1);   // any kind of slot (and maybe its pin): one per pass
 #ifdef DMPC_DEV_TRACE
                             dev_negdrops++;
 #endif
-                            if (bulk_left <= 0) crash_stop = true;
-                            redo = true; fresh = false;   // (solve the multipliers of what is left before anything else)
+                            crash_stop = true; fresh = false;
                             PH(6);
                             continue;
                         }
-                        redo = false;
-                        if (SOFT && bulk_left > 0 && !crash_stop && round_app > 0 && q < (QCAP - 4 < 44 ? QCAP - 4 : 44)) {   // next round: every kind of constraint, from this iterate
-                            --bulk_left; crash_all = true; crash_box = false; round_app = 0;
-                        } else if (was_fresh || crash_stop || ++crash_rounds >= 8) {
+                        if (was_fresh || crash_stop || ++crash_rounds >= 8) {
                             crash = false;
                             if (!soft) dual = dual0 + 0.5 * wave_sum0(g_l * (a - a_unc));   // cost at x(lambda): f(x_unc) + 1/2 nu' H^-1 nu
                         }
@@ -1348,7 +1202,13 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                 // lazily instantiate the eps<=0 pin of a soft row that becomes active (S(u,u) = 1/2)
                 if (soft && !hp && p.ty == TY_COLL && !(r_fl[p.idx] & RF_LIVE)) {
                     if (q >= QCAP - 1) { rc = 2; break; }
-                    pin_row(p.idx);
+                    const Cd u = slack_desc(TY_SLKU, p.idx);
+                    if (lane < ((q + 8) & ~7)) ((TF *)(B + SL::T))[tcol(q) + lane] = (TF)((lane == q) ? 1.4142135623730951 : 0.0);
+                    if (lane == 0) { r_fl[p.idx] |= (RF_LIVE | RF_SLKU); m_row[nrmax + p.idx] = (unsigned char)q; }
+                    nlive++;
+                    write_slot(u, -r_st[p.idx]);
+                    q++;
+                    LSYNC();
                 }
                 PH(1);
                 double lam_p = 0.0;
@@ -1382,18 +1242,12 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                     PH(2);
                     if (crash) {   // append without a step: column [-r/rho; 1/rho] with rho^2 = s_pp - |T's|^2, lambda_p = 0 until the batch is solved
                         const double dlt = spp - wave_sum0(dvj * dvj);
-                        if (SOFT && seed_code >= 0) {   // a seed that is (nearly) dependent on the set so far is left out: the iteration adds it if it belongs
-                            if (!(dlt > 1e-7 * spp)) {
-                                if (seed_live) { LSYNC(); if (lane == 0) r_fl[p.idx] &= ~RF_LIVE; nlive--; LSYNC(); }
-                                break;
-                            }
-                        } else if (!(dlt > (crash_all ? 1e-7 : 1e-9) * spp)) { crash_stop = true; break; }   // (distinct bounds are independent: guard only; bulk rounds: a dependent candidate ends them)
+                        if (!(dlt > 1e-9 * spp)) { crash_stop = true; break; }   // (distinct bounds are independent; guard only)
                         const double irho = fast_rsq(dlt);
                         if (lane < ((q + 8) & ~7)) ((TF *)(B + SL::T))[tcol(q) + lane] = (TF)((lane < q) ? (-ri * irho) : ((lane == q) ? irho : 0.0));
                         write_slot(p, 0.0);
-                        book_append(p);
-                        q++; nfast++; round_app++;
-                        if (crash_all && p.ty >= TY_POSHI) cert_cnt++;
+                        if (lane == p.idx) cslot = (cslot & ~0xffu) | (unsigned)q | (p.ty == TY_BOXHI ? 0x10000u : 0x20000u);
+                        q++; nfast++;
                         if (q > maxq) maxq = q;
                         LSYNC();
                         break;
@@ -1492,7 +1346,20 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                         ENSURE_EXT(q);
                         if (lane < ((q + 8) & ~7)) ((TF *)(B + SL::T))[tcol(q) + ((TS < QCAP && q >= TS) ? xo : 0) + lane] = (TF)((lane < q) ? (-ri * irho) : ((lane == q) ? irho : 0.0));
                         write_slot(p, lam_p);
-                        book_append(p);
+                        if (p.ty < TY_COLL) {
+                            if (lane == p.idx) {
+                                if (p_isA) cslot = (cslot & ~0xffu) | (unsigned)q | (p.ty == TY_BOXHI ? 0x10000u : 0x20000u);
+                                else cslot = (cslot & ~0xff00u) | ((unsigned)q << 8) | (p.ty == TY_POSHI ? 0x40000u : 0x80000u);
+                            }
+                        } else {
+                            if (!soft && p.idx < 64 * RC) { if (lane == (p.idx & 63)) rcfl |= 1u << (p.idx >> 6); }
+                            else if (lane == 0) {
+                                const int bit = (p.ty == TY_COLL) ? RF_COLL : (p.ty == TY_SLKU ? RF_SLKU : RF_SLKL);
+                                if (soft) { r_fl[p.idx] |= bit; if (p.ss != 0.0) m_row[(size_t)(p.ty - TY_COLL) * nrmax + p.idx] = (unsigned char)q; }
+                                else r_bits[p.idx >> 5] |= 1u << (p.idx & 31);
+                            }
+                            if (p.ty == TY_COLL && comp && k_l == p.gi - 15) cm |= 1ull << q;
+                        }
                         q++;
                         if (q > maxq) maxq = q;
                         LSYNC();
@@ -1519,7 +1386,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                     remove_slot2<SOFT, QCAP, PERSIST, TS, TF>(B, lane, q, ul, cslot, cm, xo, m_row, nrmax);
                     nlive--;
                 }
-                if (((++since_sync) & 31) == 0 && !(SOFT && crash && P.bulk_rounds > 0)) primal_fast();   // periodic re-sync with x(lambda) (bulk rounds look at the iterate of their last finish)
+                if (((++since_sync) & 31) == 0) primal_fast();   // periodic re-sync with x(lambda)
                 PH(4);
             }
             iters_total += iters;
@@ -1527,7 +1394,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
             dev_nfast += nfast; dev_rounds += crash_rounds;
             if (ph_on && lane == 0 && P.dbg_cap >= 16 && dev_try < 8) {   // development: one record per solve of the traced agent (rows cap-12 .. cap-5 of the trace)
                 double *d = P.dbg + (size_t)(P.dbg_cap - 12 + dev_try) * 8;
-                d[0] = (double)tries; d[1] = (double)iters; d[2] = (double)nfast; d[3] = (double)rc; d[4] = (double)q; d[5] = hp ? 1.0 : 0.0; d[6] = (double)scale_pow; d[7] = (double)seed_i;
+                d[0] = (double)tries; d[1] = (double)iters; d[2] = (double)nfast; d[3] = (double)rc; d[4] = (double)q; d[5] = hp ? 1.0 : 0.0; d[6] = (double)scale_pow; d[7] = 0.0;
             }
             ++dev_try;
 #endif
@@ -1562,10 +1429,16 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                 PH(4);
                 double f = 2.0;
                 cert_known = false;
+                // (between two solves the inverse factor is dead: its block holds the planes of up to 128 rows; zeroed again afterwards -- every value
+                // the products can read stays finite whatever the factor's storage type makes of these bits)
+                constexpr int CERT_PLANES = (t_doubles(QCAP) * (int)sizeof(TF) / 8) / 4 < 134 ? (t_doubles(QCAP) * (int)sizeof(TF) / 8) / 4 : 134;
+                const int cert_used = 4 * ((nr < CERT_PLANES - 6 ? nr : CERT_PLANES - 6) + 6);
                 while (tries < max_tries - 1) {
-                    if (!ladder_level_infeasible(r_xi, r_b, r_sd, r_slb, r_kc, nr, B + SL::RR, P.h, P.alim, f, whi_l, wlo_l, lane)) { cert_known = true; break; }
+                    if (!ladder_level_infeasible(r_xi, r_b, r_sd, r_slb, r_kc, nr, B + SL::T, P.h, P.alim, f, whi_l, wlo_l, lane, CERT_PLANES)) { cert_known = true; break; }
                     f *= 2.0; ++tries;
                 }
+                LSYNC();
+                for (int i = lane; i < cert_used; i += 64) B[SL::T + i] = 0.0;
                 for (int i = lane; i < nr; i += 64) { r_slb[i] *= f; r_st[i] *= f; }
                 rcslb[0] *= f; rcslb[1] *= f;
                 scale_pow += ilogb(f);
@@ -1592,17 +1465,6 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
         for (int i = lane; i < ext_doubles(QCAP, TS); i += 64) ex[i] = 0.0;
         LSYNC();
         if (lane == 0) atomicOr((unsigned *)(shtab) + (PERSIST_TABLE_BYTES - 16) / 4, 1u << ((xo + tcol(TS) - ext0) / ext_doubles(QCAP, TS)));
-    }
-    if (SOFT && Qp->ws_n && !(status & ST_QOVER)) {   // warm start: the final working set seeds this agent's next MPC step
-        const int nsave = solved ? q : 0;
-        if (lane < nsave) {
-            const int meta = s_meta[lane], ty = (meta >> 8) & 0xff, idx = meta >> 16;
-            int key = idx, kcv = 0;
-            if (ty >= TY_COLL) { key = Qp->rownb ? Qp->rownb[(size_t)gid * nrmax + idx] : -1; kcv = r_kc[idx]; }
-            int *wp = Qp->ws_set + ((size_t)gid * QMAX + lane) * 2;
-            wp[0] = ty | (kcv << 8); wp[1] = key;
-        }
-        if (lane == 0) Qp->ws_n[gid] = nsave;
     }
     int nslack = 0;
     if (solved) {

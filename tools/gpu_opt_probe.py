@@ -8,7 +8,8 @@ import numpy as np
 import multiagent_planning_amd as mp
 from multiagent_planning_amd import workload as wl
 which, steps = sys.argv[1], int(sys.argv[2])
-optsets = sys.argv[3:]
+optsets = [a for a in sys.argv[3:] if not a.startswith("--dump=")]
+dump = [a[7:] for a in sys.argv[3:] if a.startswith("--dump=")]   # --dump=file.npz: the reference run's outputs (A/B of two builds: tools/with_lib.py + np.array_equal)
 cfgname, N, S, variant = {"C4": ("C4", 10000, 1, "bound"), "C3": ("C3", 1000, 16, "softall"), "C5": ("C5", 200, 64, "repair"),
                           "C2b": ("C4", 100, 512, "bound"), "all3": ("C4", 100, 128, "all3"), "bound2": ("C4", 100, 128, "bound2"),
                           "cpp": ("C4", 100, 128, "cpp")}[which]
@@ -24,7 +25,7 @@ def ctx(opts):
     if warm: d.warm_start(True)
     d.profile(True)
     return d
-ref = ctx("bulk_rounds=0")
+ref = ctx("")
 l, _, _ = ref.init_batch(po, pf)
 xp, xv, xa = po.copy(), np.zeros_like(po), np.zeros_like(po)
 inputs, refs = [], []
@@ -35,7 +36,7 @@ for k in range(steps):
     ok = (o["status"] & 1) == 1
     l = np.where(ok[..., None], o["p"], l); xp = np.where(ok[..., None], o["p"][..., :3], xp)
     xv = np.where(ok[..., None], o["v"][..., :3], xv); xa = np.where(ok[..., None], o["a"][..., :3], xa)
-print(f"{which}: {S} x {N} agents of {variant}; reference = bulk_rounds=0")
+print(f"{which}: {S} x {N} agents of {variant}; reference = no options")
 print("step  " + "  ".join(f"[{o}]" for o in ["reference"] + optsets))
 tot = np.zeros(len(optsets) + 1)
 ds = [ctx(o) for o in optsets]
@@ -54,4 +55,6 @@ for k in range(steps):
             bad = np.argwhere((c["status"] != w["status"]) | (c["info"][..., :4] != w["info"][..., :4]).any(-1))[:3]
             for b in bad: line += f"\n        at {tuple(b)}: ref st {c['status'][tuple(b)]} info {c['info'][tuple(b)]} | st {w['status'][tuple(b)]} info {w['info'][tuple(b)]}"
     print(line)
+if dump:
+    np.savez(dump[0], **{f"{k}_{i}": refs[i][k] for i in range(steps) for k in ("p", "v", "a", "status", "info")})
 print("solve ms, sum over the steps: " + "  ".join(f"{t:.3f}" for t in tot))
