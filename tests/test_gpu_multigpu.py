@@ -199,19 +199,21 @@ def test_group_context_large_batch_runs_as_two_groups(emulated):
 
 def test_bench_launches_its_own_ranks():
     """`python bench.py --gpus 2` without torch.distributed.run: bench.py starts the two ranks itself.  On this one-GPU box they share the
-    GPU and the exchange is staged through gloo (a functional check of the multi-rank path, flagged as such in the JSON line); the
-    sharded step must equal the unsharded step of the same scenes per agent, bit for bit (config.exchange_verified)."""
+    GPU and the exchange is staged through gloo (a functional check of the multi-rank path, flagged as such in the JSON line): the headline
+    scene (here 2 000 agents of it) sharded over the two ranks in a device-resident closed loop; the sharded step must equal the unsharded
+    step of the same scene per agent, bit for bit, and every rank must hold the same gathered table (config.exchange_verified)."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, DMPC_BENCH_SHARE_GPU="1")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--scenes", "16", "--no-secondary",
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--agents", "2000", "--no-secondary",
                         "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-    assert line["n_gpus"] == 2 and line["config"]["exchange_verified"] is True
-    assert line["config"]["agents_per_scene"] == 200 and "FUNCTIONAL CHECK" in line["data"]
+    assert line["n_gpus"] == 2 and line["config"]["exchange_verified"] is True and line["scaling"] == "strong"
+    assert line["config"]["agents_per_scene"] == 2000 and line["config"]["agents_per_gpu"] == 1000 and "FUNCTIONAL CHECK" in line["data"]
+    assert line["config"]["workload"].startswith("C4") and "setup_s" in line["config"] and "exchange_advance_and_gaps" in line["step_breakdown_ms"]
 
 
 def test_two_real_ranks_over_rccl():
