@@ -389,7 +389,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "measured_copy_ceiling_GBps": copy_gbs, "frac_of_copy_ceiling": (achieved / copy_gbs if copy_gbs else None),
-                         "kernel": "dmpc_solve_kernel<true,56,double>" if N_loc < 128 * 256 else "dmpc_solve_persist_kernel<true,56,56,double>",
+                         # (dmpc_api.hip launch_step: the 56-slot tier of a large scene runs as persistent waves with the split factor from 8 agents per CU on)
+                         "kernel": ("dmpc_solve_persist_kernel<true, 56, 48, double>" if N_loc >= 8 * torch.cuda.get_device_properties(dev).multi_processor_count
+                                    else "dmpc_solve_kernel<true, 56, double>"),
                          "kernel_ms_avg": kern_ms, "launches": n_launch,
                          "other_kernels_ms_avg": {"neighbour lists (bbox, table copy, grid_bin/scan/fill/query) + dmpc_scan_kernel + order_kernel": scan_ms},
                          "alg_bytes_per_solve": ba, "solves_per_launch": N_loc,

@@ -127,6 +127,7 @@ struct dmpc_ctx {
     int nbr_grid = 1;        // development option nbr_grid: 0 = neighbour lists of large scenes from the all-pairs box test of round 3 (nbr_kernel) instead of the cell grid + distance filter
     DevBuf grid;             // cell grid of the neighbour lists (counts, starts, entries)
     int no_level_check = 0;  // development option no_level_check (see StepParams)
+    int lds_pad_kb = 0;      // development option lds_pad_kb: KB of unused LDS per one-agent solve workgroup (occupancy experiments: fewer resident agents per CU)
     int f32_dep_exp = 8;     // development option f32_dep_exp: fp32-factor kernels treat a pivot as dependent below delta / s_pp = 10^-n
     int ext_cap = 0;         // development option ext_cap (tests): at most this many T extensions per workgroup (1: every agent that needs one waits for the same slot)
     int static_queue = 0;    // development option static_queue: persistent waves take queue positions round-robin instead of by ticket
@@ -403,7 +404,7 @@ extern "C" int dmpc_debug_option(dmpc_ctx *ctx, const char *name, int value)
         {"no_fuse", &dmpc_ctx::no_fuse}, {"no_persist", &dmpc_ctx::no_persist}, {"force_persist", &dmpc_ctx::force_persist}, {"no_cull", &dmpc_ctx::no_cull}, {"order_slices", &dmpc_ctx::order_slices}, {"cull_min", &dmpc_ctx::cull_min},
         {"no_lpt", &dmpc_ctx::no_lpt}, {"order_hint", &dmpc_ctx::order_hint}, {"crash_min", &dmpc_ctx::crash_min}, {"crash_any", &dmpc_ctx::crash_any}, {"no_fast_exit", &dmpc_ctx::no_fast_exit}, {"pivot_explore", &dmpc_ctx::pivot_explore},
         {"iter_cap", &dmpc_ctx::iter_cap}, {"tier1_qcap", &dmpc_ctx::tier1_env}, {"split_parts", &dmpc_ctx::split_parts}, {"no_split", &dmpc_ctx::no_split},
-        {"static_queue", &dmpc_ctx::static_queue}, {"no_split_t", &dmpc_ctx::no_split_t}, {"ext_cap", &dmpc_ctx::ext_cap}, {"nbr_grid", &dmpc_ctx::nbr_grid}, {"f32_dep_exp", &dmpc_ctx::f32_dep_exp}, {"grid_min", &dmpc_ctx::grid_min}, {"no_level_check", &dmpc_ctx::no_level_check}};
+        {"static_queue", &dmpc_ctx::static_queue}, {"no_split_t", &dmpc_ctx::no_split_t}, {"ext_cap", &dmpc_ctx::ext_cap}, {"nbr_grid", &dmpc_ctx::nbr_grid}, {"f32_dep_exp", &dmpc_ctx::f32_dep_exp}, {"grid_min", &dmpc_ctx::grid_min}, {"no_level_check", &dmpc_ctx::no_level_check}, {"lds_pad_kb", &dmpc_ctx::lds_pad_kb}};
     for (auto &t : tab)
         if (!std::strcmp(t.n, name)) {
             ctx->*(t.f) = value;
@@ -688,7 +689,10 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     // of solveSoftDMPC at MPC step 12, one iteration per agent -- stay with one agent per workgroup: 0.21 against 0.25 ms.)
     const bool heavy_agents = (p.variant == DMPC_VAR_SOFTALL || p.variant == DMPC_VAR_REPAIR || p.variant == DMPC_VAR_ELLIP || p.variant == DMPC_VAR_CPP1) && G * C >= 200;
     // (crossover, agents per launch: C3 4 000: 0.72 / 0.71 ms, 8 000: 1.06 / 0.96; C5 3 200: 0.37 / 0.47, 6 400: 0.59 / 0.61 -- one agent per workgroup / persistent)
-    const bool shallow = (long)S * c_count < (heavy_agents ? 28L : 128L) * ncu && !ctx->force_persist && !ctx->tier1_env;
+    // (round 5: the slack variants in LARGE scenes -- the 56-slot tier, agents of ~100 us each -- are bound by their work per wave slot: persistent
+    // waves with the split factor, seven per CU, from two launches' worth of one-agent workgroups on)
+    const bool big_soft = soft && G * C >= 1024 && !ctx->no_split_t && !(ctx->precision & DMPC_PREC_F32FACTOR) && !ctx->single_tier && !ctx->tier1_env;
+    const bool shallow = (long)S * c_count < (big_soft ? 8L : (heavy_agents ? 28L : 128L)) * ncu && !ctx->force_persist && !ctx->tier1_env;
     // fp32 inverse factor: one tier with the full capacity, no split T.  Not for solveSoftDMPCall: its three nearly parallel rows per neighbour
     // need the fp64 factor (sweep of round 4: 1 % of its agent-steps ended on another ladder level) -- that variant keeps it whatever the context says.
     const bool f32t = (ctx->precision & DMPC_PREC_F32FACTOR) != 0 && p.variant != DMPC_VAR_ALL3;
@@ -711,7 +715,7 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     P.scene_done = scene_done;
     P.short_from = short_from;   // unequal clusters: chunks from here on hold C-1 agents (dmpc_multigpu.hip)
     const size_t lds0 = scan_lds_bytes();
-    const size_t lds1 = solve_lds_bytes(P.nrmax, soft, q1, false, 0, f32t), lds2 = solve_lds_bytes(P.nrmax, soft, q2, false, 0, f32t);
+    const size_t lds1 = solve_lds_bytes(P.nrmax, soft, q1, false, 0, f32t) + (size_t)ctx->lds_pad_kb * 1024, lds2 = solve_lds_bytes(P.nrmax, soft, q2, false, 0, f32t) + (size_t)ctx->lds_pad_kb * 1024;
     const size_t ldsmax = lds2 > lds1 ? lds2 : lds1;
     if ((int)ldsmax > ctx->max_lds_set) {
         HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_kernel<true, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsmax));
@@ -867,9 +871,15 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     // Slack-free variants (round 4): split T -- HARD_TS columns of the inverse factor in every wave's block, the rest of the 48 in
     // extensions that the waves of a workgroup take from a pool when an agent's working set outgrows them (dmpc_solve.hip) -- so that
     // twelve waves (three per SIMD: what 168 registers per lane allow) share a CU's LDS instead of nine.
-    const int tsplit = (!soft && !ctx->no_split_t && !f32t) ? HARD_TS : 0;
+    // Slack variants, 56-slot tier of large scenes (round 5): the same split with 48 own columns -- the eight columns beyond them (3.6 KB) come from
+    // the pool for the 2 % of the agents whose working set outgrows 48 slots -- so that SEVEN waves share a CU where five one-agent workgroups
+    // (30 KB each, their own copy of the tables) or six unsplit persistent waves did: the 10^4-agent scene is bound by its work per wave slot
+    // (four / five resident agents per CU: 1.03 / 0.88 ms, option lds_pad_kb).
+    const int tsplit_hard = (!soft && !ctx->no_split_t && !f32t) ? HARD_TS : 0;
+    int tsplit = tsplit_hard;
     int n_ext = 0;
     auto persist_waves = [&](int qcap, size_t &per) -> int {
+        tsplit = soft ? ((qcap == 56 && !ctx->no_split_t && !f32t) ? SOFT_TS : 0) : tsplit_hard;
         per = solve_lds_bytes(P.nrmax, soft, qcap, true, tsplit, f32t);
         int pw = (int)((LDS_CU - PERSIST_TABLE_BYTES) / per);
 #ifdef DMPC_DEV_PW   // development builds: fewer persistent waves per CU (how much does a long agent lose to the wave it shares a SIMD with?)
@@ -901,6 +911,7 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
         if (f32t) { if (soft) hipLaunchKernelGGL((dmpc_solve_persist_kernel<true, 64, 64, float>), g, b, lds, st, P); else hipLaunchKernelGGL((dmpc_solve_persist_kernel<false, 48, 48, float>), g, b, lds, st, P); }
         else if (soft && qcap == 32) hipLaunchKernelGGL((dmpc_solve_persist_kernel<true, 32>), g, b, lds, st, P);
         else if (soft && qcap == 48) hipLaunchKernelGGL((dmpc_solve_persist_kernel<true, 48>), g, b, lds, st, P);
+        else if (soft && qcap == 56 && tsplit) hipLaunchKernelGGL((dmpc_solve_persist_kernel<true, 56, SOFT_TS>), g, b, lds, st, P);
         else if (soft && qcap == 56) hipLaunchKernelGGL((dmpc_solve_persist_kernel<true, 56>), g, b, lds, st, P);
         else if (soft) hipLaunchKernelGGL((dmpc_solve_persist_kernel<true, 64>), g, b, lds, st, P);
         else if (tsplit) hipLaunchKernelGGL((dmpc_solve_persist_kernel<false, 48, HARD_TS>), g, b, lds, st, P);
@@ -920,6 +931,7 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
             HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_persist_kernel<true, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_persist_kernel<true, 48>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_persist_kernel<true, 56>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_persist_kernel<true, 56, SOFT_TS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_persist_kernel<true, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_persist_kernel<false, 48>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_persist_kernel<false, 48, HARD_TS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -939,7 +951,7 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     // bound by their single slowest agent, which runs ~4 % faster in the leaner one-agent-per-workgroup kernel.
     size_t per1 = 0, per2 = 0;
     const int pw1 = persist_waves(q1, per1), pw2 = persist_waves(q2, per2);
-    const bool deep = !shallow && (long)S * c_count >= (heavy_agents ? 28L : 16L * (pw1 > 0 ? pw1 : 1)) * ctx->num_cu;
+    const bool deep = !shallow && (big_soft || (long)S * c_count >= (heavy_agents ? 28L : 16L * (pw1 > 0 ? pw1 : 1)) * ctx->num_cu);
     // tier 2 as persistent waves over the flagged list (nearly always empty: the launch then costs a few microseconds
     // instead of one workgroup per agent just to find out that there is nothing to do)
     const bool t2_list = two_tier && !tiny && !ctx->no_persist && pw2 >= 2 && ctx->num_cu >= 1;

@@ -23,6 +23,7 @@ __host__ __device__ constexpr int t_doubles(int qcap) { return tcol((qcap + 7) &
 #define DMPC_HARD_PW 12
 #endif
 constexpr int HARD_PW = DMPC_HARD_PW;   // persistent waves per CU the slack-free solve kernel is compiled for (12 = three per SIMD at 168 registers per lane)
+constexpr int SOFT_TS = 48;             // slack variants, 56-slot tier (large scenes): own columns of T per wave; columns 48 .. 55 from the workgroup's pool
 constexpr int HARD_TS = DMPC_HARD_TS;   // slack-free persistent solve: columns of T in a wave's own LDS block (split T, dmpc_solve.hip); the other 48 - HARD_TS come from the workgroup's pool
 constexpr int ITER_CAP = 4000;
 constexpr int CRASH_MIN_DEFAULT = 4;

@@ -304,11 +304,12 @@ __device__ __forceinline__ void remove_slot2(double *B, int lane, int &q, int l,
 // crash (dependent pivot: guard only), bit 2 this call used the table, bits 8.. bounds appended (0: nothing was violated).
 typedef __attribute__((address_space(3))) double LdsD;
 struct CrashRes { int q; unsigned cslot; int flags; };
-template <bool SOFT, int QCAP, bool PERSIST, typename TF = double>
+template <bool SOFT, int QCAP, bool PERSIST, typename TF = double, int TS = QCAP>
 __device__ __attribute__((noinline)) CrashRes crash_append(LdsD *Bl, const LdsD *Gl, const double *tpg, const int lane, const int q, unsigned cslot,
                                                            const double a, const double alim, const double tol, const bool tbl_ok)
 {
-    using SL = SolveLds<SOFT, QCAP, PERSIST, QCAP, TF>;
+    using SL = SolveLds<SOFT, QCAP, PERSIST, TS, TF>;
+    static_assert(!SOFT || TS == QCAP || TS >= 48, "split T: the crash start (at most 44 slots, then three more per call) stays inside the wave's own columns");
     double *B = (double *)Bl;
     TF *Tf = (TF *)(B + SL::T);
     const double *G = (const double *)Gl;
@@ -436,9 +437,9 @@ __device__ __attribute__((noinline)) CrashRes crash_append(LdsD *Bl, const LdsD 
         sv = has ? G[gj * 30 + pkj] * (sgj * sgp) : 0.0;
     }
     B[SL::XS + lane] = sv; LSYNC();
-    const double dvj = t_tmul2<QCAP, SL::T, SL::XS, QCAP, TF>(B, lane, q);
+    const double dvj = t_tmul2<QCAP, SL::T, SL::XS, TS, TF>(B, lane, q);
     B[SL::RR + lane] = dvj; LSYNC();
-    const double ri = t_mul2<QCAP, SL::T, SL::RR, QCAP, TF>(B, lane, q);
+    const double ri = t_mul2<QCAP, SL::T, SL::RR, TS, TF>(B, lane, q);
     LSYNC();
     const double d2 = (lane < q) ? dvj * dvj : 0.0;
     double irho[3]; bool okx[3];
@@ -528,7 +529,8 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
     // the dependence threshold moves up, and the refinement gets more passes (it contracts by ~1e-7 cond(S) per pass instead of at once)
     const double DEP_TOL = F32T ? P.dep_tol_f32 : 1e-13;
     constexpr int REFINE_PASSES = F32T ? 10 : 3;
-    static_assert(TS == QCAP || (PERSIST && !SOFT && TS % 8 == 0 && TS < QCAP), "split T: persistent slack-free kernels");
+    // (round 5: also the slack kernels of large scenes -- QCAP 56 with 48 own columns: seven waves per CU instead of five one-agent workgroups)
+    static_assert(TS == QCAP || (PERSIST && TS % 8 == 0 && TS < QCAP && (!SOFT || TS >= 48)), "split T: persistent kernels");
     const int nrmax = P.nrmax, var = P.variant;
     // split T: offset (doubles from the wave's base) that puts column j >= TS of the factor at tcol(j) + xo; 0: no extension held.
     // The pool: a bit mask of the free extensions behind the workgroup's tables; lane 0 takes the lowest free one (LDS atomic), waits
@@ -989,7 +991,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
             // that meets the polytope (microseconds); when it fails, a whole solve that would have ended in the dual method's own proof is saved.
             bool pre_inf = false;
             if (SOFT && ladder && violation && !cert_known && !hp && nr > 38 && q == 0) {
-                constexpr int CP = (t_doubles(QCAP) * (int)sizeof(TF) / 8) / 4 < 134 ? (t_doubles(QCAP) * (int)sizeof(TF) / 8) / 4 : 134;
+                constexpr int CP = (t_doubles(TS) * (int)sizeof(TF) / 8) / 4 < 134 ? (t_doubles(TS) * (int)sizeof(TF) / 8) / 4 : 134;
                 cost += 176;
                 pre_inf = ladder_level_infeasible(r_xi, r_b, r_sd, r_slb, r_kc, nr, B + SL::T, P.h, P.alim, 1.0, whi_l, wlo_l, lane, CP);
                 LSYNC();
@@ -1005,7 +1007,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
             if (SOFT && crash && !pre_inf) {
                 bool tbl_ok = true;
                 while (q < (QCAP - 4 < 44 ? QCAP - 4 : 44)) {
-                    const CrashRes cr = crash_append<SOFT, QCAP, PERSIST, TF>((LdsD *)B, (const LdsD *)G, P.tables + TAB_DOUBLES + (size_t)ccase * 2 * TAB_TP_CASE,
+                    const CrashRes cr = crash_append<SOFT, QCAP, PERSIST, TF, TS>((LdsD *)B, (const LdsD *)G, P.tables + TAB_DOUBLES + (size_t)ccase * 2 * TAB_TP_CASE,
                                                                           lane, q, cslot, a, P.alim, tol, tbl_ok);
                     const int nb = cr.flags >> 8;
                     if (cr.flags & 2) crash_stop = true;
@@ -1203,7 +1205,8 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                 if (soft && !hp && p.ty == TY_COLL && !(r_fl[p.idx] & RF_LIVE)) {
                     if (q >= QCAP - 1) { rc = 2; break; }
                     const Cd u = slack_desc(TY_SLKU, p.idx);
-                    if (lane < ((q + 8) & ~7)) ((TF *)(B + SL::T))[tcol(q) + lane] = (TF)((lane == q) ? 1.4142135623730951 : 0.0);
+                    ENSURE_EXT(q);
+                    if (lane < ((q + 8) & ~7)) ((TF *)(B + SL::T))[tcol(q) + ((TS < QCAP && q >= TS) ? xo : 0) + lane] = (TF)((lane == q) ? 1.4142135623730951 : 0.0);
                     if (lane == 0) { r_fl[p.idx] |= (RF_LIVE | RF_SLKU); m_row[nrmax + p.idx] = (unsigned char)q; }
                     nlive++;
                     write_slot(u, -r_st[p.idx]);
@@ -1431,7 +1434,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                 cert_known = false;
                 // (between two solves the inverse factor is dead: its block holds the planes of up to 128 rows; zeroed again afterwards -- every value
                 // the products can read stays finite whatever the factor's storage type makes of these bits)
-                constexpr int CERT_PLANES = (t_doubles(QCAP) * (int)sizeof(TF) / 8) / 4 < 134 ? (t_doubles(QCAP) * (int)sizeof(TF) / 8) / 4 : 134;
+                constexpr int CERT_PLANES = (t_doubles(TS) * (int)sizeof(TF) / 8) / 4 < 134 ? (t_doubles(TS) * (int)sizeof(TF) / 8) / 4 : 134;
                 const int cert_used = 4 * ((nr < CERT_PLANES - 6 ? nr : CERT_PLANES - 6) + 6);
                 while (tries < max_tries - 1) {
                     if (!ladder_level_infeasible(r_xi, r_b, r_sd, r_slb, r_kc, nr, B + SL::T, P.h, P.alim, f, whi_l, wlo_l, lane, CERT_PLANES)) { cert_known = true; break; }

@@ -124,6 +124,21 @@ def convert_cpp_dump(name):
     print(name, {k: np.shape(v) for k, v in out.items()})
 
 
+def convert_outcomes(path, name):
+    """The per-trial outcome record of test/failure_rate.m (:61-203): for the ten swarm sizes N_vector = 20 .. 200 and 50 random trials each the
+    flags the script keeps -- feasible (:112-120), failed_goal (:128-131), violation (:177-181, after the interpolated pairwise check), coll,
+    outbound, success_dmpc = feasible && ~failed_goal && ~violation (:196) -- and the transition's wall time t_dmpc.  The workspace was saved while
+    trial (10, 50) was running (k = 14, n = 170): its entries are the script's initial zeros, so N = 200 has 49 completed trials."""
+    m = sio.loadmat(os.path.join(REF, path))
+    q, r = int(m["q"][0, 0]) - 1, int(m["r"][0, 0]) - 1
+    done = np.ones((10, 50), dtype=np.int8); done[q, r] = 0       # the trial in progress when the workspace was saved
+    out = dict(N_vector=m["N_vector"].ravel().astype(np.int32), trials=int(m["trials"][0, 0]), completed=done,
+               **{k: m[k].astype(np.int8) for k in ("success_dmpc", "feasible", "failed_goal", "violation", "coll", "outbound")},
+               t_dmpc=m["t_dmpc"].astype(np.float32), traj_time=m["traj_time"].astype(np.float32))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print("wrote", name, "success per N:", (out["success_dmpc"] * done).sum(1) / done.sum(1))
+
+
 if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("reference not present; fixtures are already committed")
@@ -131,3 +146,4 @@ if __name__ == "__main__":
     convert("data/comp_kctr/comp_kctr_3.mat", "comp_kctr_3_bound2", "bound2")
     convert_postcheck("data/comp_kctr/comp_kctr_2.mat", "postcheck_comp_kctr_2", "2")
     convert_cpp_dump("cpp_dump_200_first_solve")
+    convert_outcomes("data/failure_rate/failure_rate2.mat", "failure_rate2_outcomes")

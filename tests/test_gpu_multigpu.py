@@ -20,6 +20,65 @@ def _scenes(N, S, seed, cfgname="C4"):
     return cfg, kw, po, pf
 
 
+# ---- a box with two or more GPUs: the transports themselves, FIRST in this file (everything below needs one GPU only) --------------------
+def test_two_real_ranks_over_rccl():
+    """The wire itself: two processes, two GPUs, the library's RCCL all-gather between them (tests/rccl_two_ranks.py under
+    torch.distributed.run): sharded transition (fp64 and mixed: the fp32 exchange), unequal clusters, the history gather and the post-checks
+    on every rank, against the single-GPU run bit for bit.  Skipped on a box with one GPU (the emulated-rank tests above cover everything
+    but the transport there)."""
+    import os, subprocess, sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29541",
+                        os.path.join(root, "tests", "rccl_two_ranks.py")], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0 and "RCCL_TWO_RANKS_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
+
+
+def test_two_real_gpus_in_one_process():
+    """The other transport: ONE process, every visible GPU (dmpc_create(.., DMPC_DEVICE_ALL, ..): a host thread + stream + sub-context per GPU,
+    hipMemcpyPeerAsync of every rank's chunk into every GPU's next table, events between the MPC steps) on REAL devices -- whole transitions
+    (fp64 and mixed, unequal clusters), a second call on the same context, the post-checks on the histories gathered on the first GPU and
+    dmpc_step_batch, against the single-GPU context bit for bit; also the bench's own closed loop through `python bench.py --gpus 2`.  Skipped
+    on a box with one GPU (the emulated-rank tests below run the same protocol with the ranks sharing the device)."""
+    import json, os, subprocess, sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    for precision, N in (("f64", 21), ("mixed", 20)):
+        cfg, kw, po, pf = _scenes(N, 6, wl.SEED0 + 72)
+        ref_d = mp.Dmpc("bound", precision=precision, **kw)
+        ref = ref_d.transition(po, pf, 90, cfg["error_tol"])
+        d = mp.Dmpc("bound", device=mp.Dmpc.DEVICE_ALL, precision=precision, **kw)
+        assert d.n_devices == torch.cuda.device_count()
+        for rep in range(2):
+            out = d.transition(po, pf, 90, cfg["error_tol"])
+            assert np.array_equal(out["K_T_used"], ref["K_T_used"]) and np.array_equal(out["scene_status"], ref["scene_status"])
+            for k in ("pk", "vk", "ak"):
+                assert np.array_equal(out[k], ref[k]), (precision, rep, k)
+        ok = ((ref["scene_status"] & mp.ST_REACHED) != 0).astype(np.int32)
+        pc, pc_ref = d.postcheck(out["K_T_used"], pf, KT_alloc=90, mask=ok), ref_d.postcheck(ref["K_T_used"], pf, KT_alloc=90, mask=ok)
+        for k in pc:
+            assert np.array_equal(pc[k], pc_ref[k], equal_nan=True), k
+        l, _, _ = ref_d.init_batch(po, pf); z = np.zeros_like(po)
+        a, b = d.step_batch(l, po, z, z, pf), ref_d.step_batch(l, po, z, z, pf)
+        for k in ("p", "v", "a", "status"):
+            assert np.array_equal(a[k], b[k]), k
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "DMPC_BENCH_SHARE_GPU"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "9", "--warmup", "2", "--no-secondary", "--no-cpu-baseline"],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["exchange_verified"] is True and line["config"]["n_ranks_seen"] == 2 and line["scaling"] == "strong"
+
+
 @pytest.mark.parametrize("with_comm", [False, True])
 def test_sharded_transition_one_rank_equals_dmpc_transition(with_comm):
     cfg, kw, po, pf = _scenes(20, 3, wl.SEED0 + 21)
@@ -214,21 +273,3 @@ def test_bench_launches_its_own_ranks():
     assert line["n_gpus"] == 2 and line["config"]["exchange_verified"] is True and line["scaling"] == "strong"
     assert line["config"]["agents_per_scene"] == 2000 and line["config"]["agents_per_gpu"] == 1000 and "FUNCTIONAL CHECK" in line["data"]
     assert line["config"]["workload"].startswith("C4") and "setup_s" in line["config"] and "exchange_advance_and_gaps" in line["step_breakdown_ms"]
-
-
-def test_two_real_ranks_over_rccl():
-    """The wire itself: two processes, two GPUs, the library's RCCL all-gather between them (tests/rccl_two_ranks.py under
-    torch.distributed.run): sharded transition (fp64 and mixed: the fp32 exchange), unequal clusters, the history gather and the post-checks
-    on every rank, against the single-GPU run bit for bit.  Skipped on a box with one GPU (the emulated-rank tests above cover everything
-    but the transport there)."""
-    import os, subprocess, sys
-    import torch
-    if torch.cuda.device_count() < 2:
-        pytest.skip("needs two GPUs")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
-        env.pop(k, None)
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29541",
-                        os.path.join(root, "tests", "rccl_two_ranks.py")], capture_output=True, text=True, env=env, timeout=900)
-    assert r.returncode == 0 and "RCCL_TWO_RANKS_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])

@@ -157,6 +157,24 @@ def test_split_inverse_factor_does_not_change_a_bit(variant, N, S, opts):
     assert max(int(x["info"][..., 7].max()) for x in a) > 16      # some agent did take an extension
 
 
+@pytest.mark.parametrize("opts", [{}, {"ext_cap": 1}])
+def test_split_inverse_factor_of_the_slack_kernels_in_large_scenes(opts):
+    """round 5: the 56-slot tier of the slack variants in scenes of >= 1024 agents runs as persistent waves with 48 own columns of the factor
+    and the last eight from the workgroup's pool (seven waves per CU).  A dense 3 000-agent scene far from its goals (most bounds saturated:
+    working sets of 45-56 slots) against the unsplit one-agent-per-workgroup form (option no_split_t), closed-loop steps 2-4: every output
+    word identical, also with ONE extension per workgroup."""
+    cfg = wl.CONFIGS["C4"]
+    N = 3000
+    kw = wl.solver_kwargs(cfg, N)
+    po, pf = wl.make_scenes(cfg, 1, N, wl.SEED0 + 62)
+    a = _steps("bound", kw, po, pf, 3, **opts)
+    b = _steps("bound", kw, po, pf, 3, no_split_t=1)
+    for x, y in zip(a, b):
+        for k in ("status", "info", "p", "v", "a"):
+            assert np.array_equal(x[k], y[k]), k
+    assert max(int(x["info"][..., 7].max()) for x in a) > 48      # some agent did take an extension
+
+
 def test_order_hint_is_pure_scheduling():
     """option order_hint (the launch order also uses, or -- 2 -- is, every agent's work estimate of the context's previous step): another ORDER of the
     same solves, so three closed-loop steps are identical bit for bit to the default order and to no order at all"""

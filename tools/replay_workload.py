@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """development: the secondary workloads of bench.py as stand-alone replay loops for the profiler passes of tools/gpu_profile_round.sh
-(usage: replay_workload.py bound|c4 --steps K --warmup W).
-  bound: the headline scenes (C2 box, 100 agents x 512 scenes) with the reference's primary variant solveSoftDMPCbound, replay of MPC step 12
+(usage: replay_workload.py hard|bound|c4 --steps K --warmup W).
+  hard:  C2 (BASELINE configs[1], the headline of rounds 1-4): 100 agents x 512 scenes of solveHardDMPC, replay of the captured first solve
+  bound: the same scenes (C2 box, 100 agents x 512 scenes) with the reference's primary variant solveSoftDMPCbound, replay of MPC step 12
   c4:    ONE scene of 10^4 agents, solveSoftDMPCbound, teacher-forced MPC steps 2-10 replayed round-robin"""
 import argparse, os, sys, time
 import numpy as np
@@ -15,10 +16,10 @@ a = ap.parse_args()
 dev = torch.device("cuda", 0)
 t = lambda x, dt=torch.float64: torch.from_numpy(np.ascontiguousarray(x)).to(dev, dt)
 stream = torch.cuda.current_stream().cuda_stream
-if a.what == "bound":
-    cfg, N, S = dict(wl.CONFIGS["C2"], variant="bound"), 100, 512
+if a.what in ("bound", "hard"):
+    cfg, N, S = dict(wl.CONFIGS["C2"], variant=a.what), 100, 512
     kw = wl.solver_kwargs(cfg, N)
-    d = mp.Dmpc("bound", **kw)
+    d = mp.Dmpc(a.what, **kw)
     l, xp, xv, xa, pf, alive = bench.capture_state(d, cfg, S, N, 12, wl.SEED0 + 2)
     states = [(l, xp, xv, xa)]
 else:
