@@ -798,6 +798,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
         // `hp`: this pass of the loop is that check -- rows as hard constraints with right-hand side b - d slb, nothing recorded; an
         // infeasible verdict takes the ladder step exactly as a failed try would, a feasible one is followed by the real solve of the level.
         const bool hp_variant = SOFT && var == VAR_ALL3 && violation && !P.no_level_check;
+        int lev_skip = 0;   // ladder levels above the current one that the last infeasibility proof covers as well
         bool hp = false, level_checked = false;
         while (tries < max_tries) {
             tries++;
@@ -1314,6 +1315,32 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
 #endif
                     if (!(t < INFINITY)) {
                         if (SOFT && lam_p == 0.0 && !x_synced && resyncs < 3) { ++resyncs; resync = true; break; }   // not believed on a stale iterate
+                        // How far up the retry ladder does THIS proof reach (round 5)?  The verdict is a Farkas combination: the pivot depends on the
+                        // working set, n_p = N_W r with no r_j > 0, so y = (1, -r) >= 0 combines the constraints to 0 <= d_p - sum r_j d_j, and that
+                        // number is negative.  A ladder step changes nothing but right-hand sides -- the slack bounds -slb 2^t (in the level check of
+                        // solveSoftDMPCall: the rows' b - d slb 2^t) -- so the same combination reads C + 2^m U at level t + m: every level where it
+                        // is still clearly negative is infeasible by the same proof and is skipped (counted as a try, as the reference would have
+                        // spent it).  The longest agents of the solveSoftDMPCall replay proved four levels in a row infeasible with 80 iterations each.
+                        if (SOFT && ladder && violation) {
+                            double c_l = 0.0, u_l = 0.0;
+                            if (lane < q) {
+                                const int mt = (mymeta >> 8) & 0xff, mi = mymeta >> 16;
+                                const double dj = B[SL::SD + lane];
+                                double uj = 0.0;
+                                if (hp) { if (mt == TY_COLL) uj = -r_sd[mi] * r_slb[mi]; }
+                                else if (mt == TY_SLKL) uj = dj;
+                                c_l = -ri * (dj - uj); u_l = -ri * uj;
+                            }
+                            double up = 0.0;
+                            if (hp) { if (p.ty == TY_COLL) up = -r_sd[p.idx] * r_slb[p.idx]; }
+                            else if (p.ty == TY_SLKL) up = p.d;
+                            const double Cc = (p.d - up) + wave_sum0(c_l), Uc = up + wave_sum0(u_l);
+                            lev_skip = 0;
+                            if (Cc + Uc < 0.0) {   // (the proof as it stands; anything else is round-off: no skipping)
+                                double kk = 2.0;
+                                while (lev_skip < 40 && Cc + kk * Uc < -1e-7 * (fabs(Cc) + kk * fabs(Uc))) { ++lev_skip; kk *= 2.0; }
+                            }
+                        }
                         rc = 1; break;
                     }
                     if (lane < q) B[SL::SLAM + lane] -= t * ri;
@@ -1437,9 +1464,11 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                 constexpr int CERT_PLANES = (t_doubles(TS) * (int)sizeof(TF) / 8) / 4 < 134 ? (t_doubles(TS) * (int)sizeof(TF) / 8) / 4 : 134;
                 const int cert_used = 4 * ((nr < CERT_PLANES - 6 ? nr : CERT_PLANES - 6) + 6);
                 while (tries < max_tries - 1) {
+                    if (lev_skip > 0) { --lev_skip; f *= 2.0; ++tries; continue; }   // (infeasible by the proof the failed solve ended with)
                     if (!ladder_level_infeasible(r_xi, r_b, r_sd, r_slb, r_kc, nr, B + SL::T, P.h, P.alim, f, whi_l, wlo_l, lane, CERT_PLANES)) { cert_known = true; break; }
                     f *= 2.0; ++tries;
                 }
+                lev_skip = 0;
                 LSYNC();
                 for (int i = lane; i < cert_used; i += 64) B[SL::T + i] = 0.0;
                 for (int i = lane; i < nr; i += 64) { r_slb[i] *= f; r_st[i] *= f; }

@@ -1,16 +1,18 @@
-"""development (DEV_TRACE build: python tools/with_trace_lib.py tools/gpu_c4_iter_trace.py [mpc_step] [rank]): the pivot sequence of one heavy agent of
-the 10^4-agent scene (C4) -- which constraints enter, how often each, full steps against partial steps (drops)."""
+"""development (DEV_TRACE build: python tools/with_trace_lib.py tools/gpu_iter_trace.py [mpc_step] [rank] [workload]): the solves and the pivot sequence of
+one heavy agent (the rank-th by iterations) of a closed loop -- per solve (ladder level) its iterations and verdict; which constraints enter, how often
+each, full steps against partial steps (drops).  workload: C4 (default: ONE scene of 10^4 agents, solveSoftDMPCbound) | all3 | bound2 | C2b (100 agents x S scenes)"""
 import sys, os, ctypes as C, collections
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import multiagent_planning_amd as mp
 from multiagent_planning_amd import workload as wl, _lib
-N = 10000
 kstep = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 rank = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+which = sys.argv[3] if len(sys.argv) > 3 else "C4"
+N, S, variant = {"C4": (10000, 1, "bound"), "all3": (100, 128, "all3"), "bound2": (100, 128, "bound2"), "C2b": (100, 512, "bound")}[which]
 cfg = wl.CONFIGS["C4"]; kw = wl.solver_kwargs(cfg, N)
-po, pf = wl.make_scenes(cfg, 1, N, wl.SEED0 + 4)
-d = mp.Dmpc(cfg["variant"], **kw)
+po, pf = wl.make_scenes(cfg, S, N, wl.SEED0 + 4)
+d = mp.Dmpc(variant, **kw)
 l, _, _ = d.init_batch(po, pf)
 xp, xv, xa = po.copy(), np.zeros_like(po), np.zeros_like(po)
 for k in range(kstep - 2):
@@ -19,7 +21,7 @@ for k in range(kstep - 2):
     l = np.where(ok[..., None], out["p"], l); xp = np.where(ok[..., None], out["p"][..., :3], xp)
     xv = np.where(ok[..., None], out["v"][..., :3], xv); xa = np.where(ok[..., None], out["a"][..., :3], xa)
 o_ = d.step_batch(l, xp, xv, xa, pf)
-g = int(np.argsort(o_["info"][0, :, 4])[::-1][rank])
+g = int(np.argsort(o_["info"][..., 4].ravel())[::-1][rank])
 L = _lib.load()
 L.dmpc_debug_trace.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
 cap = 400
@@ -27,8 +29,8 @@ L.dmpc_debug_trace(d._ctx, g, cap, None)
 out = d.step_batch(l, xp, xv, xa, pf)
 buf = np.zeros((cap, 8))
 L.dmpc_debug_trace(d._ctx, g, cap, buf.ctypes.data_as(C.c_void_p))
-i = out["info"][0, g]
-print(f"agent {g} status {out['status'][0, g]} viol_k {i[0]} rows {i[1]} tries {i[2]} iters {i[4]} nslack {i[5]} active {i[6]} maxq {i[7]}")
+i = out["info"].reshape(-1, 8)[g]
+print(f"agent {g} status {out['status'].ravel()[g]} viol_k {i[0]} rows {i[1]} tries {i[2]} iters {i[4]} nslack {i[5]} active {i[6]} maxq {i[7]}")
 print("solves of this agent (ladder count after, iterations, of them appends without a step, verdict 0 ok / 1 infeasible / 2 slots / 3 cap, final slots, level check, 2^k scaling):")
 for r in buf[cap - 12:cap - 4]:
     if r[1] > 0: print("   ", [int(x) for x in r[:7]])
