@@ -19,6 +19,7 @@ ST_REACHED = 256   # scene_status of transition(): every agent reached its goal
 INFO_LEN = 8
 I_VIOLK, I_NROWS, I_TRIES, I_CASE, I_ITERS, I_NSLACK, I_NACTIVE, I_MAXQ = range(8)
 K_HOR = 15
+ABI_VERSION = 5    # DMPC_ABI_VERSION of include/dmpc_hip.h
 
 # every symbol include/dmpc_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
@@ -68,6 +69,10 @@ def load():
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C multiagent_planning_amd/csrc` (hipcc, gfx950). There is no CPU fallback.")
     L = C.CDLL(LIB_PATH)
+    # the header revision these bindings were written against (DMPC_ABI_VERSION: the special device values DEVICE_ALL / DEVICE_CURRENT below
+    # changed once between revisions): refuse another library instead of passing it values that mean something else there
+    if not hasattr(L, "dmpc_abi_version") or L.dmpc_abi_version() != ABI_VERSION:
+        raise DmpcError(f"{LIB_PATH}: ABI revision {L.dmpc_abi_version() if hasattr(L, 'dmpc_abi_version') else '< 5'}, these bindings need {ABI_VERSION}: rebuild the library")
     dp, ip, vp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_void_p
     pp = C.POINTER(DmpcParams)
     L.dmpc_create.restype = vp

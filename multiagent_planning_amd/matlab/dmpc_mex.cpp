@@ -85,6 +85,8 @@ static dmpc_ctx *context(const dmpc_params &p)
         if (dmpc_set_params(c, &p)) mexErrMsgIdAndTxt("dmpc:params", "%s", dmpc_last_error(c));
         g_nslots = 3;
     } else {
+        // (the library found at run time must speak the header this gateway was compiled with: the special device values changed once)
+        if (dmpc_abi_version() != DMPC_ABI_VERSION) mexErrMsgIdAndTxt("dmpc:abi", "libdmpc_hip.so has ABI revision %d, this gateway was compiled for %d", dmpc_abi_version(), DMPC_ABI_VERSION);
         c = dmpc_create(&p, DMPC_DEVICE_ALL, DMPC_PREC_F64);
         if (!c) mexErrMsgIdAndTxt("dmpc:create", "%s", dmpc_last_error(nullptr));
     }
