@@ -314,9 +314,11 @@ DMPC_API int dmpc_postcheck(dmpc_ctx *ctx, int S, int N, int KT_alloc, const int
                    double *totdist, double *traj_time, double *p_interp, int ns_alloc);
 
 /* f-3: dense collision rows behind the CollConstr / AddCollConstr helpers named in the north star.  All of them
- * compute, per neighbour j (order = 2, E1 = diag(1,1,1/c), E2 = E1^2):
- *     dist = |E1 (p - p_j)|,  diff = E2 (p - p_j),  r = dist (rmin - dist + diff.p/dist) - diff.a0,
- *     Ain(row,:) = -diff_mat * A = -(diff . A(3 k_blk + 1..3, :)),  bin(row) = -r
+ * compute, per neighbour j (E1 = diag(1,1,1/c), E2 = E1^order; the ORDER is the context's, dmpc_params.order: 2, or 4 on a context of an
+ * all-neighbour variant -- the helpers are generic in it, CollConstrSoftDMPC.m:16-21, and test/comp_test_ellipconstr.m:158 sets 4):
+ *     dist = |E1 (p - p_j)|_order,  diff = E2 (p - p_j).^(order-1),  pd = dist^(order-1),
+ *     r = pd (rmin - dist + diff.p/pd) - diff.a0,   Ain(row,:) = -diff_mat * A = -(diff . A(3 k_blk + 1..3, :)),  bin(row) = -r
+ * (`dist` below returns pd = prev_dist, what CollConstrSoftDMPC.m:19 hands back: the distance itself for order 2)
  * replacing (file:line)
  *     dec-iSCP/CollConstr.m:1-24                (k_cmp = k-1, k_blk = k-2, a0 = po; all obstacles of `l`)
  *     dmpc/matlab/CollConstrSoftDMPC.m:1-32     (k_cmp = k_blk = k-1, a0 = A_initp(3k-2:3k,:)[po;vo]; `violation` mask)

@@ -187,12 +187,12 @@ def CheckCollSoftDMPC(p, l, n, k, E1, rmin, order):
     l = np.asarray(l, float)
     N = l.shape[2]
     E1 = np.asarray(E1, float)
-    c = _c_of(E1, E1 @ E1, order)
+    c = _c_of(E1, np.linalg.matrix_power(E1, int(order)), order)
     others = [j for j in range(N) if j != n - 1]
     d = np.full(N, np.inf)
     if others:
-        _, _, dist = _rowctx().coll_rows(_obst(l), others, k - 1, 0, np.ravel(p), np.zeros(3), rmin, c, np.zeros((3, 1)))
-        d[others] = dist
+        _, _, dist = _rowctx(order).coll_rows(_obst(l), others, k - 1, 0, np.ravel(p), np.zeros(3), rmin, c, np.zeros((3, 1)))
+        d[others] = dist if int(order) == 2 else np.cbrt(dist)      # (the builder returns prev_dist = dist^(order-1))
     violation = (d < rmin).astype(float)
     viol_constr = (d < rmin * 3).astype(float)
     return violation, float(d.min()) if others else np.inf, viol_constr
@@ -219,14 +219,13 @@ def collision_rows(variant, po, vo, n, h, l, K, rmin, pmin, pmax, alim, Q1, S1, 
 # CollConstr* / AddCollConstr: the dense collision rows the reference's helpers return, built on the GPU
 # ---------------------------------------------------------------------------------------------
 def _c_of(E1, E2, order):
+    """the c of E = diag(1,1,c) behind E1 = E^-1 and E2 = E^-order (dmpc_soft_bound.m:20-22; order 4: test/comp_test_ellipconstr.m:160-163)"""
     E1, E2 = np.asarray(E1, float), np.asarray(E2, float)
-    if int(order) != 2:
-        # (order 4 -- test/comp_test_ellipconstr.m:158 -- exists inside the all-neighbour SOLVERS (solveSoftDMPC, solveEllipDMPC,
-        # solveSoftDMPCrepair, DMPC::solveQP) and dmpc_rows_one; the dense row builders behind these standalone helpers are order 2)
-        raise NotImplementedError("the standalone dense row builders take order = 2 ellipsoids only (order 4: the all-neighbour solvers and rows_one)")
+    if int(order) not in (2, 4):
+        raise NotImplementedError("ellipsoid order must be 2 or 4 (the values the reference's scripts use)")
     if not (np.allclose(E1, np.diag(np.diag(E1))) and abs(E1[0, 0] - 1) < 1e-15 and abs(E1[1, 1] - 1) < 1e-15
-            and np.allclose(E2, E1 @ E1, rtol=0, atol=1e-15)):
-        raise NotImplementedError("E1 must be diag(1,1,1/c) and E2 = E1^2")
+            and np.allclose(E2, np.linalg.matrix_power(E1, int(order)), rtol=0, atol=1e-15)):
+        raise NotImplementedError("E1 must be diag(1,1,1/c) and E2 = E1^order")
     return 1.0 / E1[2, 2]
 
 
@@ -239,10 +238,13 @@ def _obst(l):
 _ROWCTX = {}
 
 
-def _rowctx(device=0):
-    if device not in _ROWCTX:
-        _ROWCTX[device] = _lib.Dmpc("bound", device=device)
-    return _ROWCTX[device]
+def _rowctx(order=2, device=0):
+    """the context behind the standalone helpers; the dense row builders take the ellipsoid order from it (dmpc_params.order: an order-4
+    context is one of an all-neighbour variant)"""
+    key = (int(order), device)
+    if key not in _ROWCTX:
+        _ROWCTX[key] = _lib.Dmpc("bound", device=device) if int(order) == 2 else _lib.Dmpc("ellip", device=device, order=int(order))
+    return _ROWCTX[key]
 
 
 def CollConstr(p, po, k, l, Ain, rmin, E1, E2, order):
@@ -255,7 +257,7 @@ def CollConstr(p, po, k, l, Ain, rmin, E1, E2, order):
     if N_obs == 0:
         return np.zeros((0, Ain.shape[1])), np.zeros((0, 1))
     c = _c_of(E1, E2, order)
-    A, b, _ = _rowctx().coll_rows(lo, np.arange(N_obs), k - 1, k - 2, np.ravel(p), np.ravel(po), rmin, c, Ain)
+    A, b, _ = _rowctx(order).coll_rows(lo, np.arange(N_obs), k - 1, k - 2, np.ravel(p), np.ravel(po), rmin, c, Ain)
     return A, b[:, None]
 
 
@@ -265,7 +267,7 @@ def _dmpc_rows(p, po, vo, n, k, l, rmin, Ain, A_initp, E1, E2, order, sel, k_ctr
     # A_initp(3*(k_ctr-1)+1:3*k_ctr,:)*[po';vo'] (CollConstrSoftDMPC.m:21), on the device like the rest of the row
     a0, _ = _rowctx().prop_state(np.zeros((3, 1)), np.zeros((3, 1)), [0.0], A_initp=np.asarray(A_initp, float)[3 * (k_ctr - 1):3 * k_ctr, :],
                                  po=po, vo=vo)
-    return _rowctx().coll_rows(lo, sel, k - 1, k_ctr - 1, np.ravel(p), a0, rmin, c, np.asarray(Ain, float))
+    return _rowctx(order).coll_rows(lo, sel, k - 1, k_ctr - 1, np.ravel(p), a0, rmin, c, np.asarray(Ain, float))
 
 
 def CollConstrSoftDMPC(p, po, vo, n, k, l, rmin, Ain, A_initp, E1, E2, order, violation):
@@ -331,5 +333,5 @@ def AddCollConstr(p, po, K, rmin, A, E1, E2, order):
         return np.zeros((0, A.shape[1])), np.zeros((0, 1))
     po = np.asarray(po, float)
     po = np.ascontiguousarray(po[0].T) if po.ndim == 3 else po.reshape(N, 3)      # MATLAB po(1,3,N) or [N,3]
-    Ain, b = _rowctx().add_coll_constr(np.ascontiguousarray(p.transpose(2, 1, 0)), po, rmin, c, A)
+    Ain, b = _rowctx(order).add_coll_constr(np.ascontiguousarray(p.transpose(2, 1, 0)), po, rmin, c, A)
     return Ain, b[:, None]

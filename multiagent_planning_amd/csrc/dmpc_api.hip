@@ -1757,7 +1757,7 @@ extern "C" int dmpc_coll_rows_device(dmpc_ctx *ctx, int K, int n_sel, const int3
     const size_t tot = (size_t)n_sel * ncols;
     hipLaunchKernelGGL(rb::coll_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        n_sel, (const int *)d_sel, K, d_l, k_cmp, k_blk, p[0], p[1], p[2], a0[0], a0[1], a0[2], rmin, 1.0 / c, d_A,
-                       (long)a_rs, (long)a_cs, ncols, d_Ain, (long)o_rs, (long)o_cs, d_bin, d_dist);
+                       (long)a_rs, (long)a_cs, ncols, d_Ain, (long)o_rs, (long)o_cs, d_bin, d_dist, ctx->prm.order == 4 ? 4 : 2);
     HIPCHK(ctx, hipGetLastError());
     return 0;
 }
@@ -1838,14 +1838,14 @@ extern "C" int dmpc_add_coll_constr_device(dmpc_ctx *ctx, int K, int N, const do
     const size_t pch = ((size_t)N * (N - 1) / 2 + RB_PCH - 1) / RB_PCH;
     if (o_cs == 1 && K <= 65535 && pch <= 65535) {   // row-major output: (column tile, k, pair chunk) blocks
         hipLaunchKernelGGL(rb::add_coll_rows_rm_kernel, dim3((unsigned)((ncols + 255) / 256), (unsigned)K, (unsigned)pch), dim3(256), 0, st,
-                           N, K, d_p, d_po, rmin, 1.0 / c, d_A, (long)a_rs, (long)a_cs, ncols, d_Ain, (long)o_rs, d_bin);
+                           N, K, d_p, d_po, rmin, 1.0 / c, d_A, (long)a_rs, (long)a_cs, ncols, d_Ain, (long)o_rs, d_bin, ctx->prm.order == 4 ? 4 : 2);
     } else if (o_rs == 1 && (ncols + RB_CCH - 1) / RB_CCH <= 65535) {   // column-major output (MATLAB): row-per-thread
         hipLaunchKernelGGL(rb::add_coll_rows_cm_kernel, dim3((unsigned)((nrows + 255) / 256), (unsigned)((ncols + RB_CCH - 1) / RB_CCH)),
                            dim3(256), 0, st, N, K, d_p, d_po, rmin, 1.0 / c, d_A, (long)a_rs, (long)a_cs, ncols, d_Ain, (long)o_cs,
-                           d_bin, nrows);
+                           d_bin, nrows, ctx->prm.order == 4 ? 4 : 2);
     } else {                                // arbitrary strides: one element per thread
         hipLaunchKernelGGL(rb::add_coll_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, N, K, d_p, d_po, rmin,
-                           1.0 / c, d_A, (long)a_rs, (long)a_cs, ncols, d_Ain, (long)o_rs, (long)o_cs, d_bin, nrows);
+                           1.0 / c, d_A, (long)a_rs, (long)a_cs, ncols, d_Ain, (long)o_rs, (long)o_cs, d_bin, nrows, ctx->prm.order == 4 ? 4 : 2);
     }
     HIPCHK(ctx, hipGetLastError());
     return 0;

@@ -14,17 +14,34 @@ namespace rb {
 
 struct RowGeom { double xi[3]; double dist; double r; };
 
-// dist = |E1 (p - pj)|_2, diff = E2 (p - pj), r = dist (rmin - dist + diff.p / dist) - diff.a0   (order = 2)
-__device__ __forceinline__ RowGeom row_geom(const double p[3], const double pj[3], const double a0[3], double rmin, double cinv)
+// The ellipsoid of the helpers for order 2 and 4 (CollConstr.m:10-14, CollConstrSoftDMPC.m:16-21, AddCollConstr.m:13-17; E1 = E^-1, E2 = E^-order,
+// `.^` binds tighter than `*`):  dist = |E1 d|_order,  diff = E2 d.^(order-1),  pd = dist^(order-1).  Returns dist; xi = diff, pd by reference.
+__device__ __forceinline__ double ell_geom(double dx, double dy, double dz, double cinv, int order, double xi[3], double &pd)
+{
+    const double ez = dz * cinv;
+    if (order == 4) {
+        const double dist = sqrt(sqrt(dx * dx * dx * dx + dy * dy * dy * dy + ez * ez * ez * ez));
+        const double c2 = cinv * cinv;
+        xi[0] = dx * dx * dx; xi[1] = dy * dy * dy; xi[2] = dz * dz * dz * (c2 * c2);
+        pd = dist * dist * dist;
+        return dist;
+    }
+    const double dist = sqrt(dx * dx + dy * dy + ez * ez);
+    xi[0] = dx; xi[1] = dy; xi[2] = dz * cinv * cinv;
+    pd = dist;
+    return dist;
+}
+
+// r = pd (rmin - dist + diff.p / pd) - diff.a0;  g.dist = prev_dist = pd (what CollConstrSoftDMPC returns as its third output)
+__device__ __forceinline__ RowGeom row_geom(const double p[3], const double pj[3], const double a0[3], double rmin, double cinv, int order)
 {
     RowGeom g;
-    const double dx = p[0] - pj[0], dy = p[1] - pj[1], dz = p[2] - pj[2];
-    const double ez = dz * cinv;
-    g.dist = sqrt(dx * dx + dy * dy + ez * ez);
-    g.xi[0] = dx; g.xi[1] = dy; g.xi[2] = dz * cinv * cinv;
+    double pd;
+    const double dist = ell_geom(p[0] - pj[0], p[1] - pj[1], p[2] - pj[2], cinv, order, g.xi, pd);
     const double dp = g.xi[0] * p[0] + g.xi[1] * p[1] + g.xi[2] * p[2];
     const double da = g.xi[0] * a0[0] + g.xi[1] * a0[1] + g.xi[2] * a0[2];
-    g.r = g.dist * (rmin - g.dist + dp / g.dist) - da;
+    g.r = pd * (rmin - dist + dp / pd) - da;
+    g.dist = pd;
     return g;
 }
 
@@ -33,7 +50,7 @@ __device__ __forceinline__ RowGeom row_geom(const double p[3], const double pj[3
 __global__ void coll_rows_kernel(int n_sel, const int *__restrict__ sel, int K, const double *__restrict__ l, int k_cmp, int k_blk,
                                  double p0, double p1, double p2, double a00, double a01, double a02, double rmin, double cinv,
                                  const double *__restrict__ A, long a_rs, long a_cs, int ncols, double *__restrict__ Ain, long o_rs,
-                                 long o_cs, double *__restrict__ bin, double *__restrict__ dist)
+                                 long o_cs, double *__restrict__ bin, double *__restrict__ dist, int order)
 {
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (size_t)n_sel * ncols) return;
@@ -43,7 +60,7 @@ __global__ void coll_rows_kernel(int n_sel, const int *__restrict__ sel, int K, 
     const double p[3] = {p0, p1, p2}, a0[3] = {a00, a01, a02};
     const double *pj = l + ((size_t)sel[r] * K + k_cmp) * 3;
     const double q[3] = {pj[0], pj[1], pj[2]};
-    const RowGeom g = row_geom(p, q, a0, rmin, cinv);
+    const RowGeom g = row_geom(p, q, a0, rmin, cinv, order);
     const double *Ab = A + (size_t)(3 * k_blk) * a_rs + (size_t)c * a_cs;
     Ain[(size_t)r * o_rs + (size_t)c * o_cs] = -(g.xi[0] * Ab[0] + g.xi[1] * Ab[a_rs] + g.xi[2] * Ab[2 * a_rs]);
     if (c == 0) { bin[r] = -g.r; if (dist) dist[r] = g.dist; }
@@ -64,7 +81,7 @@ __global__ void xi_rows_kernel(int nr, const double *__restrict__ xi, const int 
 //   r = dist (rmin - dist) + diff.(pi_k - pj_k) - diff.(po_i - po_j);  Ain = -(diff . A[blk(i,k)] - diff . A[blk(j,k)])
 __global__ void add_coll_rows_kernel(int N, int K, const double *__restrict__ p, const double *__restrict__ po, double rmin,
                                      double cinv, const double *__restrict__ A, long a_rs, long a_cs, int ncols,
-                                     double *__restrict__ Ain, long o_rs, long o_cs, double *__restrict__ bin, size_t nrows)
+                                     double *__restrict__ Ain, long o_rs, long o_cs, double *__restrict__ bin, size_t nrows, int order)
 {
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= nrows * (size_t)ncols) return;
@@ -79,16 +96,16 @@ __global__ void add_coll_rows_kernel(int N, int K, const double *__restrict__ p,
     const int j = (int)(pr - (long)i * (2 * N - i - 1) / 2) + i + 1;
     const double *pi = p + ((size_t)i * K + k) * 3, *pj = p + ((size_t)j * K + k) * 3;
     const double dx = pi[0] - pj[0], dy = pi[1] - pj[1], dz = pi[2] - pj[2];
-    const double ez = dz * cinv;
-    const double dist = sqrt(dx * dx + dy * dy + ez * ez);
-    const double x0 = dx, x1 = dy, x2 = dz * cinv * cinv;
+    double xi_[3], pd;
+    const double dist = ell_geom(dx, dy, dz, cinv, order, xi_, pd);
+    const double x0 = xi_[0], x1 = xi_[1], x2 = xi_[2];
     const double *Ai = A + (size_t)(3 * ((size_t)K * i + k)) * a_rs + (size_t)c * a_cs;
     const double *Aj = A + (size_t)(3 * ((size_t)K * j + k)) * a_rs + (size_t)c * a_cs;
     Ain[r * (size_t)o_rs + (size_t)c * o_cs] =
         -((x0 * Ai[0] + x1 * Ai[a_rs] + x2 * Ai[2 * a_rs]) - (x0 * Aj[0] + x1 * Aj[a_rs] + x2 * Aj[2 * a_rs]));
     if (c == 0) {
         const double *oi = po + (size_t)i * 3, *oj = po + (size_t)j * 3;
-        const double rr = dist * (rmin - dist) + (x0 * dx + x1 * dy + x2 * dz) -
+        const double rr = pd * (rmin - dist) + (x0 * dx + x1 * dy + x2 * dz) -
                           (x0 * (oi[0] - oj[0]) + x1 * (oi[1] - oj[1]) + x2 * (oi[2] - oj[2]));
         bin[r] = -rr;
     }
@@ -104,15 +121,14 @@ __device__ __forceinline__ void unrank_pair(long pr, int N, int &i, int &j)
 }
 
 __device__ __forceinline__ double pair_geom(const double *__restrict__ p, const double *__restrict__ po, int K, int i, int j, int k,
-                                            double rmin, double cinv, double xi[3])
+                                            double rmin, double cinv, double xi[3], int order)
 {
     const double *pi = p + ((size_t)i * K + k) * 3, *pj = p + ((size_t)j * K + k) * 3;
     const double dx = pi[0] - pj[0], dy = pi[1] - pj[1], dz = pi[2] - pj[2];
-    const double ez = dz * cinv;
-    const double dist = sqrt(dx * dx + dy * dy + ez * ez);
-    xi[0] = dx; xi[1] = dy; xi[2] = dz * cinv * cinv;
+    double pd;
+    const double dist = ell_geom(dx, dy, dz, cinv, order, xi, pd);
     const double *oi = po + (size_t)i * 3, *oj = po + (size_t)j * 3;
-    return dist * (rmin - dist) + (xi[0] * dx + xi[1] * dy + xi[2] * dz) -
+    return pd * (rmin - dist) + (xi[0] * dx + xi[1] * dy + xi[2] * dz) -
            (xi[0] * (oi[0] - oj[0]) + xi[1] * (oi[1] - oj[1]) + xi[2] * (oi[2] - oj[2]));
 }
 
@@ -124,7 +140,7 @@ __device__ __forceinline__ double pair_geom(const double *__restrict__ p, const 
 __global__ __launch_bounds__(256) void add_coll_rows_rm_kernel(int N, int K, const double *__restrict__ p,
                                                                const double *__restrict__ po, double rmin, double cinv,
                                                                const double *__restrict__ A, long a_rs, long a_cs, int ncols,
-                                                               double *__restrict__ Ain, long o_rs, double *__restrict__ bin)
+                                                               double *__restrict__ Ain, long o_rs, double *__restrict__ bin, int order)
 {
     __shared__ double gx[RB_PCH][3];
     __shared__ int gij[RB_PCH][2];
@@ -137,7 +153,7 @@ __global__ __launch_bounds__(256) void add_coll_rows_rm_kernel(int N, int K, con
         int i, j;
         unrank_pair(base + tid, N, i, j);
         double xi[3];
-        const double r = pair_geom(p, po, K, i, j, k, rmin, cinv, xi);
+        const double r = pair_geom(p, po, K, i, j, k, rmin, cinv, xi, order);
         gx[tid][0] = xi[0]; gx[tid][1] = xi[1]; gx[tid][2] = xi[2];
         gij[tid][0] = i; gij[tid][1] = j;
         if (blockIdx.x == 0) bin[(base + tid) * K + k] = -r;
@@ -170,7 +186,7 @@ __global__ __launch_bounds__(256) void add_coll_rows_cm_kernel(int N, int K, con
                                                                const double *__restrict__ po, double rmin, double cinv,
                                                                const double *__restrict__ A, long a_rs, long a_cs, int ncols,
                                                                double *__restrict__ Ain, long o_cs, double *__restrict__ bin,
-                                                               size_t nrows)
+                                                               size_t nrows, int order)
 {
     const size_t r = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (r >= nrows) return;
@@ -178,7 +194,7 @@ __global__ __launch_bounds__(256) void add_coll_rows_cm_kernel(int N, int K, con
     int i, j;
     unrank_pair((long)(r / K), N, i, j);
     double xi[3];
-    const double rr = pair_geom(p, po, K, i, j, k, rmin, cinv, xi);
+    const double rr = pair_geom(p, po, K, i, j, k, rmin, cinv, xi, order);
     if (blockIdx.y == 0) bin[r] = -rr;
     const double *Ai = A + (size_t)(3 * ((size_t)K * i + k)) * a_rs, *Aj = A + (size_t)(3 * ((size_t)K * j + k)) * a_rs;
     const int cbeg = blockIdx.y * RB_CCH, cend = min(ncols, cbeg + RB_CCH);

@@ -1023,6 +1023,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                 }
                 if (q > maxq) maxq = q;
                 LSYNC();
+                PH(17);   // (development: the crash start's first batch on its own)
             }
             bool fresh = !warm && nfast == 0;   // primal == x(lambda) with refined lambda
             int since_sync = 0;

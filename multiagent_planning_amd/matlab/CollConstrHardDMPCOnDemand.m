@@ -1,15 +1,19 @@
 function [Ain_total, bin_total] = CollConstrHardDMPCOnDemand(p,po,vo,n,k,l,rmin,Ain,A_initp,E1,E2,order,violation)
 % Shadows dmpc/matlab/CollConstrHardDMPCOnDemand.m (same signature): rows for the neighbours flagged in `violation` only; the reference
 % preallocates sum(violation) rows (the flag of agent n itself, if set, leaves one of them zero) -- reproduced.
-assert(order == 2, 'only order = 2 is supported');
+assert(order == 2 || order == 4, 'ellipsoid order 2 or 4');   % (order 4: an all-neighbour context carries it, the dense rows are generic in it)
 N = size(l,3);
 v = logical(violation(:))';
 sel = find(v) - 1; sel = sel(sel ~= n-1);
 a0 = A_initp(3*(k-1)+1:3*k,:)*[po(:); vo(:)];
-prm = dmpc_params_struct(4, 0.2, size(l,2), rmin, [-1 -1 0], [1 1 1], 1, 1000, 100, E1, order, -5e4);   % context only
+prm = dmpc_params_struct(vsel(order, 4), 0.2, size(l,2), rmin, [-1 -1 0], [1 1 1], 1, 1000, 100, E1, order, -5e4);   % context only
 Ain_total = zeros(nnz(v), size(Ain,2)); bin_total = zeros(nnz(v),1);
 if ~isempty(sel)
     [A1, b1] = dmpc_mex('coll_rows', prm, l, sel, k-1, k-1, p(:), a0, rmin, 1/E1(3,3), Ain);
     Ain_total(1:numel(sel),:) = A1; bin_total(1:numel(sel)) = b1;
 end
+end
+function v = vsel(order, v2)
+% the context's variant: an order-4 context is one of an all-neighbour variant (5 = solveEllipDMPC)
+if order == 4, v = 5; else, v = v2; end
 end

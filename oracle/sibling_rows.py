@@ -11,9 +11,10 @@ tests/test_oracle_golden.py.
 import numpy as np
 
 
-def _geom(p, pj, E1, E2):
-    dist = np.linalg.norm(E1 @ (p - pj), 2)
-    diff = (E2 @ (p - pj))            # row vector diff
+def _geom(p, pj, E1, E2, order=2):
+    """dist = norm(E1*(p-pj),order); diff = (E2*(p-pj).^(order-1))'  (`.^` binds tighter than `*`); order 2 or 4"""
+    dist = np.linalg.norm(E1 @ (p - pj), order)
+    diff = E2 @ ((p - pj) ** (order - 1))
     return dist, diff
 
 
@@ -43,7 +44,6 @@ def CollConstrEllipDMPC_order(p, po, vo, n, k, l, rmin, Ain, A_initp, E1, E2, or
 
 
 def CollConstr(p, po, k, l, Ain, rmin, E1, E2, order=2):
-    assert order == 2
     p, po = np.ravel(p).astype(float), np.ravel(po).astype(float)
     l = np.asarray(l, float)
     N_obs = l.shape[2] if l.size else 0
@@ -51,15 +51,16 @@ def CollConstr(p, po, k, l, Ain, rmin, E1, E2, order=2):
     for i in range(N_obs):
         pj = l[:, :, i]
         K = pj.shape[1]
-        dist, diff = _geom(p, pj[:, k - 1], E1, E2)
-        r = dist * (rmin - dist + diff @ p / dist) - diff @ po
+        dist, diff = _geom(p, pj[:, k - 1], E1, E2, order)
+        pd = dist ** (order - 1)
+        r = pd * (rmin - dist + diff @ p / pd) - diff @ po
         diff_mat = np.r_[np.zeros(3 * (k - 2)), diff, np.zeros(3 * (K - (k - 1)))]
         Ain_total[i] = -diff_mat @ Ain
         bin_total[i] = -r
     return Ain_total, bin_total
 
 
-def _dmpc(p, po, vo, n, k, l, rmin, Ain, A_initp, E1, E2, sel_fn, nrows, k_ctr, dist_lt=None):
+def _dmpc(p, po, vo, n, k, l, rmin, Ain, A_initp, E1, E2, sel_fn, nrows, k_ctr, dist_lt=None, order=2):
     p, po, vo = (np.ravel(x).astype(float) for x in (p, po, vo))
     l = np.asarray(l, float)
     N_obs, K = l.shape[2], l.shape[1]
@@ -68,48 +69,48 @@ def _dmpc(p, po, vo, n, k, l, rmin, Ain, A_initp, E1, E2, sel_fn, nrows, k_ctr, 
     for i in range(1, N_obs + 1):
         if i != n and sel_fn(i):
             pj = l[:, :, i - 1]
-            dist, diff = _geom(p, pj[:, k - 1], E1, E2)
+            dist, diff = _geom(p, pj[:, k - 1], E1, E2, order)
             if dist_lt is not None and not dist < dist_lt:
                 continue
-            r = dist * (rmin - dist + diff @ p / dist) - diff @ A_initp[3 * (k_ctr - 1):3 * k_ctr, :] @ np.r_[po, vo]
+            pd = dist ** (order - 1)
+            r = pd * (rmin - dist + diff @ p / pd) - diff @ A_initp[3 * (k_ctr - 1):3 * k_ctr, :] @ np.r_[po, vo]
             diff_mat = np.r_[np.zeros(3 * (k_ctr - 1)), diff, np.zeros(3 * (K - k_ctr))]
             if idx >= Ain_total.shape[0]:
                 Ain_total = np.vstack([Ain_total, np.zeros((1, 3 * K))]); bin_total = np.vstack([bin_total, [[0.0]]])
                 prev_dist = np.vstack([prev_dist, [[0.0]]])
             Ain_total[idx] = -diff_mat @ Ain
             bin_total[idx] = -r
-            prev_dist[idx] = dist
+            prev_dist[idx] = pd
             idx += 1
     return Ain_total, bin_total, prev_dist
 
 
 def CollConstrSoftDMPC(p, po, vo, n, k, l, rmin, Ain, A_initp, E1, E2, order, violation):
     v = np.ravel(violation).astype(bool)
-    return _dmpc(p, po, vo, n, k, l, rmin, Ain, A_initp, E1, E2, lambda i: v[i - 1], int(v.sum()), k)
+    return _dmpc(p, po, vo, n, k, l, rmin, Ain, A_initp, E1, E2, lambda i: v[i - 1], int(v.sum()), k, order=order)
 
 
 def CollConstrSoftDMPC2(p, po, vo, n, k, l, rmin, Ain, A_initp, E1, E2, order, violation):
     v = np.ravel(violation).astype(bool)
-    return _dmpc(p, po, vo, n, k, l, rmin, Ain, A_initp, E1, E2, lambda i: v[i - 1], int(v.sum()), k - 1)
+    return _dmpc(p, po, vo, n, k, l, rmin, Ain, A_initp, E1, E2, lambda i: v[i - 1], int(v.sum()), k - 1, order=order)
 
 
 def CollConstrHardDMPCOnDemand(p, po, vo, n, k, l, rmin, Ain, A_initp, E1, E2, order, violation):
     v = np.ravel(violation).astype(bool)
-    return _dmpc(p, po, vo, n, k, l, rmin, Ain, A_initp, E1, E2, lambda i: v[i - 1], int(v.sum()), k)[:2]
+    return _dmpc(p, po, vo, n, k, l, rmin, Ain, A_initp, E1, E2, lambda i: v[i - 1], int(v.sum()), k, order=order)[:2]
 
 
 def CollConstrHardDMPC(p, po, vo, n, k, l, rmin, Ain, A_initp, E1, E2, order):
     N_obs = np.asarray(l).shape[2]
-    return _dmpc(p, po, vo, n, k, l, rmin, Ain, A_initp, E1, E2, lambda i: True, N_obs - 1, k, dist_lt=1.0)[:2]
+    return _dmpc(p, po, vo, n, k, l, rmin, Ain, A_initp, E1, E2, lambda i: True, N_obs - 1, k, dist_lt=1.0, order=order)[:2]
 
 
 def CollConstrEllipDMPC(p, po, vo, n, k, l, rmin, Ain, A_initp, E1, E2, order):
     N_obs = np.asarray(l).shape[2]
-    return _dmpc(p, po, vo, n, k, l, rmin, Ain, A_initp, E1, E2, lambda i: True, N_obs - 1, k)
+    return _dmpc(p, po, vo, n, k, l, rmin, Ain, A_initp, E1, E2, lambda i: True, N_obs - 1, k, order=order)
 
 
 def AddCollConstr(p, po, K, rmin, A, E1, E2, order=2):
-    assert order == 2
     p = np.asarray(p, float); po = np.asarray(po, float).reshape(-1, 3)
     N = p.shape[2]
     Ain_total = np.zeros((K * N * (N - 1) // 2, A.shape[1])); bin_total = np.zeros((K * N * (N - 1) // 2, 1))
@@ -118,9 +119,9 @@ def AddCollConstr(p, po, K, rmin, A, E1, E2, order=2):
         for j in range(i + 1, N):
             for k in range(K):
                 d = p[:, k, i] - p[:, k, j]
-                dist = np.linalg.norm(E1 @ d, 2)
-                diff = E2 @ d
-                r = dist * (rmin - dist) + diff @ d - diff @ (po[i] - po[j])
+                dist = np.linalg.norm(E1 @ d, order)
+                diff = E2 @ (d ** (order - 1))
+                r = dist ** (order - 1) * (rmin - dist) + diff @ d - diff @ (po[i] - po[j])
                 diff_mat = np.zeros(3 * K * N)
                 diff_mat[3 * K * i + 3 * k:3 * K * i + 3 * k + 3] = diff
                 diff_mat[3 * K * j + 3 * k:3 * K * j + 3 * k + 3] = -diff

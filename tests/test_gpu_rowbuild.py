@@ -13,6 +13,7 @@ pytestmark = pytest.mark.gpu
 
 C_ = 2.0
 E1 = np.diag([1, 1, 1 / C_]); E2 = np.diag([1, 1, 1 / C_ ** 2])
+E2_4 = np.diag([1, 1, 1 / C_ ** 4])       # order 4: E2 = E^-4 (test/comp_test_ellipconstr.m:160-163)
 
 
 def _scene(rng, N, K):
@@ -41,8 +42,17 @@ def test_CollConstr_dec_iSCP():
         assert np.array_equal(got_f[0], got[0])
     e = api.CollConstr(np.zeros(3), np.zeros(3), 2, np.zeros((3, K, 0)), A, 0.5, E1, E2, 2)
     assert e[0].shape == (0, 3 * K) and e[1].shape == (0, 1)
+    # the super-ellipsoid of order 4 (round 5: the dense builders take the order of their context): dist = |E1 d|_4, diff = E2 d.^3
+    for k in (2, 7, 20):
+        p, po = rng.uniform(-2, 2, 3), rng.uniform(-2, 2, 3)
+        got = api.CollConstr(p, po, k, l, A, 0.5, E1, E2_4, 4)
+        ref = SR.CollConstr(p, po, k, l, A, 0.5, E1, E2_4, 4)
+        _close(got[0], ref[0]); _close(got[1], ref[1])
+        assert not np.allclose(got[0], api.CollConstr(p, po, k, l, A, 0.5, E1, E2, 2)[0])
     with pytest.raises(NotImplementedError):
-        api.CollConstr(np.zeros(3), np.zeros(3), 2, l, A, 0.5, E1, E2, 4)
+        api.CollConstr(np.zeros(3), np.zeros(3), 2, l, A, 0.5, E1, E2, 3)
+    with pytest.raises(NotImplementedError):
+        api.CollConstr(np.zeros(3), np.zeros(3), 2, l, A, 0.5, E1, E2, 4)      # E2 must be E1^order
 
 
 def test_CollConstr_dmpc_family():
@@ -65,6 +75,13 @@ def test_CollConstr_dmpc_family():
         for name in ("CollConstrHardDMPC", "CollConstrEllipDMPC"):
             got = getattr(api, name)(p, po, vo, n, k, l, 0.35, Lam, A0, E1, E2, 2)
             ref = getattr(SR, name)(p, po, vo, n, k, l, 0.35, Lam, A0, E1, E2, 2)
+            assert len(got) == len(ref)
+            for g, r in zip(got, ref):
+                _close(g, r)
+        # order 4 (CollConstrSoftDMPC.m:16-21 is generic in `order`; prev_dist = dist^3)
+        for name, extra in (("CollConstrSoftDMPC", (viol,)), ("CollConstrEllipDMPC", ()), ("CollConstrHardDMPC", ())):
+            got = getattr(api, name)(p, po, vo, n, k, l, 0.35, Lam, A0, E1, E2_4, 4, *extra)
+            ref = getattr(SR, name)(p, po, vo, n, k, l, 0.35, Lam, A0, E1, E2_4, 4, *extra)
             assert len(got) == len(ref)
             for g, r in zip(got, ref):
                 _close(g, r)
@@ -119,6 +136,16 @@ def test_AddCollConstr_cup_SCP():
             for layout in "CFS":
                 Ain, b = d.add_coll_constr(np.ascontiguousarray(p.transpose(2, 1, 0)), po, 0.4, C_, Aop, out_order=layout)
                 _close(Ain, ref[0]); _close(b[:, None], ref[1])
+    # ... and each of them for the super-ellipsoid of order 4 (the order is the context's: an order-4 context of an all-neighbour variant)
+    d4 = mp.Dmpc("ellip", order=4)
+    for N, K in ((5, 7),):
+        p = _scene(rng, N, K); po = rng.uniform(-2, 2, (N, 3))
+        A = rng.normal(size=(3 * K * N, 3 * K * N + 3))
+        ref = SR.AddCollConstr(p, po, K, 0.4, A, E1, E2_4, 4)
+        _close(api.AddCollConstr(p, po.T.reshape(1, 3, N), K, 0.4, A, E1, E2_4, 4)[0], ref[0])
+        for layout in "CFS":
+            Ain, b = d4.add_coll_constr(np.ascontiguousarray(p.transpose(2, 1, 0)), po, 0.4, C_, A, out_order=layout)
+            _close(Ain, ref[0]); _close(b[:, None], ref[1])
     N, K = 4, 6
     p = _scene(rng, N, K); po = rng.uniform(-2, 2, (N, 3))
     A = rng.normal(size=(3 * K * N, 3 * K * N + 7))

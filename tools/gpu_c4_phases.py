@@ -23,7 +23,7 @@ if pick_top:   # (round 4) the agents with the most iterations of this step
     gids = [int(g) for g in np.argsort(o_["info"][0, :, 4])[-5:][::-1]]
 L = _lib.load()
 L.dmpc_debug_trace.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
-names = ["pivot scan", "descriptor", "T T's / crash round", "resid+dir", "append/other", "drops", "verify", "ladder", "setup", "-", "-", "-", "-", "s", "T's", "ratio", "step+certs"]
+names = ["pivot scan", "descriptor", "T T's / crash round", "resid+dir", "append/other", "drops", "verify", "ladder", "setup", "-", "-", "-", "-", "s", "T's", "ratio", "step+certs", "crash batch"]
 cap = 8
 tots = np.zeros(20); nag = 0
 for g in gids:
@@ -34,13 +34,13 @@ for g in gids:
         L.dmpc_debug_trace(d._ctx, g, cap, buf.ctypes.data_as(C.c_void_p))
     ph = buf.ravel()[(cap - 3) * 8:(cap - 3) * 8 + 20]
     i = out["info"][0, g]
-    use = [0, 1, 2, 3, 4, 5, 6, 7, 8, 13, 14, 15, 16]
+    use = [0, 1, 2, 3, 4, 5, 6, 7, 8, 13, 14, 15, 16, 17]
     tot = ph[use].sum()
     if tot <= 0: print("agent", g, "not traced (status", out["status"][0, g], ")"); continue
     tots += ph; nag += 1
     print(f"agent {g} status {out['status'][0, g]} rows {i[1]} tries {i[2]} iters {i[4]} maxq {i[7]}: total {tot/100:.0f} us; verifications {ph[10]:.0f} drops {ph[11]:.0f} certs {ph[12]:.0f}")
     print("   " + "  ".join(f"{names[u]} {ph[u]/tot*100:.0f}%" for u in use if ph[u] > 0))
 if nag:
-    use = [0, 1, 2, 3, 4, 5, 6, 7, 8, 13, 14, 15, 16]
+    use = [0, 1, 2, 3, 4, 5, 6, 7, 8, 13, 14, 15, 16, 17]
     tot = tots[use].sum()
     print(f"mean of {nag} agents: {tot/nag/100:.0f} us; " + "  ".join(f"{names[u]} {tots[u]/tot*100:.0f}%" for u in use if tots[u] > 0))
