@@ -71,7 +71,8 @@ def load():
     L = C.CDLL(LIB_PATH)
     # the header revision these bindings were written against (DMPC_ABI_VERSION: the special device values DEVICE_ALL / DEVICE_CURRENT below
     # changed once between revisions): refuse another library instead of passing it values that mean something else there
-    if not hasattr(L, "dmpc_abi_version") or L.dmpc_abi_version() != ABI_VERSION:
+    # (DMPC_SKIP_ABI_CHECK=1: development A/B runs against an older build of the library, tools/with_lib.py)
+    if not os.environ.get("DMPC_SKIP_ABI_CHECK") and (not hasattr(L, "dmpc_abi_version") or L.dmpc_abi_version() != ABI_VERSION):
         raise DmpcError(f"{LIB_PATH}: ABI revision {L.dmpc_abi_version() if hasattr(L, 'dmpc_abi_version') else '< 5'}, these bindings need {ABI_VERSION}: rebuild the library")
     dp, ip, vp = C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_void_p
     pp = C.POINTER(DmpcParams)
