@@ -133,14 +133,23 @@ __device__ __forceinline__ double wave_max0(double v)   // v >= 0 on every lane
     return readlane_d(v, 63);
 }
 
+// wave-uniform by construction, not by what the compiler can see (a value read from LDS or global memory at a uniform address, the result
+// of an out-of-line function): say so -- everything derived from it is then scalar, branches on it are scalar branches
+#define UNI(x_) __builtin_amdgcn_readfirstlane(x_)
+__device__ __forceinline__ bool uni_b(bool b) { return __builtin_amdgcn_readfirstlane((int)b) != 0; }
+
 // uniform description of one constraint
 struct Cd {
     int ty, idx, gi, si;     // type, index (component or row), Gram index (space, step), slack row (-1: none)
     double v0, v1, v2, ss, d;
 };
 
+typedef __attribute__((address_space(3))) double LdsD;
 // y = T' x  (lane j gets y_j; 0 for j >= q).  x is the LDS vector at offset XOFF (zero beyond q).  Groups of 8 with one
 // lane mask per group; two FMA chains per group (half the dependent latency).
+// (round 5: the group loop fully unrolled with a scalar exit per group -- every LDS offset of a group is then an immediate of its
+// ds_read; the rolled loop carried 6 scalar induction variables and 7 vector address additions per group of T x, a third of its
+// instructions.  Same sums in the same order: bit-identical.)
 template <int QCAP, int TOFF, int XOFF, int TS = QCAP, typename TF = double>
 __device__ __forceinline__ double t_tmul2(const double *B, int lane, int q, const int xo = 0)
 {
@@ -148,8 +157,15 @@ __device__ __forceinline__ double t_tmul2(const double *B, int lane, int q, cons
     const int qlim = (TS < QCAP && xo == 0) ? TS : QCAP;   // (no extension held: q <= TS, the lanes beyond read column TS-1, masked)
     const int jc = lane < qlim ? lane : qlim - 1;
     const TF *col = (const TF *)(B + TOFF) + tcol(jc) + ((TS < QCAP && jc >= TS) ? xo : 0);
-    const double *xs = B + XOFF;
-    for (int i0 = 0; i0 < q; i0 += 8) {
+    // (x through ONE vector register with immediate offsets, the group masks compared on the spot: as wave-uniform / loop-invariant values
+    // the compiler computed every address and every mask once per solve, kept them in scalar registers, spilled those to vector lanes and
+    // read them back in front of each use -- three instructions where one does)
+    const LdsD *xs = (const LdsD *)(B + XOFF);
+    asm volatile("" : "+v"(xs));
+    asm volatile("" : "+v"(lane));
+#pragma unroll
+    for (int i0 = 0; i0 < QCAP; i0 += 8) {
+        if (i0 >= q) break;
         double t[8], x[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) { t[u] = (double)col[i0 + u]; x[u] = xs[i0 + u]; }
@@ -167,30 +183,22 @@ __device__ __forceinline__ double t_mul2(const double *B, int lane, int q, const
 {
     double acc = 0.0;
     const TF *row = (const TF *)(B + TOFF) + lane;
-    const double *xs = B + XOFF;
-    const int q0 = (TS < QCAP && q > TS) ? TS : q;
-    for (int j0 = 0; j0 < q0; j0 += 8) {
+    const TF *rowx = row + xo;   // the column groups of the extension (split T; the same sums in the same order)
+    const LdsD *xs = (const LdsD *)(B + XOFF);
+    asm volatile("" : "+v"(xs));
+    asm volatile("" : "+v"(lane));
+#pragma unroll
+    for (int j0 = 0; j0 < QCAP; j0 += 8) {
+        if (j0 >= q) break;
+        const TF *rw = (TS < QCAP && j0 >= TS) ? rowx : row;
         double t[8], x[8];
         const int c0 = tcol(j0), len = j0 + 9;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { t[u] = (double)row[c0 + u * len]; x[u] = xs[j0 + u]; }
+        for (int u = 0; u < 8; ++u) { t[u] = (double)rw[c0 + u * len]; x[u] = xs[j0 + u]; }
         double s0 = t[0] * x[0], s1 = t[1] * x[1];
 #pragma unroll
         for (int u = 2; u < 8; u += 2) { s0 = fma(t[u], x[u], s0); s1 = fma(t[u + 1], x[u + 1], s1); }
         acc += (lane < j0 + 8) ? (s0 + s1) : 0.0;
-    }
-    if (TS < QCAP) {   // the column groups of the extension (the same sums in the same order)
-        const TF *rowx = row + xo;
-        for (int j0 = TS; j0 < q; j0 += 8) {
-            double t[8], x[8];
-            const int c0 = tcol(j0), len = j0 + 9;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { t[u] = (double)rowx[c0 + u * len]; x[u] = xs[j0 + u]; }
-            double s0 = t[0] * x[0], s1 = t[1] * x[1];
-#pragma unroll
-            for (int u = 2; u < 8; u += 2) { s0 = fma(t[u], x[u], s0); s1 = fma(t[u + 1], x[u + 1], s1); }
-            acc += (lane < j0 + 8) ? (s0 + s1) : 0.0;
-        }
     }
     return (lane < q) ? acc : 0.0;
 }
@@ -302,7 +310,6 @@ __device__ __forceinline__ void remove_slot2(double *B, int lane, int &q, int l,
 // round they were the largest single piece of the solve launch.)
 // Returns the new slot count, the calling lane's updated slot record and flags: bit 0 the factor is still the table's, bit 1 stop the
 // crash (dependent pivot: guard only), bit 2 this call used the table, bits 8.. bounds appended (0: nothing was violated).
-typedef __attribute__((address_space(3))) double LdsD;
 struct CrashRes { int q; unsigned cslot; int flags; };
 template <bool SOFT, int QCAP, bool PERSIST, typename TF = double, int TS = QCAP>
 __device__ __attribute__((noinline)) CrashRes crash_append(LdsD *Bl, const LdsD *Gl, const double *tpg, const int lane, const int q, unsigned cslot,
@@ -589,8 +596,10 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
     // instead of a chain of four -- header flag, state, row count, rows.  Rows addressed without the count, i.e. reads of
     // scratch the scan never wrote, were measured slower: those lines come cold from HBM and the whole set-up waits for them.)
     struct { int x, y, z, w; } h0, h1;   // the scan's hand-off header: 8 ints
-    h0.x = hdr[0]; h0.y = hdr[1]; h0.z = hdr[2]; h0.w = hdr[3]; h1.x = hdr[4]; h1.y = hdr[5]; h1.z = hdr[6]; h1.w = hdr[7];
-    const int stq = P.only_flagged ? P.status[gid] : ST_QOVER;
+    // (readfirstlane: the header is read with vector loads -- the scan wrote it in this launch's lifetime, no scalar load -- and everything
+    // derived from it, the row count, the status word, the ladder start, would be compiled as lane-dependent: masked loops, vector compares)
+    h0.x = UNI(hdr[0]); h0.y = UNI(hdr[1]); h0.z = UNI(hdr[2]); h0.w = UNI(hdr[3]); h1.x = UNI(hdr[4]); h1.y = UNI(hdr[5]); h1.z = UNI(hdr[6]); h1.w = UNI(hdr[7]);
+    const int stq = P.only_flagged ? UNI(P.status[gid]) : ST_QOVER;
     double po[3], vo[3], ao[3], pf[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
@@ -633,7 +642,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
     }
 
     // ---------------------------------------------------------------- cost case + tables (a7, :43-58)
-    const int ccase = cost_case(var, po[0] - pf[0], po[1] - pf[1], po[2] - pf[2], rows_exist);
+    const int ccase = UNI(cost_case(var, po[0] - pf[0], po[1] - pf[1], po[2] - pf[2], rows_exist));   // (the state comes through vector loads: the table base of every Gram lookup would be per-lane arithmetic)
     const double qw = ccase == 0 ? P.Qfar : (ccase == 1 ? P.Qnear : P.Q1);
     const double sw = ccase == 2 ? ((var == VAR_ALL3) ? 10.0 : P.S1) : P.Sfree;
     const double *G, *Lt;
@@ -754,6 +763,9 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
     const bool ph_on = P.dbg && gid == P.dbg_agent;
 #define PH(i_) do { const long long t__ = __builtin_amdgcn_s_memtime(); if (ph_on) phv[i_] += t__ - ph_last; ph_last = t__; } while (0)
 #define PHC(i_) do { if (ph_on) phv[i_] += 1; } while (0)
+#elif defined(DMPC_ISA_MARK)   // development (tools/isa_stats.sh): phase boundaries as comments in the instruction stream
+#define PH(i_) asm volatile("; @@PH " #i_ ::: "memory")
+#define PHC(i_) do { } while (0)
 #else
 #define PH(i_) do { } while (0)
 #define PHC(i_) do { } while (0)
@@ -962,7 +974,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
             // delete slot l from the working set, with the bookkeeping of its kind; the pin of a soft row whose collision row just
             // left the set is de-instantiated with it (not for row `keep_row`: the entering constraint's own row)
             auto drop_slot = [&](int l, int keep_row) {
-                const int dmeta = s_meta[l];
+                const int dmeta = UNI(s_meta[l]);
                 const int dty = (dmeta >> 8) & 0xff, didx = dmeta >> 16;
                 LSYNC();
                 if (dty >= TY_COLL) {
@@ -974,7 +986,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                 }
                 remove_slot2<SOFT, QCAP, PERSIST, TS, TF>(B, lane, q, l, cslot, cm, xo, m_row, nrmax);
                 if (soft && dty == TY_COLL && didx != keep_row) {
-                    const int fl = r_fl[didx];
+                    const int fl = UNI((int)r_fl[didx]);
                     if ((fl & RF_LIVE) && (fl & RF_SLKU) && !(fl & RF_SLKL)) {
                         const int mm = (lane < q) ? s_meta[lane] : 0;
                         const unsigned long long um = __ballot(lane < q && ((mm >> 8) & 0xff) == TY_SLKU && (mm >> 16) == didx);
@@ -994,7 +1006,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
             if (SOFT && ladder && violation && !cert_known && !hp && nr > 38 && q == 0) {
                 constexpr int CP = (t_doubles(TS) * (int)sizeof(TF) / 8) / 4 < 134 ? (t_doubles(TS) * (int)sizeof(TF) / 8) / 4 : 134;
                 cost += 176;
-                pre_inf = ladder_level_infeasible(r_xi, r_b, r_sd, r_slb, r_kc, nr, B + SL::T, P.h, P.alim, 1.0, whi_l, wlo_l, lane, CP);
+                pre_inf = uni_b(ladder_level_infeasible(r_xi, r_b, r_sd, r_slb, r_kc, nr, B + SL::T, P.h, P.alim, 1.0, whi_l, wlo_l, lane, CP));
                 LSYNC();
                 for (int i = lane; i < 4 * ((nr < CP - 6 ? nr : CP - 6) + 6); i += 64) B[SL::T + i] = 0.0;
                 LSYNC();
@@ -1010,15 +1022,16 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                 while (q < (QCAP - 4 < 44 ? QCAP - 4 : 44)) {
                     const CrashRes cr = crash_append<SOFT, QCAP, PERSIST, TF, TS>((LdsD *)B, (const LdsD *)G, P.tables + TAB_DOUBLES + (size_t)ccase * 2 * TAB_TP_CASE,
                                                                           lane, q, cslot, a, P.alim, tol, tbl_ok);
-                    const int nb = cr.flags >> 8;
-                    if (cr.flags & 2) crash_stop = true;
+                    const int crf = UNI(cr.flags);   // (an out-of-line function returns in vector registers: the slot count would be lane-dependent from here on)
+                    const int nb = crf >> 8;
+                    if (crf & 2) crash_stop = true;
                     if (nb == 0) break;
                     iters += nb; nfast += nb;
 #ifdef DMPC_DEV_TRACE
-                    if (cr.flags & 4) dev_tbl += nb; else dev_gen += nb;
+                    if (crf & 4) dev_tbl += nb; else dev_gen += nb;
 #endif
-                    q = cr.q; cslot = cr.cslot;
-                    tbl_ok = (cr.flags & 1) != 0;
+                    q = UNI(cr.q); cslot = cr.cslot;
+                    tbl_ok = (crf & 1) != 0;
                     if (crash_stop) break;
                 }
                 if (q > maxq) maxq = q;
@@ -1043,7 +1056,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                     PH(4); PHC(12);
                     cost += 176;   // (44 us a call)
                     static_assert(!SOFT || (SL::XS == SL::RR + 64 && SL::NU == SL::XS + 64), "the three staging vectors are one block of 176 doubles");
-                    const bool cert_inf = ladder_level_infeasible(r_xi, r_b, r_sd, r_slb, r_kc, nr, B + SL::RR, P.h, P.alim, 1.0, whi_l, wlo_l, lane, 44);   // (RR | XS | NU are dead between two iterations: 38 rows of a step)
+                    const bool cert_inf = uni_b(ladder_level_infeasible(r_xi, r_b, r_sd, r_slb, r_kc, nr, B + SL::RR, P.h, P.alim, 1.0, whi_l, wlo_l, lane, 44));   // (RR | XS | NU are dead between two iterations: 38 rows of a step)
                     PH(7);
                     if (cert_inf) { rc = 1; break; }
                 }
@@ -1212,7 +1225,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                     } else p = slack_desc(pty, pidx);
                 }
                 // lazily instantiate the eps<=0 pin of a soft row that becomes active (S(u,u) = 1/2)
-                if (soft && !hp && p.ty == TY_COLL && !(r_fl[p.idx] & RF_LIVE)) {
+                if (soft && !hp && p.ty == TY_COLL && !(UNI((int)r_fl[p.idx]) & RF_LIVE)) {
                     if (q >= QCAP - 1) { rc = 2; break; }
                     const Cd u = slack_desc(TY_SLKU, p.idx);
                     ENSURE_EXT(q);
@@ -1295,7 +1308,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                             if (s2 != 0xff) nue -= B[SL::RR + s2] * B[SL::SSS + s2];
                             owner = lane == s0;
                         }
-                        if (p.si >= 0) p_row_has_slot = (m_row[p.si] & m_row[nrmax + p.si] & m_row[2 * nrmax + p.si]) != 0xff;
+                        if (p.si >= 0) p_row_has_slot = (UNI((int)(m_row[p.si] & m_row[nrmax + p.si] & m_row[2 * nrmax + p.si])) & 0xff) != 0xff;
                         if (owner) part += 0.5 * nue * nue;
                         if (p.si >= 0 && !p_row_has_slot && lane == 63) part += 0.5 * p.ss * p.ss;
                     }
@@ -1416,7 +1429,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                 if (rc) break;
                 if (SOFT && resync) continue;
                 // pin added while its collision row is not active: decoupled again -> drop both
-                if (soft && p.ty == TY_SLKU && !(r_fl[p.idx] & (RF_COLL | RF_SLKL))) {
+                if (soft && p.ty == TY_SLKU && !(UNI((int)r_fl[p.idx]) & (RF_COLL | RF_SLKL))) {
                     const int mm = (lane < q) ? s_meta[lane] : 0;
                     const unsigned long long um = __ballot(lane < q && ((mm >> 8) & 0xff) == TY_SLKU && (mm >> 16) == p.idx);
                     const int ul = __ffsll((long long)um) - 1;
@@ -1474,7 +1487,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                 const int cert_used = 4 * ((nr < CERT_PLANES - 6 ? nr : CERT_PLANES - 6) + 6);
                 while (tries < max_tries - 1) {
                     if (lev_skip > 0) { --lev_skip; f *= 2.0; ++tries; continue; }   // (infeasible by the proof the failed solve ended with)
-                    if (!ladder_level_infeasible(r_xi, r_b, r_sd, r_slb, r_kc, nr, B + SL::T, P.h, P.alim, f, whi_l, wlo_l, lane, CERT_PLANES)) { cert_known = true; break; }
+                    if (!uni_b(ladder_level_infeasible(r_xi, r_b, r_sd, r_slb, r_kc, nr, B + SL::T, P.h, P.alim, f, whi_l, wlo_l, lane, CERT_PLANES))) { cert_known = true; break; }
                     f *= 2.0; ++tries;
                 }
                 lev_skip = 0;
