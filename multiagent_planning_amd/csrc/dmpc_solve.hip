@@ -628,17 +628,17 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
 #define DMPC_HARD_RC 2
 #endif
     constexpr int RC = soft ? 1 : DMPC_HARD_RC;   // register cache of the first collision rows (RC per lane; the rest is streamed from the L2-resident scratch)
-    double rcx0[2], rcx1[2], rcx2[2], rcb[2], rcsd[2], rcslb[2];
+    double rcx0[2], rcx1[2], rcx2[2], rcb[2], rcsd[2], rcslb[2], rcst[2];   // (rcst: the slack's linear cost -- read by every re-derivation of the iterate, a global round trip each until round 5)
     float rcw[2];
     int rckc[2];
-    rcx0[1] = rcx1[1] = rcx2[1] = rcb[1] = rcsd[1] = rcslb[1] = 0.0; rcw[1] = 0.f; rckc[1] = 0;
+    rcx0[1] = rcx1[1] = rcx2[1] = rcb[1] = rcsd[1] = rcslb[1] = rcst[1] = 0.0; rcw[1] = 0.f; rckc[1] = 0;
 #pragma unroll
     for (int c = 0; c < RC; ++c) {
         const int i = lane + 64 * c;
         const int ii = i < nr ? i : 0;
         rcx0[c] = r_xi[3 * ii]; rcx1[c] = r_xi[3 * ii + 1]; rcx2[c] = r_xi[3 * ii + 2];
         rcb[c] = r_b[ii]; rckc[c] = r_kc[ii];
-        rcsd[c] = soft ? r_sd[ii] : 0.0; rcslb[c] = soft ? r_slb[ii] : 0.0;
+        rcsd[c] = soft ? r_sd[ii] : 0.0; rcslb[c] = soft ? r_slb[ii] : 0.0; rcst[c] = soft ? r_st[ii] : 0.0;
     }
 
     // ---------------------------------------------------------------- cost case + tables (a7, :43-58)
@@ -781,7 +781,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
             const double f = ldexp(1.0, tries);
             scale_pow = tries;
             for (int i = lane; i < nr; i += 64) { r_slb[i] *= f; r_st[i] *= f; }
-            rcslb[0] *= f; rcslb[1] *= f;
+            rcslb[0] *= f; rcslb[1] *= f; rcst[0] *= f; rcst[1] *= f;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
@@ -943,7 +943,9 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                         if (s2 != 0xff) acc += B[SL::RR + s2] * B[SL::SSS + s2];
                         owner = lane == s0;
                     }
-                    if (owner) r_eps[myrow] = -0.5 * (r_st[myrow] + acc);
+                    // (the row's linear cost from the register of the lane that holds the row -- rows 0 .. 63 --, all lanes in the shuffle)
+                    double stv = __shfl(rcst[0], (mine && myrow < 64) ? myrow : 0);
+                    if (owner) { if (myrow >= 64) stv = r_st[myrow]; r_eps[myrow] = -0.5 * (stv + acc); }
                 }
                 LSYNC();
             };
@@ -1114,7 +1116,11 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                 PH(0);
                 if (wm == 0ull) {
                     PHC(10);
-                    if (!forced) CLAIM_NEXT();
+                    // (not inside the crash start: its scans look at the acceleration bounds only, and the first of them -- right after the table batch, at
+                    // the very BEGINNING of a solve -- finds nothing: until round 5 every agent with a crash start claimed its wave's next queue position
+                    // there, and that position then waited behind the whole solve: the queue degenerated to an assignment one agent ahead, measured
+                    // launch 880 us where list scheduling of the same durations in the same order gives 770)
+                    if (!forced && !crash) CLAIM_NEXT();
                     if (!crash && !forced && (q == 0 || fresh)) break;   // optimal
                     if (!crash && !soft && !F32T && !forced) {   // (fp32 factor: the incrementally updated iterate drifts by ~1e-7 per step -- always the full verification)
                         // (slack-free variants; the slack variants carry multipliers of 1e5-1e6 and always take the full verification)
@@ -1232,7 +1238,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                     if (lane < ((q + 8) & ~7)) ((TF *)(B + SL::T))[tcol(q) + ((TS < QCAP && q >= TS) ? xo : 0) + lane] = (TF)((lane == q) ? 1.4142135623730951 : 0.0);
                     if (lane == 0) { r_fl[p.idx] |= (RF_LIVE | RF_SLKU); m_row[nrmax + p.idx] = (unsigned char)q; }
                     nlive++;
-                    write_slot(u, -r_st[p.idx]);
+                    write_slot(u, p.idx < 64 ? -readlane_d(rcst[0], p.idx) : -r_st[p.idx]);
                     q++;
                     LSYNC();
                 }
@@ -1494,7 +1500,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                 LSYNC();
                 for (int i = lane; i < cert_used; i += 64) B[SL::T + i] = 0.0;
                 for (int i = lane; i < nr; i += 64) { r_slb[i] *= f; r_st[i] *= f; }
-                rcslb[0] *= f; rcslb[1] *= f;
+                rcslb[0] *= f; rcslb[1] *= f; rcst[0] *= f; rcst[1] *= f;
                 scale_pow += ilogb(f);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
