@@ -130,6 +130,7 @@ struct dmpc_ctx {
     int lds_pad_kb = 0;      // development option lds_pad_kb: KB of unused LDS per one-agent solve workgroup (occupancy experiments: fewer resident agents per CU)
     int f32_dep_exp = 8;     // development option f32_dep_exp: fp32-factor kernels treat a pivot as dependent below delta / s_pp = 10^-n
     int ext_cap = 0;         // development option ext_cap (tests): at most this many T extensions per workgroup (1: every agent that needs one waits for the same slot)
+    int queue_chunk = 0;     // development option queue_chunk: positions per ticket of the persistent queue's light bulk (0: chosen per launch)
     int static_queue = 0;    // development option static_queue: persistent waves take queue positions round-robin instead of by ticket
     DevBuf pc_p, pc_v, pc_a, pc_M, pc_w, pc_scene, pc_agent, pc_interp;   // post-check work buffers
     DevBuf pc_pts, pc_cell, pc_fill, pc_start, pc_sorted, pc_on;           // post-check, large scenes: cell grid of a batch of samples
@@ -404,7 +405,7 @@ extern "C" int dmpc_debug_option(dmpc_ctx *ctx, const char *name, int value)
         {"no_fuse", &dmpc_ctx::no_fuse}, {"no_persist", &dmpc_ctx::no_persist}, {"force_persist", &dmpc_ctx::force_persist}, {"no_cull", &dmpc_ctx::no_cull}, {"order_slices", &dmpc_ctx::order_slices}, {"cull_min", &dmpc_ctx::cull_min},
         {"no_lpt", &dmpc_ctx::no_lpt}, {"order_hint", &dmpc_ctx::order_hint}, {"crash_min", &dmpc_ctx::crash_min}, {"crash_any", &dmpc_ctx::crash_any}, {"no_fast_exit", &dmpc_ctx::no_fast_exit}, {"pivot_explore", &dmpc_ctx::pivot_explore},
         {"iter_cap", &dmpc_ctx::iter_cap}, {"tier1_qcap", &dmpc_ctx::tier1_env}, {"split_parts", &dmpc_ctx::split_parts}, {"no_split", &dmpc_ctx::no_split},
-        {"static_queue", &dmpc_ctx::static_queue}, {"no_split_t", &dmpc_ctx::no_split_t}, {"ext_cap", &dmpc_ctx::ext_cap}, {"nbr_grid", &dmpc_ctx::nbr_grid}, {"f32_dep_exp", &dmpc_ctx::f32_dep_exp}, {"grid_min", &dmpc_ctx::grid_min}, {"no_level_check", &dmpc_ctx::no_level_check}, {"lds_pad_kb", &dmpc_ctx::lds_pad_kb}};
+        {"static_queue", &dmpc_ctx::static_queue}, {"queue_chunk", &dmpc_ctx::queue_chunk}, {"no_split_t", &dmpc_ctx::no_split_t}, {"ext_cap", &dmpc_ctx::ext_cap}, {"nbr_grid", &dmpc_ctx::nbr_grid}, {"f32_dep_exp", &dmpc_ctx::f32_dep_exp}, {"grid_min", &dmpc_ctx::grid_min}, {"no_level_check", &dmpc_ctx::no_level_check}, {"lds_pad_kb", &dmpc_ctx::lds_pad_kb}};
     for (auto &t : tab)
         if (!std::strcmp(t.n, name)) {
             ctx->*(t.f) = value;
@@ -943,6 +944,8 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
         P.lds_per_wave = (int)per;
         int wgs = (total + pw - 1) / pw;
         if (wgs > ctx->num_cu) wgs = ctx->num_cu;
+        // tickets of the queue's light bulk: single positions where a wave solves few, heavy agents (fewer than 12 per wave, or solveSoftDMPCall)
+        P.queue_chunk = ctx->queue_chunk > 0 ? ctx->queue_chunk : ((total < 12 * wgs * pw || ctx->prm.variant == DMPC_VAR_ALL3) ? 1 : 2);
         launch_persist(qcap, dim3((unsigned)wgs), dim3((unsigned)(64 * pw)), lds);
         return 0;
     };
@@ -1424,10 +1427,10 @@ static int transition_one(dmpc_ctx *ctx, int S, int N, const double *po, const d
 static void copy_debug_options(dmpc_ctx *dst, const dmpc_ctx *src)
 {
     static const char *names[] = {"no_fuse", "no_persist", "force_persist", "no_cull", "order_slices", "cull_min", "no_lpt", "crash_min", "crash_any", "no_fast_exit",
-                                  "pivot_explore", "iter_cap", "tier1_qcap", "static_queue", "no_split_t", "ext_cap", "nbr_grid", "f32_dep_exp", "grid_min", "no_level_check", "order_hint"};
+                                  "pivot_explore", "iter_cap", "tier1_qcap", "static_queue", "queue_chunk", "no_split_t", "ext_cap", "nbr_grid", "f32_dep_exp", "grid_min", "no_level_check", "order_hint"};
     int dmpc_ctx::*fields[] = {&dmpc_ctx::no_fuse, &dmpc_ctx::no_persist, &dmpc_ctx::force_persist, &dmpc_ctx::no_cull, &dmpc_ctx::order_slices, &dmpc_ctx::cull_min,
                                &dmpc_ctx::no_lpt, &dmpc_ctx::crash_min, &dmpc_ctx::crash_any, &dmpc_ctx::no_fast_exit, &dmpc_ctx::pivot_explore, &dmpc_ctx::iter_cap,
-                               &dmpc_ctx::tier1_env, &dmpc_ctx::static_queue, &dmpc_ctx::no_split_t, &dmpc_ctx::ext_cap, &dmpc_ctx::nbr_grid, &dmpc_ctx::f32_dep_exp, &dmpc_ctx::grid_min, &dmpc_ctx::no_level_check, &dmpc_ctx::order_hint};
+                               &dmpc_ctx::tier1_env, &dmpc_ctx::static_queue, &dmpc_ctx::queue_chunk, &dmpc_ctx::no_split_t, &dmpc_ctx::ext_cap, &dmpc_ctx::nbr_grid, &dmpc_ctx::f32_dep_exp, &dmpc_ctx::grid_min, &dmpc_ctx::no_level_check, &dmpc_ctx::order_hint};
     for (size_t i = 0; i < sizeof(names) / sizeof(names[0]); ++i) (void)dmpc_debug_option(dst, names[i], src->*(fields[i]));
 }
 

@@ -81,6 +81,7 @@ struct StepParams {
     const int *live_bound;  // persistent solve kernel: queue positions from *live_bound on hold agents the scan finished (order_kernel), or null
     int no_level_check;     // development option no_level_check: solveSoftDMPCall without the slack-free feasibility pass per ladder level (A/B runs, tests)
     double dep_tol_f32;     // fp32-factor kernels: dependence threshold on delta / s_pp (development option f32_dep_exp: 10^-n)
+    int queue_chunk;        // persistent solve kernel: adjacent queue positions a ticket of the light bulk stands for (1 or 2, launch_step)
     int n_ext;              // persistent solve kernel with a split T: extensions in the workgroup's pool (behind the waves' blocks)
     int *cost_out;          // [S*c_count] or null: work estimate of this agent's solve (quarter microseconds: iterations weighted by the working-set size,
                             // certificate calls) -- the NEXT step's launch order is built from it (order_kernel; dmpc_api.hip: order hint)

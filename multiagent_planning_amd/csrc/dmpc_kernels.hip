@@ -988,7 +988,10 @@ __global__ __launch_bounds__(SOFT ? 512 : DMPC_HARD_PW * 64, 1) void dmpc_solve_
     const int rest = total > nw ? total - nw : 0;
     const int T1 = rest < QUEUE_T1 * nw ? rest : QUEUE_T1 * nw;
     const int T3 = (rest - T1) < QUEUE_T3 * nw ? (rest - T1) : QUEUE_T3 * nw;
-    constexpr int CHUNK = QUEUE_CHUNK;
+    // (round 5: per launch -- two positions per ticket pay where the queue is deep and its agents light, the 512-scene replays: fewer atomics;
+    // in a shallow queue of heavy agents, the 10^4-agent scene at 5.6 agents per wave, the second position waits behind a solve that may turn
+    // out long and such positions ended the launch: 0.75 -> 0.71 ms with single positions)
+    const int CHUNK = P.queue_chunk > 0 ? P.queue_chunk : QUEUE_CHUNK;
     const int mid = rest - T1 - T3, T2 = (mid + CHUNK - 1) / CHUNK;
     // (Rounds 2-3 claimed the next ticket right BEFORE the current agent was solved -- the atomic's latency hides completely -- and the
     // positions parked behind long solves ended the launch late: waves ending 779-878 us.  Claiming two positions ahead -- the agent behind the next ticket resolved through the order during the solve, so that

@@ -183,7 +183,8 @@ def test_order_hint_is_pure_scheduling():
     kw = wl.solver_kwargs(cfg, N)
     po, pf = wl.make_scenes(cfg, S, N, wl.SEED0 + 41)
     base = _steps("bound", kw, po, pf, 3)
-    for opts in (dict(order_hint=1), dict(order_hint=2), dict(no_lpt=1)):
+    # (round 5: queue_chunk -- one or two queue positions per ticket of the persistent waves -- and static_queue are scheduling too)
+    for opts in (dict(order_hint=1), dict(order_hint=2), dict(no_lpt=1), dict(queue_chunk=1), dict(queue_chunk=2), dict(static_queue=1)):
         other = _steps("bound", kw, po, pf, 3, **opts)
         for a, b in zip(base, other):
             for k in ("status", "info", "p", "v", "a"):

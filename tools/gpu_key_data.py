@@ -1,0 +1,33 @@
+"""development (DEV_TRACE build: python tools/with_trace_lib.py tools/gpu_key_data.py): per agent and MPC step of the C4 closed loop (N = 10^4) the scan's feature word
+(dmpc_debug_trace -6) next to the MEASURED duration of its solve (-5, a second launch on the same state) -> gpurun_out/key_data.npz for tools/key_fit2.py."""
+import sys, os, ctypes as C
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import multiagent_planning_amd as mp
+from multiagent_planning_amd import workload as wl, _lib
+N = 10000
+cfg = wl.CONFIGS["C4"]; kw = wl.solver_kwargs(cfg, N)
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else wl.SEED0 + 4
+po, pf = wl.make_scenes(cfg, 1, N, seed)
+d = mp.Dmpc(cfg["variant"], **kw)
+l, _, _ = d.init_batch(po, pf)
+xp, xv, xa = po.copy(), np.zeros_like(po), np.zeros_like(po)
+L = _lib.load()
+L.dmpc_debug_trace.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+cap = N * 2 // 8 + 8
+infos, durs, plain = [], [], []
+for k in range(9):
+    assert L.dmpc_debug_trace(d._ctx, -5, cap, None) == 0
+    out = d.step_batch(l, xp, xv, xa, pf)
+    buf = np.zeros(cap * 8)
+    assert L.dmpc_debug_trace(d._ctx, -5, cap, buf.ctypes.data_as(C.c_void_p)) == 0
+    durs.append(buf[:N * 2].reshape(N, 2)[:, 1] * 1e-2); plain.append(out["info"][0].copy())
+    assert L.dmpc_debug_trace(d._ctx, -6, 8, None) == 0
+    out = d.step_batch(l, xp, xv, xa, pf)
+    infos.append(out["info"][0].copy())
+    st = out["status"][0]; ok = st == 1
+    l = np.where(ok[None, :, None], out["p"], l); xp = np.where(ok[None, :, None], out["p"][..., :3], xp)
+    xv = np.where(ok[None, :, None], out["v"][..., :3], xv); xa = np.where(ok[None, :, None], out["a"][..., :3], xa)
+os.makedirs("gpurun_out", exist_ok=True)
+np.savez_compressed(f"gpurun_out/key_data_{seed}.npz", info=np.array(infos), dur=np.array(durs), plain=np.array(plain))
+print("saved", np.array(durs).shape, "duration mean per step", np.round(np.array(durs).mean(axis=1), 1))
