@@ -349,7 +349,7 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
         L.r_kc = P.rowkc + (size_t)gid * nrmax;
     }
     int *hdr = P.hdr + (size_t)gid * 8;
-    if (P.scene_done && P.scene_done[scene]) {
+    if (P.scene_done && __builtin_amdgcn_readfirstlane(P.scene_done[scene])) {
         // the scene's transition is over (dmpc_transition): nothing to solve, the state stays frozen (status 0 = no update)
         if (lane == 0) { hdr[0] = 0; hdr[1] = 0; hdr[2] = 0; hdr[3] = 0; hdr[4] = 8; hdr[5] = 0; hdr[6] = 0; hdr[7] = 0; P.status[gid] = 0; }
         return;
@@ -398,7 +398,7 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
         int tot = 0;
         bool fits = true;
         for (int q = 0; q < NBR_PARTS; ++q) {
-            const int n = P.nbr_cnt[(size_t)gid * NBR_PARTS + q];
+            const int n = __builtin_amdgcn_readfirstlane(P.nbr_cnt[(size_t)gid * NBR_PARTS + q]);   // (a vector load of a wave-uniform value: the list length steers every loop of the walk)
             if (n < 0) { fits = false; break; }
             if (q > 0 && tot < q * pcap)
                 for (int i = lane; i < n; i += 64) lst[tot + i] = lst[q * pcap + i];   // moves down: a round's reads are at or above its writes

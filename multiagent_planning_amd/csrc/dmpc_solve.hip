@@ -150,7 +150,7 @@ typedef __attribute__((address_space(3))) double LdsD;
 // (round 5: the group loop fully unrolled with a scalar exit per group -- every LDS offset of a group is then an immediate of its
 // ds_read; the rolled loop carried 6 scalar induction variables and 7 vector address additions per group of T x, a third of its
 // instructions.  Same sums in the same order: bit-identical.)
-template <int QCAP, int TOFF, int XOFF, int TS = QCAP, typename TF = double>
+template <int QCAP, int TOFF, int XOFF, int TS = QCAP, typename TF = double, bool PAIR = false>
 __device__ __forceinline__ double t_tmul2(const double *B, int lane, int q, const int xo = 0)
 {
     double acc = 0.0;
@@ -163,22 +163,31 @@ __device__ __forceinline__ double t_tmul2(const double *B, int lane, int q, cons
     const LdsD *xs = (const LdsD *)(B + XOFF);
     asm volatile("" : "+v"(xs));
     asm volatile("" : "+v"(lane));
+    // (two groups per round trip: the loads of both are issued before either is summed.  The second group may lie beyond q: x is exactly zero
+    // there and every value of the wave's LDS is finite, so it adds +0 -- the same bits as leaving it out)
+    // (PAIR: the slack kernels, which have the registers -- 2 waves per SIMD; the slack-free kernels sit at their 168 and would spill)
+    constexpr int GS = PAIR ? 16 : 8;
 #pragma unroll
-    for (int i0 = 0; i0 < QCAP; i0 += 8) {
+    for (int i0 = 0; i0 < QCAP; i0 += GS) {
         if (i0 >= q) break;
-        double t[8], x[8];
+        constexpr int NG = GS / 8;
+        double t[GS], x[GS];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { t[u] = (double)col[i0 + u]; x[u] = xs[i0 + u]; }
-        double s0 = t[0] * x[0], s1 = t[1] * x[1];
+        for (int u = 0; u < GS; ++u) { const bool in = i0 + u < QCAP; t[u] = in ? (double)col[i0 + u] : 0.0; x[u] = in ? xs[i0 + u] : 0.0; }
 #pragma unroll
-        for (int u = 2; u < 8; u += 2) { s0 = fma(t[u], x[u], s0); s1 = fma(t[u + 1], x[u + 1], s1); }
-        acc += (i0 <= lane) ? (s0 + s1) : 0.0;
+        for (int g = 0; g < NG; ++g) {
+            if (i0 + 8 * g >= QCAP) break;
+            double s0 = t[8 * g] * x[8 * g], s1 = t[8 * g + 1] * x[8 * g + 1];
+#pragma unroll
+            for (int u = 2; u < 8; u += 2) { s0 = fma(t[8 * g + u], x[8 * g + u], s0); s1 = fma(t[8 * g + u + 1], x[8 * g + u + 1], s1); }
+            acc += (i0 + 8 * g <= lane) ? (s0 + s1) : 0.0;
+        }
     }
     return (lane < q) ? acc : 0.0;
 }
 // y = T x  (lane i gets y_i; 0 for i >= q).  The 8 columns of group g hold rows 0 .. 8(g+1)-1 (zeros below the diagonal),
 // so a lane either owns the whole group or skips it; columns >= q only meet x_j = 0.
-template <int QCAP, int TOFF, int XOFF, int TS = QCAP, typename TF = double>
+template <int QCAP, int TOFF, int XOFF, int TS = QCAP, typename TF = double, bool PAIR = false>
 __device__ __forceinline__ double t_mul2(const double *B, int lane, int q, const int xo = 0)
 {
     double acc = 0.0;
@@ -187,18 +196,31 @@ __device__ __forceinline__ double t_mul2(const double *B, int lane, int q, const
     const LdsD *xs = (const LdsD *)(B + XOFF);
     asm volatile("" : "+v"(xs));
     asm volatile("" : "+v"(lane));
+    constexpr int GS = PAIR ? 16 : 8;
 #pragma unroll
-    for (int j0 = 0; j0 < QCAP; j0 += 8) {
+    for (int j0 = 0; j0 < QCAP; j0 += GS) {
         if (j0 >= q) break;
-        const TF *rw = (TS < QCAP && j0 >= TS) ? rowx : row;
-        double t[8], x[8];
-        const int c0 = tcol(j0), len = j0 + 9;
+        constexpr int NG = GS / 8;
+        double t[GS], x[GS];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { t[u] = (double)rw[c0 + u * len]; x[u] = xs[j0 + u]; }
-        double s0 = t[0] * x[0], s1 = t[1] * x[1];
+        for (int g = 0; g < NG; ++g) {
+            const int jg = j0 + 8 * g;
+            if (jg >= QCAP) break;
+            // (split T without an extension held: the group at TS reads the vectors behind the wave's columns -- finite -- against x = 0)
+            const TF *rw = (TS < QCAP && jg >= TS) ? rowx : row;
+            const int c0 = tcol(jg), len = jg + 9;
 #pragma unroll
-        for (int u = 2; u < 8; u += 2) { s0 = fma(t[u], x[u], s0); s1 = fma(t[u + 1], x[u + 1], s1); }
-        acc += (lane < j0 + 8) ? (s0 + s1) : 0.0;
+            for (int u = 0; u < 8; ++u) { t[8 * g + u] = (double)rw[c0 + u * len]; x[8 * g + u] = xs[jg + u]; }
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int jg = j0 + 8 * g;
+            if (jg >= QCAP) break;
+            double s0 = t[8 * g] * x[8 * g], s1 = t[8 * g + 1] * x[8 * g + 1];
+#pragma unroll
+            for (int u = 2; u < 8; u += 2) { s0 = fma(t[8 * g + u], x[8 * g + u], s0); s1 = fma(t[8 * g + u + 1], x[8 * g + u + 1], s1); }
+            acc += (lane < jg + 8) ? (s0 + s1) : 0.0;
+        }
     }
     return (lane < q) ? acc : 0.0;
 }
@@ -444,9 +466,9 @@ __device__ __attribute__((noinline)) CrashRes crash_append(LdsD *Bl, const LdsD 
         sv = has ? G[gj * 30 + pkj] * (sgj * sgp) : 0.0;
     }
     B[SL::XS + lane] = sv; LSYNC();
-    const double dvj = t_tmul2<QCAP, SL::T, SL::XS, TS, TF>(B, lane, q);
+    const double dvj = t_tmul2<QCAP, SL::T, SL::XS, TS, TF, SOFT>(B, lane, q);
     B[SL::RR + lane] = dvj; LSYNC();
-    const double ri = t_mul2<QCAP, SL::T, SL::RR, TS, TF>(B, lane, q);
+    const double ri = t_mul2<QCAP, SL::T, SL::RR, TS, TF, SOFT>(B, lane, q);
     LSYNC();
     const double d2 = (lane < q) ? dvj * dvj : 0.0;
     double irho[3]; bool okx[3];
@@ -1145,9 +1167,9 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                         if (F32T && !(mx < 0.5 * mx_prev)) break;   // (fp32 factor: the refinement has stopped contracting)
                         mx_prev = mx;
                         B[SL::XS + lane] = rho; LSYNC();
-                        const double dvj = t_tmul2<QCAP, SL::T, SL::XS, TS, TF>(B, lane, q, xo);
+                        const double dvj = t_tmul2<QCAP, SL::T, SL::XS, TS, TF, SOFT>(B, lane, q, xo);
                         B[SL::RR + lane] = dvj; LSYNC();
-                        const double ri = t_mul2<QCAP, SL::T, SL::RR, TS, TF>(B, lane, q, xo);
+                        const double ri = t_mul2<QCAP, SL::T, SL::RR, TS, TF, SOFT>(B, lane, q, xo);
                         if (lane < q) B[SL::SLAM + lane] += ri;
                         LSYNC();
                         primal_fast();
@@ -1266,10 +1288,10 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                     }
                     B[SL::XS + lane] = sv; LSYNC();
                     PH(13);
-                    const double dvj = t_tmul2<QCAP, SL::T, SL::XS, TS, TF>(B, lane, q, xo);
+                    const double dvj = t_tmul2<QCAP, SL::T, SL::XS, TS, TF, SOFT>(B, lane, q, xo);
                     B[SL::RR + lane] = dvj; LSYNC();
                     PH(14);
-                    const double ri = t_mul2<QCAP, SL::T, SL::RR, TS, TF>(B, lane, q, xo);
+                    const double ri = t_mul2<QCAP, SL::T, SL::RR, TS, TF, SOFT>(B, lane, q, xo);
                     LSYNC();
                     PH(2);
                     if (crash) {   // append without a step: column [-r/rho; 1/rho] with rho^2 = s_pp - |T's|^2, lambda_p = 0 until the batch is solved
