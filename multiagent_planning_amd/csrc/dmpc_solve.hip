@@ -861,6 +861,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
             bool crash_stop = warm;          // warm: straight to the finish (solve the multipliers of the kept working set)
             bool crash_box = !warm;          // every slot of the batch is an acceleration bound
             int crash_rounds = 0, nfast = 0, accept_drops = 0;
+            bool pristine = !warm;
             const double dual0 = dual;
             LSYNC();
 
@@ -932,6 +933,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
             // x(lambda) re-derived from the multipliers: nu = -N_W lambda, a = a_unc + H^-1 nu, w = w_unc + Lambda H^-1 nu,
             // eps = -(st + sum lambda sigma)/2 for live slack rows
             auto primal_fast = [&]() {
+                pristine = false;
                 B[SL::RR + lane] = (lane < q) ? B[SL::SLAM + lane] : 0.0;
                 unsigned long long smk = 0ull;
                 if (soft) {
@@ -1044,6 +1046,8 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
             if (SOFT && crash && !pre_inf) {
                 bool tbl_ok = true;
                 while (q < (QCAP - 4 < 44 ? QCAP - 4 : 44)) {
+                    // (the function's own first test, here: the call that only finds nothing left costs an out-of-line call with its register traffic)
+                    if (__ballot(comp && !(cslot & 0x30000u) && fabs(a) - P.alim > tol) == 0ull) break;
                     const CrashRes cr = crash_append<SOFT, QCAP, PERSIST, TF, TS>((LdsD *)B, (const LdsD *)G, P.tables + TAB_DOUBLES + (size_t)ccase * 2 * TAB_TP_CASE,
                                                                           lane, q, cslot, a, P.alim, tol, tbl_ok);
                     const int crf = UNI(cr.flags);   // (an out-of-line function returns in vector registers: the slot count would be lane-dependent from here on)
@@ -1158,7 +1162,9 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                     // verification: primal from the multipliers, refine the active-set residual, re-check
                     // (crash: the appended slots carry lambda = 0 and their violation at the stale iterate -- the same pass solves them)
                     if (!fresh) {
-                    primal_fast();
+                    // (pristine: nothing but appends without a step since the try began -- every multiplier is zero and the iterate in registers and LDS
+                    // IS x(lambda) = the unconstrained minimiser: re-deriving it would write the same bits)
+                    if (!(SOFT && pristine)) primal_fast();
                     double mx_prev = INFINITY;
                     for (int pass = 0; pass < REFINE_PASSES; ++pass) {
                         const double rho = (lane < q) ? slot_value(lane) : 0.0;
@@ -1394,7 +1400,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                         rc = 1; break;
                     }
                     if (lane < q) B[SL::SLAM + lane] -= t * ri;
-                    lam_p += t;
+                    lam_p += t; pristine = false;
                     if (!dependent) {
                         if (!soft) {
                             dual += t * delta * (lam_p - 0.5 * t);
