@@ -631,7 +631,9 @@ static int tier1_qcap(const dmpc_ctx *ctx, int variant, int scene_agents)
     // step outgrew a 48-slot tier, none needs more than 50 -- and the few that overflow are re-solved from scratch in a second,
     // serialized launch that lasts as long as its slowest agent (0.56 ms of a 2.7 ms step).  56 slots cost 3.6 KB of LDS per agent
     // (5 instead of 6 one-agent workgroups per CU) and take them all: solve 1.81 -> 1.44 ms per step.
-    return scene_agents >= 1024 ? 56 : 48;
+    // (round 5: solveSoftDMPCall too, at any scene size -- its agents carry three rows per neighbour, 2-3 % of them outgrow 48 slots, and the second
+    // launch that re-solves those from scratch lasted 1.6 ms of a 4.5 ms step of 512 scenes: 3.16 -> 2.17 ms of solve launches per step)
+    return (scene_agents >= 1024 || variant == DMPC_VAR_ALL3) ? 56 : 48;
 }
 
 static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_first, int c_count, const double *lT,
