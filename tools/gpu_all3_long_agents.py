@@ -30,7 +30,7 @@ t = buf[:tot * 2].reshape(tot, 2)
 dur = t[:, 1] * 1e-2; st = (t[:, 0] - t[t[:, 1] > 0, 0].min()) * 1e-2
 inf = out["info"].reshape(tot, 8)
 ran = dur > 0
-print(f"{variant} x {S} scenes: solve launch {sms*1e3:.0f} us; {ran.sum()} agents through the solver, duration mean {dur[ran].mean():.1f} us, sum / 2048 slots {dur[ran].sum()/2048:.0f} us; longest {dur.max():.0f} us")
+print(f"{variant} x {S} scenes: solve launch {sms*1e3:.0f} us; {ran.sum()} agents through the solver, duration mean {dur[ran].mean():.1f} us, sum / 1000 = {dur[ran].sum()/1000:.0f} us (divide by the thousands of wave slots of the launch: 2.048 at eight, 1.792 at seven, 3.072 at twelve waves per CU); longest {dur.max():.0f} us")
 top = np.argsort(dur)[-10:][::-1]
 for i in top:
     print(f"   agent {i}: start {st[i]:.0f} us, {dur[i]:.0f} us, iterations {inf[i,4]}, tries {inf[i,2]}, rows {inf[i,1]}, final slots {inf[i,6]}, most {inf[i,7]}: {dur[i]/max(inf[i,4],1):.2f} us per iteration")
