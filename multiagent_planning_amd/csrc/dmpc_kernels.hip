@@ -222,12 +222,31 @@ __device__ __attribute__((noinline)) bool ladder_level_infeasible(const double *
     const int kc0 = lane < nr ? r_kc[lane] : -1, kc1 = lane + 64 < nr ? r_kc[lane + 64] : -1;
     bool empty_any = false;
     for (int k = 0; k < K && !empty_any; ++k) {
-        const bool s0 = (lane < nr) && kc0 == k, s1 = (lane + 64 < nr) && kc1 == k;
+        const bool t0 = (lane < nr) && kc0 == k, t1 = (lane + 64 < nr) && kc1 == k;
+        if (!__any(t0 || t1)) continue;
+        const double sh = (double)(k + 1) * h, R = 0.5 * alim * sh * sh;
+        // Round 5: rows that the WHOLE reachable box satisfies at this level -- max over |w| <= R of -xi.w = |xi|_1 R <= rhs -- cannot cut the
+        // polytope and are left out (exact: the box faces are planes of the set).  The search is cubic in the planes -- every pair's line against
+        // every plane, all of them when the level IS infeasible -- and most rows of a step belong to neighbours that only come near: at N = 10^4 a
+        // ladder climber spent more time here than iterating.  A row that the whole box violates settles the level at once.
+        double rx0[2], rx1[2], rx2[2], rrhs[2];
+        bool keep[2], dead = false;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const bool sel = c ? t1 : t0;
+            const int i = sel ? lane + 64 * c : 0;
+            rx0[c] = r_xi[3 * i]; rx1[c] = r_xi[3 * i + 1]; rx2[c] = r_xi[3 * i + 2];
+            rrhs[c] = r_b[i] - r_sd[i] * r_slb[i] * f;
+            const double n1 = (fabs(rx0[c]) + fabs(rx1[c]) + fabs(rx2[c])) * R;
+            keep[c] = sel && !(n1 * (1.0 + 1e-9) + 1e-12 * fabs(rrhs[c]) <= rrhs[c]);
+            dead = dead || (sel && -n1 > rrhs[c] + 1e-7 * (n1 + fabs(rrhs[c])));
+        }
+        if (__any(dead)) { empty_any = true; break; }
+        const bool s0 = keep[0], s1 = keep[1];
         const unsigned long long m0 = __ballot(s0), m1 = __ballot(s1);
         const int c0 = __popcll(m0), m = c0 + __popcll(m1);
         if (m == 0) continue;
         const int M = m < mcap ? m : mcap;
-        const double sh = (double)(k + 1) * h, R = 0.5 * alim * sh * sh;
         LSYNC();
         {
             const int p0 = lanes_below(m0, lane), p1 = c0 + lanes_below(m1, lane);
@@ -236,9 +255,8 @@ __device__ __attribute__((noinline)) bool ladder_level_infeasible(const double *
                 const bool sel = c ? s1 : s0;
                 const int pp = c ? p1 : p0;
                 if (sel && pp < mcap) {
-                    const int i = lane + 64 * c;
-                    const double x0 = r_xi[3 * i], x1 = r_xi[3 * i + 1], x2 = r_xi[3 * i + 2];
-                    const double rhs = r_b[i] - r_sd[i] * r_slb[i] * f;
+                    const double x0 = rx0[c], x1 = rx1[c], x2 = rx2[c];
+                    const double rhs = rrhs[c];
                     const double sn = 1.0 / ((fabs(x0) + fabs(x1) + fabs(x2)) * R + fabs(rhs) + 1e-300);
                     pl[4 * pp] = -x0 * sn; pl[4 * pp + 1] = -x1 * sn; pl[4 * pp + 2] = -x2 * sn; pl[4 * pp + 3] = rhs * sn;
                 }
