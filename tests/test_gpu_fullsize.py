@@ -2,6 +2,8 @@
 compared (C2: 6 400 QPs, C5: 200 agents); at N = 1 000 / 10 000 a random sample is, and the rest is covered by
 size-independent properties: model consistency p = Lambda a + A0 x0, acceleration and workspace bounds, bitwise
 determinism, and invariance of the result under the sharded table layout (1 vs 8 chunks)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -147,35 +149,46 @@ def test_c4_bound_10000_agents_sharded_in_8_chunks():
     _sample_vs_oracle("bound", kw, l[0], po[0], z[0], z[0], pf[0], o1, idx, 1e-9, "C4")
 
 
-def test_c4_closed_loop_steps_3_6_10_sampled_against_the_oracle():
-    """BASELINE configs[3] in the state the bench TIMES: the closed loop of the 10^4-agent scene at MPC steps 3, 6 and 10, where the
+def test_c4_closed_loop_all_agents_all_steps_against_the_oracle(capsys):
+    """BASELINE configs[3] in the state the bench TIMES: the closed loop of the 10^4-agent scene over MPC steps 2-10, where the
     agents move (neighbour lists from the cell grid at full density, crash start of the acceleration bounds from the factor
-    tables, retry ladder, 56-slot first tier).  Every step: size-independent properties on all agents and, at steps 3, 6, 10, a sample of
-    48 agents against the oracle -- the agents with the most iterations, with ladder retries, with the most rows, and random ones --
-    on identical inputs (teacher forcing on the GPU's own states), 1e-9."""
+    tables, retry ladder, 56-slot first tier).  EVERY agent of EVERY step against the oracle on identical inputs (teacher forcing on
+    the GPU's own states): identical status, first violating step, row count, cost case and retry-ladder count, l_inf(p, v, a) <= 1e-9;
+    plus the size-independent properties.  The oracle runs the step's 10^4 dense QPs on all host cores (0.4-0.6 s per step on the GPU
+    box); with fewer than 8 cores the comparison falls back to the 48 heaviest / ladder / most-rows / random agents of steps 3, 6, 10."""
     cfg, N = wl.CONFIGS["C4"], 10000
     kw = wl.solver_kwargs(cfg, N)
     po, pf = wl.make_scenes(cfg, 1, N, wl.SEED0 + 4)
     d = mp.Dmpc("bound", **kw)
+    prm = orc.make_params("bound", **kw)
     l, _, _ = d.init_batch(po, pf)
     xp, xv, xa = po.copy(), np.zeros_like(po), np.zeros_like(po)
     rng = np.random.default_rng(13)
+    ncores = os.cpu_count() or 1
+    compared, worst, heavy_seen, ladder_seen = 0, 0.0, False, False
     for step in range(2, 11):
         out = d.step_batch(l, xp, xv, xa, pf)
         _properties(out, l, xp, xv, kw, "bound", f"C4 step {step}")
-        if step in (3, 6, 10):
-            inf, st = out["info"][0], out["status"][0]
+        inf = out["info"][0]
+        o1 = {k: v[0] for k, v in out.items()}
+        if ncores >= 8:
+            ref = orc.step(prm, l[0], xp[0], xv[0], xa[0], pf[0], nthreads=ncores)
+            errs = compare_to_oracle(o1, ref, 1e-9, f"C4 step {step}")
+            compared += N; worst = max(worst, max(errs.values()))
+        elif step in (3, 6, 10):
             heavy = np.argsort(inf[:, 4])[-12:]
             ladder = np.where(inf[:, 2] > 1)[0][:12]
             rows = np.argsort(inf[:, 1])[-12:]
             idx = np.unique(np.concatenate([heavy, ladder, rows, rng.integers(0, N, 12)]))
-            assert idx.size >= 30
-            o1 = {k: v[0] for k, v in out.items()}
             _sample_vs_oracle("bound", kw, l[0], xp[0], xv[0], xa[0], pf[0], o1, idx, 1e-9, f"C4 step {step}")
-            assert (inf[:, 7] >= 40).any() and (inf[:, 2] > 1).any()            # the heavy paths did run
+            compared += idx.size
+        heavy_seen = heavy_seen or bool((inf[:, 7] >= 40).any()); ladder_seen = ladder_seen or bool((inf[:, 2] > 1).any())
         ok = (out["status"] == 1)[..., None]
         l = np.where(ok, out["p"], l); xp = np.where(ok, out["p"][..., :3], xp)
         xv = np.where(ok, out["v"][..., :3], xv); xa = np.where(ok, out["a"][..., :3], xa)
+    assert heavy_seen and ladder_seen            # the heavy paths did run
+    with capsys.disabled():
+        print(f"\nC4 closed loop (10 000 agents, MPC steps 2-10) vs oracle: {compared} agent-steps compared on {ncores} host cores, worst l_inf {worst:.2e}")
 
 
 @pytest.mark.parametrize("N,G", [(120, 3), (320, 4)])
