@@ -58,7 +58,19 @@ enum {
      * (:715), quadratic slack weight 1 (:719); cost cases by `violation` (:640-661); ONE QuadProgDense solve, no retry, no in-bounds
      * test, no first-step collision test.  A violation at k = 0 makes the reference index row -3 of A0 (undefined behaviour): reported
      * as DMPC_ST_COLL without a solve.  Float members as for DMPC_VAR_CPP. */
-    DMPC_VAR_CPP1 = 10
+    DMPC_VAR_CPP1 = 10,
+    /* solveSoftDMPC_c.m:1-96 (test/comp_confidence.m:184): solveSoftDMPC with the slack penalties of :60-63 -- linear -1e4 (K/k)^2, quadratic
+     * 1e6 (K/k)^2, k the first violating horizon step (1-based) -- and no outbound output.  order 2 or 4. */
+    DMPC_VAR_SOFTALL_C = 11,
+    /* solveDMPC.m:1-74, the legacy SCP loop (dmpc/matlab/dmpc.m:79, test/success_test_dmpc.m:80, test/comp_heuristics.m:76): up to k_hor
+     * passes; every pass re-linearises HARD spherical rows (CheckCollDMPC.m:6-8: plain Euclidean norm, no E1; CollConstrDMPC.m:8-30) for ALL
+     * N-1 neighbours at every horizon step of `addConstr` about the previous pass's prediction, adds at most ONE new step per pass (the first
+     * violating step not yet in the set, :28-33), solves the QP (cost case by `isempty(Ain_total)` only, :38-48) and stops when
+     * maxDeviation(p, prev_p) <= dmpc_params.tol (:17,69; maxDeviation.m:3 looks at the first length(p)/3 = 5 steps of the 3 x 15 matrix).
+     * The whole loop of an agent runs inside ONE kernel launch.  info: VIOLK = smallest step of addConstr, NROWS = rows of the last pass,
+     * TRIES = passes made, CASE = 0 / 2 of the last pass; an infeasible pass ends the loop with DMPC_ST_INFEAS (`success = 0`, :58-63).
+     * c and order are not used (sphere); no in-bounds test, no first-step collision test. */
+    DMPC_VAR_SCP = 12
 };
 
 /* per-agent status bits (the reference's feasible/success, outbound, coll flags) */
@@ -91,7 +103,7 @@ typedef struct {
     int32_t K;         /* horizon length k_hor; must be 15                                   */
     int32_t variant;   /* DMPC_VAR_*                                                         */
     int32_t order;     /* ellipsoid order: 2; or 4 (super-ellipsoid of test/comp_test_ellipconstr.m:158-187: dist = |E1 d|_4, E2 = E^-4) with
-                        * the all-neighbour variants DMPC_VAR_SOFTALL / _ELLIP / _REPAIR / _CPP1; refused otherwise */
+                        * the all-neighbour variants DMPC_VAR_SOFTALL / _SOFTALL_C / _ELLIP / _REPAIR / _CPP1; refused otherwise */
     int32_t max_tries; /* <=0: reference default (30)                                        */
     double h;          /* time step                                                          */
     double rmin;       /* collision radius                                                   */
@@ -105,6 +117,8 @@ typedef struct {
      * Earlier revisions of dmpc/cpp used other values: the recorded dmpc/cpp_results/trajectories (200-agents).txt is
      * reproduced to its 6 printed digits with Qfar = 100, Qnear = 1000 (tests/test_oracle_golden.py). */
     double Qfar, Qnear, Sfree;
+    double tol;        /* DMPC_VAR_SCP only: `tol` of solveDMPC(..., Delta, tol, Q1, S1) (solveDMPC.m:1): the SCP loop ends when the largest
+                        * position change of a pass falls to tol or below.  Ignored by every other variant.  (new in ABI revision 6) */
 } dmpc_params;
 
 typedef struct dmpc_ctx dmpc_ctx;
@@ -148,7 +162,7 @@ enum {
 /* ABI revision of this header.  The special device values changed once (the round-3 header had DMPC_DEVICE_ALL = -1, DMPC_DEVICE_CURRENT = -2;
  * since revision 4 they are the two values above and any other negative device is refused), so a binding compiled against another header
  * should compare dmpc_abi_version() with the DMPC_ABI_VERSION it was built with before its first dmpc_create. */
-#define DMPC_ABI_VERSION 5
+#define DMPC_ABI_VERSION 6
 DMPC_API int dmpc_abi_version(void);
 DMPC_API dmpc_ctx *dmpc_create(const dmpc_params *prm, int device, int precision);
 /* number of GPUs the context drives (1 unless created with DMPC_DEVICE_ALL on a multi-GPU node) */
@@ -390,12 +404,16 @@ DMPC_API int dmpc_random_sets_device(dmpc_ctx *ctx, int S, int N, const double *
  *                     A_p, A_v: [n_rows][n_cols] row-major, A_initp: [n_rows][6] or NULL; off_p/off_v: 3-vectors tiled
  *                     over the rows (or NULL).
  *   dmpc_is_inbounds  is_inbounds.m:1-6 on npts points [npts][3] (5 cm tolerance)
- *   dmpc_reached_goal ReachedGoal.m:1-11: max_i |p_i - pf_i| < error_tol, p, pf [N][3] */
+ *   dmpc_reached_goal ReachedGoal.m:1-11: max_i |p_i - pf_i| < error_tol, p, pf [N][3]
+ *   dmpc_max_deviation maxDeviation.m:1-11 (the stopping measure of solveDMPC.m:69): p, prev_p [K_cols][3] (== MATLAB 3 x K_cols); the
+ *                     largest per-step distance over the steps the .m looks at -- `K = length(p)/3` of the MATRIX p is max(3, K_cols)/3,
+ *                     i.e. the first 5 of 15 horizon steps, restated as written */
 DMPC_API int dmpc_prop_state(dmpc_ctx *ctx, int n_rows, int n_cols, const double *A_p, const double *A_v, const double *A_initp,
                     const double *po, const double *vo, const double *off_p, const double *off_v, const double *a,
                     double *p, double *v);
 DMPC_API int dmpc_is_inbounds(dmpc_ctx *ctx, int npts, const double *p, const double *pmin, const double *pmax, int32_t *inbounds);
 DMPC_API int dmpc_reached_goal(dmpc_ctx *ctx, int N, const double *p, const double *pf, double error_tol, int32_t *reached);
+DMPC_API int dmpc_max_deviation(dmpc_ctx *ctx, int K_cols, const double *p, const double *prev_p, double *tol_out);
 
 /* Agent-steps LAUNCHED by this context so far (incl. the half of a split dmpc_transition batch that runs on the internal
  * second context).  An upper bound of the QPs actually solved: agents of scenes that already stopped are skipped on the

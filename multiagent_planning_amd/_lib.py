@@ -12,14 +12,14 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdmpc_hip.so")
 
-VARIANTS = dict(bound=0, bound2=1, all3=2, hard=3, ondemand=4, ellip=5, softall=6, repair=7, cpp=8, cpp2=9, cpp1=10)
+VARIANTS = dict(bound=0, bound2=1, all3=2, hard=3, ondemand=4, ellip=5, softall=6, repair=7, cpp=8, cpp2=9, cpp1=10, softall_c=11, scp=12)
 ST_SOLVED, ST_OUTBOUND, ST_COLL, ST_INFEAS, ST_CAPACITY, ST_ITERCAP = 1, 2, 4, 8, 16, 32
 PRECISIONS = dict(f64=0, mixed=1, f32factor=2, low=3)
 ST_REACHED = 256   # scene_status of transition(): every agent reached its goal
 INFO_LEN = 8
 I_VIOLK, I_NROWS, I_TRIES, I_CASE, I_ITERS, I_NSLACK, I_NACTIVE, I_MAXQ = range(8)
 K_HOR = 15
-ABI_VERSION = 5    # DMPC_ABI_VERSION of include/dmpc_hip.h
+ABI_VERSION = 6    # DMPC_ABI_VERSION of include/dmpc_hip.h
 
 # every symbol include/dmpc_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
@@ -32,6 +32,7 @@ ABI_SYMBOLS = [
     "dmpc_prop_state", "dmpc_is_inbounds", "dmpc_reached_goal", "dmpc_rows_dense",
     "dmpc_partition", "dmpc_comm_unique_id", "dmpc_comm_init", "dmpc_comm_destroy", "dmpc_step_sharded_device",
     "dmpc_transition_sharded", "dmpc_transition_sharded_gather", "dmpc_group_size", "dmpc_comm_size", "dmpc_abi_version",
+    "dmpc_max_deviation",
 ]
 
 
@@ -42,6 +43,7 @@ class DmpcParams(C.Structure):
         ("Q1", C.c_double), ("S1", C.c_double), ("term", C.c_double),
         ("pmin", C.c_double * 3), ("pmax", C.c_double * 3),
         ("Qfar", C.c_double), ("Qnear", C.c_double), ("Sfree", C.c_double),
+        ("tol", C.c_double),
     ]
 
 
@@ -110,6 +112,7 @@ def load():
     L.dmpc_prop_state.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, dp, dp, dp, dp]
     L.dmpc_is_inbounds.argtypes = [vp, C.c_int, dp, dp, dp, ip]
     L.dmpc_reached_goal.argtypes = [vp, C.c_int, dp, dp, C.c_double, ip]
+    L.dmpc_max_deviation.argtypes = [vp, C.c_int, dp, dp, dp]
     L.dmpc_postcheck.argtypes = [vp, C.c_int, C.c_int, C.c_int, ip, ip, dp, dp, dp, dp, C.c_double, C.c_double, C.c_double,
                                  dp, dp, ip, dp, ip, dp, dp, dp, C.c_int]
     L.dmpc_partition.argtypes = [C.c_int, C.c_int, C.c_int, ip, ip, ip]
@@ -133,7 +136,7 @@ def load():
 
 
 def make_params(variant="bound", K=K_HOR, h=0.2, rmin=0.35, c=2.0, alim=1.0, Q1=1000.0, S1=100.0, term=-5e4,
-                pmin=(-2.5, -2.5, 0.2), pmax=(2.5, 2.5, 2.2), order=2, max_tries=0, Qfar=0.0, Qnear=0.0, Sfree=0.0):
+                pmin=(-2.5, -2.5, 0.2), pmax=(2.5, 2.5, 2.2), order=2, max_tries=0, Qfar=0.0, Qnear=0.0, Sfree=0.0, tol=2.0):
     p = DmpcParams()
     p.K, p.order, p.max_tries = int(K), int(order), int(max_tries)
     p.variant = VARIANTS[variant] if isinstance(variant, str) else int(variant)
@@ -142,6 +145,7 @@ def make_params(variant="bound", K=K_HOR, h=0.2, rmin=0.35, c=2.0, alim=1.0, Q1=
         p.pmin[i] = float(pmin[i])
         p.pmax[i] = float(pmax[i])
     p.Qfar, p.Qnear, p.Sfree = float(Qfar), float(Qnear), float(Sfree)
+    p.tol = float(tol)
     return p
 
 
@@ -403,6 +407,13 @@ class Dmpc:
         return bool(out[0])
 
     # ---- start / goal generators (randomTest.m, randomExchange.m) on the device ---------------
+    def max_deviation(self, p, prev_p):
+        """maxDeviation.m: p, prev_p [K,3] (the transposes of the MATLAB 3 x K matrices)."""
+        p, prev_p = _f(p), _f(prev_p)
+        out = np.zeros(1)
+        self._chk(self._L.dmpc_max_deviation(self._ctx, p.shape[0], _dp(p), _dp(prev_p), _dp(out)))
+        return float(out[0])
+
     def random_test(self, S, N, pmin, pmax, rmin, c, seed):
         """S scenes of randomTest(N,pmin,pmax,rmin,E1,order=2): (po, pf) each [S,N,3]."""
         po, pf = np.zeros((S, N, 3)), np.zeros((S, N, 3))

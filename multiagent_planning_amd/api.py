@@ -25,16 +25,16 @@ def _table(l):
     return np.ascontiguousarray(l.transpose(2, 1, 0).reshape(l.shape[2], -1))
 
 
-def _ctx(variant, h, K, rmin, pmin, pmax, alim, Q1, S1, E1, order, term, device=0):
+def _ctx(variant, h, K, rmin, pmin, pmax, alim, Q1, S1, E1, order, term, device=0, tol=0.0):
     if int(K) != _lib.K_HOR:
         raise ValueError("K (k_hor) must be 15")
     c = 1.0 / float(np.asarray(E1)[2, 2])
     key = (variant, float(h), float(rmin), tuple(map(float, np.ravel(pmin))), tuple(map(float, np.ravel(pmax))),
-           float(alim), float(Q1), float(S1), c, int(order), float(term), device)
+           float(alim), float(Q1), float(S1), c, int(order), float(term), device, float(tol))
     d = _ctx_cache.get(key)
     if d is None:
         d = Dmpc(variant, device=device, h=h, rmin=rmin, c=c, alim=alim, Q1=Q1, S1=S1, term=term,
-                 pmin=tuple(np.ravel(pmin)), pmax=tuple(np.ravel(pmax)), order=order)
+                 pmin=tuple(np.ravel(pmin)), pmax=tuple(np.ravel(pmax)), order=order, tol=tol)
         _ctx_cache[key] = d
     return d
 
@@ -107,6 +107,65 @@ def solveSoftDMPC(po, pf, vo, ao, n, h, l, K, rmin, pmin, pmax, alim, A, A_initp
     if st & ST_SOLVED:
         return tuple(r[k].reshape(K, 3).T.copy() for k in ("p", "v", "a")) + (1, 0)
     return _EMPTY, _EMPTY, _EMPTY, 0, int(r["info"][_lib.I_VIOLK] == 0)
+
+
+def solveSoftDMPC_c(po, pf, vo, ao, n, h, l, K, rmin, pmin, pmax, alim, A, A_initp, Delta, Q1, S1, E1, E2, order):
+    """[p,v,a,success] = solveSoftDMPC_c(...)  (solveSoftDMPC_c.m:1; test/comp_confidence.m:184): solveSoftDMPC with the slack penalties
+    -1e4 (K/k)^2 and 1e6 (K/k)^2 (:60-63); `isempty(x)` -> p = v = a = [], success = 0 (:80-87), else success = exitflag = 1."""
+    d = _ctx("softall_c", h, K, rmin, pmin, pmax, alim, Q1, S1, E1, order, -1e4)
+    r = d.solve_one(_table(l), int(n) - 1, np.ravel(po), np.ravel(vo), np.ravel(ao), np.ravel(pf))
+    st = r["status"]
+    if st & (ST_CAPACITY | ST_ITERCAP):
+        raise _lib.DmpcError(f"internal capacity/iteration limit hit (status {st}); result not valid")
+    if st & ST_SOLVED:
+        return tuple(r[k].reshape(K, 3).T.copy() for k in ("p", "v", "a")) + (1,)
+    return _EMPTY, _EMPTY, _EMPTY, 0
+
+
+def solveDMPC(po, pf, vo, ao, n, h, l, K, rmin, pmin, pmax, alim, A, A_initp, Delta, tol, Q1, S1):
+    """[p,v,a,success] = solveDMPC(po,pf,vo,ao,n,h,l,K,rmin,pmin,pmax,alim,A,A_initp,Delta,tol,Q1,S1)  (solveDMPC.m:1; dmpc/matlab/dmpc.m:79):
+    the legacy SCP loop -- up to k_hor passes of spherical hard rows re-linearised about the previous pass -- all of it inside one kernel
+    launch (DMPC_VAR_SCP).  An infeasible pass returns p = v = [] and success = 0 (:58-63; `a` is quadprog's empty result)."""
+    d = _ctx("scp", h, K, rmin, pmin, pmax, alim, Q1, S1, np.eye(3), 2, -5e4, tol=tol)
+    r = d.solve_one(_table(l), int(n) - 1, np.ravel(po), np.ravel(vo), np.ravel(ao), np.ravel(pf))
+    st = r["status"]
+    if st & (ST_CAPACITY | ST_ITERCAP):
+        raise _lib.DmpcError(f"internal capacity/iteration limit hit (status {st}); result not valid")
+    if st & ST_SOLVED:
+        return tuple(r[k].reshape(K, 3).T.copy() for k in ("p", "v", "a")) + (1,)
+    return _EMPTY, _EMPTY, _EMPTY, 0
+
+
+def maxDeviation(p, prev_p):
+    """tol = maxDeviation(p, prev_p)  (maxDeviation.m:1-11); p, prev_p are 3 x K.  Restated as written: `K = length(p)/3` of the matrix is
+    max(3, K)/3, so only the first 5 of 15 horizon steps are looked at."""
+    return _rowctx().max_deviation(np.asarray(p, float).T, np.asarray(prev_p, float).T)
+
+
+def CheckCollDMPC(p, l, n, k, r_min):
+    """violation = CheckCollDMPC(p,l,n,k,r_min)  (CheckCollDMPC.m:1-10): any other agent closer than r_min (plain Euclidean norm) at step k."""
+    l = np.asarray(l, float)
+    N = l.shape[2]
+    others = [j for j in range(N) if j != n - 1]
+    if not others:
+        return False
+    _, _, dist = _rowctx().coll_rows(_obst(l), others, k - 1, 0, np.ravel(p), np.zeros(3), r_min, 1.0, np.zeros((3, 1)))
+    return bool((dist < r_min).any())
+
+
+def CollConstrDMPC(p, po, vo, n, k, l, Ain, r_min, A_initp):
+    """[Ain_total, bin_total] = CollConstrDMPC(p,po,vo,n,k,l,Ain,r_min,A_initp)  (CollConstrDMPC.m:1-34): one spherical row per other agent at
+    horizon step k, linearised about p."""
+    l = np.asarray(l, float)
+    Ain = np.asarray(Ain, float)
+    if l.size == 0:
+        return np.zeros((0, Ain.shape[1])), np.zeros((0, 1))
+    N = l.shape[2]
+    sel = [j for j in range(N) if j != n - 1]
+    if not sel:
+        return np.zeros((0, Ain.shape[1])), np.zeros((0, 1))
+    A, b, _ = _dmpc_rows(p, po, vo, n, k, l, r_min, Ain, A_initp, np.eye(3), np.eye(3), 2, sel, k)
+    return A, b[:, None]
 
 
 def solveEllipDMPC(po, pf, vo, ao, n, h, l, K, rmin, pmin, pmax, alim, A, A_initp, Delta, Q1, S1, E1, E2, order):

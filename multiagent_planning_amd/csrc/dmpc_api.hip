@@ -87,6 +87,7 @@ struct dmpc_ctx {
     double hsum[3] = {0, 0, 0};   // per cost case: sum of |H1(i,j)| (dual-bound certificate of the slack-free variants)
     std::string err;
     int64_t solves = 0;
+    int max_lds_scp = 0;
     int max_lds_set = 0;
     // scratch for the host-pointer entry points
     DevBuf post_acc; int post_acc_S = 0, post_fused = 0;
@@ -178,10 +179,11 @@ static int check_params(const dmpc_params *p, std::string &why)
 {
     if (!p) { why = "params is NULL"; return -1; }
     if (p->K != K) { why = "only K = k_hor = 15 is supported (the value every reference script uses)"; return -1; }
-    if (p->order != 2 && !(p->order == 4 && (p->variant == DMPC_VAR_SOFTALL || p->variant == DMPC_VAR_ELLIP || p->variant == DMPC_VAR_REPAIR || p->variant == DMPC_VAR_CPP1))) {
+    if (p->order != 2 && !(p->order == 4 && (p->variant == DMPC_VAR_SOFTALL || p->variant == DMPC_VAR_SOFTALL_C || p->variant == DMPC_VAR_ELLIP || p->variant == DMPC_VAR_REPAIR || p->variant == DMPC_VAR_CPP1))) {
         why = "ellipsoid order must be 2, or 4 with solveSoftDMPC / solveEllipDMPC / solveSoftDMPCrepair / DMPC::solveQP (test/comp_test_ellipconstr.m:158)"; return -1;
     }
-    if (p->variant < 0 || p->variant > DMPC_VAR_CPP1) { why = "unknown variant"; return -1; }
+    if (p->variant < 0 || p->variant > DMPC_VAR_SCP) { why = "unknown variant"; return -1; }
+    if (p->variant == DMPC_VAR_SCP && !(p->tol >= 0)) { why = "solveDMPC: tol must be >= 0"; return -1; }
     if (!(p->h > 0) || !(p->rmin > 0) || !(p->c > 0) || !(p->alim > 0)) { why = "h, rmin, c, alim must be positive"; return -1; }
     for (int d = 0; d < 3; ++d)
         if (!(p->pmax[d] > p->pmin[d])) { why = "pmax must exceed pmin"; return -1; }
@@ -580,7 +582,7 @@ extern "C" int dmpc_profile(dmpc_ctx *ctx, int enable)
 static bool variant_soft(int v)
 {
     return v == DMPC_VAR_BOUND || v == DMPC_VAR_BOUND2 || v == DMPC_VAR_ALL3 || v == DMPC_VAR_SOFTALL || v == DMPC_VAR_REPAIR ||
-           v == DMPC_VAR_CPP || v == DMPC_VAR_CPP2 || v == DMPC_VAR_CPP1;
+           v == DMPC_VAR_CPP || v == DMPC_VAR_CPP2 || v == DMPC_VAR_CPP1 || v == DMPC_VAR_SOFTALL_C;
 }
 
 // row capacity per agent.  Rows live in global scratch (40-64 B each); LDS only holds 4-12 B per row
@@ -591,7 +593,8 @@ static int row_capacity(int variant, int N)
     const long nb = N > 1 ? N - 1 : 1;
     long want, cap;
     switch (variant) {
-    case DMPC_VAR_HARD: want = (long)K * nb; cap = 640; break;     // every k, neighbours with d < 1 (CollConstrHardDMPC.m:19), after exact pruning
+    case DMPC_VAR_HARD: want = (long)K * nb; cap = 640; break;
+    case DMPC_VAR_SCP: want = (long)K * nb; cap = 4096; break;     // every neighbour at every step of addConstr (up to all k_hor of them), after exact pruning     // every k, neighbours with d < 1 (CollConstrHardDMPC.m:19), after exact pruning
     case DMPC_VAR_ALL3: want = 3 * nb; cap = 384; break;           // three steps x neighbours with d < 3 rmin
     case DMPC_VAR_BOUND: case DMPC_VAR_BOUND2: case DMPC_VAR_ONDEMAND: case DMPC_VAR_CPP: case DMPC_VAR_CPP2: want = nb; cap = 128; break;   // d < 3 rmin only
     default: want = nb; cap = 4096; break;                         // ellip / softall / repair: all N-1 neighbours
@@ -654,6 +657,7 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     P.max_tries = p.max_tries;
     P.ell_order = p.order;
     P.h = p.h; P.rmin = p.rmin; P.e1z = 1.0 / p.c; P.e2z = p.order == 4 ? 1.0 / (p.c * p.c * p.c * p.c) : 1.0 / (p.c * p.c);   // E1 = E^-1, E2 = E^-order
+    if (p.variant == DMPC_VAR_SCP) { P.e1z = 1.0; P.e2z = 1.0; }   // solveDMPC: plain Euclidean norm (CheckCollDMPC.m:6, CollConstrDMPC.m:12-13)
     P.alim = p.alim; P.Q1 = p.Q1; P.S1 = p.S1; P.term = p.term;
     P.Qfar = p.Qfar > 0 ? p.Qfar : 1000.0; P.Qnear = p.Qnear > 0 ? p.Qnear : 10000.0; P.Sfree = p.Sfree > 0 ? p.Sfree : 10.0;
     for (int d = 0; d < 3; ++d) { P.pmin[d] = p.pmin[d]; P.pmax[d] = p.pmax[d]; }
@@ -672,10 +676,11 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     }
     P.dbg = ctx->dbg; P.dbg_agent = ctx->dbg_agent; P.dbg_cap = ctx->dbg_cap;
     P.iter_cap = ctx->iter_cap;
+    P.scp_tol = p.tol;
     P.dep_tol_f32 = std::pow(10.0, -(double)ctx->f32_dep_exp);
     P.no_level_check = ctx->no_level_check;
     // (not for solveHardDMPC: rows at every horizon step, 3 % of the agents would qualify and every scan would pay for the test)
-    P.fast_exit = (ctx->no_fast_exit || p.variant == DMPC_VAR_HARD || p.order == 4) ? 0 : 1;
+    P.fast_exit = (ctx->no_fast_exit || p.variant == DMPC_VAR_HARD || p.variant == DMPC_VAR_SCP || p.order == 4) ? 0 : 1;
     // measured: the crash start pays for the slack-carrying variants (C4, N = 10^4: solve launch -16 %) and costs on solveHardDMPC
     // (C2: -16 % throughput: with rows at every horizon step the bounds violated at the unconstrained minimiser are a poor guess)
     P.crash_min = (soft || ctx->crash_any) ? ctx->crash_min : 0;
@@ -690,7 +695,7 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     // violating agent carries a row per neighbour: C3 16 x 1 000 agents 37 iterations each, C5 64 x 200 agents 29 -- are throughput-bound from a
     // quarter of that depth on: persistent waves 1.50 / 0.89 ms against 1.77 / 1.05.  Light launches of the same depth -- 128 scenes x 100 agents
     // of solveSoftDMPC at MPC step 12, one iteration per agent -- stay with one agent per workgroup: 0.21 against 0.25 ms.)
-    const bool heavy_agents = (p.variant == DMPC_VAR_SOFTALL || p.variant == DMPC_VAR_REPAIR || p.variant == DMPC_VAR_ELLIP || p.variant == DMPC_VAR_CPP1) && G * C >= 200;
+    const bool heavy_agents = (p.variant == DMPC_VAR_SOFTALL || p.variant == DMPC_VAR_SOFTALL_C || p.variant == DMPC_VAR_REPAIR || p.variant == DMPC_VAR_ELLIP || p.variant == DMPC_VAR_CPP1) && G * C >= 200;
     // (crossover, agents per launch: C3 4 000: 0.72 / 0.71 ms, 8 000: 1.06 / 0.96; C5 3 200: 0.37 / 0.47, 6 400: 0.59 / 0.61 -- one agent per workgroup / persistent)
     // (round 5: the slack variants in LARGE scenes -- the 56-slot tier, agents of ~100 us each -- are bound by their work per wave slot: persistent
     // waves with the split factor, seven per CU, from two launches' worth of one-agent workgroups on)
@@ -702,7 +707,7 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     const int q1 = (ctx->single_tier || tiny || f32t) ? full_qcap(p.variant) : tier1_qcap(ctx, p.variant, G * C), q2 = full_qcap(p.variant);
     const bool two_tier = q1 < q2;
     ctx->post_fused = 0;
-    if (post && tiny && !two_tier && g_local == 0 && G == 1 && !ctx->no_fuse) {
+    if (post && tiny && !two_tier && g_local == 0 && G == 1 && !ctx->no_fuse && p.variant != DMPC_VAR_SCP) {
         if (ctx->post_acc.ensure((size_t)S * 16 + 64)) FAIL(ctx, "device allocation failed (post-step accumulators)");
         if (ctx->post_acc_S != S) {   // zero once per batch shape; the last wave of a scene leaves them zeroed again
             HIPCHK(ctx, hipMemsetAsync(ctx->post_acc.p, 0, (size_t)S * 16 + 64, st));
@@ -821,6 +826,26 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
                                (const float *)ctx->bbox.as<float>(), (const float *)ctx->bbox_nm.as<float>(), (int)cap, ctx->nbr_list.as<int>(), ctx->nbr_cnt.as<int>());
         }
         P.nbr_cap = (int)cap; P.nbr_list = ctx->nbr_list.as<int>(); P.nbr_cnt = ctx->nbr_cnt.as<int>();
+    }
+    if (p.variant == DMPC_VAR_SCP) {
+        // solveDMPC.m: the whole SCP loop of an agent -- up to k_hor passes of {scan about the previous pass's prediction, slack-free QP} -- in ONE
+        // launch, one agent per 64-thread workgroup (dmpc_scp_kernel); no neighbour lists (rows for every other agent), no launch order
+        if (lTf) FAIL(ctx, "solveDMPC (DMPC_VAR_SCP) runs in fp64 only: create the context with DMPC_PREC_F64");
+        P.qcap = 48; P.only_flagged = 0; P.qover_bit = ST_CAPACITY; P.lds_per_wave = (int)lds0;
+        const size_t lds_scp = solve_lds_bytes(P.nrmax, false, 48, false) > lds0 ? solve_lds_bytes(P.nrmax, false, 48, false) : lds0;
+        if ((int)lds_scp > ctx->max_lds_scp) {
+            HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_scp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_scp));
+            ctx->max_lds_scp = (int)lds_scp;
+        }
+        if (ctx->profile) HIPCHK(ctx, hipEventRecord(ev.t1, st));
+        hipLaunchKernelGGL(dmpc_scp_kernel, grid, block, lds_scp, st, P);
+        HIPCHK(ctx, hipGetLastError());
+        if (ctx->profile) {
+            HIPCHK(ctx, hipEventRecord(ev.t2, st));
+            ctx->events.push_back(ev);
+        }
+        ctx->solves += (int64_t)S * c_count;
+        return 0;
     }
     const bool run_order = ctx->forced_n != S * c_count && S * c_count >= 512 && !ctx->no_lpt;
     P.zero4 = (!tiny || run_order) ? ctx->counter.as<int>() : nullptr;   // queue heads of the persistent solve launches, tier-2 count, live bound: zeroed by the scan kernel (a memset is a launch of its own, 5 us)
@@ -1244,6 +1269,7 @@ extern "C" int dmpc_rows_one(dmpc_ctx *ctx, int N, int n, const double *l, const
     P.nrmax = (int)((want + 1) & ~1L);   // the exact worst case: nothing is pruned or truncated here
     P.ell_order = p.order;
     P.h = p.h; P.rmin = p.rmin; P.e1z = 1.0 / p.c; P.e2z = p.order == 4 ? 1.0 / (p.c * p.c * p.c * p.c) : 1.0 / (p.c * p.c);   // E1 = E^-1, E2 = E^-order
+    if (p.variant == DMPC_VAR_SCP) { P.e1z = 1.0; P.e2z = 1.0; }   // solveDMPC: plain Euclidean norm (CheckCollDMPC.m:6, CollConstrDMPC.m:12-13)
     P.alim = p.alim; P.Q1 = p.Q1; P.S1 = p.S1; P.term = p.term;
     for (int d = 0; d < 3; ++d) { P.pmin[d] = p.pmin[d]; P.pmax[d] = p.pmax[d]; }
     P.tables = ctx->d_tables; P.lT = ctx->lT.as<double>();
@@ -1987,7 +2013,38 @@ __global__ void reached_kernel(int N, const double *__restrict__ p, const double
     const double dx = p[3 * i] - pf[3 * i], dy = p[3 * i + 1] - pf[3 * i + 1], dz = p[3 * i + 2] - pf[3 * i + 2];
     if (!(sqrt(dx * dx + dy * dy + dz * dz) < tol)) atomicOr(bad, 1);
 }
+// maxDeviation.m:3-9: per step the distance between the two trajectories (non-negative doubles order like their bit patterns: integer maximum)
+__global__ void max_dev_kernel(int nsteps, const double *__restrict__ p, const double *__restrict__ q, unsigned long long *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nsteps) return;
+    const double dx = p[3 * i] - q[3 * i], dy = p[3 * i + 1] - q[3 * i + 1], dz = p[3 * i + 2] - q[3 * i + 2];
+    atomicMax(out, (unsigned long long)__double_as_longlong(sqrt(dx * dx + dy * dy + dz * dz)));
+}
 }   // namespace hp
+
+extern "C" int dmpc_max_deviation(dmpc_ctx *ctx, int K_cols, const double *p, const double *prev_p, double *tol_out)
+{
+    if (!ctx) { g_err = "dmpc_max_deviation: ctx is NULL"; return -1; }
+    if (K_cols < 1 || !p || !prev_p || !tol_out) FAIL(ctx, "dmpc_max_deviation: bad arguments");
+    // `K = length(p)/3; for k = 1:K` on the 3 x K_cols matrix (maxDeviation.m:3-5): length() = max(3, K_cols), the loop visits floor(that / 3) columns
+    const int nsteps = (K_cols > 3 ? K_cols : 3) / 3;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    if (ctx->hp_in.ensure((size_t)6 * nsteps * 8) || ctx->hp_out.ensure(16)) FAIL(ctx, "device allocation failed");
+    double *dp = ctx->hp_in.as<double>(), *dq = dp + 3 * nsteps;
+    unsigned long long *out = ctx->hp_out.as<unsigned long long>();
+    HIPCHK(ctx, hipMemcpyAsync(dp, p, (size_t)3 * nsteps * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(dq, prev_p, (size_t)3 * nsteps * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemsetAsync(out, 0, 8, st));
+    hipLaunchKernelGGL(hp::max_dev_kernel, dim3((unsigned)((nsteps + 63) / 64)), dim3(64), 0, st, nsteps, (const double *)dp, (const double *)dq, out);
+    HIPCHK(ctx, hipGetLastError());
+    unsigned long long bits = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&bits, out, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    std::memcpy(tol_out, &bits, 8);
+    return 0;
+}
 
 extern "C" int dmpc_prop_state(dmpc_ctx *ctx, int n_rows, int n_cols, const double *A_p, const double *A_v, const double *A_initp,
                                const double *po, const double *vo, const double *off_p, const double *off_v, const double *a,

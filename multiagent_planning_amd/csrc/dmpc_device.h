@@ -31,7 +31,8 @@ constexpr int NBR_PARTS = 16;   // nbr_kernel: the neighbours of a scene are spl
 constexpr int NBOX_NM = 20;     // floats per neighbour in the neighbour-major copy of the segment boxes (18 used; five 16-byte scalar loads)
 
 enum { VAR_BOUND = 0, VAR_BOUND2 = 1, VAR_ALL3 = 2, VAR_HARD = 3, VAR_ONDEMAND = 4, VAR_ELLIP = 5, VAR_SOFTALL = 6, VAR_REPAIR = 7,
-       VAR_CPP = 8, VAR_CPP2 = 9 /* dmpc/cpp solveQPv2 with _k_factor 0 / -1 */, VAR_CPP1 = 10 /* dmpc/cpp solveQP (first version, dmpc.cpp:554-801) */ };
+       VAR_CPP = 8, VAR_CPP2 = 9 /* dmpc/cpp solveQPv2 with _k_factor 0 / -1 */, VAR_CPP1 = 10 /* dmpc/cpp solveQP (first version, dmpc.cpp:554-801) */,
+       VAR_SOFTALL_C = 11 /* solveSoftDMPC_c.m */, VAR_SCP = 12 /* solveDMPC.m: the SCP loop (dmpc_scp_kernel) */ };
 enum { ST_SOLVED = 1, ST_OUTBOUND = 2, ST_COLL = 4, ST_INFEAS = 8, ST_CAPACITY = 16, ST_ITERCAP = 32,
        ST_QOVER = 64 /* internal: tier-1 working set overflowed, tier 2 re-solves */ };
 
@@ -85,6 +86,7 @@ struct StepParams {
     int n_ext;              // persistent solve kernel with a split T: extensions in the workgroup's pool (behind the waves' blocks)
     int *cost_out;          // [S*c_count] or null: work estimate of this agent's solve (quarter microseconds: iterations weighted by the working-set size,
                             // certificate calls) -- the NEXT step's launch order is built from it (order_kernel; dmpc_api.hip: order hint)
+    double scp_tol;         // VAR_SCP: `tol` of solveDMPC.m:1,17 (the loop stops when maxDeviation(p, prev_p) <= tol)
     int iter_cap;           // active-set iteration cap per try (ITER_CAP; development runs lower it to measure the per-iteration cost)
 };
 

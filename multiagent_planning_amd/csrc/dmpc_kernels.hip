@@ -160,6 +160,7 @@ struct Agent {   // wave-uniform agent data
 // cost case of solveSoftDMPCbound.m:43-58 (0 far, 1 near, 2 collision rows)
 __device__ __forceinline__ int cost_case(int var, double d0, double d1, double d2 /* po - pf */, bool rows_exist)
 {
+    if (var == VAR_SCP) return rows_exist ? 2 : 0;   // solveDMPC.m:38-48: `isempty(Ain_total)` alone decides (Q = 1000, S = 10, or Q1, S1)
     const double dn = sqrt(fma(d2, d2, fma(d1, d1, d0 * d0)));
     const bool far = (var == VAR_ELLIP) ? (dn > 1.0) : (dn >= 1.0);
     if (!rows_exist && far) return 0;
@@ -328,8 +329,11 @@ return empty_any;
 // register and LDS footprint free of the scan's needs (more resident agents per CU) and lets the solver be re-launched
 // for the few agents that overflow the tier-1 working-set capacity.
 // `vb`: the agent's index in the launch (already renumbered XCD-aware by the kernel); `smem`: this wave's LDS.
-template <bool SOFT, typename TT, bool FAST, bool ORD4 = false>
-__device__ __forceinline__ void scan_body(const StepParams &P, const int lane, const int vb, unsigned char *smem)
+// SCP (solveDMPC.m, dmpc_scp_kernel): `scp_prev` = prev_p of the pass (the previous pass's prediction of this agent, 45 doubles; null in the
+// first pass: the table's own column, solveDMPC.m:10), `scp_mask` = addConstr as a bit per horizon step (in / out).
+template <bool SOFT, typename TT, bool FAST, bool ORD4 = false, bool SCP = false>
+__device__ __forceinline__ void scan_body(const StepParams &P, const int lane, const int vb, unsigned char *smem,
+                                          const double *scp_prev = nullptr, unsigned *scp_mask = nullptr)
 {
     const int S = P.S, G = P.G, C = P.C, nrmax = P.nrmax;
     const int scene = vb / P.c_count, ci = vb - scene * P.c_count;
@@ -382,7 +386,7 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
     }
     // own previous prediction: prev_p = l(:,:,n)  (solveSoftDMPCbound.m:6)
     const TT *lT_own = tab + ((size_t)(P.g_local * S + scene) * N3) * C + cl;
-    if (lane < N3) own_s[lane] = lT_own[(size_t)lane * C];
+    if (lane < N3) own_s[lane] = (SCP && scp_prev) ? (real)scp_prev[lane] : lT_own[(size_t)lane * C];
     LSYNC();
     real po_[3], vo_[3];
 #pragma unroll
@@ -530,6 +534,15 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
                     if (var == VAR_BOUND2 || var == VAR_ALL3) slb = -0.01;           // bound2:77, all:92
                     else if (cppv) slb = -(real)0.01f;                              // dmpc.cpp:907-914,1079: -eps <= lim, float lim = 0.01
                     else if (var == VAR_SOFTALL) { sd = 1.0; st = -1e5; slb = -INFINITY; }  // solveSoftDMPC.m:21,65
+                    else if (var == VAR_SOFTALL_C) {
+                        // solveSoftDMPC_c.m:18-20,60-63: rows [Ainr I], cost EPS eps^2 + f_eps eps with EPS = 1e6 (K/k)^2, f_eps = -1e4 (K/k)^2, k the
+                        // violating step (1-based).  The solver's slack variables carry the unit weight of every other variant (H_eps = 2): substitute
+                        // eps = eps' / sqrt(EPS) -- the row's slack coefficient becomes 1 / sqrt(EPS), the linear cost f_eps / sqrt(EPS), the pin
+                        // eps <= 0 is eps' <= 0; the minimiser in a is the same.
+                        const double rk = (double)K / (double)(kc + 1), quad = 1.0 * 1e6 * (rk * rk), lin = -1.0 * 1e4 * (rk * rk);
+                        const double isq = 1.0 / sqrt(quad);
+                        sd = (real)isq; st = (real)(lin * isq); slb = -INFINITY;
+                    }
                     else if (var == VAR_CPP1) { sd = 1.0; st = -1e6; slb = -INFINITY; }     // dmpc.cpp:629-633,715: [A I] x <= b, eps <= 0, f_w = -10^6
                     else if (var == VAR_REPAIR) { st = P.term / pd; slb = -INFINITY; }      // repair:77,81 (term ./ prev_dist)
                     L.r_sd[pos] = sd; L.r_st[pos] = st; L.r_slb[pos] = slb;
@@ -726,9 +739,9 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
                     real nx[5], ny[5], nz[5];
     #pragma unroll
                     for (int u = 0; u < 5; ++u) {
-                        nx[u] = base[roff]; roff += (size_t)C; asm volatile("" : "+s"(roff));
-                        ny[u] = base[roff]; roff += (size_t)C; asm volatile("" : "+s"(roff));
-                        nz[u] = base[roff]; roff += (size_t)C; asm volatile("" : "+s"(roff));
+                        nx[u] = base[roff]; roff += (size_t)C; if (!SCP) asm volatile("" : "+s"(roff));   // (not in the SCP instantiation: inside dmpc_scp_kernel's pass loop the compiler keeps the offset in a vector register and refuses the constraint)
+                        ny[u] = base[roff]; roff += (size_t)C; if (!SCP) asm volatile("" : "+s"(roff));
+                        nz[u] = base[roff]; roff += (size_t)C; if (!SCP) asm volatile("" : "+s"(roff));
                     }
     #pragma unroll
                     for (int u = 0; u < 5; ++u) {
@@ -753,7 +766,22 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
                 }
             }
         }
-        if (var == VAR_HARD) {
+        if (SCP) {
+            // solveDMPC.m:21-35: CheckCollDMPC at every step of prev_p (anyb: the walk above with E1 = I); rows for ALL other agents at every step
+            // of addConstr, and at the FIRST violating step that is not in it yet (at most one new step per pass); ascending k = the reference's order
+            anyb = wave_or(anyb);
+            unsigned m = *scp_mask;
+            bool newc = false;
+            for (int k = 0; k < K; ++k) {
+                bool add = (m >> k) & 1u;
+                if (!add && !newc && ((anyb >> k) & 1u)) { add = true; newc = true; m |= 1u << k; }
+                if (add) build_rows(k, k, k, (real)0, true);
+            }
+            *scp_mask = m;
+            rows_exist = nrows_ref > 0;               // `isempty(Ain_total)` (:38)
+            violation = m != 0u;
+            viol_k = m ? __ffs((int)m) : 0;           // smallest member of addConstr, 1-based
+        } else if (var == VAR_HARD) {
             flush_candidates();
             rows_exist = (G * C - (P.short_from ? G - P.short_from : 0) > 1);   // preallocated zero rows make Ain_coll non-empty (CollConstrHardDMPC.m:3-4)
         } else {
@@ -905,7 +933,7 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
                 const double p_out = w_unc + p0_l;
                 double v_out = 0.0;
                 if (comp) v_out = vel_out(a_s, k_l, ax_l, Qp->h, vo_l);
-                const bool ob_check = !(var == VAR_ELLIP || var == VAR_SOFTALL || var == VAR_CPP1 || cppv);   // (as the solver's output stage)
+                const bool ob_check = !(var == VAR_ELLIP || var == VAR_SOFTALL || var == VAR_SOFTALL_C || var == VAR_SCP || var == VAR_CPP1 || cppv);   // (as the solver's output stage)
                 if (ob_check) {
                     const double tolb = 50e-3;
                     bool bad = false;
@@ -962,6 +990,56 @@ __global__ __launch_bounds__(64, SOLVE_WAVES_PER_SIMD) void dmpc_solve_kernel(St
 {
     int tk_unused = 0; bool cl_unused = false;
     solve_body<SOFT, QCAP, false, QCAP, TF>(P, threadIdx.x, blockIdx.x, gridDim.x, dmpc_smem, nullptr, false, tk_unused, cl_unused);
+}
+
+// solveDMPC.m:17-72, the SCP loop of ONE agent inside one launch: every pass is the scan (CheckCollDMPC + CollConstrDMPC about the previous
+// pass's prediction, scan_body<.., SCP>) followed by the slack-free QP (solve_body) of the same wave; between the two and between passes the
+// agent's rows, header and outputs travel through its slices of the global scratch / output arrays (same wave, same CU: workgroup-scope fences
+// order them).  The loop ends when the pass's largest position change is <= tol (maxDeviation.m), after k_hor passes, or with the first
+// infeasible pass (`success = 0`, :58-63).  Scan and solver use the same LDS one after the other.
+__global__ __launch_bounds__(64, SOLVE_WAVES_PER_SIMD) void dmpc_scp_kernel(StepParams P)
+{
+    const int lane = (int)threadIdx.x;
+    const int nb = (int)gridDim.x, x = (int)blockIdx.x & 7, y = (int)blockIdx.x >> 3;
+    int off = 0;
+    for (int xx = 0; xx < x; ++xx) off += (nb - xx + 7) >> 3;
+    const int vb = off + y;   // (solve_body renumbers blockIdx the same way)
+    const int scene = vb / P.c_count, ci = vb - scene * P.c_count, gid = scene * P.c_count + ci;
+    if (P.zero4 && blockIdx.x == 0 && threadIdx.x < 4) P.zero4[threadIdx.x] = 0;
+    unsigned mask = 0u;
+    double prev_l = 0.0;
+    if (lane < N3) prev_l = P.lT[((size_t)(P.g_local * P.S + scene) * N3 + lane) * P.C + P.c_first + ci];   // prev_p = l(:,:,n) (:10)
+    int passes = 0, iters_sum = 0, st = 0;
+    const double *own_out = P.p_out + (size_t)gid * N3;
+    for (int i = 1; i <= K; ++i) {   // `while (i <= k_hor && val > tol)` (:17); val = tol + 2 before the first pass
+        scan_body<false, double, false, false, true>(P, lane, vb, dmpc_smem, i > 1 ? own_out : nullptr, &mask);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        LSYNC();
+        if (UNI(P.hdr[(size_t)gid * 8 + 4]) & 8) return;   // scene of a transition that already stopped
+        int tk_unused = 0; bool cl_unused = false;
+        solve_body<false, 48, false>(P, lane, (int)blockIdx.x, nb, dmpc_smem, nullptr, false, tk_unused, cl_unused);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        LSYNC();
+        ++passes;
+        st = UNI(P.status[gid]);
+        if (P.info) iters_sum += UNI(P.info[(size_t)gid * 8 + 4]);
+        if (!(st & ST_SOLVED)) break;
+        // val = maxDeviation(p, prev_p) (:69): maxDeviation.m:3 takes K = length(p)/3 of the 3 x k_hor matrix -- the first max(3, k_hor)/3 = 5 steps
+        const double new_l = lane < N3 ? own_out[lane] : 0.0;
+        const double dl = new_l - prev_l, d2 = dl * dl;
+        // (lanes 3k: the squared distance of step k; the maximum over the first five steps through the fixed-order wave reduction)
+        const double s3 = (d2 + dpp_row_shl<1>(d2)) + dpp_row_shl<2>(d2);
+        const bool head = lane < 3 * ((K > 3 ? K : 3) / 3) && (lane % 3) == 0 && (lane & 15) <= 13;
+        double val = wave_max(head ? sqrt(s3) : 0.0);
+        {   // steps whose three lanes straddle a 16-lane row (step 5 = lanes 15..17 is beyond the five steps looked at: none here)
+            static_assert(((K > 3 ? K : 3) / 3) * 3 <= 16, "maxDeviation: the steps looked at lie in the first DPP row");
+        }
+        prev_l = new_l;   // (:70)
+        if (!(val > P.scp_tol)) break;
+    }
+    if (lane == 0 && P.info) { P.info[(size_t)gid * 8 + 2] = passes; P.info[(size_t)gid * 8 + 4] = iters_sum; }
 }
 
 // Persistent form of the solve phase: one workgroup of up to 8 independent waves per CU (two per SIMD).  The Gram tables of the three

@@ -1577,7 +1577,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
         a_out = a;
     }
     if (solved) {
-        const bool ob_check = !(var == VAR_ELLIP || var == VAR_SOFTALL || var == VAR_CPP1 || cppv);   // solveQPv2 / solveQP have no in-bounds test
+        const bool ob_check = !(var == VAR_ELLIP || var == VAR_SOFTALL || var == VAR_SOFTALL_C || var == VAR_SCP || var == VAR_CPP1 || cppv);   // solveQPv2 / solveQP / solveSoftDMPC[_c] / solveDMPC have no in-bounds test
         if (h1.x & 4) status |= ST_COLL;   // cpp: collision noticed at the first step, solution still returned
         if (ob_check) {   // is_inbounds.m:2-5 on p(:,1)
             const double tolb = 50e-3;

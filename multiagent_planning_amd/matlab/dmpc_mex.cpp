@@ -19,6 +19,7 @@
 //   [pk,vk,ak,K_T_used,scene_status] = dmpc_mex('transition', params, po, pf, K_T_max, error_tol)   the whole k-loop on the GPU
 //   inbounds       = dmpc_mex('is_inbounds', params, p, pmin, pmax)                    is_inbounds.m
 //   pass           = dmpc_mex('reached_goal', params, p, pf, error_tol)                ReachedGoal.m
+//   tol            = dmpc_mex('max_deviation', params, p, prev_p)                      maxDeviation.m (p, prev_p: 3 x K)
 //   [po,pf]        = dmpc_mex('random_test', params, N, pmin, pmax, rmin, c, seed)      randomTest.m
 //   [po,pf]        = dmpc_mex('random_exchange', params, N, pmin, pmax, rmin, seed)     randomExchange.m
 // `params` is a struct with the fields of dmpc_params (variant as the DMPC_VAR_* integer).
@@ -65,6 +66,9 @@ static dmpc_params read_params(const mxArray *s)
     // optional: weights of the collision-free cost cases (0 = the reference's HEAD constants)
     const mxArray *qf = mxGetField(s, 0, "Qfar"), *qn = mxGetField(s, 0, "Qnear"), *sf = mxGetField(s, 0, "Sfree");
     p.Qfar = qf ? mxGetScalar(qf) : 0.0; p.Qnear = qn ? mxGetScalar(qn) : 0.0; p.Sfree = sf ? mxGetScalar(sf) : 0.0;
+    // optional: `tol` of solveDMPC.m:1 (DMPC_VAR_SCP)
+    const mxArray *tl = mxGetField(s, 0, "tol");
+    p.tol = tl ? mxGetScalar(tl) : 0.0;
     return p;
 }
 
@@ -272,6 +276,14 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
         if (dmpc_reached_goal(ctx, (int)mxGetN(prhs[2]), mxGetPr(prhs[2]), mxGetPr(prhs[3]), mxGetScalar(prhs[4]), &ok))
             mexErrMsgIdAndTxt("dmpc:reached_goal", "%s", dmpc_last_error(ctx));
         plhs[0] = mxCreateDoubleScalar(ok ? 1.0 : 0.0);   // (a double 0/1: `if (...)` and `&&` in the scripts take it like the logical of the .m file)
+        return;
+    }
+    if (!std::strcmp(cmd, "max_deviation")) {   // maxDeviation.m:1-11: p, prev_p are 3 x K (column-major = [K][3])
+        need(nrhs == 4 && mxGetM(prhs[2]) == 3 && mxGetNumberOfElements(prhs[3]) == mxGetNumberOfElements(prhs[2]), "max_deviation: (cmd, params, p(3 x K), prev_p(3 x K))");
+        double tol = 0.0;
+        if (dmpc_max_deviation(ctx, (int)mxGetN(prhs[2]), mxGetPr(prhs[2]), mxGetPr(prhs[3]), &tol))
+            mexErrMsgIdAndTxt("dmpc:max_deviation", "%s", dmpc_last_error(ctx));
+        plhs[0] = mxCreateDoubleScalar(tol);
         return;
     }
     if (!std::strcmp(cmd, "rows_one")) {   // CheckCollSoftDMPC.m + CollConstr*DMPC.m of the context's variant, structured rows

@@ -413,7 +413,7 @@ static double edist_o(const double *p, const double *pj, double c, int order)
 static int order_ok(const orc_params *prm)
 {
     if (prm->order == 2) return 1;
-    return prm->order == 4 && (prm->variant == ORC_SOFTALL || prm->variant == ORC_ELLIP || prm->variant == ORC_REPAIR || prm->variant == ORC_CPP1);
+    return prm->order == 4 && (prm->variant == ORC_SOFTALL || prm->variant == ORC_SOFTALL_C || prm->variant == ORC_ELLIP || prm->variant == ORC_REPAIR || prm->variant == ORC_CPP1);
 }
 
 typedef struct {
@@ -518,6 +518,10 @@ static double cpp_near_radius(double rmin, int k0, int K)
     return (double)r;
 }
 
+static int scp_check_coll(const double *p, const double *l, int N, int n, int k, int n3, double rmin);
+static void scp_coll_constr(const ctx_t *c, const orc_params *prm, const double *p, const double *l, int N, int n, int k,
+                            const double x0[6], rows_t *R);
+
 /* solveSoftDMPCbound.m:21-38 and the corresponding loops of the other variants */
 static scan_t scan_and_rows(const ctx_t *c, const orc_params *prm, int N, int n, const double *l,
                             const double x0[6], rows_t *R)
@@ -527,6 +531,16 @@ static scan_t scan_and_rows(const ctx_t *c, const orc_params *prm, int N, int n,
     const int K = c->K, n3 = c->n3, var = prm->variant;
     const double rmin = prm->rmin;
     const double *own = &l[(size_t)n * n3];
+    if (var == ORC_SCP) {
+        /* the FIRST pass of solveDMPC.m:21-35 (prev_p = l(:,:,n), addConstr = []): rows for every other agent at the first violating step */
+        for (int k = 1; k <= K; ++k)
+            if (scp_check_coll(&own[3 * (k - 1)], l, N, n, k, n3, rmin)) {
+                scp_coll_constr(c, prm, &own[3 * (k - 1)], l, N, n, k, x0, R);
+                sc.viol_k = k; sc.nv = N - 1; sc.nblocks = 1; sc.rows_exist = R->nrows > 0; sc.violation = 1;
+                break;
+            }
+        return sc;
+    }
     if (var == ORC_HARD) {
         /* solveHardDMPC.m:18-22 + CollConstrHardDMPC.m:11-31: every k, every j with dist < 1 */
         for (int k = 1; k <= K; ++k)
@@ -612,17 +626,21 @@ typedef struct {
     double lin;          /* linear cost term (per-row divided by dist if lin_over_dist) */
     int lin_over_dist;
     int ub_as_row;       /* solveSoftDMPC.m:21-23: eps <= 0 as extra rows (same maths) */
+    double quad;         /* weight of eps^2 in the cost: EPS = quad * I (solveSoftDMPCbound.m:85-86: 1; solveSoftDMPC_c.m:63: 1e6 (K/k)^2) */
 } slackcfg_t;
 
 static slackcfg_t slack_cfg(const orc_params *prm)
 {
     slackcfg_t s;
     memset(&s, 0, sizeof(s));
+    s.quad = 1.0;
     switch (prm->variant) {
     case ORC_BOUND: s.has_slack = 1; s.coef_is_dist = 1; s.lb = -0.05; s.lin = prm->term; break;   /* :34,78,82 */
     case ORC_BOUND2: s.has_slack = 1; s.coef_is_dist = 1; s.lb = -0.01; s.lin = prm->term; break;  /* bound2:77 */
     case ORC_ALL3: s.has_slack = 1; s.coef_is_dist = 1; s.lb = -0.01; s.lin = prm->term; break;    /* all:92 */
     case ORC_SOFTALL: s.has_slack = 1; s.coef_is_dist = 0; s.lb = -INFINITY; s.lin = -1e5; s.ub_as_row = 1; break; /* solveSoftDMPC.m:21,65 */
+    case ORC_SOFTALL_C: /* solveSoftDMPC_c.m:18-20,60-63: [Ainr I; 0 I], f_eps = -1e4 (K/k)^2, EPS = 1e6 (K/k)^2 -- k is only known after the scan: slack_cfg_c */
+        s.has_slack = 1; s.coef_is_dist = 0; s.lb = -INFINITY; s.lin = -1e4; s.quad = 1e6; s.ub_as_row = 1; break;
     case ORC_CPP: case ORC_CPP2: /* dmpc.cpp:907-914: eps <= 0, -eps <= lim with float lim = 0.01 (:1079); term = -1e6 via params */
         s.has_slack = 1; s.coef_is_dist = 1; s.lb = -(double)0.01f; s.lin = prm->term; break;
     case ORC_CPP1: /* dmpc.cpp:629-633 [A_coll I; 0 I] x <= [b; 0]: coefficient 1, eps <= 0, no lower bound; f_w = -10^6 (:715), W = I (:719) */
@@ -631,6 +649,15 @@ static slackcfg_t slack_cfg(const orc_params *prm)
     default: break;
     }
     return s;
+}
+
+/* solveSoftDMPC_c.m:60-63: `f_eps = -1*10^4*(K/k)^2*[...]`, `EPS = 1*10^6*(K/k)^2*[...]` with k the horizon step the scan broke at */
+static void slack_cfg_c(slackcfg_t *s, const orc_params *prm, int K, int viol_k)
+{
+    if (prm->variant != ORC_SOFTALL_C || viol_k < 1) return;
+    const double r = (double)K / (double)viol_k;
+    s->lin = -1.0 * 1e4 * (r * r);
+    s->quad = 1.0 * 1e6 * (r * r);
 }
 
 typedef struct {
@@ -715,6 +742,180 @@ static void cost_case(const orc_params *prm, const scan_t *sc, const double po[3
     else { *qw = prm->Q1; *sw = (prm->variant == ORC_ALL3) ? 10 : prm->S1; *which = 2; } /* :53-57; all:71 */
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* solveDMPC.m:1-74 -- the legacy spherical SCP loop                                          */
+/* ------------------------------------------------------------------------------------------ */
+
+/* CheckCollDMPC.m:1-10: any other agent i with norm(p - l(:,k,i)) < r_min (plain Euclidean norm: no E1) */
+static int scp_check_coll(const double *p, const double *l, int N, int n, int k, int n3, double rmin)
+{
+    int violation = 0;
+    for (int i = 0; i < N; ++i) {
+        if (i == n) continue;
+        const double *pj = &l[(size_t)i * n3 + 3 * (k - 1)];
+        const double dist = sqrt((p[0] - pj[0]) * (p[0] - pj[0]) + (p[1] - pj[1]) * (p[1] - pj[1]) + (p[2] - pj[2]) * (p[2] - pj[2]));
+        violation = violation || (dist < rmin);
+    }
+    return violation;
+}
+
+/* CollConstrDMPC.m:1-34: one row per other agent i at horizon step k, linearised about the GIVEN p (prev_p(:,k) of the SCP loop):
+ *   dist = norm(p - pj(:,k));  diff = (p - pj(:,k))';
+ *   r = dist*(r_min - dist + (p - pj(:,k))'*p/dist) - (p - pj(:,k))'*A_initp(3(k-1)+1:3k,:)*[po';vo'];      (:16)
+ *   Ain_total = [Ain_total; -diff_mat*Ain];  bin_total = [bin_total; -r]                                  (:23-24) */
+static void scp_coll_constr(const ctx_t *c, const orc_params *prm, const double *p, const double *l, int N, int n, int k,
+                            const double x0[6], rows_t *R)
+{
+    const int n3 = c->n3;
+    for (int i = 0; i < N; ++i) {
+        if (i == n) continue;
+        const double *pj = &l[(size_t)i * n3 + 3 * (k - 1)];
+        const double diff[3] = {p[0] - pj[0], p[1] - pj[1], p[2] - pj[2]};
+        const double dist = sqrt(diff[0] * diff[0] + diff[1] * diff[1] + diff[2] * diff[2]);
+        const double dp = diff[0] * p[0] + diff[1] * p[1] + diff[2] * p[2];
+        double da = 0.0;
+        for (int t = 0; t < 3; ++t) {
+            const double *a0 = &c->A0[(size_t)(3 * (k - 1) + t) * 6];
+            double s = 0.0;
+            for (int u = 0; u < 6; ++u) s += a0[u] * x0[u];
+            da += diff[t] * s;
+        }
+        const double r = dist * (prm->rmin - dist + dp / dist) - da;
+        rows_push(R, n3);
+        double *g = &R->G[(size_t)(R->nrows - 1) * n3];
+        for (int jj = 0; jj < n3; ++jj) {
+            double s = 0.0;
+            for (int t = 0; t < 3; ++t) s += diff[t] * c->Lam[(size_t)(3 * (k - 1) + t) * n3 + jj];
+            g[jj] = -s;
+        }
+        R->b[R->nrows - 1] = -r;
+        R->dist[R->nrows - 1] = dist;
+    }
+}
+
+/* maxDeviation.m:1-11.  `K = length(p)/3` is taken of the 3 x k_hor MATRIX p: length() = max(3, k_hor), so the loop `for k = 1:K` visits
+ * only the first max(3, k_hor)/3 horizon steps (5 of 15) -- restated as written. */
+static double scp_max_deviation(const double *p, const double *prev_p, int K)
+{
+    const int len = K > 3 ? K : 3;
+    const int kmax = len / 3;   /* 1:K with K = len/3: k = 1 .. floor(K) */
+    double tol = 0.0;           /* max() of an empty `dist` would be [] in MATLAB; k_hor >= 3 here */
+    for (int k = 0; k < kmax; ++k) {
+        const double d0 = p[3 * k] - prev_p[3 * k], d1 = p[3 * k + 1] - prev_p[3 * k + 1], d2 = p[3 * k + 2] - prev_p[3 * k + 2];
+        const double dist = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+        if (k == 0 || dist > tol) tol = dist;
+    }
+    return tol;
+}
+
+/* solveDMPC.m:1-74.  `last`: optional export of the LAST pass's QP (certificates): its rows, cost weights and multipliers.
+ * info: VIOLK = smallest member of addConstr (0: none), NV = |addConstr|, TRIES = SCP passes made, CASE = 0 / 2 of the last pass,
+ * ITERS = active-set iterations of all passes, NROWS = collision rows of the last pass. */
+typedef struct { qp_t qp; double qw, sw; int valid; } scp_last_t;
+static int solve_scp(ctx_t *c, const orc_params *prm, int N, int n, const double *l, const double po[3], const double vo[3],
+                     const double ao[3], const double pf[3], double *p, double *v, double *a, int *info, double *obj, scp_last_t *last)
+{
+    const int n3 = c->n3, K = c->K;   /* k_hor = size(l,2) (:4) */
+    double x0[6] = {po[0], po[1], po[2], vo[0], vo[1], vo[2]};
+    const double tol = prm->tol;
+    double val = tol + 2;             /* :5 */
+    int i = 1;                        /* :8 */
+    unsigned char in_add[MAXK + 1];   /* addConstr (:9) as a membership table */
+    memset(in_add, 0, sizeof(in_add));
+    double prev_p[3 * MAXK], pn[3 * MAXK], vn[3 * MAXK], an[3 * MAXK];
+    memcpy(prev_p, &l[(size_t)n * n3], sizeof(double) * n3);   /* prev_p = l(:,:,n) (:10) */
+    slackcfg_t sl;
+    memset(&sl, 0, sizeof(sl));
+    sl.quad = 1.0;
+    int status = ORC_ST_INFEAS, which = 0, nrows_last = 0;
+    while (i <= K && val > tol) {     /* :17 */
+        int newConstrCount = 0;       /* :18 */
+        rows_t R;
+        memset(&R, 0, sizeof(R));
+        for (int k = 1; k <= K; ++k) {   /* :21-35 */
+            const int violation = scp_check_coll(&prev_p[3 * (k - 1)], l, N, n, k, n3, prm->rmin);
+            if (in_add[k]) scp_coll_constr(c, prm, &prev_p[3 * (k - 1)], l, N, n, k, x0, &R);
+            else if (newConstrCount == 0 && violation) {
+                scp_coll_constr(c, prm, &prev_p[3 * (k - 1)], l, N, n, k, x0, &R);
+                in_add[k] = 1;
+                newConstrCount = newConstrCount + 1;
+            }
+        }
+        /* :38-48: isempty(Ain_total) -> Q = 1000, S = 10; else Q1, S1 */
+        double qw, sw;
+        if (R.nrows == 0) { qw = prm->Qfar > 0 ? prm->Qfar : 1000; sw = prm->Sfree > 0 ? prm->Sfree : 10; which = 0; }
+        else { qw = prm->Q1; sw = prm->S1; which = 2; }
+        hcase_t *hc = ctx_case(c, qw, sw);
+        scan_t sc;
+        memset(&sc, 0, sizeof(sc));
+        qp_t qp;
+        assemble(c, prm, &R, &sc, &sl, qw, sw, 0.0, 0.0, x0, ao, pf, &qp);   /* :50-54: [rows; A; -A], lb/ub, H, f */
+        nrows_last = R.nrows;
+        double *J = (double *)calloc((size_t)n3 * n3, sizeof(double));
+        for (int j = 0; j < n3; ++j)
+            for (int ii = 0; ii < n3; ++ii) J[ii + (size_t)n3 * j] = hc->Linv[(size_t)j * n3 + ii];
+        double x[3 * MAXK], tmp[3 * MAXK];
+        for (int j = 0; j < n3; ++j) {
+            double s = 0.0;
+            for (int ii = 0; ii < n3; ++ii) s += J[ii + (size_t)n3 * j] * qp.f[ii];
+            tmp[j] = s;
+        }
+        for (int ii = 0; ii < n3; ++ii) {
+            double s = 0.0;
+            for (int j = 0; j < n3; ++j) s += J[ii + (size_t)n3 * j] * tmp[j];
+            x[ii] = -s;
+        }
+        double *lam = (double *)malloc(sizeof(double) * qp.m);
+        int iters = 0, nact = 0;
+        const int rc = gi_core(n3, qp.m, J, x, qp.C, qp.d, lam, &iters, &nact);   /* quadprog (:57) */
+        free(lam);
+        info[ORC_I_ITERS] += iters;
+        double objv = 0.0;
+        if (rc == 0)
+            for (int ii = 0; ii < n3; ++ii) {
+                double s = 0.0;
+                for (int j = 0; j < n3; ++j) s += hc->H[(size_t)ii * n3 + j] * x[j];
+                objv += 0.5 * x[ii] * s + qp.f[ii] * x[ii];
+            }
+        if (last) { if (last->valid) qp_free(&last->qp); last->qp = qp; last->qw = qw; last->sw = sw; last->valid = 1; }
+        else qp_free(&qp);
+        free(R.G); free(R.b); free(R.dist);
+        if (rc != 0) {   /* :58-63: isempty(a) -> p = [], v = [], success = 0 */
+            status = ORC_ST_INFEAS;
+            break;
+        }
+        memcpy(an, x, sizeof(double) * n3);
+        for (int ii = 0; ii < n3; ++ii) {   /* propStatedmpc (:65; the stale 4-argument call: p = A a + A_initp [po;vo], v = A_v a + vo) */
+            double sp = 0.0, sv = 0.0;
+            for (int j = 0; j < n3; ++j) {
+                sp += c->Lam[(size_t)ii * n3 + j] * an[j];
+                sv += c->Av[(size_t)ii * n3 + j] * an[j];
+            }
+            double s0 = 0.0;
+            for (int u = 0; u < 6; ++u) s0 += c->A0[(size_t)ii * 6 + u] * x0[u];
+            pn[ii] = sp + s0;
+            vn[ii] = sv + vo[ii % 3];
+        }
+        if (obj) *obj = objv;
+        info[ORC_I_NACTIVE] = nact;
+        status = ORC_ST_SOLVED;
+        val = scp_max_deviation(pn, prev_p, K);   /* :69 */
+        memcpy(prev_p, pn, sizeof(double) * n3);  /* :70 */
+        i = i + 1;                                /* :71 */
+    }
+    int nadd = 0, kmin = 0;
+    for (int k = K; k >= 1; --k) if (in_add[k]) { nadd++; kmin = k; }
+    info[ORC_I_VIOLK] = kmin;
+    info[ORC_I_NV] = nadd;
+    info[ORC_I_TRIES] = status == ORC_ST_SOLVED ? i - 1 : i;
+    info[ORC_I_CASE] = which;
+    info[ORC_I_NROWS] = nrows_last;
+    if (status == ORC_ST_SOLVED) {
+        memcpy(p, pn, sizeof(double) * n3); memcpy(v, vn, sizeof(double) * n3); memcpy(a, an, sizeof(double) * n3);
+    }
+    return status;
+}
+
 static int solve_ctx(ctx_t *c, const orc_params *prm, int N, int n, const double *l, const double po[3],
                      const double vo[3], const double ao[3], const double pf[3], double *p, double *v,
                      double *a, int *info, double *obj)
@@ -723,6 +924,7 @@ static int solve_ctx(ctx_t *c, const orc_params *prm, int N, int n, const double
     int dummy[ORC_INFO_LEN];
     if (!info) info = dummy;
     memset(info, 0, sizeof(int) * ORC_INFO_LEN);
+    if (prm->variant == ORC_SCP) return solve_scp(c, prm, N, n, l, po, vo, ao, pf, p, v, a, info, obj, NULL);
     double x0[6] = {po[0], po[1], po[2], vo[0], vo[1], vo[2]};
     rows_t R;
     memset(&R, 0, sizeof(R));
@@ -737,6 +939,7 @@ static int solve_ctx(ctx_t *c, const orc_params *prm, int N, int n, const double
     info[ORC_I_CASE] = which;
     hcase_t *hc = ctx_case(c, qw, sw);
     slackcfg_t sl = slack_cfg(prm);
+    slack_cfg_c(&sl, prm, c->K, sc.viol_k);
     const int cppv = (prm->variant == ORC_CPP || prm->variant == ORC_CPP2);
     const int ladder = (prm->variant == ORC_BOUND || prm->variant == ORC_BOUND2 || prm->variant == ORC_ALL3 || cppv);
     /* cpp: one solve + `while (status && tries < 20)` retries (dmpc.cpp:1081) */
@@ -747,11 +950,11 @@ static int solve_ctx(ctx_t *c, const orc_params *prm, int N, int n, const double
         qp_t qp;
         assemble(c, prm, &R, &sc, &sl, qw, sw, lbs, lin, x0, ao, pf, &qp);
         const int nn = qp.n;
-        /* J = blkdiag(L^{-T}, I/sqrt(2)) : slack block of H is 2*EPS = 2I (:85-86,98) */
+        /* J = blkdiag(L^{-T}, I/sqrt(2 quad)) : slack block of H is 2*EPS = 2 quad I (:85-86,98; quad = 1 but for solveSoftDMPC_c.m:63) */
         double *J = (double *)calloc((size_t)nn * nn, sizeof(double));
         for (int j = 0; j < n3; ++j)
             for (int i = 0; i < n3; ++i) J[i + (size_t)nn * j] = hc->Linv[(size_t)j * n3 + i];
-        for (int i = n3; i < nn; ++i) J[i + (size_t)nn * i] = 1.0 / sqrt(2.0);
+        for (int i = n3; i < nn; ++i) J[i + (size_t)nn * i] = 1.0 / sqrt(2.0 * sl.quad);
         double *x = (double *)malloc(sizeof(double) * nn);
         double *tmp = (double *)malloc(sizeof(double) * nn);
         for (int j = 0; j < nn; ++j) {
@@ -790,7 +993,7 @@ static int solve_ctx(ctx_t *c, const orc_params *prm, int N, int n, const double
                     for (int j = 0; j < n3; ++j) s += hc->H[(size_t)i * n3 + j] * x[j];
                     o += 0.5 * x[i] * s + qp.f[i] * x[i];
                 }
-                for (int i = n3; i < nn; ++i) o += x[i] * x[i] + qp.f[i] * x[i];
+                for (int i = n3; i < nn; ++i) o += sl.quad * x[i] * x[i] + qp.f[i] * x[i];
                 *obj = o;
             }
             int nsl = 0;
@@ -799,7 +1002,7 @@ static int solve_ctx(ctx_t *c, const orc_params *prm, int N, int n, const double
             info[ORC_I_NSLACK] = nsl;
             info[ORC_I_NACTIVE] = nact;
             status = ORC_ST_SOLVED;
-            const int ob_check = !(prm->variant == ORC_ELLIP || prm->variant == ORC_SOFTALL || cppv || prm->variant == ORC_CPP1); /* solveQPv2 / solveQP have no in-bounds test */
+            const int ob_check = !(prm->variant == ORC_ELLIP || prm->variant == ORC_SOFTALL || prm->variant == ORC_SOFTALL_C || cppv || prm->variant == ORC_CPP1); /* solveQPv2 / solveQP have no in-bounds test */
             if (sc.coll_flag) status |= ORC_ST_COLL;
             if (ob_check && !in_bounds(p, prm->pmin, prm->pmax)) status |= ORC_ST_OUTBOUND; /* :125-128 */
             free(x); free(lam); qp_free(&qp);
@@ -971,6 +1174,27 @@ int orc_assemble_one(const orc_params *prm, int N, int n, const double *l, const
     if (!order_ok(prm) || prm->K < 1 || prm->K > MAXK) return -1;
     ctx_t *c = ctx_new(prm->h, prm->K);
     const int n3 = c->n3;
+    if (prm->variant == ORC_SCP) {   /* the QP of the LAST pass of the SCP loop (the one whose minimiser solveDMPC returns, or that proved infeasible) */
+        scp_last_t last;
+        memset(&last, 0, sizeof(last));
+        double pp[3 * MAXK], vv[3 * MAXK], aa[3 * MAXK];
+        int inf[ORC_INFO_LEN];
+        memset(inf, 0, sizeof(inf));
+        (void)level;
+        solve_scp(c, prm, N, n, l, po, vo, ao, pf, pp, vv, aa, inf, NULL, &last);
+        *n_out = last.qp.n; *m_out = last.qp.m;
+        if (ncoll_out) *ncoll_out = inf[ORC_I_NROWS];
+        if (H) {
+            hcase_t *hc = ctx_case(c, last.qw, last.sw);
+            for (int i = 0; i < n3; ++i) memcpy(&H[(size_t)i * n3], &hc->H[(size_t)i * n3], sizeof(double) * n3);
+            memcpy(f, last.qp.f, sizeof(double) * n3);
+            memcpy(C, last.qp.C, sizeof(double) * (size_t)last.qp.m * n3);
+            memcpy(d, last.qp.d, sizeof(double) * last.qp.m);
+        }
+        qp_free(&last.qp);
+        ctx_free(c);
+        return 0;
+    }
     double x0[6] = {po[0], po[1], po[2], vo[0], vo[1], vo[2]};
     rows_t R;
     memset(&R, 0, sizeof(R));
@@ -983,6 +1207,7 @@ int orc_assemble_one(const orc_params *prm, int N, int n, const double *l, const
         cost_case(prm, &sc, po, pf, &qw, &sw, &which);
         hcase_t *hc = ctx_case(c, qw, sw);
         slackcfg_t sl = slack_cfg(prm);
+        slack_cfg_c(&sl, prm, c->K, sc.viol_k);
         qp_t qp;
         assemble(c, prm, &R, &sc, &sl, qw, sw, ldexp(sl.lb, level), ldexp(sl.lin, level), x0, ao, pf, &qp);
         *n_out = qp.n; *m_out = qp.m;
@@ -990,7 +1215,7 @@ int orc_assemble_one(const orc_params *prm, int N, int n, const double *l, const
         if (H) {
             memset(H, 0, sizeof(double) * (size_t)qp.n * qp.n);
             for (int i = 0; i < n3; ++i) memcpy(&H[(size_t)i * qp.n], &hc->H[(size_t)i * n3], sizeof(double) * n3);
-            for (int i = n3; i < qp.n; ++i) H[(size_t)i * qp.n + i] = 2.0;
+            for (int i = n3; i < qp.n; ++i) H[(size_t)i * qp.n + i] = 2.0 * sl.quad;
             memcpy(f, qp.f, sizeof(double) * qp.n);
             memcpy(C, qp.C, sizeof(double) * (size_t)qp.m * qp.n);
             memcpy(d, qp.d, sizeof(double) * qp.m);

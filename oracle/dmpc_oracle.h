@@ -35,7 +35,9 @@ enum {
     ORC_REPAIR = 7,     /* solveSoftDMPCrepair.m       */
     ORC_CPP = 8,        /* dmpc/cpp DMPC::solveQPv2, _k_factor = 0  (dmpc.cpp:803-1287) */
     ORC_CPP2 = 9,       /* dmpc/cpp DMPC::solveQPv2, _k_factor = -1                      */
-    ORC_CPP1 = 10       /* dmpc/cpp DMPC::solveQP (the first version: dmpc.cpp:554-801; rows for ALL N-1 neighbours, check_collisions :378-396, build_collconstraint :450-498) */
+    ORC_CPP1 = 10,      /* dmpc/cpp DMPC::solveQP (the first version: dmpc.cpp:554-801; rows for ALL N-1 neighbours, check_collisions :378-396, build_collconstraint :450-498) */
+    ORC_SOFTALL_C = 11, /* solveSoftDMPC_c.m (solveSoftDMPC with slack penalties -1e4 (K/k)^2, 1e6 (K/k)^2, :60-63; test/comp_confidence.m:184) */
+    ORC_SCP = 12        /* solveDMPC.m (the legacy spherical SCP loop, :17-72; dmpc/matlab/dmpc.m:79, test/success_test_dmpc.m:80) */
 };
 
 /* status bits returned per agent */
@@ -49,7 +51,7 @@ enum {
 typedef struct {
     int K;          /* horizon length k_hor (15)                         */
     int variant;    /* ORC_*                                             */
-    int order;      /* ellipsoid order: 2; 4 for the all-neighbour variants (softall, ellip, repair, cpp1) */
+    int order;      /* ellipsoid order: 2; 4 for the all-neighbour variants (softall, softall_c, ellip, repair, cpp1) */
     int max_tries;  /* <=0: reference default (30; repair: 10; cpp: 21)  */
     double h;       /* time step                                         */
     double rmin;    /* collision radius                                  */
@@ -59,6 +61,7 @@ typedef struct {
     double term;    /* linear slack penalty (negative)                   */
     double pmin[3], pmax[3];
     double Qfar, Qnear, Sfree; /* collision-free cost cases; 0 = HEAD constants 1000 / 10000 / 10 (solveSoftDMPCbound.m:44-52) */
+    double tol;     /* ORC_SCP only: `tol` of solveDMPC.m:1,17 (stop when maxDeviation(p, prev_p) <= tol)                   */
 } orc_params;
 
 /* info[] layout (8 ints per agent) */

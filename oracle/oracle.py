@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "libdmpc_oracle.so")
 
-VARIANTS = dict(bound=0, bound2=1, all3=2, hard=3, ondemand=4, ellip=5, softall=6, repair=7, cpp=8, cpp2=9, cpp1=10)
+VARIANTS = dict(bound=0, bound2=1, all3=2, hard=3, ondemand=4, ellip=5, softall=6, repair=7, cpp=8, cpp2=9, cpp1=10, softall_c=11, scp=12)
 ST_SOLVED, ST_OUTBOUND, ST_COLL, ST_INFEAS = 1, 2, 4, 8
 INFO_LEN = 8
 I_VIOLK, I_NV, I_TRIES, I_CASE, I_ITERS, I_NSLACK, I_NACTIVE, I_NROWS = range(8)
@@ -25,6 +25,7 @@ class Params(C.Structure):
         ("Q1", C.c_double), ("S1", C.c_double), ("term", C.c_double),
         ("pmin", C.c_double * 3), ("pmax", C.c_double * 3),
         ("Qfar", C.c_double), ("Qnear", C.c_double), ("Sfree", C.c_double),
+        ("tol", C.c_double),
     ]
 
 
@@ -78,11 +79,12 @@ def _f(a):
 
 
 def make_params(variant, K=15, h=0.2, rmin=0.35, c=2.0, alim=1.0, Q1=1000.0, S1=100.0, term=-5e4,
-                pmin=(-2.5, -2.5, 0.2), pmax=(2.5, 2.5, 2.2), max_tries=0, Qfar=0.0, Qnear=0.0, Sfree=0.0, order=2):
+                pmin=(-2.5, -2.5, 0.2), pmax=(2.5, 2.5, 2.2), max_tries=0, Qfar=0.0, Qnear=0.0, Sfree=0.0, order=2, tol=2.0):
     p = Params()
     p.K, p.variant, p.order, p.max_tries = K, VARIANTS[variant] if isinstance(variant, str) else variant, int(order), max_tries
     p.h, p.rmin, p.c, p.alim, p.Q1, p.S1, p.term = h, rmin, c, alim, Q1, S1, term
     p.Qfar, p.Qnear, p.Sfree = Qfar, Qnear, Sfree
+    p.tol = float(tol)
     for i in range(3):
         p.pmin[i] = float(pmin[i])
         p.pmax[i] = float(pmax[i])

@@ -129,3 +129,44 @@ def AddCollConstr(p, po, K, rmin, A, E1, E2, order=2):
                 bin_total[row] = -r
                 row += 1
     return Ain_total, bin_total
+
+
+# ---- dmpc/matlab helpers of the legacy SCP loop (solveDMPC.m) ---------------------------------------------------------------------
+def CheckCollDMPC(p, l, n, k, r_min):
+    """CheckCollDMPC.m:1-10 literally: violation = any_i~=n norm(p - l(:,k,i)) < r_min"""
+    p = np.ravel(p).astype(float)
+    l = np.asarray(l, float)
+    violation = False
+    for i in range(1, l.shape[2] + 1):
+        if i != n:
+            pj = l[:, :, i - 1]
+            dist = np.linalg.norm(p - pj[:, k - 1])
+            violation = violation or (dist < r_min)
+    return violation
+
+
+def CollConstrDMPC(p, po, vo, n, k, l, Ain, r_min, A_initp):
+    """CollConstrDMPC.m:1-34 literally (one row per other agent at step k, linearised about p)."""
+    p, po, vo = (np.ravel(x).astype(float) for x in (p, po, vo))
+    l = np.asarray(l, float)
+    rows, rhs = [], []
+    if l.size:
+        for i in range(1, l.shape[2] + 1):
+            if i != n:
+                pj = l[:, :, i - 1]
+                K = pj.shape[1]
+                dist = np.linalg.norm(p - pj[:, k - 1])
+                diff = p - pj[:, k - 1]
+                r = dist * (r_min - dist + (p - pj[:, k - 1]) @ p / dist) - (p - pj[:, k - 1]) @ A_initp[3 * (k - 1):3 * k, :] @ np.r_[po, vo]
+                diff_mat = np.r_[np.zeros(3 * (k - 1)), diff, np.zeros(3 * (K - k))]
+                rows.append(-diff_mat @ Ain)
+                rhs.append(-r)
+    return (np.array(rows).reshape(len(rows), np.asarray(Ain).shape[1]), np.array(rhs).reshape(-1, 1))
+
+
+def maxDeviation(p, prev_p):
+    """maxDeviation.m:1-11 literally: K = length(p)/3 (of the 3 x k_hor MATRIX: max(size)/3), dist(k) = norm(p(:,k) - prev_p(:,k)), max"""
+    p, prev_p = np.asarray(p, float), np.asarray(prev_p, float)
+    K = max(p.shape) / 3
+    dist = [np.linalg.norm(p[:, k - 1] - prev_p[:, k - 1]) for k in range(1, int(K) + 1)]
+    return max(dist)

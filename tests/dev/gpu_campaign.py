@@ -36,7 +36,7 @@ for it in range(nscen):
         l = init_table(po, pf); xp, xv, xa = po.copy(), np.zeros_like(po), np.zeros_like(po)
         # slack multipliers scale with |term|: eps = -(t + sum lambda sigma)/2 loses |term| * 1e-16 * cond absolutely
         # (cpp1: DMPC::solveQP hard-codes a slack penalty of -1e6, ten times solveSoftDMPC's: ten times its allowance)
-        tol = 1e-6 if variant == "cpp1" else (5e-8 if variant in ("softall", "repair") else 1e-9 * max(1.0, abs(kw["term"]) / 5e4))
+        tol = 1e-6 if variant == "cpp1" else (5e-8 if variant in ("softall", "repair", "softall_c") else 1e-9 * max(1.0, abs(kw["term"]) / 5e4))
         for k in range(int(rng.integers(2, 7))):
             out = d.step_batch(l, xp, xv, xa, pf); ref = orc.step(prm, l, xp, xv, xa, pf, nthreads=8)
             total += N

@@ -6,7 +6,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden")
 
-ALL_VARIANTS = ["bound", "bound2", "all3", "hard", "ondemand", "ellip", "softall", "repair", "cpp", "cpp2", "cpp1"]
+ALL_VARIANTS = ["bound", "bound2", "all3", "hard", "ondemand", "ellip", "softall", "repair", "cpp", "cpp2", "cpp1", "softall_c", "scp"]
+# (scp without a `tol` keyword runs with make_params' default tol = 2, the value of dmpc/matlab/dmpc.m:14; tests/test_gpu_scp.py sweeps smaller ones)
+CAMPAIGN_VARIANTS = ALL_VARIANTS[:11]   # the variant list of rounds 2-5: the recorded scenes of the randomized campaigns are positions in ITS random stream
 
 
 def load_golden(name):

@@ -31,7 +31,7 @@ def call(cmd, prm, args=(), nlhs=1, emulate_devices=0):
     exe = build()
     req = struct.pack("<i", len(cmd)) + cmd.encode()
     req += struct.pack("<3i", int(prm["K"]), int(prm["variant"]), int(prm["order"]))
-    req += struct.pack("<13d", prm["h"], prm["rmin"], prm["c"], prm["alim"], prm["Q1"], prm["S1"], prm["term"], *prm["pmin"], *prm["pmax"])
+    req += struct.pack("<14d", prm["h"], prm["rmin"], prm["c"], prm["alim"], prm["Q1"], prm["S1"], prm["term"], *prm["pmin"], *prm["pmax"], prm.get("tol", 0.0))
     req += struct.pack("<i", len(args))
     for a in args:
         a = np.asarray(a, dtype=np.float64)
@@ -64,7 +64,7 @@ def call(cmd, prm, args=(), nlhs=1, emulate_devices=0):
     return outs
 
 
-def params(variant, kw, K=15, order=2):
+def params(variant, kw, K=15, order=2, tol=0.0):
     from multiagent_planning_amd import _lib
     return dict(K=K, variant=_lib.VARIANTS[variant], order=order, h=kw["h"], rmin=kw["rmin"], c=kw["c"], alim=kw["alim"], Q1=kw["Q1"],
-                S1=kw["S1"], term=kw["term"], pmin=tuple(kw["pmin"]), pmax=tuple(kw["pmax"]))
+                S1=kw["S1"], term=kw["term"], pmin=tuple(kw["pmin"]), pmax=tuple(kw["pmax"]), tol=tol)

@@ -1,7 +1,7 @@
 // harness.cpp -- calls the MEX gateway's mexFunction() the way MATLAB would, with arguments read from a request file
 // (TEST INFRASTRUCTURE, with the mock MEX runtime of this directory).
 //   harness <request.bin> <reply.bin>
-// request: int32 cmdlen, cmd bytes | int32 K, variant, order | double h, rmin, c, alim, Q1, S1, term, pmin[3], pmax[3] |
+// request: int32 cmdlen, cmd bytes | int32 K, variant, order | double h, rmin, c, alim, Q1, S1, term, pmin[3], pmax[3], tol |
 //          int32 nargs, per argument: int32 ndim, int64 dims[ndim], column-major doubles | int32 nlhs
 // reply:   int32 rc (0 ok, 1 = mexErrMsgIdAndTxt: int32 len + message) | int32 nout, per output: int32 class (6 double, 12 int32),
 //          int32 ndim, int64 dims[], raw column-major data
@@ -26,7 +26,7 @@ int main(int argc, char **argv)
     int32_t cmdlen; rd(f, &cmdlen, 4);
     std::string cmd(cmdlen, '\0'); rd(f, &cmd[0], cmdlen);
     int32_t ip[3]; rd(f, ip, 12);
-    double dp[13]; rd(f, dp, sizeof(dp));
+    double dp[14]; rd(f, dp, sizeof(dp));
     mxArray *prm = mockStruct();
     const char *inames[3] = {"K", "variant", "order"};
     for (int i = 0; i < 3; ++i) mockSetField(prm, inames[i], mxCreateDoubleScalar((double)ip[i]));
@@ -35,6 +35,7 @@ int main(int argc, char **argv)
     mxArray *pmin = mxCreateDoubleMatrix(1, 3, mxREAL), *pmax = mxCreateDoubleMatrix(1, 3, mxREAL);
     memcpy(mxGetPr(pmin), dp + 7, 24); memcpy(mxGetPr(pmax), dp + 10, 24);
     mockSetField(prm, "pmin", pmin); mockSetField(prm, "pmax", pmax);
+    mockSetField(prm, "tol", mxCreateDoubleScalar(dp[13]));
     int32_t nargs; rd(f, &nargs, 4);
     std::vector<const mxArray *> prhs;
     prhs.push_back(mockString(cmd.c_str()));

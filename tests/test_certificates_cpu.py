@@ -10,7 +10,7 @@ from oracle import oracle as orc
 from helpers import load_golden, step14_inputs
 import certificates as cert
 
-UNPINNED = ["hard", "ondemand", "ellip", "softall", "repair", "all3", "cpp1"]
+UNPINNED = ["hard", "ondemand", "ellip", "softall", "repair", "all3", "cpp1", "softall_c", "scp"]
 
 
 def check_batch(prm, l, xp, xv, xa, pf, a, status, tries, what, agents=None, tol=1e-8, t_min=1e-7):

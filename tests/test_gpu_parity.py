@@ -14,7 +14,7 @@ from helpers import ALL_VARIANTS, load_golden, oracle_params, init_table, step14
 
 pytestmark = pytest.mark.gpu
 
-TOL = {"softall": 2e-8, "repair": 2e-8, "cpp1": 2e-8}   # |term| = 1e5-scale multipliers: see DESIGN.md section 6
+TOL = {"softall": 2e-8, "repair": 2e-8, "cpp1": 2e-8, "softall_c": 2e-8}   # |term| = 1e5-scale multipliers: see DESIGN.md section 6
 
 
 @pytest.mark.parametrize("name,variant", [("failure_rate2_bound", "bound"), ("comp_kctr_3_bound2", "bound2")])
@@ -109,7 +109,7 @@ def test_scan_and_rows_match_oracle(name, variant):
     l, xp, xv, xa, pf = step14_inputs(g)
     prm = oracle_params(variant, kw)
     l3 = l.reshape(-1, 15, 3).transpose(2, 1, 0)
-    E1 = np.diag([1, 1, 1 / kw["c"]])
+    E1 = np.diag([1, 1, 1 / kw["c"]]) if variant != "scp" else np.eye(3)   # (solveDMPC: plain Euclidean norm)
     N = l.shape[0]
     for n in list(range(0, N, 9)) + [int(g["n_done"])]:
         ref = orc.rows_one(prm, l, n, xp[n], xv[n])

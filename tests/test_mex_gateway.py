@@ -80,6 +80,17 @@ def test_gateway_commands_match_the_c_abi():
     assert bool(rg.ravel()[0]) == bool(d.reached_goal(xp, pf, 0.05))
     rg2, = mh.call("reached_goal", prm, [pf.T, pf.T, 0.05])
     assert bool(rg2.ravel()[0])
+    # solveDMPC.m / solveSoftDMPC_c.m shims: 'solve_one' on a context of variant 12 (params.tol = the .m's tol) / 11; maxDeviation.m: 'max_deviation'
+    dscp, dsc = mp.Dmpc("scp", tol=0.05, **kw), mp.Dmpc("softall_c", **kw)
+    for n in (0, 5, 57):
+        for pr, dd in ((mh.params("scp", kw, tol=0.05), dscp), (mh.params("softall_c", kw), dsc)):
+            p, v, a, st, inf = mh.call("solve_one", pr, [lm, n + 1, xp[n], xv[n], xa[n], pf[n]], nlhs=5)
+            r = dd.solve_one(l, n, xp[n], xv[n], xa[n], pf[n])
+            assert int(st.ravel()[0]) == r["status"] and np.array_equal(inf.ravel(), r["info"])
+            assert np.array_equal(p.T.ravel(), r["p"]) and np.array_equal(a.T.ravel(), r["a"]) and np.array_equal(v.T.ravel(), r["v"])
+    pa = out["p"][ok].reshape(15, 3).T
+    md, = mh.call("max_deviation", prm, [pa, lm[:, :, ok]])
+    assert md.ravel()[0] == max(np.linalg.norm(pa[:, k] - lm[:, k, ok]) for k in range(5))
     # generators and a whole transition (C1: the 4-agent swap of dmpc_soft_bound.m)
     from multiagent_planning_amd import workload as wl
     c1 = wl.CONFIGS["C1"]
