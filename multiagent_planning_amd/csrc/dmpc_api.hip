@@ -122,6 +122,8 @@ struct dmpc_ctx {
     std::vector<int> split_at;          // non-empty: the last dmpc_transition left scenes [split_at[i], split_at[i+1]) in part i (0: here, i > 0: children[i-1])
     int split_parts = 0;     // development option split_parts: number of parts (0: the built-in rule)
     int no_split = 0;        // development option no_split
+    int reduced_solver = 1;  // solveSoftDMPCbound: the reduced solver (dmpc_rsolve.hip) in front of the general one; 0: the general solver alone (A/B runs, tests)
+    int rsolve_blocks = 0;   // workgroups of dmpc_rsolve_persist_kernel a CU holds (occupancy query, once per context)
     int no_split_t = 0;      // development option no_split_t: slack-free persistent solve with the whole inverse factor in every wave's block (nine waves per CU; A/B runs, tests)
     int grid_min = 768;      // development option grid_min: cell-grid neighbour lists from this many agents per scene on (below: nbr_kernel) ...
     int grid_min_part = 2048; // ... and when the query covers only a PART of the scene's agents (a rank's chunk: the grid is still built over all of them)
@@ -407,7 +409,7 @@ extern "C" int dmpc_debug_option(dmpc_ctx *ctx, const char *name, int value)
         {"no_fuse", &dmpc_ctx::no_fuse}, {"no_persist", &dmpc_ctx::no_persist}, {"force_persist", &dmpc_ctx::force_persist}, {"no_cull", &dmpc_ctx::no_cull}, {"order_slices", &dmpc_ctx::order_slices}, {"cull_min", &dmpc_ctx::cull_min},
         {"no_lpt", &dmpc_ctx::no_lpt}, {"order_hint", &dmpc_ctx::order_hint}, {"crash_min", &dmpc_ctx::crash_min}, {"crash_any", &dmpc_ctx::crash_any}, {"no_fast_exit", &dmpc_ctx::no_fast_exit}, {"pivot_explore", &dmpc_ctx::pivot_explore},
         {"iter_cap", &dmpc_ctx::iter_cap}, {"tier1_qcap", &dmpc_ctx::tier1_env}, {"split_parts", &dmpc_ctx::split_parts}, {"no_split", &dmpc_ctx::no_split},
-        {"static_queue", &dmpc_ctx::static_queue}, {"queue_chunk", &dmpc_ctx::queue_chunk}, {"no_split_t", &dmpc_ctx::no_split_t}, {"ext_cap", &dmpc_ctx::ext_cap}, {"nbr_grid", &dmpc_ctx::nbr_grid}, {"f32_dep_exp", &dmpc_ctx::f32_dep_exp}, {"grid_min", &dmpc_ctx::grid_min}, {"no_level_check", &dmpc_ctx::no_level_check}, {"lds_pad_kb", &dmpc_ctx::lds_pad_kb}};
+        {"static_queue", &dmpc_ctx::static_queue}, {"queue_chunk", &dmpc_ctx::queue_chunk}, {"no_split_t", &dmpc_ctx::no_split_t}, {"ext_cap", &dmpc_ctx::ext_cap}, {"nbr_grid", &dmpc_ctx::nbr_grid}, {"f32_dep_exp", &dmpc_ctx::f32_dep_exp}, {"grid_min", &dmpc_ctx::grid_min}, {"no_level_check", &dmpc_ctx::no_level_check}, {"lds_pad_kb", &dmpc_ctx::lds_pad_kb}, {"reduced_solver", &dmpc_ctx::reduced_solver}};
     for (auto &t : tab)
         if (!std::strcmp(t.n, name)) {
             ctx->*(t.f) = value;
@@ -848,7 +850,9 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
         return 0;
     }
     const bool run_order = ctx->forced_n != S * c_count && S * c_count >= 512 && !ctx->no_lpt;
-    P.zero4 = (!tiny || run_order) ? ctx->counter.as<int>() : nullptr;   // queue heads of the persistent solve launches, tier-2 count, live bound: zeroed by the scan kernel (a memset is a launch of its own, 5 us)
+    // the reduced solver (dmpc_rsolve.hip) takes solveSoftDMPCbound in every launch form: which kernel solves an agent must not depend on how deep the launch is
+    const bool reduced = ctx->reduced_solver && p.variant == DMPC_VAR_BOUND && !f32t && ctx->num_cu >= 1;
+    P.zero4 = (!tiny || run_order || reduced) ? ctx->counter.as<int>() : nullptr;   // queue heads of the persistent solve launches, tier-2 count, live bound: zeroed by the scan kernel (a memset is a launch of its own, 5 us)
     // phase 0: scan + rows
     P.qcap = q1; P.only_flagged = 0; P.qover_bit = two_tier ? ST_QOVER : ST_CAPACITY;
     {
@@ -985,6 +989,34 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     // tier 2 as persistent waves over the flagged list (nearly always empty: the launch then costs a few microseconds
     // instead of one workgroup per agent just to find out that there is nothing to do)
     const bool t2_list = two_tier && !tiny && !ctx->no_persist && pw2 >= 2 && ctx->num_cu >= 1;
+    if (reduced) {
+        // tier 0: the reduced solver over every agent of the launch (persistent waves, as many workgroups per CU as its registers allow); the agents it
+        // does not take -- more than 64 rows, a third active wall, more than five hard constraints -- go to the general solver with its full capacity
+        if (ctx->rsolve_blocks == 0) {
+            int nb = 0;
+            HIPCHK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)dmpc_rsolve_persist_kernel, RSOLVE_WAVES * 64, (size_t)RSOLVE_WAVES * RSOLVE_LDS_PER_WAVE));
+            ctx->rsolve_blocks = nb > 0 ? nb : 1;
+        }
+        const int total = S * c_count;
+        P.qcap = 0; P.only_flagged = 0; P.qover_bit = ST_QOVER;
+        P.flag_count = ctx->counter.as<int>() + 2; P.flag_list = ctx->flag_list.as<int>();
+        P.counter = ctx->static_queue ? nullptr : ctx->counter.as<int>();
+        P.lds_per_wave = RSOLVE_LDS_PER_WAVE;
+        int wgs = (total + RSOLVE_WAVES - 1) / RSOLVE_WAVES;
+        if (wgs > ctx->rsolve_blocks * ctx->num_cu) wgs = ctx->rsolve_blocks * ctx->num_cu;
+        P.queue_chunk = ctx->queue_chunk > 0 ? ctx->queue_chunk : (total < 12 * wgs * RSOLVE_WAVES ? 1 : 2);
+        hipLaunchKernelGGL(dmpc_rsolve_persist_kernel, dim3((unsigned)wgs), dim3(RSOLVE_WAVES * 64), (size_t)RSOLVE_WAVES * RSOLVE_LDS_PER_WAVE, st, P);
+        P.qcap = q2; P.only_flagged = 1; P.qover_bit = ST_CAPACITY;
+        P.order = ctx->flag_list.as<int>(); P.flag_list = nullptr; P.live_bound = nullptr;
+        if (solve_launch(q2, lds2, 1, !ctx->no_persist && pw2 >= 2)) return -1;
+        HIPCHK(ctx, hipGetLastError());
+        if (ctx->profile) {
+            HIPCHK(ctx, hipEventRecord(ev.t2, st));
+            ctx->events.push_back(ev);
+        }
+        ctx->solves += (int64_t)S * c_count;
+        return 0;
+    }
     if (t2_list) { P.flag_count = ctx->counter.as<int>() + 2; P.flag_list = ctx->flag_list.as<int>(); }
     if (solve_launch(q1, lds1, 0, deep || ctx->force_persist)) return -1;
     if (two_tier) {   // tier 2: only agents flagged ST_QOVER do any work
@@ -1455,10 +1487,10 @@ static int transition_one(dmpc_ctx *ctx, int S, int N, const double *po, const d
 static void copy_debug_options(dmpc_ctx *dst, const dmpc_ctx *src)
 {
     static const char *names[] = {"no_fuse", "no_persist", "force_persist", "no_cull", "order_slices", "cull_min", "no_lpt", "crash_min", "crash_any", "no_fast_exit",
-                                  "pivot_explore", "iter_cap", "tier1_qcap", "static_queue", "queue_chunk", "no_split_t", "ext_cap", "nbr_grid", "f32_dep_exp", "grid_min", "no_level_check", "order_hint"};
+                                  "pivot_explore", "iter_cap", "tier1_qcap", "static_queue", "queue_chunk", "no_split_t", "ext_cap", "nbr_grid", "f32_dep_exp", "grid_min", "no_level_check", "order_hint", "lds_pad_kb", "reduced_solver"};
     int dmpc_ctx::*fields[] = {&dmpc_ctx::no_fuse, &dmpc_ctx::no_persist, &dmpc_ctx::force_persist, &dmpc_ctx::no_cull, &dmpc_ctx::order_slices, &dmpc_ctx::cull_min,
                                &dmpc_ctx::no_lpt, &dmpc_ctx::crash_min, &dmpc_ctx::crash_any, &dmpc_ctx::no_fast_exit, &dmpc_ctx::pivot_explore, &dmpc_ctx::iter_cap,
-                               &dmpc_ctx::tier1_env, &dmpc_ctx::static_queue, &dmpc_ctx::queue_chunk, &dmpc_ctx::no_split_t, &dmpc_ctx::ext_cap, &dmpc_ctx::nbr_grid, &dmpc_ctx::f32_dep_exp, &dmpc_ctx::grid_min, &dmpc_ctx::no_level_check, &dmpc_ctx::order_hint};
+                               &dmpc_ctx::tier1_env, &dmpc_ctx::static_queue, &dmpc_ctx::queue_chunk, &dmpc_ctx::no_split_t, &dmpc_ctx::ext_cap, &dmpc_ctx::nbr_grid, &dmpc_ctx::f32_dep_exp, &dmpc_ctx::grid_min, &dmpc_ctx::no_level_check, &dmpc_ctx::order_hint, &dmpc_ctx::lds_pad_kb, &dmpc_ctx::reduced_solver};
     for (size_t i = 0; i < sizeof(names) / sizeof(names[0]); ++i) (void)dmpc_debug_option(dst, names[i], src->*(fields[i]));
 }
 

@@ -964,6 +964,7 @@ __device__ __forceinline__ void scan_body(const StepParams &P, const int lane, c
 extern __shared__ __attribute__((aligned(16))) unsigned char dmpc_smem[];
 
 #include "dmpc_solve.hip"
+#include "dmpc_rsolve.hip"
 
 // Scan phase: blockDim.x / 64 independent waves per workgroup, one agent each (P.lds_per_wave bytes of LDS per wave).
 // Single-wave workgroups leave the launch bound by the workgroup dispatch rate (51 200 workgroups in ~180 us whatever the
@@ -1040,6 +1041,55 @@ __global__ __launch_bounds__(64, SOLVE_WAVES_PER_SIMD) void dmpc_scp_kernel(Step
         if (!(val > P.scp_tol)) break;
     }
     if (lane == 0 && P.info) { P.info[(size_t)gid * 8 + 2] = passes; P.info[(size_t)gid * 8 + 4] = iters_sum; }
+}
+
+// Persistent form of the REDUCED solver (dmpc_rsolve.hip): workgroups of RSOLVE_WAVES independent waves, as many per CU as the registers
+// allow (no tables, 768 bytes of LDS per wave); the queue is the one of dmpc_solve_persist_kernel.
+#ifndef RSOLVE_WAVES
+#define RSOLVE_WAVES 4
+#endif
+constexpr int RSOLVE_LDS_PER_WAVE = 96 * 8;
+__global__ __launch_bounds__(RSOLVE_WAVES * 64) void dmpc_rsolve_persist_kernel(StepParams P)
+{
+    int total = P.S * P.c_count;
+    if (P.live_bound) { const int lb = *P.live_bound; total = lb < total ? lb : total; }
+    if (total == 0) return;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    unsigned char *mine = (unsigned char *)__builtin_assume_aligned(dmpc_smem + (size_t)wave * RSOLVE_LDS_PER_WAVE, 16);
+    const int nw = (int)(gridDim.x * (blockDim.x >> 6));
+    const int rest = total > nw ? total - nw : 0;
+    const int T1 = rest < QUEUE_T1 * nw ? rest : QUEUE_T1 * nw;
+    const int T3 = (rest - T1) < QUEUE_T3 * nw ? (rest - T1) : QUEUE_T3 * nw;
+    const int CHUNK = P.queue_chunk > 0 ? P.queue_chunk : QUEUE_CHUNK;
+    const int mid = rest - T1 - T3, T2 = (mid + CHUNK - 1) / CHUNK;
+    const bool dyn = P.counter != nullptr;
+    auto resolve = [&](int ps) -> int { return (ps < total && P.order) ? P.order[ps] : ps; };
+    auto decode = [&](int t, int &left) -> int {
+        left = 0;
+        if (t < T1) return nw + t;
+        if (t < T1 + T2) {
+            const int ps = nw + T1 + CHUNK * (t - T1), end = nw + T1 + mid;
+            left = (end - ps < CHUNK ? end - ps : CHUNK) - 1;
+            return ps;
+        }
+        return nw + T1 + mid + (t - T1 - T2);
+    };
+    int pos = wave * (int)gridDim.x + (int)blockIdx.x, left = 0;
+    for (;;) {
+        if (pos >= total) break;
+        int tkv = 0;
+        bool claimed = false;
+        const bool want = dyn && left == 0;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int agent = resolve(pos);
+        rsolve_body(P, ln, agent, mine, want, tkv, claimed);
+        if (want && !claimed && lane == 0) tkv = atomicAdd(P.counter, 1);
+        LSYNC();
+        if (!dyn) { pos += nw; continue; }
+        if (left > 0) { pos++; left--; continue; }
+        pos = decode(__builtin_amdgcn_readfirstlane(tkv), left);
+    }
 }
 
 // Persistent form of the solve phase: one workgroup of up to 8 independent waves per CU (two per SIMD).  The Gram tables of the three

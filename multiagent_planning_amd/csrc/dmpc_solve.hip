@@ -57,7 +57,11 @@ struct SolveLds {   // offsets in doubles from the wave's LDS base
 // value), two wait states between a VALU write and the DPP read of the same register
 __device__ __forceinline__ float wave_max_f(float v)
 {
-    asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+    // (the FIRST wait is five states, not two: the assembler block may directly follow an s_or_b64 exec that closes a lane-dependent branch -- the
+    // candidate blocks of the violation scans -- and a DPP operation needs five wait states behind a write of EXEC; the hazard recogniser does not
+    // look into inline assembly.  dmpc_rsolve.hip, round 6: with the stale mask the maximum missed lanes, no lane equalled it, and the scan
+    // reported "nothing violated" -- in one build of two)
+    asm volatile("s_nop 4\n\tv_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
                  "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
                  "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
                  "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"

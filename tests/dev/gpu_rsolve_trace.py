@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Development: per-EQP trace of one agent of a golden scene in the reduced solver (DEV_TRACE build: run through tools/with_trace_lib.py).
+usage: python tools/with_trace_lib.py tests/dev/gpu_rsolve_trace.py <golden name> <agent>"""
+import ctypes as C
+import os
+import sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import multiagent_planning_amd as mp
+from multiagent_planning_amd import _lib
+from helpers import load_golden
+name, agent = sys.argv[1], int(sys.argv[2])
+if name.startswith("c4:"):   # c4:N:step:seed -- the scene of tools/proto/run_proto.py N steps seed, teacher-forced by the oracle up to `step`
+    from multiagent_planning_amd import workload as wl
+    from oracle import oracle as orc
+    _, N, step, seed = name.split(":")
+    N, step, seed = int(N), int(step), int(seed)
+    cfg = dict(wl.CONFIGS["C4"]); cfg["N"] = N
+    kw = wl.solver_kwargs(cfg, N)
+    po, pf = wl.make_scenes(cfg, 1, N, seed)
+    po, pf = po[0], pf[0]
+    prm = orc.make_params("bound", **kw)
+    l = np.stack([orc.init_one(po[n], pf[n], cfg["h"], 15)[0] for n in range(N)])
+    xp, xv, xa = po.copy(), np.zeros_like(po), np.zeros_like(po)
+    for k in range(2, step):
+        ref = orc.step(prm, l, xp, xv, xa, pf, nthreads=os.cpu_count())
+        ok = (ref["status"] & 1) == 1
+        l = np.where(ok[:, None], ref["p"], l)
+        xp = np.where(ok[:, None], ref["p"][:, :3], xp); xv = np.where(ok[:, None], ref["v"][:, :3], xv); xa = np.where(ok[:, None], ref["a"][:, :3], xa)
+else:
+    g, kw = load_golden(name)
+    l, xp, xv, xa, pf = g["l"], g["pk"][:, 12], g["vk"][:, 12], g["ak"][:, 12], g["pf"]
+d = mp.Dmpc("bound", device=0, **kw)
+L = _lib.load()
+L.dmpc_debug_trace.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+cap = 256
+assert L.dmpc_debug_trace(d._ctx, agent, cap, None) == 0
+out = d.step_batch(l, xp, xv, xa, pf)
+buf = np.zeros((cap, 8))
+assert L.dmpc_debug_trace(d._ctx, agent, cap, buf.ctypes.data_as(C.c_void_p)) == 0
+print("status", out["status"][agent], "info", out["info"][agent])
+for i in range(cap - 2):
+    r = buf[i]
+    if r[1] == 0: break
+    c0, c1 = int(r[0]), int(r[1])
+    print(f"EQP {i}: phase {c0 % 10} ent {(c0 // 10) % 100} idx {c0 // 1000}  nh {c1 & 15} ne {(c1 >> 4) & 15} sing {((c1 >> 8) & 15) - 1} nhr {c1 >> 12}   {r[2]:.10e} {r[3]:.10e} {r[4]:.10e}  | {r[5]:.6e} {r[6]:.6e} {r[7]:.6e}")
+r = buf[cap - 2]
+print("first scan: w_kc", r[0], r[1], r[2], "score", r[3], "pcode", int(r[4]), "rb", r[5], "xi0", r[6], "xi1", r[7])
+r = buf[cap - 1]
+print("FINAL fixed hi %x lo %x rows in %x pin0 %x pinL %x  code %d" % (int(r[0]) | (int(r[1]) << 32), int(r[2]) | (int(r[3]) << 32), int(r[4]), int(r[5]), int(r[6]), int(r[7])))
+print("a (axis-major):")
+a = out["a"][agent].reshape(15, 3)
+for x in range(3): print("  ", " ".join(f"{v:+.6f}" for v in a[:, x]))

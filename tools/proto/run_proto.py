@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""Development driver of tools/proto/rqp_proto.c: a C4-like scene in closed loop with the CPU oracle, every agent of every MPC step
+also solved by the prototype of the reduced active-set method; prints agreement (status, retry count, l_inf of the accelerations) and
+the prototype's work statistics.  usage: run_proto.py [N] [steps] [seed]"""
+import ctypes as C
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import oracle as orc  # noqa: E402
+from multiagent_planning_amd import workload as wl  # noqa: E402
+
+K = 15
+NRMAX = 256
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = "/tmp/librqp.so"
+subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-std=gnu11", "-o", SO, os.path.join(HERE, "rqp_proto.c"), "-lm"])
+lib = C.CDLL(SO)
+
+
+class Prob(C.Structure):
+    _fields_ = [("h", C.c_double), ("alim", C.c_double), ("q", C.c_double), ("s", C.c_double), ("st", C.c_double), ("slb", C.c_double),
+                ("f", C.c_double * (3 * K)), ("whi", C.c_double * (3 * K)), ("wlo", C.c_double * (3 * K)),
+                ("kc", C.c_int), ("nr", C.c_int),
+                ("xi", C.c_double * (3 * NRMAX)), ("b", C.c_double * NRMAX), ("sd", C.c_double * NRMAX)]
+
+
+assert lib.rqp_prob_size() == C.sizeof(Prob), (lib.rqp_prob_size(), C.sizeof(Prob))
+if os.environ.get("RQP_JITTER"): C.c_int.in_dll(lib, "rqp_jitter").value = 1
+lib.rqp_solve.argtypes = [C.POINTER(Prob), C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+
+
+def main():
+    N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+    seed = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+    variant = sys.argv[4] if len(sys.argv) > 4 else "bound"
+    dbg = [tuple(int(v) for v in a.split(":")) for a in sys.argv[5].split(",")] if len(sys.argv) > 5 else []
+    cfg = dict(wl.CONFIGS["C4"]); cfg["N"] = N
+    kw = wl.solver_kwargs(cfg, N)
+    prm = orc.make_params(variant, **kw)
+    golden = os.environ.get("RQP_GOLDEN")
+    if golden:   # one recorded scene (tests/golden), teacher-forced MPC step 14
+        g = np.load(os.path.join(ROOT, "tests", "golden", golden + ".npz"))
+        kw = dict(rmin=float(g["rmin"]), c=float(g["c"]), alim=float(g["alim"]), Q1=float(g["Q"]), S1=float(g["S"]), term=float(g["term"]), pmin=tuple(g["pmin"]), pmax=tuple(g["pmax"]), h=float(g["h"]))
+        cfg.update(Q1=kw["Q1"], S1=kw["S1"], term=kw["term"], alim=kw["alim"], h=kw["h"])
+        prm = orc.make_params(variant, **kw)
+        l, xp, xv, xa, pf = g["l"].copy(), g["pk"][:, 12].copy(), g["vk"][:, 12].copy(), g["ak"][:, 12].copy(), g["pf"].copy()
+        N = l.shape[0]; steps = 1
+    else:
+        po, pf = wl.make_scenes(cfg, 1, N, seed)
+        po, pf = po[0], pf[0]
+        l = np.zeros((N, 3 * K))
+        for n in range(N):
+            l[n] = orc.init_one(po[n], pf[n], cfg["h"], K)[0]
+        xp, xv, xa = po.copy(), np.zeros_like(po), np.zeros_like(po)
+    h, alim = cfg["h"], cfg["alim"]
+    pmin, pmax = np.array(kw["pmin"]), np.array(kw["pmax"])
+    lK = h * h * (K - 1 - np.arange(K) + 0.5)
+    tot = dict(n=0, mism_status=0, mism_tries=0, fallback=0, maxerr=0.0)
+    agg = np.zeros(8)
+    hist_hard, hist_extra = np.zeros(16, int), np.zeros(8, int)
+    reasons = {}
+    fb_list = []
+    for step in range(2, 2 + steps):
+        t0 = time.time()
+        ref = orc.step(prm, l, xp, xv, xa, pf, nthreads=8)
+        t_or = time.time() - t0
+        t0 = time.time()
+        worst = []
+        for n in range(N):
+            st_ref = int(ref["status"][n])
+            if st_ref & orc.ST_COLL and not (st_ref & orc.ST_SOLVED):
+                continue
+            rows = orc.rows_one(prm, l, n, xp[n], xv[n])
+            P = Prob()
+            nr = rows["nrows"]
+            if nr > NRMAX:
+                tot["fallback"] += 1; continue
+            far = np.linalg.norm(xp[n] - pf[n]) >= 1
+            if nr > 0:
+                q, s = cfg["Q1"], cfg["S1"]
+            else:
+                q, s = (1000.0, 10.0) if far else (10000.0, 10.0)
+            P.h, P.alim, P.q, P.s, P.st, P.slb = h, alim, q, s, cfg["term"], (-0.05 if variant == "bound" else -0.01)
+            gap = pf[n] - (xp[n] + K * h * xv[n])
+            for x in range(3):
+                for k in range(K):
+                    P.f[x * K + k] = -2.0 * q * lK[k] * gap[x] - (2.0 * s * xa[n][x] if k == 0 else 0.0)
+                    P.whi[x * K + k] = pmax[x] - xp[n][x] - (k + 1) * h * xv[n][x]
+                    P.wlo[x * K + k] = pmin[x] - xp[n][x] - (k + 1) * h * xv[n][x]
+            kc = rows["viol_k"] - 1 - (1 if variant == "bound2" else 0)
+            P.kc, P.nr = max(kc, 0), nr
+            for j in range(nr):
+                for t in range(3):
+                    P.xi[3 * j + t] = -rows["G"][j][3 * kc + t] / (0.5 * h * h)
+                P.b[j] = rows["b"][j]; P.sd[j] = rows["dist"][j]
+            a = (C.c_double * (3 * K))()
+            tries = C.c_int(0)
+            stats = (C.c_int * 8)()
+            if (step, n) in dbg:
+                C.c_int.in_dll(lib, "rqp_debug").value = 1
+                print("DEBUG agent", n, "step", step, "nr", nr, "kc", kc, "ref status", st_ref, "ref tries", int(ref["info"][n][orc.I_TRIES]), "ref iters", int(ref["info"][n][orc.I_ITERS]))
+            rc = lib.rqp_solve(C.byref(P), 30, 400, a, C.byref(tries), stats)
+            C.c_int.in_dll(lib, "rqp_debug").value = 0
+            if (step, n) in dbg:
+                print("DEBUG rc", rc, "tries", tries.value, "stats", stats[:])
+                if rc == 0:
+                    for lev in range(3):
+                        pr = orc.make_params(variant, **kw)
+                        _, obj, mv = orc.eval_one(pr, l, n, xp[n], xv[n], xa[n], pf[n], np.array(a[:]))
+                        print("   eval of proto a at level 0: obj", obj, "maxviol", mv); break
+                    if st_ref & 1:
+                        _, obj, mv = orc.eval_one(pr, l, n, xp[n], xv[n], xa[n], pf[n], ref["a"][n])
+                        print("   eval of oracle a: obj", obj, "maxviol", mv, "oracle obj", ref["obj"][n])
+            tot["n"] += 1
+            sv = np.array(stats[:])
+            agg += sv
+            hist_hard[min(sv[4], 15)] += 1; hist_extra[min(sv[5], 7)] += 1
+            if rc == 2:
+                tot["fallback"] += 1
+                reasons[int(sv[7])] = reasons.get(int(sv[7]), 0) + 1
+                if len(fb_list) < 12: fb_list.append((step, n))
+                continue
+            solved_ref = bool(st_ref & orc.ST_SOLVED)
+            if (rc == 0) != solved_ref:
+                tot["mism_status"] += 1
+                print("  status mismatch agent", n, "rc", rc, "ref", st_ref, "tries", tries.value, int(ref["info"][n][orc.I_TRIES]), "nr", nr)
+                continue
+            if tries.value != int(ref["info"][n][orc.I_TRIES]):
+                tot["mism_tries"] += 1
+                print("  tries mismatch agent", n, tries.value, int(ref["info"][n][orc.I_TRIES]), "nr", nr)
+            if rc == 0:
+                err = float(np.abs(np.array(a[:]) - ref["a"][n]).max())
+                worst.append((err, n, nr, int(sv[0])))
+                tot["maxerr"] = max(tot["maxerr"], err)
+        worst.sort(reverse=True)
+        print(f"step {step}: oracle {t_or:.2f}s proto {time.time() - t0:.2f}s  worst", [(f"{e:.1e}", n, nr, it) for e, n, nr, it in worst[:3]], flush=True)
+        ok = (ref["status"] & 1) == 1
+        l = np.where(ok[:, None], ref["p"], l)
+        xp = np.where(ok[:, None], ref["p"][:, :3], xp)
+        xv = np.where(ok[:, None], ref["v"][:, :3], xv)
+        xa = np.where(ok[:, None], ref["a"][:, :3], xa)
+    n = max(tot["n"], 1)
+    print(tot)
+    print("fallback reasons", reasons, fb_list)
+    print("per agent: iters %.2f eqps %.2f partial %.2f singular %.3f crashdrops %.2f" % (agg[0] / n, agg[1] / n, agg[2] / n, agg[3] / n, agg[6] / n))
+    print("max hard", hist_hard.tolist(), "max extra", hist_extra.tolist())
+
+
+if __name__ == "__main__":
+    main()
