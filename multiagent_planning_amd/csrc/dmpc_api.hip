@@ -999,6 +999,7 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
         }
         const int total = S * c_count;
         P.qcap = 0; P.only_flagged = 0; P.qover_bit = ST_QOVER;
+        if (P.post_on) P.live_bound = nullptr;   // fused post-step: the agents the scan finished are visited too (their part of the state advance and of the scene's verdict)
         P.flag_count = ctx->counter.as<int>() + 2; P.flag_list = ctx->flag_list.as<int>();
         P.counter = ctx->static_queue ? nullptr : ctx->counter.as<int>();
         P.lds_per_wave = RSOLVE_LDS_PER_WAVE;
@@ -1007,8 +1008,9 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
         P.queue_chunk = ctx->queue_chunk > 0 ? ctx->queue_chunk : (total < 12 * wgs * RSOLVE_WAVES ? 1 : 2);
         hipLaunchKernelGGL(dmpc_rsolve_persist_kernel, dim3((unsigned)wgs), dim3(RSOLVE_WAVES * 64), (size_t)RSOLVE_WAVES * RSOLVE_LDS_PER_WAVE, st, P);
         P.qcap = q2; P.only_flagged = 1; P.qover_bit = ST_CAPACITY;
-        P.order = ctx->flag_list.as<int>(); P.flag_list = nullptr; P.live_bound = nullptr;
-        if (solve_launch(q2, lds2, 1, !ctx->no_persist && pw2 >= 2)) return -1;
+        const bool t2p = !ctx->no_persist && pw2 >= 2;   // persistent waves over the flagged list (nearly always empty); else one workgroup per agent, each looking at its agent's flag
+        P.order = t2p ? ctx->flag_list.as<int>() : nullptr; P.flag_list = nullptr; P.live_bound = nullptr;
+        if (solve_launch(q2, lds2, 1, t2p)) return -1;
         HIPCHK(ctx, hipGetLastError());
         if (ctx->profile) {
             HIPCHK(ctx, hipEventRecord(ev.t2, st));

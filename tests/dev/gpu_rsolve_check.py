@@ -31,7 +31,7 @@ def compare(tag, kw, l, xp, xv, xa, pf, variant="bound"):
     for n in range(N):
         e = float(np.abs(o_r["a"].reshape(N, 45)[n] - ref["a"][n]).max()) if (st_o[n] & 1) and (st_r[n] & 1) else 0.0
         eg = float(np.abs(o_g["a"].reshape(N, 45)[n] - ref["a"][n]).max()) if (st_o[n] & 1) and (st_g[n] & 1) else 0.0
-        ep = float(np.abs(o_r["p"].reshape(N, 45)[n] - ref["p"][n]).max()) if (st_o[n] & 1) and (st_r[n] & 1) else 0.0
+        ep = float(max(np.abs(o_r["p"].reshape(N, 45)[n] - ref["p"][n]).max(), np.abs(o_r["v"].reshape(N, 45)[n] - ref["v"][n]).max())) if (st_o[n] & 1) and (st_r[n] & 1) else 0.0
         worst = max(worst, e, ep)
         if st_r[n] != st_o[n] or ir[n, 2] != io[n, 2] or e > 1e-8 or ep > 1e-8:
             bad.append((n, int(st_r[n]), int(st_o[n]), int(ir[n, 2]), int(io[n, 2]), e, ep, eg, int(ir[n, 1]), int(ir[n, 4]), int(ir[n, 7]), int(ig[n, 4])))
@@ -43,6 +43,35 @@ def compare(tag, kw, l, xp, xv, xa, pf, variant="bound"):
 
 def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "golden"
+    if what.startswith("trans"):   # whole transitions, reduced against general solver
+        S = int(what.split(":")[1]) if ":" in what else 4
+        cfg = wl.CONFIGS["C4"]; N = 100
+        kw = wl.solver_kwargs(cfg, N)
+        po, pf = wl.make_scenes(cfg, S, N, wl.SEED0 + 55)
+        red = mp.Dmpc("bound", **kw); gen = mp.Dmpc("bound", **kw); gen.debug_option("reduced_solver", 0)
+        a, b = red.transition(po, pf, 151, cfg["error_tol"]), gen.transition(po, pf, 151, cfg["error_tol"])
+        print("scene status reduced", a["scene_status"], "general", b["scene_status"])
+        print("K_T used reduced", a["K_T_used"], "general", b["K_T_used"])
+        for key in ("pk", "vk", "ak"):
+            print(key, "max diff", float(np.abs(a[key] - b[key]).max()))
+        return
+    if what.startswith("batch"):   # S scenes of 100 agents, closed loop by the general solver, every step compared
+        S = int(what.split(":")[1])
+        cfg = wl.CONFIGS["C4"]; N = 100
+        kw = wl.solver_kwargs(cfg, N)
+        po, pf = wl.make_scenes(cfg, S, N, wl.SEED0 + 55)
+        red = mp.Dmpc("bound", **kw); gen = mp.Dmpc("bound", **kw); gen.debug_option("reduced_solver", 0)
+        l, _, _ = gen.init_batch(po, pf)
+        xp, xv, xa = po.copy(), np.zeros_like(po), np.zeros_like(po)
+        for k in range(2, 12):
+            o_r, o_g = red.step_batch(l, xp, xv, xa, pf), gen.step_batch(l, xp, xv, xa, pf)
+            ok = (o_g["status"] & 1) == 1
+            dst = (o_r["status"] != o_g["status"]).sum()
+            e = max(float(np.abs(o_r[key][ok] - o_g[key][ok]).max()) for key in ("p", "v", "a"))
+            print(f"step {k}: status differences {dst} of {ok.size}  max diff on solved agents {e:.2e}  statuses reduced {np.unique(o_r['status'], return_counts=True)}")
+            l = np.where(ok[..., None], o_g["p"], l)
+            xp = np.where(ok[..., None], o_g["p"][..., :3], xp); xv = np.where(ok[..., None], o_g["v"][..., :3], xv); xa = np.where(ok[..., None], o_g["a"][..., :3], xa)
+        return
     if what == "golden":
         g, kw = load_golden("failure_rate2_bound")
         compare("failure_rate2 step 14", kw, *step14_inputs(g))
