@@ -1046,7 +1046,7 @@ __global__ __launch_bounds__(64, SOLVE_WAVES_PER_SIMD) void dmpc_scp_kernel(Step
 // Persistent form of the REDUCED solver (dmpc_rsolve.hip): workgroups of RSOLVE_WAVES independent waves, as many per CU as the registers
 // allow (no tables, 768 bytes of LDS per wave); the queue is the one of dmpc_solve_persist_kernel.
 #ifndef RSOLVE_WAVES
-#define RSOLVE_WAVES 4
+#define RSOLVE_WAVES 8
 #endif
 constexpr int RSOLVE_LDS_PER_WAVE = 96 * 8;
 __global__ __launch_bounds__(RSOLVE_WAVES * 64) void dmpc_rsolve_persist_kernel(StepParams P)

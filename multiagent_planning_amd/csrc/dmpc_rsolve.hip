@@ -94,89 +94,6 @@ __device__ __forceinline__ void sym3_mul(const Sym3 &M, const double *v, double 
     o[2] = M.m02 * v[0] + M.m12 * v[1] + M.m22 * v[2];
 }
 
-// The small system of the hard constraints:  (Y' B^-1 Y + Om) lam = -rho - Y' B^-1 qt,  zeta = -B^-1 (Y lam + qt), the entering
-// constraint last.  Returns 0 regular, 1 the last constraint depends on the others (rr = its coordinates in them), -1 the working set
-// itself is dependent (not a state of the method: give up).
-template <int NH>
-__device__ __forceinline__ int hard_solve(const double (&y)[R_NH][3], const double (&rho)[R_NH], const double (&om)[R_NE][R_NE], const int ne,
-                                          const Sym3 &Bi, const double (&qt)[3], const double (&scale)[R_NH], const bool has_p,
-                                          double (&lam)[R_NH], double (&zeta)[3], double (&rr)[R_NH])
-{
-    double by[NH > 0 ? NH : 1][3], S[NH > 0 ? NH : 1][NH > 0 ? NH : 1], L[NH > 0 ? NH : 1][NH > 0 ? NH : 1], rh[NH > 0 ? NH : 1], bq[3];
-    sym3_mul(Bi, qt, bq);
-#pragma unroll
-    for (int c = 0; c < NH; ++c) {
-        sym3_mul(Bi, y[c], by[c]);
-        rh[c] = -rho[c] - (y[c][0] * bq[0] + y[c][1] * bq[1] + y[c][2] * bq[2]);
-    }
-#pragma unroll
-    for (int c = 0; c < NH; ++c)
-#pragma unroll
-        for (int e = 0; e <= c; ++e) {
-            double t = y[c][0] * by[e][0] + y[c][1] * by[e][1] + y[c][2] * by[e][2];
-            // the extras are the LAST ne entries of the list
-            const int ce = c - (NH - ne), ee = e - (NH - ne);
-            if (ce >= 0 && ee >= 0) t += om[ce < R_NE ? ce : 0][ee < R_NE ? ee : 0];
-            S[c][e] = t;
-        }
-    bool dep = false, bad = false;
-#pragma unroll
-    for (int c = 0; c < NH; ++c) {
-#pragma unroll
-        for (int e = 0; e <= c; ++e) {
-            double t = S[c][e];
-#pragma unroll
-            for (int k = 0; k < e; ++k) t -= L[c][k] * L[e][k];
-            if (e < c) L[c][e] = t * L[e][e];   // (the diagonal holds the RECIPROCAL root)
-            else {
-                if (!(t > 1e-13 * scale[c])) {
-                    if (c == NH - 1 && has_p) dep = true; else bad = true;
-                    L[c][c] = 0.0;
-                } else L[c][c] = fast_rsq(t);
-            }
-        }
-    }
-    if (bad) return -1;
-    if (!dep) {
-        double yv[NH > 0 ? NH : 1];
-#pragma unroll
-        for (int c = 0; c < NH; ++c) { double t = rh[c]; for (int k = 0; k < c; ++k) t -= L[c][k] * yv[k]; yv[c] = t * L[c][c]; }
-#pragma unroll
-        for (int c = NH - 1; c >= 0; --c) { double t = yv[c]; for (int k = c + 1; k < NH; ++k) t -= L[k][c] * lam[k]; lam[c] = t * L[c][c]; }
-        double s3[3] = {qt[0], qt[1], qt[2]};
-#pragma unroll
-        for (int c = 0; c < NH; ++c) { s3[0] += y[c][0] * lam[c]; s3[1] += y[c][1] * lam[c]; s3[2] += y[c][2] * lam[c]; }
-        sym3_mul(Bi, s3, zeta);
-        zeta[0] = -zeta[0]; zeta[1] = -zeta[1]; zeta[2] = -zeta[2];
-        // a posteriori: the hard constraints must hold at the computed point.  When they do not -- a last pivot of 1e-11 of its scale passes the
-        // test above, the multipliers are 1e17 and the point is noise -- the system is numerically singular: the entering constraint is dependent
-        if (has_p) {
-            double worst = 0.0;
-#pragma unroll
-            for (int c = 0; c < NH; ++c) {
-                double t = y[c][0] * zeta[0] + y[c][1] * zeta[1] + y[c][2] * zeta[2] - rho[c];
-                const int ce = c - (NH - ne);
-                if (ce >= 0)
-#pragma unroll
-                    for (int e = 0; e < R_NE; ++e) if (e < ne) t -= om[ce < R_NE ? ce : 0][e] * lam[NH - ne + e < NH ? NH - ne + e : 0];
-                worst = fmax(worst, fabs(t));
-            }
-            if (!(worst <= 1e-9)) dep = true;
-        }
-        if (!dep) return 0;
-    }
-    // coordinates of the last constraint in the others: S_WW rr = S_Wp
-    {
-        constexpr int M = NH > 0 ? NH - 1 : 0;
-        double yv[M > 0 ? M : 1];
-#pragma unroll
-        for (int c = 0; c < M; ++c) { double t = S[NH - 1][c]; for (int k = 0; k < c; ++k) t -= L[c][k] * yv[k]; yv[c] = t * L[c][c]; }
-#pragma unroll
-        for (int c = M - 1; c >= 0; --c) { double t = yv[c]; for (int k = c + 1; k < M; ++k) t -= L[k][c] * rr[k]; rr[c] = t * L[c][c]; }
-    }
-    return 1;
-}
-
 // one agent; the wave's 96 doubles of LDS (`smem`) serve the output stage only
 __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane, const int vb, unsigned char *smem, const bool want_ticket, int &ticket, bool &claimed)
 {
@@ -375,12 +292,9 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
 #pragma unroll
                     for (int i = 0; i < 2; ++i) if (i < nw) Yw[i] = rax_solve(A, fixd ? 0.0 : nbw[i], lKl, q2);
                 }
-                // ---- extras: the walls of the working set, then an entering wall / bound
+                // ---- extras: the walls of the working set, then an entering wall / bound (a-space normal nbe, H~ nbe = Ye, both on one axis)
                 int ne = nw;
                 double nbe[R_NE] = {nbw[0], nbw[1], 0.0}, Ye[R_NE] = {Yw[0], Yw[1], 0.0};
-                double te[R_NE][3], u0e[R_NE], de[R_NE], sce[R_NE], G0[R_NE][R_NE];
-#pragma unroll
-                for (int i = 0; i < R_NE; ++i) { te[i][0] = te[i][1] = te[i][2] = 0.0; u0e[i] = 0.0; de[i] = 0.0; sce[i] = 1.0; for (int j = 0; j < R_NE; ++j) G0[i][j] = 0.0; }
                 const bool ent_extra = (phase == 2) && (ent == RE_BOUND || ent == RE_WALL);
                 if (nw == 1 && ent_extra) { nbe[1] = 0.0; Ye[1] = 0.0; }
                 if (ent_extra) {
@@ -396,53 +310,30 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
                     for (int i = 0; i < R_NE; ++i) if (i == s) { nbe[i] = nbp; Ye[i] = Yp; }
                     ne = nw + 1;
                 }
-                if (ne > 0) {
-                    cost += 2;
-#pragma unroll
-                    for (int i = 0; i < R_NE; ++i) {
-                        if (i >= ne) continue;
-                        const bool is_b = ent_extra && i == nw && ent == RE_BOUND;
-                        const int wl = is_b ? eidx : ((i < nw ? wcode[i < 2 ? i : 0] : eidx) & 63);
-                        const int wsg = is_b ? esg : (i < nw ? ((wcode[i < 2 ? i : 0] & 256) ? 1 : -1) : esg);
-                        if (is_b) {   // unit normal: the sums are single entries
-                            const double sgd = (double)esg;
-                            const double t = sgd * readlane_d(Ykc, eidx);
-                            const int x = eidx >> 4;
-                            te[i][0] = x == 0 ? t : 0.0; te[i][1] = x == 1 ? t : 0.0; te[i][2] = x == 2 ? t : 0.0;
-                            u0e[i] = sgd * readlane_d(a0, eidx); de[i] = P.alim; sce[i] = readlane_d(sc_bound_l, eidx);
-#pragma unroll
-                            for (int j = 0; j <= i; ++j) G0[i][j] = G0[j][i] = sgd * readlane_d(Ye[j], eidx);
-                        } else {
-                            const double tl = row_allsum(lkc * Ye[i]), ul = row_allsum(nbe[i] * a0);
-                            te[i][0] = readlane_d(tl, 0); te[i][1] = readlane_d(tl, 16); te[i][2] = readlane_d(tl, 32);
-                            u0e[i] = readlane_d(ul, wl & 48);
-                            de[i] = wsg > 0 ? readlane_d(whi_l, wl) : -readlane_d(wlo_l, wl);
-                            sce[i] = readlane_d(sc_wall_l, wl);
-#pragma unroll
-                            for (int j = 0; j <= i; ++j) { const double gl2 = row_allsum(nbe[i] * Ye[j]); G0[i][j] = G0[j][i] = readlane_d(gl2, wl & 48); }
-                        }
-                    }
-                }
-                // ---- soft rows: M_s = sum 2/sd^2 xi xi', q_s = sum (2/sd^2 (xi.w0) + 2 b/sd^2 + st/sd) xi
+                // ---- soft rows: M_s = sum 2/sd^2 xi xi', q_s = M_s w0 + sum (2 b/sd^2 + st/sd) xi;  B = I + sqrt(G) M_s sqrt(G)
                 const bool r_in = rv && (rfl & RB_IN), r_hard = r_in && (rfl & (RB_PIN0 | RB_PINL)), r_soft = r_in && !r_hard;
-                Sym3 Bm; Bm.m00 = 1.0; Bm.m11 = 1.0; Bm.m22 = 1.0; Bm.m01 = 0.0; Bm.m02 = 0.0; Bm.m12 = 0.0;
-                Sym3 Ms; Ms.m00 = Ms.m01 = Ms.m02 = Ms.m11 = Ms.m12 = Ms.m22 = 0.0;
-                double qs[3] = {0.0, 0.0, 0.0}, mss[3] = {0.0, 0.0, 0.0};
+                Sym3 Bi; Bi.m00 = 1.0; Bi.m11 = 1.0; Bi.m22 = 1.0; Bi.m01 = 0.0; Bi.m02 = 0.0; Bi.m12 = 0.0;
+                double qt[3] = {0.0, 0.0, 0.0};
                 if (__ballot(r_soft) != 0ull) {
                     cost += 2;
                     const double al = r_soft ? 2.0 * risd * risd : 0.0;
                     const double be = r_soft ? (2.0 * rb * risd + rst) * risd : 0.0;
+                    Sym3 Ms;
                     Ms.m00 = wave_sum0(al * xi0 * xi0); Ms.m01 = wave_sum0(al * xi0 * xi1); Ms.m02 = wave_sum0(al * xi0 * xi2);
                     Ms.m11 = wave_sum0(al * xi1 * xi1); Ms.m12 = wave_sum0(al * xi1 * xi2); Ms.m22 = wave_sum0(al * xi2 * xi2);
-                    mss[0] = wave_sum0(be * xi0); mss[1] = wave_sum0(be * xi1); mss[2] = wave_sum0(be * xi2);
+                    double qs[3];
                     sym3_mul(Ms, w03, qs);
-                    qs[0] += mss[0]; qs[1] += mss[1]; qs[2] += mss[2];
+                    qs[0] += wave_sum0(be * xi0); qs[1] += wave_sum0(be * xi1); qs[2] += wave_sum0(be * xi2);
+                    Sym3 Bm;
                     Bm.m00 = fma(sg3[0] * sg3[0], Ms.m00, 1.0); Bm.m11 = fma(sg3[1] * sg3[1], Ms.m11, 1.0); Bm.m22 = fma(sg3[2] * sg3[2], Ms.m22, 1.0);
                     Bm.m01 = sg3[0] * sg3[1] * Ms.m01; Bm.m02 = sg3[0] * sg3[2] * Ms.m02; Bm.m12 = sg3[1] * sg3[2] * Ms.m12;
+                    Bi = sym3_inv(Bm);
+                    qt[0] = sg3[0] * qs[0]; qt[1] = sg3[1] * qs[1]; qt[2] = sg3[2] * qs[2];
                 }
-                const Sym3 Bi = sym3_inv(Bm);
-                const double qt[3] = {sg3[0] * qs[0], sg3[1] * qs[1], sg3[2] * qs[2]};
-                // ---- the hard list: hard rows of the working set, walls, the entering constraint last
+                // ---- the hard list, ONE CONSTRAINT PER LANE (lanes 0 .. nh-1): the hard rows of the working set in row order, the entering row
+                // (while it is hard) last among them, then the extras.  Lane c holds yt_c = its normal in the scaled w-space, its right-hand sides
+                // and row c of the small matrix S = Y' B^-1 Y + Om; the elimination broadcasts one pivot row at a time (Gauss-Jordan on a positive
+                // definite matrix, the entering constraint LAST: its pivot is delta = n_p' P n_p, the dependence test of the dual method).
                 int erow = (phase == 2 && ent >= RE_ROW && ent <= RE_PINL) ? eidx : -1;
                 if (erow >= 0 && !((readlane_i(rfl, erow) & RB_IN) && (readlane_i(rfl, erow) & (RB_PIN0 | RB_PINL)))) erow = -1;   // soft by now (its pin gave way): no bordered constraint
                 unsigned long long hm = __ballot(r_hard);
@@ -452,65 +343,156 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
                 const int nh = nhr + ne;
                 if (nh > R_NH) { rc = 2; break; }
                 const bool has_p = (phase == 2) && (ent_extra || erow >= 0);
-                double hy[R_NH][3], hrho[R_NH], hd[R_NH], hsc[R_NH];
-                int hj[R_NH];
-#pragma unroll
-                for (int c = 0; c < R_NH; ++c) { hy[c][0] = hy[c][1] = hy[c][2] = 0.0; hrho[c] = 0.0; hd[c] = 0.0; hsc[c] = 1.0; hj[c] = -1; }
+                int src = 0;
                 {
                     unsigned long long m = hm;
 #pragma unroll
                     for (int c = 0; c < R_NH; ++c) {
-                        if (c >= nhr) continue;
-                        int j;
-                        if (c < nhr0) { j = __ffsll((long long)m) - 1; m &= m - 1ull; } else j = erow;
-                        hj[c] = j;
-                        const double x0 = readlane_d(xi0, j), x1 = readlane_d(xi1, j), x2 = readlane_d(xi2, j);
-                        const double sdj = readlane_d(rsd, j), bj = readlane_d(rb, j), slj = readlane_d(rslb, j);
-                        const bool low = (readlane_i(rfl, j) & RB_PINL) != 0;
-                        hy[c][0] = -sg3[0] * x0; hy[c][1] = -sg3[1] * x1; hy[c][2] = -sg3[2] * x2;
-                        hd[c] = bj - (low ? sdj * slj : 0.0);
-                        hrho[c] = hd[c] + (x0 * w03[0] + x1 * w03[1] + x2 * w03[2]);
-                        hsc[c] = sc_row * readlane_d(rn2, j);
+                        if (c >= nhr0) continue;
+                        const int j = __ffsll((long long)m) - 1; m &= m - 1ull;
+                        if (lane == c) src = j;
+                    }
+                    if (erow >= 0 && lane == nhr0) src = erow;
+                }
+                double hy0, hy1, hy2, hrho = 0.0, hd = 0.0, hsc = 1.0;
+                {
+                    const double gx0 = __shfl(xi0, src), gx1 = __shfl(xi1, src), gx2 = __shfl(xi2, src), gb = __shfl(rb, src), gsd = __shfl(rsd, src), gslb = __shfl(rslb, src);
+                    const int gfl = __shfl(rfl, src);
+                    const bool mine = lane < nhr;
+                    hy0 = mine ? -sg3[0] * gx0 : 0.0; hy1 = mine ? -sg3[1] * gx1 : 0.0; hy2 = mine ? -sg3[2] * gx2 : 0.0;
+                    if (mine) {
+                        hd = gb - ((gfl & RB_PINL) ? gsd * gslb : 0.0);
+                        hrho = hd + (gx0 * w03[0] + gx1 * w03[1] + gx2 * w03[2]);
+                        hsc = sc_row * (gx0 * gx0 + gx1 * gx1 + gx2 * gx2);
                     }
                 }
-                double om[R_NE][R_NE];
+                double om00 = 0.0, om01 = 0.0, om02 = 0.0, om11 = 0.0, om12 = 0.0, om22 = 0.0;   // Om = G0 - yt yt' over the extras
+                if (ne > 0) {
+                    cost += 2;
+                    double yte[R_NE][3], g0[R_NE][R_NE];
 #pragma unroll
-                for (int i = 0; i < R_NE; ++i) for (int j = 0; j < R_NE; ++j) om[i][j] = 0.0;
+                    for (int i = 0; i < R_NE; ++i) { yte[i][0] = yte[i][1] = yte[i][2] = 0.0; for (int j = 0; j < R_NE; ++j) g0[i][j] = 0.0; }
 #pragma unroll
-                for (int i = 0; i < R_NE; ++i) {
-                    if (i >= ne) continue;
-                    double yt[3] = {te[i][0] * isg3[0], te[i][1] * isg3[1], te[i][2] * isg3[2]};
+                    for (int i = 0; i < R_NE; ++i) {
+                        if (i >= ne) continue;
+                        const bool is_b = ent_extra && i == nw && ent == RE_BOUND;
+                        const int wl = is_b ? eidx : ((i < nw ? wcode[i < 2 ? i : 0] : eidx) & 63);
+                        const int wsg = is_b ? esg : (i < nw ? ((wcode[i < 2 ? i : 0] & 256) ? 1 : -1) : esg);
+                        double t3[3], u0, dd, sc;
+                        if (is_b) {   // unit normal: the sums are single entries
+                            const double sgd = (double)esg;
+                            const double t = sgd * readlane_d(Ykc, eidx);
+                            const int x = eidx >> 4;
+                            t3[0] = x == 0 ? t : 0.0; t3[1] = x == 1 ? t : 0.0; t3[2] = x == 2 ? t : 0.0;
+                            u0 = sgd * readlane_d(a0, eidx); dd = P.alim; sc = Gt[(eidx & 15) * 31];
 #pragma unroll
-                    for (int c = 0; c < R_NH; ++c) if (c == nhr + i) { hy[c][0] = yt[0]; hy[c][1] = yt[1]; hy[c][2] = yt[2]; hd[c] = de[i]; hrho[c] = de[i] - u0e[i]; hsc[c] = sce[i]; }
-                }
+                            for (int j = 0; j <= i; ++j) g0[i][j] = g0[j][i] = sgd * readlane_d(Ye[j], eidx);
+                        } else {
+                            const double tl = row_allsum(lkc * Ye[i]), ul = row_allsum(nbe[i] * a0);
+                            t3[0] = readlane_d(tl, 0); t3[1] = readlane_d(tl, 16); t3[2] = readlane_d(tl, 32);
+                            u0 = readlane_d(ul, wl & 48);
+                            dd = wsg > 0 ? readlane_d(whi_l, wl) : -readlane_d(wlo_l, wl);
+                            sc = Gt[(15 + (wl & 15)) * 31];
 #pragma unroll
-                for (int i = 0; i < R_NE; ++i)
-#pragma unroll
-                    for (int j = 0; j < R_NE; ++j) {
-                        if (i >= ne || j >= ne) continue;
-                        double d = 0.0;
-#pragma unroll
-                        for (int x = 0; x < 3; ++x) d += (te[i][x] * isg3[x]) * (te[j][x] * isg3[x]);
-                        om[i][j] = G0[i][j] - d;
+                            for (int j = 0; j <= i; ++j) { const double gl2 = row_allsum(nbe[i] * Ye[j]); g0[i][j] = g0[j][i] = readlane_d(gl2, wl & 48); }
+                        }
+                        yte[i][0] = t3[0] * isg3[0]; yte[i][1] = t3[1] * isg3[1]; yte[i][2] = t3[2] * isg3[2];
+                        if (lane == nhr + i) { hy0 = yte[i][0]; hy1 = yte[i][1]; hy2 = yte[i][2]; hd = dd; hrho = dd - u0; hsc = sc; }
                     }
-                double hlam[R_NH] = {0, 0, 0, 0, 0}, zeta[3] = {0, 0, 0}, hrr[R_NH] = {0, 0, 0, 0, 0};
-                int sing;
-                switch (nh) {
-                case 0: { double bq[3]; sym3_mul(Bi, qt, bq); zeta[0] = -bq[0]; zeta[1] = -bq[1]; zeta[2] = -bq[2]; sing = 0; break; }
-                case 1: sing = hard_solve<1>(hy, hrho, om, ne, Bi, qt, hsc, has_p, hlam, zeta, hrr); break;
-                case 2: sing = hard_solve<2>(hy, hrho, om, ne, Bi, qt, hsc, has_p, hlam, zeta, hrr); break;
-                case 3: sing = hard_solve<3>(hy, hrho, om, ne, Bi, qt, hsc, has_p, hlam, zeta, hrr); break;
-                case 4: sing = hard_solve<4>(hy, hrho, om, ne, Bi, qt, hsc, has_p, hlam, zeta, hrr); break;
-                default: sing = hard_solve<5>(hy, hrho, om, ne, Bi, qt, hsc, has_p, hlam, zeta, hrr); break;
+                    om00 = g0[0][0] - (yte[0][0] * yte[0][0] + yte[0][1] * yte[0][1] + yte[0][2] * yte[0][2]);
+                    om01 = g0[0][1] - (yte[0][0] * yte[1][0] + yte[0][1] * yte[1][1] + yte[0][2] * yte[1][2]);
+                    om02 = g0[0][2] - (yte[0][0] * yte[2][0] + yte[0][1] * yte[2][1] + yte[0][2] * yte[2][2]);
+                    om11 = g0[1][1] - (yte[1][0] * yte[1][0] + yte[1][1] * yte[1][1] + yte[1][2] * yte[1][2]);
+                    om12 = g0[1][2] - (yte[1][0] * yte[2][0] + yte[1][1] * yte[2][1] + yte[1][2] * yte[2][2]);
+                    om22 = g0[2][2] - (yte[2][0] * yte[2][0] + yte[2][1] * yte[2][1] + yte[2][2] * yte[2][2]);
                 }
-                sing = UNI(sing);
-                if (sing < 0 || (sing && phase != 2)) { rc = 2; break; }
+                // row c of S and the right-hand side in lane c
+                double Sr[R_NH], rh, hlam = 0.0;
+                double zeta[3] = {0.0, 0.0, 0.0};
+                int sing = 0;
+                {
+                    const double hv[3] = {hy0, hy1, hy2};
+                    double by[3], bq[3];
+                    sym3_mul(Bi, hv, by);
+                    sym3_mul(Bi, qt, bq);
+                    rh = -hrho - (hy0 * bq[0] + hy1 * bq[1] + hy2 * bq[2]);
+                    // my row of Om (extras i = lane - nhr)
+                    const int ie = lane - nhr;
+                    const double omr0 = ie == 0 ? om00 : (ie == 1 ? om01 : om02), omr1 = ie == 0 ? om01 : (ie == 1 ? om11 : om12), omr2 = ie == 0 ? om02 : (ie == 1 ? om12 : om22);
+#pragma unroll
+                    for (int e = 0; e < R_NH; ++e) {
+                        Sr[e] = 0.0;
+                        if (e >= nh) continue;
+                        const double b0 = readlane_d(by[0], e), b1 = readlane_d(by[1], e), b2 = readlane_d(by[2], e);
+                        double t = hy0 * b0 + hy1 * b1 + hy2 * b2;
+                        if (e >= nhr && ie >= 0 && ie < ne) t += (e - nhr == 0) ? omr0 : ((e - nhr == 1) ? omr1 : omr2);
+                        Sr[e] = (lane < nh) ? t : 0.0;
+                    }
+                    if (lane >= nh) rh = 0.0;
+                    // Gauss-Jordan, pivots in list order; the entering constraint's pivot decides dependence
+                    bool bad = false;
+                    double csave = 0.0;   // column of the entering constraint in the eliminated rows, before its own pivot
+#pragma unroll
+                    for (int k = 0; k < R_NH; ++k) {
+                        if (k >= nh) continue;
+                        const double piv = readlane_d(Sr[k], k), psc = readlane_d(hsc, k);
+                        if (k == nh - 1 && has_p) csave = Sr[k];
+                        if (!(piv > 1e-13 * psc)) {
+                            if (k == nh - 1 && has_p) sing = 1; else bad = true;
+                            continue;
+                        }
+                        const double ipiv = fast_rcp(piv);
+                        const double f = (lane == k) ? 0.0 : Sr[k] * ipiv;
+                        const double prh = readlane_d(rh, k);
+                        rh = fma(-f, prh, rh);
+#pragma unroll
+                        for (int e = 0; e < R_NH; ++e) {
+                            if (e <= k || e >= nh) continue;
+                            Sr[e] = fma(-f, readlane_d(Sr[e], k), Sr[e]);
+                        }
+                        if (lane != k) Sr[k] = 0.0;
+                    }
+                    if (uni_b(bad)) { rc = 2; break; }
+                    sing = UNI(sing);
+                    // my diagonal entry
+                    const double dgn = lane == 0 ? Sr[0] : (lane == 1 ? Sr[1] : (lane == 2 ? Sr[2] : (lane == 3 ? Sr[3] : Sr[4])));
+                    const double idg = (lane < nh && dgn > 0.0) ? fast_rcp(dgn) : 0.0;
+                    if (!sing) {
+                        hlam = rh * idg;
+                        // zeta = -B^-1 (qt + sum_c yt_c lam_c): sums over the eight lanes that can hold a constraint
+                        double p0 = hy0 * hlam, p1 = hy1 * hlam, p2 = hy2 * hlam;
+                        p0 += rshr<1>(p0); p0 += rshr<2>(p0); p0 += rshr<4>(p0);
+                        p1 += rshr<1>(p1); p1 += rshr<2>(p1); p1 += rshr<4>(p1);
+                        p2 += rshr<1>(p2); p2 += rshr<2>(p2); p2 += rshr<4>(p2);
+                        const double s3[3] = {qt[0] + readlane_d(p0, 7), qt[1] + readlane_d(p1, 7), qt[2] + readlane_d(p2, 7)};
+                        sym3_mul(Bi, s3, zeta);
+                        zeta[0] = -zeta[0]; zeta[1] = -zeta[1]; zeta[2] = -zeta[2];
+                        // a posteriori: the hard constraints must hold at the computed point (a last pivot of 1e-11 of its scale passes the test above,
+                        // the multipliers are 1e17 and the point is noise: numerically singular -> the entering constraint is dependent)
+                        if (has_p && nh > 0) {
+                            double r = hy0 * zeta[0] + hy1 * zeta[1] + hy2 * zeta[2] - hrho;
+                            if (ne > 0) {
+                                const double l0 = readlane_d(hlam, nhr), l1 = readlane_d(hlam, nhr + 1 < 64 ? nhr + 1 : 63), l2 = readlane_d(hlam, nhr + 2 < 64 ? nhr + 2 : 63);
+                                if (ie >= 0 && ie < ne) r -= omr0 * l0 + (ne > 1 ? omr1 * l1 : 0.0) + (ne > 2 ? omr2 * l2 : 0.0);
+                            }
+                            const double worst = wave_max0(lane < nh ? fabs(r) : 0.0);
+                            if (!(worst <= 1e-9)) sing = 1;
+                        }
+                    }
+                    if (sing && phase != 2) { rc = 2; break; }
+                    if (sing) {
+                        // the entering constraint in terms of the others: rr_c = (S_WW^-1 s)_c = its column in the eliminated rows (saved before its own
+                        // pivot) over their diagonal
+                        hlam = (lane < nh - 1) ? csave * idg : 0.0;   // rr_c
+                    }
+                }
                 // ---- new values (regular) or rates per unit of the entering multiplier (dependent: the primal does not move)
                 double a_n = a, mu_n = 0.0, lam_n = 0.0, pi_n = 0.0, rho_n = 0.0, eps_n = eps, lamp_n = 1.0, farkas = 0.0;
                 double lw_n[2] = {0.0, 0.0};
+                // the hard rows' multipliers (or rates) back in their row lanes: list position of row `lane`
+                const int hpos = (erow >= 0 && lane == erow) ? nhr0 : __popcll(hm & ((1ull << lane) - 1ull));
                 if (!sing) {
-                    // w = w0 + sqrt(g) zeta; the rows' multipliers; c = sum lam xi over the active rows -- summed directly: on an axis whose components are
-                    // all fixed (g = 0) c moves no acceleration, but it is part of the gradient there, i.e. of the multipliers of those bounds
+                    const double lam_h = __shfl(hlam, r_hard ? hpos : 0);
                     double wv[3];
 #pragma unroll
                     for (int x = 0; x < 3; ++x) wv[x] = fma(sg3[x], zeta[x], w03[x]);
@@ -523,12 +505,13 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
                         } else if (r_hard) {
                             const bool low = (rfl & RB_PINL) != 0;
                             eps_n = low ? rslb : 0.0;
-#pragma unroll
-                            for (int c = 0; c < R_NH; ++c) if (hj[c] == lane) lam_n = hlam[c];
+                            lam_n = lam_h;
                             if (low) { pi_n = 0.0; rho_n = fma(rsd, lam_n, 2.0 * rslb + rst); }
                             else pi_n = -rst - rsd * lam_n;
                         } else eps_n = 0.0;
                     }
+                    // c = sum lam xi over the active rows -- summed directly: on an axis whose components are all fixed (g = 0) c moves no
+                    // acceleration, but it is part of the gradient there, i.e. of the multipliers of those bounds
                     double cv[3] = {0.0, 0.0, 0.0};
                     if (__ballot(r_in) != 0ull) {
                         const double lr = r_in ? lam_n : 0.0;
@@ -540,9 +523,7 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
 #pragma unroll
                     for (int i = 0; i < R_NE; ++i) {
                         if (i >= ne) continue;
-                        double le = 0.0;
-#pragma unroll
-                        for (int c = 0; c < R_NH; ++c) if (c == nhr + i) le = hlam[c];
+                        const double le = readlane_d(hlam, nhr + i);
                         a_n = fma(-le, Ye[i], a_n);
                         grad = fma(le, nbe[i], grad);
                         if (i < nw) lw_n[i < 2 ? i : 0] = le; else lamp_n = le;
@@ -556,37 +537,29 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
                     double dl_last = 1.0;
                     if (ent == RE_PIN0) dl_last = -readlane_d(risd, eidx);
                     if (ent == RE_PINL) dl_last = readlane_d(risd, eidx);
-                    double dlh[R_NH];
-#pragma unroll
-                    for (int c = 0; c < R_NH; ++c) dlh[c] = (c < nh - 1) ? -hrr[c] * dl_last : ((c == nh - 1) ? dl_last : 0.0);
-                    double fk = 0.0, dc[3] = {0.0, 0.0, 0.0};
-#pragma unroll
-                    for (int c = 0; c < R_NH; ++c) {
-                        if (c >= nh) continue;
-                        fk += dlh[c] * hd[c];
-                        if (c < nhr) {   // hard rows: c = sum lam xi
-                            const int j = hj[c];
-                            dc[0] += dlh[c] * readlane_d(xi0, j); dc[1] += dlh[c] * readlane_d(xi1, j); dc[2] += dlh[c] * readlane_d(xi2, j);
-                        }
+                    const double dlh = (lane < nh - 1) ? -hlam * dl_last : ((lane == nh - 1) ? dl_last : 0.0);   // lane c: rate of constraint c
+                    double fk = wave_sum0(dlh * hd);
+                    const double dl_row = __shfl(dlh, r_hard ? hpos : 0);
+                    if (rv && r_hard) {
+                        lam_n = dl_row;
+                        if (rfl & RB_PINL) rho_n = rsd * lam_n; else pi_n = -rsd * lam_n;
+                    }
+                    double dc[3] = {0.0, 0.0, 0.0};
+                    {
+                        const double lr = (rv && r_hard) ? lam_n : 0.0;
+                        dc[0] = wave_sum0(lr * xi0); dc[1] = wave_sum0(lr * xi1); dc[2] = wave_sum0(lr * xi2);
                     }
                     const double c_l = ax_l == 0 ? dc[0] : (ax_l == 1 ? dc[1] : dc[2]);
                     double grad = -c_l * lkc;
 #pragma unroll
                     for (int i = 0; i < R_NE; ++i) {
                         if (i >= ne) continue;
-                        double le = 0.0;
-#pragma unroll
-                        for (int c = 0; c < R_NH; ++c) if (c == nhr + i) le = dlh[c];
+                        const double le = readlane_d(dlh, nhr + i);
                         grad = fma(le, nbe[i], grad);
                         if (i < nw) lw_n[i < 2 ? i : 0] = le;
                     }
                     mu_n = (comp && fx != 0) ? -(double)fx * grad : 0.0;
                     fk += wave_sum0(mu_n * P.alim);
-                    if (rv && r_hard) {
-#pragma unroll
-                        for (int c = 0; c < R_NH; ++c) if (hj[c] == lane) lam_n = dlh[c];
-                        if (rfl & RB_PINL) rho_n = rsd * lam_n; else pi_n = -rsd * lam_n;
-                    }
                     farkas = fk;
                     lamp_n = 1.0;
                 }

@@ -12,7 +12,7 @@ import csv, glob, sys, collections
 for f in sorted(glob.glob(sys.argv[1] + "/*/*counter_collection.csv")):
     acc = collections.defaultdict(float); n = collections.Counter()
     for r in csv.DictReader(open(f)):
-        if "solve_persist_kernel<true, 56" in r["Kernel_Name"]:
+        if "solve_persist_kernel<true, 56" in r["Kernel_Name"] or "rsolve_persist" in r["Kernel_Name"]:
             acc[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
     d = {c: round(v / n[c] / 10000, 1) for c, v in acc.items()}
     print(d, "total", round(sum(v for k, v in d.items() if k != "SQ_WAVES")))
