@@ -1047,7 +1047,7 @@ extern "C" int dmpc_debug_trace(dmpc_ctx *ctx, int agent, int cap, double *host_
     }
     if (ctx->dbg) { (void)hipFree(ctx->dbg); ctx->dbg = nullptr; }
     ctx->dbg_agent = agent; ctx->dbg_cap = cap;
-    if ((agent >= 0 || agent == -2 || agent == -3 || agent == -5) && cap > 0) {
+    if ((agent >= 0 || agent == -2 || agent == -3 || agent == -5 || agent == -7) && cap > 0) {
         HIPCHK(ctx, hipMalloc((void **)&ctx->dbg, sizeof(double) * 8 * cap));
         HIPCHK(ctx, hipMemset(ctx->dbg, 0, sizeof(double) * 8 * cap));
     }

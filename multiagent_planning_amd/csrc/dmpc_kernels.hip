@@ -1048,7 +1048,7 @@ __global__ __launch_bounds__(64, SOLVE_WAVES_PER_SIMD) void dmpc_scp_kernel(Step
 #ifndef RSOLVE_WAVES
 #define RSOLVE_WAVES 8
 #endif
-constexpr int RSOLVE_LDS_PER_WAVE = 96 * 8;
+constexpr int RSOLVE_LDS_PER_WAVE = 4 * 70 * 8;   // the output stage's 96 doubles; the ladder certificate's planes (4 doubles each: 64 rows + 6 box faces)
 __global__ __launch_bounds__(RSOLVE_WAVES * 64) void dmpc_rsolve_persist_kernel(StepParams P)
 {
     int total = P.S * P.c_count;

@@ -24,7 +24,7 @@
 // flagged ST_QOVER and solved by the general kernel (dmpc_solve.hip) in the tier-2 launch: none in the 27 000 agent-steps of the prototype's
 // campaign but for a third wall (1).
 
-// #define RSOLVE_TRACE 1
+#define RSOLVE_TRACE 1
 template <int N> __device__ __forceinline__ double rshr(double v) { return dpp0_d<0x110 + N>(v); }   // lane i <- lane i-N of its row (0 off the row)
 template <int N> __device__ __forceinline__ double rshl(double v) { return dpp0_d<0x100 + N>(v); }   // lane i <- lane i+N
 template <int N> __device__ __forceinline__ double rror(double v) { return dpp0_d<0x120 + N>(v); }   // rotation inside the row
@@ -33,8 +33,11 @@ __device__ __forceinline__ double row_prefix(double v) { v += rshr<1>(v); v += r
 
 enum { RE_BOUND = 0, RE_WALL = 1, RE_ROW = 2, RE_PIN0 = 3, RE_PINL = 4, RE_NONE = 5 };
 enum { RB_IN = 1, RB_PIN0 = 2, RB_PINL = 4 };
-constexpr int R_NH = 5;   // hard constraints of the small system (hard rows + walls + the entering constraint)
-constexpr int R_NE = 3;   // extras among them: two walls of the working set + an entering wall / bound
+constexpr int R_NH = 8;   // hard constraints of the small system, one per lane (hard rows + walls + the entering constraint)
+constexpr int R_NW = 3;   // walls of the working set (a corner of the workspace)
+constexpr int R_NE = R_NW + 1;
+constexpr int RCERT_AFTER = 6;      // scans of a ladder level before the certificate looks at it
+constexpr int RCERT_PLANES = 70;    // planes the wave's LDS holds for it: 64 rows + 6 box faces   // extras: the walls + an entering wall / bound
 
 // the per-axis tridiagonal solver of a free set (PCR multipliers of the four strides), u = T3_FF^-1 lK_F and kap = 1 / (1 + 2 q lK_F'u)
 struct RAx {
@@ -94,10 +97,34 @@ __device__ __forceinline__ void sym3_mul(const Sym3 &M, const double *v, double 
     o[2] = M.m02 * v[0] + M.m12 * v[1] + M.m22 * v[2];
 }
 
+// a-space normal of wall `code` (component lane | sign bit 8): sg l_k on its axis
+__device__ __forceinline__ double wall_normal(const int code, const bool comp, const int ax_l, const int k_l, const double h2)
+{
+    const int wl = code & 63, ka = wl & 15;
+    return (comp && ax_l == (wl >> 4) && k_l <= ka) ? ((code & 256) ? 1.0 : -1.0) * h2 * ((double)(ka - k_l) + 0.5) : 0.0;
+}
+
 // one agent; the wave's 96 doubles of LDS (`smem`) serve the output stage only
+//
+// State of a level.  Component lanes (16 axis + step): a, fx (0 free, +-1 fixed at +-alim), mu (multiplier of the fixed bound; lanes 48 .. 48 + nw - 1,
+// which are no components, hold the multipliers of the walls).  Row lanes: rfl (RB_IN the row is active, RB_PIN0 / RB_PINL its slack is fixed at 0 / slb) and
+// ONE multiplier lam -- the slack and the multipliers of its bounds follow from it (stationarity in eps: 2 eps + st + sd lam + pi - rho = 0):
+//   free slack  eps = -(sd lam + st) / 2;   pin at 0  pi = -st - sd lam;   pin at slb  rho = 2 slb + st + sd lam
+// all linear in lam, so a partial step interpolates lam alone.
 __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane, const int vb, unsigned char *smem, const bool want_ticket, int &ticket, bool &claimed)
 {
+#if defined(RSOLVE_TRACE)
+    long long rph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long rph_last = __builtin_amdgcn_s_memtime();
+#define RPH(i_) do { const long long t__ = __builtin_amdgcn_s_memtime(); rph[i_] += t__ - rph_last; rph_last = t__; } while (0)
+#else
+#define RPH(i_) do { } while (0)
+#endif
 #define RCLAIM_NEXT() do { if (want_ticket && !claimed) { claimed = true; if (lane == 0) ticket = atomicAdd(kernarg_params()->counter, 1); } } while (0)
+    // (fields of the parameter block that are picked by a run-time index -- pmin / pmax by axis, the weights by cost case -- are read through the
+    // kernel-argument segment: a select between fields of the by-value struct is compiled as a select of ADDRESSES and sends the whole block to scratch)
+    const KargPtr Qk = kernarg_params();
+#define PMAXQ(x_) ((x_) == 0 ? Qk->pmax[0] : ((x_) == 1 ? Qk->pmax[1] : Qk->pmax[2]))
+#define PMINQ(x_) ((x_) == 0 ? Qk->pmin[0] : ((x_) == 1 ? Qk->pmin[1] : Qk->pmin[2]))
     const int nrmax = P.nrmax, var = P.variant;
     const int scene = vb / P.c_count, ci = vb - scene * P.c_count;
     const int cl = P.c_first + ci;
@@ -134,19 +161,22 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
     const bool rv = lane < nr;
     const int ri = rv ? lane : 0;
     double xi0 = r_xi[3 * ri], xi1 = r_xi[3 * ri + 1], xi2 = r_xi[3 * ri + 2];
-    double rb = r_b[ri], rsd = r_sd[ri], rst = r_st[ri], rslb = r_slb[ri];
+    double rb = r_b[ri], rsd = r_sd[ri];
+    const double rst_l = r_st[ri], rslb_l = r_slb[ri];
     const int rkc = r_kc[ri];
-    if (!rv) { xi0 = xi1 = xi2 = 0.0; rb = 0.0; rsd = 1.0; rst = 0.0; rslb = 0.0; }
+    if (!rv) { xi0 = xi1 = xi2 = 0.0; rb = 0.0; rsd = 1.0; }
     const int kc = (nr > 0) ? UNI(rkc) : 0;
-    bool giveup = nr > 64 || __ballot(rv && rkc != kc) != 0ull;
+    // the slacks' linear cost and lower bound are the same for every row of these variants (solveSoftDMPCbound.m:78,82): wave-uniform
+    double st = (nr > 0) ? readlane_d(rst_l, 0) : 0.0, slb = (nr > 0) ? readlane_d(rslb_l, 0) : 0.0;
+    bool giveup = nr > 64 || __ballot(rv && (rkc != kc || rst_l != st || rslb_l != slb)) != 0ull;
+    int why = giveup ? (nr > 64 ? 1 : 2) : 0;   // development: why the agent goes to the general solver
     const double risd = fast_rcp(rsd);                                                  // 1 / sd
     const float rwt = 4.f * __builtin_amdgcn_rsqf((float)(xi0 * xi0 + xi1 * xi1 + xi2 * xi2));   // pivot weight of the row ("rows first", dmpc_solve.hip)
-    const double rn2 = xi0 * xi0 + xi1 * xi1 + xi2 * xi2;
 
     // ---------------------------------------------------------------- cost case, component constants: lane = 16 axis + step
     const int ccase = UNI(cost_case(var, po[0] - pf[0], po[1] - pf[1], po[2] - pf[2], rows_exist));
-    const double qw = ccase == 0 ? P.Qfar : (ccase == 1 ? P.Qnear : P.Q1);
-    const double sw = ccase == 2 ? P.S1 : P.Sfree;
+    const double qw = ccase == 0 ? Qk->Qfar : (ccase == 1 ? Qk->Qnear : Qk->Q1);
+    const double sw = ccase == 2 ? Qk->S1 : Qk->Sfree;
     const double q2 = 2.0 * qw, e_off = -2.0 * sw;
     const int ax_l = lane >> 4, k_l = lane & 15;
     const bool comp = ax_l < 3 && k_l < K;
@@ -154,63 +184,76 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
     const double lKl = comp ? h2 * ((double)(K - 1 - k_l) + 0.5) : 0.0;                  // lK(k)
     const double lkc = (comp && k_l <= kc) ? h2 * ((double)(kc - k_l) + 0.5) : 0.0;      // l_kc(k)
     const double dg = comp ? (k_l < K - 1 ? 4.0 * sw + 2.0 : 2.0 * sw + 2.0) : 0.0;
-    const double gax = comp ? goal_gap(sel3(pf, ax_l), sel3(po, ax_l), sel3(vo, ax_l), P.h) : 0.0;
-    const double ao_l = comp ? sel3(ao, ax_l) : 0.0;
-    const double f_l = comp ? (-q2 * lKl * gax - (k_l == 0 ? 2.0 * sw * ao_l : 0.0)) : 0.0;
-    double whi_l = INFINITY, wlo_l = -INFINITY;
-    if (comp) {
-        const double sh = (double)(k_l + 1) * P.h * sel3(vo, ax_l);
-        whi_l = sel3(P.pmax, ax_l) - sel3(po, ax_l) - sh;
-        wlo_l = sel3(P.pmin, ax_l) - sel3(po, ax_l) - sh;
-    }
-    // unconstrained minimiser from the Gram tables, exactly as the scan's unconstrained exit and the general solver form it
     const double *Gt = P.tables + (size_t)ccase * TAB_CASE_DOUBLES;
     const int kt = comp ? k_l : 0;
-    const double a_unc = comp ? unc_entry(qw, sw, gax, ao_l, Gt[kt * 30 + 15 + (K - 1)], Gt[kt * 30]) : 0.0;
-    // scales of the dependence test: n'H^-1 n of the UNREDUCED Hessian (dmpc_solve.hip: delta <= 1e-13 s_pp)
-    const double sc_bound_l = Gt[kt * 31];                 // H1^-1(k,k)
-    const double sc_wall_l = Gt[(15 + kt) * 31];           // (L H1^-1 L')(k,k)
-    const double sc_row = Gt[(15 + kc) * 31];
+    double f_l = 0.0, pbase = 0.0, a_unc = 0.0, whi_l = 0.0, wlo_l = 0.0;
+    {
+        const double gax = comp ? goal_gap(sel3(pf, ax_l), sel3(po, ax_l), sel3(vo, ax_l), P.h) : 0.0;
+        const double ao_l = comp ? sel3(ao, ax_l) : 0.0;
+        f_l = comp ? (-q2 * lKl * gax - (k_l == 0 ? 2.0 * sw * ao_l : 0.0)) : 0.0;
+        pbase = comp ? sel3(po, ax_l) + (double)(k_l + 1) * P.h * sel3(vo, ax_l) : 0.0;   // A_initp(k,:) [po; vo]: the walls are pmin - pbase <= w <= pmax - pbase
+        whi_l = comp ? PMAXQ(ax_l) - pbase : INFINITY; wlo_l = comp ? PMINQ(ax_l) - pbase : -INFINITY;
+        // unconstrained minimiser from the Gram tables, exactly as the scan's unconstrained exit and the general solver form it
+        a_unc = comp ? unc_entry(qw, sw, gax, ao_l, Gt[kt * 30 + 15 + (K - 1)], Gt[kt * 30]) : 0.0;
+    }
+    const double sc_row = Gt[(15 + kc) * 31];   // n'H^-1 n of the UNREDUCED Hessian: the scale of the dependence test (dmpc_solve.hip: delta <= 1e-13 s_pp)
 
+    // the ladder certificate (ladder_level_infeasible, dmpc_kernels.hip) wants the walls of component (k, axis) in lane 3 k + axis
+    const int cl3 = lane < N3 ? 16 * (lane % 3) + lane / 3 : 63;
+    const double whi_s = __shfl(whi_l, cl3), wlo_s = __shfl(wlo_l, cl3);
     const bool ladder = (var == VAR_BOUND || var == VAR_BOUND2 || cppv);
     const int max_tries = P.max_tries > 0 ? P.max_tries : (cppv ? 21 : 30);
     const double tol = 1e-10;
     int tries = h1.z, iters_total = 0, maxq = 0, qfinal = 0, cost = 0;
+    double lev_f = 1.0;   // the rows' slack bound and penalty carry this factor (a power of two) on the current ladder level
     bool solved = false;
-    double a = 0.0, eps = 0.0;
+    double a = 0.0, lam = 0.0;
     int fx = 0, rfl = 0, nw = 0;
 
     if (status & ST_INFEAS) tries = 1;
     if (tries > 0 && !(status & ST_INFEAS)) {
         if (tries >= max_tries) { status |= ST_INFEAS; tries = max_tries; }
-        else { const double f = ldexp(1.0, tries); rslb *= f; rst *= f; }
+        else { const double f = ldexp(1.0, tries); slb *= f; st *= f; lev_f = f; }
     }
     if (!(status & (ST_COLL | ST_CAPACITY | ST_INFEAS)) && !giveup) {
+        bool cert_known = false;   // the level about to start has passed the certificate
         while (tries < max_tries) {
             tries++;
             int rc = 0;   // 0 solved, 1 infeasible, 2 give up
             int lev_skip = 0;
             // ---- state of the level
             fx = 0; rfl = rv ? RB_PIN0 : 0; nw = 0;
-            a = a_unc; eps = 0.0;
-            double mu = 0.0, lam = 0.0, pi_ = rv ? -rst : 0.0, rho = 0.0;
-            int wcode[2] = {0, 0};          // walls of the working set: lane of the component | sign bit 8
-            double lw[2] = {0.0, 0.0}, nbw[2] = {0.0, 0.0}, Yw[2] = {0.0, 0.0};
+            a = a_unc; lam = 0.0;
+            double mu = 0.0;
+            int wcode[R_NW] = {0, 0, 0};    // walls of the working set: lane of the component | sign bit 8
             RAx A;
             double a0 = 0.0, Ykc = 0.0;
-            double g3[3] = {0, 0, 0}, w03[3] = {0, 0, 0}, sg3[3] = {0, 0, 0}, isg3[3] = {0, 0, 0};
+            double w03[3] = {0, 0, 0}, sg3[3] = {0, 0, 0}, isg3[3] = {0, 0, 0};
             bool fdirty = true;
+            // the soft rows' penalty, kept up to date one row at a time: M_s = sum 2/sd^2 xi xi', m_s = sum (2 b/sd^2 + st/sd) xi
+            Sym3 Ms; Ms.m00 = Ms.m01 = Ms.m02 = Ms.m11 = Ms.m12 = Ms.m22 = 0.0;
+            double msv[3] = {0.0, 0.0, 0.0};
+            unsigned long long softm_prev = 0ull;
+            // the hard rows' data in the lanes of the small system (lane c: xi, b, sd, flags of the c-th hard row), gathered again when the list changes
+            double gx0 = 0.0, gx1 = 0.0, gx2 = 0.0, gb = 0.0, gsd = 1.0;
+            int gfl = 0, herow_prev = -2;
+            unsigned long long hm_prev = ~0ull;
             int ent = RE_NONE, eidx = 0, esg = 0;   // entering constraint: type, lane of the component / row, sign
-            double lam_p = 0.0;
-            int phase = 0;                  // 0: crash start (fix the bounds violated at the unconstrained minimiser), 1: crash (free the negative multipliers), 2: iteration
-            int inner = 0, iters = 0;
-            {   // crash start
+            int phase = 0;                  // 1: crash (free the negative multipliers), 2: iteration, 3: violation scan
+            int inner = 0, iters = 0, zero_steps = 0;
+            bool cert_done = cert_known;
+            cert_known = false;
+            {   // crash start: every bound violated at the unconstrained minimiser is fixed
                 const bool viol = comp && fabs(a_unc) - P.alim > tol;
                 if (__ballot(viol) != 0ull) { fx = viol ? (a_unc > 0.0 ? 1 : -1) : 0; phase = 1; }
                 else phase = 3;             // straight to the first violation scan: the unconstrained minimiser is the state
             }
             for (;;) {
                 // =========================================================== violation scan (state: the minimiser of the working set)
+#ifdef RSOLVE_MARK
+                asm volatile("; @@R SCAN" ::: "memory");
+#endif
+                RPH(11);
                 if (phase == 3) {
                     // positions w = Lambda a per axis by two prefix sums: w_k = h^2 ((k + 1/2) S0_k - S1_k)
                     const double s0 = row_prefix(comp ? a : 0.0), s1 = row_prefix(comp ? (double)k_l * a : 0.0);
@@ -220,46 +263,56 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
 #define RCAND(v_, w_, code_) do { const double v__ = (v_); const float s__ = (float)v__ * (w_); if (v__ > tol && s__ > bests) { bests = s__; bestc = (code_); } } while (0)
                     if (comp) {
                         if (fx == 0) RCAND(fabs(a) - P.alim, 1.f, (RE_BOUND << 16) | (a > 0.0 ? 256 : 0) | lane);
-                        const bool inw = (nw > 0 && (wcode[0] & 63) == lane) || (nw > 1 && (wcode[1] & 63) == lane);
+                        const bool inw = (nw > 0 && (wcode[0] & 63) == lane) || (nw > 1 && (wcode[1] & 63) == lane) || (nw > 2 && (wcode[2] & 63) == lane);
                         const double c2 = w - whi_l, c3 = wlo_l - w;
                         if (!inw) RCAND(fmax(c2, c3), 1.f, (RE_WALL << 16) | (c2 > c3 ? 256 : 0) | lane);
                     }
                     if (rv) {
+                        // (a lane is a component AND a row: the row's candidates compete with the component's through the same best-of)
                         if (!(rfl & RB_IN)) RCAND(-(xi0 * wk0 + xi1 * wk1 + xi2 * wk2) - rb, rwt, (RE_ROW << 16) | lane);
                         else if (!(rfl & (RB_PIN0 | RB_PINL))) {
-                            // (a lane is a component AND a row: the row's candidates compete with the component's through the same best-of)
+                            const double eps = -0.5 * fma(rsd, lam, st);
                             RCAND(eps, 1.4142135f, (RE_PIN0 << 16) | lane);
-                            RCAND(rslb - eps, 1.4142135f, (RE_PINL << 16) | lane);
+                            RCAND(slb - eps, 1.4142135f, (RE_PINL << 16) | lane);
                         }
                     }
 #undef RCAND
                     const float smax = wave_max_f(bests);
                     const unsigned long long wm = __ballot(bestc >= 0 && bests == smax);
                     if (wm == 0ull) { RCLAIM_NEXT(); rc = 0; break; }   // optimal
-                    if (++iters > P.iter_cap || iters > 600) { rc = 2; break; }
+                    if (++iters > P.iter_cap || iters > 400) { rc = 2; why = 3; break; }
+                    // the level is looked at by the ladder certificate once (3-variable polytope emptiness over the rows of the step with every slack at its
+                    // bound): an infeasible level costs the dual method tens of steps to prove
+                    if (ladder && violation && !cert_done && iters > RCERT_AFTER) {
+                        cert_done = true;
+                        cost += 100;
+                        if (uni_b(ladder_level_infeasible(r_xi, r_b, r_sd, r_slb, r_kc, nr, B, P.h, P.alim, lev_f, whi_s, wlo_s, lane, RCERT_PLANES))) { rc = 1; break; }
+                    }
                     const int pcode = readlane_i(bestc, __ffsll((long long)wm) - 1);
                     ent = pcode >> 16; eidx = pcode & 63; esg = (pcode & 256) ? 1 : -1;
-#if defined(DMPC_DEV_TRACE) || defined(RSOLVE_TRACE)
-                    if (P.dbg && gid == P.dbg_agent && lane == 0 && iters_total <= P.dbg_cap - 3) {   // development: the scan's choice (shares the slot of the EQP that follows: written first, overwritten unless the EQP gives up)
-                        double *d = P.dbg + (size_t)(P.dbg_cap - 2) * 8;
-                        if (iters_total == 0) { d[0] = wk0; d[1] = wk1; d[2] = wk2; d[3] = (double)smax; d[4] = (double)pcode; d[5] = readlane_d(rb, eidx); d[6] = readlane_d(xi0, eidx); d[7] = readlane_d(xi1, eidx); }
-                    }
-#endif
-                    if (ent == RE_WALL && nw >= 2) { rc = 2; break; }
-                    // rows and pins join the working set at once with multiplier 0 (they stay "entering": their own multiplier does not block)
+                    if (ent == RE_WALL && nw >= R_NW) { rc = 2; why = 5; break; }
+                    // rows and pins join the working set at once (they stay "entering": their own multiplier does not block)
                     if (lane == eidx) {
                         if (ent == RE_ROW) rfl |= RB_IN;
-                        if (ent == RE_PIN0) { rfl |= RB_PIN0; pi_ = 0.0; }
-                        if (ent == RE_PINL) { rfl |= RB_PINL; rho = 0.0; }
+                        if (ent == RE_PIN0) rfl |= RB_PIN0;
+                        if (ent == RE_PINL) rfl |= RB_PINL;
                     }
-                    lam_p = 0.0; inner = 0;
+                    inner = 0;
                     phase = 2;
                 }
-                if (phase == 2 && ++inner > 200) { rc = 2; break; }
+#ifdef RSOLVE_MARK
+                asm volatile("; @@R EQP_START" ::: "memory");
+#endif
+                RPH(0);
+                if (phase == 2 && ++inner > 200) { rc = 2; why = 4; break; }
                 cost += 6;
                 iters_total++;
                 // =========================================================== the equality-constrained QP of the working set (+ entering constraint)
                 const bool fixd = !comp || fx != 0;
+#ifdef RSOLVE_MARK
+                asm volatile("; @@R FDIRTY" ::: "memory");
+#endif
+                RPH(1);
                 if (fdirty) {
                     fdirty = false;
                     cost += 2;
@@ -284,56 +337,59 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
                     const double gl = row_allsum(lkc * Ykc), w0l = row_allsum(lkc * a0);
 #pragma unroll
                     for (int x = 0; x < 3; ++x) {
-                        g3[x] = readlane_d(gl, 16 * x); w03[x] = readlane_d(w0l, 16 * x);
-                        const bool pos = g3[x] > 1e-300;
-                        sg3[x] = pos ? g3[x] * fast_rsq(pos ? g3[x] : 1.0) : 0.0;
-                        isg3[x] = pos ? fast_rsq(pos ? g3[x] : 1.0) : 0.0;
+                        const double g = readlane_d(gl, 16 * x);
+                        w03[x] = readlane_d(w0l, 16 * x);
+                        const bool pos = g > 1e-300;
+                        const double ir_ = fast_rsq(pos ? g : 1.0);
+                        sg3[x] = pos ? g * ir_ : 0.0;
+                        isg3[x] = pos ? ir_ : 0.0;
                     }
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) if (i < nw) Yw[i] = rax_solve(A, fixd ? 0.0 : nbw[i], lKl, q2);
                 }
-                // ---- extras: the walls of the working set, then an entering wall / bound (a-space normal nbe, H~ nbe = Ye, both on one axis)
-                int ne = nw;
-                double nbe[R_NE] = {nbw[0], nbw[1], 0.0}, Ye[R_NE] = {Yw[0], Yw[1], 0.0};
-                const bool ent_extra = (phase == 2) && (ent == RE_BOUND || ent == RE_WALL);
-                if (nw == 1 && ent_extra) { nbe[1] = 0.0; Ye[1] = 0.0; }
-                if (ent_extra) {
-                    const int s = nw;   // its slot
-                    double nbp;
-                    if (ent == RE_BOUND) nbp = (lane == eidx) ? (double)esg : 0.0;
-                    else {
-                        const int ka = eidx & 15;
-                        nbp = (comp && ax_l == (eidx >> 4) && k_l <= ka) ? (double)esg * h2 * ((double)(ka - k_l) + 0.5) : 0.0;
-                    }
-                    const double Yp = rax_solve(A, fixd ? 0.0 : nbp, lKl, q2);
-#pragma unroll
-                    for (int i = 0; i < R_NE; ++i) if (i == s) { nbe[i] = nbp; Ye[i] = Yp; }
-                    ne = nw + 1;
-                }
+#ifdef RSOLVE_MARK
+                asm volatile("; @@R SOFT" ::: "memory");
+#endif
+                RPH(2);
                 // ---- soft rows: M_s = sum 2/sd^2 xi xi', q_s = M_s w0 + sum (2 b/sd^2 + st/sd) xi;  B = I + sqrt(G) M_s sqrt(G)
                 const bool r_in = rv && (rfl & RB_IN), r_hard = r_in && (rfl & (RB_PIN0 | RB_PINL)), r_soft = r_in && !r_hard;
                 Sym3 Bi; Bi.m00 = 1.0; Bi.m11 = 1.0; Bi.m22 = 1.0; Bi.m01 = 0.0; Bi.m02 = 0.0; Bi.m12 = 0.0;
                 double qt[3] = {0.0, 0.0, 0.0};
-                if (__ballot(r_soft) != 0ull) {
-                    cost += 2;
-                    const double al = r_soft ? 2.0 * risd * risd : 0.0;
-                    const double be = r_soft ? (2.0 * rb * risd + rst) * risd : 0.0;
-                    Sym3 Ms;
-                    Ms.m00 = wave_sum0(al * xi0 * xi0); Ms.m01 = wave_sum0(al * xi0 * xi1); Ms.m02 = wave_sum0(al * xi0 * xi2);
-                    Ms.m11 = wave_sum0(al * xi1 * xi1); Ms.m12 = wave_sum0(al * xi1 * xi2); Ms.m22 = wave_sum0(al * xi2 * xi2);
-                    double qs[3];
-                    sym3_mul(Ms, w03, qs);
-                    qs[0] += wave_sum0(be * xi0); qs[1] += wave_sum0(be * xi1); qs[2] += wave_sum0(be * xi2);
-                    Sym3 Bm;
-                    Bm.m00 = fma(sg3[0] * sg3[0], Ms.m00, 1.0); Bm.m11 = fma(sg3[1] * sg3[1], Ms.m11, 1.0); Bm.m22 = fma(sg3[2] * sg3[2], Ms.m22, 1.0);
-                    Bm.m01 = sg3[0] * sg3[1] * Ms.m01; Bm.m02 = sg3[0] * sg3[2] * Ms.m02; Bm.m12 = sg3[1] * sg3[2] * Ms.m12;
-                    Bi = sym3_inv(Bm);
-                    qt[0] = sg3[0] * qs[0]; qt[1] = sg3[1] * qs[1]; qt[2] = sg3[2] * qs[2];
+                {
+                    const unsigned long long softm = __ballot(r_soft);
+                    unsigned long long df = softm ^ softm_prev;
+                    softm_prev = softm;
+                    while (df != 0ull) {   // (a row at a time: one or none per step)
+                        const int j = __ffsll((long long)df) - 1; df &= df - 1ull;
+                        const double sgn = ((softm >> j) & 1ull) ? 1.0 : -1.0;
+                        const double x0 = readlane_d(xi0, j), x1 = readlane_d(xi1, j), x2 = readlane_d(xi2, j), bj = readlane_d(rb, j), isj = readlane_d(risd, j);
+                        const double al = sgn * 2.0 * isj * isj, be = sgn * (2.0 * bj * isj + st) * isj;
+                        Ms.m00 = fma(al * x0, x0, Ms.m00); Ms.m01 = fma(al * x0, x1, Ms.m01); Ms.m02 = fma(al * x0, x2, Ms.m02);
+                        Ms.m11 = fma(al * x1, x1, Ms.m11); Ms.m12 = fma(al * x1, x2, Ms.m12); Ms.m22 = fma(al * x2, x2, Ms.m22);
+                        msv[0] = fma(be, x0, msv[0]); msv[1] = fma(be, x1, msv[1]); msv[2] = fma(be, x2, msv[2]);
+                    }
+                    if (softm == 0ull) { Ms.m00 = Ms.m01 = Ms.m02 = Ms.m11 = Ms.m12 = Ms.m22 = 0.0; msv[0] = msv[1] = msv[2] = 0.0; }   // (nothing left of the sums' round-off)
+                    else {
+                        cost += 1;
+                        double qs[3];
+                        sym3_mul(Ms, w03, qs);
+                        qs[0] += msv[0]; qs[1] += msv[1]; qs[2] += msv[2];
+                        Sym3 Bm;
+                        Bm.m00 = fma(sg3[0] * sg3[0], Ms.m00, 1.0); Bm.m11 = fma(sg3[1] * sg3[1], Ms.m11, 1.0); Bm.m22 = fma(sg3[2] * sg3[2], Ms.m22, 1.0);
+                        Bm.m01 = sg3[0] * sg3[1] * Ms.m01; Bm.m02 = sg3[0] * sg3[2] * Ms.m02; Bm.m12 = sg3[1] * sg3[2] * Ms.m12;
+                        Bi = sym3_inv(Bm);
+                        qt[0] = sg3[0] * qs[0]; qt[1] = sg3[1] * qs[1]; qt[2] = sg3[2] * qs[2];
+                    }
                 }
+#ifdef RSOLVE_MARK
+                asm volatile("; @@R HARDLIST" ::: "memory");
+#endif
+                RPH(3);
                 // ---- the hard list, ONE CONSTRAINT PER LANE (lanes 0 .. nh-1): the hard rows of the working set in row order, the entering row
-                // (while it is hard) last among them, then the extras.  Lane c holds yt_c = its normal in the scaled w-space, its right-hand sides
-                // and row c of the small matrix S = Y' B^-1 Y + Om; the elimination broadcasts one pivot row at a time (Gauss-Jordan on a positive
-                // definite matrix, the entering constraint LAST: its pivot is delta = n_p' P n_p, the dependence test of the dual method).
+                // (while it is hard) last among them, then the extras (walls of the working set, an entering wall / bound).  Lane c holds
+                // yt_c = its normal in the scaled w-space, its right-hand sides and row c of the small matrix S = Y' B^-1 Y + Om; the elimination
+                // broadcasts one pivot row at a time (Gauss-Jordan on a positive definite matrix, the entering constraint LAST: its pivot is
+                // delta = n_p' P n_p, the dependence test of the dual method).
+                const bool ent_extra = (phase == 2) && (ent == RE_BOUND || ent == RE_WALL);
+                const int ne = nw + (ent_extra ? 1 : 0);
                 int erow = (phase == 2 && ent >= RE_ROW && ent <= RE_PINL) ? eidx : -1;
                 if (erow >= 0 && !((readlane_i(rfl, erow) & RB_IN) && (readlane_i(rfl, erow) & (RB_PIN0 | RB_PINL)))) erow = -1;   // soft by now (its pin gave way): no bordered constraint
                 unsigned long long hm = __ballot(r_hard);
@@ -341,110 +397,115 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
                 const int nhr0 = __popcll(hm);
                 const int nhr = nhr0 + (erow >= 0 ? 1 : 0);
                 const int nh = nhr + ne;
-                if (nh > R_NH) { rc = 2; break; }
+                if (nh > R_NH) { rc = 2; why = 6; break; }
                 const bool has_p = (phase == 2) && (ent_extra || erow >= 0);
-                int src = 0;
-                {
-                    unsigned long long m = hm;
+                double hy0 = 0.0, hy1 = 0.0, hy2 = 0.0, hrho = 0.0, hd = 0.0, hsc = 1.0;
+                if (nhr > 0) {
+                    if (hm != hm_prev || erow != herow_prev) {
+                        hm_prev = hm; herow_prev = erow;
+                        int src = 0;
+                        unsigned long long m = hm;
 #pragma unroll
-                    for (int c = 0; c < R_NH; ++c) {
-                        if (c >= nhr0) continue;
-                        const int j = __ffsll((long long)m) - 1; m &= m - 1ull;
-                        if (lane == c) src = j;
+                        for (int c = 0; c < R_NH; ++c) {
+                            if (c >= nhr0) break;
+                            const int j = __ffsll((long long)m) - 1; m &= m - 1ull;
+                            if (lane == c) src = j;
+                        }
+                        if (erow >= 0 && lane == nhr0) src = erow;
+                        gx0 = __shfl(xi0, src); gx1 = __shfl(xi1, src); gx2 = __shfl(xi2, src); gb = __shfl(rb, src); gsd = __shfl(rsd, src);
+                        gfl = __shfl(rfl, src);
                     }
-                    if (erow >= 0 && lane == nhr0) src = erow;
-                }
-                double hy0, hy1, hy2, hrho = 0.0, hd = 0.0, hsc = 1.0;
-                {
-                    const double gx0 = __shfl(xi0, src), gx1 = __shfl(xi1, src), gx2 = __shfl(xi2, src), gb = __shfl(rb, src), gsd = __shfl(rsd, src), gslb = __shfl(rslb, src);
-                    const int gfl = __shfl(rfl, src);
-                    const bool mine = lane < nhr;
-                    hy0 = mine ? -sg3[0] * gx0 : 0.0; hy1 = mine ? -sg3[1] * gx1 : 0.0; hy2 = mine ? -sg3[2] * gx2 : 0.0;
-                    if (mine) {
-                        hd = gb - ((gfl & RB_PINL) ? gsd * gslb : 0.0);
+                    if (lane < nhr) {
+                        hy0 = -sg3[0] * gx0; hy1 = -sg3[1] * gx1; hy2 = -sg3[2] * gx2;
+                        hd = gb - ((gfl & RB_PINL) ? gsd * slb : 0.0);
                         hrho = hd + (gx0 * w03[0] + gx1 * w03[1] + gx2 * w03[2]);
                         hsc = sc_row * (gx0 * gx0 + gx1 * gx1 + gx2 * gx2);
                     }
-                }
-                double om00 = 0.0, om01 = 0.0, om02 = 0.0, om11 = 0.0, om12 = 0.0, om22 = 0.0;   // Om = G0 - yt yt' over the extras
+                } else { hm_prev = ~0ull; herow_prev = -2; }
+                double omr[R_NE] = {0.0, 0.0, 0.0, 0.0};   // lane nhr + i: row i of Om = G0 - yt yt' over the extras
+                double Yp = 0.0;                             // H~ n of the entering bound (the common extra): kept for the update of a
                 if (ne > 0) {
                     cost += 2;
-                    double yte[R_NE][3], g0[R_NE][R_NE];
+                    if (ne == 1 && ent_extra && ent == RE_BOUND) {   // the entering bound alone: unit normal, every sum is a single entry
+                        const double sgd = (double)esg;
+                        Yp = rax_solve(A, (lane == eidx) ? sgd : 0.0, lKl, q2);
+                        const int x = eidx >> 4;
+                        const double t = sgd * readlane_d(Ykc, eidx) * (x == 0 ? isg3[0] : (x == 1 ? isg3[1] : isg3[2]));   // yt on its axis
+                        const double g0 = sgd * readlane_d(Yp, eidx), u0 = sgd * readlane_d(a0, eidx);
+                        if (lane == nhr) { hy0 = x == 0 ? t : 0.0; hy1 = x == 1 ? t : 0.0; hy2 = x == 2 ? t : 0.0; hd = P.alim; hrho = P.alim - u0; hsc = Gt[(eidx & 15) * 31]; omr[0] = g0 - t * t; }
+                    } else {
+                        // walls (and maybe an entering wall / bound), one at a time: normal and H~ n are formed here and again for the update of a -- nothing of
+                        // them is kept; an extra's normal lives on ONE axis, so yt_i is a scalar on that axis and G0_ij = n_j' H~ n_i needs extra i's H~ n only
+                        double yts[R_NE] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                    for (int i = 0; i < R_NE; ++i) { yte[i][0] = yte[i][1] = yte[i][2] = 0.0; for (int j = 0; j < R_NE; ++j) g0[i][j] = 0.0; }
+                        for (int i = 0; i < R_NE; ++i) {
+                            if (i >= ne) continue;
+                            const bool is_b = ent_extra && i == nw && ent == RE_BOUND;
+                            const int code = i < nw ? wcode[i < R_NW ? i : 0] : (eidx | (esg > 0 ? 256 : 0));
+                            const int wl = code & 63, xa = wl >> 4;
+                            const double nbi = is_b ? ((lane == eidx) ? (double)esg : 0.0) : wall_normal(code, comp, ax_l, k_l, h2);
+                            const double Yi = rax_solve(A, fixd ? 0.0 : nbi, lKl, q2);
+                            const double tl = row_allsum(lkc * Yi), ul = row_allsum(nbi * a0);
+                            yts[i] = readlane_d(tl, wl & 48) * (xa == 0 ? isg3[0] : (xa == 1 ? isg3[1] : isg3[2]));
+                            const double u0 = readlane_d(ul, wl & 48);
+                            const double dd = is_b ? P.alim : ((code & 256) ? readlane_d(whi_l, wl) : -readlane_d(wlo_l, wl));
+                            const double sc = is_b ? Gt[(wl & 15) * 31] : Gt[(15 + (wl & 15)) * 31];
+                            if (lane == nhr + i) { hy0 = xa == 0 ? yts[i] : 0.0; hy1 = xa == 1 ? yts[i] : 0.0; hy2 = xa == 2 ? yts[i] : 0.0; hd = dd; hrho = dd - u0; hsc = sc; }
 #pragma unroll
-                    for (int i = 0; i < R_NE; ++i) {
-                        if (i >= ne) continue;
-                        const bool is_b = ent_extra && i == nw && ent == RE_BOUND;
-                        const int wl = is_b ? eidx : ((i < nw ? wcode[i < 2 ? i : 0] : eidx) & 63);
-                        const int wsg = is_b ? esg : (i < nw ? ((wcode[i < 2 ? i : 0] & 256) ? 1 : -1) : esg);
-                        double t3[3], u0, dd, sc;
-                        if (is_b) {   // unit normal: the sums are single entries
-                            const double sgd = (double)esg;
-                            const double t = sgd * readlane_d(Ykc, eidx);
-                            const int x = eidx >> 4;
-                            t3[0] = x == 0 ? t : 0.0; t3[1] = x == 1 ? t : 0.0; t3[2] = x == 2 ? t : 0.0;
-                            u0 = sgd * readlane_d(a0, eidx); dd = P.alim; sc = Gt[(eidx & 15) * 31];
-#pragma unroll
-                            for (int j = 0; j <= i; ++j) g0[i][j] = g0[j][i] = sgd * readlane_d(Ye[j], eidx);
-                        } else {
-                            const double tl = row_allsum(lkc * Ye[i]), ul = row_allsum(nbe[i] * a0);
-                            t3[0] = readlane_d(tl, 0); t3[1] = readlane_d(tl, 16); t3[2] = readlane_d(tl, 32);
-                            u0 = readlane_d(ul, wl & 48);
-                            dd = wsg > 0 ? readlane_d(whi_l, wl) : -readlane_d(wlo_l, wl);
-                            sc = Gt[(15 + (wl & 15)) * 31];
-#pragma unroll
-                            for (int j = 0; j <= i; ++j) { const double gl2 = row_allsum(nbe[i] * Ye[j]); g0[i][j] = g0[j][i] = readlane_d(gl2, wl & 48); }
+                            for (int j = 0; j <= i; ++j) {
+                                const bool jb = ent_extra && j == nw && ent == RE_BOUND;
+                                const int cj = j < nw ? wcode[j < R_NW ? j : 0] : (eidx | (esg > 0 ? 256 : 0));
+                                const double nbj = (j == i) ? nbi : (jb ? ((lane == eidx) ? (double)esg : 0.0) : wall_normal(cj, comp, ax_l, k_l, h2));
+                                const bool same = ((cj & 63) >> 4) == xa;
+                                const double g0 = readlane_d(row_allsum(nbj * Yi), wl & 48);   // (0 when the two are on different axes)
+                                const double o = g0 - (same ? yts[i] * yts[j] : 0.0);
+                                if (lane == nhr + i) omr[j] = o;
+                                if (lane == nhr + j) omr[i] = o;
+                            }
                         }
-                        yte[i][0] = t3[0] * isg3[0]; yte[i][1] = t3[1] * isg3[1]; yte[i][2] = t3[2] * isg3[2];
-                        if (lane == nhr + i) { hy0 = yte[i][0]; hy1 = yte[i][1]; hy2 = yte[i][2]; hd = dd; hrho = dd - u0; hsc = sc; }
                     }
-                    om00 = g0[0][0] - (yte[0][0] * yte[0][0] + yte[0][1] * yte[0][1] + yte[0][2] * yte[0][2]);
-                    om01 = g0[0][1] - (yte[0][0] * yte[1][0] + yte[0][1] * yte[1][1] + yte[0][2] * yte[1][2]);
-                    om02 = g0[0][2] - (yte[0][0] * yte[2][0] + yte[0][1] * yte[2][1] + yte[0][2] * yte[2][2]);
-                    om11 = g0[1][1] - (yte[1][0] * yte[1][0] + yte[1][1] * yte[1][1] + yte[1][2] * yte[1][2]);
-                    om12 = g0[1][2] - (yte[1][0] * yte[2][0] + yte[1][1] * yte[2][1] + yte[1][2] * yte[2][2]);
-                    om22 = g0[2][2] - (yte[2][0] * yte[2][0] + yte[2][1] * yte[2][1] + yte[2][2] * yte[2][2]);
                 }
+#ifdef RSOLVE_MARK
+                asm volatile("; @@R SROWS" ::: "memory");
+#endif
+                RPH(5);
                 // row c of S and the right-hand side in lane c
-                double Sr[R_NH], rh, hlam = 0.0;
+                double Sr[R_NH], rh, hlam = 0.0, csave = 0.0;
                 double zeta[3] = {0.0, 0.0, 0.0};
                 int sing = 0;
+                const int ie = lane - nhr;
                 {
                     const double hv[3] = {hy0, hy1, hy2};
                     double by[3], bq[3];
                     sym3_mul(Bi, hv, by);
                     sym3_mul(Bi, qt, bq);
-                    rh = -hrho - (hy0 * bq[0] + hy1 * bq[1] + hy2 * bq[2]);
-                    // my row of Om (extras i = lane - nhr)
-                    const int ie = lane - nhr;
-                    const double omr0 = ie == 0 ? om00 : (ie == 1 ? om01 : om02), omr1 = ie == 0 ? om01 : (ie == 1 ? om11 : om12), omr2 = ie == 0 ? om02 : (ie == 1 ? om12 : om22);
+                    rh = (lane < nh) ? -hrho - (hy0 * bq[0] + hy1 * bq[1] + hy2 * bq[2]) : 0.0;
 #pragma unroll
                     for (int e = 0; e < R_NH; ++e) {
                         Sr[e] = 0.0;
                         if (e >= nh) continue;
                         const double b0 = readlane_d(by[0], e), b1 = readlane_d(by[1], e), b2 = readlane_d(by[2], e);
                         double t = hy0 * b0 + hy1 * b1 + hy2 * b2;
-                        if (e >= nhr && ie >= 0 && ie < ne) t += (e - nhr == 0) ? omr0 : ((e - nhr == 1) ? omr1 : omr2);
+                        if (e >= nhr && ie >= 0 && ie < ne) t += (e - nhr == 0) ? omr[0] : ((e - nhr == 1) ? omr[1] : ((e - nhr == 2) ? omr[2] : omr[3]));
                         Sr[e] = (lane < nh) ? t : 0.0;
                     }
-                    if (lane >= nh) rh = 0.0;
+#ifdef RSOLVE_MARK
+                asm volatile("; @@R GJ" ::: "memory");
+#endif
+                RPH(6);
                     // Gauss-Jordan, pivots in list order; the entering constraint's pivot decides dependence
                     bool bad = false;
-                    double csave = 0.0;   // column of the entering constraint in the eliminated rows, before its own pivot
 #pragma unroll
                     for (int k = 0; k < R_NH; ++k) {
                         if (k >= nh) continue;
                         const double piv = readlane_d(Sr[k], k), psc = readlane_d(hsc, k);
-                        if (k == nh - 1 && has_p) csave = Sr[k];
+                        if (k == nh - 1 && has_p) csave = Sr[k];   // (the entering constraint's column in the eliminated rows, before its own pivot)
                         if (!(piv > 1e-13 * psc)) {
                             if (k == nh - 1 && has_p) sing = 1; else bad = true;
                             continue;
                         }
-                        const double ipiv = fast_rcp(piv);
-                        const double f = (lane == k) ? 0.0 : Sr[k] * ipiv;
-                        const double prh = readlane_d(rh, k);
-                        rh = fma(-f, prh, rh);
+                        const double f = (lane == k) ? 0.0 : Sr[k] * fast_rcp(piv);
+                        rh = fma(-f, readlane_d(rh, k), rh);
 #pragma unroll
                         for (int e = 0; e < R_NH; ++e) {
                             if (e <= k || e >= nh) continue;
@@ -452,164 +513,179 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
                         }
                         if (lane != k) Sr[k] = 0.0;
                     }
-                    if (uni_b(bad)) { rc = 2; break; }
+                    if (uni_b(bad)) { rc = 2; why = 7; break; }
                     sing = UNI(sing);
-                    // my diagonal entry
-                    const double dgn = lane == 0 ? Sr[0] : (lane == 1 ? Sr[1] : (lane == 2 ? Sr[2] : (lane == 3 ? Sr[3] : Sr[4])));
+#ifdef RSOLVE_MARK
+                asm volatile("; @@R SOLVE_TAIL" ::: "memory");
+#endif
+                RPH(7);
+                    double dgn = Sr[0];   // my diagonal entry
+#pragma unroll
+                    for (int e = 1; e < R_NH; ++e) dgn = (lane == e) ? Sr[e] : dgn;
                     const double idg = (lane < nh && dgn > 0.0) ? fast_rcp(dgn) : 0.0;
                     if (!sing) {
                         hlam = rh * idg;
-                        // zeta = -B^-1 (qt + sum_c yt_c lam_c): sums over the eight lanes that can hold a constraint
-                        double p0 = hy0 * hlam, p1 = hy1 * hlam, p2 = hy2 * hlam;
-                        p0 += rshr<1>(p0); p0 += rshr<2>(p0); p0 += rshr<4>(p0);
-                        p1 += rshr<1>(p1); p1 += rshr<2>(p1); p1 += rshr<4>(p1);
-                        p2 += rshr<1>(p2); p2 += rshr<2>(p2); p2 += rshr<4>(p2);
-                        const double s3[3] = {qt[0] + readlane_d(p0, 7), qt[1] + readlane_d(p1, 7), qt[2] + readlane_d(p2, 7)};
-                        sym3_mul(Bi, s3, zeta);
+                        if (nh > 0) {
+                            // zeta = -B^-1 (qt + sum_c yt_c lam_c): sums over the eight lanes that can hold a constraint
+                            double p0 = hy0 * hlam, p1 = hy1 * hlam, p2 = hy2 * hlam;
+                            p0 += rshr<1>(p0); p0 += rshr<2>(p0); p0 += rshr<4>(p0);
+                            p1 += rshr<1>(p1); p1 += rshr<2>(p1); p1 += rshr<4>(p1);
+                            p2 += rshr<1>(p2); p2 += rshr<2>(p2); p2 += rshr<4>(p2);
+                            const double s3[3] = {qt[0] + readlane_d(p0, 7), qt[1] + readlane_d(p1, 7), qt[2] + readlane_d(p2, 7)};
+                            sym3_mul(Bi, s3, zeta);
+                        } else sym3_mul(Bi, qt, zeta);
                         zeta[0] = -zeta[0]; zeta[1] = -zeta[1]; zeta[2] = -zeta[2];
                         // a posteriori: the hard constraints must hold at the computed point (a last pivot of 1e-11 of its scale passes the test above,
                         // the multipliers are 1e17 and the point is noise: numerically singular -> the entering constraint is dependent)
-                        if (has_p && nh > 0) {
+                        if (has_p) {
                             double r = hy0 * zeta[0] + hy1 * zeta[1] + hy2 * zeta[2] - hrho;
                             if (ne > 0) {
-                                const double l0 = readlane_d(hlam, nhr), l1 = readlane_d(hlam, nhr + 1 < 64 ? nhr + 1 : 63), l2 = readlane_d(hlam, nhr + 2 < 64 ? nhr + 2 : 63);
-                                if (ie >= 0 && ie < ne) r -= omr0 * l0 + (ne > 1 ? omr1 * l1 : 0.0) + (ne > 2 ? omr2 * l2 : 0.0);
+#pragma unroll
+                                for (int i = 0; i < R_NE; ++i) { if (i >= ne) continue; const double li = readlane_d(hlam, nhr + i); if (ie >= 0 && ie < ne) r = fma(-omr[i], li, r); }
                             }
-                            const double worst = wave_max0(lane < nh ? fabs(r) : 0.0);
-                            if (!(worst <= 1e-9)) sing = 1;
+                            double wr = lane < nh ? fabs(r) : 0.0;   // (lanes 0 .. 7)
+                            wr = max_raw(wr, rshr<1>(wr)); wr = max_raw(wr, rshr<2>(wr)); wr = max_raw(wr, rshr<4>(wr));
+                            if (!(readlane_d(wr, 7) <= 1e-9)) sing = 1;
                         }
                     }
-                    if (sing && phase != 2) { rc = 2; break; }
-                    if (sing) {
-                        // the entering constraint in terms of the others: rr_c = (S_WW^-1 s)_c = its column in the eliminated rows (saved before its own
-                        // pivot) over their diagonal
-                        hlam = (lane < nh - 1) ? csave * idg : 0.0;   // rr_c
-                    }
+                    if (sing && phase != 2) { rc = 2; why = 8; break; }
+                    // dependent: the entering constraint in terms of the others, rr_c = (S_WW^-1 s)_c = its saved column over the rows' diagonals
+                    if (sing) hlam = (lane < nh - 1) ? csave * idg : 0.0;
                 }
+#ifdef RSOLVE_MARK
+                asm volatile("; @@R NEWVALS" ::: "memory");
+#endif
+                RPH(8);
                 // ---- new values (regular) or rates per unit of the entering multiplier (dependent: the primal does not move)
-                double a_n = a, mu_n = 0.0, lam_n = 0.0, pi_n = 0.0, rho_n = 0.0, eps_n = eps, lamp_n = 1.0, farkas = 0.0;
-                double lw_n[2] = {0.0, 0.0};
+                double a_n = a, mu_n = 0.0, lam_n = 0.0, lamp_n = 1.0, farkas = 0.0;
                 // the hard rows' multipliers (or rates) back in their row lanes: list position of row `lane`
                 const int hpos = (erow >= 0 && lane == erow) ? nhr0 : __popcll(hm & ((1ull << lane) - 1ull));
-                if (!sing) {
-                    const double lam_h = __shfl(hlam, r_hard ? hpos : 0);
-                    double wv[3];
-#pragma unroll
-                    for (int x = 0; x < 3; ++x) wv[x] = fma(sg3[x], zeta[x], w03[x]);
-                    if (rv) {
-                        pi_n = -rst;
-                        if (r_soft) {
-                            eps_n = (rb + (xi0 * wv[0] + xi1 * wv[1] + xi2 * wv[2])) * risd;
-                            lam_n = -(2.0 * eps_n + rst) * risd;
-                            pi_n = 0.0;
-                        } else if (r_hard) {
-                            const bool low = (rfl & RB_PINL) != 0;
-                            eps_n = low ? rslb : 0.0;
-                            lam_n = lam_h;
-                            if (low) { pi_n = 0.0; rho_n = fma(rsd, lam_n, 2.0 * rslb + rst); }
-                            else pi_n = -rst - rsd * lam_n;
-                        } else eps_n = 0.0;
-                    }
-                    // c = sum lam xi over the active rows -- summed directly: on an axis whose components are all fixed (g = 0) c moves no
-                    // acceleration, but it is part of the gradient there, i.e. of the multipliers of those bounds
-                    double cv[3] = {0.0, 0.0, 0.0};
-                    if (__ballot(r_in) != 0ull) {
-                        const double lr = r_in ? lam_n : 0.0;
-                        cv[0] = wave_sum0(lr * xi0); cv[1] = wave_sum0(lr * xi1); cv[2] = wave_sum0(lr * xi2);
-                    }
-                    const double c_l = ax_l == 0 ? cv[0] : (ax_l == 1 ? cv[1] : cv[2]);
-                    a_n = fma(Ykc, c_l, a0);
-                    double grad = -c_l * lkc;
-#pragma unroll
-                    for (int i = 0; i < R_NE; ++i) {
-                        if (i >= ne) continue;
-                        const double le = readlane_d(hlam, nhr + i);
-                        a_n = fma(-le, Ye[i], a_n);
-                        grad = fma(le, nbe[i], grad);
-                        if (i < nw) lw_n[i < 2 ? i : 0] = le; else lamp_n = le;
-                    }
-                    if (!comp) a_n = 0.0;
-                    // (the product with H1 is a wave collective -- DPP row shifts and rotations read 0 from lanes that are switched off: never inside a lane-dependent branch)
-                    const double ha_n = rax_hmul(a_n, dg, e_off, lKl, q2);
-                    mu_n = (comp && fx != 0) ? -(double)fx * (ha_n + f_l + grad) : 0.0;
-                } else {
-                    // dl of the last hard entry per unit of the entering multiplier, the others: -rr dl_last
+                double dlh = 0.0;
+                if (sing) {   // rate of constraint c in lane c: the last one dl_last per unit of the entering multiplier, the others -rr dl_last
                     double dl_last = 1.0;
                     if (ent == RE_PIN0) dl_last = -readlane_d(risd, eidx);
                     if (ent == RE_PINL) dl_last = readlane_d(risd, eidx);
-                    const double dlh = (lane < nh - 1) ? -hlam * dl_last : ((lane == nh - 1) ? dl_last : 0.0);   // lane c: rate of constraint c
-                    double fk = wave_sum0(dlh * hd);
-                    const double dl_row = __shfl(dlh, r_hard ? hpos : 0);
-                    if (rv && r_hard) {
-                        lam_n = dl_row;
-                        if (rfl & RB_PINL) rho_n = rsd * lam_n; else pi_n = -rsd * lam_n;
-                    }
-                    double dc[3] = {0.0, 0.0, 0.0};
-                    {
-                        const double lr = (rv && r_hard) ? lam_n : 0.0;
-                        dc[0] = wave_sum0(lr * xi0); dc[1] = wave_sum0(lr * xi1); dc[2] = wave_sum0(lr * xi2);
-                    }
-                    const double c_l = ax_l == 0 ? dc[0] : (ax_l == 1 ? dc[1] : dc[2]);
-                    double grad = -c_l * lkc;
-#pragma unroll
-                    for (int i = 0; i < R_NE; ++i) {
-                        if (i >= ne) continue;
-                        const double le = readlane_d(dlh, nhr + i);
-                        grad = fma(le, nbe[i], grad);
-                        if (i < nw) lw_n[i < 2 ? i : 0] = le;
-                    }
-                    mu_n = (comp && fx != 0) ? -(double)fx * grad : 0.0;
-                    fk += wave_sum0(mu_n * P.alim);
-                    farkas = fk;
-                    lamp_n = 1.0;
+                    dlh = (lane < nh - 1) ? -hlam * dl_last : ((lane == nh - 1) ? dl_last : 0.0);
+                    farkas = wave_sum0(dlh * hd);
                 }
+                const double hval = sing ? dlh : hlam;
+                double wv[3];
+#pragma unroll
+                for (int x = 0; x < 3; ++x) wv[x] = fma(sg3[x], zeta[x], w03[x]);
+                // the hard rows' values back in their row lanes (a handful of broadcasts: cheaper than a trip through the LDS crossbar), and
+                // c = sum lam xi over the active rows: the hard rows' part summed over the lanes of the small system, the soft rows' part is
+                // -(M_s w + m_s) (lam_j = -2/sd^2 (b + xi.w) - st/sd).  c is formed directly, not from zeta: on an axis whose components are all fixed
+                // (g = 0) it moves no acceleration, but it is part of the gradient there, i.e. of the multipliers of those bounds.  (dependent: the
+                // soft rows' multipliers do not move)
+                double cv[3] = {0.0, 0.0, 0.0};
+                if (nhr > 0) {
+                    double lam_h = 0.0;
+#pragma unroll
+                    for (int c = 0; c < R_NH; ++c) {
+                        if (c >= nhr) break;
+                        const double v = readlane_d(hval, c);
+                        if (hpos == c) lam_h = v;
+                    }
+                    if (r_hard) lam_n = lam_h;
+                    const bool mine = lane < nhr;
+                    double p0 = mine ? hval * gx0 : 0.0, p1 = mine ? hval * gx1 : 0.0, p2 = mine ? hval * gx2 : 0.0;
+                    p0 += rshr<1>(p0); p0 += rshr<2>(p0); p0 += rshr<4>(p0);
+                    p1 += rshr<1>(p1); p1 += rshr<2>(p1); p1 += rshr<4>(p1);
+                    p2 += rshr<1>(p2); p2 += rshr<2>(p2); p2 += rshr<4>(p2);
+                    cv[0] = readlane_d(p0, 7); cv[1] = readlane_d(p1, 7); cv[2] = readlane_d(p2, 7);
+                }
+                if (!sing && softm_prev != 0ull) {
+                    if (r_soft) lam_n = -(2.0 * ((rb + (xi0 * wv[0] + xi1 * wv[1] + xi2 * wv[2])) * risd) + st) * risd;
+                    double mw[3];
+                    sym3_mul(Ms, wv, mw);
+                    cv[0] -= mw[0] + msv[0]; cv[1] -= mw[1] + msv[1]; cv[2] -= mw[2] + msv[2];
+                }
+                const double c_l = ax_l == 0 ? cv[0] : (ax_l == 1 ? cv[1] : cv[2]);
+                double grad = -c_l * lkc;
+                if (!sing) a_n = fma(Ykc, c_l, a0);
+                if (ne > 0) {
+                    if (ne == 1 && ent_extra && ent == RE_BOUND) {
+                        const double le = readlane_d(hval, nhr);
+                        if (!sing) { a_n = fma(-le, Yp, a_n); lamp_n = le; }
+                        if (lane == eidx) grad += le * (double)esg;
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < R_NE; ++i) {
+                            if (i >= ne) continue;
+                            const bool is_b = ent_extra && i == nw && ent == RE_BOUND;
+                            const int code = i < nw ? wcode[i < R_NW ? i : 0] : (eidx | (esg > 0 ? 256 : 0));
+                            const double nb = is_b ? ((lane == eidx) ? (double)esg : 0.0) : wall_normal(code, comp, ax_l, k_l, h2);
+                            const double le = readlane_d(hval, nhr + i);
+                            if (!sing) { const double Yi = rax_solve(A, fixd ? 0.0 : nb, lKl, q2); a_n = fma(-le, Yi, a_n); }
+                            grad = fma(le, nb, grad);
+                            if (i < nw) { if (lane == 48 + i) mu_n = le; } else if (!sing) lamp_n = le;
+                        }
+                    }
+                }
+                if (!comp) a_n = 0.0;
+                {
+                    // (the product with H1 is a wave collective -- DPP row shifts and rotations read 0 from lanes that are switched off: never inside a lane-dependent branch)
+                    const double ha_n = sing ? 0.0 : rax_hmul(a_n, dg, e_off, lKl, q2) + f_l;
+                    if (comp && fx != 0) mu_n = -(double)fx * (ha_n + grad);
+                }
+                if (sing) farkas += wave_sum0((comp && fx != 0) ? mu_n * P.alim : 0.0);
+#ifdef RSOLVE_MARK
+                asm volatile("; @@R PHASE" ::: "memory");
+#endif
+                RPH(9);
                 // =========================================================== what the phase does with it
-#if defined(DMPC_DEV_TRACE) || defined(RSOLVE_TRACE)
+#if defined(RSOLVE_TRACE)
                 if (phase == 1 && P.dbg && gid == P.dbg_agent && lane == 0 && iters_total <= P.dbg_cap - 2) {
                     double *d = P.dbg + (size_t)(iters_total - 1) * 8;
                     d[0] = (double)(phase + 10 * ent + 1000 * eidx); d[1] = (double)(nh + 16 * ne + 256 * (sing + 1) + 4096 * nhr);
-                    d[2] = w03[0]; d[3] = w03[1]; d[4] = w03[2]; d[5] = g3[0]; d[6] = g3[1]; d[7] = g3[2];
+                    d[2] = w03[0]; d[3] = w03[1]; d[4] = w03[2]; d[5] = sg3[0] * sg3[0]; d[6] = sg3[1] * sg3[1]; d[7] = sg3[2] * sg3[2];
                 }
 #endif
                 if (phase == 1) {   // crash: free the bounds whose multipliers came out negative, solve again; then the first scan
                     const unsigned long long neg = __ballot(comp && fx != 0 && mu_n < 0.0);
                     if (neg != 0ull) { if (comp && fx != 0 && mu_n < 0.0) fx = 0; fdirty = true; continue; }
-                    a = a_n; mu = mu_n; eps = eps_n; lam = lam_n; pi_ = pi_n; rho = rho_n;
+                    a = a_n; mu = mu_n; lam = lam_n;
                     phase = 3;
                     continue;
                 }
+#ifdef RSOLVE_MARK
+                asm volatile("; @@R RATIO" ::: "memory");
+#endif
+                RPH(9);
                 // ---- ratio test over the multipliers of the working set (the entering constraint's own multiplier does not block)
                 // inverse step lengths, identity 0: regular (new < 0): (cur - new) / cur >= 1 blocks at tau = cur / (cur - new); dependent (rate < 0): -rate / cur
                 double ir = 0.0; int bt = -1;
 #define RRT(cur_, new_, ty_) do { const double c__ = (cur_), n__ = (new_); if (n__ < 0.0) { \
                     const double num__ = sing ? -n__ : (c__ - n__); const double r__ = c__ > 1e-300 ? fast_div(num__, c__) : INFINITY; \
                     if (r__ > ir) { ir = r__; bt = (ty_); } } } while (0)
-                if (comp && fx != 0) RRT(mu, mu_n, 0);
+                if ((comp && fx != 0) || (lane >= 48 && lane < 48 + nw)) RRT(mu, mu_n, lane < 48 ? 0 : 4);
                 if (r_in) {
-                    const int own = (phase == 2 && ent >= RE_ROW && ent <= RE_PINL && lane == eidx) ? ent : -1;
+                    const int own = (ent >= RE_ROW && ent <= RE_PINL && lane == eidx) ? ent : -1;
                     if (own != RE_ROW) RRT(lam, lam_n, 1);
-                    if ((rfl & RB_PIN0) && own != RE_PIN0) RRT(pi_, pi_n, 2);
-                    if ((rfl & RB_PINL) && own != RE_PINL) RRT(rho, rho_n, 3);
+                    // the pins' multipliers from lam: pi = -st - sd lam, rho = 2 slb + st + sd lam (rates: -sd dlam, +sd dlam)
+                    if ((rfl & RB_PIN0) && own != RE_PIN0) RRT(-st - rsd * lam, sing ? -rsd * lam_n : -st - rsd * lam_n, 2);
+                    if ((rfl & RB_PINL) && own != RE_PINL) RRT(fma(rsd, lam, 2.0 * slb + st), sing ? rsd * lam_n : fma(rsd, lam_n, 2.0 * slb + st), 3);
                 }
-                // (walls: uniform values, tested by lanes 48 and 49 -- never component lanes with a multiplier of their own)
-                if (lane == 48 && nw > 0) RRT(lw[0], lw_n[0], 4);
-                if (lane == 49 && nw > 1) RRT(lw[1], lw_n[1], 5);
 #undef RRT
                 const double imax = wave_max0(ir);
                 const bool blocked = sing ? (imax > 0.0) : (imax > 1.0);
-#if defined(DMPC_DEV_TRACE) || defined(RSOLVE_TRACE)
-                if (P.dbg && gid == P.dbg_agent && lane == 0 && iters_total <= P.dbg_cap - 2) {   // development: one record per equality-constrained QP
+#if defined(RSOLVE_TRACE)
+                if (P.dbg && gid == P.dbg_agent && lane == 0 && iters_total <= P.dbg_cap - 5) {   // development: one record per equality-constrained QP
                     double *d = P.dbg + (size_t)(iters_total - 1) * 8;
                     d[0] = (double)(phase + 10 * ent + 1000 * eidx); d[1] = (double)(nh + 16 * ne + 256 * (sing + 1) + 4096 * nhr);
-                    d[2] = fma(sg3[0], zeta[0], w03[0]); d[3] = fma(sg3[1], zeta[1], w03[1]); d[4] = fma(sg3[2], zeta[2], w03[2]);
-                    d[5] = imax; d[6] = g3[0]; d[7] = w03[0];
+                    d[2] = wv[0]; d[3] = wv[1]; d[4] = wv[2];
+                    d[5] = imax; d[6] = sg3[0] * sg3[0]; d[7] = w03[0];
                 }
 #endif
+#ifdef RSOLVE_MARK
+                asm volatile("; @@R STEP" ::: "memory");
+#endif
+                RPH(10);
                 if (sing && !blocked) {
-                    if (!(farkas < 0.0)) { rc = 2; break; }
+                    if (!(farkas < 0.0)) { rc = 2; why = 9; break; }
                     // how far up the ladder does this Farkas combination reach (dmpc_solve.hip, round 5): C + 2^m U with U the part that carries slb
                     if (ladder && violation) {
-                        const double u_l = (rv && r_hard && (rfl & RB_PINL)) ? lam_n * (-rsd * rslb) : 0.0;
+                        const double u_l = (r_hard && (rfl & RB_PINL)) ? lam_n * (-rsd * slb) : 0.0;
                         const double Uc = wave_sum0(u_l), Cc = farkas - Uc;
                         if (Cc + Uc < 0.0) {
                             double kk = 2.0;
@@ -619,12 +695,12 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
                     rc = 1; break;
                 }
                 if (!blocked) {   // full step: the entering constraint joins the working set
-                    a = a_n; mu = mu_n; eps = eps_n; lam = lam_n; pi_ = pi_n; rho = rho_n; lw[0] = lw_n[0]; lw[1] = lw_n[1];
+                    a = a_n; mu = mu_n; lam = lam_n;
                     if (ent == RE_BOUND) { if (lane == eidx) { fx = esg; mu = lamp_n; } fdirty = true; }
                     else if (ent == RE_WALL) {
-                        const int s = nw;
 #pragma unroll
-                        for (int i = 0; i < 2; ++i) if (i == s) { wcode[i] = eidx | (esg > 0 ? 256 : 0); lw[i] = lamp_n; nbw[i] = nbe[i]; Yw[i] = Ye[i]; }
+                        for (int i = 0; i < R_NW; ++i) if (i == nw) wcode[i] = eidx | (esg > 0 ? 256 : 0);
+                        if (lane == 48 + nw) mu = lamp_n;
                         nw++;
                     }
                     phase = 3;
@@ -632,29 +708,27 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
                 }
                 // partial step to the blocking multiplier, which leaves the working set
                 const double tau = imax < INFINITY ? fast_rcp(imax) : 0.0;
-                if (sing) {
-                    mu = fma(tau, mu_n, mu); lam = fma(tau, lam_n, lam); pi_ = fma(tau, pi_n, pi_); rho = fma(tau, rho_n, rho);
-                    lw[0] = fma(tau, lw_n[0], lw[0]); lw[1] = fma(tau, lw_n[1], lw[1]);
-                    lam_p += tau;
-                } else {
-                    a = fma(tau, a_n - a, a); eps = fma(tau, eps_n - eps, eps);
-                    mu = fma(tau, mu_n - mu, mu); lam = fma(tau, lam_n - lam, lam); pi_ = fma(tau, pi_n - pi_, pi_); rho = fma(tau, rho_n - rho, rho);
-                    lw[0] = fma(tau, lw_n[0] - lw[0], lw[0]); lw[1] = fma(tau, lw_n[1] - lw[1], lw[1]);
-                    lam_p = fma(tau, lamp_n - lam_p, lam_p);
-                }
+                if (!(tau > 0.0) && ++zero_steps > 6) { rc = 2; why = 10; break; }   // (degenerate: steps of length zero trading two dependent constraints for each other -- the general solver takes the agent)
+                if (sing) { mu = fma(tau, mu_n, mu); lam = fma(tau, lam_n, lam); }
+                else { a = fma(tau, a_n - a, a); mu = fma(tau, mu_n - mu, mu); lam = fma(tau, lam_n - lam, lam); }
                 const unsigned long long bm = __ballot(bt >= 0 && ir == imax);
                 const int bl = __ffsll((long long)bm) - 1;
                 const int bty = readlane_i(bt, bl);
+#if defined(RSOLVE_TRACE)
+                if (P.dbg && gid == P.dbg_agent && lane == 0 && iters_total <= P.dbg_cap - 5) { double *d = P.dbg + (size_t)(iters_total - 1) * 8; d[6] = (double)(bty * 100 + bl); d[7] = tau; }
+#endif
                 if (bty == 0) { if (lane == bl) { fx = 0; mu = 0.0; } fdirty = true; }
                 else if (bty == 1) {
-                    if (lane == bl) { rfl = RB_PIN0; lam = 0.0; pi_ = -rst; rho = 0.0; eps = 0.0; }
+                    if (lane == bl) { rfl = RB_PIN0; lam = 0.0; }
                     if ((ent == RE_PIN0 || ent == RE_PINL) && eidx == bl) { phase = 3; continue; }   // the entering pin's row left: nothing to add
                 }
-                else if (bty == 2) { if (lane == bl) { rfl &= ~RB_PIN0; pi_ = 0.0; } }
-                else if (bty == 3) { if (lane == bl) { rfl &= ~RB_PINL; rho = 0.0; } }
-                else {
-                    const int s = bty - 4;
-                    if (s == 0) { wcode[0] = wcode[1]; lw[0] = lw[1]; nbw[0] = nbw[1]; Yw[0] = Yw[1]; }
+                else if (bty == 2) { if (lane == bl) rfl &= ~RB_PIN0; }
+                else if (bty == 3) { if (lane == bl) rfl &= ~RB_PINL; }
+                else {   // wall bl - 48 leaves: the ones behind it move up
+                    const int s = bl - 48;
+                    const double m1 = readlane_d(mu, 49), m2 = readlane_d(mu, 50);
+                    if (s == 0) { wcode[0] = wcode[1]; if (lane == 48) mu = m1; }
+                    if (s <= 1) { wcode[1] = wcode[2]; if (lane == 49) mu = m2; }
                     nw--;
                 }
             }
@@ -668,8 +742,12 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
             // infeasible: the retry ladder (solveSoftDMPCbound.m:147-153): lb_eps *= 2, term *= 2
             if (ladder && violation) {
                 double f = 2.0;
-                while (tries < max_tries - 1 && lev_skip > 0) { --lev_skip; f *= 2.0; ++tries; }
-                rslb *= f; rst *= f;
+                while (tries < max_tries - 1) {
+                    if (lev_skip > 0) { --lev_skip; f *= 2.0; ++tries; continue; }   // (infeasible by the proof the failed solve ended with)
+                    if (!uni_b(ladder_level_infeasible(r_xi, r_b, r_sd, r_slb, r_kc, nr, B, P.h, P.alim, lev_f * f, whi_s, wlo_s, lane, RCERT_PLANES))) { cert_known = true; break; }
+                    f *= 2.0; ++tries;
+                }
+                slb *= f; st *= f; lev_f *= f;
                 continue;
             }
             if (ladder) tries = max_tries;
@@ -677,7 +755,7 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
         }
         if (!solved && !giveup) status |= ST_INFEAS;
     }
-#if defined(DMPC_DEV_TRACE) || defined(RSOLVE_TRACE)
+#if defined(RSOLVE_TRACE)
     {
         const unsigned long long mhi = __ballot(comp && fx > 0), mlo = __ballot(comp && fx < 0), min_ = __ballot(rv && (rfl & RB_IN)), mp0 = __ballot(rv && (rfl & RB_IN) && (rfl & RB_PIN0)), mpl = __ballot(rv && (rfl & RB_PINL));
         if (P.dbg && gid == P.dbg_agent && lane == 0 && P.dbg_cap >= 2) {
@@ -686,7 +764,10 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
             d[4] = (double)min_; d[5] = (double)mp0; d[6] = (double)mpl; d[7] = (double)(iters_total + 1000 * nw + 100000 * (giveup ? 1 : 0));
         }
     }
+    if (P.dbg && gid == P.dbg_agent && lane == 0 && P.dbg_cap >= 4) { double *d = P.dbg + (size_t)(P.dbg_cap - 4) * 8; for (int u = 0; u < 12; ++u) d[u] = (double)rph[u]; }
+    if (giveup && P.dbg && P.dbg_agent == -7 && lane == 0) { atomicAdd((int *)P.dbg + (why & 15), 1); P.dbg[16 + (why & 15)] = (double)gid + 1e-3 * (double)iters_total; }   // development: histogram of the reasons, an agent of each
 #endif
+    (void)why;
     const KargPtr Qp = kernarg_params();
     RCLAIM_NEXT();
     if (giveup) {   // the general kernel takes this agent (tier-2 launch over the flagged list)
@@ -702,7 +783,9 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
     const bool no_set = solved && __ballot((comp && fx != 0) || (rv && (rfl & RB_IN))) == 0ull && nw == 0;
     if (solved) {
         status |= ST_SOLVED;
-        nslack = (int)wave_sum0((rv && eps < -1e-12) ? 1.0 : 0.0);
+        const bool in_ = rv && (rfl & RB_IN);
+        const double eps = !in_ ? 0.0 : ((rfl & RB_PINL) ? slb : ((rfl & RB_PIN0) ? 0.0 : -0.5 * fma(rsd, lam, st)));
+        nslack = __popcll(__ballot(eps < -1e-12));
     }
     {
         const double s0 = row_prefix(comp ? a : 0.0), s1 = row_prefix(comp ? (double)k_l * a : 0.0);
@@ -762,4 +845,6 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
         }
     }
 #undef RCLAIM_NEXT
+#undef PMAXQ
+#undef PMINQ
 }

@@ -19,10 +19,16 @@ from helpers import load_golden, step14_inputs  # noqa: E402
 def compare(tag, kw, l, xp, xv, xa, pf, variant="bound"):
     red = mp.Dmpc(variant, device=0, **kw)
     gen = mp.Dmpc(variant, device=0, **kw)
+    import ctypes as C
+    from multiagent_planning_amd import _lib
+    L = _lib.load(); L.dmpc_debug_trace.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.dmpc_debug_trace(red._ctx, -7, 8, None)
     gen.debug_option("reduced_solver", 0)
     o_r = red.step_batch(l, xp, xv, xa, pf)
     o_g = gen.step_batch(l, xp, xv, xa, pf)
     ref = orc.step(orc.make_params(variant, **kw), l, xp, xv, xa, pf, nthreads=os.cpu_count())
+    hb = np.zeros((8, 8)); L.dmpc_debug_trace(red._ctx, -7, 8, hb.ctypes.data_as(C.c_void_p))
+    print("      give-up reasons (1 rows>64, 2 steps, 3 iter cap, 4 inner cap, 5 third wall, 6 nh>5, 7 bad pivot, 8 crash singular, 9 farkas):", hb.view(np.int32).ravel()[:10].tolist(), "agents", hb.ravel()[16:26].tolist())
     st_r, st_g, st_o = o_r["status"].ravel(), o_g["status"].ravel(), ref["status"].ravel()
     ir, ig, io = o_r["info"].reshape(-1, 8), o_g["info"].reshape(-1, 8), ref["info"].reshape(-1, 8)
     N = len(st_o)
@@ -36,6 +42,9 @@ def compare(tag, kw, l, xp, xv, xa, pf, variant="bound"):
         if st_r[n] != st_o[n] or ir[n, 2] != io[n, 2] or e > 1e-8 or ep > 1e-8:
             bad.append((n, int(st_r[n]), int(st_o[n]), int(ir[n, 2]), int(io[n, 2]), e, ep, eg, int(ir[n, 1]), int(ir[n, 4]), int(ir[n, 7]), int(ig[n, 4])))
     print(f"{tag}: N {N}  worst l_inf(a, p) reduced vs oracle {worst:.2e}  disagreeing agents {len(bad)}  mean EQPs {ir[:, 4].mean():.2f}  general iters {ig[:, 4].mean():.2f}")
+    same = int(((ir[:, 4] == ig[:, 4]) & (ir[:, 7] == ig[:, 7]) & (ig[:, 4] > 3)).sum())
+    top = np.argsort(-ir[:, 4])[:8]
+    print("      agents that look like the general solver's (flagged):", same, " longest (agent, EQPs, rows, tries):", [(int(n), int(ir[n, 4]), int(ir[n, 1]), int(ir[n, 2])) for n in top])
     for b in bad[:25]:
         print("   agent %d status %d/%d tries %d/%d err a %.2e p %.2e (general %.2e) rows %d eqps %d maxq %d gen.iters %d" % b)
     return len(bad)

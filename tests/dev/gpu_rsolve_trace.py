@@ -34,17 +34,19 @@ else:
 d = mp.Dmpc("bound", device=0, **kw)
 L = _lib.load()
 L.dmpc_debug_trace.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
-cap = 256
+cap = int(os.environ.get('TRACE_CAP', '256'))
 assert L.dmpc_debug_trace(d._ctx, agent, cap, None) == 0
 out = d.step_batch(l, xp, xv, xa, pf)
 buf = np.zeros((cap, 8))
 assert L.dmpc_debug_trace(d._ctx, agent, cap, buf.ctypes.data_as(C.c_void_p)) == 0
 print("status", out["status"][agent], "info", out["info"][agent])
-for i in range(cap - 2):
+for i in range(cap - 4):
     r = buf[i]
     if r[1] == 0: break
     c0, c1 = int(r[0]), int(r[1])
     print(f"EQP {i}: phase {c0 % 10} ent {(c0 // 10) % 100} idx {c0 // 1000}  nh {c1 & 15} ne {(c1 >> 4) & 15} sing {((c1 >> 8) & 15) - 1} nhr {c1 >> 12}   {r[2]:.10e} {r[3]:.10e} {r[4]:.10e}  | {r[5]:.6e} {r[6]:.6e} {r[7]:.6e}")
+ph = buf[cap - 4:cap - 2].ravel()[:12]
+print("cycles by section (0 scan, 1 start, 2 fdirty, 3 soft, 4 hardlist, 5 extras, 6 srows, 7 gj, 8 solve tail, 9 newvals, 10 ratio, 11 step):", [int(v) for v in ph], "sum", int(ph.sum()))
 r = buf[cap - 2]
 print("first scan: w_kc", r[0], r[1], r[2], "score", r[3], "pcode", int(r[4]), "rb", r[5], "xi0", r[6], "xi1", r[7])
 r = buf[cap - 1]
