@@ -36,6 +36,7 @@ enum { RB_IN = 1, RB_PIN0 = 2, RB_PINL = 4 };
 constexpr int R_NH = 8;   // hard constraints of the small system, one per lane (hard rows + walls + the entering constraint)
 constexpr int R_NW = 3;   // walls of the working set (a corner of the workspace)
 constexpr int R_NE = R_NW + 1;
+constexpr int RBLOCK_MAX = 24;     // block moves of the bounds per ladder level (then the exact one-at-a-time steps only)
 constexpr int RCERT_AFTER = 6;      // scans of a ladder level before the certificate looks at it
 constexpr int RCERT_PLANES = 70;    // planes the wave's LDS holds for it: 64 rows + 6 box faces   // extras: the walls + an entering wall / bound
 
@@ -241,6 +242,19 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
             int ent = RE_NONE, eidx = 0, esg = 0;   // entering constraint: type, lane of the component / row, sign
             int phase = 0;                  // 1: crash (free the negative multipliers), 2: iteration, 3: violation scan
             int inner = 0, iters = 0, zero_steps = 0;
+            // Block moves of the acceleration bounds.  An equality-constrained QP costs the same whatever changed since the last one, and the bounds flip
+            // in blocks: a row that enters pushes a dozen of the fixed accelerations off their bounds, which the ratio test frees one partial step at
+            // a time, and a dozen others are then violated and enter one full step at a time (an agent of 79 steps: 60 of them such).  So: (a) when the
+            // scan's choice is a bound, EVERY violated bound is fixed at once; (b) when a bound's multiplier blocks the entering constraint, the entering
+            // constraint joins and every bound whose multiplier would turn negative is freed at once -- then, as in the crash start, the bounds with
+            // negative multipliers are freed until none is left.  The result is accepted if every multiplier of the working set is non-negative: it is
+            // then a state of the dual method like any other (the minimiser of its working set, dual feasible).  If a row's, pin's or wall's
+            // multiplier comes out negative the move is taken back and the exact step is made.  A budget per level keeps the method finite.
+            bool blk = false, noblock = false;
+#define RBLOCK_UNDO() do { fx = ((fxhi_s >> lane) & 1ull) ? 1 : (((fxlo_s >> lane) & 1ull) ? -1 : 0); rfl = rfl_s; \
+                           blk = false; noblock = true; fdirty = true; phase = sphase; inner = 0; } while (0)
+            int nblock = 0, sphase = 0, rfl_s = 0;
+            unsigned long long fxhi_s = 0ull, fxlo_s = 0ull;
             bool cert_done = cert_known;
             cert_known = false;
             {   // crash start: every bound violated at the unconstrained minimiser is fixed
@@ -291,6 +305,15 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
                     const int pcode = readlane_i(bestc, __ffsll((long long)wm) - 1);
                     ent = pcode >> 16; eidx = pcode & 63; esg = (pcode & 256) ? 1 : -1;
                     if (ent == RE_WALL && nw >= R_NW) { rc = 2; why = 5; break; }
+                    if (ent == RE_BOUND && !noblock && nblock < RBLOCK_MAX) {
+                        const bool vb_ = comp && fx == 0 && fabs(a) - P.alim > tol;
+                        if (__popcll(__ballot(vb_)) >= 2) {
+                            fxhi_s = __ballot(comp && fx > 0); fxlo_s = __ballot(comp && fx < 0); rfl_s = rfl; sphase = 3;
+                            if (vb_) fx = a > 0.0 ? 1 : -1;
+                            blk = true; ++nblock; fdirty = true; phase = 1; inner = 0;
+                        }
+                    }
+                    if (phase == 3) {
                     // rows and pins join the working set at once (they stay "entering": their own multiplier does not block)
                     if (lane == eidx) {
                         if (ent == RE_ROW) rfl |= RB_IN;
@@ -299,6 +322,7 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
                     }
                     inner = 0;
                     phase = 2;
+                    }
                 }
 #ifdef RSOLVE_MARK
                 asm volatile("; @@R EQP_START" ::: "memory");
@@ -397,7 +421,7 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
                 const int nhr0 = __popcll(hm);
                 const int nhr = nhr0 + (erow >= 0 ? 1 : 0);
                 const int nh = nhr + ne;
-                if (nh > R_NH) { rc = 2; why = 6; break; }
+                if (nh > R_NH) { if (blk) { RBLOCK_UNDO(); continue; } rc = 2; why = 6; break; }
                 const bool has_p = (phase == 2) && (ent_extra || erow >= 0);
                 double hy0 = 0.0, hy1 = 0.0, hy2 = 0.0, hrho = 0.0, hd = 0.0, hsc = 1.0;
                 if (nhr > 0) {
@@ -513,7 +537,7 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
                         }
                         if (lane != k) Sr[k] = 0.0;
                     }
-                    if (uni_b(bad)) { rc = 2; why = 7; break; }
+                    if (uni_b(bad)) { if (blk) { RBLOCK_UNDO(); continue; } rc = 2; why = 7; break; }   // (a block move that made the working set dependent is taken back)
                     sing = UNI(sing);
 #ifdef RSOLVE_MARK
                 asm volatile("; @@R SOLVE_TAIL" ::: "memory");
@@ -548,7 +572,7 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
                             if (!(readlane_d(wr, 7) <= 1e-9)) sing = 1;
                         }
                     }
-                    if (sing && phase != 2) { rc = 2; why = 8; break; }
+                    if (sing && phase != 2 && !blk) { rc = 2; why = 8; break; }
                     // dependent: the entering constraint in terms of the others, rr_c = (S_WW^-1 s)_c = its saved column over the rows' diagonals
                     if (sing) hlam = (lane < nh - 1) ? csave * idg : 0.0;
                 }
@@ -643,8 +667,17 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
 #endif
                 if (phase == 1) {   // crash: free the bounds whose multipliers came out negative, solve again; then the first scan
                     const unsigned long long neg = __ballot(comp && fx != 0 && mu_n < 0.0);
+                    if (blk) {   // block move: the other multipliers must stay non-negative, or the move is taken back
+                        const bool rneg = r_in && (lam_n < 0.0 || ((rfl & RB_PIN0) && -st - rsd * lam_n < 0.0) || ((rfl & RB_PINL) && fma(rsd, lam_n, 2.0 * slb + st) < 0.0));
+                        const bool wneg = lane >= 48 && lane < 48 + nw && mu_n < 0.0;
+                        if (sing || __ballot(rneg || wneg) != 0ull || ++inner > 12) {
+                            RBLOCK_UNDO();
+                            continue;
+                        }
+                    }
                     if (neg != 0ull) { if (comp && fx != 0 && mu_n < 0.0) fx = 0; fdirty = true; continue; }
                     a = a_n; mu = mu_n; lam = lam_n;
+                    blk = false; noblock = false;
                     phase = 3;
                     continue;
                 }
@@ -695,7 +728,7 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
                     rc = 1; break;
                 }
                 if (!blocked) {   // full step: the entering constraint joins the working set
-                    a = a_n; mu = mu_n; lam = lam_n;
+                    a = a_n; mu = mu_n; lam = lam_n; noblock = false;
                     if (ent == RE_BOUND) { if (lane == eidx) { fx = esg; mu = lamp_n; } fdirty = true; }
                     else if (ent == RE_WALL) {
 #pragma unroll
@@ -706,14 +739,25 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
                     phase = 3;
                     continue;
                 }
+                // the blocking multiplier
+                const unsigned long long bm = __ballot(bt >= 0 && ir == imax);
+                const int bl = __ffsll((long long)bm) - 1;
+                const int bty = readlane_i(bt, bl);
+                if (!sing && bty == 0 && !noblock && nblock < RBLOCK_MAX && ent != RE_WALL) {
+                    const bool ng = comp && fx != 0 && mu_n < 0.0;
+                    if (__popcll(__ballot(ng)) >= 2) {   // block move (b): the entering constraint joins, every bound whose multiplier would turn negative is freed
+                        fxhi_s = __ballot(comp && fx > 0); fxlo_s = __ballot(comp && fx < 0); rfl_s = rfl; sphase = 2;
+                        if (ng) fx = 0;
+                        if (ent == RE_BOUND && lane == eidx) fx = esg;
+                        blk = true; ++nblock; fdirty = true; phase = 1; inner = 0;
+                        continue;
+                    }
+                }
                 // partial step to the blocking multiplier, which leaves the working set
                 const double tau = imax < INFINITY ? fast_rcp(imax) : 0.0;
                 if (!(tau > 0.0) && ++zero_steps > 6) { rc = 2; why = 10; break; }   // (degenerate: steps of length zero trading two dependent constraints for each other -- the general solver takes the agent)
                 if (sing) { mu = fma(tau, mu_n, mu); lam = fma(tau, lam_n, lam); }
                 else { a = fma(tau, a_n - a, a); mu = fma(tau, mu_n - mu, mu); lam = fma(tau, lam_n - lam, lam); }
-                const unsigned long long bm = __ballot(bt >= 0 && ir == imax);
-                const int bl = __ffsll((long long)bm) - 1;
-                const int bty = readlane_i(bt, bl);
 #if defined(RSOLVE_TRACE)
                 if (P.dbg && gid == P.dbg_agent && lane == 0 && iters_total <= P.dbg_cap - 5) { double *d = P.dbg + (size_t)(iters_total - 1) * 8; d[6] = (double)(bty * 100 + bl); d[7] = tau; }
 #endif
@@ -845,6 +889,7 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
         }
     }
 #undef RCLAIM_NEXT
+#undef RBLOCK_UNDO
 #undef PMAXQ
 #undef PMINQ
 }
