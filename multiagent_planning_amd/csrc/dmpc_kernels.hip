@@ -1083,9 +1083,16 @@ __global__ __launch_bounds__(RSOLVE_WAVES * 64) void dmpc_rsolve_persist_kernel(
         int ln = lane;
         asm volatile("" : "+v"(ln));
         const int agent = resolve(pos);
+#ifdef RSOLVE_TRACE
+        const long long t_a = wall_clock64();
+#endif
         rsolve_body(P, ln, agent, mine, want, tkv, claimed);
         if (want && !claimed && lane == 0) tkv = atomicAdd(P.counter, 1);
         LSYNC();
+#ifdef RSOLVE_TRACE
+        // development: start time and duration of every agent (dmpc_debug_trace with agent = -5), 100 MHz ticks
+        if (P.dbg && P.dbg_agent == -5 && lane == 0) { P.dbg[(size_t)agent * 2] = (double)t_a; P.dbg[(size_t)agent * 2 + 1] = (double)(wall_clock64() - t_a); }
+#endif
         if (!dyn) { pos += nw; continue; }
         if (left > 0) { pos++; left--; continue; }
         pos = decode(__builtin_amdgcn_readfirstlane(tkv), left);

@@ -24,7 +24,7 @@
 // flagged ST_QOVER and solved by the general kernel (dmpc_solve.hip) in the tier-2 launch: none in the 27 000 agent-steps of the prototype's
 // campaign but for a third wall (1).
 
-#define RSOLVE_TRACE 1
+// #define RSOLVE_TRACE 1
 template <int N> __device__ __forceinline__ double rshr(double v) { return dpp0_d<0x110 + N>(v); }   // lane i <- lane i-N of its row (0 off the row)
 template <int N> __device__ __forceinline__ double rshl(double v) { return dpp0_d<0x100 + N>(v); }   // lane i <- lane i+N
 template <int N> __device__ __forceinline__ double rror(double v) { return dpp0_d<0x120 + N>(v); }   // rotation inside the row
