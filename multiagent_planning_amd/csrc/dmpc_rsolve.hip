@@ -36,6 +36,7 @@ enum { RB_IN = 1, RB_PIN0 = 2, RB_PINL = 4 };
 constexpr int R_NH = 8;   // hard constraints of the small system, one per lane (hard rows + walls + the entering constraint)
 constexpr int R_NW = 3;   // walls of the working set (a corner of the workspace)
 constexpr int R_NE = R_NW + 1;
+constexpr int REQP_MAX = 160;       // equality-constrained solves per ladder level before the agent is handed to the general solver
 constexpr int RBLOCK_MAX = 24;     // block moves of the bounds per ladder level (then the exact one-at-a-time steps only)
 constexpr int RCERT_AFTER = 6;      // scans of a ladder level before the certificate looks at it
 constexpr int RCERT_PLANES = 70;    // planes the wave's LDS holds for it: 64 rows + 6 box faces   // extras: the walls + an entering wall / bound
@@ -241,7 +242,7 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
             unsigned long long hm_prev = ~0ull;
             int ent = RE_NONE, eidx = 0, esg = 0;   // entering constraint: type, lane of the component / row, sign
             int phase = 0;                  // 1: crash (free the negative multipliers), 2: iteration, 3: violation scan
-            int inner = 0, iters = 0, zero_steps = 0;
+            int inner = 0, iters = 0, zero_steps = 0, leqp = 0;
             // Block moves of the acceleration bounds.  An equality-constrained QP costs the same whatever changed since the last one, and the bounds flip
             // in blocks: a row that enters pushes a dozen of the fixed accelerations off their bounds, which the ratio test frees one partial step at
             // a time, and a dozen others are then violated and enter one full step at a time (an agent of 79 steps: 60 of them such).  So: (a) when the
@@ -329,6 +330,7 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
 #endif
                 RPH(0);
                 if (phase == 2 && ++inner > 200) { rc = 2; why = 4; break; }
+                if (++leqp > REQP_MAX) { rc = 2; why = 3; break; }   // (the longest level of 90 000 agent-steps of the 10^4-agent scene took 80: what runs on is a degenerate cycle)
                 cost += 6;
                 iters_total++;
                 // =========================================================== the equality-constrained QP of the working set (+ entering constraint)
@@ -421,6 +423,8 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
                 const int nhr0 = __popcll(hm);
                 const int nhr = nhr0 + (erow >= 0 ? 1 : 0);
                 const int nh = nhr + ne;
+                const int xb = nhr0;                      // the extras' lanes: xb .. xb + ne - 1 (an entering extra is the last of them = lane nh - 1)
+                const int erl = erow >= 0 ? nh - 1 : -1;   // the entering row's lane: the last of the list, behind the walls
                 if (nh > R_NH) { if (blk) { RBLOCK_UNDO(); continue; } rc = 2; why = 6; break; }
                 const bool has_p = (phase == 2) && (ent_extra || erow >= 0);
                 double hy0 = 0.0, hy1 = 0.0, hy2 = 0.0, hrho = 0.0, hd = 0.0, hsc = 1.0;
@@ -435,18 +439,18 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
                             const int j = __ffsll((long long)m) - 1; m &= m - 1ull;
                             if (lane == c) src = j;
                         }
-                        if (erow >= 0 && lane == nhr0) src = erow;
+                        if (lane == erl) src = erow;
                         gx0 = __shfl(xi0, src); gx1 = __shfl(xi1, src); gx2 = __shfl(xi2, src); gb = __shfl(rb, src); gsd = __shfl(rsd, src);
                         gfl = __shfl(rfl, src);
                     }
-                    if (lane < nhr) {
+                    if (lane < nhr0 || lane == erl) {
                         hy0 = -sg3[0] * gx0; hy1 = -sg3[1] * gx1; hy2 = -sg3[2] * gx2;
                         hd = gb - ((gfl & RB_PINL) ? gsd * slb : 0.0);
                         hrho = hd + (gx0 * w03[0] + gx1 * w03[1] + gx2 * w03[2]);
                         hsc = sc_row * (gx0 * gx0 + gx1 * gx1 + gx2 * gx2);
                     }
                 } else { hm_prev = ~0ull; herow_prev = -2; }
-                double omr[R_NE] = {0.0, 0.0, 0.0, 0.0};   // lane nhr + i: row i of Om = G0 - yt yt' over the extras
+                double omr[R_NE] = {0.0, 0.0, 0.0, 0.0};   // lane xb + i: row i of Om = G0 - yt yt' over the extras
                 double Yp = 0.0;                             // H~ n of the entering bound (the common extra): kept for the update of a
                 if (ne > 0) {
                     cost += 2;
@@ -456,7 +460,7 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
                         const int x = eidx >> 4;
                         const double t = sgd * readlane_d(Ykc, eidx) * (x == 0 ? isg3[0] : (x == 1 ? isg3[1] : isg3[2]));   // yt on its axis
                         const double g0 = sgd * readlane_d(Yp, eidx), u0 = sgd * readlane_d(a0, eidx);
-                        if (lane == nhr) { hy0 = x == 0 ? t : 0.0; hy1 = x == 1 ? t : 0.0; hy2 = x == 2 ? t : 0.0; hd = P.alim; hrho = P.alim - u0; hsc = Gt[(eidx & 15) * 31]; omr[0] = g0 - t * t; }
+                        if (lane == xb) { hy0 = x == 0 ? t : 0.0; hy1 = x == 1 ? t : 0.0; hy2 = x == 2 ? t : 0.0; hd = P.alim; hrho = P.alim - u0; hsc = Gt[(eidx & 15) * 31]; omr[0] = g0 - t * t; }
                     } else {
                         // walls (and maybe an entering wall / bound), one at a time: normal and H~ n are formed here and again for the update of a -- nothing of
                         // them is kept; an extra's normal lives on ONE axis, so yt_i is a scalar on that axis and G0_ij = n_j' H~ n_i needs extra i's H~ n only
@@ -474,7 +478,7 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
                             const double u0 = readlane_d(ul, wl & 48);
                             const double dd = is_b ? P.alim : ((code & 256) ? readlane_d(whi_l, wl) : -readlane_d(wlo_l, wl));
                             const double sc = is_b ? Gt[(wl & 15) * 31] : Gt[(15 + (wl & 15)) * 31];
-                            if (lane == nhr + i) { hy0 = xa == 0 ? yts[i] : 0.0; hy1 = xa == 1 ? yts[i] : 0.0; hy2 = xa == 2 ? yts[i] : 0.0; hd = dd; hrho = dd - u0; hsc = sc; }
+                            if (lane == xb + i) { hy0 = xa == 0 ? yts[i] : 0.0; hy1 = xa == 1 ? yts[i] : 0.0; hy2 = xa == 2 ? yts[i] : 0.0; hd = dd; hrho = dd - u0; hsc = sc; }
 #pragma unroll
                             for (int j = 0; j <= i; ++j) {
                                 const bool jb = ent_extra && j == nw && ent == RE_BOUND;
@@ -483,8 +487,8 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
                                 const bool same = ((cj & 63) >> 4) == xa;
                                 const double g0 = readlane_d(row_allsum(nbj * Yi), wl & 48);   // (0 when the two are on different axes)
                                 const double o = g0 - (same ? yts[i] * yts[j] : 0.0);
-                                if (lane == nhr + i) omr[j] = o;
-                                if (lane == nhr + j) omr[i] = o;
+                                if (lane == xb + i) omr[j] = o;
+                                if (lane == xb + j) omr[i] = o;
                             }
                         }
                     }
@@ -497,7 +501,7 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
                 double Sr[R_NH], rh, hlam = 0.0, csave = 0.0;
                 double zeta[3] = {0.0, 0.0, 0.0};
                 int sing = 0;
-                const int ie = lane - nhr;
+                const int ie = lane - xb;   // (an extra's index; the entering row's lane xb + ne is none)
                 {
                     const double hv[3] = {hy0, hy1, hy2};
                     double by[3], bq[3];
@@ -510,7 +514,7 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
                         if (e >= nh) continue;
                         const double b0 = readlane_d(by[0], e), b1 = readlane_d(by[1], e), b2 = readlane_d(by[2], e);
                         double t = hy0 * b0 + hy1 * b1 + hy2 * b2;
-                        if (e >= nhr && ie >= 0 && ie < ne) t += (e - nhr == 0) ? omr[0] : ((e - nhr == 1) ? omr[1] : ((e - nhr == 2) ? omr[2] : omr[3]));
+                        if (e >= xb && e < xb + ne && ie >= 0 && ie < ne) t += (e - xb == 0) ? omr[0] : ((e - xb == 1) ? omr[1] : ((e - xb == 2) ? omr[2] : omr[3]));
                         Sr[e] = (lane < nh) ? t : 0.0;
                     }
 #ifdef RSOLVE_MARK
@@ -519,12 +523,19 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
                 RPH(6);
                     // Gauss-Jordan, pivots in list order; the entering constraint's pivot decides dependence
                     bool bad = false;
+                    double sd0 = Sr[0];   // my diagonal entry before the elimination: n_c' P n_c
+#pragma unroll
+                    for (int e = 1; e < R_NH; ++e) sd0 = (lane == e) ? Sr[e] : sd0;
 #pragma unroll
                     for (int k = 0; k < R_NH; ++k) {
                         if (k >= nh) continue;
                         const double piv = readlane_d(Sr[k], k), psc = readlane_d(hsc, k);
                         if (k == nh - 1 && has_p) csave = Sr[k];   // (the entering constraint's column in the eliminated rows, before its own pivot)
-                        if (!(piv > 1e-13 * psc)) {
+                        // (the entering constraint also counts as dependent when the others take all but 1e-10 of its own norm in the reduced metric: fixing the
+                        // last free acceleration a hard row can feel leaves a pivot of 1e-12 that passes the absolute test -- and a working set whose next
+                        // elimination fails on the row)
+                        const bool last = k == nh - 1 && has_p;
+                        if (!(piv > (blk ? 1e-9 : 1e-13) * psc) || (last && !(piv > 1e-10 * readlane_d(sd0, k)))) {   // (a block move must leave a well-conditioned working set: it fixes bounds without the dependence test of an entering constraint)
                             if (k == nh - 1 && has_p) sing = 1; else bad = true;
                             continue;
                         }
@@ -565,7 +576,7 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
                             double r = hy0 * zeta[0] + hy1 * zeta[1] + hy2 * zeta[2] - hrho;
                             if (ne > 0) {
 #pragma unroll
-                                for (int i = 0; i < R_NE; ++i) { if (i >= ne) continue; const double li = readlane_d(hlam, nhr + i); if (ie >= 0 && ie < ne) r = fma(-omr[i], li, r); }
+                                for (int i = 0; i < R_NE; ++i) { if (i >= ne) continue; const double li = readlane_d(hlam, xb + i); if (ie >= 0 && ie < ne) r = fma(-omr[i], li, r); }
                             }
                             double wr = lane < nh ? fabs(r) : 0.0;   // (lanes 0 .. 7)
                             wr = max_raw(wr, rshr<1>(wr)); wr = max_raw(wr, rshr<2>(wr)); wr = max_raw(wr, rshr<4>(wr));
@@ -583,7 +594,7 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
                 // ---- new values (regular) or rates per unit of the entering multiplier (dependent: the primal does not move)
                 double a_n = a, mu_n = 0.0, lam_n = 0.0, lamp_n = 1.0, farkas = 0.0;
                 // the hard rows' multipliers (or rates) back in their row lanes: list position of row `lane`
-                const int hpos = (erow >= 0 && lane == erow) ? nhr0 : __popcll(hm & ((1ull << lane) - 1ull));
+                const int hpos = (erow >= 0 && lane == erow) ? erl : __popcll(hm & ((1ull << lane) - 1ull));
                 double dlh = 0.0;
                 if (sing) {   // rate of constraint c in lane c: the last one dl_last per unit of the entering multiplier, the others -rr dl_last
                     double dl_last = 1.0;
@@ -606,12 +617,13 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
                     double lam_h = 0.0;
 #pragma unroll
                     for (int c = 0; c < R_NH; ++c) {
-                        if (c >= nhr) break;
+                        if (c >= nhr0) break;
                         const double v = readlane_d(hval, c);
                         if (hpos == c) lam_h = v;
                     }
+                    if (erow >= 0) { const double v = readlane_d(hval, erl); if (hpos == erl) lam_h = v; }
                     if (r_hard) lam_n = lam_h;
-                    const bool mine = lane < nhr;
+                    const bool mine = lane < nhr0 || lane == erl;
                     double p0 = mine ? hval * gx0 : 0.0, p1 = mine ? hval * gx1 : 0.0, p2 = mine ? hval * gx2 : 0.0;
                     p0 += rshr<1>(p0); p0 += rshr<2>(p0); p0 += rshr<4>(p0);
                     p1 += rshr<1>(p1); p1 += rshr<2>(p1); p1 += rshr<4>(p1);
@@ -629,7 +641,7 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
                 if (!sing) a_n = fma(Ykc, c_l, a0);
                 if (ne > 0) {
                     if (ne == 1 && ent_extra && ent == RE_BOUND) {
-                        const double le = readlane_d(hval, nhr);
+                        const double le = readlane_d(hval, xb);
                         if (!sing) { a_n = fma(-le, Yp, a_n); lamp_n = le; }
                         if (lane == eidx) grad += le * (double)esg;
                     } else {
@@ -639,7 +651,7 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
                             const bool is_b = ent_extra && i == nw && ent == RE_BOUND;
                             const int code = i < nw ? wcode[i < R_NW ? i : 0] : (eidx | (esg > 0 ? 256 : 0));
                             const double nb = is_b ? ((lane == eidx) ? (double)esg : 0.0) : wall_normal(code, comp, ax_l, k_l, h2);
-                            const double le = readlane_d(hval, nhr + i);
+                            const double le = readlane_d(hval, xb + i);
                             if (!sing) { const double Yi = rax_solve(A, fixd ? 0.0 : nb, lKl, q2); a_n = fma(-le, Yi, a_n); }
                             grad = fma(le, nb, grad);
                             if (i < nw) { if (lane == 48 + i) mu_n = le; } else if (!sing) lamp_n = le;

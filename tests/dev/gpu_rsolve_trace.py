@@ -42,7 +42,7 @@ assert L.dmpc_debug_trace(d._ctx, agent, cap, buf.ctypes.data_as(C.c_void_p)) ==
 print("status", out["status"][agent], "info", out["info"][agent])
 for i in range(cap - 4):
     r = buf[i]
-    if r[1] == 0: break
+    if r[1] == 0: continue
     c0, c1 = int(r[0]), int(r[1])
     print(f"EQP {i}: phase {c0 % 10} ent {(c0 // 10) % 100} idx {c0 // 1000}  nh {c1 & 15} ne {(c1 >> 4) & 15} sing {((c1 >> 8) & 15) - 1} nhr {c1 >> 12}   {r[2]:.10e} {r[3]:.10e} {r[4]:.10e}  | {r[5]:.6e} {r[6]:.6e} {r[7]:.6e}")
 ph = buf[cap - 4:cap - 2].ravel()[:12]
