@@ -31,7 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-PMC_SUMMARY = "r05_c4_pmc_summary.json"
+PMC_SUMMARY = "r06_c4_pmc_summary.json"
 CYCLE = 9               # MPC steps 2 .. 10
 
 
@@ -374,7 +374,7 @@ def main():
             "value": value, "unit": "solves/s", "n_gpus": (1 if emu else G), "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic" + (" [SHARED-GPU FUNCTIONAL CHECK, not a measurement]" if share else ""),
-            "config": {"workload": f"C4 (BASELINE configs[3]): ONE scene of {N4} agents, solveSoftDMPCbound (test/failure_rate.m constants), K=15, "
+            "config": {"workload": f"C4 (BASELINE configs[3]): ONE scene of {N4} agents, solveSoftDMPCbound (test/failure_rate.m constants), K=15, first `coll` return at MPC step 4 (value counts such early returns as solves: value_solved_only), "
                                    f"device-resident closed loop over MPC steps 2-{CYCLE + 1} (from the initDMPC state again every {CYCLE} steps), "
                                    f"agents sharded over {G} GPU(s)" + (" [rank 0's cluster only, emulated]" if emu else ""),
                        "agents_per_scene": N4, "scenes": 1, "solves_per_step": (N4 if not emu else loop.cnt), "agents_per_gpu": N_loc,
@@ -389,9 +389,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "measured_copy_ceiling_GBps": copy_gbs, "frac_of_copy_ceiling": (achieved / copy_gbs if copy_gbs else None),
-                         # (dmpc_api.hip launch_step: the 56-slot tier of a large scene runs as persistent waves with the split factor from 8 agents per CU on)
-                         "kernel": ("dmpc_solve_persist_kernel<true, 56, 48, double>" if N_loc >= 8 * torch.cuda.get_device_properties(dev).multi_processor_count
-                                    else "dmpc_solve_kernel<true, 56, double>"),
+                         # (the library names the kernel its last step launched for the bulk of the agents: dmpc_last_solve_kernel, ABI revision 7)
+                         "kernel": dmpc.last_solve_kernel,
                          "kernel_ms_avg": kern_ms, "launches": n_launch,
                          "other_kernels_ms_avg": {"neighbour lists (bbox, table copy, grid_bin/scan/fill/query) + dmpc_scan_kernel + order_kernel": scan_ms},
                          "alg_bytes_per_solve": ba, "solves_per_launch": N_loc,
@@ -400,11 +399,11 @@ def main():
                                             whole_step_traffic=pmc.get("whole_step_bytes_per_launch"), fp64=pmc.get("fp64"),
                                             traffic_calibration=pmc.get("traffic_calibration"), git_commit=pmc.get("git_commit"), source_hash=pmc.get("source_hash"),
                                             source=f"profiles/{PMC_SUMMARY} (rocprofv3 passes of this workload on these kernel sources, committed; not re-measured in this run)") if pmc else pmc_note),
-                         "note": "on-chip bound (profiles/README.md): compulsory HBM traffic is ~1.5 KB/solve against tens of thousands of dependent wave instructions, so the "
+                         "note": "on-chip bound (profiles/README.md): compulsory HBM traffic is ~1.5 KB/solve against ~10 k dependent wave instructions, so the "
                                  "HBM fraction is small by construction; what bounds the kernel -- per-wave active / waiting cycles, VALU-pipe busy fraction -- is in `secondary` "
-                                 "(counters, not a model).  No MFMA: the only dense contraction of the path, the Hessian / Gram build, does not depend on the inputs and is "
-                                 "precomputed on the host (three 30x30 tables); what is left per solve are 8-wide triangular products of a factor that changes by one column "
-                                 "per iteration and Givens sweeps (profiles/r04_pmc_sq3_*: 655 fp64 FMA of 3.7 k VALU instructions per solve of the hard variant)"},
+                                 "(counters, not a model).  No MFMA: the reduced solver of solveSoftDMPCbound (dmpc_rsolve.hip, round 6) has no dense contraction at all -- "
+                                 "per axis a tridiagonal + rank-1 Hessian (parallel cyclic reduction in DPP rows + Sherman-Morrison), the soft rows as a 3x3 penalty, "
+                                 "hard rows / walls / entering constraint as a system of at most eight unknowns, one per lane"},
             "value_solved_only": value * float(sa[:, 0].mean()),
             "workload_stats": {"per_mpc_step": [{"mpc_step": i + 2, "solved_frac": s[0], "mean_iters": s[1], "max_iters": s[2], "max_tries": s[3]} for i, s in enumerate(stats)],
                                "solved_frac": float(sa[:, 0].mean()), "mean_iters": float(sa[:, 1].mean()), "max_iters": int(max(s[2] for s in stats)),

@@ -162,7 +162,7 @@ enum {
 /* ABI revision of this header.  The special device values changed once (the round-3 header had DMPC_DEVICE_ALL = -1, DMPC_DEVICE_CURRENT = -2;
  * since revision 4 they are the two values above and any other negative device is refused), so a binding compiled against another header
  * should compare dmpc_abi_version() with the DMPC_ABI_VERSION it was built with before its first dmpc_create. */
-#define DMPC_ABI_VERSION 6
+#define DMPC_ABI_VERSION 7
 DMPC_API int dmpc_abi_version(void);
 DMPC_API dmpc_ctx *dmpc_create(const dmpc_params *prm, int device, int precision);
 /* number of GPUs the context drives (1 unless created with DMPC_DEVICE_ALL on a multi-GPU node) */
@@ -427,6 +427,11 @@ DMPC_API int dmpc_profile(dmpc_ctx *ctx, int enable);
 DMPC_API int dmpc_profile_read(dmpc_ctx *ctx, double *avg_ms, int64_t *n_launches);
 /* same, split into the solve kernel(s) (dmpc_solve_kernel, the dominant kernel) and scan + ordering */
 DMPC_API int dmpc_profile_read2(dmpc_ctx *ctx, double *solve_avg_ms, double *scan_avg_ms, int64_t *n_steps);
+/* the solve kernel the context's last MPC step launched for the bulk of its agents, as a profiler names it (e.g. "dmpc_rsolve_persist_kernel",
+ * "dmpc_solve_persist_kernel<true, 56, 48, double>"): the launch form is picked per step from the variant and the depth of the launch, and whoever
+ * reports the measured duration of "the dominant kernel" (bench.py's roofline block) names the kernel from here, not from a copy of that rule.
+ * The string lives in the context; empty before the first step.  (ABI revision 7) */
+DMPC_API const char *dmpc_last_solve_kernel(const dmpc_ctx *ctx);
 
 #ifdef __cplusplus
 }

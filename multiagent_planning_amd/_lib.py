@@ -19,7 +19,7 @@ ST_REACHED = 256   # scene_status of transition(): every agent reached its goal
 INFO_LEN = 8
 I_VIOLK, I_NROWS, I_TRIES, I_CASE, I_ITERS, I_NSLACK, I_NACTIVE, I_MAXQ = range(8)
 K_HOR = 15
-ABI_VERSION = 6    # DMPC_ABI_VERSION of include/dmpc_hip.h
+ABI_VERSION = 7    # DMPC_ABI_VERSION of include/dmpc_hip.h
 
 # every symbol include/dmpc_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "dmpc_trajectories2file", "dmpc_test2file", "dmpc_random_test", "dmpc_random_exchange", "dmpc_random_sets_device",
     "dmpc_prop_state", "dmpc_is_inbounds", "dmpc_reached_goal", "dmpc_rows_dense",
     "dmpc_partition", "dmpc_comm_unique_id", "dmpc_comm_init", "dmpc_comm_destroy", "dmpc_step_sharded_device",
-    "dmpc_transition_sharded", "dmpc_transition_sharded_gather", "dmpc_group_size", "dmpc_comm_size", "dmpc_abi_version",
+    "dmpc_transition_sharded", "dmpc_transition_sharded_gather", "dmpc_group_size", "dmpc_comm_size", "dmpc_abi_version", "dmpc_last_solve_kernel",
     "dmpc_max_deviation",
 ]
 
@@ -131,6 +131,8 @@ def load():
     L.dmpc_profile.argtypes = [vp, C.c_int]
     L.dmpc_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.dmpc_profile_read2.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    L.dmpc_last_solve_kernel.argtypes = [vp]
+    L.dmpc_last_solve_kernel.restype = C.c_char_p
     _lib = L
     return L
 
@@ -494,6 +496,11 @@ class Dmpc:
         a, b, n = C.c_double(0.0), C.c_double(0.0), C.c_int64(0)
         self._chk(self._L.dmpc_profile_read2(self._ctx, C.byref(a), C.byref(b), C.byref(n)))
         return a.value, b.value, n.value
+
+    @property
+    def last_solve_kernel(self):
+        """profiler name of the solve kernel the last MPC step launched for the bulk of its agents (dmpc_last_solve_kernel)"""
+        return self._L.dmpc_last_solve_kernel(self._ctx).decode()
 
     @property
     def solve_count(self):

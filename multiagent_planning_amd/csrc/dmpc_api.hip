@@ -122,6 +122,7 @@ struct dmpc_ctx {
     std::vector<int> split_at;          // non-empty: the last dmpc_transition left scenes [split_at[i], split_at[i+1]) in part i (0: here, i > 0: children[i-1])
     int split_parts = 0;     // development option split_parts: number of parts (0: the built-in rule)
     int no_split = 0;        // development option no_split
+    std::string last_kernel; // the solve kernel the last step launched for the bulk of its agents (dmpc_last_solve_kernel)
     int reduced_solver = 1;  // solveSoftDMPCbound: the reduced solver (dmpc_rsolve.hip) in front of the general one; 0: the general solver alone (A/B runs, tests)
     int rsolve_blocks = 0;   // workgroups of dmpc_rsolve_persist_kernel a CU holds (occupancy query, once per context)
     int no_split_t = 0;      // development option no_split_t: slack-free persistent solve with the whole inverse factor in every wave's block (nine waves per CU; A/B runs, tests)
@@ -388,6 +389,7 @@ static int upload_tables(dmpc_ctx *ctx)
 
 extern "C" const char *dmpc_last_error(const dmpc_ctx *ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
 extern "C" int dmpc_abi_version(void) { return DMPC_ABI_VERSION; }
+extern "C" const char *dmpc_last_solve_kernel(const dmpc_ctx *ctx) { return ctx ? ctx->last_kernel.c_str() : ""; }
 
 static std::atomic<int> g_emulate_devices{0};
 // development / tests (not in the public header): DMPC_DEVICE_ALL then builds a group of n ranks that all sit on the calling thread's
@@ -932,6 +934,7 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     };
     // the working-set capacity is a template parameter of the solve kernels
     auto launch_plain = [&](int qcap, size_t lds) {
+        if (!P.only_flagged) ctx->last_kernel = std::string("dmpc_solve_kernel<") + (soft ? "true, " : "false, ") + std::to_string(f32t ? (soft ? 64 : 48) : (soft ? qcap : 48)) + (f32t ? ", float>" : ", double>");
         if (f32t) { if (soft) hipLaunchKernelGGL((dmpc_solve_kernel<true, 64, float>), grid, block, lds, st, P); else hipLaunchKernelGGL((dmpc_solve_kernel<false, 48, float>), grid, block, lds, st, P); }
         else if (soft && qcap == 32) hipLaunchKernelGGL((dmpc_solve_kernel<true, 32>), grid, block, lds, st, P);
         else if (soft && qcap == 48) hipLaunchKernelGGL((dmpc_solve_kernel<true, 48>), grid, block, lds, st, P);
@@ -940,6 +943,11 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
         else hipLaunchKernelGGL((dmpc_solve_kernel<false, 48>), grid, block, lds, st, P);
     };
     auto launch_persist = [&](int qcap, dim3 g, dim3 b, size_t lds) {
+        if (!P.only_flagged) {
+            const int qc = f32t ? (soft ? 64 : 48) : (soft ? qcap : 48);
+            const int ts = f32t ? qc : (tsplit ? (soft ? SOFT_TS : HARD_TS) : qc);
+            ctx->last_kernel = std::string("dmpc_solve_persist_kernel<") + (soft ? "true, " : "false, ") + std::to_string(qc) + ", " + std::to_string(ts) + (f32t ? ", float>" : ", double>");
+        }
         if (f32t) { if (soft) hipLaunchKernelGGL((dmpc_solve_persist_kernel<true, 64, 64, float>), g, b, lds, st, P); else hipLaunchKernelGGL((dmpc_solve_persist_kernel<false, 48, 48, float>), g, b, lds, st, P); }
         else if (soft && qcap == 32) hipLaunchKernelGGL((dmpc_solve_persist_kernel<true, 32>), g, b, lds, st, P);
         else if (soft && qcap == 48) hipLaunchKernelGGL((dmpc_solve_persist_kernel<true, 48>), g, b, lds, st, P);
@@ -1006,6 +1014,7 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
         int wgs = (total + RSOLVE_WAVES - 1) / RSOLVE_WAVES;
         if (wgs > ctx->rsolve_blocks * ctx->num_cu) wgs = ctx->rsolve_blocks * ctx->num_cu;
         P.queue_chunk = ctx->queue_chunk > 0 ? ctx->queue_chunk : (total < 12 * wgs * RSOLVE_WAVES ? 1 : 2);
+        ctx->last_kernel = "dmpc_rsolve_persist_kernel";
         hipLaunchKernelGGL(dmpc_rsolve_persist_kernel, dim3((unsigned)wgs), dim3(RSOLVE_WAVES * 64), (size_t)RSOLVE_WAVES * RSOLVE_LDS_PER_WAVE, st, P);
         P.qcap = q2; P.only_flagged = 1; P.qover_bit = ST_CAPACITY;
         const bool t2p = !ctx->no_persist && pw2 >= 2;   // persistent waves over the flagged list (nearly always empty); else one workgroup per agent, each looking at its agent's flag

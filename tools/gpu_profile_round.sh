@@ -16,7 +16,7 @@ OUT=$REPO/gpurun_out/$LABEL
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 case $WL in
-  headline|c4) BENCH="python $REPO/bench.py --no-cpu-baseline --no-secondary"; SPL=10000; KERN="solve_persist_kernel<true, 56, 48"; WPS=1.75;;
+  headline|c4) BENCH="python $REPO/bench.py --no-cpu-baseline --no-secondary"; SPL=10000; KERN="rsolve_persist_kernel"; WPS=2.0;;
   c2)       BENCH="python $REPO/tools/replay_workload.py hard"; SPL=51200; KERN="solve_persist_kernel<false, 48"; WPS=3;;
   bound)    BENCH="python $REPO/tools/replay_workload.py bound"; SPL=51200; KERN="solve_persist_kernel<true, 48"; WPS=2;;
 esac
