@@ -430,19 +430,30 @@ def main():
 
 def cpu_baseline(wl, cfg4, kw4, N4, po4, pf4, dmpc):
     """The oracle (the literal dense QP of the .m files + dense Goldfarb-Idnani, oracle/dmpc_oracle.c -- test infrastructure, used here only as
-    the timed CPU baseline) on the SAME scene, timed on this box's host cores on a bounded sample: MPC step 3 of the headline's closed loop
-    (state and table produced by the GPU path through the host API), every agent of the scene scanning all 10 000 neighbours as
+    the timed CPU baseline) on the SAME scene, timed on this box's host cores on a bounded sample: MPC steps 3, 6 and 10 of the headline's
+    closed loop (states and tables produced by the GPU path through the host API), every agent of the scene scanning all 10 000 neighbours as
     CheckCollSoftDMPC.m:7-10 does.  Threads = the reference's own parallelisation: contiguous agent clusters inside ONE scene
-    (dmpc.cpp:1600-1625), T in {8, physical cores}; T = 1 on a slice of the agents."""
+    (dmpc.cpp:1600-1625), T in {8, physical cores}; T = 1 on a slice of the agents.  The library is compiled HERE for this host
+    (-O3 -march=native; the checker the tests use is the portable x86-64-v3 build that travels with the repository)."""
+    import tempfile
     from oracle import oracle as orc
+    native = None
+    try:
+        native = orc.lib(orc.build(force=True, cflags=["-O3", "-march=native"], out=os.path.join(tempfile.mkdtemp(prefix="orc_native_"), "libdmpc_oracle_native.so")))
+    except Exception:   # noqa: BLE001 -- no compiler on the box: the portable build
+        native = None
     prm = orc.make_params("bound", **kw4)
     l, _, _ = dmpc.init_batch(po4, pf4)
     xp, xv, xa = po4.copy(), np.zeros_like(po4), np.zeros_like(po4)
-    out = dmpc.step_batch(l, xp, xv, xa, pf4)          # MPC step 2 on the GPU: the input of step 3
-    ok = (out["status"] & 1) == 1
-    l = np.where(ok[..., None], out["p"], l); xp = np.where(ok[..., None], out["p"][..., :3], xp)
-    xv = np.where(ok[..., None], out["v"][..., :3], xv); xa = np.where(ok[..., None], out["a"][..., :3], xa)
-    l, xp, xv, xa, pf = l[0], xp[0], xv[0], xa[0], pf4[0]
+    states = {}
+    for k in range(2, 10):                                 # MPC steps 2 .. 9 on the GPU: the inputs of steps 3 .. 10
+        out = dmpc.step_batch(l, xp, xv, xa, pf4)
+        ok = (out["status"] & 1) == 1
+        l = np.where(ok[..., None], out["p"], l); xp = np.where(ok[..., None], out["p"][..., :3], xp)
+        xv = np.where(ok[..., None], out["v"][..., :3], xv); xa = np.where(ok[..., None], out["a"][..., :3], xa)
+        if k + 1 in (3, 6, 10):
+            states[k + 1] = (l[0].copy(), xp[0].copy(), xv[0].copy(), xa[0].copy())
+    pf = pf4[0]
     ncpu = os.cpu_count() or 1
     try:
         import psutil
@@ -450,22 +461,29 @@ def cpu_baseline(wl, cfg4, kw4, N4, po4, pf4, dmpc):
     except Exception:
         phys = ncpu
     sweep = []
+    l3, xp3, xv3, xa3 = states[3]
     n1 = min(N4, 400)
     tt = time.perf_counter()
     for n in range(n1):
-        orc.solve_one(prm, l, n, xp[n], xv[n], xa[n], pf[n])
+        orc.solve_one(prm, l3, n, xp3[n], xv3[n], xa3[n], pf[n])
     w1 = time.perf_counter() - tt
-    sweep.append({"threads": 1, "value": n1 / w1, "agents": n1, "wall_s": w1})
+    sweep.append({"threads": 1, "value": n1 / w1, "agents": n1, "wall_s": w1, "mpc_steps": [3], "build": "x86-64-v3"})
     for T in sorted(set([8, phys])):
-        tt = time.perf_counter(); reps = 0
-        while reps == 0 or (time.perf_counter() - tt < 4.0 and reps < 16):
-            orc.step(prm, l, xp, xv, xa, pf, nthreads=T); reps += 1
-        w = time.perf_counter() - tt
-        sweep.append({"threads": T, "value": reps * N4 / w, "agents": N4, "repeats": reps, "wall_s": w})
+        per_step = {}
+        tt_all = time.perf_counter(); reps_all = 0
+        for k, (lk, xpk, xvk, xak) in sorted(states.items()):
+            tt = time.perf_counter(); reps = 0
+            while reps == 0 or (time.perf_counter() - tt < 1.5 and reps < 8):
+                orc.step(prm, lk, xpk, xvk, xak, pf, nthreads=T, library=native); reps += 1
+            per_step[k] = reps * N4 / (time.perf_counter() - tt)
+            reps_all += reps
+        w = time.perf_counter() - tt_all
+        sweep.append({"threads": T, "value": reps_all * N4 / w, "agents": N4, "repeats": reps_all, "wall_s": w, "mpc_steps": sorted(states), "per_mpc_step": per_step,
+                      "build": "-march=native" if native is not None else "x86-64-v3"})
     best = max(sweep, key=lambda e: e["value"])
     return {"value": best["value"], "unit": "solves/s", "cores": best["threads"], "kind": "port",
-            "sample": f"MPC step 3 of the headline scene ({N4} agents, all of them) x {best.get('repeats', 1)} repeat(s), oracle/dmpc_oracle.c (literal dense QP + dense "
-                      "Goldfarb-Idnani; every agent scans the whole table), agents in contiguous clusters over the threads as dmpc.cpp:1600-1625",
+            "sample": f"MPC steps 3, 6 and 10 of the headline scene ({N4} agents, all of them) x {best.get('repeats', 1)} pass(es) in all, oracle/dmpc_oracle.c (literal dense QP + dense "
+                      "Goldfarb-Idnani; every agent scans the whole table), compiled on this host with -O3 -march=native, agents in contiguous clusters over the threads as dmpc.cpp:1600-1625",
             "single_thread": sweep[0]["value"], "thread_sweep": sweep, "host_cpus": ncpu, "physical_cores": phys}
 
 

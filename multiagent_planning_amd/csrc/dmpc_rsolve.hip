@@ -330,7 +330,7 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
 #endif
                 RPH(0);
                 if (phase == 2 && ++inner > 200) { rc = 2; why = 4; break; }
-                if (++leqp > REQP_MAX) { rc = 2; why = 3; break; }   // (the longest level of 90 000 agent-steps of the 10^4-agent scene took 80: what runs on is a degenerate cycle)
+                if (++leqp > (P.rsolve_cap > 0 ? P.rsolve_cap : REQP_MAX)) { rc = 2; why = 3; break; }   // (the longest level of 90 000 agent-steps of the 10^4-agent scene took 80: what runs on is a degenerate cycle)
                 cost += 6;
                 iters_total++;
                 // =========================================================== the equality-constrained QP of the working set (+ entering constraint)

@@ -1065,6 +1065,10 @@ int orc_step(const orc_params *prm, int N, const double *l, const double *x_p, c
     if (!order_ok(prm) || prm->K < 1 || prm->K > MAXK) return -1;
     if (nthreads < 1) nthreads = 1;
     if (nthreads > N) nthreads = N > 0 ? N : 1;
+    /* as in orc_step_scenes: the dense QP of every solve is allocated and freed; keep those blocks in the per-thread heap arenas
+     * (mmap/munmap per solve serialises the threads on the process's memory-map lock: 128 threads gave 1.6 x of 8) */
+    mallopt(M_MMAP_THRESHOLD, 1 << 28);
+    mallopt(M_TRIM_THRESHOLD, 1 << 29);
     ctx_t *c = ctx_new(prm->h, prm->K);
     work_t *w = (work_t *)calloc(nthreads, sizeof(work_t));
     pthread_t *th = (pthread_t *)calloc(nthreads, sizeof(pthread_t));

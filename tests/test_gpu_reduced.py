@@ -1,0 +1,111 @@
+"""The reduced solver of solveSoftDMPCbound (csrc/dmpc_rsolve.hip, round 6) against the general solver (development option reduced_solver = 0)
+and the oracle: same branch records, same minimiser; the hand-over of agents it does not take; workspace walls."""
+import os
+
+import numpy as np
+import pytest
+
+import multiagent_planning_amd as mp
+from multiagent_planning_amd import workload as wl
+from oracle import oracle as orc
+from helpers import load_golden, step14_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def _c4_like(N, seed):
+    cfg = dict(wl.CONFIGS["C4"]); cfg["N"] = N
+    kw = wl.solver_kwargs(cfg, N)
+    po, pf = wl.make_scenes(cfg, 1, N, seed)
+    return cfg, kw, po[0], pf[0]
+
+
+def _agree(out, ref, tol_plain=1e-9, tol_ladder=5e-8):
+    st_o, st_r = out["status"].ravel(), ref["status"].ravel()
+    assert np.array_equal(st_o, st_r)
+    io, ir = out["info"].reshape(-1, 8), ref["info"].reshape(-1, 8)
+    assert np.array_equal(io[:, 0], ir[:, 0]) and np.array_equal(io[:, 3], ir[:, 3])
+    assert np.array_equal(io[:, 2], ir[:, 2]), "retry-ladder counts"
+    ok = (st_r & 1) == 1
+    worst = 0.0
+    for key in ("p", "v", "a"):
+        e = np.abs(out[key].reshape(-1, 45)[ok] - ref[key].reshape(-1, 45)[ok]).max(axis=1)
+        first = ir[ok, 2] == 1
+        assert (e[first] <= tol_plain).all(), (key, float(e[first].max()))
+        assert (e <= tol_ladder).all(), (key, float(e.max()))
+        worst = max(worst, float(e.max()))
+    return worst
+
+
+def test_reduced_solver_is_what_runs_for_solveSoftDMPCbound():
+    g, kw = load_golden("failure_rate2_bound")
+    d = mp.Dmpc("bound", **kw)
+    d.step_batch(*step14_inputs(g))
+    assert d.last_solve_kernel == "dmpc_rsolve_persist_kernel"
+    d.debug_option("reduced_solver", 0)
+    d.step_batch(*step14_inputs(g))
+    assert d.last_solve_kernel.startswith("dmpc_solve_")
+    h = mp.Dmpc("hard", **kw)
+    h.step_batch(*step14_inputs(g))
+    assert h.last_solve_kernel.startswith("dmpc_solve_")
+
+
+def test_reduced_against_general_and_oracle_closed_loop():
+    """a scene at the headline's density, teacher-forced by the oracle over MPC steps 2-6: every agent of every step"""
+    cfg, kw, po, pf = _c4_like(1500, wl.SEED0 + 606)
+    prm = orc.make_params("bound", **kw)
+    red, gen = mp.Dmpc("bound", **kw), mp.Dmpc("bound", **kw)
+    gen.debug_option("reduced_solver", 0)
+    l = np.stack([orc.init_one(po[n], pf[n], cfg["h"], 15)[0] for n in range(len(po))])
+    xp, xv, xa = po.copy(), np.zeros_like(po), np.zeros_like(po)
+    for k in range(2, 7):
+        ref = orc.step(prm, l, xp, xv, xa, pf, nthreads=os.cpu_count())
+        o_r, o_g = red.step_batch(l, xp, xv, xa, pf), gen.step_batch(l, xp, xv, xa, pf)
+        _agree(o_r, ref)
+        assert np.array_equal(o_r["status"], o_g["status"]) and np.array_equal(o_r["info"][..., :4], o_g["info"][..., :4])
+        ok = (ref["status"] & 1) == 1
+        l = np.where(ok[:, None], ref["p"], l)
+        xp = np.where(ok[:, None], ref["p"][:, :3], xp); xv = np.where(ok[:, None], ref["v"][:, :3], xv); xa = np.where(ok[:, None], ref["a"][:, :3], xa)
+
+
+def test_hand_over_to_the_general_solver_changes_nothing():
+    """agents the reduced solver gives up (here: nearly all, by a cap of three equality solves per ladder level) are solved by the general
+    solver in the tier-2 launch: the step's outputs are then the general solver's, bit for bit, for those agents -- and the oracle's minimiser"""
+    cfg, kw, po, pf = _c4_like(600, wl.SEED0 + 607)
+    prm = orc.make_params("bound", **kw)
+    red, gen = mp.Dmpc("bound", **kw), mp.Dmpc("bound", **kw)
+    red.debug_option("rsolve_cap", 3)
+    gen.debug_option("reduced_solver", 0)
+    l = np.stack([orc.init_one(po[n], pf[n], cfg["h"], 15)[0] for n in range(len(po))])
+    z = np.zeros_like(po)
+    o_r, o_g = red.step_batch(l, po, z, z, pf), gen.step_batch(l, po, z, z, pf)
+    ref = orc.step(prm, l, po, z, z, pf, nthreads=os.cpu_count())
+    _agree(o_r, ref)
+    handed = o_r["info"][:, 4] == o_g["info"][:, 4]          # (the general solver's iteration count in the record)
+    assert handed.sum() > 100
+    same = np.all(o_r["a"] == o_g["a"], axis=1)
+    assert same[handed & (o_g["info"][:, 4] > 4)].all()
+
+
+def test_walls_of_a_tight_workspace():
+    """a box so small that agents are pressed against its walls (up to three of them in a corner): the walls are extras of the small system"""
+    cfg, kw, po, pf = _c4_like(120, wl.SEED0 + 608)
+    s = 0.62
+    kw = dict(kw); kw["pmin"] = tuple(np.array(kw["pmin"]) * s + np.array([0, 0, 0.2 * (1 - s)])); kw["pmax"] = tuple(np.array(kw["pmax"]) * s)
+    lo, hi = np.array(kw["pmin"]) + 0.02, np.array(kw["pmax"]) - 0.02
+    po, pf = np.clip(po * s, lo, hi), np.clip(pf * s, lo, hi)
+    prm = orc.make_params("bound", **kw)
+    red = mp.Dmpc("bound", **kw)
+    l = np.stack([orc.init_one(po[n], pf[n], cfg["h"], 15)[0] for n in range(len(po))])
+    xp, xv, xa = po.copy(), np.zeros_like(po), np.zeros_like(po)
+    walls = 0
+    for k in range(2, 9):
+        ref = orc.step(prm, l, xp, xv, xa, pf, nthreads=os.cpu_count())
+        out = red.step_batch(l, xp, xv, xa, pf)
+        _agree(out, ref)
+        ok = (ref["status"] & 1) == 1
+        rel = ref["p"].reshape(-1, 15, 3)[ok]
+        walls += int(((np.abs(rel - np.array(kw["pmax"])) < 1e-9) | (np.abs(rel - np.array(kw["pmin"])) < 1e-9)).any(axis=(1, 2)).sum())
+        l = np.where(ok[:, None], ref["p"], l)
+        xp = np.where(ok[:, None], ref["p"][:, :3], xp); xv = np.where(ok[:, None], ref["v"][:, :3], xv); xa = np.where(ok[:, None], ref["a"][:, :3], xa)
+    assert walls > 0, "the scene was meant to press agents against the walls"

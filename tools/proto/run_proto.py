@@ -31,7 +31,6 @@ class Prob(C.Structure):
 
 
 assert lib.rqp_prob_size() == C.sizeof(Prob), (lib.rqp_prob_size(), C.sizeof(Prob))
-if os.environ.get("RQP_JITTER"): C.c_int.in_dll(lib, "rqp_jitter").value = 1
 lib.rqp_solve.argtypes = [C.POINTER(Prob), C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int)]
 
 
@@ -41,6 +40,12 @@ def main():
     seed = int(sys.argv[3]) if len(sys.argv) > 3 else 5
     variant = sys.argv[4] if len(sys.argv) > 4 else "bound"
     dbg = [tuple(int(v) for v in a.split(":")) for a in sys.argv[5].split(",")] if len(sys.argv) > 5 else []
+    run(N, steps, seed, variant, dbg)
+
+
+def run(N, steps, seed, variant="bound", dbg=(), jitter=False, quiet=False):
+    """closed loop of a C4-like scene with the oracle; every agent of every step also by the prototype.  Returns the agreement counters."""
+    C.c_int.in_dll(lib, "rqp_jitter").value = 1 if (jitter or os.environ.get("RQP_JITTER")) else 0
     cfg = dict(wl.CONFIGS["C4"]); cfg["N"] = N
     kw = wl.solver_kwargs(cfg, N)
     prm = orc.make_params(variant, **kw)
@@ -140,17 +145,20 @@ def main():
                 worst.append((err, n, nr, int(sv[0])))
                 tot["maxerr"] = max(tot["maxerr"], err)
         worst.sort(reverse=True)
-        print(f"step {step}: oracle {t_or:.2f}s proto {time.time() - t0:.2f}s  worst", [(f"{e:.1e}", n, nr, it) for e, n, nr, it in worst[:3]], flush=True)
+        if not quiet: print(f"step {step}: oracle {t_or:.2f}s proto {time.time() - t0:.2f}s  worst", [(f"{e:.1e}", n, nr, it) for e, n, nr, it in worst[:3]], flush=True)
         ok = (ref["status"] & 1) == 1
         l = np.where(ok[:, None], ref["p"], l)
         xp = np.where(ok[:, None], ref["p"][:, :3], xp)
         xv = np.where(ok[:, None], ref["v"][:, :3], xv)
         xa = np.where(ok[:, None], ref["a"][:, :3], xa)
     n = max(tot["n"], 1)
+    if quiet:
+        return tot
     print(tot)
     print("fallback reasons", reasons, fb_list)
     print("per agent: iters %.2f eqps %.2f partial %.2f singular %.3f crashdrops %.2f" % (agg[0] / n, agg[1] / n, agg[2] / n, agg[3] / n, agg[6] / n))
     print("max hard", hist_hard.tolist(), "max extra", hist_extra.tolist())
+    return tot
 
 
 if __name__ == "__main__":
