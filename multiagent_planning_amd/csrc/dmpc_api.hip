@@ -854,8 +854,8 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
         return 0;
     }
     const bool run_order = ctx->forced_n != S * c_count && S * c_count >= 512 && !ctx->no_lpt;
-    // the reduced solver (dmpc_rsolve.hip) takes solveSoftDMPCbound in every launch form: which kernel solves an agent must not depend on how deep the launch is
-    const bool reduced = ctx->reduced_solver && p.variant == DMPC_VAR_BOUND && !f32t && ctx->num_cu >= 1;
+    // the reduced solver (dmpc_rsolve.hip) takes solveSoftDMPCbound / bound2 and DMPC::solveQPv2 in every launch form: which kernel solves an agent must not depend on how deep the launch is
+    const bool reduced = ctx->reduced_solver && (p.variant == DMPC_VAR_BOUND || p.variant == DMPC_VAR_BOUND2 || p.variant == DMPC_VAR_CPP || p.variant == DMPC_VAR_CPP2) && !f32t && ctx->num_cu >= 1;   // the variants with slack rows on ONE horizon step
     P.zero4 = (!tiny || run_order || reduced) ? ctx->counter.as<int>() : nullptr;   // queue heads of the persistent solve launches, tier-2 count, live bound: zeroed by the scan kernel (a memset is a launch of its own, 5 us)
     // phase 0: scan + rows
     P.qcap = q1; P.only_flagged = 0; P.qover_bit = two_tier ? ST_QOVER : ST_CAPACITY;
