@@ -36,7 +36,9 @@ enum { RB_IN = 1, RB_PIN0 = 2, RB_PINL = 4 };
 constexpr int R_NH = 8;   // hard constraints of the small system, one per lane (hard rows + walls + the entering constraint)
 constexpr int R_NW = 3;   // walls of the working set (a corner of the workspace)
 constexpr int R_NE = R_NW + 1;
-constexpr int REQP_MAX = 160;       // equality-constrained solves per ladder level before the agent is handed to the general solver
+constexpr int REQP_MAX = 110;       // equality-constrained solves per ladder level before the agent is handed to the general solver
+constexpr int RBLOCK_UNTIL = 48;    // ... and only among the first equality solves of a level: a level that runs longer goes on with the exact steps (a block move is not
+                                    // monotone in the dual objective: an agent in a corner of the workspace cycled through walls and block moves with period 24)
 constexpr int RBLOCK_MAX = 24;     // block moves of the bounds per ladder level (then the exact one-at-a-time steps only)
 constexpr int RCERT_AFTER = 6;      // scans of a ladder level before the certificate looks at it
 constexpr int RCERT_PLANES = 70;    // planes the wave's LDS holds for it: 64 rows + 6 box faces   // extras: the walls + an entering wall / bound
@@ -306,7 +308,7 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
                     const int pcode = readlane_i(bestc, __ffsll((long long)wm) - 1);
                     ent = pcode >> 16; eidx = pcode & 63; esg = (pcode & 256) ? 1 : -1;
                     if (ent == RE_WALL && nw >= R_NW) { rc = 2; why = 5; break; }
-                    if (ent == RE_BOUND && !noblock && nblock < RBLOCK_MAX) {
+                    if (ent == RE_BOUND && !noblock && nblock < RBLOCK_MAX && leqp < RBLOCK_UNTIL) {
                         const bool vb_ = comp && fx == 0 && fabs(a) - P.alim > tol;
                         if (__popcll(__ballot(vb_)) >= 2) {
                             fxhi_s = __ballot(comp && fx > 0); fxlo_s = __ballot(comp && fx < 0); rfl_s = rfl; sphase = 3;
@@ -755,7 +757,7 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
                 const unsigned long long bm = __ballot(bt >= 0 && ir == imax);
                 const int bl = __ffsll((long long)bm) - 1;
                 const int bty = readlane_i(bt, bl);
-                if (!sing && bty == 0 && !noblock && nblock < RBLOCK_MAX && ent != RE_WALL) {
+                if (!sing && bty == 0 && !noblock && nblock < RBLOCK_MAX && leqp < RBLOCK_UNTIL && ent != RE_WALL) {
                     const bool ng = comp && fx != 0 && mu_n < 0.0;
                     if (__popcll(__ballot(ng)) >= 2) {   // block move (b): the entering constraint joins, every bound whose multiplier would turn negative is freed
                         fxhi_s = __ballot(comp && fx > 0); fxlo_s = __ballot(comp && fx < 0); rfl_s = rfl; sphase = 2;
