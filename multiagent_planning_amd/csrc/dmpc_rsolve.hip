@@ -200,6 +200,8 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
         // unconstrained minimiser from the Gram tables, exactly as the scan's unconstrained exit and the general solver form it
         a_unc = comp ? unc_entry(qw, sw, gax, ao_l, Gt[kt * 30 + 15 + (K - 1)], Gt[kt * 30]) : 0.0;
     }
+    // (the scales of the bounds and walls per lane, loaded here: a table load inside the iteration is a trip to the L2 on its critical path)
+    const double sc_bound_l = Gt[kt * 31], sc_wall_l = Gt[(15 + kt) * 31];   // H1^-1(k,k), (L H1^-1 L')(k,k)
     const double sc_row = Gt[(15 + kc) * 31];   // n'H^-1 n of the UNREDUCED Hessian: the scale of the dependence test (dmpc_solve.hip: delta <= 1e-13 s_pp)
 
     // the ladder certificate (ladder_level_infeasible, dmpc_kernels.hip) wants the walls of component (k, axis) in lane 3 k + axis
@@ -462,7 +464,7 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
                         const int x = eidx >> 4;
                         const double t = sgd * readlane_d(Ykc, eidx) * (x == 0 ? isg3[0] : (x == 1 ? isg3[1] : isg3[2]));   // yt on its axis
                         const double g0 = sgd * readlane_d(Yp, eidx), u0 = sgd * readlane_d(a0, eidx);
-                        if (lane == xb) { hy0 = x == 0 ? t : 0.0; hy1 = x == 1 ? t : 0.0; hy2 = x == 2 ? t : 0.0; hd = P.alim; hrho = P.alim - u0; hsc = Gt[(eidx & 15) * 31]; omr[0] = g0 - t * t; }
+                        if (lane == xb) { hy0 = x == 0 ? t : 0.0; hy1 = x == 1 ? t : 0.0; hy2 = x == 2 ? t : 0.0; hd = P.alim; hrho = P.alim - u0; hsc = readlane_d(sc_bound_l, eidx); omr[0] = g0 - t * t; }
                     } else {
                         // walls (and maybe an entering wall / bound), one at a time: normal and H~ n are formed here and again for the update of a -- nothing of
                         // them is kept; an extra's normal lives on ONE axis, so yt_i is a scalar on that axis and G0_ij = n_j' H~ n_i needs extra i's H~ n only
@@ -479,7 +481,7 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
                             yts[i] = readlane_d(tl, wl & 48) * (xa == 0 ? isg3[0] : (xa == 1 ? isg3[1] : isg3[2]));
                             const double u0 = readlane_d(ul, wl & 48);
                             const double dd = is_b ? P.alim : ((code & 256) ? readlane_d(whi_l, wl) : -readlane_d(wlo_l, wl));
-                            const double sc = is_b ? Gt[(wl & 15) * 31] : Gt[(15 + (wl & 15)) * 31];
+                            const double sc = is_b ? readlane_d(sc_bound_l, wl) : readlane_d(sc_wall_l, wl);
                             if (lane == xb + i) { hy0 = xa == 0 ? yts[i] : 0.0; hy1 = xa == 1 ? yts[i] : 0.0; hy2 = xa == 2 ? yts[i] : 0.0; hd = dd; hrho = dd - u0; hsc = sc; }
 #pragma unroll
                             for (int j = 0; j <= i; ++j) {
