@@ -131,6 +131,7 @@ struct dmpc_ctx {
     int grid_min_part = 2048; // ... and when the query covers only a PART of the scene's agents (a rank's chunk: the grid is still built over all of them)
     int nbr_grid = 1;        // development option nbr_grid: 0 = neighbour lists of large scenes from the all-pairs box test of round 3 (nbr_kernel) instead of the cell grid + distance filter
     DevBuf grid;             // cell grid of the neighbour lists (counts, starts, entries)
+    int no_level_skip = 0;   // development option no_level_skip (see StepParams)
     int no_level_check = 0;  // development option no_level_check (see StepParams)
     int lds_pad_kb = 0;      // development option lds_pad_kb: KB of unused LDS per one-agent solve workgroup (occupancy experiments: fewer resident agents per CU)
     int f32_dep_exp = 8;     // development option f32_dep_exp: fp32-factor kernels treat a pivot as dependent below delta / s_pp = 10^-n
@@ -412,7 +413,7 @@ extern "C" int dmpc_debug_option(dmpc_ctx *ctx, const char *name, int value)
         {"no_fuse", &dmpc_ctx::no_fuse}, {"no_persist", &dmpc_ctx::no_persist}, {"force_persist", &dmpc_ctx::force_persist}, {"no_cull", &dmpc_ctx::no_cull}, {"order_slices", &dmpc_ctx::order_slices}, {"cull_min", &dmpc_ctx::cull_min},
         {"no_lpt", &dmpc_ctx::no_lpt}, {"order_hint", &dmpc_ctx::order_hint}, {"crash_min", &dmpc_ctx::crash_min}, {"crash_any", &dmpc_ctx::crash_any}, {"no_fast_exit", &dmpc_ctx::no_fast_exit}, {"pivot_explore", &dmpc_ctx::pivot_explore},
         {"iter_cap", &dmpc_ctx::iter_cap}, {"tier1_qcap", &dmpc_ctx::tier1_env}, {"split_parts", &dmpc_ctx::split_parts}, {"no_split", &dmpc_ctx::no_split},
-        {"static_queue", &dmpc_ctx::static_queue}, {"queue_chunk", &dmpc_ctx::queue_chunk}, {"no_split_t", &dmpc_ctx::no_split_t}, {"ext_cap", &dmpc_ctx::ext_cap}, {"nbr_grid", &dmpc_ctx::nbr_grid}, {"f32_dep_exp", &dmpc_ctx::f32_dep_exp}, {"grid_min", &dmpc_ctx::grid_min}, {"no_level_check", &dmpc_ctx::no_level_check}, {"lds_pad_kb", &dmpc_ctx::lds_pad_kb}, {"reduced_solver", &dmpc_ctx::reduced_solver}, {"rsolve_cap", &dmpc_ctx::rsolve_cap}};
+        {"no_level_skip", &dmpc_ctx::no_level_skip}, {"static_queue", &dmpc_ctx::static_queue}, {"queue_chunk", &dmpc_ctx::queue_chunk}, {"no_split_t", &dmpc_ctx::no_split_t}, {"ext_cap", &dmpc_ctx::ext_cap}, {"nbr_grid", &dmpc_ctx::nbr_grid}, {"f32_dep_exp", &dmpc_ctx::f32_dep_exp}, {"grid_min", &dmpc_ctx::grid_min}, {"no_level_check", &dmpc_ctx::no_level_check}, {"lds_pad_kb", &dmpc_ctx::lds_pad_kb}, {"reduced_solver", &dmpc_ctx::reduced_solver}, {"rsolve_cap", &dmpc_ctx::rsolve_cap}};
     for (auto &t : tab)
         if (!std::strcmp(t.n, name)) {
             ctx->*(t.f) = value;
@@ -685,6 +686,7 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     P.scp_tol = p.tol;
     P.dep_tol_f32 = std::pow(10.0, -(double)ctx->f32_dep_exp);
     P.no_level_check = ctx->no_level_check;
+    P.no_level_skip = ctx->no_level_skip;
     // (not for solveHardDMPC: rows at every horizon step, 3 % of the agents would qualify and every scan would pay for the test)
     P.fast_exit = (ctx->no_fast_exit || p.variant == DMPC_VAR_HARD || p.variant == DMPC_VAR_SCP || p.order == 4) ? 0 : 1;
     // measured: the crash start pays for the slack-carrying variants (C4, N = 10^4: solve launch -16 %) and costs on solveHardDMPC
@@ -705,11 +707,11 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     // (crossover, agents per launch: C3 4 000: 0.72 / 0.71 ms, 8 000: 1.06 / 0.96; C5 3 200: 0.37 / 0.47, 6 400: 0.59 / 0.61 -- one agent per workgroup / persistent)
     // (round 5: the slack variants in LARGE scenes -- the 56-slot tier, agents of ~100 us each -- are bound by their work per wave slot: persistent
     // waves with the split factor, seven per CU, from two launches' worth of one-agent workgroups on)
-    const bool big_soft = soft && G * C >= 1024 && !ctx->no_split_t && !(ctx->precision & DMPC_PREC_F32FACTOR) && !ctx->single_tier && !ctx->tier1_env;
+    const bool f32t = (ctx->precision & DMPC_PREC_F32FACTOR) != 0 && p.variant != DMPC_VAR_ALL3;   // (solveSoftDMPCall keeps the fp64 factor under every precision)
+    const bool big_soft = soft && G * C >= 1024 && !ctx->no_split_t && !f32t && !ctx->single_tier && !ctx->tier1_env;
     const bool shallow = (long)S * c_count < (big_soft ? 8L : (heavy_agents ? 28L : 128L)) * ncu && !ctx->force_persist && !ctx->tier1_env;
     // fp32 inverse factor: one tier with the full capacity, no split T.  Not for solveSoftDMPCall: its three nearly parallel rows per neighbour
     // need the fp64 factor (sweep of round 4: 1 % of its agent-steps ended on another ladder level) -- that variant keeps it whatever the context says.
-    const bool f32t = (ctx->precision & DMPC_PREC_F32FACTOR) != 0 && p.variant != DMPC_VAR_ALL3;
     const int q1 = (ctx->single_tier || tiny || f32t) ? full_qcap(p.variant) : tier1_qcap(ctx, p.variant, G * C), q2 = full_qcap(p.variant);
     const bool two_tier = q1 < q2;
     ctx->post_fused = 0;
@@ -731,6 +733,7 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     const size_t lds0 = scan_lds_bytes();
     const size_t lds1 = solve_lds_bytes(P.nrmax, soft, q1, false, 0, f32t) + (size_t)ctx->lds_pad_kb * 1024, lds2 = solve_lds_bytes(P.nrmax, soft, q2, false, 0, f32t) + (size_t)ctx->lds_pad_kb * 1024;
     const size_t ldsmax = lds2 > lds1 ? lds2 : lds1;
+    if (ctx->lds_pad_kb < 0 || ldsmax > 160 * 1024) FAIL(ctx, "development option lds_pad_kb: the solve workgroup's LDS block would exceed the CU's 160 KB");
     if ((int)ldsmax > ctx->max_lds_set) {
         HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_kernel<true, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsmax));
         HIPCHK(ctx, hipFuncSetAttribute((const void *)dmpc_solve_kernel<true, 48>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsmax));
@@ -1500,10 +1503,10 @@ static int transition_one(dmpc_ctx *ctx, int S, int N, const double *po, const d
 static void copy_debug_options(dmpc_ctx *dst, const dmpc_ctx *src)
 {
     static const char *names[] = {"no_fuse", "no_persist", "force_persist", "no_cull", "order_slices", "cull_min", "no_lpt", "crash_min", "crash_any", "no_fast_exit",
-                                  "pivot_explore", "iter_cap", "tier1_qcap", "static_queue", "queue_chunk", "no_split_t", "ext_cap", "nbr_grid", "f32_dep_exp", "grid_min", "no_level_check", "order_hint", "lds_pad_kb", "reduced_solver", "rsolve_cap"};
+                                  "pivot_explore", "iter_cap", "tier1_qcap", "static_queue", "queue_chunk", "no_split_t", "ext_cap", "nbr_grid", "f32_dep_exp", "grid_min", "no_level_check", "order_hint", "lds_pad_kb", "reduced_solver", "rsolve_cap", "no_level_skip"};
     int dmpc_ctx::*fields[] = {&dmpc_ctx::no_fuse, &dmpc_ctx::no_persist, &dmpc_ctx::force_persist, &dmpc_ctx::no_cull, &dmpc_ctx::order_slices, &dmpc_ctx::cull_min,
                                &dmpc_ctx::no_lpt, &dmpc_ctx::crash_min, &dmpc_ctx::crash_any, &dmpc_ctx::no_fast_exit, &dmpc_ctx::pivot_explore, &dmpc_ctx::iter_cap,
-                               &dmpc_ctx::tier1_env, &dmpc_ctx::static_queue, &dmpc_ctx::queue_chunk, &dmpc_ctx::no_split_t, &dmpc_ctx::ext_cap, &dmpc_ctx::nbr_grid, &dmpc_ctx::f32_dep_exp, &dmpc_ctx::grid_min, &dmpc_ctx::no_level_check, &dmpc_ctx::order_hint, &dmpc_ctx::lds_pad_kb, &dmpc_ctx::reduced_solver, &dmpc_ctx::rsolve_cap};
+                               &dmpc_ctx::tier1_env, &dmpc_ctx::static_queue, &dmpc_ctx::queue_chunk, &dmpc_ctx::no_split_t, &dmpc_ctx::ext_cap, &dmpc_ctx::nbr_grid, &dmpc_ctx::f32_dep_exp, &dmpc_ctx::grid_min, &dmpc_ctx::no_level_check, &dmpc_ctx::order_hint, &dmpc_ctx::lds_pad_kb, &dmpc_ctx::reduced_solver, &dmpc_ctx::rsolve_cap, &dmpc_ctx::no_level_skip};
     for (size_t i = 0; i < sizeof(names) / sizeof(names[0]); ++i) (void)dmpc_debug_option(dst, names[i], src->*(fields[i]));
 }
 

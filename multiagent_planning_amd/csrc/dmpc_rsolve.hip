@@ -736,7 +736,7 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
                     if (ladder && violation) {
                         const double u_l = (r_hard && (rfl & RB_PINL)) ? lam_n * (-rsd * slb) : 0.0;
                         const double Uc = wave_sum0(u_l), Cc = farkas - Uc;
-                        if (Cc + Uc < 0.0) {
+                        if (Cc + Uc < 0.0 && !P.no_level_skip) {
                             double kk = 2.0;
                             while (lev_skip < 40 && Cc + kk * Uc < -1e-7 * (fabs(Cc) + kk * fabs(Uc))) { ++lev_skip; kk *= 2.0; }
                         }

@@ -1396,7 +1396,7 @@ __device__ __forceinline__ void solve_body(const StepParams &P, const int lane, 
                             else if (p.ty == TY_SLKL) up = p.d;
                             const double Cc = (p.d - up) + wave_sum0(c_l), Uc = up + wave_sum0(u_l);
                             lev_skip = 0;
-                            if (Cc + Uc < 0.0) {   // (the proof as it stands; anything else is round-off: no skipping)
+                            if (Cc + Uc < 0.0 && !P.no_level_skip) {   // (the proof as it stands; anything else is round-off: no skipping)
                                 double kk = 2.0;
                                 while (lev_skip < 40 && Cc + kk * Uc < -1e-7 * (fabs(Cc) + kk * fabs(Uc))) { ++lev_skip; kk *= 2.0; }
                             }

@@ -28,7 +28,7 @@ def compare(tag, kw, l, xp, xv, xa, pf, variant="bound"):
     o_g = gen.step_batch(l, xp, xv, xa, pf)
     ref = orc.step(orc.make_params(variant, **kw), l, xp, xv, xa, pf, nthreads=os.cpu_count())
     hb = np.zeros((8, 8)); L.dmpc_debug_trace(red._ctx, -7, 8, hb.ctypes.data_as(C.c_void_p))
-    print("      give-up reasons (1 rows>64, 2 steps, 3 iter cap, 4 inner cap, 5 third wall, 6 nh>5, 7 bad pivot, 8 crash singular, 9 farkas):", hb.view(np.int32).ravel()[:10].tolist(), "agents", hb.ravel()[16:26].tolist())
+    print("      give-up reasons (1 rows>64, 2 steps, 3 iter cap, 4 inner cap, 5 third wall, 6 nh>5, 7 bad pivot, 8 crash singular, 9 farkas, 10 zero steps, 11 cycle):", hb.view(np.int32).ravel()[:12].tolist(), "agents", hb.ravel()[16:28].tolist())
     st_r, st_g, st_o = o_r["status"].ravel(), o_g["status"].ravel(), ref["status"].ravel()
     ir, ig, io = o_r["info"].reshape(-1, 8), o_g["info"].reshape(-1, 8), ref["info"].reshape(-1, 8)
     N = len(st_o)

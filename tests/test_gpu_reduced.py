@@ -68,6 +68,24 @@ def test_reduced_against_general_and_oracle_closed_loop():
         xp = np.where(ok[:, None], ref["p"][:, :3], xp); xv = np.where(ok[:, None], ref["v"][:, :3], xv); xa = np.where(ok[:, None], ref["a"][:, :3], xa)
 
 
+def test_level_skip_extrapolation_changes_no_retry_count():
+    """the retry ladder skips the levels a failed solve's Farkas combination still proves infeasible (margin 1e-7 of its cancelling sums): with the
+    extrapolation switched off (development option no_level_skip: every level the certificate does not settle is solved) the retry counts, the
+    statuses and the minimisers are the same -- in the reduced and in the general solver, on MPC step 2 of a dense scene (ladder levels up to 6)"""
+    cfg, kw, po, pf = _c4_like(3000, wl.SEED0 + 611)
+    l = np.stack([orc.init_one(po[n], pf[n], cfg["h"], 15)[0] for n in range(len(po))])
+    xp, xv, xa = po.copy(), np.zeros_like(po), np.zeros_like(po)
+    for reduced in (1, 0):
+        a, b = mp.Dmpc("bound", **kw), mp.Dmpc("bound", **kw)
+        a.debug_option("reduced_solver", reduced); b.debug_option("reduced_solver", reduced)
+        b.debug_option("no_level_skip", 1)
+        oa, ob = a.step_batch(l, xp, xv, xa, pf), b.step_batch(l, xp, xv, xa, pf)
+        assert oa["info"][..., 2].max() >= 3, "the scene must climb the ladder"
+        worst = _agree(oa, ob)
+        assert worst <= 5e-8
+        assert ob["info"][..., 4].sum() >= oa["info"][..., 4].sum()   # (equal when the level certificate settles every level the extrapolation would have skipped)
+
+
 def test_hand_over_to_the_general_solver_changes_nothing():
     """agents the reduced solver gives up (here: nearly all, by a cap of three equality solves per ladder level) are solved by the general
     solver in the tier-2 launch: the step's outputs are then the general solver's, bit for bit, for those agents -- and the oracle's minimiser"""

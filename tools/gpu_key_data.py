@@ -23,7 +23,9 @@ for k in range(9):
     assert L.dmpc_debug_trace(d._ctx, -5, cap, buf.ctypes.data_as(C.c_void_p)) == 0
     durs.append(buf[:N * 2].reshape(N, 2)[:, 1] * 1e-2); plain.append(out["info"][0].copy())
     assert L.dmpc_debug_trace(d._ctx, -6, 8, None) == 0
+    d.debug_option("reduced_solver", 0)   # (the feature word travels in the general solver's info record; the durations above are the reduced solver's)
     out = d.step_batch(l, xp, xv, xa, pf)
+    d.debug_option("reduced_solver", 1)
     infos.append(out["info"][0].copy())
     st = out["status"][0]; ok = st == 1
     l = np.where(ok[None, :, None], out["p"], l); xp = np.where(ok[None, :, None], out["p"][..., :3], xp)
