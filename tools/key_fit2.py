@@ -1,8 +1,9 @@
-"""development (CPU): launch-order keys against MEASURED solve durations (gpurun_out/key_data_*.npz from tools/gpu_key_data.py): list scheduling on 1792 wave slots
+"""development (CPU): launch-order keys against MEASURED solve durations (gpurun_out/key_data_*.npz from tools/gpu_key_data.py): list scheduling on the launch's wave slots (KEY_SLOTS)
 in the order a candidate key gives; makespan against the perfect order and the key as built."""
 import sys, heapq, glob
 import numpy as np
-M = 1792
+import os
+M = int(os.environ.get('KEY_SLOTS', '2048'))   # wave slots of the solve launch (reduced solver: 256 CUs x 8; the general split-factor kernel: 1792)
 files = sorted(glob.glob("gpurun_out/key_data_*.npz"))
 def makespan(dur, order):
     h = [0.0] * M; heapq.heapify(h)
@@ -51,3 +52,12 @@ for extra in (False, True):
 k = S[2]; live = k["dur"] > 0
 print("correlations with the duration (step 4):", {n: round(float(np.corrcoef(k[n][live], k["dur"][live])[0, 1]), 3) for n in names + ["key", "iters", "maxq", "tries"]})
 print("work per slot", round(k["dur"].sum() / M), "longest", round(k["dur"].max()))
+# the agent's own previous solve (closed loop): alone, and combined with the key as built
+by = {(s["file"], s["step"]): s for s in S}
+def prev_of(s, what):
+    p = by.get((s["file"], s["step"] - 1))
+    return p[what] if p is not None else np.zeros_like(s["dur"])
+evaluate(lambda s: prev_of(s, "dur"), "previous MPC step's duration")
+evaluate(lambda s: prev_of(s, "iters"), "previous MPC step's iterations / equality solves")
+for w in (0.5, 1.0, 2.0):
+    evaluate(lambda s: prev_of(s, "iters") * w + s["key"], f"{w} x previous iterations + key")
