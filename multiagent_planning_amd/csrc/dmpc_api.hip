@@ -129,6 +129,9 @@ struct dmpc_ctx {
     int no_split_t = 0;      // development option no_split_t: slack-free persistent solve with the whole inverse factor in every wave's block (nine waves per CU; A/B runs, tests)
     int grid_min = 768;      // development option grid_min: cell-grid neighbour lists from this many agents per scene on (below: nbr_kernel) ...
     int grid_min_part = 2048; // ... and when the query covers only a PART of the scene's agents (a rank's chunk: the grid is still built over all of them)
+    int prep_fuse = 1;       // development option prep_fuse: 0 = the cell grid of a single scene by the five kernels of round 4 instead of grid_prep_kernel + grid_fill2_kernel
+    bool grid_clean = false; // the cell grid's counters were left zero by the last scan launch (grid_clean_key: for which buffer / size)
+    unsigned long long grid_clean_key = 0;
     int nbr_grid = 1;        // development option nbr_grid: 0 = neighbour lists of large scenes from the all-pairs box test of round 3 (nbr_kernel) instead of the cell grid + distance filter
     DevBuf grid;             // cell grid of the neighbour lists (counts, starts, entries)
     int no_level_skip = 0;   // development option no_level_skip (see StepParams)
@@ -413,7 +416,7 @@ extern "C" int dmpc_debug_option(dmpc_ctx *ctx, const char *name, int value)
         {"no_fuse", &dmpc_ctx::no_fuse}, {"no_persist", &dmpc_ctx::no_persist}, {"force_persist", &dmpc_ctx::force_persist}, {"no_cull", &dmpc_ctx::no_cull}, {"order_slices", &dmpc_ctx::order_slices}, {"cull_min", &dmpc_ctx::cull_min},
         {"no_lpt", &dmpc_ctx::no_lpt}, {"order_hint", &dmpc_ctx::order_hint}, {"crash_min", &dmpc_ctx::crash_min}, {"crash_any", &dmpc_ctx::crash_any}, {"no_fast_exit", &dmpc_ctx::no_fast_exit}, {"pivot_explore", &dmpc_ctx::pivot_explore},
         {"iter_cap", &dmpc_ctx::iter_cap}, {"tier1_qcap", &dmpc_ctx::tier1_env}, {"split_parts", &dmpc_ctx::split_parts}, {"no_split", &dmpc_ctx::no_split},
-        {"no_level_skip", &dmpc_ctx::no_level_skip}, {"static_queue", &dmpc_ctx::static_queue}, {"queue_chunk", &dmpc_ctx::queue_chunk}, {"no_split_t", &dmpc_ctx::no_split_t}, {"ext_cap", &dmpc_ctx::ext_cap}, {"nbr_grid", &dmpc_ctx::nbr_grid}, {"f32_dep_exp", &dmpc_ctx::f32_dep_exp}, {"grid_min", &dmpc_ctx::grid_min}, {"no_level_check", &dmpc_ctx::no_level_check}, {"lds_pad_kb", &dmpc_ctx::lds_pad_kb}, {"reduced_solver", &dmpc_ctx::reduced_solver}, {"rsolve_cap", &dmpc_ctx::rsolve_cap}};
+        {"no_level_skip", &dmpc_ctx::no_level_skip}, {"prep_fuse", &dmpc_ctx::prep_fuse}, {"static_queue", &dmpc_ctx::static_queue}, {"queue_chunk", &dmpc_ctx::queue_chunk}, {"no_split_t", &dmpc_ctx::no_split_t}, {"ext_cap", &dmpc_ctx::ext_cap}, {"nbr_grid", &dmpc_ctx::nbr_grid}, {"f32_dep_exp", &dmpc_ctx::f32_dep_exp}, {"grid_min", &dmpc_ctx::grid_min}, {"no_level_check", &dmpc_ctx::no_level_check}, {"lds_pad_kb", &dmpc_ctx::lds_pad_kb}, {"reduced_solver", &dmpc_ctx::reduced_solver}, {"rsolve_cap", &dmpc_ctx::rsolve_cap}};
     for (auto &t : tab)
         if (!std::strcmp(t.n, name)) {
             ctx->*(t.f) = value;
@@ -764,8 +767,6 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
     if (G * C >= ctx->cull_min && !ctx->no_cull && finite_radius) {
         const int total = G * S * C;
         if (ctx->bbox.ensure((size_t)total * 6 * NSEG * 4) || ctx->bbox_nm.ensure((size_t)total * NBOX_NM * 4)) FAIL(ctx, "device allocation failed (bbox)");
-        if (lTf) hipLaunchKernelGGL(bbox_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, C, lTf, ctx->bbox.as<float>(), ctx->bbox_nm.as<float>());
-        else hipLaunchKernelGGL(bbox_kernel<double>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, C, lT, ctx->bbox.as<float>(), ctx->bbox_nm.as<float>());
         if (C >= (1 << 20) || G > 2047)   // a list entry packs (chunk << 20) | column into an int
             FAIL(ctx, "neighbour lists: at most 2047 chunks of fewer than 2^20 agents");
         // neighbour lists from the boxes (nbr_kernel): up to 4096 entries per agent, within 1 GB of scratch
@@ -790,9 +791,10 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
         // size is two fill launches, 9 us)
         GridGeom gg{};
         int ncell = 1;
-        int *g_cnt = nullptr, *g_mh = nullptr, *g_st = nullptr, *g_cell = nullptr;
+        int *g_cnt = nullptr, *g_mh = nullptr, *g_st = nullptr, *g_cell = nullptr, *g_pos = nullptr;
         f4_t *g_ent = nullptr;
         size_t n_zero = 0;
+        bool fused = false;   // ONE scene: the grid in two launches (grid_prep_kernel, grid_fill2_kernel) instead of five
         if (use_grid) {
             // cells: R along x (the cells of a run along x are contiguous in the entry array: their granularity is free), 1.5 R along y
             // and 1.5 R c along z (the metric's z scale), at most 32 per axis
@@ -807,23 +809,42 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
             // one grid per third of the horizon (keyed by the centre of that segment's box: a third of the extent of the whole horizon's).  One
             // buffer: [S][3][ncell] counts, [S][3][3] largest half extents (zeroed together), [S][3][ncell + 1] starts, [3][G S C] cells, [S][3][G C] entries
             const size_t n_cnt = (size_t)S * NSEG * ncell, n_mh = (size_t)S * NSEG * 3, n_st = (size_t)S * NSEG * (ncell + 1);
-            const size_t n_hd = (n_cnt + n_mh + n_st + (size_t)NSEG * total + 7) & ~(size_t)7;   // (the entry records behind it are 32-byte aligned)
+            const size_t n_hd = (n_cnt + n_mh + n_st + 2 * (size_t)NSEG * total + 7) & ~(size_t)7;   // (the entry records behind it are 32-byte aligned)
             if (ctx->grid.ensure((n_hd + 8 * (size_t)NSEG * total) * 4)) FAIL(ctx, "device allocation failed (neighbour grid)");
-            g_cnt = ctx->grid.as<int>(); g_mh = g_cnt + n_cnt; g_st = g_mh + n_mh; g_cell = g_st + n_st;
+            g_cnt = ctx->grid.as<int>(); g_mh = g_cnt + n_cnt; g_st = g_mh + n_mh; g_cell = g_st + n_st; g_pos = g_cell + (size_t)NSEG * total;
             g_ent = (f4_t *)(g_cnt + n_hd);
             n_zero = n_cnt + n_mh;
+            fused = S == 1 && ctx->prep_fuse && (size_t)NSEG * (ncell + 1) * 4 <= 48 * 1024;
+        }
+        if (!fused) {
+            if (lTf) hipLaunchKernelGGL(bbox_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, C, lTf, ctx->bbox.as<float>(), ctx->bbox_nm.as<float>());
+            else hipLaunchKernelGGL(bbox_kernel<double>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, C, lT, ctx->bbox.as<float>(), ctx->bbox_nm.as<float>());
         }
         if (p.variant != DMPC_VAR_HARD || use_grid) {   // neighbour-major fp32 copy of the table: the list walk of the per-step distance scan, the distance test of the grid query
             const size_t tot = (size_t)total * 64;
             if (ctx->lrow.ensure(tot * 4)) FAIL(ctx, "device allocation failed (neighbour-major table)");
-            if (lTf) hipLaunchKernelGGL(table_nbrmajor_kernel<float>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, tot, C, lTf, ctx->lrow.as<float>(), g_cnt, n_zero);
+            if (fused) {}   // (grid_prep_kernel below makes the copy)
+            else if (lTf) hipLaunchKernelGGL(table_nbrmajor_kernel<float>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, tot, C, lTf, ctx->lrow.as<float>(), g_cnt, n_zero);
             else hipLaunchKernelGGL(table_nbrmajor_kernel<double>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, tot, C, lT, ctx->lrow.as<float>(), g_cnt, n_zero);
             if (p.variant != DMPC_VAR_HARD) P.lrow = ctx->lrow.p;
         }
-        if (use_grid) {
+        if (use_grid && fused) {
+            // the counters are zero when the last scan launch left them so (for this buffer and size); a memset otherwise (first step, another batch shape in between)
+            const unsigned long long key = (unsigned long long)(size_t)g_cnt ^ ((unsigned long long)n_zero << 48) ^ ((unsigned long long)total << 20);
+            if (!ctx->grid_clean || ctx->grid_clean_key != key) HIPCHK(ctx, hipMemsetAsync(g_cnt, 0, n_zero * 4, st));
+            ctx->grid_clean = false; ctx->grid_clean_key = key;
+            P.gzero = g_cnt; P.gzero_n = (int)n_zero;
+            const int nbA = (total + 255) / 256, nbC = (int)(((size_t)total * 64 + 255) / 256);
+            if (lTf) hipLaunchKernelGGL(grid_prep_kernel<float>, dim3((unsigned)(nbA + nbC)), dim3(256), 0, st, total, C, short_from, gg, nbA, lTf, ctx->bbox.as<float>(), ctx->bbox_nm.as<float>(), ctx->lrow.as<float>(), g_cell, g_pos, g_cnt, g_mh);
+            else hipLaunchKernelGGL(grid_prep_kernel<double>, dim3((unsigned)(nbA + nbC)), dim3(256), 0, st, total, C, short_from, gg, nbA, lT, ctx->bbox.as<float>(), ctx->bbox_nm.as<float>(), ctx->lrow.as<float>(), g_cell, g_pos, g_cnt, g_mh);
+            hipLaunchKernelGGL(grid_fill2_kernel, dim3((unsigned)nbA), dim3(256), (size_t)NSEG * (ncell + 1) * 4, st, total, C, ncell, (float)(1.0 / p.c), (const int *)g_cell, (const int *)g_pos, (const int *)g_cnt, g_st, (const float *)ctx->lrow.as<float>(), g_ent);
+        } else if (use_grid) {
+            ctx->grid_clean = false;
             hipLaunchKernelGGL(grid_bin_kernel, dim3((unsigned)((total + 255) / 256), NSEG), dim3(256), 0, st, total, S, C, short_from, gg, (const float *)ctx->bbox_nm.as<float>(), g_cell, g_cnt, g_mh);
             hipLaunchKernelGGL(grid_scan_kernel, dim3((unsigned)(S * NSEG)), dim3(ncell > 512 ? 1024 : 256), 0, st, ncell, g_cnt, g_st);
             hipLaunchKernelGGL(grid_fill_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, S, C, ncell, (float)(1.0 / p.c), (const int *)g_cell, g_cnt, (const int *)g_st, (const float *)ctx->lrow.as<float>(), g_ent);
+        }
+        if (use_grid) {
             const int nq = S * c_count;
             hipLaunchKernelGGL(grid_query_kernel, dim3((unsigned)nq), dim3(64 * GQ_WAVES), gq_lds, st, S, G, C, g_local, c_first, c_count, gg,
                                (float)R, (float)(R * p.c), (float)(1.0 / p.c), (float)(Rsel * Rsel * 1.002), (const float *)ctx->bbox_nm.as<float>(), (const float *)ctx->lrow.as<float>(),
@@ -882,6 +903,7 @@ static int launch_step(dmpc_ctx *ctx, int S, int G, int C, int g_local, int c_fi
             else { if (fx) hipLaunchKernelGGL((dmpc_scan_kernel<false, double, true>), sgrid, sblock, lds0 * W, st, P); else hipLaunchKernelGGL((dmpc_scan_kernel<false, double, false>), sgrid, sblock, lds0 * W, st, P); }
         }
     }
+    if (P.gzero) ctx->grid_clean = true;   // (this scan launch leaves the cell grid's counters zero for the next step's grid_prep_kernel)
     // heaviest-first launch order for the solve phase (key left by the scan in hdr[7]).  Tiny launches do not need it.
     if (ctx->forced_n == S * c_count) P.order = ctx->forced_order.as<int>();   // development aid: externally supplied launch order
     else if (run_order) {
@@ -1503,10 +1525,10 @@ static int transition_one(dmpc_ctx *ctx, int S, int N, const double *po, const d
 static void copy_debug_options(dmpc_ctx *dst, const dmpc_ctx *src)
 {
     static const char *names[] = {"no_fuse", "no_persist", "force_persist", "no_cull", "order_slices", "cull_min", "no_lpt", "crash_min", "crash_any", "no_fast_exit",
-                                  "pivot_explore", "iter_cap", "tier1_qcap", "static_queue", "queue_chunk", "no_split_t", "ext_cap", "nbr_grid", "f32_dep_exp", "grid_min", "no_level_check", "order_hint", "lds_pad_kb", "reduced_solver", "rsolve_cap", "no_level_skip"};
+                                  "pivot_explore", "iter_cap", "tier1_qcap", "static_queue", "queue_chunk", "no_split_t", "ext_cap", "nbr_grid", "f32_dep_exp", "grid_min", "no_level_check", "order_hint", "lds_pad_kb", "reduced_solver", "rsolve_cap", "no_level_skip", "prep_fuse"};
     int dmpc_ctx::*fields[] = {&dmpc_ctx::no_fuse, &dmpc_ctx::no_persist, &dmpc_ctx::force_persist, &dmpc_ctx::no_cull, &dmpc_ctx::order_slices, &dmpc_ctx::cull_min,
                                &dmpc_ctx::no_lpt, &dmpc_ctx::crash_min, &dmpc_ctx::crash_any, &dmpc_ctx::no_fast_exit, &dmpc_ctx::pivot_explore, &dmpc_ctx::iter_cap,
-                               &dmpc_ctx::tier1_env, &dmpc_ctx::static_queue, &dmpc_ctx::queue_chunk, &dmpc_ctx::no_split_t, &dmpc_ctx::ext_cap, &dmpc_ctx::nbr_grid, &dmpc_ctx::f32_dep_exp, &dmpc_ctx::grid_min, &dmpc_ctx::no_level_check, &dmpc_ctx::order_hint, &dmpc_ctx::lds_pad_kb, &dmpc_ctx::reduced_solver, &dmpc_ctx::rsolve_cap, &dmpc_ctx::no_level_skip};
+                               &dmpc_ctx::tier1_env, &dmpc_ctx::static_queue, &dmpc_ctx::queue_chunk, &dmpc_ctx::no_split_t, &dmpc_ctx::ext_cap, &dmpc_ctx::nbr_grid, &dmpc_ctx::f32_dep_exp, &dmpc_ctx::grid_min, &dmpc_ctx::no_level_check, &dmpc_ctx::order_hint, &dmpc_ctx::lds_pad_kb, &dmpc_ctx::reduced_solver, &dmpc_ctx::rsolve_cap, &dmpc_ctx::no_level_skip, &dmpc_ctx::prep_fuse};
     for (size_t i = 0; i < sizeof(names) / sizeof(names[0]); ++i) (void)dmpc_debug_option(dst, names[i], src->*(fields[i]));
 }
 

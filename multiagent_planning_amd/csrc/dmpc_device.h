@@ -87,6 +87,8 @@ struct StepParams {
     int *cost_out;          // [S*c_count] or null: work estimate of this agent's solve (quarter microseconds: iterations weighted by the working-set size,
                             // certificate calls) -- the NEXT step's launch order is built from it (order_kernel; dmpc_api.hip: order hint)
     double scp_tol;         // VAR_SCP: `tol` of solveDMPC.m:1,17 (the loop stops when maxDeviation(p, prev_p) <= tol)
+    int *gzero;             // scan kernel: the cell grid's counters (cell counts, largest half extents), set to zero for the NEXT step's grid_prep_kernel (no memset launch), or null
+    int gzero_n;
     int no_level_skip;      // development option no_level_skip: the retry ladder does not extrapolate a failed solve's Farkas combination to higher levels (every level not
                             // certified infeasible is solved: A/B runs of the extrapolation's margin, tests/test_gpu_reduced.py)
     int rsolve_cap;         // reduced solver (dmpc_rsolve.hip): equality-constrained solves per ladder level before an agent is handed to the general solver (0: REQP_MAX; development option rsolve_cap)

@@ -982,6 +982,7 @@ __global__ __launch_bounds__(64 * SCAN_WAVES_PER_WG, SCAN_WAVES_PER_SIMD) void d
     for (int xx = 0; xx < x; ++xx) off += (nb - xx + 7) >> 3;
     const int agent = (off + y) * W + wave, total = P.S * P.c_count;
     if (P.zero4 && blockIdx.x == 0 && threadIdx.x < 4) P.zero4[threadIdx.x] = 0;   // (nothing reads them before the order / solve kernels of this step)
+    if (P.gzero) for (int z = (int)(blockIdx.x * blockDim.x + threadIdx.x); z < P.gzero_n; z += (int)(gridDim.x * blockDim.x)) P.gzero[z] = 0;   // (the cell grid's counters: their last reader, the list query, ran before this launch)
     if (agent >= total) return;
     scan_body<SOFT, TT, FAST, ORD4>(P, lane, agent, dmpc_smem + (size_t)wave * P.lds_per_wave);
 }
@@ -1455,6 +1456,119 @@ __global__ void grid_fill_kernel(int total, int S, int C, int ncell, float e1z, 
         r0.x = __int_as_float((r << 20) | c); r0.y = a0.x; r0.z = a0.y; r0.w = a0.z;
         r1.x = a1.x - a0.x; r1.y = a1.y - a0.y; r1.z = a1.z - a0.z; r1.w = sqrtf(dev2) * 1.0001f + 1e-5f;   // (rounded up)
         ent[ei] = r0; ent[(size_t)S * NSEG * nag + ei] = r1;   // two arrays of 16-byte halves: a wave's load of either is whole cache lines
+    }
+}
+// ---- the cell grid of ONE scene in two launches (round 6; the five kernels above -- boxes, neighbour-major copy, bin, scan, fill: 42 us of
+// a 0.7 ms MPC step at N = 10^4, every one of them a chain of dependent round trips at the launch floor -- stay for batches of scenes).
+// grid_prep_kernel: blocks [0, nbA): thread per table column -- segment boxes (bbox_kernel), cell of each segment's centre, its position within the
+// cell (the value the count's atomicAdd returns: the fill needs no second round of atomics), the scene's largest half extents through a
+// block-wide maximum in LDS (nine global atomics per block); blocks [nbA, ..): the neighbour-major fp32 copy (table_nbrmajor_kernel).  The
+// counters must be ZERO at entry: the scan kernel of the previous step leaves them so (StepParams::gzero), a memset the first time.
+template <typename TT>
+__global__ __launch_bounds__(256) void grid_prep_kernel(int total, int C, int short_from, GridGeom gg, int nbA, const TT *__restrict__ lT, float *__restrict__ bbox,
+                                                        float *__restrict__ bbox_nm, float *__restrict__ lrow, int *__restrict__ cellof, int *__restrict__ posof,
+                                                        int *__restrict__ cnt, int *__restrict__ maxhalf)
+{
+    if ((int)blockIdx.x >= nbA) {
+        const size_t t = (size_t)((int)blockIdx.x - nbA) * 256 + threadIdx.x;
+        if (t >= (size_t)total * 64) return;
+        const int l = (int)(t & 63), k4 = l >> 2, a4 = l & 3;
+        const size_t gc = t >> 6, gs = gc / (size_t)C, c = gc - gs * (size_t)C;
+        lrow[t] = (a4 < 3 && k4 < K) ? (float)lT[(gs * N3 + 3 * k4 + a4) * C + c] : 0.f;
+        return;
+    }
+    __shared__ int mh[NSEG * 3];
+    if (threadIdx.x < NSEG * 3) mh[threadIdx.x] = 0;
+    __syncthreads();
+    const int i = (int)blockIdx.x * 256 + (int)threadIdx.x;   // r * C + c (one scene)
+    if (i < total) {
+        const int c = i % C, r = i / C;
+        const bool valid = !(short_from && r >= short_from && c == C - 1);   // (padding column of a short chunk)
+        const TT *src = lT + (size_t)r * N3 * C + c;
+        float *dst = bbox + (size_t)r * (6 * NSEG) * C + c;
+        const int ncell = gg.n[0] * gg.n[1] * gg.n[2];
+#pragma unroll
+        for (int sg = 0; sg < NSEG; ++sg) {
+            double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+#pragma unroll
+            for (int k = sg * SEG_STEPS; k < (sg + 1) * SEG_STEPS; ++k)
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const double v = (double)src[(size_t)(3 * k + a) * C];
+                    lo[a] = fmin(lo[a], v); hi[a] = fmax(hi[a], v);
+                }
+            int cc[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float flo = __double2float_rd(lo[a]), fhi = __double2float_ru(hi[a]);
+                dst[(size_t)(6 * sg + 2 * a) * C] = flo; dst[(size_t)(6 * sg + 2 * a + 1) * C] = fhi;
+                bbox_nm[(size_t)i * NBOX_NM + 6 * sg + 2 * a] = flo; bbox_nm[(size_t)i * NBOX_NM + 6 * sg + 2 * a + 1] = fhi;
+                const float half = 0.5f * (fhi - flo) * 1.0001f + 1e-5f;   // (as grid_bin_kernel: rounded up, the query's reach must cover it)
+                cc[a] = grid_coord(gg, a, 0.5f * (flo + fhi));
+                if (valid) atomicMax(&mh[3 * sg + a], __float_as_int(half));   // non-negative floats order like integers
+            }
+            const int cell = (cc[2] * gg.n[1] + cc[1]) * gg.n[0] + cc[0];
+            cellof[(size_t)sg * total + i] = valid ? cell : -1;
+            posof[(size_t)sg * total + i] = valid ? atomicAdd(cnt + (size_t)sg * ncell + cell, 1) : 0;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < NSEG * 3) { const int v = mh[threadIdx.x]; if (v > *(volatile int *)(maxhalf + threadIdx.x)) atomicMax(maxhalf + threadIdx.x, v); }
+}
+// grid_fill2_kernel: every block forms the exclusive prefix of the three segments' cell counts in its LDS (1 560 cells each at N = 10^4: cheaper
+// than a launch of its own and a trip through memory), block 0 also writes it out for the query; then the entry records as grid_fill_kernel,
+// at start[cell] + the position grid_prep_kernel drew.  Dynamic LDS: NSEG * (ncell + 1) ints.
+__global__ __launch_bounds__(256) void grid_fill2_kernel(int total, int C, int ncell, float e1z, const int *__restrict__ cellof, const int *__restrict__ posof,
+                                                         const int *__restrict__ cnt, int *__restrict__ start, const float *__restrict__ lrow, f4_t *__restrict__ ent)
+{
+    int *st = (int *)dmpc_smem;   // [NSEG][ncell + 1]
+    __shared__ int part[256];
+    const int t = (int)threadIdx.x;
+    const int chunk = (ncell + 255) / 256;
+    for (int sg = 0; sg < NSEG; ++sg) {
+        const int *c = cnt + (size_t)sg * ncell;
+        const int lo = t * chunk, hi = lo + chunk < ncell ? lo + chunk : ncell;
+        int sum = 0;
+        for (int j = lo; j < hi; ++j) sum += c[j];
+        part[t] = sum;
+        __syncthreads();
+        for (int off = 1; off < 256; off <<= 1) {
+            const int add = t >= off ? part[t - off] : 0;
+            __syncthreads();
+            part[t] += add;
+            __syncthreads();
+        }
+        int run = part[t] - sum;   // exclusive
+        for (int j = lo; j < hi; ++j) { st[sg * (ncell + 1) + j] = run; run += c[j]; }
+        if (t == 255) st[sg * (ncell + 1) + ncell] = part[255];
+        __syncthreads();
+    }
+    if (blockIdx.x == 0) for (int j = t; j < NSEG * (ncell + 1); j += 256) start[j] = st[j];
+    const int i = (int)blockIdx.x * 256 + t;
+    if (i >= total) return;
+    const int code = ((i / C) << 20) | (i % C);   // (chunk << 20) | column
+#pragma unroll
+    for (int sg = 0; sg < NSEG; ++sg) {
+        const int cell = cellof[(size_t)sg * total + i];
+        if (cell < 0) return;
+        const int pos = posof[(size_t)sg * total + i];
+        const f4_t *row = (const f4_t *)lrow + (size_t)i * 16 + SEG_STEPS * sg;
+        f4_t v[SEG_STEPS];
+#pragma unroll
+        for (int u = 0; u < SEG_STEPS; ++u) { v[u] = row[u]; v[u].z *= e1z; }
+        const f4_t a0 = v[0], a1 = v[SEG_STEPS - 1];
+        float dev2 = 0.f;
+#pragma unroll
+        for (int u = 1; u < SEG_STEPS - 1; ++u) {
+            const float tt = (float)u / (float)(SEG_STEPS - 1);
+            const float dx = v[u].x - (a0.x + tt * (a1.x - a0.x)), dy = v[u].y - (a0.y + tt * (a1.y - a0.y)), dz = v[u].z - (a0.z + tt * (a1.z - a0.z));
+            dev2 = fmaxf(dev2, dx * dx + dy * dy + dz * dz);
+        }
+        const size_t ei = (size_t)sg * total + st[sg * (ncell + 1) + cell] + pos;
+        f4_t r0, r1;
+        r0.x = __int_as_float(code); r0.y = a0.x; r0.z = a0.y; r0.w = a0.z;
+        r1.x = a1.x - a0.x; r1.y = a1.y - a0.y; r1.z = a1.z - a0.z; r1.w = sqrtf(dev2) * 1.0001f + 1e-5f;   // (rounded up)
+        ent[ei] = r0; ent[(size_t)NSEG * total + ei] = r1;
     }
 }
 // A workgroup = ONE agent, a wave per horizon segment (the segments are independent up to the bitmap, which the three waves share): three

@@ -68,7 +68,7 @@ def test_neighbour_list_overflow_falls_back_to_the_table(monkeypatch):
 
 def test_cell_grid_lists_at_full_size_do_not_change_a_bit():
     """one scene of 3 000 agents (>= 2 048: the cell grid is the default), three closed-loop steps, bound and hard rows: identical to
-    the whole-table walk (no_cull) and to the all-pairs lists (nbr_grid = 0); sharded layouts of the same scene are in tests/test_gpu_fullsize.py"""
+    the whole-table walk (no_cull), to the all-pairs lists (nbr_grid = 0) and to the grid built the round-4 way (prep_fuse = 0); sharded layouts of the same scene are in tests/test_gpu_fullsize.py"""
     cfg = wl.CONFIGS["C4"]
     N, S = 3000, 1
     kw = wl.solver_kwargs(cfg, N)
@@ -77,9 +77,10 @@ def test_cell_grid_lists_at_full_size_do_not_change_a_bit():
         a = _steps(variant, kw, po, pf, 3)
         b = _steps(variant, kw, po, pf, 3, no_cull=1)
         c = _steps(variant, kw, po, pf, 3, nbr_grid=0)
-        for x, y, z in zip(a, b, c):
+        d = _steps(variant, kw, po, pf, 3, prep_fuse=0)   # the grid by the five kernels of round 4 instead of grid_prep_kernel + grid_fill2_kernel (round 6)
+        for x, y, z, w in zip(a, b, c, d):
             for k in ("status", "info", "p", "v", "a"):
-                assert np.array_equal(x[k], y[k]) and np.array_equal(x[k], z[k]), (variant, k)
+                assert np.array_equal(x[k], y[k]) and np.array_equal(x[k], z[k]) and np.array_equal(x[k], w[k]), (variant, k)
 
 
 @pytest.mark.parametrize("variant", ["bound", "bound2", "repair"])
