@@ -433,8 +433,11 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
                 const bool has_p = (phase == 2) && (ent_extra || erow >= 0);
                 double hy0 = 0.0, hy1 = 0.0, hy2 = 0.0, hrho = 0.0, hd = 0.0, hsc = 1.0;
                 if (nhr > 0) {
-                    if (hm != hm_prev || erow != herow_prev) {
-                        hm_prev = hm; herow_prev = erow;
+                    // (the key holds the entering row's LANE too: a wall that leaves during the row's inner iteration moves it down one lane with the same rows -- a
+                    // gather keyed on the rows alone left row 0's data there: scene 452 of campaign seed 602, the one wrong answer of 2.4 M agent-steps)
+                    const int ekey = erow >= 0 ? (erow | (erl << 8)) : -1;
+                    if (hm != hm_prev || ekey != herow_prev) {
+                        hm_prev = hm; herow_prev = ekey;
                         int src = 0;
                         unsigned long long m = hm;
 #pragma unroll

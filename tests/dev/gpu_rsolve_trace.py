@@ -28,10 +28,34 @@ if name.startswith("c4:"):   # c4:N:step:seed -- the scene of tools/proto/run_pr
         ok = (ref["status"] & 1) == 1
         l = np.where(ok[:, None], ref["p"], l)
         xp = np.where(ok[:, None], ref["p"][:, :3], xp); xv = np.where(ok[:, None], ref["v"][:, :3], xv); xa = np.where(ok[:, None], ref["a"][:, :3], xa)
+elif name.startswith("camp:"):   # camp:SEED:SCENE:STEP:VARIANT -- a scene of tests/dev/gpu_campaign.py, teacher-forced by the oracle up to MPC step STEP
+    from multiagent_planning_amd import workload as wl
+    from oracle import oracle as orc
+    from helpers import ALL_VARIANTS, init_table
+    _, seed0, scn, step, VARIANT = name.split(":")
+    seed0, scn, step = int(seed0), int(scn), int(step)
+    rng = np.random.default_rng(seed0)
+    for it in range(scn + 1):
+        N = int(rng.integers(2, 90))
+        dense = rng.random() < 0.5
+        cfg = wl.CONFIGS["C5" if dense else "C2"]
+        kw = wl.solver_kwargs(cfg, N)
+        if rng.random() < 0.3:
+            kw["pmin"] = tuple(np.asarray(kw["pmin"]) * [0.8, 0.8, 1]); kw["pmax"] = tuple(np.asarray(kw["pmax"]) * [0.8, 0.8, 1])
+        sc_seed = int(rng.integers(1 << 30))
+        for v in ALL_VARIANTS: rng.integers(2, 7)
+    po, pf = wl.make_scenes(dict(cfg), 1, N, sc_seed); po, pf = po[0], pf[0]
+    prm = orc.make_params(VARIANT, **kw)
+    l = init_table(po, pf); xp, xv, xa = po.copy(), np.zeros_like(po), np.zeros_like(po)
+    for k in range(2, step):
+        ref = orc.step(prm, l, xp, xv, xa, pf, nthreads=os.cpu_count())
+        ok = (ref["status"] & 1) == 1
+        l = np.where(ok[:, None], ref["p"], l)
+        xp = np.where(ok[:, None], ref["p"][:, :3], xp); xv = np.where(ok[:, None], ref["v"][:, :3], xv); xa = np.where(ok[:, None], ref["a"][:, :3], xa)
 else:
     g, kw = load_golden(name)
     l, xp, xv, xa, pf = g["l"], g["pk"][:, 12], g["vk"][:, 12], g["ak"][:, 12], g["pf"]
-d = mp.Dmpc("bound", device=0, **kw)
+d = mp.Dmpc(globals().get("VARIANT", "bound"), device=0, **kw)
 L = _lib.load()
 L.dmpc_debug_trace.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
 cap = int(os.environ.get('TRACE_CAP', '256'))

@@ -83,6 +83,36 @@ def test_cell_grid_lists_at_full_size_do_not_change_a_bit():
                 assert np.array_equal(x[k], y[k]) and np.array_equal(x[k], z[k]) and np.array_equal(x[k], w[k]), (variant, k)
 
 
+def test_cell_grid_counters_survive_a_change_of_batch_shape():
+    """the two-launch cell grid of a single scene counts into counters the PREVIOUS step's scan kernel left zero (no memset per step): one context
+    that steps a single scene, then a batch of two scenes (the five-kernel grid, which leaves the counters dirty, in the same buffer), then the single
+    scene again, then a single scene of another size must give what fresh contexts give"""
+    cfg = wl.CONFIGS["C4"]
+    kw = wl.solver_kwargs(cfg, 3000)
+    gen = mp.Dmpc("bound", **kw)
+    po1, pf1 = wl.make_scenes_device(gen, cfg, 1, 3000, wl.SEED0 + 34)
+    po2, pf2 = wl.make_scenes_device(gen, cfg, 2, 1500, wl.SEED0 + 35)
+    po3, pf3 = wl.make_scenes_device(gen, cfg, 1, 2000, wl.SEED0 + 36)
+    def one(d, po, pf):
+        l, _, _ = d.init_batch(po, pf)
+        z = np.zeros_like(po)
+        outs = []
+        for _ in range(2):   # (two steps: the second finds the counters as the first's scan left them)
+            o = d.step_batch(l, po.copy(), z, z, pf)
+            outs.append(o)
+        return outs
+    shared = mp.Dmpc("bound", **kw)
+    shared.debug_option("grid_min", 768)
+    for po, pf in ((po1, pf1), (po2, pf2), (po1, pf1), (po3, pf3), (po1, pf1)):
+        fresh = mp.Dmpc("bound", **kw)
+        fresh.debug_option("grid_min", 768)
+        fresh.debug_option("prep_fuse", 0)
+        for a, b in zip(one(shared, po, pf), one(fresh, po, pf)):
+            for k in ("status", "info", "p", "v", "a"):
+                assert np.array_equal(a[k], b[k]), (po.shape, k)
+        assert (a["info"][..., 1] > 0).any()
+
+
 @pytest.mark.parametrize("variant", ["bound", "bound2", "repair"])
 def test_crash_start_reaches_the_same_minimiser(variant, monkeypatch):
     cfg = wl.CONFIGS["C4"]

@@ -86,6 +86,32 @@ def test_level_skip_extrapolation_changes_no_retry_count():
         assert ob["info"][..., 4].sum() >= oa["info"][..., 4].sum()   # (equal when the level certificate settles every level the extrapolation would have skipped)
 
 
+def test_wall_leaving_while_a_row_enters_regression():
+    """scene 452 of the randomized campaign with seed 602 (tests/dev/gpu_campaign.py; 64 agents in the small dense box, MPC step 4, agent 24): a workspace
+    wall left the working set during the inner iteration of an entering hard row -- the row moved down one lane of the small system and the cached
+    gather of the hard rows' data, keyed on the rows alone, served row 0's there: a "solved" agent 0.97 off the minimiser, violating the row"""
+    from helpers import ALL_VARIANTS, init_table
+    rng = np.random.default_rng(602)
+    for it in range(453):
+        N = int(rng.integers(2, 90))
+        cfg = wl.CONFIGS["C5" if rng.random() < 0.5 else "C2"]
+        kw = wl.solver_kwargs(cfg, N)
+        if rng.random() < 0.3:
+            kw["pmin"] = tuple(np.asarray(kw["pmin"]) * [0.8, 0.8, 1]); kw["pmax"] = tuple(np.asarray(kw["pmax"]) * [0.8, 0.8, 1])
+        sc_seed = int(rng.integers(1 << 30))
+        for _ in ALL_VARIANTS: rng.integers(2, 7)
+    assert N == 64
+    po, pf = wl.make_scenes(dict(cfg), 1, N, sc_seed); po, pf = po[0], pf[0]
+    d, prm = mp.Dmpc("bound", **kw), orc.make_params("bound", **kw)
+    l = init_table(po, pf); xp, xv, xa = po.copy(), np.zeros_like(po), np.zeros_like(po)
+    for k in range(2, 7):
+        out, ref = d.step_batch(l, xp, xv, xa, pf), orc.step(prm, l, xp, xv, xa, pf, nthreads=8)
+        _agree(out, ref)
+        ok = (ref["status"] & 1) == 1
+        l = np.where(ok[:, None], ref["p"], l)
+        xp = np.where(ok[:, None], ref["p"][:, :3], xp); xv = np.where(ok[:, None], ref["v"][:, :3], xv); xa = np.where(ok[:, None], ref["a"][:, :3], xa)
+
+
 def test_hand_over_to_the_general_solver_changes_nothing():
     """agents the reduced solver gives up (here: nearly all, by a cap of three equality solves per ladder level) are solved by the general
     solver in the tier-2 launch: the step's outputs are then the general solver's, bit for bit, for those agents -- and the oracle's minimiser"""
