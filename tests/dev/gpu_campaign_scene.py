@@ -28,6 +28,8 @@ for it in range(scene + 1):
 po, pf = wl.make_scenes(dict(cfg), 1, N, sc_seed); po, pf = po[0], pf[0]
 print(f"seed {seed0} scene {scene}: N = {N}, box {cfgname}, variant {want}, {nsteps[want]} steps")
 d = mp.Dmpc(want, **kw); prm = orc.make_params(want, **kw)
+for kv in filter(None, os.environ.get("DBG_OPTS", "").split(",")):   # development options of the context, e.g. DBG_OPTS=reduced_solver=0
+    d.debug_option(kv.split("=")[0], int(kv.split("=")[1]))
 l = init_table(po, pf); xp, xv, xa = po.copy(), np.zeros_like(po), np.zeros_like(po)
 for k in range(nsteps[want]):
     out = d.step_batch(l, xp, xv, xa, pf); ref = orc.step(prm, l, xp, xv, xa, pf, nthreads=8)
