@@ -112,6 +112,46 @@ def test_wall_leaving_while_a_row_enters_regression():
         xp = np.where(ok[:, None], ref["p"][:, :3], xp); xv = np.where(ok[:, None], ref["v"][:, :3], xv); xa = np.where(ok[:, None], ref["a"][:, :3], xa)
 
 
+def test_tight_workspace_campaign_time_boxed():
+    """a time-boxed slice (15 s) of tests/dev/gpu_campaign_walls.py: scenes at the headline's density squeezed into boxes of 0.5-0.8 of their size, the
+    four variants of the reduced solver, 4-8 teacher-forced MPC steps: walls enter and leave the working set while collision rows do (the regime of
+    the gather defect of round 6).  Statuses, branch records, retry counts identical; 1e-8 on the first ladder level, 1e-7 above"""
+    import time
+    rng = np.random.default_rng(int(time.time() // (7 * 86400)) + 17)
+    t0, total, walls = time.time(), 0, 0
+    while time.time() - t0 < 15.0:
+        N = int(rng.integers(30, 160))
+        cfg = dict(wl.CONFIGS["C4"]); cfg["N"] = N
+        kw = dict(wl.solver_kwargs(cfg, N))
+        po, pf = wl.make_scenes(cfg, 1, N, int(rng.integers(1 << 30))); po, pf = po[0], pf[0]
+        s = 0.5 + 0.3 * rng.random()
+        kw["pmin"] = tuple(np.array(kw["pmin"]) * s + np.array([0, 0, 0.2 * (1 - s)])); kw["pmax"] = tuple(np.array(kw["pmax"]) * s)
+        lo, hi = np.array(kw["pmin"]) + 0.02, np.array(kw["pmax"]) - 0.02
+        po, pf = np.clip(po * s, lo, hi), np.clip(pf * s, lo, hi)
+        for variant in ("bound", "bound2", "cpp", "cpp2"):
+            d, prm = mp.Dmpc(variant, **kw), orc.make_params(variant, **kw)
+            l = np.stack([orc.init_one(po[n], pf[n], cfg["h"], 15)[0] for n in range(N)])
+            xp, xv, xa = po.copy(), np.zeros_like(po), np.zeros_like(po)
+            for k in range(int(rng.integers(4, 9))):
+                out, ref = d.step_batch(l, xp, xv, xa, pf), orc.step(prm, l, xp, xv, xa, pf, nthreads=8)
+                what = f"N={N} scale {s:.3f} {variant} step {k + 2}"
+                assert np.array_equal(out["status"], ref["status"]), what
+                assert np.array_equal(out["info"][:, 0], ref["info"][:, 0]) and np.array_equal(out["info"][:, 2], ref["info"][:, 2]), what
+                ok = (ref["status"] & 1) == 1
+                e = np.zeros(N)
+                for key in ("p", "v", "a"):
+                    e = np.maximum(e, np.abs(out[key] - ref[key]).max(axis=1) * ok)
+                first = ref["info"][:, 2] == 1
+                assert (e[first] <= 1e-8).all() and (e <= 1e-7).all(), f"{what}: {e.max():.2e}"
+                rel = ref["p"].reshape(-1, 15, 3)[ok]
+                walls += int(((np.abs(rel - np.array(kw["pmax"])) < 1e-9) | (np.abs(rel - np.array(kw["pmin"])) < 1e-9)).any(axis=(1, 2)).sum())
+                total += N
+                l = np.where(ok[:, None], ref["p"], l)
+                xp = np.where(ok[:, None], ref["p"][:, :3], xp); xv = np.where(ok[:, None], ref["v"][:, :3], xv); xa = np.where(ok[:, None], ref["a"][:, :3], xa)
+    print(f"tight-workspace campaign: {total} agent-steps, {walls} of them with a horizon step on a wall")
+    assert total > 5000 and walls > 100
+
+
 def test_hand_over_to_the_general_solver_changes_nothing():
     """agents the reduced solver gives up (here: nearly all, by a cap of three equality solves per ladder level) are solved by the general
     solver in the tier-2 launch: the step's outputs are then the general solver's, bit for bit, for those agents -- and the oracle's minimiser"""
