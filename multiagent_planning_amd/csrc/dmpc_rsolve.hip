@@ -200,13 +200,15 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
         // unconstrained minimiser from the Gram tables, exactly as the scan's unconstrained exit and the general solver form it
         a_unc = comp ? unc_entry(qw, sw, gax, ao_l, Gt[kt * 30 + 15 + (K - 1)], Gt[kt * 30]) : 0.0;
     }
-    // (the scales of the bounds and walls per lane, loaded here: a table load inside the iteration is a trip to the L2 on its critical path)
-    const double sc_bound_l = Gt[kt * 31], sc_wall_l = Gt[(15 + kt) * 31];   // H1^-1(k,k), (L H1^-1 L')(k,k)
+    // the scales of the bounds and walls, H1^-1(k,k) and (L H1^-1 L')(k,k), are read where an entering bound / wall needs one: a SCALAR load from the table
+    // (constant address space: the index is wave-uniform) issued a section ahead of its use -- kept per lane they were four registers of a kernel that spills
+    typedef const double __attribute__((address_space(4))) *ConstD;
+    const ConstD Gts = (ConstD)(unsigned long long)Gt;
     const double sc_row = Gt[(15 + kc) * 31];   // n'H^-1 n of the UNREDUCED Hessian: the scale of the dependence test (dmpc_solve.hip: delta <= 1e-13 s_pp)
 
     // the ladder certificate (ladder_level_infeasible, dmpc_kernels.hip) wants the walls of component (k, axis) in lane 3 k + axis
-    const int cl3 = lane < N3 ? 16 * (lane % 3) + lane / 3 : 63;
-    const double whi_s = __shfl(whi_l, cl3), wlo_s = __shfl(wlo_l, cl3);
+    // (formed at the two calls, not kept: four registers for the whole solve)
+#define RWALLS_STACKED(v_) __shfl((v_), lane < N3 ? 16 * (lane % 3) + lane / 3 : 63)
     const bool ladder = (var == VAR_BOUND || var == VAR_BOUND2 || cppv);
     const int max_tries = P.max_tries > 0 ? P.max_tries : (cppv ? 21 : 30);
     const double tol = 1e-10;
@@ -240,10 +242,7 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
             Sym3 Ms; Ms.m00 = Ms.m01 = Ms.m02 = Ms.m11 = Ms.m12 = Ms.m22 = 0.0;
             double msv[3] = {0.0, 0.0, 0.0};
             unsigned long long softm_prev = 0ull;
-            // the hard rows' data in the lanes of the small system (lane c: xi, b, sd, flags of the c-th hard row), gathered again when the list changes
-            double gx0 = 0.0, gx1 = 0.0, gx2 = 0.0, gb = 0.0, gsd = 1.0;
-            int gfl = 0, herow_prev = -2;
-            unsigned long long hm_prev = ~0ull;
+            // (gathered for every solve: kept across solves behind a key they were eleven registers of the loop's state -- and the key was wrong once, section 2 of DESIGN.md)
             int ent = RE_NONE, eidx = 0, esg = 0;   // entering constraint: type, lane of the component / row, sign
             int phase = 0;                  // 1: crash (free the negative multipliers), 2: iteration, 3: violation scan
             int inner = 0, iters = 0, zero_steps = 0, leqp = 0;
@@ -305,7 +304,7 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
                     if (ladder && violation && !cert_done && iters > RCERT_AFTER) {
                         cert_done = true;
                         cost += 100;
-                        if (uni_b(ladder_level_infeasible(r_xi, r_b, r_sd, r_slb, r_kc, nr, B, P.h, P.alim, lev_f, whi_s, wlo_s, lane, RCERT_PLANES))) { rc = 1; break; }
+                        if (uni_b(ladder_level_infeasible(r_xi, r_b, r_sd, r_slb, r_kc, nr, B, P.h, P.alim, lev_f, RWALLS_STACKED(whi_l), RWALLS_STACKED(wlo_l), lane, RCERT_PLANES))) { rc = 1; break; }
                     }
                     const int pcode = readlane_i(bestc, __ffsll((long long)wm) - 1);
                     ent = pcode >> 16; eidx = pcode & 63; esg = (pcode & 256) ? 1 : -1;
@@ -432,12 +431,12 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
                 if (nh > R_NH) { if (blk) { RBLOCK_UNDO(); continue; } rc = 2; why = 6; break; }
                 const bool has_p = (phase == 2) && (ent_extra || erow >= 0);
                 double hy0 = 0.0, hy1 = 0.0, hy2 = 0.0, hrho = 0.0, hd = 0.0, hsc = 1.0;
+                double gx0 = 0.0, gx1 = 0.0, gx2 = 0.0, gb = 0.0, gsd = 1.0;
+                int gfl = 0;
                 if (nhr > 0) {
                     // (the key holds the entering row's LANE too: a wall that leaves during the row's inner iteration moves it down one lane with the same rows -- a
                     // gather keyed on the rows alone left row 0's data there: scene 452 of campaign seed 602, the one wrong answer of 2.4 M agent-steps)
-                    const int ekey = erow >= 0 ? (erow | (erl << 8)) : -1;
-                    if (hm != hm_prev || ekey != herow_prev) {
-                        hm_prev = hm; herow_prev = ekey;
+                    {
                         int src = 0;
                         unsigned long long m = hm;
 #pragma unroll
@@ -456,7 +455,7 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
                         hrho = hd + (gx0 * w03[0] + gx1 * w03[1] + gx2 * w03[2]);
                         hsc = sc_row * (gx0 * gx0 + gx1 * gx1 + gx2 * gx2);
                     }
-                } else { hm_prev = ~0ull; herow_prev = -2; }
+                }
                 double omr[R_NE] = {0.0, 0.0, 0.0, 0.0};   // lane xb + i: row i of Om = G0 - yt yt' over the extras
                 double Yp = 0.0;                             // H~ n of the entering bound (the common extra): kept for the update of a
                 if (ne > 0) {
@@ -467,7 +466,7 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
                         const int x = eidx >> 4;
                         const double t = sgd * readlane_d(Ykc, eidx) * (x == 0 ? isg3[0] : (x == 1 ? isg3[1] : isg3[2]));   // yt on its axis
                         const double g0 = sgd * readlane_d(Yp, eidx), u0 = sgd * readlane_d(a0, eidx);
-                        if (lane == xb) { hy0 = x == 0 ? t : 0.0; hy1 = x == 1 ? t : 0.0; hy2 = x == 2 ? t : 0.0; hd = P.alim; hrho = P.alim - u0; hsc = readlane_d(sc_bound_l, eidx); omr[0] = g0 - t * t; }
+                        if (lane == xb) { hy0 = x == 0 ? t : 0.0; hy1 = x == 1 ? t : 0.0; hy2 = x == 2 ? t : 0.0; hd = P.alim; hrho = P.alim - u0; hsc = Gts[(eidx & 15) * 31]; omr[0] = g0 - t * t; }
                     } else {
                         // walls (and maybe an entering wall / bound), one at a time: normal and H~ n are formed here and again for the update of a -- nothing of
                         // them is kept; an extra's normal lives on ONE axis, so yt_i is a scalar on that axis and G0_ij = n_j' H~ n_i needs extra i's H~ n only
@@ -484,7 +483,7 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
                             yts[i] = readlane_d(tl, wl & 48) * (xa == 0 ? isg3[0] : (xa == 1 ? isg3[1] : isg3[2]));
                             const double u0 = readlane_d(ul, wl & 48);
                             const double dd = is_b ? P.alim : ((code & 256) ? readlane_d(whi_l, wl) : -readlane_d(wlo_l, wl));
-                            const double sc = is_b ? readlane_d(sc_bound_l, wl) : readlane_d(sc_wall_l, wl);
+                            const double sc = is_b ? Gts[(wl & 15) * 31] : Gts[(15 + (wl & 15)) * 31];
                             if (lane == xb + i) { hy0 = xa == 0 ? yts[i] : 0.0; hy1 = xa == 1 ? yts[i] : 0.0; hy2 = xa == 2 ? yts[i] : 0.0; hd = dd; hrho = dd - u0; hsc = sc; }
 #pragma unroll
                             for (int j = 0; j <= i; ++j) {
@@ -601,7 +600,7 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
                 // ---- new values (regular) or rates per unit of the entering multiplier (dependent: the primal does not move)
                 double a_n = a, mu_n = 0.0, lam_n = 0.0, lamp_n = 1.0, farkas = 0.0;
                 // the hard rows' multipliers (or rates) back in their row lanes: list position of row `lane`
-                const int hpos = (erow >= 0 && lane == erow) ? erl : __popcll(hm & ((1ull << lane) - 1ull));
+                const int hpos = (erow >= 0 && lane == erow) ? erl : (int)__builtin_amdgcn_mbcnt_hi((unsigned)(hm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)hm, 0u));   // (set bits of hm below this lane: v_mbcnt, no lane mask kept in registers)
                 double dlh = 0.0;
                 if (sing) {   // rate of constraint c in lane c: the last one dl_last per unit of the entering multiplier, the others -rr dl_last
                     double dl_last = 1.0;
@@ -807,7 +806,7 @@ __device__ __forceinline__ void rsolve_body(const StepParams &P, const int lane,
                 double f = 2.0;
                 while (tries < max_tries - 1) {
                     if (lev_skip > 0) { --lev_skip; f *= 2.0; ++tries; continue; }   // (infeasible by the proof the failed solve ended with)
-                    if (!uni_b(ladder_level_infeasible(r_xi, r_b, r_sd, r_slb, r_kc, nr, B, P.h, P.alim, lev_f * f, whi_s, wlo_s, lane, RCERT_PLANES))) { cert_known = true; break; }
+                    if (!uni_b(ladder_level_infeasible(r_xi, r_b, r_sd, r_slb, r_kc, nr, B, P.h, P.alim, lev_f * f, RWALLS_STACKED(whi_l), RWALLS_STACKED(wlo_l), lane, RCERT_PLANES))) { cert_known = true; break; }
                     f *= 2.0; ++tries;
                 }
                 slb *= f; st *= f; lev_f *= f;
